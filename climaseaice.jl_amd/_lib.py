@@ -1,0 +1,153 @@
+"""ctypes binding of libcsi_hip.so (include/csi.h).
+
+The HIP library is the product; there is no CPU fallback.  Importing this module never touches
+the GPU; `load()` raises loudly when the shared library is missing, and every compute entry
+point raises `CsiError` when there is no HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsi_hip.so")
+
+# ---- enums (include/csi.h) ---------------------------------------------------------------------
+OK = 0
+PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3, 4
+METRIC_UNIFORM, METRIC_PER_J = 0, 1
+FIELD_IDS = ["U", "V", "H", "A", "S11", "S22", "S12", "UN", "VN", "P", "ALPHA", "DELTA", "ZETA_F", "ZETA_C",
+             "GH", "GA", "HM", "AM", "UM", "VM", "TOP_U", "TOP_V", "BOT_U", "BOT_V", "MASS_FLUX"]
+F = {n: k for k, n in enumerate(FIELD_IDS)}
+STRESS_NONE, STRESS_CONST, STRESS_FIELD, STRESS_SEMI_IMPLICIT = 0, 1, 2, 3
+VEL_ZERO, VEL_CONST, VEL_FIELD = 0, 1, 2
+STRESS_TOP, STRESS_BOTTOM = 0, 1
+MODE_STRICT, MODE_FAST = 0, 1
+PRESSURE_REPLACEMENT, PRESSURE_ICE_STRENGTH = 0, 1
+
+# every symbol include/csi.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last_error", "csi_sync", "csi_set_mode",
+           "csi_grid_set", "csi_mask_set", "csi_field_bind", "csi_evp_params_set", "csi_stress_set",
+           "csi_evp_initialize", "csi_evp_subcycle", "csi_evp_finalize", "csi_time_step_momentum",
+           "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
+           "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
+           "csi_slab_thermo_step", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
+           "csi_last_subcycle_ms", "csi_launches_per_substep"]
+
+
+class Metrics(C.Structure):
+    _fields_ = [("dx", C.c_double), ("dy", C.c_double),
+                ("dxc", C.POINTER(C.c_double)), ("dxf", C.POINTER(C.c_double)),
+                ("azc", C.POINTER(C.c_double)), ("azf", C.POINTER(C.c_double))]
+
+
+class EvpParams(C.Structure):
+    _fields_ = [("ice_compressive_strength", C.c_double), ("ice_compaction_hardening", C.c_double),
+                ("yield_curve_eccentricity", C.c_double), ("minimum_plastic_stress", C.c_double),
+                ("min_relaxation_parameter", C.c_double), ("max_relaxation_parameter", C.c_double),
+                ("relaxation_strength", C.c_double), ("pressure_formulation", C.c_int32), ("has_coriolis", C.c_int32),
+                ("coriolis_f", C.c_double), ("minimum_concentration", C.c_double), ("minimum_mass", C.c_double),
+                ("sea_ice_density", C.c_double)]
+
+
+class Stress(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ue_kind", C.c_int32), ("ve_kind", C.c_int32), ("reserved", C.c_int32),
+                ("tau_u", C.c_double), ("tau_v", C.c_double), ("ue", C.c_double), ("ve", C.c_double),
+                ("rho_e", C.c_double), ("Cd", C.c_double)]
+
+
+class SlabParams(C.Structure):
+    _fields_ = [("conductivity", C.c_double), ("sea_ice_density", C.c_double), ("density", C.c_double),
+                ("liquid_density", C.c_double), ("liquid_heat_capacity", C.c_double), ("heat_capacity", C.c_double),
+                ("reference_latent_heat", C.c_double), ("reference_temperature", C.c_double),
+                ("liquidus_slope", C.c_double), ("freshwater_melting_temperature", C.c_double),
+                ("bottom_salinity", C.c_double), ("ice_consolidation_thickness", C.c_double),
+                ("top_temperature", C.c_double), ("top_flux_kind", C.c_int32), ("bottom_flux_kind", C.c_int32),
+                ("top_heat_flux", C.c_double), ("bottom_heat_flux", C.c_double)]
+
+
+class CsiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcsi_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libcsi_hip.so; fail loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C climaseaice.jl_amd/csrc).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.csi_version.restype = i32
+    L.csi_last_error.restype = C.c_char_p
+    L.csi_last_error.argtypes = [vp]
+    sig = {
+        "csi_context_create": [i32, vp, C.POINTER(vp)],
+        "csi_context_destroy": [vp], "csi_sync": [vp], "csi_set_mode": [vp, i32],
+        "csi_grid_set": [vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(Metrics)],
+        "csi_mask_set": [vp, vp, i64],
+        "csi_field_bind": [vp, i32, vp, i64, i32, i32],
+        "csi_evp_params_set": [vp, C.POINTER(EvpParams)],
+        "csi_stress_set": [vp, i32, C.POINTER(Stress)],
+        "csi_evp_initialize": [vp], "csi_evp_subcycle": [vp, dbl, i32, i32], "csi_evp_finalize": [vp],
+        "csi_time_step_momentum": [vp, dbl, i32, i32],
+        "csi_compute_tracer_tendencies": [vp, i32], "csi_dynamic_step_tracers": [vp, dbl, i32],
+        "csi_cache_current_fields": [vp], "csi_update_state": [vp], "csi_fill_halo_local": [vp, i32],
+        "csi_time_step_fe": [vp, dbl, i32, i32, i32], "csi_time_step_rk3": [vp, dbl, i32, i32],
+        "csi_slab_thermo_step": [vp, C.POINTER(SlabParams), dbl],
+        "csi_tile_set": [vp, i32, i32, i32, i32, i32, i32],
+        "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
+        "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],
+        "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
+        "csi_last_subcycle_ms": [vp, C.POINTER(dbl)], "csi_launches_per_substep": [vp, C.POINTER(i32)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class Context:
+    """One csi_context (one GPU).  Thin: every method is one ABI call that raises on failure."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.csi_context_create(device_id, C.c_void_p(stream) if stream else None, C.byref(self.h))
+        if rc != OK:
+            raise CsiError(rc, self.L.csi_last_error(None).decode())
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise CsiError(rc, self.L.csi_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.csi_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name, *args):
+        self._ck(getattr(self.L, name)(self.h, *args))
+
+    def last_subcycle_ms(self):
+        v = C.c_double()
+        self.call("csi_last_subcycle_ms", C.byref(v))
+        return v.value
+
+    def launches_per_substep(self):
+        v = C.c_int32()
+        self.call("csi_launches_per_substep", C.byref(v))
+        return v.value

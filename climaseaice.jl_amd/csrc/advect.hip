@@ -1,0 +1,160 @@
+// advect.hip -- h / aice advection tendencies and the tracer update.
+//
+//   k_tendencies  _compute_dynamic_tracer_tendencies!  tracer_tendency_kernel_functions.jl:27-45
+//                 = - horizontal_div_Uc (sea_ice_advection.jl:51-54) with the upstream
+//                 Oceananigans upwind-biased reconstructions (WENO(order = 5 | 7) in the WENO-Z
+//                 form, UpwindBiased(order = 5), first-order upwind).
+//   k_tracer_step _dynamic_step_tracers!               sea_ice_fe_step.jl:56-82
+//                 (RK3: h^n, aice^n = Psi^-, sea_ice_rk_substep.jl:140-149)
+//
+// This translation unit is compiled with -ffp-contract=off and keeps the oracle's expression
+// order, so both arithmetic modes give bit-identical tracer tendencies.  Each thread owns one
+// face pair (west, south) of its cell: fluxes are computed once, shared with the east / north
+// neighbours through LDS, so every face flux is evaluated exactly once per tile interior.
+#include "csi_dev.h"
+#include "csi_kernels.h"
+
+namespace csi {
+namespace adv {
+
+#define WENO_EPS 1e-8
+
+__device__ __forceinline__ double weno5(const double* p) {
+    double q0 = (2 * p[2] + 5 * p[3] - p[4]) / 6;
+    double q1 = (-p[1] + 5 * p[2] + 2 * p[3]) / 6;
+    double q2 = (2 * p[0] - 7 * p[1] + 11 * p[2]) / 6;
+    double b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
+    double b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
+    double b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
+    double tau = fabs(b0 - b2);
+    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS), r2 = tau / (b2 + WENO_EPS);
+    double a0 = (3.0 / 10) * (1 + r0 * r0);
+    double a1 = (3.0 / 5) * (1 + r1 * r1);
+    double a2 = (1.0 / 10) * (1 + r2 * r2);
+    double s = a0 + a1 + a2;
+    return (a0 * q0 + a1 * q1 + a2 * q2) / s;
+}
+__device__ __forceinline__ double upwind5(const double* p) {
+    return (2 * p[0] - 13 * p[1] + 47 * p[2] + 27 * p[3] - 3 * p[4]) / 60;
+}
+__device__ __forceinline__ double weno7(const double* p) {
+    double q0 = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) / 12;
+    double q1 = (-p[2] + 7 * p[3] + 7 * p[4] - p[5]) / 12;
+    double q2 = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) / 12;
+    double q3 = (-3 * p[0] + 13 * p[1] - 23 * p[2] + 25 * p[3]) / 12;
+    double b0 = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
+                p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
+    double b1 = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
+                p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
+    double b2 = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
+                p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
+    double b3 = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
+                p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
+    double tau = fabs(b0 + 3 * b1 - 3 * b2 - b3);
+    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS), r2 = tau / (b2 + WENO_EPS), r3 = tau / (b3 + WENO_EPS);
+    double a0 = (4.0 / 35) * (1 + r0 * r0);
+    double a1 = (18.0 / 35) * (1 + r1 * r1);
+    double a2 = (12.0 / 35) * (1 + r2 * r2);
+    double a3 = (1.0 / 35) * (1 + r3 * r3);
+    double s = a0 + a1 + a2 + a3;
+    return (a0 * q0 + a1 * q1 + a2 * q2 + a3 * q3) / s;
+}
+
+// reconstruct at a face from the line of values through `base` (cell on the high side of the
+// face); st = element stride of the line; left bias (vel > 0): upwind cell is base - st.
+template <int SCHEME>
+__device__ __forceinline__ double reconstruct(const double* base, long st, bool left) {
+    const double* up = left ? base - st : base;
+    const long s = left ? st : -st;
+    if (SCHEME == 1) return up[0];
+    if (SCHEME == 5 || SCHEME == -5) {
+        double p[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p[k] = up[(k - 2) * s];
+        return SCHEME == 5 ? weno5(p) : upwind5(p);
+    }
+    double p[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) p[k] = up[(k - 3) * s];
+    return weno7(p);
+}
+
+__device__ __forceinline__ double dxf_row(const GridDev& g, int j) { return g.metric_kind == 0 ? g.dx : g.dxf[j]; }
+__device__ __forceinline__ double azc_row(const GridDev& g, int j) { return g.metric_kind == 0 ? g.dx * g.dy : g.azc[j]; }
+
+constexpr int TX = 64, TY = 4;
+
+// One thread per cell of a (TX+1) x (TY+1) flux tile: the extra column / row holds the east /
+// north faces of the tile.  Fx[i] = Ax u c~ at the west face of cell i, Fy[j] at the south face.
+template <int SCHEME>
+__global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_tendencies(AdvDev A) {
+    __shared__ double sFxh[TY + 1][TX + 2], sFxa[TY + 1][TX + 2], sFyh[TY + 1][TX + 2], sFya[TY + 1][TX + 2];
+    const GridDev& g = A.g;
+    const int tx = threadIdx.x, ty = threadIdx.y;          // tx in [0, TX], ty in [0, TY]
+    const int i = 1 + blockIdx.x * TX + tx, j = 1 + blockIdx.y * TY + ty;
+    const bool in_x = i <= g.Nx + 1, in_y = j <= g.Ny + 1;
+    if (in_x && in_y) {
+        // x-face flux (needed for ty < TY rows), y-face flux (needed for tx < TX columns)
+        if (ty < TY && j <= g.Ny) {
+            const double uu = A.u(i, j);
+            const bool left = uu > 0;
+            const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left);
+            const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left);
+            sFxh[ty][tx] = g.dy * uu * ch;
+            sFxa[ty][tx] = g.dy * uu * ca;
+        }
+        if (tx < TX && i <= g.Nx) {
+            const double vv = A.v(i, j);
+            const bool left = vv > 0;
+            const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left);
+            const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left);
+            const double dxf = dxf_row(g, j);
+            sFyh[ty][tx] = dxf * vv * ch;
+            sFya[ty][tx] = dxf * vv * ca;
+        }
+    }
+    __syncthreads();
+    if (tx < TX && ty < TY && i <= g.Nx && j <= g.Ny) {
+        const double V = azc_row(g, j);
+        const double fxh = sFxh[ty][tx + 1] - sFxh[ty][tx], fyh = sFyh[ty + 1][tx] - sFyh[ty][tx];
+        const double fxa = sFxa[ty][tx + 1] - sFxa[ty][tx], fya = sFya[ty + 1][tx] - sFya[ty][tx];
+        A.Gh(i, j) = -(1 / V * (fxh + fyh));
+        A.Ga(i, j) = -(1 / V * (fxa + fya));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > A.g.Nx || j > A.g.Ny) return;
+    const double hn = A.from_cache ? A.hm(i, j) : A.h(i, j);
+    const double an = A.from_cache ? A.am(i, j) : A.a(i, j);
+    double hp = hn + A.dt * A.Gh(i, j);
+    double ap = an + A.dt * A.Ga(i, j);
+    ap = fmax(0.0, ap);
+    hp = fmax(0.0, hp);
+    ap = (hp == 0) ? 0.0 : ap;
+    hp = (ap == 0) ? 0.0 : hp;
+    const double Vp = hp * ap;
+    A.a(i, j) = (ap > 1) ? 1.0 : ap;
+    A.h(i, j) = (ap > 1) ? Vp : hp;
+}
+
+}  // namespace adv
+
+void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
+    (void)mode;
+    dim3 b(adv::TX + 1, adv::TY + 1);
+    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY - 1) / adv::TY));
+    switch (A.scheme) {
+        case 1: hipLaunchKernelGGL(adv::k_tendencies<1>, gr, b, 0, s, A); break;
+        case 5: hipLaunchKernelGGL(adv::k_tendencies<5>, gr, b, 0, s, A); break;
+        case -5: hipLaunchKernelGGL(adv::k_tendencies<-5>, gr, b, 0, s, A); break;
+        default: hipLaunchKernelGGL(adv::k_tendencies<7>, gr, b, 0, s, A); break;
+    }
+}
+void launch_tracer_step(const AdvDev& A, hipStream_t s) {
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(adv::k_tracer_step, dim3((unsigned)((A.g.Nx + 63) / 64), (unsigned)((A.g.Ny + 3) / 4)), b, 0, s, A);
+}
+
+}  // namespace csi

@@ -1,0 +1,612 @@
+// csi_abi.hip -- the C ABI of libcsi_hip.so (include/csi.h) and the HIP launch loops.
+//
+// The launch loop here replaces the host side of the reference's
+//   time_step_momentum!   SeaIceDynamics/split_explicit_momentum_equations.jl:103-195
+//   rk_substep! / cache_current_fields! / dynamic_time_step!   sea_ice_rk_substep.jl:29-152
+//   time_step!(::FESeaIceModel)   sea_ice_fe_step.jl:13-34
+// All work is ordered on the context's stream; nothing here synchronises with the host
+// except csi_sync / csi_context_destroy.
+#include "../../include/csi.h"
+#include "csi_dev.h"
+#include "csi_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace csi;
+
+namespace {
+
+struct Bound {
+    double* p = nullptr;
+    int64_t ld = 0;
+    int ni = 0, nj = 0;
+};
+
+// (x, y) location of every field slot
+const int kLoc[CSI_F_COUNT][2] = {
+    {LOC_F, LOC_C}, {LOC_C, LOC_F}, {LOC_C, LOC_C}, {LOC_C, LOC_C},   // U V H A
+    {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_F, LOC_F},                   // S11 S22 S12
+    {LOC_F, LOC_C}, {LOC_C, LOC_F}, {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C},  // UN VN P ALPHA DELTA
+    {LOC_F, LOC_F}, {LOC_C, LOC_C},                                   // ZETA_F ZETA_C
+    {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C},   // GH GA HM AM
+    {LOC_F, LOC_C}, {LOC_C, LOC_F},                                   // UM VM
+    {LOC_F, LOC_C}, {LOC_C, LOC_F}, {LOC_F, LOC_C}, {LOC_C, LOC_F},   // TOP_U TOP_V BOT_U BOT_V
+    {LOC_C, LOC_C}};                                                  // MASS_FLUX
+const char* kName[CSI_F_COUNT] = {"u", "v", "h", "aice", "sigma11", "sigma22", "sigma12", "un", "vn", "P", "alpha",
+                                  "Delta", "zeta_f", "zeta_c", "Gh", "Gaice", "h-", "aice-", "u-", "v-",
+                                  "top_u", "top_v", "bottom_u", "bottom_v", "mass_flux"};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct csi_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool grid_set = false, evp_set = false;
+    int Nx = 0, Ny = 0, Hx = 0, Hy = 0, topo_x = 0, topo_y = 0, metric_kind = 0;
+    GridDev g{};
+    double* dev_metrics = nullptr;   // 8 vectors of length Ny + 2Hy + 1
+    double* dev_coef = nullptr;      // FAST per-row stencil coefficients [FC_COUNT][Ny + 2Hy + 1]
+    FastCoef coef{};
+    Bound f[CSI_F_COUNT];
+    csi_evp_params evp{};
+    csi_stress stress[2]{};
+    int mode = CSI_MODE_STRICT;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int launches_per_substep = 0;
+};
+
+namespace {
+
+int32_t fail(csi_context* c, int32_t code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(c, CSI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+int side_lo(int topo) {
+    switch (topo) {
+        case CSI_PERIODIC: return SIDE_PERIODIC;
+        case CSI_BOUNDED: return SIDE_WALL;
+        case CSI_FULLY_CONNECTED: return SIDE_CONNECTED;
+        case CSI_LEFT_CONNECTED: return SIDE_CONNECTED;
+        default: return SIDE_WALL;   // RIGHT_CONNECTED: low side is the wall
+    }
+}
+int side_hi(int topo) {
+    switch (topo) {
+        case CSI_PERIODIC: return SIDE_PERIODIC;
+        case CSI_BOUNDED: return SIDE_WALL;
+        case CSI_FULLY_CONNECTED: return SIDE_CONNECTED;
+        case CSI_LEFT_CONNECTED: return SIDE_WALL;
+        default: return SIDE_CONNECTED;
+    }
+}
+int img_of(int side, int loc) {
+    if (side == SIDE_PERIODIC) return IMG_WRAP;
+    if (side == SIDE_WALL) return loc == LOC_C ? IMG_MIRROR : IMG_NONE;
+    return IMG_NONE;
+}
+ImageSpec image_spec(const csi_context* c, int fid) {
+    ImageSpec im;
+    im.xlo = img_of(c->g.xlo, kLoc[fid][0]);
+    im.xhi = img_of(c->g.xhi, kLoc[fid][0]);
+    im.ylo = img_of(c->g.ylo, kLoc[fid][1]);
+    im.yhi = img_of(c->g.yhi, kLoc[fid][1]);
+    return im;
+}
+// a Face-located field has one extra point where the HIGH side of that direction is a wall
+int extra_x(const csi_context* c, int fid) { return (kLoc[fid][0] == LOC_F && c->g.xhi == SIDE_WALL) ? 1 : 0; }
+int extra_y(const csi_context* c, int fid) { return (kLoc[fid][1] == LOC_F && c->g.yhi == SIDE_WALL) ? 1 : 0; }
+
+FRef ref_of(const csi_context* c, int fid) {
+    FRef r;
+    const Bound& b = c->f[fid];
+    r.p = b.p ? b.p + (c->Hx - 1) + (int64_t)(c->Hy - 1) * b.ld : nullptr;
+    r.ld = (int)b.ld;
+    return r;
+}
+int32_t need(csi_context* c, std::initializer_list<int> ids) {
+    if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");
+    for (int id : ids)
+        if (!c->f[id].p) return fail(c, CSI_ERR_NOT_BOUND, std::string("field not bound: ") + kName[id]);
+    return CSI_OK;
+}
+
+StressDev stress_dev(const csi_context* c, int side) {
+    const csi_stress& s = c->stress[side];
+    StressDev d{};
+    d.kind = s.kind; d.ue_kind = s.ue_kind; d.ve_kind = s.ve_kind;
+    d.tau_u = s.tau_u; d.tau_v = s.tau_v; d.ue = s.ue; d.ve = s.ve; d.rho_e = s.rho_e; d.Cd = s.Cd;
+    d.fu = ref_of(c, side == CSI_STRESS_TOP ? CSI_F_TOP_U : CSI_F_BOT_U);
+    d.fv = ref_of(c, side == CSI_STRESS_TOP ? CSI_F_TOP_V : CSI_F_BOT_V);
+    return d;
+}
+int32_t check_stress_fields(csi_context* c, int side) {
+    const csi_stress& s = c->stress[side];
+    int fu = side == CSI_STRESS_TOP ? CSI_F_TOP_U : CSI_F_BOT_U, fv = side == CSI_STRESS_TOP ? CSI_F_TOP_V : CSI_F_BOT_V;
+    bool need_u = s.kind == CSI_STRESS_FIELD || (s.kind == CSI_STRESS_SEMI_IMPLICIT && s.ue_kind == CSI_VEL_FIELD);
+    bool need_v = s.kind == CSI_STRESS_FIELD || (s.kind == CSI_STRESS_SEMI_IMPLICIT && s.ve_kind == CSI_VEL_FIELD);
+    if (need_u && !c->f[fu].p) return fail(c, CSI_ERR_NOT_BOUND, std::string("stress field not bound: ") + kName[fu]);
+    if (need_v && !c->f[fv].p) return fail(c, CSI_ERR_NOT_BOUND, std::string("stress field not bound: ") + kName[fv]);
+    return CSI_OK;
+}
+
+EvpDev evp_dev(const csi_context* c, double dt) {
+    EvpDev P{};
+    P.g = c->g;
+    P.u = ref_of(c, CSI_F_U); P.v = ref_of(c, CSI_F_V); P.h = ref_of(c, CSI_F_H); P.a = ref_of(c, CSI_F_A);
+    P.s11 = ref_of(c, CSI_F_S11); P.s22 = ref_of(c, CSI_F_S22); P.s12 = ref_of(c, CSI_F_S12);
+    P.zc = ref_of(c, CSI_F_ZETA_C); P.zf = ref_of(c, CSI_F_ZETA_F); P.Dl = ref_of(c, CSI_F_DELTA);
+    P.al = ref_of(c, CSI_F_ALPHA); P.P = ref_of(c, CSI_F_P); P.un = ref_of(c, CSI_F_UN); P.vn = ref_of(c, CSI_F_VN);
+    P.top = stress_dev(c, CSI_STRESS_TOP);
+    P.bot = stress_dev(c, CSI_STRESS_BOTTOM);
+    const csi_evp_params& e = c->evp;
+    P.P_star = e.ice_compressive_strength; P.C_star = e.ice_compaction_hardening; P.ecc = e.yield_curve_eccentricity;
+    P.Dmin = e.minimum_plastic_stress; P.amin = e.min_relaxation_parameter; P.amax = e.max_relaxation_parameter;
+    P.ca = e.relaxation_strength; P.min_mass = e.minimum_mass; P.min_conc = e.minimum_concentration;
+    P.rho = e.sea_ice_density; P.fcor = e.coriolis_f; P.has_cor = e.has_coriolis; P.pressure_kind = e.pressure_formulation;
+    P.dt = dt;
+    P.write_diag = 0;
+    return P;
+}
+
+// Index ranges (1-based, inclusive).  Stress kernels: Auxiliaries kernel parameters
+// -H+2 : N+H-1 (elasto_visco_plastic_rheology.jl:145); velocity kernels: :xy on a serial grid,
+// split_explicit_kernel_size on connected (tile) sides (split_explicit_momentum_equations.jl:40-46).
+Range stress_range(const csi_context* c) { return Range{-c->Hx + 2, c->Nx + c->Hx - 1, -c->Hy + 2, c->Ny + c->Hy - 1}; }
+Range interior_range(const csi_context* c) { return Range{1, c->Nx, 1, c->Ny}; }
+Range parent_range(const csi_context* c) { return Range{1 - c->Hx, c->Nx + c->Hx, 1 - c->Hy, c->Ny + c->Hy}; }
+
+int32_t fill_halo(csi_context* c, int fid) {
+    launch_fill_halo(ref_of(c, fid), c->g, image_spec(c, fid), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int32_t copy_parent(csi_context* c, int dst, int src) {
+    const Bound &d = c->f[dst], &s = c->f[src];
+    if (d.ld != s.ld || d.nj != s.nj) return fail(c, CSI_ERR_INVALID_ARGUMENT, std::string("parent shape mismatch: ") + kName[dst] + " vs " + kName[src]);
+    HIP_TRY(c, hipMemcpyAsync(d.p, s.p, sizeof(double) * (size_t)d.ld * (size_t)d.nj, hipMemcpyDeviceToDevice, c->stream));
+    return CSI_OK;
+}
+
+int32_t do_initialize(csi_context* c) {
+    EvpDev P = evp_dev(c, 0.0);
+    if (c->mode == CSI_MODE_FAST) launch_fast_init(P, parent_range(c), c->stream);
+    else launch_strict_init(P, parent_range(c), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
+    int32_t rc;
+    if ((rc = fill_halo(c, CSI_F_U))) return rc;     // :170
+    if ((rc = fill_halo(c, CSI_F_V))) return rc;     // :171
+    EvpDev P = evp_dev(c, dt);
+    const Range rs = stress_range(c), rv = interior_range(c);
+    const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
+    const bool fast = c->mode == CSI_MODE_FAST;
+    FastCoef fc = c->coef;
+    {
+        const double ie = 1.0 / P.ecc;
+        fc.em2 = ie * ie;
+        fc.ca_dt = P.ca * dt;
+        fc.rdt = 1.0 / dt;
+    }
+    if (fast && !fast_supported(P)) return fail(c, CSI_ERR_UNSUPPORTED, "CSI_MODE_FAST does not support this configuration yet; use CSI_MODE_STRICT");
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (int s = first; s < first + substeps; ++s) {
+        if (fast) {
+            P.write_diag = (s == first + substeps - 1);
+            launch_fast_stress(P, rs, fc, c->stream);
+        } else {
+            launch_strict_visc(P, rs, c->stream);          // compute_stresses!, evp:222-234
+            launch_strict_stress(P, rs, c->stream);
+        }
+        if ((s % 2) == 0) {                                // :178-182
+            if (fast) { launch_fast_ustep(P, rv, imu, fc, c->stream); launch_fast_vstep(P, rv, imv, fc, c->stream); }
+            else { launch_strict_ustep(P, rv, imu, c->stream); launch_strict_vstep(P, rv, imv, c->stream); }
+        } else {                                           // :184-187
+            if (fast) { launch_fast_vstep(P, rv, imv, fc, c->stream); launch_fast_ustep(P, rv, imu, fc, c->stream); }
+            else { launch_strict_vstep(P, rv, imv, c->stream); launch_strict_ustep(P, rv, imu, c->stream); }
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipGetLastError());
+    c->timed = true;
+    c->launches_per_substep = fast ? 3 : 4;
+    return CSI_OK;
+}
+
+int32_t do_finalize(csi_context* c) {
+    int32_t rc;
+    if ((rc = fill_halo(c, CSI_F_S11))) return rc;
+    if ((rc = fill_halo(c, CSI_F_S12))) return rc;
+    if ((rc = fill_halo(c, CSI_F_S22))) return rc;
+    return CSI_OK;
+}
+
+int32_t need_evp(csi_context* c) {
+    int32_t rc = need(c, {CSI_F_U, CSI_F_V, CSI_F_H, CSI_F_A, CSI_F_S11, CSI_F_S22, CSI_F_S12, CSI_F_UN, CSI_F_VN,
+                          CSI_F_P, CSI_F_ALPHA, CSI_F_DELTA, CSI_F_ZETA_F, CSI_F_ZETA_C});
+    if (rc) return rc;
+    if (!c->evp_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_evp_params_set has not been called");
+    if ((rc = check_stress_fields(c, CSI_STRESS_TOP))) return rc;
+    if ((rc = check_stress_fields(c, CSI_STRESS_BOTTOM))) return rc;
+    if (c->Hx < 2 || c->Hy < 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "EVP needs halo >= 2");
+    if (c->Nx < c->Hx || c->Ny < c->Hy) return fail(c, CSI_ERR_UNSUPPORTED, "tile smaller than its halo");
+    return CSI_OK;
+}
+
+int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_reset) {
+    int32_t rc;
+    if (rk_reset) {                                         // reset_velocities! :89-93
+        if ((rc = need(c, {CSI_F_UM, CSI_F_VM}))) return rc;
+        if ((rc = copy_parent(c, CSI_F_U, CSI_F_UM))) return rc;
+        if ((rc = copy_parent(c, CSI_F_V, CSI_F_VM))) return rc;
+    }
+    if ((rc = do_initialize(c))) return rc;                 // :130
+    if ((rc = do_subcycle(c, dt, substeps, 1))) return rc;  // :170-189
+    return do_finalize(c);                                  // :192
+}
+
+AdvDev adv_dev(const csi_context* c, int scheme, double dt, int from_cache) {
+    AdvDev A{};
+    A.g = c->g;
+    A.u = ref_of(c, CSI_F_U); A.v = ref_of(c, CSI_F_V); A.h = ref_of(c, CSI_F_H); A.a = ref_of(c, CSI_F_A);
+    A.Gh = ref_of(c, CSI_F_GH); A.Ga = ref_of(c, CSI_F_GA); A.hm = ref_of(c, CSI_F_HM); A.am = ref_of(c, CSI_F_AM);
+    A.scheme = scheme; A.dt = dt; A.from_cache = from_cache;
+    return A;
+}
+
+int32_t do_update_state(csi_context* c) {
+    int32_t rc;
+    if ((rc = need(c, {CSI_F_H, CSI_F_A}))) return rc;
+    launch_mask_center(ref_of(c, CSI_F_H), c->g, c->stream);
+    launch_mask_center(ref_of(c, CSI_F_A), c->g, c->stream);
+    if ((rc = fill_halo(c, CSI_F_H))) return rc;
+    if ((rc = fill_halo(c, CSI_F_A))) return rc;
+    if (c->f[CSI_F_U].p && c->f[CSI_F_V].p) {
+        launch_mask_u(ref_of(c, CSI_F_U), c->g, c->stream);
+        launch_mask_v(ref_of(c, CSI_F_V), c->g, c->stream);
+        if ((rc = fill_halo(c, CSI_F_U))) return rc;
+        if ((rc = fill_halo(c, CSI_F_V))) return rc;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int32_t do_tendencies(csi_context* c, int scheme) {
+    int32_t rc;
+    if ((rc = need(c, {CSI_F_U, CSI_F_V, CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA}))) return rc;
+    int need_h = scheme == CSI_ADVECT_WENO7 ? 4 : (scheme == CSI_ADVECT_UPWIND1 ? 1 : 3);
+    if (scheme != CSI_ADVECT_UPWIND1 && scheme != CSI_ADVECT_WENO5 && scheme != CSI_ADVECT_WENO7 && scheme != CSI_ADVECT_UPWIND5)
+        return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown advection scheme");
+    if (c->Hx < need_h || c->Hy < need_h) return fail(c, CSI_ERR_INVALID_ARGUMENT, "halo too small for the advection scheme");
+    if (c->g.xlo == SIDE_WALL || c->g.ylo == SIDE_WALL || c->g.xhi == SIDE_WALL || c->g.yhi == SIDE_WALL)
+        if (scheme != CSI_ADVECT_UPWIND1)
+            return fail(c, CSI_ERR_UNSUPPORTED, "high-order advection next to walls (upstream boundary-order reduction) is not implemented");
+    launch_tracer_tendencies(adv_dev(c, scheme, 0.0, 0), c->mode, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+int32_t do_tracer_step(csi_context* c, double dt, int from_cache) {
+    int32_t rc;
+    if ((rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA}))) return rc;
+    if (from_cache && (rc = need(c, {CSI_F_HM, CSI_F_AM}))) return rc;
+    launch_tracer_step(adv_dev(c, 0, dt, from_cache), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int32_t csi_version(void) { return CSI_VERSION; }
+
+const char* csi_last_error(const csi_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** out) {
+    if (!out) return fail(nullptr, CSI_ERR_INVALID_ARGUMENT, "out == NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, CSI_ERR_NO_DEVICE, "no HIP device visible (libcsi_hip has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, CSI_ERR_INVALID_ARGUMENT, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    csi_context* c = new csi_context();
+    c->device = device_id;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(nullptr, CSI_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+    c->stress[0].kind = CSI_STRESS_NONE;
+    c->stress[1].kind = CSI_STRESS_NONE;
+    *out = c;
+    return CSI_OK;
+}
+
+int32_t csi_context_destroy(csi_context* c) {
+    if (!c) return CSI_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->dev_metrics) hipFree(c->dev_metrics);
+    if (c->dev_coef) hipFree(c->dev_coef);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return CSI_OK;
+}
+
+int32_t csi_sync(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CSI_OK;
+}
+
+int32_t csi_set_mode(csi_context* c, int32_t mode) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (mode != CSI_MODE_STRICT && mode != CSI_MODE_FAST) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown mode");
+    c->mode = mode;
+    return CSI_OK;
+}
+
+int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y,
+                     int32_t metric_kind, const csi_metrics* m) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (Nx < 1 || Ny < 1 || Hx < 1 || Hy < 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "grid sizes must be >= 1");
+    if (topo_x < CSI_PERIODIC || topo_x > CSI_RIGHT_CONNECTED || topo_y < CSI_PERIODIC || topo_y > CSI_RIGHT_CONNECTED)
+        return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown topology");
+    if (!m) return fail(c, CSI_ERR_INVALID_ARGUMENT, "metrics == NULL");
+    if (metric_kind != CSI_METRIC_UNIFORM && metric_kind != CSI_METRIC_PER_J) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown metric kind");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->Nx = Nx; c->Ny = Ny; c->Hx = Hx; c->Hy = Hy; c->topo_x = topo_x; c->topo_y = topo_y; c->metric_kind = metric_kind;
+    GridDev& g = c->g;
+    g = GridDev{};   // a new grid also drops any mask
+    g.Nx = Nx; g.Ny = Ny; g.Hx = Hx; g.Hy = Hy;
+    g.xlo = side_lo(topo_x); g.xhi = side_hi(topo_x); g.ylo = side_lo(topo_y); g.yhi = side_hi(topo_y);
+    g.metric_kind = metric_kind;
+    g.dx = m->dx; g.dy = m->dy;
+    if (c->dev_metrics) { hipFree(c->dev_metrics); c->dev_metrics = nullptr; }
+    if (metric_kind == CSI_METRIC_PER_J) {
+        if (!m->dxc || !m->dxf || !m->azc || !m->azf) return fail(c, CSI_ERR_INVALID_ARGUMENT, "PER_J metrics need dxc, dxf, azc, azf");
+        const size_t n = (size_t)Ny + 2 * (size_t)Hy + 1;
+        std::vector<double> host(8 * n);
+        const double* src[4] = {m->dxc, m->dxf, m->azc, m->azf};
+        for (int k = 0; k < 4; ++k)
+            for (size_t t = 0; t < n; ++t) {
+                host[k * n + t] = src[k][t];
+                host[(4 + k) * n + t] = 1.0 / src[k][t];
+            }
+        HIP_TRY(c, hipMalloc((void**)&c->dev_metrics, sizeof(double) * 8 * n));
+        HIP_TRY(c, hipMemcpy(c->dev_metrics, host.data(), sizeof(double) * 8 * n, hipMemcpyHostToDevice));
+        const double* base = c->dev_metrics + (Hy - 1);   // so that ptr[j] is row j
+        g.dxc = base; g.dxf = base + n; g.azc = base + 2 * n; g.azf = base + 3 * n;
+        g.rdxc = base + 4 * n; g.rdxf = base + 5 * n; g.razc = base + 6 * n; g.razf = base + 7 * n;
+    }
+    // FAST-mode stencil coefficients
+    if (c->dev_coef) { hipFree(c->dev_coef); c->dev_coef = nullptr; }
+    c->coef = FastCoef{};
+    c->coef.uniform = metric_kind == CSI_METRIC_UNIFORM;
+    if (metric_kind == CSI_METRIC_UNIFORM) {
+        build_fast_coef_uniform(m->dx, m->dy, c->coef.uni);
+    } else {
+        const int n = Ny + 2 * Hy + 1;
+        std::vector<double> host;
+        build_fast_coef_per_j(n, m->dy, m->dxc, m->dxf, m->azc, m->azf, host);
+        HIP_TRY(c, hipMalloc((void**)&c->dev_coef, sizeof(double) * host.size()));
+        HIP_TRY(c, hipMemcpy(c->dev_coef, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+        c->coef.vec = c->dev_coef + (Hy - 1);
+        c->coef.stride = n;
+    }
+    for (auto& b : c->f) b = Bound{};   // bindings refer to the previous grid
+    c->grid_set = true;
+    return CSI_OK;
+}
+
+int32_t csi_mask_set(csi_context* c, const uint8_t* dev_mask, int64_t ld) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");
+    if (!dev_mask) { c->g.mask = nullptr; c->g.has_mask = 0; c->g.mask_ld = 0; return CSI_OK; }
+    if (ld < c->Nx + 2 * c->Hx) return fail(c, CSI_ERR_INVALID_ARGUMENT, "mask ld too small");
+    c->g.mask = dev_mask + (c->Hx - 1) + (int64_t)(c->Hy - 1) * ld;
+    c->g.mask_ld = (int)ld;
+    c->g.has_mask = 1;
+    return CSI_OK;
+}
+
+int32_t csi_field_bind(csi_context* c, int32_t fid, void* dev_ptr, int64_t ld, int32_t ni, int32_t nj) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");
+    if (fid < 0 || fid >= CSI_F_COUNT) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown field id");
+    if (!dev_ptr) { c->f[fid] = Bound{}; return CSI_OK; }
+    const int eni = c->Nx + 2 * c->Hx + extra_x(c, fid), enj = c->Ny + 2 * c->Hy + extra_y(c, fid);
+    if (ni != eni || nj != enj || ld < ni) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "field %s: parent extents (%d, %d, ld %lld) do not match the grid (expected %d x %d)",
+                 kName[fid], ni, nj, (long long)ld, eni, enj);
+        return fail(c, CSI_ERR_INVALID_ARGUMENT, buf);
+    }
+    if (ld > 0x7fffffff) return fail(c, CSI_ERR_INVALID_ARGUMENT, "ld too large");
+    if (((uintptr_t)dev_ptr) & 7) return fail(c, CSI_ERR_INVALID_ARGUMENT, "field pointer must be 8-byte aligned");
+    c->f[fid].p = (double*)dev_ptr; c->f[fid].ld = ld; c->f[fid].ni = ni; c->f[fid].nj = nj;
+    return CSI_OK;
+}
+
+int32_t csi_evp_params_set(csi_context* c, const csi_evp_params* p) {
+    if (!c || !p) return CSI_ERR_INVALID_ARGUMENT;
+    if (p->pressure_formulation != CSI_PRESSURE_REPLACEMENT && p->pressure_formulation != CSI_PRESSURE_ICE_STRENGTH)
+        return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown pressure formulation");
+    c->evp = *p;
+    c->evp_set = true;
+    return CSI_OK;
+}
+
+int32_t csi_stress_set(csi_context* c, int32_t side, const csi_stress* s) {
+    if (!c || !s) return CSI_ERR_INVALID_ARGUMENT;
+    if (side != CSI_STRESS_TOP && side != CSI_STRESS_BOTTOM) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown stress side");
+    if (s->kind < CSI_STRESS_NONE || s->kind > CSI_STRESS_SEMI_IMPLICIT) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown stress kind");
+    c->stress[side] = *s;
+    return CSI_OK;
+}
+
+int32_t csi_evp_initialize(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need_evp(c);
+    if (rc) return rc;
+    return do_initialize(c);
+}
+
+int32_t csi_evp_subcycle(csi_context* c, double dt, int32_t substeps, int32_t first_substep) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need_evp(c);
+    if (rc) return rc;
+    if (substeps < 0 || first_substep < 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "substeps >= 0 and first_substep >= 1 required");
+    return do_subcycle(c, dt, substeps, first_substep);
+}
+
+int32_t csi_evp_finalize(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need(c, {CSI_F_S11, CSI_F_S22, CSI_F_S12});
+    if (rc) return rc;
+    return do_finalize(c);
+}
+
+int32_t csi_time_step_momentum(csi_context* c, double dt, int32_t substeps, int32_t rk_reset) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need_evp(c);
+    if (rc) return rc;
+    if (substeps < 0) return fail(c, CSI_ERR_INVALID_ARGUMENT, "substeps >= 0 required");
+    return do_time_step_momentum(c, dt, substeps, rk_reset);
+}
+
+int32_t csi_compute_tracer_tendencies(csi_context* c, int32_t scheme) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    return do_tendencies(c, scheme);
+}
+
+int32_t csi_dynamic_step_tracers(csi_context* c, double dt, int32_t from_cache) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    return do_tracer_step(c, dt, from_cache);
+}
+
+int32_t csi_cache_current_fields(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_HM, CSI_F_AM});
+    if (rc) return rc;
+    if ((rc = copy_parent(c, CSI_F_HM, CSI_F_H))) return rc;
+    if ((rc = copy_parent(c, CSI_F_AM, CSI_F_A))) return rc;
+    if (c->f[CSI_F_U].p && c->f[CSI_F_UM].p) {
+        if ((rc = copy_parent(c, CSI_F_UM, CSI_F_U))) return rc;
+        if ((rc = copy_parent(c, CSI_F_VM, CSI_F_V))) return rc;
+    }
+    return CSI_OK;
+}
+
+int32_t csi_update_state(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    return do_update_state(c);
+}
+
+int32_t csi_fill_halo_local(csi_context* c, int32_t fid) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (fid < 0 || fid >= CSI_F_COUNT) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown field id");
+    int32_t rc = need(c, {fid});
+    if (rc) return rc;
+    return fill_halo(c, fid);
+}
+
+int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t scheme, int32_t first_iteration) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need_evp(c);
+    if (rc) return rc;
+    if (first_iteration && (rc = do_update_state(c))) return rc;          // sea_ice_fe_step.jl:16
+    if (scheme && (rc = do_tendencies(c, scheme))) return rc;             // :19
+    if ((rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
+    if (scheme && (rc = do_tracer_step(c, dt, 0))) return rc;             // :25
+    return do_update_state(c);                                            // :31
+}
+
+int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t scheme) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need_evp(c);
+    if (rc) return rc;
+    if ((rc = need(c, {CSI_F_HM, CSI_F_AM, CSI_F_UM, CSI_F_VM}))) return rc;
+    if ((rc = csi_cache_current_fields(c))) return rc;                    // sea_ice_rk_substep.jl:29-42
+    for (int beta = 3; beta >= 1; --beta) {                               // upstream stage loop
+        const double dtau = dt / beta;
+        if (scheme && (rc = do_tendencies(c, scheme))) return rc;         // :84
+        if ((rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
+        if (scheme && (rc = do_tracer_step(c, dtau, 1))) return rc;       // :89
+        if ((rc = do_update_state(c))) return rc;
+    }
+    return CSI_OK;
+}
+
+int32_t csi_slab_thermo_step(csi_context* c, const csi_slab_params* p, double dt) {
+    if (!c || !p) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need(c, {CSI_F_H, CSI_F_A});
+    if (rc) return rc;
+    SlabDev S{};
+    S.k = p->conductivity; S.rho_bulk = p->sea_ice_density; S.rho_pure = p->density; S.rho_l = p->liquid_density;
+    S.c_l = p->liquid_heat_capacity; S.c_i = p->heat_capacity; S.L0 = p->reference_latent_heat; S.T0 = p->reference_temperature;
+    S.liq_slope = p->liquidus_slope; S.liq_T0 = p->freshwater_melting_temperature; S.S = p->bottom_salinity;
+    S.hc = p->ice_consolidation_thickness; S.Tu = p->top_temperature; S.Qu = p->top_heat_flux; S.Qb = p->bottom_heat_flux;
+    S.top_flux_kind = p->top_flux_kind; S.bot_flux_kind = p->bottom_flux_kind;
+    const bool has_mf = c->f[CSI_F_MASS_FLUX].p != nullptr;
+    launch_slab_step(S, c->g, ref_of(c, CSI_F_H), ref_of(c, CSI_F_A), ref_of(c, CSI_F_MASS_FLUX), has_mf, dt, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
+int32_t csi_tile_set(csi_context* c, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) {
+    return fail(c, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet");
+}
+int32_t csi_comm_unique_id(uint8_t*) { return fail(nullptr, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet"); }
+int32_t csi_comm_init(csi_context* c, int32_t, int32_t, const uint8_t*) {
+    return fail(c, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet");
+}
+int32_t csi_halo_exchange(csi_context* c, const int32_t*, int32_t, int32_t) {
+    return fail(c, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet");
+}
+
+int32_t csi_last_subcycle_ms(csi_context* c, double* ms) {
+    if (!c || !ms) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->timed) return fail(c, CSI_ERR_NOT_BOUND, "no sub-cycle has been timed yet");
+    float t = 0.f;
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    *ms = (double)t;
+    return CSI_OK;
+}
+
+int32_t csi_launches_per_substep(csi_context* c, int32_t* n) {
+    if (!c || !n) return CSI_ERR_INVALID_ARGUMENT;
+    *n = c->launches_per_substep;
+    return CSI_OK;
+}
+
+}  // extern "C"

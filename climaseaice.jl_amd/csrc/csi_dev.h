@@ -1,0 +1,126 @@
+// csi_dev.h -- device-side problem description shared by all kernels of libcsi_hip.so.
+// gfx950 (MI355X) only.  Indices (i, j) are the reference's 1-based indices; a field
+// reference points at the (virtual) element (0, 0) so that element (i, j) = p[i + j * ld].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace csi {
+
+enum : int { SIDE_PERIODIC = 0, SIDE_WALL = 1, SIDE_CONNECTED = 2 };
+enum : int { LOC_C = 0, LOC_F = 1 };
+enum : int { IMG_NONE = 0, IMG_WRAP = 1, IMG_MIRROR = 2 };
+
+struct FRef {
+    double* p;   // element (0, 0) in reference indexing
+    int ld;
+    __device__ __forceinline__ double& operator()(int i, int j) const { return p[i + (long)j * ld]; }
+    __device__ __forceinline__ double ld_(int i, int j) const { return p[i + (long)j * ld]; }
+};
+
+struct GridDev {
+    int Nx, Ny, Hx, Hy;
+    int xlo, xhi, ylo, yhi;   // SIDE_* of each edge of this tile
+    int metric_kind;          // 0 uniform, 1 per-j
+    int has_mask;
+    double dx, dy;
+    // per-j vectors, indexable directly with the reference j (pointer pre-offset): j in [1-Hy, Ny+Hy+1]
+    const double *dxc, *dxf, *azc, *azf;
+    const double *rdxc, *rdxf, *razc, *razf;   // reciprocals (FAST mode)
+    const uint8_t* mask;      // element (0,0)-offset like FRef
+    int mask_ld;
+};
+
+struct StressDev {
+    int kind, ue_kind, ve_kind, pad;
+    double tau_u, tau_v, ue, ve, rho_e, Cd;
+    FRef fu, fv;
+};
+
+struct EvpDev {
+    GridDev g;
+    FRef u, v, h, a, s11, s22, s12, zc, zf, Dl, al, P, un, vn;
+    StressDev top, bot;
+    double P_star, C_star, ecc, Dmin, amin, amax, ca;
+    double min_mass, min_conc, rho, fcor;
+    int pressure_kind, has_cor;
+    double dt;
+    int write_diag;   // FAST: also store zeta_c, zeta_f, Delta (last sub-step only)
+};
+
+struct Range { int i0, i1, j0, j1; };
+
+// ---- activity / peripheral nodes (upstream Grids.inactive_cell / peripheral_node) ------------
+__device__ __forceinline__ bool inactive_cell(const GridDev& g, int i, int j) {
+    if ((g.xlo == SIDE_WALL && i < 1) || (g.xhi == SIDE_WALL && i > g.Nx)) return true;
+    if ((g.ylo == SIDE_WALL && j < 1) || (g.yhi == SIDE_WALL && j > g.Ny)) return true;
+    if (g.has_mask) {
+        if (i < 1 - g.Hx || i > g.Nx + g.Hx || j < 1 - g.Hy || j > g.Ny + g.Hy) return true;
+        return g.mask[i + (long)j * g.mask_ld] == 0;
+    }
+    return false;
+}
+__device__ __forceinline__ bool inactive_cell_underlying(const GridDev& g, int i, int j) {
+    if ((g.xlo == SIDE_WALL && i < 1) || (g.xhi == SIDE_WALL && i > g.Nx)) return true;
+    if ((g.ylo == SIDE_WALL && j < 1) || (g.yhi == SIDE_WALL && j > g.Ny)) return true;
+    return false;
+}
+__device__ __forceinline__ bool peripheral_u(const GridDev& g, int i, int j) {
+    return inactive_cell(g, i, j) | inactive_cell(g, i - 1, j);
+}
+__device__ __forceinline__ bool peripheral_v(const GridDev& g, int i, int j) {
+    return inactive_cell(g, i, j) | inactive_cell(g, i, j - 1);
+}
+__device__ __forceinline__ bool immersed_peripheral_cc(const GridDev& g, int i, int j) {
+    if (!g.has_mask) return false;
+    return inactive_cell(g, i, j) && !inactive_cell_underlying(g, i, j);
+}
+__device__ __forceinline__ bool immersed_peripheral_ff(const GridDev& g, int i, int j) {
+    if (!g.has_mask) return false;
+    bool p = inactive_cell(g, i, j) | inactive_cell(g, i - 1, j) | inactive_cell(g, i, j - 1) | inactive_cell(g, i - 1, j - 1);
+    bool pu = inactive_cell_underlying(g, i, j) | inactive_cell_underlying(g, i - 1, j) |
+              inactive_cell_underlying(g, i, j - 1) | inactive_cell_underlying(g, i - 1, j - 1);
+    return p && !pu;
+}
+
+// ---- fused local halo fill: the thread that owns interior element (i, j) also writes the halo
+// images that fill_halo_regions!(...; only_local_halos = true) would copy from it
+// (split_explicit_momentum_equations.jl:170-187; upstream BC semantics).
+// imgx / imgy: IMG_WRAP (Periodic), IMG_MIRROR (no-flux, Center location on a wall), IMG_NONE.
+// A mirrored low side and a connected high side (tile edges) are encoded per side.
+struct ImageSpec {
+    int xlo, xhi, ylo, yhi;   // IMG_* per side
+};
+__device__ __forceinline__ int image_lo(int mode, int i, int N, int H, bool& has) {
+    // halo index on the LOW side that copies from interior index i
+    if (mode == IMG_WRAP) { has = (i > N - H); return i - N; }
+    if (mode == IMG_MIRROR) { has = (i <= H); return 1 - i; }
+    has = false; return 0;
+}
+__device__ __forceinline__ int image_hi(int mode, int i, int N, int H, bool& has) {
+    if (mode == IMG_WRAP) { has = (i <= H); return i + N; }
+    if (mode == IMG_MIRROR) { has = (i > N - H); return 2 * N + 1 - i; }
+    has = false; return 0;
+}
+__device__ __forceinline__ void store_with_images(const FRef& f, const GridDev& g, const ImageSpec& im, int i, int j, double val) {
+    f(i, j) = val;
+    // only interior elements have images; the test is cheap and almost always false
+    const bool near_x = (i <= g.Hx) | (i > g.Nx - g.Hx);
+    const bool near_y = (j <= g.Hy) | (j > g.Ny - g.Hy);
+    if (!(near_x | near_y)) return;
+    if (i < 1 || i > g.Nx || j < 1 || j > g.Ny) return;
+    int xi[3], yj[3];
+    int nx = 0, ny = 0;
+    xi[nx++] = i;
+    yj[ny++] = j;
+    bool has;
+    int t = image_lo(im.xlo, i, g.Nx, g.Hx, has); if (has) xi[nx++] = t;
+    t = image_hi(im.xhi, i, g.Nx, g.Hx, has);     if (has) xi[nx++] = t;
+    t = image_lo(im.ylo, j, g.Ny, g.Hy, has);     if (has) yj[ny++] = t;
+    t = image_hi(im.yhi, j, g.Ny, g.Hy, has);     if (has) yj[ny++] = t;
+    for (int b = 0; b < ny; ++b)
+        for (int a = 0; a < nx; ++a)
+            if (a | b) f(xi[a], yj[b]) = val;
+}
+
+}  // namespace csi

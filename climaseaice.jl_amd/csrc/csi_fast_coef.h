@@ -1,0 +1,94 @@
+// csi_fast_coef.h -- per-row stencil coefficients of the FAST kernels.
+//
+// The reference evaluates the strain rates and the stress divergence with metric weights inside
+// the differences (Rheologies/elasto_visco_plastic_rheology.jl:360-375,
+// Rheologies/ice_stress_divergence.jl:39-51).  For the grids this library supports
+// (regular rectilinear, regular latitude-longitude: dy constant, dx and Az functions of j only)
+// those operators are short linear stencils whose weights depend on the row j alone.  The
+// weights are computed once on the host in fp64 (build_fast_coef) and read by the kernels as
+// wave-uniform scalars; on a uniform grid they are kernel-argument constants.
+#pragma once
+#include <vector>
+
+namespace csi {
+
+enum : int {
+    // centre rows j
+    FC_A = 0,   // e11: A (u[i+1] - u[i])               = dy / Az^cc
+    FC_BN,      // e11: + BN v[j+1]                      = (dxf[j+1]/Az - dxc^2/(dxf[j+1] Az)) / 2
+    FC_BS,      // e11: - BS v[j]
+    FC_CN,      // e22: + CN v[j+1]
+    FC_CS,      // e22: - CS v[j]
+    FC_E,       // div1: E (s11[i] - s11[i-1])           = dy / Az^fc
+    FC_FN,      // div1: + FN s12[j+1]                   = dxf[j+1]^2 / (dxc[j] Az^fc)
+    FC_FS,      // div1: - FS s12[j]
+    FC_RAZC,    // 1 / Az^cc
+    // face rows j
+    FC_SN,      // e12: + SN u[j]                        = dxf[j]^2 / (2 dxc[j] Az^ff)
+    FC_SS,      // e12: - SS u[j-1]
+    FC_SV,      // e12: + SV (v[i] - v[i-1])             = dy / (2 Az^ff)
+    FC_Q1N,     // div2: + Q1N s11[j] + Q2N s22[j] - Q1S s11[j-1] - Q2S s22[j-1] + K (s12[i+1] - s12[i])
+    FC_Q2N,
+    FC_Q1S,
+    FC_Q2S,
+    FC_K,
+    FC_RAZF,    // 1 / Az^ff
+    FC_COUNT
+};
+
+struct FastCoef {
+    double uni[FC_COUNT];   // uniform grid: the (row-independent) values
+    const double* vec;      // per-j: device array [FC_COUNT][stride], pre-offset so vec[w*stride + j] is row j
+    int stride;
+    int uniform;
+    double em2;             // e^-2
+    double ca_dt;           // c_alpha * dt (stage step)
+    double rdt;             // 1 / dt
+};
+
+// Host: fill `uni` (uniform) or `out` ([FC_COUNT][n], n = Ny + 2Hy + 1, entry for row j at [j + Hy - 1]).
+inline void build_fast_coef_uniform(double dx, double dy, double* uni) {
+    const double raz = 1.0 / (dx * dy);
+    uni[FC_A] = dy * raz;
+    const double d = dx * raz, t = dx * dx / dx * raz;
+    uni[FC_BN] = 0.5 * (d - t); uni[FC_BS] = 0.5 * (d - t);
+    uni[FC_CN] = 0.5 * (d + t); uni[FC_CS] = 0.5 * (d + t);
+    uni[FC_E] = dy * raz;
+    uni[FC_FN] = dx * dx / dx * raz; uni[FC_FS] = uni[FC_FN];
+    uni[FC_RAZC] = raz;
+    uni[FC_SN] = 0.5 * dx * dx / dx * raz; uni[FC_SS] = uni[FC_SN];
+    uni[FC_SV] = 0.5 * dy * raz;
+    const double G = 0.5 * dx * raz, H = 0.5 * dx * dx / dx * raz;
+    uni[FC_Q1N] = G - H; uni[FC_Q2N] = G + H; uni[FC_Q1S] = G - H; uni[FC_Q2S] = G + H;
+    uni[FC_K] = dy * raz;
+    uni[FC_RAZF] = raz;
+}
+
+inline void build_fast_coef_per_j(int n, double dy, const double* dxc, const double* dxf, const double* azc,
+                                  const double* azf, std::vector<double>& out) {
+    out.assign((size_t)FC_COUNT * n, 0.0);
+    auto at = [&](int w, int t) -> double& { return out[(size_t)w * n + t]; };
+    for (int t = 0; t < n; ++t) {
+        const int tp = t + 1 < n ? t + 1 : t, tm = t > 0 ? t - 1 : t;   // clamped neighbours (edge rows are never used)
+        const double razc = 1.0 / azc[t], razf = 1.0 / azf[t];
+        at(FC_A, t) = dy * razc;
+        const double dn = dxf[tp] * razc, ds = dxf[t] * razc;
+        const double tn = dxc[t] * dxc[t] / dxf[tp] * razc, ts = dxc[t] * dxc[t] / dxf[t] * razc;
+        at(FC_BN, t) = 0.5 * (dn - tn); at(FC_BS, t) = 0.5 * (ds - ts);
+        at(FC_CN, t) = 0.5 * (dn + tn); at(FC_CS, t) = 0.5 * (ds + ts);
+        at(FC_E, t) = dy * razc;
+        at(FC_FN, t) = dxf[tp] * dxf[tp] / dxc[t] * razc;
+        at(FC_FS, t) = dxf[t] * dxf[t] / dxc[t] * razc;
+        at(FC_RAZC, t) = razc;
+        at(FC_SN, t) = 0.5 * dxf[t] * dxf[t] / dxc[t] * razf;
+        at(FC_SS, t) = 0.5 * dxf[t] * dxf[t] / dxc[tm] * razf;
+        at(FC_SV, t) = 0.5 * dy * razf;
+        const double G = 0.5 * dxf[t] * razf;
+        const double Hn = 0.5 * dxc[t] * dxc[t] / dxf[t] * razf, Hs = 0.5 * dxc[tm] * dxc[tm] / dxf[t] * razf;
+        at(FC_Q1N, t) = G - Hn; at(FC_Q2N, t) = G + Hn; at(FC_Q1S, t) = G - Hs; at(FC_Q2S, t) = G + Hs;
+        at(FC_K, t) = dy * razf;
+        at(FC_RAZF, t) = razf;
+    }
+}
+
+}  // namespace csi

@@ -1,0 +1,65 @@
+// halo.hip -- local halo fill and immersed masking kernels.
+//
+// fill_halo_regions!(field; only_local_halos = true) (upstream Oceananigans, semantics recorded
+// in SURVEY.md App. B): Periodic sides wrap, Center-located fields on a wall mirror (no-flux),
+// Face-located fields on a wall are untouched; connected (tile) sides are left to
+// csi_halo_exchange.  Used once per stage (split_explicit_momentum_equations.jl:170-171,
+// elasto_visco_plastic_rheology.jl:275-280, sea_ice_model.jl:381-384); inside the sub-cycle
+// the fill is fused into the velocity kernels' stores.
+#include "csi_dev.h"
+#include "csi_kernels.h"
+
+namespace csi {
+
+// Only threads within H of an edge do anything; they copy their interior value to its images.
+// strip 0: the rows within Hy of the y edges (all i); strip 1: the columns within Hx of the x
+// edges for the remaining middle rows.
+__global__ void k_fill_halo(FRef f, GridDev g, ImageSpec im, int strip) {
+    const int Nx = g.Nx, Ny = g.Ny, Hx = g.Hx, Hy = g.Hy;
+    int i, j;
+    if (strip == 0) {
+        i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+        int jj = blockIdx.y * blockDim.y + threadIdx.y;      // 0 .. 2Hy-1
+        if (i > Nx || jj >= 2 * Hy) return;
+        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 + jj;          // rows 1..Hy and Ny-Hy+1..Ny
+        if (j < 1 || j > Ny || (jj >= Hy && j <= Hy)) return; // overlap when Ny < 2Hy
+    } else {
+        int ii = blockIdx.x * blockDim.x + threadIdx.x;      // 0 .. 2Hx-1
+        j = 1 + Hy + blockIdx.y * blockDim.y + threadIdx.y;  // middle rows Hy+1 .. Ny-Hy
+        if (ii >= 2 * Hx || j > Ny - Hy) return;
+        i = ii < Hx ? 1 + ii : Nx - 2 * Hx + 1 + ii;
+        if (i < 1 || i > Nx || (ii >= Hx && i <= Hx)) return;
+    }
+    store_with_images(f, g, im, i, j, f(i, j));
+}
+
+void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipStream_t s) {
+    dim3 b(64, 4);
+    unsigned gx0 = (unsigned)((g.Nx + 63) / 64), gy0 = (unsigned)((2 * g.Hy + 3) / 4);
+    hipLaunchKernelGGL(k_fill_halo, dim3(gx0, gy0, 1), b, 0, s, f, g, im, 0);
+    int mid = g.Ny - 2 * g.Hy;
+    if (mid > 0) {
+        unsigned gx1 = (unsigned)((2 * g.Hx + 63) / 64), gy1 = (unsigned)((mid + 3) / 4);
+        hipLaunchKernelGGL(k_fill_halo, dim3(gx1, gy1, 1), b, 0, s, f, g, im, 1);
+    }
+}
+
+// mask_immersed_field_xy!(field, k = Nz), sea_ice_model.jl:381-389: zero at peripheral nodes of an
+// immersed grid (no-op without a mask).
+__global__ void k_mask(FRef f, GridDev g, int kind) {
+    int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    bool z = kind == 0 ? inactive_cell(g, i, j) : (kind == 1 ? peripheral_u(g, i, j) : peripheral_v(g, i, j));
+    if (z) f(i, j) = 0.0;
+}
+static void launch_mask(const FRef& f, const GridDev& g, int kind, hipStream_t s) {
+    if (!g.has_mask) return;
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(k_mask, dim3((unsigned)((g.Nx + 63) / 64), (unsigned)((g.Ny + 3) / 4), 1), b, 0, s, f, g, kind);
+}
+void launch_mask_center(const FRef& f, const GridDev& g, hipStream_t s) { launch_mask(f, g, 0, s); }
+void launch_mask_u(const FRef& f, const GridDev& g, hipStream_t s) { launch_mask(f, g, 1, s); }
+void launch_mask_v(const FRef& f, const GridDev& g, hipStream_t s) { launch_mask(f, g, 2, s); }
+
+}  // namespace csi

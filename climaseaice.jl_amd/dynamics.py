@@ -1,0 +1,85 @@
+"""Host-side mirror of the reference's dynamics containers (plain data; no arithmetic here).
+
+ElastoViscoPlasticRheology   Rheologies/elasto_visco_plastic_rheology.jl:14-25,119-137
+Auxiliaries                  :140-173
+SplitExplicitSolver          SeaIceDynamics/split_explicit_momentum_equations.jl:18-46
+SemiImplicitStress           SeaIceDynamics/sea_ice_external_stress.jl:84-130
+SeaIceMomentumEquation       SeaIceDynamics/sea_ice_momentum_equations.jl:3-12,67-94
+FPlane                       upstream Oceananigans.Coriolis (f-plane only)
+"""
+import math
+from dataclasses import dataclass, field as dc_field
+from types import SimpleNamespace
+
+from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
+
+
+class ReplacementPressure:
+    pass
+
+
+class IceStrength:
+    pass
+
+
+@dataclass
+class ElastoViscoPlasticRheology:
+    ice_compressive_strength: float = 27500.0
+    ice_compaction_hardening: float = 20.0
+    yield_curve_eccentricity: float = 2.0
+    minimum_plastic_stress: float = 2e-9
+    min_relaxation_parameter: float = 50.0
+    max_relaxation_parameter: float = 300.0
+    relaxation_strength: float = math.pi ** 2
+    pressure_formulation: object = dc_field(default_factory=ReplacementPressure)
+
+
+@dataclass
+class SplitExplicitSolver:
+    """SplitExplicitSolver(grid; substeps=120): default 120 (:31); SeaIceMomentumEquation's default is 150."""
+    substeps: int = 120
+
+
+@dataclass
+class FPlane:
+    f: float = 1e-4
+
+
+@dataclass
+class SemiImplicitStress:
+    """tau = rho_e Cd |u_e - u| (u_e - u); u_e, v_e: None (ZeroField), a number (ConstantField) or a Field."""
+    ue: object = None
+    ve: object = None
+    rho_e: float = 1026.0
+    Cd: float = 5.5e-3
+
+
+def Auxiliaries(rheology, grid, device=None):
+    """The ten auxiliary fields of the EVP rheology; alpha pre-filled with alpha+ (evp:147-161)."""
+    f = SimpleNamespace(
+        s11=CenterField(grid, device, "sigma11"), s22=CenterField(grid, device, "sigma22"),
+        s12=CornerField(grid, device, "sigma12"),
+        un=XFaceField(grid, device, "un"), vn=YFaceField(grid, device, "vn"),
+        P=CenterField(grid, device, "P"), alpha=CenterField(grid, device, "alpha"),
+        Delta=CenterField(grid, device, "Delta"),
+        zeta_f=CornerField(grid, device, "zeta_f"), zeta_c=CenterField(grid, device, "zeta_c"))
+    f.alpha.fill_parent(rheology.max_relaxation_parameter)
+    return SimpleNamespace(fields=f)
+
+
+class SeaIceMomentumEquation:
+    def __init__(self, grid, coriolis=None, rheology=None, top_momentum_stress=None, bottom_momentum_stress=None,
+                 free_drift=None, solver=None, minimum_concentration=1e-3, minimum_mass=1.0, device=None):
+        self.grid = grid
+        self.coriolis = coriolis
+        self.rheology = rheology if rheology is not None else ElastoViscoPlasticRheology()
+        if not isinstance(self.rheology, ElastoViscoPlasticRheology):
+            raise NotImplementedError("only ElastoViscoPlasticRheology is on the accelerated path (SURVEY.md 2, row 3)")
+        self.solver = solver if solver is not None else SplitExplicitSolver(substeps=150)
+        if free_drift is not None:
+            raise NotImplementedError("free_drift closed forms are 'next' (SURVEY.md 8f-4); only `nothing` is supported")
+        self.free_drift = None
+        self.external_momentum_stresses = SimpleNamespace(top=top_momentum_stress, bottom=bottom_momentum_stress)
+        self.minimum_concentration = float(minimum_concentration)
+        self.minimum_mass = float(minimum_mass)
+        self.auxiliaries = Auxiliaries(self.rheology, grid, device)

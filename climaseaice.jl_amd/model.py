@@ -1,0 +1,242 @@
+"""SeaIceModel / set! / time_step! / update_state! -- host-side mirror of the reference API for the
+accelerated path.  All arithmetic happens in libcsi_hip.so through the C ABI (include/csi.h).
+
+SeaIceModel       sea_ice_model.jl:22-51,140-297 (fields allocated as :182-200, timestepper :235)
+set!              :301-315
+time_step!        sea_ice_fe_step.jl:13-34 (ForwardEuler) / upstream SplitRungeKutta3 loop around
+                  rk_substep!, sea_ice_rk_substep.jl:81-94
+update_state!     sea_ice_model.jl:379-394
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+from .dynamics import (ElastoViscoPlasticRheology, FPlane, IceStrength, SeaIceMomentumEquation, SemiImplicitStress)
+from .fields import CenterField, Field, XFaceField, YFaceField
+from .grids import Bounded, Periodic
+
+
+class WENO:
+    def __init__(self, order=5):
+        if order not in (5, 7):
+            raise NotImplementedError("WENO order 5 or 7")
+        self.order = order
+        self.scheme = order
+
+
+class UpwindBiased:
+    def __init__(self, order=5):
+        if order not in (1, 5):
+            raise NotImplementedError("UpwindBiased order 1 or 5")
+        self.order = order
+        self.scheme = 1 if order == 1 else -5
+
+
+_TOPO = {Periodic: _lib.PERIODIC, Bounded: _lib.BOUNDED}
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class SeaIceModel:
+    def __init__(self, grid, dynamics=None, advection=None, timestepper="SplitRungeKutta3", sea_ice_density=900.0,
+                 device="cuda:0", mode="fast", stream=None):
+        self.grid = grid
+        self.dynamics = dynamics
+        self.advection = advection
+        if timestepper not in ("SplitRungeKutta3", "ForwardEuler"):
+            raise ValueError("timestepper must be 'SplitRungeKutta3' or 'ForwardEuler'")
+        self.timestepper_kind = timestepper
+        self.sea_ice_density = float(sea_ice_density)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("SeaIceModel needs a HIP device (torch 'cuda' device); there is no CPU path")
+        dev = self.device
+        # prognostic fields (sea_ice_model.jl:182-183,199-200)
+        self.velocities = SimpleNamespace(u=XFaceField(grid, dev, "u"), v=YFaceField(grid, dev, "v"))
+        self.ice_thickness = CenterField(grid, dev, "h")
+        self.ice_concentration = CenterField(grid, dev, "aice")
+        # TimeStepper(timestepper, grid, prognostic_fields): G^n for both, Psi^- for RK (:235)
+        Gn = SimpleNamespace(h=CenterField(grid, dev, "Gh"), aice=CenterField(grid, dev, "Gaice"))
+        self.timestepper = SimpleNamespace(Gn=Gn, Psi_minus=None)
+        if timestepper == "SplitRungeKutta3":
+            self.timestepper.Psi_minus = SimpleNamespace(h=CenterField(grid, dev, "h-"), aice=CenterField(grid, dev, "aice-"),
+                                                         u=XFaceField(grid, dev, "u-"), v=YFaceField(grid, dev, "v-"))
+        self.clock = SimpleNamespace(time=0.0, iteration=0)
+        self._keep = []
+        self._stress_fields = {}
+        self.ctx = _lib.Context(dev.index or 0, stream)
+        self._configure()
+        self.set_mode(mode)
+        torch.cuda.synchronize(self.device)   # field initialisation ran on torch's stream
+
+    # ---- plumbing: describe the problem to the library -----------------------------------------
+    def _bind(self, name, fld):
+        self.ctx.call("csi_field_bind", _lib.F[name], C.c_void_p(fld.data.data_ptr()), fld.ni, fld.ni, fld.nj)
+
+    def _configure(self):
+        g = self.grid
+        m = g.metrics()
+        met = _lib.Metrics()
+        if m["kind"] == "uniform":
+            kind = _lib.METRIC_UNIFORM
+            met.dx, met.dy = m["dx"], m["dy"]
+        else:
+            kind = _lib.METRIC_PER_J
+            met.dy = m["dy"]
+            for k in ("dxc", "dxf", "azc", "azf"):
+                a = np.ascontiguousarray(m[k], dtype=np.float64)
+                self._keep.append(a)
+                setattr(met, k, _dptr(a))
+        self.ctx.call("csi_grid_set", g.Nx, g.Ny, g.Hx, g.Hy, _TOPO[g.topology[0]], _TOPO[g.topology[1]], kind, C.byref(met))
+        self._bind("H", self.ice_thickness)
+        self._bind("A", self.ice_concentration)
+        self._bind("U", self.velocities.u)
+        self._bind("V", self.velocities.v)
+        self._bind("GH", self.timestepper.Gn.h)
+        self._bind("GA", self.timestepper.Gn.aice)
+        if self.timestepper.Psi_minus is not None:
+            pm = self.timestepper.Psi_minus
+            self._bind("HM", pm.h); self._bind("AM", pm.aice); self._bind("UM", pm.u); self._bind("VM", pm.v)
+        d = self.dynamics
+        if d is None:
+            return
+        if d.grid is not g:
+            raise ValueError("dynamics was built on a different grid")
+        f = d.auxiliaries.fields
+        for fld in vars(f).values():
+            if fld.data.device != self.device:
+                fld.data = fld.data.to(self.device)
+        for name, fld in (("S11", f.s11), ("S22", f.s22), ("S12", f.s12), ("UN", f.un), ("VN", f.vn), ("P", f.P),
+                          ("ALPHA", f.alpha), ("DELTA", f.Delta), ("ZETA_F", f.zeta_f), ("ZETA_C", f.zeta_c)):
+            self._bind(name, fld)
+        r = d.rheology
+        p = _lib.EvpParams(r.ice_compressive_strength, r.ice_compaction_hardening, r.yield_curve_eccentricity,
+                           r.minimum_plastic_stress, r.min_relaxation_parameter, r.max_relaxation_parameter,
+                           r.relaxation_strength,
+                           _lib.PRESSURE_ICE_STRENGTH if isinstance(r.pressure_formulation, IceStrength) else _lib.PRESSURE_REPLACEMENT,
+                           0 if d.coriolis is None else 1, 0.0 if d.coriolis is None else float(d.coriolis.f),
+                           d.minimum_concentration, d.minimum_mass, self.sea_ice_density)
+        self.ctx.call("csi_evp_params_set", C.byref(p))
+        self._set_stress(_lib.STRESS_TOP, d.external_momentum_stresses.top, "TOP")
+        self._set_stress(_lib.STRESS_BOTTOM, d.external_momentum_stresses.bottom, "BOT")
+
+    def _stress_field(self, slot, comp, value):
+        """materialize_stress (sea_ice_external_stress.jl:63-69,132-137): a device copy on the model grid."""
+        mk = XFaceField if comp == "U" else YFaceField
+        if isinstance(value, Field):
+            fld = value
+            if fld.data.device != self.device:
+                fld.data = fld.data.to(self.device)
+        else:
+            fld = mk(self.grid, self.device, f"{slot}_{comp}".lower())
+            fld.set(value)
+        self._stress_fields[f"{slot}_{comp}"] = fld
+        self._bind(f"{slot}_{comp}", fld)
+        return fld
+
+    def _set_stress(self, side, stress, slot):
+        s = _lib.Stress()
+        if stress is None:
+            s.kind = _lib.STRESS_NONE
+        elif isinstance(stress, SemiImplicitStress):
+            s.kind = _lib.STRESS_SEMI_IMPLICIT
+            s.rho_e, s.Cd = stress.rho_e, stress.Cd
+            for comp, val in (("u", stress.ue), ("v", stress.ve)):
+                if val is None:
+                    setattr(s, comp + "e_kind", _lib.VEL_ZERO)
+                elif np.isscalar(val):
+                    setattr(s, comp + "e_kind", _lib.VEL_CONST)
+                    setattr(s, comp + "e", float(val))
+                else:
+                    setattr(s, comp + "e_kind", _lib.VEL_FIELD)
+                    self._stress_field(slot, comp.upper(), val)
+        else:
+            tu, tv = (stress["u"], stress["v"]) if isinstance(stress, dict) else (stress[0], stress[1])
+            if np.isscalar(tu) and np.isscalar(tv):
+                s.kind = _lib.STRESS_CONST
+                s.tau_u, s.tau_v = float(tu), float(tv)
+            else:
+                s.kind = _lib.STRESS_FIELD
+                self._stress_field(slot, "U", tu)
+                self._stress_field(slot, "V", tv)
+        self.ctx.call("csi_stress_set", side, C.byref(s))
+
+    def external_stress_field(self, slot, comp):
+        return self._stress_fields[f"{slot}_{comp}"]
+
+    def set_mode(self, mode):
+        self.mode = mode
+        self.ctx.call("csi_set_mode", _lib.MODE_FAST if mode == "fast" else _lib.MODE_STRICT)
+
+    def set_mask(self, active):
+        """ImmersedBoundaryGrid stand-in: `active` is a (Ny, Nx) boolean array of wet cells."""
+        g = self.grid
+        full = torch.zeros((g.Ny + 2 * g.Hy, g.Nx + 2 * g.Hx), dtype=torch.uint8)
+        full[g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx] = torch.from_numpy(np.ascontiguousarray(active).astype(np.uint8))
+        # halos of the mask follow the topology (periodic wrap; walls are inactive by definition)
+        a = full.numpy()
+        if g.topology[0] is Periodic:
+            a[:, :g.Hx] = a[:, g.Nx:g.Nx + g.Hx]
+            a[:, g.Nx + g.Hx:] = a[:, g.Hx:2 * g.Hx]
+        if g.topology[1] is Periodic:
+            a[:g.Hy, :] = a[g.Ny:g.Ny + g.Hy, :]
+            a[g.Ny + g.Hy:, :] = a[g.Hy:2 * g.Hy, :]
+        self.mask = full.to(self.device)
+        self.ctx.call("csi_mask_set", C.c_void_p(self.mask.data_ptr()), self.mask.shape[1])
+
+    # ---- convenience ----------------------------------------------------------------------------
+    @property
+    def substeps(self):
+        return self.dynamics.solver.substeps
+
+    @property
+    def scheme(self):
+        return 0 if self.advection is None else self.advection.scheme
+
+    def synchronize(self):
+        """Wait for the library's stream (call before reading fields with torch / numpy)."""
+        self.ctx.call("csi_sync")
+
+    def copy_to_field(self, fld, array):
+        """Overwrite a field's parent array from a host array of the same shape (ordered with the library)."""
+        self.synchronize()
+        fld.data.copy_(torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)))
+        torch.cuda.synchronize(self.device)
+
+
+def set_(model, **kw):
+    """set!(model; h, aice (or ℵ), u, v) then update_state! (sea_ice_model.jl:301-315)."""
+    names = {"h": model.ice_thickness, "aice": model.ice_concentration, "ℵ": model.ice_concentration,
+             "u": model.velocities.u, "v": model.velocities.v}
+    for k, val in kw.items():
+        if k not in names:
+            raise KeyError(f"set!: unknown field {k}")
+        names[k].set(val)
+    torch.cuda.synchronize(model.device)   # torch wrote on its stream; the library uses its own
+    update_state(model)
+
+
+def update_state(model):
+    model.ctx.call("csi_update_state")
+
+
+def time_step_momentum(model, dt, rk_reset=False):
+    """time_step_momentum!(model, model.dynamics, dt), split_explicit_momentum_equations.jl:103-195."""
+    model.ctx.call("csi_time_step_momentum", float(dt), model.substeps, int(rk_reset))
+
+
+def time_step(model, dt):
+    """time_step!(model, dt)."""
+    if model.dynamics is None:
+        raise NotImplementedError("time_step! without dynamics is not on the accelerated path")
+    if model.timestepper_kind == "ForwardEuler":
+        model.ctx.call("csi_time_step_fe", float(dt), model.substeps, model.scheme, int(model.clock.iteration == 0))
+    else:
+        model.ctx.call("csi_time_step_rk3", float(dt), model.substeps, model.scheme)
+    model.clock.time += float(dt)
+    model.clock.iteration += 1

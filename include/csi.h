@@ -1,0 +1,249 @@
+/*
+ * csi.h -- C ABI of the MI355X-native sea-ice hot path (libcsi_hip.so).
+ *
+ * Drop-in boundary for CliMA/ClimaSeaIce.jl's split-explicit EVP momentum sub-cycle,
+ * the h / aice advection and their launch loop.  The reference has no FFI of its own:
+ * its "operator API" is Julia multiple dispatch, so every entry point below names the
+ * Julia method it replaces (paths relative to /root/reference/src); INTEGRATION.md shows
+ * the `ccall` methods a maintainer adds on the Julia side.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, fp64 only, no C++ / torch types.
+ *  - Every function returns int32_t: CSI_OK (0) or a negative csi_status; the text of the
+ *    last failure is available from csi_last_error().  No exception crosses the boundary.
+ *  - Ownership: the caller (Julia / AMDGPU.jl ROCArray parents; torch tensors in this repo's
+ *    harness) owns all field memory; the library never frees or reallocates it.  Scratch
+ *    lives in the context.
+ *  - Field layout = Oceananigans parent array: column-major, i fastest, element (i, j)
+ *    (1-based) at ptr[(i + Hx - 1) + (j + Hy - 1) * ld], ld = Nx + 2Hx (+1 when the field
+ *    is Face-located in a Bounded x direction).
+ *  - One context per GPU; calls on one context are serialised by the caller.  All work is
+ *    ordered on the context's HIP stream (an external hipStream_t may be supplied); the only
+ *    host synchronisation is csi_sync().
+ *  - There is NO CPU fallback: every compute entry point needs a HIP device.
+ */
+#ifndef CSI_H
+#define CSI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSI_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    CSI_OK = 0,
+    CSI_ERR_INVALID_ARGUMENT = -1,
+    CSI_ERR_NOT_BOUND = -2,     /* a field / grid / parameter needed by the call was never set */
+    CSI_ERR_HIP = -3,           /* a HIP runtime call failed; see csi_last_error */
+    CSI_ERR_UNSUPPORTED = -4,   /* valid in the reference, not (yet) in this library */
+    CSI_ERR_NO_DEVICE = -5,
+    CSI_ERR_COMM = -6           /* RCCL failure */
+} csi_status;
+
+/* Topology of one horizontal direction (Oceananigans.Grids topologies).  The *_CONNECTED
+ * values mark tile edges whose halos are filled by csi_halo_exchange (multi-GPU) rather than
+ * by a local boundary condition (split_explicit_momentum_equations.jl:13-16). */
+typedef enum {
+    CSI_PERIODIC = 0,
+    CSI_BOUNDED = 1,
+    CSI_FULLY_CONNECTED = 2,
+    CSI_LEFT_CONNECTED = 3,   /* low side exchanged, high side Bounded */
+    CSI_RIGHT_CONNECTED = 4   /* low side Bounded, high side exchanged */
+} csi_topology;
+
+typedef enum {
+    CSI_METRIC_UNIFORM = 0,   /* RectilinearGrid, regular spacing */
+    CSI_METRIC_PER_J = 1      /* LatitudeLongitudeGrid, regular: metrics vary with j only */
+} csi_metric_kind;
+
+/* Host-side description of the grid metrics (copied by csi_grid_set).  PER_J vectors have
+ * length Ny + 2Hy + 1; the entry for row j (1-based) sits at [j + Hy - 1]:
+ *   dxc = dx at Center rows (dx^cc = dx^fc)   dxf = dx at Face rows (dx^cf = dx^ff)
+ *   azc = Az at Center rows (Az^cc = Az^fc)   azf = Az at Face rows (Az^cf = Az^ff)
+ * dy is constant for both kinds. */
+typedef struct {
+    double dx, dy;
+    const double *dxc, *dxf, *azc, *azf;
+} csi_metrics;
+
+/* Field slots (csi_field_bind).  Locations: (x, y) with c = Center, f = Face. */
+typedef enum {
+    CSI_F_U = 0,      /* (f,c) model.velocities.u */
+    CSI_F_V,          /* (c,f) model.velocities.v */
+    CSI_F_H,          /* (c,c) model.ice_thickness */
+    CSI_F_A,          /* (c,c) model.ice_concentration */
+    CSI_F_S11,        /* (c,c) auxiliaries.fields.sigma11  (elasto_visco_plastic_rheology.jl:147) */
+    CSI_F_S22,        /* (c,c) :148 */
+    CSI_F_S12,        /* (f,f) :149 */
+    CSI_F_UN,         /* (f,c) :150 */
+    CSI_F_VN,         /* (c,f) :151 */
+    CSI_F_P,          /* (c,c) :152 */
+    CSI_F_ALPHA,      /* (c,c) :153 */
+    CSI_F_DELTA,      /* (c,c) :154 */
+    CSI_F_ZETA_F,     /* (f,f) :157 */
+    CSI_F_ZETA_C,     /* (c,c) :158 */
+    CSI_F_GH,         /* (c,c) timestepper.G^n.h */
+    CSI_F_GA,         /* (c,c) timestepper.G^n.aice */
+    CSI_F_HM,         /* (c,c) timestepper.Psi^-.h   (sea_ice_rk_substep.jl:29-42) */
+    CSI_F_AM,         /* (c,c) timestepper.Psi^-.aice */
+    CSI_F_UM,         /* (f,c) timestepper.Psi^-.u */
+    CSI_F_VM,         /* (c,f) timestepper.Psi^-.v */
+    CSI_F_TOP_U,      /* (f,c) top stress array or top external velocity u_e */
+    CSI_F_TOP_V,      /* (c,f) */
+    CSI_F_BOT_U,      /* (f,c) bottom stress array or bottom external velocity u_e */
+    CSI_F_BOT_V,      /* (c,f) */
+    CSI_F_MASS_FLUX,  /* (c,c) mass_fluxes.thermodynamics.ice */
+    CSI_F_COUNT
+} csi_field_id;
+
+typedef enum { CSI_PRESSURE_REPLACEMENT = 0, CSI_PRESSURE_ICE_STRENGTH = 1 } csi_pressure_kind;
+
+/* ElastoViscoPlasticRheology (elasto_visco_plastic_rheology.jl:14-25, defaults :119-127) +
+ * SeaIceMomentumEquation scalars (sea_ice_momentum_equations.jl:67-94) + FPlane coriolis +
+ * sea_ice_density (sea_ice_model.jl:142-145). */
+typedef struct {
+    double ice_compressive_strength;   /* P*      27500 */
+    double ice_compaction_hardening;   /* C       20 */
+    double yield_curve_eccentricity;   /* e       2 */
+    double minimum_plastic_stress;     /* Dmin    2e-9 */
+    double min_relaxation_parameter;   /* alpha-  50 */
+    double max_relaxation_parameter;   /* alpha+  300 */
+    double relaxation_strength;        /* c_alpha pi^2 */
+    int32_t pressure_formulation;      /* csi_pressure_kind */
+    int32_t has_coriolis;              /* 0: coriolis = nothing, 1: FPlane(f) */
+    double coriolis_f;
+    double minimum_concentration;      /* 1e-3 */
+    double minimum_mass;               /* 1.0 */
+    double sea_ice_density;            /* 900 */
+} csi_evp_params;
+
+typedef enum {
+    CSI_STRESS_NONE = 0,           /* nothing */
+    CSI_STRESS_CONST = 1,          /* Number / NamedTuple of Numbers (sea_ice_external_stress.jl:16-17,29-37) */
+    CSI_STRESS_FIELD = 2,          /* arrays bound to CSI_F_{TOP,BOT}_{U,V} (:19-20) */
+    CSI_STRESS_SEMI_IMPLICIT = 3   /* SemiImplicitStress (:84-130,176-202) */
+} csi_stress_kind;
+typedef enum { CSI_VEL_ZERO = 0, CSI_VEL_CONST = 1, CSI_VEL_FIELD = 2 } csi_velocity_kind;
+typedef enum { CSI_STRESS_TOP = 0, CSI_STRESS_BOTTOM = 1 } csi_stress_side;
+
+typedef struct {
+    int32_t kind;                  /* csi_stress_kind */
+    int32_t ue_kind, ve_kind;      /* csi_velocity_kind: ZeroField / ConstantField / Field (bound slots) */
+    int32_t reserved;
+    double tau_u, tau_v;           /* CONST */
+    double ue, ve;                 /* SEMI_IMPLICIT with ConstantField external velocity */
+    double rho_e, Cd;              /* SEMI_IMPLICIT: 1026, 5.5e-3 */
+} csi_stress;
+
+/* Arithmetic mode of the kernels.
+ * STRICT: the reference's operation order, no FMA contraction, IEEE division -- bit-for-bit
+ *         equal to the CPU oracle (used to anchor parity).
+ * FAST:   hoisted reciprocals / FMA contraction, shared strain rates; differs from STRICT
+ *         by rounding only (tolerance stated in DESIGN.md and enforced in tests/). */
+typedef enum { CSI_MODE_STRICT = 0, CSI_MODE_FAST = 1 } csi_mode;
+
+typedef enum { CSI_ADVECT_NONE = 0, CSI_ADVECT_UPWIND1 = 1, CSI_ADVECT_WENO5 = 5, CSI_ADVECT_WENO7 = 7,
+               CSI_ADVECT_UPWIND5 = -5 } csi_advection_scheme;
+
+typedef struct csi_context csi_context;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int32_t csi_version(void);
+/* stream: a hipStream_t owned by the caller, or NULL for a library-owned stream. */
+int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** out);
+int32_t csi_context_destroy(csi_context* ctx);
+/* Text of the most recent failure on ctx (or of context creation when ctx == NULL). */
+const char* csi_last_error(const csi_context* ctx);
+int32_t csi_sync(csi_context* ctx);
+int32_t csi_set_mode(csi_context* ctx, int32_t mode);
+
+/* ---- problem description ----------------------------------------------------------------- */
+/* Replaces the grid argument every reference kernel receives (Nx, Ny, halo, topology, metrics). */
+int32_t csi_grid_set(csi_context* ctx, int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy,
+                     int32_t topo_x, int32_t topo_y, int32_t metric_kind, const csi_metrics* metrics);
+/* Cell-centred activity mask of an ImmersedBoundaryGrid (1 = active), device pointer laid out
+ * like a (c,c) parent with leading dimension ld; NULL removes it.
+ * (peripheral_node, split_explicit_momentum_equations.jl:226,261; conditional_flux_*,
+ * ice_stress_divergence.jl:21-24; mask_immersed_field_xy!, sea_ice_model.jl:381-389) */
+int32_t csi_mask_set(csi_context* ctx, const uint8_t* dev_mask, int64_t ld);
+/* Bind the parent array of one field: device pointer, leading dimension and parent extents
+ * (validated against the grid: ni = Nx + 2Hx [+1], nj = Ny + 2Hy [+1]). */
+int32_t csi_field_bind(csi_context* ctx, int32_t field_id, void* dev_ptr, int64_t ld, int32_t ni, int32_t nj);
+int32_t csi_evp_params_set(csi_context* ctx, const csi_evp_params* p);
+int32_t csi_stress_set(csi_context* ctx, int32_t side, const csi_stress* s);
+
+/* ---- the reference's verbs ----------------------------------------------------------------- */
+/* initialize_rheology!(model, ::ElastoViscoPlasticRheology), elasto_visco_plastic_rheology.jl:192-219 */
+int32_t csi_evp_initialize(csi_context* ctx);
+/* The sub-step loop of time_step_momentum!, split_explicit_momentum_equations.jl:170-189:
+ * local halo fill of u, v, then `substeps` x [compute_stresses! ; alternating u/v steps with halo
+ * fills].  dt is the stage step.  first_substep is the 1-based index of the first sub-step
+ * (parity selects the u/v order, :178). */
+int32_t csi_evp_subcycle(csi_context* ctx, double dt, int32_t substeps, int32_t first_substep);
+/* finalize_rheology!, elasto_visco_plastic_rheology.jl:275-280 (local halo fill of sigma) */
+int32_t csi_evp_finalize(csi_context* ctx);
+/* time_step_momentum!(model, ::SplitExplicitMomentumEquation, dt), split_explicit_momentum_equations.jl:103-195.
+ * rk_reset != 0: reset_velocities! from Psi^- (:89-93). */
+int32_t csi_time_step_momentum(csi_context* ctx, double dt, int32_t substeps, int32_t rk_reset);
+/* compute_tracer_tendencies!(model), tracer_tendency_kernel_functions.jl:9-45 */
+int32_t csi_compute_tracer_tendencies(csi_context* ctx, int32_t scheme);
+/* dynamic_time_step!(model, dt): sea_ice_fe_step.jl:36-82 (from_cache = 0), sea_ice_rk_substep.jl:134-152 (1) */
+int32_t csi_dynamic_step_tracers(csi_context* ctx, double dt, int32_t from_cache);
+/* cache_current_fields!(model), sea_ice_rk_substep.jl:29-42 */
+int32_t csi_cache_current_fields(csi_context* ctx);
+/* update_state!(model), sea_ice_model.jl:379-394: immersed masking + local halo fill of h, aice, u, v */
+int32_t csi_update_state(csi_context* ctx);
+/* fill_halo_regions!(field; only_local_halos = true) for one bound field */
+int32_t csi_fill_halo_local(csi_context* ctx, int32_t field_id);
+/* Whole model steps without thermodynamics: FE (sea_ice_fe_step.jl:13-34) and the
+ * SplitRungeKutta3 stage loop around rk_substep! (sea_ice_rk_substep.jl:81-94). */
+int32_t csi_time_step_fe(csi_context* ctx, double dt, int32_t substeps, int32_t scheme, int32_t first_iteration);
+int32_t csi_time_step_rk3(csi_context* ctx, double dt, int32_t substeps, int32_t scheme);
+
+/* Bare-ice slab thermodynamics with PrescribedTemperature top boundary condition
+ * (thermodynamic_time_step.jl:75-118,304-370; slab_thermodynamics_tendencies.jl:28-135). */
+typedef struct {
+    double conductivity;             /* ConductiveFlux, 2 */
+    double sea_ice_density;          /* bulk, 900 */
+    double density;                  /* PhaseTransitions.density (pure ice), 917 */
+    double liquid_density;           /* 999.8 */
+    double liquid_heat_capacity;     /* 4186 */
+    double heat_capacity;            /* 2000 */
+    double reference_latent_heat;    /* 334e3 */
+    double reference_temperature;    /* 0 */
+    double liquidus_slope;           /* 0.054 */
+    double freshwater_melting_temperature; /* 0 */
+    double bottom_salinity;          /* IceWaterThermalEquilibrium salinity, 0 */
+    double ice_consolidation_thickness;    /* 0.05 */
+    double top_temperature;          /* PrescribedTemperature */
+    int32_t top_flux_kind;           /* 0: constant Qu ; 1: internal-flux equilibrium (sea_ice_model.jl:248-256) */
+    int32_t bottom_flux_kind;        /* 0: constant Qb ; 1: -(1 - aice) * Qb (examples/freezing_bucket.jl:79-81) */
+    double top_heat_flux, bottom_heat_flux;
+} csi_slab_params;
+int32_t csi_slab_thermo_step(csi_context* ctx, const csi_slab_params* p, double dt);
+
+/* ---- multi-GPU tiles (one process per GPU; RCCL point-to-point over xGMI) ----------------- */
+/* Position of this context's tile in an Rx x Ry decomposition of a global grid; the
+ * *_CONNECTED topologies passed to csi_grid_set must agree with it. */
+int32_t csi_tile_set(csi_context* ctx, int32_t rank_x, int32_t rank_y, int32_t Rx, int32_t Ry,
+                     int32_t periodic_x, int32_t periodic_y);
+/* 128-byte RCCL unique id produced on rank 0 (csi_comm_unique_id) and broadcast by the host. */
+int32_t csi_comm_unique_id(uint8_t* id128);
+int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const uint8_t* id128);
+/* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
+int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
+
+/* ---- introspection used by bench.py / tests ------------------------------------------------ */
+/* Device time (ms) of the last csi_evp_subcycle / csi_time_step_momentum call measured with HIP
+ * events on the context's stream; valid after csi_sync. */
+int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
+/* Number of kernel launches issued for one sub-step in the current configuration. */
+int32_t csi_launches_per_substep(csi_context* ctx, int32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSI_H */

@@ -1,0 +1,730 @@
+/*
+ * csi_oracle.c -- CPU ORACLE (test infrastructure only; see csi_oracle.h header).
+ *
+ * Strict-order plain-C restatement of the ClimaSeaIce.jl hot path:
+ * EVP sub-cycle, WENO advection of h / aice, tracer update, FE / RK3 stage loop.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ * "parity unpinned": see csi_oracle.h.
+ *
+ * Each function cites the reference file:line (relative to /root/reference/src)
+ * whose arithmetic it restates; the floating-point operation order inside every
+ * expression is the reference's (Julia: left-assoc n-ary + and *, x^2 == x*x,
+ * x^(-2) == inv(x)*inv(x), a / 2b == a / (2*b)).
+ */
+#include "csi_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORA_OMP
+#define OMP_ROWS _Pragma("omp parallel for schedule(static)")
+#else
+#define OMP_ROWS
+#endif
+
+#define C_ ORA_LOC_CENTER
+#define F_ ORA_LOC_FACE
+
+/* element (i, j), 1-based reference indices */
+#define AT(g, f, i, j) ((f).p[((int64_t)(i) + (g)->Hx - 1) + ((int64_t)(j) + (g)->Hy - 1) * (f).ld])
+
+/* ------------------------------------------------------------------------ */
+/* Grid metrics (Oceananigans.Operators)                  */
+/* Rectilinear regular: constants, Az = dx*dy.  Lat-lon regular: per-j rows */
+/* ------------------------------------------------------------------------ */
+double ora_dx(const ora_problem* g, int lx, int ly, int i, int j) {
+    (void)lx; (void)i;
+    if (g->metric_kind == ORA_METRIC_UNIFORM) return g->dx;
+    return (ly == C_) ? g->dxc[j + g->Hy - 1] : g->dxf[j + g->Hy - 1];
+}
+double ora_dy(const ora_problem* g, int lx, int ly, int i, int j) {
+    (void)lx; (void)ly; (void)i; (void)j;
+    return g->dy;
+}
+double ora_az(const ora_problem* g, int lx, int ly, int i, int j) {
+    (void)lx; (void)i;
+    if (g->metric_kind == ORA_METRIC_UNIFORM) return g->dx * g->dy;
+    return (ly == C_) ? g->azc[j + g->Hy - 1] : g->azf[j + g->Hy - 1];
+}
+
+/* inactive_cell: outside a Bounded domain or immersed (upstream Grids.inactive_cell) */
+static int inactive_cell(const ora_problem* g, int i, int j) {
+    if (g->topo_x == ORA_BOUNDED && (i < 1 || i > g->Nx)) return 1;
+    if (g->topo_y == ORA_BOUNDED && (j < 1 || j > g->Ny)) return 1;
+    if (g->has_mask) {
+        /* clamp into the stored array; halos of the mask are filled by the caller */
+        if (i < 1 - g->Hx || i > g->Nx + g->Hx || j < 1 - g->Hy || j > g->Ny + g->Hy) return 1;
+        return !g->mask[((int64_t)i + g->Hx - 1) + ((int64_t)j + g->Hy - 1) * g->mask_ld];
+    }
+    return 0;
+}
+/* the same for the underlying (non-immersed) grid */
+static int inactive_cell_underlying(const ora_problem* g, int i, int j) {
+    if (g->topo_x == ORA_BOUNDED && (i < 1 || i > g->Nx)) return 1;
+    if (g->topo_y == ORA_BOUNDED && (j < 1 || j > g->Ny)) return 1;
+    return 0;
+}
+/* peripheral_node(i,j,k,grid,Face,Center,Center), split_explicit_momentum_equations.jl:226 */
+int32_t ora_peripheral_u(const ora_problem* g, int i, int j) {
+    return inactive_cell(g, i, j) | inactive_cell(g, i - 1, j);
+}
+/* peripheral_node(i,j,k,grid,Center,Face,Center), split_explicit_momentum_equations.jl:261 */
+int32_t ora_peripheral_v(const ora_problem* g, int i, int j) {
+    return inactive_cell(g, i, j) | inactive_cell(g, i, j - 1);
+}
+/* immersed_peripheral_node at (c,c) and (f,f): peripheral on the immersed grid but not on
+ * the underlying grid (upstream ImmersedBoundaries); used by conditional_flux_ccc/ffc,
+ * ice_stress_divergence.jl:21-24 */
+static int immersed_peripheral_cc(const ora_problem* g, int i, int j) {
+    if (!g->has_mask) return 0;
+    return inactive_cell(g, i, j) && !inactive_cell_underlying(g, i, j);
+}
+static int immersed_peripheral_ff(const ora_problem* g, int i, int j) {
+    if (!g->has_mask) return 0;
+    int p = inactive_cell(g, i, j) | inactive_cell(g, i - 1, j) | inactive_cell(g, i, j - 1) | inactive_cell(g, i - 1, j - 1);
+    int pu = inactive_cell_underlying(g, i, j) | inactive_cell_underlying(g, i - 1, j) |
+             inactive_cell_underlying(g, i, j - 1) | inactive_cell_underlying(g, i - 1, j - 1);
+    return p && !pu;
+}
+
+/* ice_mass, ClimaSeaIce.jl:42 : h * rho * aice (left to right) */
+static inline double ice_mass(const ora_problem* g, int i, int j) {
+    return AT(g, g->h, i, j) * g->rho_ice * AT(g, g->aice, i, j);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Strain rates, elasto_visco_plastic_rheology.jl:360-375                    */
+/* ------------------------------------------------------------------------ */
+static double eps_D(const ora_problem* g, int i, int j) {   /* :365 */
+    double a = ora_dy(g, F_, C_, i + 1, j) * AT(g, g->u, i + 1, j) - ora_dy(g, F_, C_, i, j) * AT(g, g->u, i, j);
+    double b = ora_dx(g, C_, F_, i, j + 1) * AT(g, g->v, i, j + 1) - ora_dx(g, C_, F_, i, j) * AT(g, g->v, i, j);
+    return (a + b) / ora_az(g, C_, C_, i, j);
+}
+static double eps_T(const ora_problem* g, int i, int j) {   /* :367-368 */
+    double dycc = ora_dy(g, C_, C_, i, j), dxcc = ora_dx(g, C_, C_, i, j);
+    double a = AT(g, g->u, i + 1, j) / ora_dy(g, F_, C_, i + 1, j) - AT(g, g->u, i, j) / ora_dy(g, F_, C_, i, j);
+    double b = AT(g, g->v, i, j + 1) / ora_dx(g, C_, F_, i, j + 1) - AT(g, g->v, i, j) / ora_dx(g, C_, F_, i, j);
+    return ((dycc * dycc) * a - (dxcc * dxcc) * b) / ora_az(g, C_, C_, i, j);
+}
+static double eps_S(const ora_problem* g, int i, int j) {   /* :370-371, at corner (i,j) */
+    double dxff = ora_dx(g, F_, F_, i, j), dyff = ora_dy(g, F_, F_, i, j);
+    double a = AT(g, g->u, i, j) / ora_dx(g, F_, C_, i, j) - AT(g, g->u, i, j - 1) / ora_dx(g, F_, C_, i, j - 1);
+    double b = AT(g, g->v, i, j) / ora_dy(g, C_, F_, i, j) - AT(g, g->v, i - 1, j) / ora_dy(g, C_, F_, i - 1, j);
+    return ((dxff * dxff) * a + (dyff * dyff) * b) / ora_az(g, F_, F_, i, j);
+}
+double ora_strain_xx(const ora_problem* g, int i, int j) { return (eps_D(g, i, j) + eps_T(g, i, j)) / 2; }
+double ora_strain_yy(const ora_problem* g, int i, int j) { return (eps_D(g, i, j) - eps_T(g, i, j)) / 2; }
+double ora_strain_xy(const ora_problem* g, int i, int j) { return eps_S(g, i, j) / 2; }
+
+/* 4-point averages  Ixy = Iy(Ix(f))  (upstream) */
+#define AVG4_FF(fn, g, i, j) ((((fn)(g, (i) - 1, (j) - 1) + (fn)(g, (i), (j) - 1)) / 2 + ((fn)(g, (i) - 1, (j)) + (fn)(g, (i), (j))) / 2) / 2)
+#define AVG4_CC(fn, g, i, j) ((((fn)(g, (i), (j)) + (fn)(g, (i) + 1, (j))) / 2 + ((fn)(g, (i), (j) + 1) + (fn)(g, (i) + 1, (j) + 1)) / 2) / 2)
+
+static inline double P_at(const ora_problem* g, int i, int j) { return AT(g, g->P, i, j); }
+
+/* ------------------------------------------------------------------------ */
+/* initialize_rheology! / _initialize_evp_rhology!, evp:192-219               */
+/* launched over the whole parent array of P (evp:166-167)                    */
+/* ------------------------------------------------------------------------ */
+void ora_initialize_rheology(ora_problem* g) {
+    OMP_ROWS
+    for (int j = 1 - g->Hy; j <= g->Ny + g->Hy; ++j)
+        for (int i = 1 - g->Hx; i <= g->Nx + g->Hx; ++i) {
+            /* ice_strength :219 : P* * h * exp(-C * (1 - aice)) */
+            AT(g, g->P, i, j) = g->P_star * AT(g, g->h, i, j) * exp(-g->C_star * (1 - AT(g, g->aice, i, j)));
+            AT(g, g->un, i, j) = AT(g, g->u, i, j);
+            AT(g, g->vn, i, j) = AT(g, g->v, i, j);
+        }
+}
+
+/* ------------------------------------------------------------------------ */
+/* _compute_evp_viscosities!, evp:236-273                                     */
+/* ------------------------------------------------------------------------ */
+void ora_compute_viscosities(ora_problem* g, int i0, int i1, int j0, int j1) {
+    double ie = 1.0 / g->ecc;
+    double em2 = ie * ie;                 /* e^(-2) == inv(e)^2 (literal_pow) */
+    double Dm = g->delta_min;
+    OMP_ROWS
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            double e11c = ora_strain_xx(g, i, j);
+            double e22c = ora_strain_yy(g, i, j);
+            double e12f = ora_strain_xy(g, i, j);
+            double e11f = AVG4_FF(ora_strain_xx, g, i, j);
+            double e22f = AVG4_FF(ora_strain_yy, g, i, j);
+            double e12c = AVG4_CC(ora_strain_xy, g, i, j);
+
+            double dc = e11c + e22c;
+            double df = e11f + e22f;
+            double sc = sqrt((e11c - e22c) * (e11c - e22c) + 4 * (e12c * e12c));
+            double sf = sqrt((e11f - e22f) * (e11f - e22f) + 4 * (e12f * e12f));
+            double Dc = fmax(sqrt(dc * dc + (sc * sc) * em2), Dm);
+            double Df = fmax(sqrt(df * df + (sf * sf) * em2), Dm);
+            double Pc = AT(g, g->P, i, j);
+            double Pf = AVG4_FF(P_at, g, i, j);
+
+            AT(g, g->zeta_f, i, j) = Pf / (2 * Df);
+            AT(g, g->zeta_c, i, j) = Pc / (2 * Dc);
+            AT(g, g->Delta, i, j) = Dc;
+        }
+}
+
+static inline double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+
+/* ------------------------------------------------------------------------ */
+/* _compute_evp_stresses!, evp:294-354 (+ ice_pressure :282-289)              */
+/* ------------------------------------------------------------------------ */
+void ora_compute_stresses(ora_problem* g, double dt, int i0, int i1, int j0, int j1) {
+    double ie = 1.0 / g->ecc;
+    double em2 = ie * ie;
+    double ap = g->alpha_max, am = g->alpha_min, ca = g->c_alpha;
+    OMP_ROWS
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            double e11 = ora_strain_xx(g, i, j);
+            double e22 = ora_strain_yy(g, i, j);
+            double e12 = ora_strain_xy(g, i, j);
+            double zc = AT(g, g->zeta_c, i, j);
+            double zf = AT(g, g->zeta_f, i, j);
+
+            double Pr;
+            if (g->pressure_kind == ORA_PRESSURE_REPLACEMENT) {
+                double Pc = AT(g, g->P, i, j), Dc = AT(g, g->Delta, i, j);
+                Pr = Pc * Dc / (Dc + g->delta_min);
+            } else {
+                Pr = AT(g, g->P, i, j);
+            }
+            double etac = zc * em2;
+            double etaf = zf * em2;
+
+            double s11n = 2 * etac * e11 + ((zc - etac) * (e11 + e22) - Pr / 2);
+            double s22n = 2 * etac * e22 + ((zc - etac) * (e11 + e22) - Pr / 2);
+            double s12n = 2 * etaf * e12;
+
+            double mc = ice_mass(g, i, j);
+            double mf = AVG4_FF(ice_mass, g, i, j);
+
+            double g2c = zc * ca * dt / mc / ora_az(g, C_, C_, i, j);
+            g2c = isnan(g2c) ? ap * ap : g2c;
+            double gc = clampd(sqrt(g2c), am, ap);
+
+            double g2f = zf * ca * dt / mf / ora_az(g, F_, F_, i, j);
+            g2f = isnan(g2f) ? ap * ap : g2f;
+            double gf = clampd(sqrt(g2f), am, ap);
+
+            double s11s = (s11n - AT(g, g->s11, i, j)) / gc;
+            double s22s = (s22n - AT(g, g->s22, i, j)) / gc;
+            double s12s = (s12n - AT(g, g->s12, i, j)) / gf;
+
+            AT(g, g->s11, i, j) += (mc > 0) ? s11s : 0.0;
+            AT(g, g->s22, i, j) += (mc > 0) ? s22s : 0.0;
+            AT(g, g->s12, i, j) += (mf > 0) ? s12s : 0.0;
+            AT(g, g->alpha, i, j) = gc;
+        }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Stress divergence, ice_stress_divergence.jl:16-51                          */
+/* ------------------------------------------------------------------------ */
+static inline double sig11(const ora_problem* g, int i, int j) {     /* _ice_stress_ux :16,21 */
+    return immersed_peripheral_cc(g, i, j) ? 0.0 : AT(g, g->s11, i, j);
+}
+static inline double sig22(const ora_problem* g, int i, int j) {     /* _ice_stress_vy :19,24 */
+    return immersed_peripheral_cc(g, i, j) ? 0.0 : AT(g, g->s22, i, j);
+}
+static inline double sig12(const ora_problem* g, int i, int j) {     /* _ice_stress_uy/vx :17-18,22-23 */
+    return immersed_peripheral_ff(g, i, j) ? 0.0 : AT(g, g->s12, i, j);
+}
+static inline double sigD(const ora_problem* g, int i, int j) { return sig11(g, i, j) + sig22(g, i, j); }  /* :36 */
+static inline double sigT(const ora_problem* g, int i, int j) { return sig11(g, i, j) - sig22(g, i, j); }  /* :37 */
+
+double ora_div_sigma_1(const ora_problem* g, int i, int j) {          /* :39-44 */
+    double dyfc = ora_dy(g, F_, C_, i, j);
+    double d = dyfc * (sigD(g, i, j) - sigD(g, i - 1, j)) / 2;
+    double dyc = ora_dy(g, C_, C_, i, j), dycm = ora_dy(g, C_, C_, i - 1, j);
+    double T = ((dyc * dyc) * sigT(g, i, j) - (dycm * dycm) * sigT(g, i - 1, j)) / dyfc / 2;
+    double dxfn = ora_dx(g, F_, F_, i, j + 1), dxf = ora_dx(g, F_, F_, i, j);
+    double S = ((dxfn * dxfn) * sig12(g, i, j + 1) - (dxf * dxf) * sig12(g, i, j)) / ora_dx(g, F_, C_, i, j);
+    return (d + T + S) / ora_az(g, F_, C_, i, j);
+}
+double ora_div_sigma_2(const ora_problem* g, int i, int j) {          /* :46-51 */
+    double dxcf = ora_dx(g, C_, F_, i, j);
+    double d = dxcf * (sigD(g, i, j) - sigD(g, i, j - 1)) / 2;
+    double dxc = ora_dx(g, C_, C_, i, j), dxcm = ora_dx(g, C_, C_, i, j - 1);
+    double T = -((dxc * dxc) * sigT(g, i, j) - (dxcm * dxcm) * sigT(g, i, j - 1)) / dxcf / 2;
+    double dyfn = ora_dy(g, F_, F_, i + 1, j), dyf = ora_dy(g, F_, F_, i, j);
+    double S = ((dyfn * dyfn) * sig12(g, i + 1, j) - (dyf * dyf) * sig12(g, i, j)) / ora_dy(g, C_, F_, i, j);
+    return (d + T + S) / ora_az(g, C_, F_, i, j);
+}
+/* flux-form operator the reference's test keeps for contrast, test/test_rheology_energy_budget.jl:22-32 */
+double ora_old_div_sigma_1(const ora_problem* g, int i, int j) {
+    double a = ora_dy(g, C_, C_, i, j) * AT(g, g->s11, i, j) - ora_dy(g, C_, C_, i - 1, j) * AT(g, g->s11, i - 1, j);
+    double b = ora_dx(g, F_, F_, i, j + 1) * AT(g, g->s12, i, j + 1) - ora_dx(g, F_, F_, i, j) * AT(g, g->s12, i, j);
+    return (a + b) / ora_az(g, F_, C_, i, j);
+}
+double ora_old_div_sigma_2(const ora_problem* g, int i, int j) {
+    double a = ora_dy(g, F_, F_, i + 1, j) * AT(g, g->s12, i + 1, j) - ora_dy(g, F_, F_, i, j) * AT(g, g->s12, i, j);
+    double b = ora_dx(g, C_, C_, i, j) * AT(g, g->s22, i, j) - ora_dx(g, C_, C_, i, j - 1) * AT(g, g->s22, i, j - 1);
+    return (a + b) / ora_az(g, C_, F_, i, j);
+}
+
+/* ------------------------------------------------------------------------ */
+/* External stresses, sea_ice_external_stress.jl:8-27,176-202                 */
+/* ------------------------------------------------------------------------ */
+static inline double fld(const ora_problem* g, ora_field f, int i, int j) { return AT(g, f, i, j); }
+static inline double ext_ue(const ora_problem* g, const ora_stress* s, int i, int j) {
+    return s->ue_kind == ORA_VEL_FIELD ? fld(g, s->fu, i, j) : (s->ue_kind == ORA_VEL_CONST ? s->ue : 0.0);
+}
+static inline double ext_ve(const ora_problem* g, const ora_stress* s, int i, int j) {
+    return s->ve_kind == ORA_VEL_FIELD ? fld(g, s->fv, i, j) : (s->ve_kind == ORA_VEL_CONST ? s->ve : 0.0);
+}
+/* Ixy^{fc}(q)(i,j): y-average over (j, j+1) of x-averages over (i-1, i) */
+#define AVG4_FC(expr_ij) ((( expr_ij(i - 1, j) + expr_ij(i, j)) / 2 + (expr_ij(i - 1, j + 1) + expr_ij(i, j + 1)) / 2) / 2)
+/* Ixy^{cf}(q)(i,j): y-average over (j-1, j) of x-averages over (i, i+1) */
+#define AVG4_CF(expr_ij) ((( expr_ij(i, j - 1) + expr_ij(i + 1, j - 1)) / 2 + (expr_ij(i, j) + expr_ij(i + 1, j)) / 2) / 2)
+
+/* drag speed sqrt(du^2 + dv^2) at the u point (sea_ice_external_stress.jl:176-181,192-196) */
+static double drag_norm_u(const ora_problem* g, const ora_stress* s, int i, int j) {
+    double du = ext_ue(g, s, i, j) - AT(g, g->u, i, j);
+#define VE_(ii, jj) ext_ve(g, s, ii, jj)
+#define V_(ii, jj) AT(g, g->v, ii, jj)
+    double dv = AVG4_FC(VE_) - AVG4_FC(V_);
+#undef VE_
+#undef V_
+    return sqrt(du * du + dv * dv);
+}
+static double drag_norm_v(const ora_problem* g, const ora_stress* s, int i, int j) {   /* :183-188,198-202 */
+    double dv = ext_ve(g, s, i, j) - AT(g, g->v, i, j);
+#define UE_(ii, jj) ext_ue(g, s, ii, jj)
+#define U_(ii, jj) AT(g, g->u, ii, jj)
+    double du = AVG4_CF(UE_) - AVG4_CF(U_);
+#undef UE_
+#undef U_
+    return sqrt(du * du + dv * dv);
+}
+static double explicit_tau_x(const ora_problem* g, const ora_stress* s, int i, int j) {
+    switch (s->kind) {
+    case ORA_STRESS_CONST: return s->tau_u;                       /* :16 */
+    case ORA_STRESS_FIELD: return AT(g, s->fu, i, j);             /* :19 */
+    case ORA_STRESS_SEMI_IMPLICIT:                                /* :176-181 */
+        return s->rho_e * s->Cd * drag_norm_u(g, s, i, j) * ext_ue(g, s, i, j);
+    default: return 0.0;                                          /* :13 */
+    }
+}
+static double explicit_tau_y(const ora_problem* g, const ora_stress* s, int i, int j) {
+    switch (s->kind) {
+    case ORA_STRESS_CONST: return s->tau_v;
+    case ORA_STRESS_FIELD: return AT(g, s->fv, i, j);
+    case ORA_STRESS_SEMI_IMPLICIT:                                /* :183-188 */
+        return s->rho_e * s->Cd * drag_norm_v(g, s, i, j) * ext_ve(g, s, i, j);
+    default: return 0.0;
+    }
+}
+static double implicit_tau_x(const ora_problem* g, const ora_stress* s, int i, int j) {
+    if (s->kind == ORA_STRESS_SEMI_IMPLICIT) return s->rho_e * s->Cd * drag_norm_u(g, s, i, j);   /* :192-196 */
+    return 0.0;                                                                                     /* :8 */
+}
+static double implicit_tau_y(const ora_problem* g, const ora_stress* s, int i, int j) {
+    if (s->kind == ORA_STRESS_SEMI_IMPLICIT) return s->rho_e * s->Cd * drag_norm_v(g, s, i, j);   /* :198-202 */
+    return 0.0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* u_velocity_tendency, momentum_tendencies_kernel_functions.jl:11-41         */
+/* ------------------------------------------------------------------------ */
+static double u_tendency(const ora_problem* g, int i, int j, double dtau) {
+    double ai = (AT(g, g->aice, i - 1, j) + AT(g, g->aice, i, j)) / 2;       /* Ix^f(aice) */
+    double mi = (ice_mass(g, i - 1, j) + ice_mass(g, i, j)) / 2;            /* Ix^f(ice_mass) */
+    double cor = 0.0;                                                        /* x_f_cross_U, `nothing` -> zero */
+    if (g->has_coriolis) {
+#define V_(ii, jj) AT(g, g->v, ii, jj)
+        cor = -g->f_coriolis * AVG4_FC(V_);                                  /* FPlane: -f * Ixy^{fc}(v) */
+#undef V_
+    }
+    double abar = (AT(g, g->alpha, i - 1, j) + AT(g, g->alpha, i, j)) / 2;  /* Ix^f(alpha), evp:393 */
+    /* sum_of_forcing_u, evp:391-395: user forcing (zero) + (un - u) / dt / Ix(alpha), with dt := dtau */
+    double forcing = 0.0 + (AT(g, g->un, i, j) - AT(g, g->u, i, j)) / dtau / abar;
+    double imm = 0.0 / mi;                                                   /* immersed_dj_sigma_1j == zero(grid), isd:57 (bcs TODO upstream :103-112) */
+    double G = (-cor
+                - explicit_tau_x(g, &g->top, i, j) / mi * ai
+                + explicit_tau_x(g, &g->bottom, i, j) / mi * ai
+                + ora_div_sigma_1(g, i, j) / mi
+                + imm
+                + forcing);
+    return (mi <= 0) ? 0.0 : G;                                              /* :38 */
+}
+static double v_tendency(const ora_problem* g, int i, int j, double dtau) {  /* :44-74 */
+    double ai = (AT(g, g->aice, i, j - 1) + AT(g, g->aice, i, j)) / 2;
+    double mi = (ice_mass(g, i, j - 1) + ice_mass(g, i, j)) / 2;
+    double cor = 0.0;
+    if (g->has_coriolis) {
+#define U_(ii, jj) AT(g, g->u, ii, jj)
+        cor = g->f_coriolis * AVG4_CF(U_);                                   /* FPlane: +f * Ixy^{cf}(u) */
+#undef U_
+    }
+    double abar = (AT(g, g->alpha, i, j - 1) + AT(g, g->alpha, i, j)) / 2;  /* evp:399 */
+    double forcing = 0.0 + (AT(g, g->vn, i, j) - AT(g, g->v, i, j)) / dtau / abar;
+    double imm = 0.0 / mi;
+    double G = (-cor
+                - explicit_tau_y(g, &g->top, i, j) / mi * ai
+                + explicit_tau_y(g, &g->bottom, i, j) / mi * ai
+                + ora_div_sigma_2(g, i, j) / mi
+                + imm
+                + forcing);
+    return (mi <= 0) ? 0.0 : G;
+}
+
+#define EPS64 2.220446049250313e-16
+
+/* ------------------------------------------------------------------------ */
+/* _u_velocity_step!, split_explicit_momentum_equations.jl:197-229            */
+/* ------------------------------------------------------------------------ */
+void ora_u_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int j1) {
+    OMP_ROWS
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            double mi = (ice_mass(g, i - 1, j) + ice_mass(g, i, j)) / 2;                 /* :205 */
+            double ai = (AT(g, g->aice, i - 1, j) + AT(g, g->aice, i, j)) / 2;           /* :206 */
+            double abar = (AT(g, g->alpha, i - 1, j) + AT(g, g->alpha, i, j)) / 2;
+            double dtau = dt / abar;                                                     /* :208, evp:384 */
+            double Gu = u_tendency(g, i, j, dtau);                                       /* :210 */
+            double tau_i = (implicit_tau_x(g, &g->bottom, i, j) - implicit_tau_x(g, &g->top, i, j)) / mi * ai;  /* :214-215 */
+            tau_i = (mi <= 0) ? 0.0 : tau_i;                                             /* :217 */
+            double uD = (AT(g, g->u, i, j) + dtau * Gu) / (1 + dtau * tau_i);            /* :218 */
+            double uF = 0.0;                                                             /* free_drift `nothing`, sbfd:129 */
+            int marginal = (mi > EPS64) & (ai > EPS64);                                  /* :224 */
+            int active_ice = (mi >= g->min_mass) & (ai >= g->min_conc);                  /* :225 */
+            double active = ora_peripheral_u(g, i, j) ? 0.0 : 1.0;                       /* :226 */
+            AT(g, g->u, i, j) = (active_ice ? uD : (marginal ? uF : 0.0)) * active;      /* :228 */
+        }
+}
+/* _v_velocity_step!, split_explicit_momentum_equations.jl:231-264 */
+void ora_v_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int j1) {
+    OMP_ROWS
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            double mi = (ice_mass(g, i, j - 1) + ice_mass(g, i, j)) / 2;
+            double ai = (AT(g, g->aice, i, j - 1) + AT(g, g->aice, i, j)) / 2;
+            double abar = (AT(g, g->alpha, i, j - 1) + AT(g, g->alpha, i, j)) / 2;
+            double dtau = dt / abar;                                                     /* evp:385 */
+            double Gv = v_tendency(g, i, j, dtau);
+            double tau_i = (implicit_tau_y(g, &g->bottom, i, j) - implicit_tau_y(g, &g->top, i, j)) / mi * ai;
+            tau_i = (mi <= 0) ? 0.0 : tau_i;
+            double vD = (AT(g, g->v, i, j) + dtau * Gv) / (1 + dtau * tau_i);
+            double vF = 0.0;
+            int marginal = (mi > EPS64) & (ai > EPS64);
+            int active_ice = (mi >= g->min_mass) & (ai >= g->min_conc);
+            double active = ora_peripheral_v(g, i, j) ? 0.0 : 1.0;
+            AT(g, g->v, i, j) = (active_ice ? vD : (marginal ? vF : 0.0)) * active;
+        }
+}
+
+/* ------------------------------------------------------------------------ */
+/* fill_halo_regions!(...; only_local_halos = true) (upstream) */
+/* x sides over interior rows first, then y sides over the whole x extent.    */
+/* Periodic: wrap.  MIRROR (no-flux, centre location in a Bounded direction): */
+/*   c[1-m] = c[m], c[N+m] = c[N+1-m].  NONE: nothing (Face location in a     */
+/*   Bounded direction: impenetrable / auxiliary default).                    */
+/* ------------------------------------------------------------------------ */
+void ora_fill_halo(const ora_problem* g, ora_field f, int lx, int ly, int bcx, int bcy) {
+    int Nx = g->Nx, Ny = g->Ny, Hx = g->Hx, Hy = g->Hy;
+    (void)lx; (void)ly;
+    if (bcx == ORA_BC_PERIODIC) {
+        for (int j = 1; j <= Ny; ++j)
+            for (int m = 1; m <= Hx; ++m) {
+                AT(g, f, 1 - m, j) = AT(g, f, Nx + 1 - m, j);
+                AT(g, f, Nx + m, j) = AT(g, f, m, j);
+            }
+    } else if (bcx == ORA_BC_MIRROR) {
+        for (int j = 1; j <= Ny; ++j)
+            for (int m = 1; m <= Hx; ++m) {
+                AT(g, f, 1 - m, j) = AT(g, f, m, j);
+                AT(g, f, Nx + m, j) = AT(g, f, Nx + 1 - m, j);
+            }
+    }
+    /* y sides cover the full stored x extent (including the extra Face column, if any) */
+    int64_t nxs = f.ld;
+    if (bcy == ORA_BC_PERIODIC) {
+        for (int m = 1; m <= Hy; ++m)
+            for (int64_t ii = 0; ii < nxs; ++ii) {
+                int i = (int)ii - Hx + 1;
+                AT(g, f, i, 1 - m) = AT(g, f, i, Ny + 1 - m);
+                AT(g, f, i, Ny + m) = AT(g, f, i, m);
+            }
+    } else if (bcy == ORA_BC_MIRROR) {
+        for (int m = 1; m <= Hy; ++m)
+            for (int64_t ii = 0; ii < nxs; ++ii) {
+                int i = (int)ii - Hx + 1;
+                AT(g, f, i, 1 - m) = AT(g, f, i, m);
+                AT(g, f, i, Ny + m) = AT(g, f, i, Ny + 1 - m);
+            }
+    }
+}
+static int bc_of(int topo, int loc) {
+    if (topo == ORA_PERIODIC) return ORA_BC_PERIODIC;
+    return loc == C_ ? ORA_BC_MIRROR : ORA_BC_NONE;
+}
+void ora_fill_halo_u(ora_problem* g) { ora_fill_halo(g, g->u, F_, C_, bc_of(g->topo_x, F_), bc_of(g->topo_y, C_)); }
+void ora_fill_halo_v(ora_problem* g) { ora_fill_halo(g, g->v, C_, F_, bc_of(g->topo_x, C_), bc_of(g->topo_y, F_)); }
+void ora_fill_halo_center(ora_problem* g, ora_field f) { ora_fill_halo(g, f, C_, C_, bc_of(g->topo_x, C_), bc_of(g->topo_y, C_)); }
+
+/* finalize_rheology!, evp:275-280: halo fill of sigma11, sigma12, sigma22 */
+void ora_finalize_rheology(ora_problem* g) {
+    ora_fill_halo_center(g, g->s11);
+    ora_fill_halo(g, g->s12, F_, F_, bc_of(g->topo_x, F_), bc_of(g->topo_y, F_));
+    ora_fill_halo_center(g, g->s22);
+}
+
+/* ------------------------------------------------------------------------ */
+/* the sub-step loop, split_explicit_momentum_equations.jl:173-189            */
+/* stress range: Auxiliaries kernel parameters, evp:145                       */
+/* ------------------------------------------------------------------------ */
+void ora_subcycle(ora_problem* g, double dt, int first, int last) {
+    int si0 = -g->Hx + 2, si1 = g->Nx + g->Hx - 1, sj0 = -g->Hy + 2, sj1 = g->Ny + g->Hy - 1;
+    for (int s = first; s <= last; ++s) {
+        ora_compute_viscosities(g, si0, si1, sj0, sj1);            /* compute_stresses!, evp:222-234 */
+        ora_compute_stresses(g, dt, si0, si1, sj0, sj1);
+        if ((s % 2) == 0) {                                        /* :178-182 */
+            ora_u_velocity_step(g, dt, 1, g->Nx, 1, g->Ny);
+            ora_fill_halo_u(g);
+            ora_v_velocity_step(g, dt, 1, g->Nx, 1, g->Ny);
+            ora_fill_halo_v(g);
+        } else {                                                   /* :184-187 */
+            ora_v_velocity_step(g, dt, 1, g->Nx, 1, g->Ny);
+            ora_fill_halo_v(g);
+            ora_u_velocity_step(g, dt, 1, g->Nx, 1, g->Ny);
+            ora_fill_halo_u(g);
+        }
+    }
+}
+
+static void copy_parent(const ora_problem* g, ora_field dst, ora_field src) {
+    int64_t rows = (int64_t)g->Ny + 2 * g->Hy;
+    /* parents of same-location fields have identical shape; copy the common ld x rows block */
+    int64_t ld = dst.ld < src.ld ? dst.ld : src.ld;
+    for (int64_t r = 0; r < rows; ++r) memcpy(dst.p + r * dst.ld, src.p + r * src.ld, (size_t)ld * sizeof(double));
+}
+
+/* time_step_momentum!, split_explicit_momentum_equations.jl:103-195 */
+void ora_time_step_momentum(ora_problem* g, double dt, int rk_reset) {
+    if (rk_reset) {                          /* reset_velocities! :89-93 */
+        copy_parent(g, g->u, g->um);
+        copy_parent(g, g->v, g->vm);
+    }
+    ora_initialize_rheology(g);              /* :130 */
+    /* update_external_stress! :133-134 : halo refresh of forcing fields is the caller's job */
+    ora_fill_halo_u(g);                      /* :170 */
+    ora_fill_halo_v(g);                      /* :171 */
+    ora_subcycle(g, dt, 1, g->substeps);     /* :173-189 */
+    ora_finalize_rheology(g);                /* :192 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* Advection: upstream Oceananigans WENO(order = 5 | 7), UpwindBiased(5)      */
+/* (SURVEY.md App. B -- recalled semantics, unverifiable here: classical      */
+/* Jiang-Shu / Balsara-Shu stencils and smoothness indicators, WENO-Z weights */
+/* alpha_s = C_s (1 + (tau / (beta_s + eps))^2), eps = 1e-8).                 */
+/* Face i is the west face of cell i; left bias (U > 0) is upwinded to i-1.   */
+/* ------------------------------------------------------------------------ */
+#define WENO_EPS 1e-8
+
+static double weno5(const double* p) {
+    /* p[0..4] = psi at (upwind-2, upwind-1, upwind, downwind, downwind+1) */
+    double q0 = (2 * p[2] + 5 * p[3] - p[4]) / 6;      /* stencil 0: (upwind, dw, dw+1) */
+    double q1 = (-p[1] + 5 * p[2] + 2 * p[3]) / 6;     /* stencil 1 */
+    double q2 = (2 * p[0] - 7 * p[1] + 11 * p[2]) / 6; /* stencil 2 */
+    double b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
+    double b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
+    double b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
+    double tau = fabs(b0 - b2);
+    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS), r2 = tau / (b2 + WENO_EPS);
+    double a0 = (3.0 / 10) * (1 + r0 * r0);
+    double a1 = (3.0 / 5) * (1 + r1 * r1);
+    double a2 = (1.0 / 10) * (1 + r2 * r2);
+    double s = a0 + a1 + a2;
+    return (a0 * q0 + a1 * q1 + a2 * q2) / s;
+}
+static double upwind5(const double* p) {
+    /* UpwindBiased(order=5): optimal linear combination of the three stencils */
+    return (2 * p[0] - 13 * p[1] + 47 * p[2] + 27 * p[3] - 3 * p[4]) / 60;
+}
+static double weno7(const double* p) {
+    /* p[0..6] = psi at (up-3, up-2, up-1, up, dw, dw+1, dw+2) */
+    double q0 = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) / 12;
+    double q1 = (-p[2] + 7 * p[3] + 7 * p[4] - p[5]) / 12;
+    double q2 = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) / 12;
+    double q3 = (-3 * p[0] + 13 * p[1] - 23 * p[2] + 25 * p[3]) / 12;
+    double b0 = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
+                p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
+    double b1 = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
+                p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
+    double b2 = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
+                p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
+    double b3 = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
+                p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
+    double tau = fabs(b0 + 3 * b1 - 3 * b2 - b3);
+    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS), r2 = tau / (b2 + WENO_EPS), r3 = tau / (b3 + WENO_EPS);
+    double a0 = (4.0 / 35) * (1 + r0 * r0);
+    double a1 = (18.0 / 35) * (1 + r1 * r1);
+    double a2 = (12.0 / 35) * (1 + r2 * r2);
+    double a3 = (1.0 / 35) * (1 + r3 * r3);
+    double s = a0 + a1 + a2 + a3;
+    return (a0 * q0 + a1 * q1 + a2 * q2 + a3 * q3) / s;
+}
+/* reconstruct c at a face from a 1-D line of values; `up` is the upwind cell value index
+ * stepping `st` (= +1 for left bias reading towards increasing index). */
+static double reconstruct(int scheme, const double* line, int64_t up, int64_t st) {
+    double p[7];
+    if (scheme == 1) return line[up];
+    if (scheme == 5 || scheme == -5) {
+        for (int k = 0; k < 5; ++k) p[k] = line[up + (k - 2) * st];
+        return scheme == 5 ? weno5(p) : upwind5(p);
+    }
+    for (int k = 0; k < 7; ++k) p[k] = line[up + (k - 3) * st];
+    return weno7(p);
+}
+/* _advective_tracer_flux_x = Ax^{fcc} * U * c~ (upstream; bias = left iff U > 0) */
+double ora_weno_flux_x(const ora_problem* g, int scheme, ora_field c, int i, int j) {
+    double uu = AT(g, g->u, i, j);
+    const double* base = &AT(g, c, i, j);   /* cell i; upwind of a left-biased face i is cell i-1 */
+    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1) : reconstruct(scheme, base, 0, -1);
+    return ora_dy(g, F_, C_, i, j) * uu * ct;    /* Ax = dy * dz, dz = 1 */
+}
+double ora_weno_flux_y(const ora_problem* g, int scheme, ora_field c, int i, int j) {
+    double vv = AT(g, g->v, i, j);
+    const double* base = &AT(g, c, i, j);
+    int64_t ld = c.ld;
+    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld) : reconstruct(scheme, base, 0, -ld);
+    return ora_dx(g, C_, F_, i, j) * vv * ct;    /* Ay = dx^{cf} * dz */
+}
+/* horizontal_div_Uc, sea_ice_advection.jl:51-54 ; G = -div, tracer_tendency_kernel_functions.jl:39-42 */
+static double tendency_of(const ora_problem* g, int scheme, ora_field c, int i, int j) {
+    double V = ora_az(g, C_, C_, i, j);          /* V^{ccc} = Az * dz */
+    double fx = ora_weno_flux_x(g, scheme, c, i + 1, j) - ora_weno_flux_x(g, scheme, c, i, j);
+    double fy = ora_weno_flux_y(g, scheme, c, i, j + 1) - ora_weno_flux_y(g, scheme, c, i, j);
+    return -(1 / V * (fx + fy));
+}
+void ora_compute_tracer_tendencies(ora_problem* g, int scheme) {
+    OMP_ROWS
+    for (int j = 1; j <= g->Ny; ++j)
+        for (int i = 1; i <= g->Nx; ++i) {
+            AT(g, g->Gh, i, j) = tendency_of(g, scheme, g->h, i, j);
+            AT(g, g->Ga, i, j) = tendency_of(g, scheme, g->aice, i, j);
+        }
+}
+
+/* _dynamic_step_tracers!, sea_ice_fe_step.jl:56-82 */
+void ora_dynamic_step_tracers(ora_problem* g, double dt, int from_cache) {
+    OMP_ROWS
+    for (int j = 1; j <= g->Ny; ++j)
+        for (int i = 1; i <= g->Nx; ++i) {
+            double hn = from_cache ? AT(g, g->hm, i, j) : AT(g, g->h, i, j);
+            double an = from_cache ? AT(g, g->am, i, j) : AT(g, g->aice, i, j);
+            double hp = hn + dt * AT(g, g->Gh, i, j);
+            double ap = an + dt * AT(g, g->Ga, i, j);
+            ap = fmax(0.0, ap);
+            hp = fmax(0.0, hp);
+            ap = (hp == 0) ? 0.0 : ap;
+            hp = (ap == 0) ? 0.0 : hp;
+            double Vp = hp * ap;
+            AT(g, g->aice, i, j) = (ap > 1) ? 1.0 : ap;
+            AT(g, g->h, i, j) = (ap > 1) ? Vp : hp;
+        }
+}
+
+/* update_state!, sea_ice_model.jl:379-394 : mask + halo fill of every prognostic field */
+void ora_update_state(ora_problem* g) {
+    if (g->has_mask) {
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                if (inactive_cell(g, i, j)) { AT(g, g->h, i, j) = 0; AT(g, g->aice, i, j) = 0; }
+                if (ora_peripheral_u(g, i, j)) AT(g, g->u, i, j) = 0;   /* mask_immersed_field_xy! on (f,c): peripheral nodes */
+                if (ora_peripheral_v(g, i, j)) AT(g, g->v, i, j) = 0;
+            }
+    }
+    ora_fill_halo_center(g, g->h);
+    ora_fill_halo_center(g, g->aice);
+    ora_fill_halo_u(g);
+    ora_fill_halo_v(g);
+}
+
+/* time_step!(::FESeaIceModel), sea_ice_fe_step.jl:13-34 (no thermodynamics) */
+void ora_time_step_fe(ora_problem* g, double dt, int scheme, int first_iteration) {
+    if (first_iteration) ora_update_state(g);          /* :16 */
+    if (scheme) ora_compute_tracer_tendencies(g, scheme);  /* :19 */
+    ora_time_step_momentum(g, dt, 0);                  /* :22 */
+    if (scheme) ora_dynamic_step_tracers(g, dt, 0);    /* :25 */
+    ora_update_state(g);                               /* :31 */
+}
+/* SplitRungeKutta3: cache_current_fields! (sea_ice_rk_substep.jl:29-42), then for beta in (3,2,1):
+ * rk_substep!(dt/beta) (:81-94) ; update_state!  (upstream stage loop) */
+void ora_time_step_rk3(ora_problem* g, double dt, int scheme) {
+    copy_parent(g, g->hm, g->h);
+    copy_parent(g, g->am, g->aice);
+    copy_parent(g, g->um, g->u);
+    copy_parent(g, g->vm, g->v);
+    for (int beta = 3; beta >= 1; --beta) {
+        double dtau = dt / beta;
+        if (scheme) ora_compute_tracer_tendencies(g, scheme);   /* :84 */
+        ora_time_step_momentum(g, dtau, 1);                     /* :87 */
+        if (scheme) ora_dynamic_step_tracers(g, dtau, 1);       /* :89 */
+        ora_update_state(g);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Bare-ice slab thermodynamics (plumbing)                                    */
+/* thermodynamic_time_step.jl:75-118,304-324,358-370;                         */
+/* slab_thermodynamics_tendencies.jl:28-135; SeaIceThermodynamics.jl:161-170  */
+/* ------------------------------------------------------------------------ */
+static double latent_heat(const ora_slab* s, double T) {          /* SeaIceThermodynamics.jl:161-170 */
+    return s->L0 + (s->rho_liquid * s->c_liquid / s->rho_pure - s->c_ice) * (T - s->T0);
+}
+/* slab_internal_heat_flux, slab_heat_and_tracer_fluxes.jl:8-19 */
+static double slab_internal_flux(const ora_slab* s, double Tu, double Tb, double h) {
+    return (h <= 0) ? 0.0 : -s->k_ice * (Tu - Tb) / h;
+}
+/* concentration_thermodynamic_step(::ProportionalEvolution), thermodynamic_time_step.jl:358-370 */
+static double concentration_step(double dtV, double an, double hn, double hc, double dt) {
+    double freezing = (dtV >= 0) ? 1.0 : 0.0;
+    double melting = (dtV < 0) ? 1.0 : 0.0;
+    double daf = (1 - an) / hc * dtV * freezing;
+    double dam = an / (2 * hn) * dtV * melting;
+    double ap = an + dt * (daf + dam);
+    return fmax(0.0, ap);
+}
+/* _ice_thermodynamic_time_step! :75-118 with thermodynamic_tendency (slab_thermodynamics_tendencies.jl:74-135,
+ * PrescribedTemperature branch), ice_melt_freeze_tendency (:28-68), ice_volume_update (:304-324) */
+void ora_slab_thermo_step(const ora_slab* s, int64_t n, double* h, double* aice, double* mass_flux, double dt) {
+    for (int64_t c = 0; c < n; ++c) {
+        double hn = h[c], an = aice[c], hc = s->h_consolidation;
+        int consolidated = hn >= hc;
+        double Tb = s->liq_T0 - s->liq_slope * s->salinity;       /* IceWaterThermalEquilibrium: Tm(S) */
+        double Tu = s->Tu;                                        /* PrescribedTemperature */
+        double Eb = s->rho_bulk * latent_heat(s, Tb);
+        double Eu = s->rho_bulk * latent_heat(s, Tu);
+        double Qi_fun = slab_internal_flux(s, Tu, Tb, hn);        /* internal_flux_function at Tu */
+        double Qu = (s->top_flux_kind == 1) ? Qi_fun : s->Qu;     /* sea_ice_model.jl:248-256 default */
+        double Qb = (s->bot_flux_kind == 1) ? (-(1 - an)) * s->Qb : s->Qb;
+        double Qi = consolidated ? Qi_fun : 0.0;                  /* ice_interior_heat_flux :10-18 */
+        double wu = (Qu - Qi) / Eu;
+        double wb = (Qi - Qb) / Eb;
+        double dtV = wu + wb;
+        /* ice_volume_update :304-324 */
+        double V1 = hn * an + dt * dtV;
+        V1 = fmax(0.0, V1);
+        dtV = (V1 - hn * an) / dt;
+        double ap = concentration_step(dtV, an, hn, hc, dt);
+        double hp = V1 / ap;
+        hp = (ap <= 0) ? 0.0 : hp;
+        ap = (dtV == 0) ? an : ap;
+        hp = (dtV == 0) ? hn : hp;
+        ap = (hp == 0) ? 0.0 : ap;
+        hp = (ap == 0) ? 0.0 : hp;
+        double a1 = (ap > 1) ? 1.0 : ap;
+        double h1 = (ap > 1) ? hp * ap : hp;
+        aice[c] = a1;
+        h[c] = h1;
+        if (mass_flux) mass_flux[c] = s->rho_bulk * (h1 * a1 - hn * an) / dt;   /* :111 */
+    }
+}

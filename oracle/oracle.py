@@ -1,0 +1,296 @@
+"""ctypes binding of the CPU oracle (oracle/csi_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module, and only as the checker.  The product (climaseaice.jl_amd) never does.
+
+"parity unpinned": see oracle/csi_oracle.h -- the reference is Julia + Oceananigans,
+neither of which can run in this image; this restatement is pinned only by the
+reference's own property tests (adjoint identity, drag bound, decomposition
+invariance, slab closure).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+PERIODIC, BOUNDED = 0, 1
+METRIC_UNIFORM, METRIC_PER_J = 0, 1
+STRESS_NONE, STRESS_CONST, STRESS_FIELD, STRESS_SEMI_IMPLICIT = 0, 1, 2, 3
+VEL_ZERO, VEL_CONST, VEL_FIELD = 0, 1, 2
+PRESSURE_REPLACEMENT, PRESSURE_ICE_STRENGTH = 0, 1
+CENTER, FACE = 0, 1
+
+
+class Field(C.Structure):
+    _fields_ = [("p", C.POINTER(C.c_double)), ("ld", C.c_int64)]
+
+
+class Stress(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ue_kind", C.c_int32), ("ve_kind", C.c_int32), ("pad", C.c_int32),
+                ("tau_u", C.c_double), ("tau_v", C.c_double),
+                ("fu", Field), ("fv", Field),
+                ("ue", C.c_double), ("ve", C.c_double),
+                ("rho_e", C.c_double), ("Cd", C.c_double)]
+
+
+_FIELD_NAMES = ["u", "v", "h", "aice", "s11", "s22", "s12", "zeta_c", "zeta_f", "Delta", "alpha", "P",
+                "un", "vn", "Gh", "Ga", "hm", "am", "um", "vm"]
+
+# staggering of every field: (x location, y location)
+LOCATION = {"u": (FACE, CENTER), "v": (CENTER, FACE), "h": (CENTER, CENTER), "aice": (CENTER, CENTER),
+            "s11": (CENTER, CENTER), "s22": (CENTER, CENTER), "s12": (FACE, FACE),
+            "zeta_c": (CENTER, CENTER), "zeta_f": (FACE, FACE), "Delta": (CENTER, CENTER),
+            "alpha": (CENTER, CENTER), "P": (CENTER, CENTER), "un": (FACE, CENTER), "vn": (CENTER, FACE),
+            "Gh": (CENTER, CENTER), "Ga": (CENTER, CENTER), "hm": (CENTER, CENTER), "am": (CENTER, CENTER),
+            "um": (FACE, CENTER), "vm": (CENTER, FACE)}
+
+
+class ProblemStruct(C.Structure):
+    _fields_ = ([("Nx", C.c_int32), ("Ny", C.c_int32), ("Hx", C.c_int32), ("Hy", C.c_int32),
+                 ("topo_x", C.c_int32), ("topo_y", C.c_int32), ("metric_kind", C.c_int32), ("has_mask", C.c_int32),
+                 ("dx", C.c_double), ("dy", C.c_double),
+                 ("dxc", C.POINTER(C.c_double)), ("dxf", C.POINTER(C.c_double)),
+                 ("azc", C.POINTER(C.c_double)), ("azf", C.POINTER(C.c_double)),
+                 ("mask", C.POINTER(C.c_uint8)), ("mask_ld", C.c_int64),
+                 ("P_star", C.c_double), ("C_star", C.c_double), ("ecc", C.c_double), ("delta_min", C.c_double),
+                 ("alpha_min", C.c_double), ("alpha_max", C.c_double), ("c_alpha", C.c_double),
+                 ("pressure_kind", C.c_int32), ("substeps", C.c_int32),
+                 ("min_mass", C.c_double), ("min_conc", C.c_double), ("rho_ice", C.c_double),
+                 ("f_coriolis", C.c_double), ("has_coriolis", C.c_int32), ("free_drift_kind", C.c_int32),
+                 ("top", Stress), ("bottom", Stress)] +
+                [(n, Field) for n in _FIELD_NAMES])
+
+
+class Slab(C.Structure):
+    _fields_ = [("k_ice", C.c_double), ("rho_bulk", C.c_double), ("rho_pure", C.c_double),
+                ("rho_liquid", C.c_double), ("c_liquid", C.c_double), ("c_ice", C.c_double),
+                ("L0", C.c_double), ("T0", C.c_double), ("liq_slope", C.c_double), ("liq_T0", C.c_double),
+                ("salinity", C.c_double), ("h_consolidation", C.c_double),
+                ("top_bc_kind", C.c_int32), ("top_flux_kind", C.c_int32), ("bot_flux_kind", C.c_int32), ("pad", C.c_int32),
+                ("Tu", C.c_double), ("Qu", C.c_double), ("Qb", C.c_double)]
+
+
+_lib_cache = {}
+
+
+def build(force=False):
+    """Compile the oracle shared libraries with the committed Makefile (gcc, strict IEEE order)."""
+    tgt = os.path.join(_HERE, "libcsi_oracle.so")
+    if force or not os.path.exists(tgt) or os.path.getmtime(tgt) < os.path.getmtime(os.path.join(_HERE, "csi_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return tgt
+
+
+def lib(omp=False):
+    key = "omp" if omp else "serial"
+    if key not in _lib_cache:
+        build()
+        name = "libcsi_oracle_omp.so" if omp else "libcsi_oracle.so"
+        L = C.CDLL(os.path.join(_HERE, name))
+        P = C.POINTER(ProblemStruct)
+        dbl = C.c_double
+        i32 = C.c_int
+        for fn in ("ora_strain_xx", "ora_strain_yy", "ora_strain_xy", "ora_div_sigma_1", "ora_div_sigma_2",
+                   "ora_old_div_sigma_1", "ora_old_div_sigma_2"):
+            getattr(L, fn).restype = dbl
+            getattr(L, fn).argtypes = [P, i32, i32]
+        for fn in ("ora_dx", "ora_dy", "ora_az"):
+            getattr(L, fn).restype = dbl
+            getattr(L, fn).argtypes = [P, i32, i32, i32, i32]
+        for fn in ("ora_peripheral_u", "ora_peripheral_v"):
+            getattr(L, fn).restype = C.c_int32
+            getattr(L, fn).argtypes = [P, i32, i32]
+        L.ora_initialize_rheology.argtypes = [P]
+        L.ora_compute_viscosities.argtypes = [P, i32, i32, i32, i32]
+        L.ora_compute_stresses.argtypes = [P, dbl, i32, i32, i32, i32]
+        L.ora_u_velocity_step.argtypes = [P, dbl, i32, i32, i32, i32]
+        L.ora_v_velocity_step.argtypes = [P, dbl, i32, i32, i32, i32]
+        L.ora_fill_halo.argtypes = [P, Field, i32, i32, i32, i32]
+        L.ora_fill_halo_u.argtypes = [P]
+        L.ora_fill_halo_v.argtypes = [P]
+        L.ora_fill_halo_center.argtypes = [P, Field]
+        L.ora_finalize_rheology.argtypes = [P]
+        L.ora_time_step_momentum.argtypes = [P, dbl, i32]
+        L.ora_subcycle.argtypes = [P, dbl, i32, i32]
+        L.ora_compute_tracer_tendencies.argtypes = [P, i32]
+        L.ora_dynamic_step_tracers.argtypes = [P, dbl, i32]
+        L.ora_weno_flux_x.restype = dbl
+        L.ora_weno_flux_x.argtypes = [P, i32, Field, i32, i32]
+        L.ora_weno_flux_y.restype = dbl
+        L.ora_weno_flux_y.argtypes = [P, i32, Field, i32, i32]
+        L.ora_update_state.argtypes = [P]
+        L.ora_time_step_fe.argtypes = [P, dbl, i32, i32]
+        L.ora_time_step_rk3.argtypes = [P, dbl, i32]
+        L.ora_slab_thermo_step.argtypes = [C.POINTER(Slab), C.c_int64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), dbl]
+        for fn in dir(L):
+            pass
+        _lib_cache[key] = L
+    return _lib_cache[key]
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Problem:
+    """One oracle problem: grid + EVP parameters + numpy-owned fields laid out like Oceananigans parents.
+
+    Arrays have shape (nj, ni) in C order, i.e. `i` is the fastest index exactly as in the
+    reference's column-major (ni, nj) parent arrays.  `self.f[name][j + Hy - 1, i + Hx - 1]`
+    is element (i, j) in the reference's 1-based indexing.
+    """
+
+    def __init__(self, Nx, Ny, Hx=4, Hy=4, topo=(PERIODIC, PERIODIC), dx=1.0, dy=1.0,
+                 per_j=None, substeps=120, omp=False):
+        self.L = lib(omp)
+        self.s = ProblemStruct()
+        s = self.s
+        s.Nx, s.Ny, s.Hx, s.Hy = Nx, Ny, Hx, Hy
+        s.topo_x, s.topo_y = topo
+        s.dx, s.dy = dx, dy
+        self._keep = []
+        if per_j is not None:
+            s.metric_kind = METRIC_PER_J
+            for k in ("dxc", "dxf", "azc", "azf"):
+                a = np.ascontiguousarray(per_j[k], dtype=np.float64)
+                assert a.shape == (Ny + 2 * Hy + 1,)
+                self._keep.append(a)
+                setattr(s, k, _dptr(a))
+            s.dy = per_j["dy"]
+        else:
+            s.metric_kind = METRIC_UNIFORM
+        # EVP defaults: elasto_visco_plastic_rheology.jl:119-127
+        s.P_star, s.C_star, s.ecc, s.delta_min = 27500.0, 20.0, 2.0, 2e-9
+        s.alpha_min, s.alpha_max, s.c_alpha = 50.0, 300.0, float(np.pi) ** 2
+        s.pressure_kind = PRESSURE_REPLACEMENT
+        s.substeps = substeps
+        # sea_ice_momentum_equations.jl:73-75 ; sea_ice_model.jl:142-145
+        s.min_mass, s.min_conc, s.rho_ice = 1.0, 1e-3, 900.0
+        s.has_coriolis, s.f_coriolis = 0, 0.0
+        s.free_drift_kind = 0
+        s.top.kind = STRESS_NONE
+        s.bottom.kind = STRESS_NONE
+        self.f = {}
+        for n in _FIELD_NAMES:
+            lx, ly = LOCATION[n]
+            ni = Nx + 2 * Hx + (1 if (lx == FACE and topo[0] == BOUNDED) else 0)
+            nj = Ny + 2 * Hy + (1 if (ly == FACE and topo[1] == BOUNDED) else 0)
+            a = np.zeros((nj, ni), dtype=np.float64)
+            self.f[n] = a
+            fld = getattr(s, n)
+            fld.p = _dptr(a)
+            fld.ld = ni
+        self.f["alpha"][...] = s.alpha_max     # Auxiliaries: fill!(alpha, alpha+), evp:161
+
+    # ---- helpers -------------------------------------------------------------------------
+    @property
+    def ptr(self):
+        return C.byref(self.s)
+
+    def interior(self, name):
+        s = self.s
+        a = self.f[name]
+        lx, ly = LOCATION[name]
+        nx = s.Nx + (1 if (lx == FACE and s.topo_x == BOUNDED) else 0)
+        ny = s.Ny + (1 if (ly == FACE and s.topo_y == BOUNDED) else 0)
+        return a[s.Hy:s.Hy + ny, s.Hx:s.Hx + nx]
+
+    def field_struct(self, name):
+        return getattr(self.s, name)
+
+    def set_mask(self, active):
+        """active: uint8 array shaped like a centre field parent (1 = wet/active)."""
+        a = np.ascontiguousarray(active, dtype=np.uint8)
+        assert a.shape == self.f["h"].shape
+        self._mask = a
+        self.s.mask = a.ctypes.data_as(C.POINTER(C.c_uint8))
+        self.s.mask_ld = a.shape[1]
+        self.s.has_mask = 1
+
+    def set_stress(self, which, kind, tau=(0.0, 0.0), ue=None, ve=None, rho_e=1026.0, Cd=5.5e-3, fu=None, fv=None):
+        st = getattr(self.s, which)
+        st.kind = kind
+        st.tau_u, st.tau_v = tau
+        st.rho_e, st.Cd = rho_e, Cd
+        for comp, val in (("u", ue), ("v", ve)):
+            if val is None:
+                setattr(st, comp + "e_kind", VEL_ZERO)
+            elif np.isscalar(val):
+                setattr(st, comp + "e_kind", VEL_CONST)
+                setattr(st, comp + "e", float(val))
+            else:
+                setattr(st, comp + "e_kind", VEL_FIELD)
+                a = np.ascontiguousarray(val, dtype=np.float64)
+                self._keep.append(a)
+                fld = getattr(st, "f" + comp)
+                fld.p = _dptr(a)
+                fld.ld = a.shape[1]
+        if kind == STRESS_FIELD:
+            for comp, val in (("u", fu), ("v", fv)):
+                a = np.ascontiguousarray(val, dtype=np.float64)
+                self._keep.append(a)
+                fld = getattr(st, "f" + comp)
+                fld.p = _dptr(a)
+                fld.ld = a.shape[1]
+
+    def set_coriolis(self, f):
+        self.s.has_coriolis = 0 if f is None else 1
+        self.s.f_coriolis = 0.0 if f is None else float(f)
+
+    # ---- the reference's verbs -----------------------------------------------------------
+    def update_state(self):
+        self.L.ora_update_state(self.ptr)
+
+    def initialize_rheology(self):
+        self.L.ora_initialize_rheology(self.ptr)
+
+    def stress_range(self):
+        s = self.s
+        return (-s.Hx + 2, s.Nx + s.Hx - 1, -s.Hy + 2, s.Ny + s.Hy - 1)
+
+    def compute_stresses(self, dt, rng=None):
+        r = rng or self.stress_range()
+        self.L.ora_compute_viscosities(self.ptr, *r)
+        self.L.ora_compute_stresses(self.ptr, dt, *r)
+
+    def u_step(self, dt, rng=None):
+        r = rng or (1, self.s.Nx, 1, self.s.Ny)
+        self.L.ora_u_velocity_step(self.ptr, dt, *r)
+
+    def v_step(self, dt, rng=None):
+        r = rng or (1, self.s.Nx, 1, self.s.Ny)
+        self.L.ora_v_velocity_step(self.ptr, dt, *r)
+
+    def subcycle(self, dt, first=1, last=None):
+        self.L.ora_subcycle(self.ptr, dt, first, last or self.s.substeps)
+
+    def time_step_momentum(self, dt, rk_reset=False):
+        self.L.ora_time_step_momentum(self.ptr, dt, int(rk_reset))
+
+    def compute_tracer_tendencies(self, scheme):
+        self.L.ora_compute_tracer_tendencies(self.ptr, scheme)
+
+    def dynamic_step_tracers(self, dt, from_cache=False):
+        self.L.ora_dynamic_step_tracers(self.ptr, dt, int(from_cache))
+
+    def time_step_fe(self, dt, scheme=0, first_iteration=False):
+        self.L.ora_time_step_fe(self.ptr, dt, scheme, int(first_iteration))
+
+    def time_step_rk3(self, dt, scheme=0):
+        self.L.ora_time_step_rk3(self.ptr, dt, scheme)
+
+
+def slab_step(h, aice, dt, *, k_ice=2.0, rho_bulk=900.0, rho_pure=917.0, rho_liquid=999.8, c_liquid=4186.0,
+              c_ice=2000.0, L0=334e3, T0=0.0, liq_slope=0.054, liq_T0=0.0, salinity=0.0, h_consolidation=0.05,
+              Tu=-10.0, top_flux_kind=1, Qu=0.0, bot_flux_kind=0, Qb=0.0):
+    """Bare-ice slab step with PrescribedTemperature top BC (oracle for csi_slab_thermo_step)."""
+    s = Slab(k_ice, rho_bulk, rho_pure, rho_liquid, c_liquid, c_ice, L0, T0, liq_slope, liq_T0, salinity,
+             h_consolidation, 0, top_flux_kind, bot_flux_kind, 0, Tu, Qu, Qb)
+    h = np.ascontiguousarray(h, dtype=np.float64).copy()
+    a = np.ascontiguousarray(aice, dtype=np.float64).copy()
+    mf = np.zeros_like(h)
+    lib().ora_slab_thermo_step(C.byref(s), h.size, _dptr(h), _dptr(a), _dptr(mf), dt)
+    return h, a, mf

@@ -1,0 +1,128 @@
+"""Synthetic test cases shared by the oracle tests, the GPU parity tests and bench.py.
+
+A case is a plain dict (grid description, physics switches, seeded numpy initial fields).
+`oracle_problem(case)` builds the CPU oracle problem; `csi_model(case, mode)` builds the product
+model on the GPU through the C ABI.  Inputs follow SURVEY.md 8(d): h0 is the sinusoid of
+test/distributed_tests_utils.jl:126 (+ optional seeded noise), optional open-water / thin-ice
+patches exercise the active / marginal / zero branches of the velocity kernels.
+"""
+import numpy as np
+
+import climaseaice_jl_amd as csi
+
+
+def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
+              substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
+              patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
+              field_forcing=False):
+    rng = np.random.default_rng(seed)
+    c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
+             top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing)
+    T = {"periodic": csi.Periodic, "bounded": csi.Bounded}
+    tt = (T[topo[0]], T[topo[1]])
+    if grid == "rectilinear":
+        g = csi.RectilinearGrid((Nx, Ny), x=(0.0, Nx * spacing), y=(0.0, Ny * spacing), topology=tt, halo=(H, H))
+    else:
+        g = csi.LatitudeLongitudeGrid((Nx, Ny), longitude=(0, 60), latitude=(20, 70), topology=tt, halo=(H, H))
+    c["g"] = g
+    xc = (np.arange(Nx) + 0.5) / Nx
+    yc = (np.arange(Ny) + 0.5) / Ny
+    X, Y = xc[None, :], yc[:, None]
+    h = 0.3 + 0.005 * (np.sin(2 * np.pi * 3 * X) + np.sin(2 * np.pi * 2 * Y)) + 0.0 * X * Y
+    if noise:
+        h = h * (1.0 + noise * (rng.random((Ny, Nx)) - 0.5))
+    a = np.ones((Ny, Nx))
+    if patches:
+        a = np.clip(0.6 + 0.6 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.2 * rng.random((Ny, Nx)), 0.0, 1.0)
+        i0, i1, j0, j1 = Nx // 8, Nx // 4, Ny // 6, Ny // 3
+        a[j0:j1, i0:i1] = 0.0                       # open water: zero branch
+        h[j0:j1, i0:i1] = 0.0
+        a[j1:j1 + 2, i0:i1] = 5e-4                  # below minimum_concentration: marginal branch
+        h[j1:j1 + 2, i0:i1] = 1e-3
+    nxu, nyu = g.interior_size(csi.Face, csi.Center)
+    nxv, nyv = g.interior_size(csi.Center, csi.Face)
+    u = np.full((nyu, nxu), float(u0)) + random_uv * rng.standard_normal((nyu, nxu))
+    v = np.full((nyv, nxv), float(v0)) + random_uv * rng.standard_normal((nyv, nxv))
+    if topo[0] == "bounded":
+        u[:, 0] = 0.0
+        u[:, -1] = 0.0
+    if topo[1] == "bounded":
+        v[0, :] = 0.0
+        v[-1, :] = 0.0
+    c.update(h=h, a=a, u=u, v=v)
+    if field_forcing:
+        c["top_u"] = 0.01 * (1 + 0.5 * np.sin(2 * np.pi * X)) * np.ones((nyu, 1))[:, :1] * np.ones((1, 1))
+        c["top_u"] = np.broadcast_to(0.01 * (1 + 0.5 * np.sin(2 * np.pi * np.linspace(0, 1, nxu)))[None, :], (nyu, nxu)).copy()
+        c["top_v"] = np.broadcast_to(0.01 * (1 + 0.5 * np.cos(2 * np.pi * np.linspace(0, 1, nyv)))[:, None], (nyv, nxv)).copy()
+        c["ue_f"] = 0.05 * np.cos(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu))
+        c["ve_f"] = 0.05 * np.sin(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1))
+    return c
+
+
+def _fill_parent_like(p, name, interior):
+    """numpy parent array of oracle field `name` holding `interior` with locally filled halos."""
+    import oracle as O
+    arr = np.zeros_like(p.f[name])
+    s = p.s
+    ny, nx = interior.shape
+    arr[s.Hy:s.Hy + ny, s.Hx:s.Hx + nx] = interior
+    return arr
+
+
+def oracle_problem(case, omp=False):
+    import oracle as O
+    g = case["g"]
+    topo = tuple(O.PERIODIC if t == "periodic" else O.BOUNDED for t in case["topo"])
+    m = g.metrics()
+    if m["kind"] == "uniform":
+        p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"], omp=omp)
+    else:
+        p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, per_j=m, substeps=case["substeps"], omp=omp)
+    p.set_coriolis(case["coriolis"])
+    if case["pressure"] != "replacement":
+        p.s.pressure_kind = O.PRESSURE_ICE_STRENGTH
+    if case.get("field_forcing"):
+        tu = _fill_parent_like(p, "u", case["top_u"]); tv = _fill_parent_like(p, "v", case["top_v"])
+        p.set_stress("top", O.STRESS_FIELD, fu=tu, fv=tv)
+        ue = _fill_parent_like(p, "u", case["ue_f"]); ve = _fill_parent_like(p, "v", case["ve_f"])
+        p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=ue, ve=ve)
+        # halos of the forcing fields: update_external_stress! (sea_ice_external_stress.jl:72-78,148-152)
+        for arr, (lx, ly) in ((tu, (O.FACE, O.CENTER)), (tv, (O.CENTER, O.FACE)), (ue, (O.FACE, O.CENTER)), (ve, (O.CENTER, O.FACE))):
+            fld = O.Field(arr.ctypes.data_as(O.C.POINTER(O.C.c_double)), arr.shape[1])
+            bcx = 0 if topo[0] == O.PERIODIC else (1 if lx == O.CENTER else 2)
+            bcy = 0 if topo[1] == O.PERIODIC else (1 if ly == O.CENTER else 2)
+            p.L.ora_fill_halo(p.ptr, fld, lx, ly, bcx, bcy)
+    else:
+        if case["top"] is not None:
+            p.set_stress("top", O.STRESS_CONST, tau=case["top"])
+        if case["bottom"] == "semi":
+            p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    p.interior("h")[...] = case["h"]
+    p.interior("aice")[...] = case["a"]
+    p.interior("u")[...] = case["u"]
+    p.interior("v")[...] = case["v"]
+    p.update_state()
+    return p
+
+
+def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0"):
+    g = case["g"]
+    if case.get("field_forcing"):
+        top = (case["top_u"], case["top_v"])
+        bottom = csi.SemiImplicitStress(ue=case["ue_f"], ve=case["ve_f"])
+    else:
+        top = case["top"]
+        bottom = csi.SemiImplicitStress(ue=case["ue"] or None, ve=case["ve"] or None) if case["bottom"] == "semi" else None
+    rheo = csi.ElastoViscoPlasticRheology()
+    if case["pressure"] != "replacement":
+        rheo.pressure_formulation = csi.IceStrength()
+    dyn = csi.SeaIceMomentumEquation(g, coriolis=None if case["coriolis"] is None else csi.FPlane(f=case["coriolis"]),
+                                     rheology=rheo, top_momentum_stress=top, bottom_momentum_stress=bottom,
+                                     solver=csi.SplitExplicitSolver(substeps=case["substeps"]), device=device)
+    model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode)
+    if case.get("field_forcing"):
+        for slot in ("TOP", "BOT"):
+            for comp in ("U", "V"):
+                model.ctx.call("csi_fill_halo_local", csi._lib.F[f"{slot}_{comp}"])
+    csi.set_(model, h=case["h"], aice=case["a"], u=case["u"], v=case["v"])
+    return model

@@ -1,0 +1,178 @@
+"""GPU parity tests of the EVP sub-cycle: HIP kernels (through the C ABI) against the CPU oracle.
+
+Tolerances (fp64), also stated in DESIGN.md:
+  STRICT mode  : bit-for-bit equal to the oracle on every field, given the same ice strength P
+                 (P itself involves exp(): device libm vs glibc may differ in the last bits,
+                 checked to <= 4 ulp).
+  FAST mode    : differs from the oracle by rounding only (hoisted reciprocals, FMA, shared
+                 strain rates): max|du|, max|dv| <= 1e-9 * max(|u|,|v|) after a 120-sub-step
+                 cycle, sigma <= 1e-8 relative to max|sigma|; threshold decisions
+                 (active / marginal / zero, clamp of alpha) agree on every cell of these inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import climaseaice_jl_amd as csi
+
+pytestmark = pytest.mark.gpu
+
+EVP_FIELDS = {"u": lambda m: m.velocities.u, "v": lambda m: m.velocities.v,
+              "s11": lambda m: m.dynamics.auxiliaries.fields.s11, "s22": lambda m: m.dynamics.auxiliaries.fields.s22,
+              "s12": lambda m: m.dynamics.auxiliaries.fields.s12, "alpha": lambda m: m.dynamics.auxiliaries.fields.alpha,
+              "zeta_c": lambda m: m.dynamics.auxiliaries.fields.zeta_c, "zeta_f": lambda m: m.dynamics.auxiliaries.fields.zeta_f,
+              "Delta": lambda m: m.dynamics.auxiliaries.fields.Delta, "P": lambda m: m.dynamics.auxiliaries.fields.P,
+              "un": lambda m: m.dynamics.auxiliaries.fields.un, "vn": lambda m: m.dynamics.auxiliaries.fields.vn}
+
+CASES = {
+    "periodic_patches": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
+    "periodic_full_ice": dict(Nx=96, Ny=80, topo=("periodic", "periodic"), patches=False, random_uv=0.0),
+    "bounded": dict(Nx=40, Ny=56, topo=("bounded", "bounded"), patches=True, random_uv=0.05),
+    "channel": dict(Nx=48, Ny=40, topo=("periodic", "bounded"), patches=True, random_uv=0.02),
+    "latlon_bounded": dict(Nx=40, Ny=40, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.05),
+    "latlon_channel": dict(Nx=64, Ny=40, topo=("periodic", "bounded"), grid="latlon", patches=False, random_uv=0.02),
+    "field_forcing": dict(Nx=48, Ny=48, topo=("periodic", "periodic"), patches=True, field_forcing=True, random_uv=0.03),
+    "ice_strength_nocoriolis": dict(Nx=32, Ny=32, topo=("periodic", "periodic"), pressure="ice_strength", coriolis=None,
+                                    top=None, ue=0.1, patches=False),
+    "ragged": dict(Nx=67, Ny=5, H=3, topo=("periodic", "periodic"), patches=False, random_uv=0.05),
+}
+
+
+def ulp_diff(a, b):
+    ia = a.view(np.int64).astype(np.float64)
+    ib = b.view(np.int64).astype(np.float64)
+    return np.abs(ia - ib).max()
+
+
+def gpu_fields(model):
+    model.synchronize()
+    return {k: f(model).numpy() for k, f in EVP_FIELDS.items()}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_strict_bitwise_vs_oracle(name, oracle_lib):
+    c = cases.make_case(substeps=7, **CASES[name])
+    p = cases.oracle_problem(c)
+    m = cases.csi_model(c, mode="strict")
+    # state after set! / update_state! must already be identical (halo fill + masks)
+    for k in ("u", "v"):
+        assert np.array_equal(EVP_FIELDS[k](m).numpy(), p.f[k]), f"{k} after update_state!"
+    assert np.array_equal(m.ice_thickness.numpy(), p.f["h"])
+    assert np.array_equal(m.ice_concentration.numpy(), p.f["aice"])
+    # initialize_rheology!: P uses exp() -> compare in ulps, then continue from the oracle's P
+    p.initialize_rheology()
+    m.ctx.call("csi_evp_initialize")
+    g = gpu_fields(m)
+    assert ulp_diff(g["P"], p.f["P"]) <= 4
+    assert np.array_equal(g["un"][:, :p.f["un"].shape[1]], p.f["un"]) and np.array_equal(g["vn"], p.f["vn"])
+    m.copy_to_field(m.dynamics.auxiliaries.fields.P, p.f["P"])
+    # the sub-cycle proper, bit for bit
+    p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
+    p.subcycle(c["dt"], 1, c["substeps"])
+    p.L.ora_finalize_rheology(p.ptr)
+    m.ctx.call("csi_evp_subcycle", c["dt"], c["substeps"], 1)
+    m.ctx.call("csi_evp_finalize")
+    g = gpu_fields(m)
+    for k in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
+        assert np.all(np.isfinite(g[k])), k
+        assert np.array_equal(g[k], p.f[k]), f"{name}: {k} differs, max abs diff {np.abs(g[k] - p.f[k]).max():.3e}"
+
+
+FAST_TOL_VEL, FAST_TOL_SIG = 1e-9, 1e-8
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fast_vs_oracle_full_cycle(name, oracle_lib):
+    """time_step_momentum! with the default 120 sub-steps: FAST kernels against the oracle."""
+    c = cases.make_case(substeps=120, **CASES[name])
+    p = cases.oracle_problem(c)
+    m = cases.csi_model(c, mode="fast")
+    p.time_step_momentum(c["dt"])
+    csi.time_step_momentum(m, c["dt"])
+    g = gpu_fields(m)
+    vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+    smax = max(np.abs(p.f["s11"]).max(), np.abs(p.f["s22"]).max(), np.abs(p.f["s12"]).max())
+    for k in ("u", "v"):
+        assert np.all(np.isfinite(g[k]))
+        assert np.abs(g[k] - p.f[k]).max() <= FAST_TOL_VEL * vmax, (k, np.abs(g[k] - p.f[k]).max(), vmax)
+    for k in ("s11", "s22", "s12"):
+        assert np.abs(g[k] - p.f[k]).max() <= FAST_TOL_SIG * smax, (k, np.abs(g[k] - p.f[k]).max(), smax)
+    # masks / threshold decisions: zero velocity cells (no ice, peripheral nodes) are bit-identical sets
+    assert np.array_equal(g["u"] == 0.0, p.f["u"] == 0.0)
+    assert np.array_equal(g["v"] == 0.0, p.f["v"] == 0.0)
+    # alpha clamp decisions agree (alpha- / alpha+ plateaus are the same cells)
+    for bound in (50.0, 300.0):
+        assert np.array_equal(g["alpha"] == bound, p.f["alpha"] == bound)
+    assert np.abs(g["alpha"] - p.f["alpha"]).max() <= 1e-9 * 300.0
+    # diagnostics left by the last sub-step (the reference leaves zeta, Delta of the last viscosity kernel)
+    for k in ("zeta_c", "zeta_f", "Delta"):
+        scale = np.abs(p.f[k]).max()
+        assert np.abs(g[k] - p.f[k]).max() <= 1e-7 * scale, k
+
+
+def test_strict_full_time_step_momentum_matches_oracle(oracle_lib):
+    """Whole time_step_momentum! in STRICT mode, device exp() included: equal to rounding of P."""
+    c = cases.make_case(substeps=20, **CASES["periodic_patches"])
+    p = cases.oracle_problem(c)
+    m = cases.csi_model(c, mode="strict")
+    p.time_step_momentum(c["dt"])
+    csi.time_step_momentum(m, c["dt"])
+    g = gpu_fields(m)
+    vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+    assert np.abs(g["u"] - p.f["u"]).max() <= 1e-12 * vmax
+    assert np.abs(g["v"] - p.f["v"]).max() <= 1e-12 * vmax
+
+
+def test_drag_bound_reference_property():
+    """test/test_time_stepping.jl:56-80 through the product path (RK3 default timestepper)."""
+    g = csi.RectilinearGrid((8, 8), x=(0, 10_000), y=(0, 10_000), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
+    uo = 0.1
+    dyn = csi.SeaIceMomentumEquation(g, bottom_momentum_stress=csi.SemiImplicitStress(ue=uo),
+                                     rheology=csi.ElastoViscoPlasticRheology(), solver=csi.SplitExplicitSolver(substeps=10))
+    for mode in ("strict", "fast"):
+        model = csi.SeaIceModel(g, dynamics=dyn, mode=mode)
+        csi.set_(model, h=1, ℵ=1, u=0, v=0)
+        for _ in range(20):
+            csi.time_step(model, 60)
+        model.synchronize()
+        u = model.velocities.u.interior_numpy()
+        assert np.all(np.isfinite(u))
+        assert u.max() > 0
+        assert u.max() <= uo
+
+
+@pytest.mark.parametrize("N", [2048])
+def test_full_size_properties(N):
+    """BASELINE size (2048^2 f-plane, periodic): size-independent properties.
+    (a) FAST == STRICT to the stated tolerance after 10 sub-steps;
+    (b) translation invariance on the periodic uniform grid: shifting the inputs by (sx, sy)
+        cells shifts the outputs by the same amount bit for bit (halo / wrap logic at full size);
+    (c) everything finite, |u| bounded."""
+    kw = dict(Nx=N, Ny=N, topo=("periodic", "periodic"), patches=True, random_uv=0.02, substeps=10)
+    c = cases.make_case(**kw)
+    out = {}
+    for mode in ("strict", "fast"):
+        m = cases.csi_model(c, mode=mode)
+        csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        out[mode] = {k: EVP_FIELDS[k](m).interior_numpy().copy() for k in ("u", "v", "s11", "s22", "s12")}
+        del m
+    vmax = max(np.abs(out["strict"]["u"]).max(), np.abs(out["strict"]["v"]).max())
+    smax = np.abs(out["strict"]["s11"]).max()
+    for k in ("u", "v"):
+        assert np.all(np.isfinite(out["fast"][k]))
+        assert np.abs(out["fast"][k] - out["strict"][k]).max() <= FAST_TOL_VEL * vmax
+    for k in ("s11", "s22", "s12"):
+        assert np.abs(out["fast"][k] - out["strict"][k]).max() <= FAST_TOL_SIG * smax
+    assert vmax < 10.0
+    sx, sy = 517, 1031
+    c2 = dict(c)
+    for k in ("h", "a", "u", "v"):
+        c2[k] = np.roll(c[k], (sy, sx), axis=(0, 1))
+    m = cases.csi_model(c2, mode="fast")
+    csi.time_step_momentum(m, c["dt"])
+    m.synchronize()
+    for k in ("u", "v", "s11", "s22", "s12"):
+        got = EVP_FIELDS[k](m).interior_numpy()
+        assert np.array_equal(got, np.roll(out["fast"][k], (sy, sx), axis=(0, 1))), k
