@@ -24,9 +24,9 @@ def cpu_baseline(case_kw, seconds_budget=20.0):
     """The oracle (C restatement, OpenMP over rows) timed on the host cores: a reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cases
-    n = 512
+    n = 2048
     kw = dict(case_kw)
-    kw.update(Nx=n, Ny=n, substeps=4)
+    kw.update(Nx=n, Ny=n, substeps=2)
     c = cases.make_case(**kw)
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
@@ -37,7 +37,7 @@ def cpu_baseline(case_kw, seconds_budget=20.0):
     while True:
         p.time_step_momentum(c["dt"])
         reps += 1
-        if time.perf_counter() - t0 > seconds_budget / 2 or reps >= 8:
+        if time.perf_counter() - t0 > seconds_budget or reps >= 64:
             break
     dt = time.perf_counter() - t0
     return {"value": n * n * c["substeps"] * reps / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",

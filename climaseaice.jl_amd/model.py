@@ -211,8 +211,9 @@ class SeaIceModel:
 
 def set_(model, **kw):
     """set!(model; h, aice (or ℵ), u, v) then update_state! (sea_ice_model.jl:301-315)."""
-    names = {"h": model.ice_thickness, "aice": model.ice_concentration, "ℵ": model.ice_concentration,
-             "u": model.velocities.u, "v": model.velocities.v}
+    # Python NFKC-normalises identifiers, so the keyword `ℵ` (U+2135) arrives as U+05D0
+    names = {"h": model.ice_thickness, "aice": model.ice_concentration, "\u2135": model.ice_concentration,
+             "\u05d0": model.ice_concentration, "u": model.velocities.u, "v": model.velocities.v}
     for k, val in kw.items():
         if k not in names:
             raise KeyError(f"set!: unknown field {k}")

@@ -5,9 +5,16 @@ Tolerances (fp64), also stated in DESIGN.md:
                  (P itself involves exp(): device libm vs glibc may differ in the last bits,
                  checked to <= 4 ulp).
   FAST mode    : differs from the oracle by rounding only (hoisted reciprocals, FMA, shared
-                 strain rates): max|du|, max|dv| <= 1e-9 * max(|u|,|v|) after a 120-sub-step
-                 cycle, sigma <= 1e-8 relative to max|sigma|; threshold decisions
-                 (active / marginal / zero, clamp of alpha) agree on every cell of these inputs.
+                 strain rates).  Measured on MI355X: <= 3e-15 * max|u| on u, v and <= 1e-14 *
+                 max|sigma| on sigma after a full 120-sub-step cycle on well-conditioned inputs.
+                 Asserted: max|du|, max|dv| <= 1e-12 * max(|u|,|v|), sigma <= 1e-11 * max|sigma|.
+                 The mEVP iteration itself is chaotic where the pack is rigid (Delta = Delta_min and
+                 gamma > alpha+: a uniformly moving, fully compact pack): there the ORACLE's own
+                 answer moves by 1e-3 relative under a 1e-15 relative perturbation of its inputs
+                 (scripts/diag_fast_tolerance.py), so for every case the bound is
+                 max(stated tolerance, 10 x the oracle's measured self-sensitivity).
+                 Threshold decisions (zero-velocity cells, alpha clamp plateaus) agree exactly
+                 on the well-conditioned cases.
 """
 import numpy as np
 import pytest
@@ -79,36 +86,71 @@ def test_strict_bitwise_vs_oracle(name, oracle_lib):
         assert np.array_equal(g[k], p.f[k]), f"{name}: {k} differs, max abs diff {np.abs(g[k] - p.f[k]).max():.3e}"
 
 
-FAST_TOL_VEL, FAST_TOL_SIG = 1e-9, 1e-8
+FAST_TOL_VEL, FAST_TOL_SIG = 1e-12, 1e-11
+
+
+def oracle_self_sensitivity(c, fields=("u", "v", "s11", "s22", "s12")):
+    """Conditioning of the EVP iteration on this input: oracle(inputs) vs oracle(inputs * (1 + 1e-15 N(0,1)))."""
+    p = cases.oracle_problem(c)
+    p.time_step_momentum(c["dt"])
+    rng = np.random.default_rng(11)
+    c2 = dict(c)
+    for k in ("u", "v", "h"):
+        c2[k] = c[k] * (1 + 1e-15 * rng.standard_normal(c[k].shape))
+    p2 = cases.oracle_problem(c2)
+    p2.time_step_momentum(c["dt"])
+    return p, {k: np.abs(p2.f[k] - p.f[k]).max() for k in fields}
 
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_fast_vs_oracle_full_cycle(name, oracle_lib):
     """time_step_momentum! with the default 120 sub-steps: FAST kernels against the oracle."""
     c = cases.make_case(substeps=120, **CASES[name])
-    p = cases.oracle_problem(c)
+    p, sens = oracle_self_sensitivity(c)
     m = cases.csi_model(c, mode="fast")
-    p.time_step_momentum(c["dt"])
     csi.time_step_momentum(m, c["dt"])
     g = gpu_fields(m)
     vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
     smax = max(np.abs(p.f["s11"]).max(), np.abs(p.f["s22"]).max(), np.abs(p.f["s12"]).max())
+    well_conditioned = max(sens["u"], sens["v"]) <= 1e-13 * vmax
     for k in ("u", "v"):
         assert np.all(np.isfinite(g[k]))
-        assert np.abs(g[k] - p.f[k]).max() <= FAST_TOL_VEL * vmax, (k, np.abs(g[k] - p.f[k]).max(), vmax)
+        d = np.abs(g[k] - p.f[k]).max()
+        assert d <= max(FAST_TOL_VEL * vmax, 10 * sens[k]), (k, d, vmax, sens[k])
     for k in ("s11", "s22", "s12"):
-        assert np.abs(g[k] - p.f[k]).max() <= FAST_TOL_SIG * smax, (k, np.abs(g[k] - p.f[k]).max(), smax)
+        d = np.abs(g[k] - p.f[k]).max()
+        assert d <= max(FAST_TOL_SIG * smax, 10 * sens[k]), (k, d, smax, sens[k])
     # masks / threshold decisions: zero velocity cells (no ice, peripheral nodes) are bit-identical sets
     assert np.array_equal(g["u"] == 0.0, p.f["u"] == 0.0)
     assert np.array_equal(g["v"] == 0.0, p.f["v"] == 0.0)
-    # alpha clamp decisions agree (alpha- / alpha+ plateaus are the same cells)
-    for bound in (50.0, 300.0):
-        assert np.array_equal(g["alpha"] == bound, p.f["alpha"] == bound)
-    assert np.abs(g["alpha"] - p.f["alpha"]).max() <= 1e-9 * 300.0
-    # diagnostics left by the last sub-step (the reference leaves zeta, Delta of the last viscosity kernel)
-    for k in ("zeta_c", "zeta_f", "Delta"):
-        scale = np.abs(p.f[k]).max()
-        assert np.abs(g[k] - p.f[k]).max() <= 1e-7 * scale, k
+    if well_conditioned:
+        # alpha clamp decisions agree (alpha- / alpha+ plateaus are the same cells)
+        for bound in (50.0, 300.0):
+            assert np.array_equal(g["alpha"] == bound, p.f["alpha"] == bound)
+        assert np.abs(g["alpha"] - p.f["alpha"]).max() <= 1e-11 * 300.0
+        # diagnostics of the last sub-step (the reference leaves zeta, Delta of the last viscosity kernel)
+        for k in ("zeta_c", "zeta_f", "Delta"):
+            scale = np.abs(p.f[k]).max()
+            assert np.abs(g[k] - p.f[k]).max() <= 1e-10 * scale, k
+
+
+@pytest.mark.parametrize("name", ["periodic_full_ice", "ice_strength_nocoriolis", "periodic_patches", "latlon_bounded"])
+@pytest.mark.parametrize("k", [1, 2])
+def test_fast_few_substeps_tight(name, k, oracle_lib):
+    """Before the iteration's own chaos can act (1-2 sub-steps) FAST equals the oracle to rounding on every case,
+    including the rigid-pack ones."""
+    c = cases.make_case(substeps=k, **CASES[name])
+    p = cases.oracle_problem(c)
+    p.time_step_momentum(c["dt"])
+    m = cases.csi_model(c, mode="fast")
+    csi.time_step_momentum(m, c["dt"])
+    g = gpu_fields(m)
+    vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+    smax = max(np.abs(p.f["s11"]).max(), np.abs(p.f["s22"]).max(), np.abs(p.f["s12"]).max())
+    for f in ("u", "v"):
+        assert np.abs(g[f] - p.f[f]).max() <= 1e-13 * vmax
+    for f in ("s11", "s22", "s12"):
+        assert np.abs(g[f] - p.f[f]).max() <= 1e-10 * smax
 
 
 def test_strict_full_time_step_momentum_matches_oracle(oracle_lib):
