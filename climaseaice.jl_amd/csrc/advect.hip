@@ -15,6 +15,9 @@
 #include "csi_kernels.h"
 
 namespace csi {
+// Julia's max(a, b) for floats: NaN if either is NaN
+__device__ __forceinline__ double jmax(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
+
 namespace adv {
 
 #define WENO_EPS 1e-8
@@ -130,8 +133,8 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
     const double an = A.from_cache ? A.am(i, j) : A.a(i, j);
     double hp = hn + A.dt * A.Gh(i, j);
     double ap = an + A.dt * A.Ga(i, j);
-    ap = fmax(0.0, ap);
-    hp = fmax(0.0, hp);
+    ap = jmax(0.0, ap);
+    hp = jmax(0.0, hp);
     ap = (hp == 0) ? 0.0 : ap;
     hp = (ap == 0) ? 0.0 : hp;
     const double Vp = hp * ap;

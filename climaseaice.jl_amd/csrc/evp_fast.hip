@@ -35,11 +35,26 @@ __device__ __forceinline__ double coef(const FastCoef& c, int which, int j) {
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
-#define CELL_IJ(r)                                                        \
-    const int i = (r).i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);  \
-    const int jw = (r).j0 + (int)(blockIdx.y * blockDim.y + threadIdx.y); \
-    const int j = __builtin_amdgcn_readfirstlane(jw);                     \
-    if (i > (r).i1 || j > (r).j1) return;
+// Block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an
+// XCD, MI355X_MICROARCH.md "Workgroup dispatch"); each XCD has its own L2, so a tile's halo rows
+// and the cache lines it shares with its x-neighbour are re-fetched through the fabric unless the
+// neighbouring tile runs on the same XCD.  The remap gives every XCD one contiguous band of tile
+// rows, walked in x-fastest order (speed only: any placement gives the same results).  Waves start
+// at the parent row start (i = 1 - Hx), which is 64-byte aligned for even ld.
+struct TileMap {
+    int gx, ntiles, per_xcd;
+    int ibase, jbase;
+};
+constexpr int TILE_X = 64, TILE_Y = 4;
+
+#define CELL_IJ(r, tm)                                                          \
+    const int b_ = (int)blockIdx.x;                                             \
+    const int t_ = (b_ & 7) * (tm).per_xcd + (b_ >> 3);                         \
+    if ((b_ >> 3) >= (tm).per_xcd || t_ >= (tm).ntiles) return;                 \
+    const int by_ = t_ / (tm).gx, bx_ = t_ - by_ * (tm).gx;                     \
+    const int i = (tm).ibase + bx_ * TILE_X + (int)threadIdx.x;                 \
+    const int j = __builtin_amdgcn_readfirstlane((tm).jbase + by_ * TILE_Y + (int)threadIdx.y); \
+    if (i < (r).i0 || i > (r).i1 || j > (r).j1) return;
 
 __global__ void __launch_bounds__(256) k_init(EvpDev P, Range r) {
     const int i = r.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -54,8 +69,8 @@ __global__ void __launch_bounds__(256) k_init(EvpDev P, Range r) {
 // stress phase
 // ------------------------------------------------------------------------------------------------
 template <bool UNI>
-__global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c) {
-    CELL_IJ(r)
+__global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
     // u, v neighbourhood: u[i-1..i+1][j-1..j+1] (no (i-1, j+1)), v likewise (no (i+1, j-1))
     const double u_mm = P.u(i - 1, j - 1), u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1);
     const double u_m0 = P.u(i - 1, j),     u_00 = P.u(i, j),     u_p0 = P.u(i + 1, j);
@@ -183,8 +198,8 @@ __device__ __forceinline__ void stress_y(const StressDev& s, int i, int j, doubl
 // velocity phases
 // ------------------------------------------------------------------------------------------------
 template <bool UNI, bool MASK>
-__global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img, FastCoef c) {
-    CELL_IJ(r)
+__global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
     const double h0 = P.h(i, j), hm = P.h(i - 1, j), a0 = P.a(i, j), am = P.a(i - 1, j);
     const double al0 = P.al(i, j), alm = P.al(i - 1, j);
     const double u = P.u(i, j), un = P.un(i, j);
@@ -223,8 +238,8 @@ __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img,
 }
 
 template <bool UNI, bool MASK>
-__global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img, FastCoef c) {
-    CELL_IJ(r)
+__global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
     const double h0 = P.h(i, j), hm = P.h(i, j - 1), a0 = P.a(i, j), am = P.a(i, j - 1);
     const double al0 = P.al(i, j), alm = P.al(i, j - 1);
     const double v = P.v(i, j), vn = P.vn(i, j);
@@ -279,31 +294,47 @@ void launch_fast_init(const EvpDev& P, const Range& r, hipStream_t s) {
     dim3 b(64, 4);
     hipLaunchKernelGGL(fast::k_init, grid_for(r, b), b, 0, s, P, r);
 }
+static fast::TileMap tile_map(const EvpDev& P, const Range& r, dim3& grid) {
+    fast::TileMap tm;
+    tm.ibase = 1 - P.g.Hx;                               // parent row start (aligned), <= r.i0
+    if (tm.ibase > r.i0) tm.ibase = r.i0;
+    tm.jbase = r.j0;
+    tm.gx = (r.i1 - tm.ibase + fast::TILE_X) / fast::TILE_X;
+    const int gy = (r.j1 - r.j0 + fast::TILE_Y) / fast::TILE_Y;
+    tm.ntiles = tm.gx * gy;
+    tm.per_xcd = (tm.ntiles + 7) / 8;
+    grid = dim3((unsigned)(tm.per_xcd * 8), 1, 1);
+    return tm;
+}
+
 void launch_fast_stress(const EvpDev& P, const Range& r, const FastCoef& c, hipStream_t s) {
-    dim3 b(64, 4);
-    if (c.uniform) hipLaunchKernelGGL(fast::k_stress<true>, grid_for(r, b), b, 0, s, P, r, c);
-    else hipLaunchKernelGGL(fast::k_stress<false>, grid_for(r, b), b, 0, s, P, r, c);
+    dim3 b(fast::TILE_X, fast::TILE_Y), g;
+    const fast::TileMap tm = tile_map(P, r, g);
+    if (c.uniform) hipLaunchKernelGGL(fast::k_stress<true>, g, b, 0, s, P, r, c, tm);
+    else hipLaunchKernelGGL(fast::k_stress<false>, g, b, 0, s, P, r, c, tm);
 }
 void launch_fast_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s) {
-    dim3 b(64, 4);
+    dim3 b(fast::TILE_X, fast::TILE_Y), g;
+    const fast::TileMap tm = tile_map(P, r, g);
     const bool m = P.g.has_mask != 0;
     if (c.uniform) {
-        if (m) hipLaunchKernelGGL((fast::k_ustep<true, true>), grid_for(r, b), b, 0, s, P, r, im, c);
-        else hipLaunchKernelGGL((fast::k_ustep<true, false>), grid_for(r, b), b, 0, s, P, r, im, c);
+        if (m) hipLaunchKernelGGL((fast::k_ustep<true, true>), g, b, 0, s, P, r, im, c, tm);
+        else hipLaunchKernelGGL((fast::k_ustep<true, false>), g, b, 0, s, P, r, im, c, tm);
     } else {
-        if (m) hipLaunchKernelGGL((fast::k_ustep<false, true>), grid_for(r, b), b, 0, s, P, r, im, c);
-        else hipLaunchKernelGGL((fast::k_ustep<false, false>), grid_for(r, b), b, 0, s, P, r, im, c);
+        if (m) hipLaunchKernelGGL((fast::k_ustep<false, true>), g, b, 0, s, P, r, im, c, tm);
+        else hipLaunchKernelGGL((fast::k_ustep<false, false>), g, b, 0, s, P, r, im, c, tm);
     }
 }
 void launch_fast_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s) {
-    dim3 b(64, 4);
+    dim3 b(fast::TILE_X, fast::TILE_Y), g;
+    const fast::TileMap tm = tile_map(P, r, g);
     const bool m = P.g.has_mask != 0;
     if (c.uniform) {
-        if (m) hipLaunchKernelGGL((fast::k_vstep<true, true>), grid_for(r, b), b, 0, s, P, r, im, c);
-        else hipLaunchKernelGGL((fast::k_vstep<true, false>), grid_for(r, b), b, 0, s, P, r, im, c);
+        if (m) hipLaunchKernelGGL((fast::k_vstep<true, true>), g, b, 0, s, P, r, im, c, tm);
+        else hipLaunchKernelGGL((fast::k_vstep<true, false>), g, b, 0, s, P, r, im, c, tm);
     } else {
-        if (m) hipLaunchKernelGGL((fast::k_vstep<false, true>), grid_for(r, b), b, 0, s, P, r, im, c);
-        else hipLaunchKernelGGL((fast::k_vstep<false, false>), grid_for(r, b), b, 0, s, P, r, im, c);
+        if (m) hipLaunchKernelGGL((fast::k_vstep<false, true>), g, b, 0, s, P, r, im, c, tm);
+        else hipLaunchKernelGGL((fast::k_vstep<false, false>), g, b, 0, s, P, r, im, c, tm);
     }
 }
 

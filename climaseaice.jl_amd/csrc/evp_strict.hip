@@ -29,6 +29,9 @@ __device__ __forceinline__ double azm(const GridDev& g, int ly, int j) {
     return ly == LOC_C ? g.azc[j] : g.azf[j];
 }
 
+// Julia's max(a, b) for floats: NaN if either is NaN (fmax would drop the NaN)
+__device__ __forceinline__ double jmax(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
+
 __device__ __forceinline__ double ice_mass(const EvpDev& P, int i, int j) {   // ClimaSeaIce.jl:42
     return P.h(i, j) * P.rho * P.a(i, j);
 }
@@ -89,8 +92,8 @@ __global__ void k_visc(EvpDev P, Range r) {
     double df = e11f + e22f;
     double sc = sqrt((e11c - e22c) * (e11c - e22c) + 4 * (e12c * e12c));
     double sf = sqrt((e11f - e22f) * (e11f - e22f) + 4 * (e12f * e12f));
-    double Dc = fmax(sqrt(dc * dc + (sc * sc) * em2), Dm);
-    double Df = fmax(sqrt(df * df + (sf * sf) * em2), Dm);
+    double Dc = jmax(sqrt(dc * dc + (sc * sc) * em2), Dm);
+    double Df = jmax(sqrt(df * df + (sf * sf) * em2), Dm);
     double Pc = P.P(i, j);
     double Pf = AVG4_FF(P_at, P, i, j);
     P.zf(i, j) = Pf / (2 * Df);
@@ -250,8 +253,9 @@ __global__ void k_ustep(EvpDev P, Range r, ImageSpec im) {
     double uF = 0.0;
     bool marginal = (mi > EPS64) & (ai > EPS64);
     bool active_ice = (mi >= P.min_mass) & (ai >= P.min_conc);
-    double active = peripheral_u(P.g, i, j) ? 0.0 : 1.0;
-    double res = (active_ice ? uD : (marginal ? uF : 0.0)) * active;
+    // `... * active` with a Julia Bool: false is a strong zero (sign kept), :228
+    double sel = active_ice ? uD : (marginal ? uF : 0.0);
+    double res = peripheral_u(P.g, i, j) ? copysign(0.0, sel) : sel;
     store_with_images(P.u, P.g, im, i, j, res);
 }
 
@@ -283,8 +287,8 @@ __global__ void k_vstep(EvpDev P, Range r, ImageSpec im) {
     double vF = 0.0;
     bool marginal = (mi > EPS64) & (ai > EPS64);
     bool active_ice = (mi >= P.min_mass) & (ai >= P.min_conc);
-    double active = peripheral_v(P.g, i, j) ? 0.0 : 1.0;
-    double res = (active_ice ? vD : (marginal ? vF : 0.0)) * active;
+    double sel = active_ice ? vD : (marginal ? vF : 0.0);
+    double res = peripheral_v(P.g, i, j) ? copysign(0.0, sel) : sel;
     store_with_images(P.v, P.g, im, i, j, res);
 }
 

@@ -11,6 +11,9 @@
 #include "csi_kernels.h"
 
 namespace csi {
+// Julia's max(a, b) for floats: NaN if either is NaN
+__device__ __forceinline__ double jmax(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
+
 
 __device__ __forceinline__ double latent_heat(const SlabDev& s, double T) {
     return s.L0 + (s.rho_l * s.c_l / s.rho_pure - s.c_i) * (T - s.T0);
@@ -33,13 +36,15 @@ __global__ void __launch_bounds__(256) k_slab(SlabDev s, GridDev g, FRef h, FRef
     const double wb = (Qi - Qb) / Eb;
     double dtV = wu + wb;
     double V1 = hn * an + dt * dtV;
-    V1 = fmax(0.0, V1);
+    V1 = jmax(0.0, V1);
     dtV = (V1 - hn * an) / dt;
-    const double freezing = (dtV >= 0) ? 1.0 : 0.0, melting = (dtV < 0) ? 1.0 : 0.0;
-    const double daf = (1 - an) / hc * dtV * freezing;
-    const double dam = an / (2 * hn) * dtV * melting;
+    // `x * flag` with a Julia Bool: false is a strong zero (NaN * false == 0, sign kept)
+    const bool freezing = (dtV >= 0), melting = (dtV < 0);
+    const double xf = (1 - an) / hc * dtV, xm = an / (2 * hn) * dtV;
+    const double daf = freezing ? xf : copysign(0.0, xf);
+    const double dam = melting ? xm : copysign(0.0, xm);
     double ap = an + dt * (daf + dam);
-    ap = fmax(0.0, ap);
+    ap = jmax(0.0, ap);
     double hp = V1 / ap;
     hp = (ap <= 0) ? 0.0 : hp;
     ap = (dtV == 0) ? an : ap;

@@ -22,6 +22,7 @@
 #define OMP_ROWS
 #endif
 
+static inline double jmax(double a, double b);
 #define C_ ORA_LOC_CENTER
 #define F_ ORA_LOC_FACE
 
@@ -158,8 +159,8 @@ void ora_compute_viscosities(ora_problem* g, int i0, int i1, int j0, int j1) {
             double df = e11f + e22f;
             double sc = sqrt((e11c - e22c) * (e11c - e22c) + 4 * (e12c * e12c));
             double sf = sqrt((e11f - e22f) * (e11f - e22f) + 4 * (e12f * e12f));
-            double Dc = fmax(sqrt(dc * dc + (sc * sc) * em2), Dm);
-            double Df = fmax(sqrt(df * df + (sf * sf) * em2), Dm);
+            double Dc = jmax(sqrt(dc * dc + (sc * sc) * em2), Dm);
+            double Df = jmax(sqrt(df * df + (sf * sf) * em2), Dm);
             double Pc = AT(g, g->P, i, j);
             double Pf = AVG4_FF(P_at, g, i, j);
 
@@ -169,6 +170,8 @@ void ora_compute_viscosities(ora_problem* g, int i0, int i1, int j0, int j1) {
         }
 }
 
+/* Julia's max(a, b) for floats: NaN if either is NaN (C's fmax would drop the NaN) */
+static inline double jmax(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
 static inline double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 /* ------------------------------------------------------------------------ */
@@ -394,8 +397,10 @@ void ora_u_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
             double uF = 0.0;                                                             /* free_drift `nothing`, sbfd:129 */
             int marginal = (mi > EPS64) & (ai > EPS64);                                  /* :224 */
             int active_ice = (mi >= g->min_mass) & (ai >= g->min_conc);                  /* :225 */
-            double active = ora_peripheral_u(g, i, j) ? 0.0 : 1.0;                       /* :226 */
-            AT(g, g->u, i, j) = (active_ice ? uD : (marginal ? uF : 0.0)) * active;      /* :228 */
+            int active = !ora_peripheral_u(g, i, j);                                     /* :226 */
+            double sel = active_ice ? uD : (marginal ? uF : 0.0);
+            /* `sel * active` with a Julia Bool: false is a strong zero (sign of sel kept)   :228 */
+            AT(g, g->u, i, j) = active ? sel : copysign(0.0, sel);
         }
 }
 /* _v_velocity_step!, split_explicit_momentum_equations.jl:231-264 */
@@ -414,8 +419,9 @@ void ora_v_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
             double vF = 0.0;
             int marginal = (mi > EPS64) & (ai > EPS64);
             int active_ice = (mi >= g->min_mass) & (ai >= g->min_conc);
-            double active = ora_peripheral_v(g, i, j) ? 0.0 : 1.0;
-            AT(g, g->v, i, j) = (active_ice ? vD : (marginal ? vF : 0.0)) * active;
+            int active = !ora_peripheral_v(g, i, j);
+            double sel = active_ice ? vD : (marginal ? vF : 0.0);
+            AT(g, g->v, i, j) = active ? sel : copysign(0.0, sel);
         }
 }
 
@@ -622,8 +628,8 @@ void ora_dynamic_step_tracers(ora_problem* g, double dt, int from_cache) {
             double an = from_cache ? AT(g, g->am, i, j) : AT(g, g->aice, i, j);
             double hp = hn + dt * AT(g, g->Gh, i, j);
             double ap = an + dt * AT(g, g->Ga, i, j);
-            ap = fmax(0.0, ap);
-            hp = fmax(0.0, hp);
+            ap = jmax(0.0, ap);
+            hp = jmax(0.0, hp);
             ap = (hp == 0) ? 0.0 : ap;
             hp = (ap == 0) ? 0.0 : hp;
             double Vp = hp * ap;
@@ -686,12 +692,13 @@ static double slab_internal_flux(const ora_slab* s, double Tu, double Tb, double
 }
 /* concentration_thermodynamic_step(::ProportionalEvolution), thermodynamic_time_step.jl:358-370 */
 static double concentration_step(double dtV, double an, double hn, double hc, double dt) {
-    double freezing = (dtV >= 0) ? 1.0 : 0.0;
-    double melting = (dtV < 0) ? 1.0 : 0.0;
-    double daf = (1 - an) / hc * dtV * freezing;
-    double dam = an / (2 * hn) * dtV * melting;
+    /* `x * flag` with a Julia Bool: false is a strong zero (NaN * false == 0, sign kept) */
+    int freezing = (dtV >= 0), melting = (dtV < 0);
+    double xf = (1 - an) / hc * dtV, xm = an / (2 * hn) * dtV;
+    double daf = freezing ? xf : copysign(0.0, xf);
+    double dam = melting ? xm : copysign(0.0, xm);
     double ap = an + dt * (daf + dam);
-    return fmax(0.0, ap);
+    return jmax(0.0, ap);
 }
 /* _ice_thermodynamic_time_step! :75-118 with thermodynamic_tendency (slab_thermodynamics_tendencies.jl:74-135,
  * PrescribedTemperature branch), ice_melt_freeze_tendency (:28-68), ice_volume_update (:304-324) */
@@ -712,7 +719,7 @@ void ora_slab_thermo_step(const ora_slab* s, int64_t n, double* h, double* aice,
         double dtV = wu + wb;
         /* ice_volume_update :304-324 */
         double V1 = hn * an + dt * dtV;
-        V1 = fmax(0.0, V1);
+        V1 = jmax(0.0, V1);
         dtV = (V1 - hn * an) / dt;
         double ap = concentration_step(dtV, an, hn, hc, dt);
         double hp = V1 / ap;

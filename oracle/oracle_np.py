@@ -186,7 +186,8 @@ class NP:
             i0 = r[0]
             cols = np.arange(i0, r[1] + 1)
             active[:, (cols == 1) | (cols == self.Nx + 1)] = 0.0
-        V(u, r)[...] = np.where(active_ice, uD, 0.0) * active
+        sel = np.where(active_ice, uD, 0.0)
+        V(u, r)[...] = np.where(active != 0, sel, np.copysign(0.0, sel))   # Julia Bool: strong zero
 
     def v_step(self, dt, r=None):
         f, V, rv, dy = self.fld, self.V, self.rowvec, self.dy
@@ -229,7 +230,8 @@ class NP:
         if self.topo[1] == 1:
             rows = np.arange(r[2], r[3] + 1)
             active[(rows == 1) | (rows == self.Ny + 1), :] = 0.0
-        V(v, r)[...] = np.where(active_ice, vD, 0.0) * active
+        sel = np.where(active_ice, vD, 0.0)
+        V(v, r)[...] = np.where(active != 0, sel, np.copysign(0.0, sel))
 
     # ---- local halo fill (upstream) ------------------------------------------------
     def fill_halo(self, name, lx, ly):

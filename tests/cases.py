@@ -14,7 +14,7 @@ import climaseaice_jl_amd as csi
 def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
-              field_forcing=False):
+              field_forcing=False, land=0.0):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing)
@@ -49,6 +49,20 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
     if topo[1] == "bounded":
         v[0, :] = 0.0
         v[-1, :] = 0.0
+    c["mask"] = None
+    if land:
+        # immersed "land": union of seeded discs covering about `land` of the domain
+        lr = np.random.default_rng(5)
+        wet = np.ones((Ny, Nx), dtype=bool)
+        II, JJ = np.meshgrid(np.arange(Nx), np.arange(Ny))
+        while 1.0 - wet.mean() < land:
+            cx, cy, rad = lr.integers(0, Nx), lr.integers(0, Ny), lr.integers(2, max(3, min(Nx, Ny) // 6))
+            ddx = np.minimum(np.abs(II - cx), Nx - np.abs(II - cx)) if topo[0] == "periodic" else np.abs(II - cx)
+            ddy = np.minimum(np.abs(JJ - cy), Ny - np.abs(JJ - cy)) if topo[1] == "periodic" else np.abs(JJ - cy)
+            wet &= (ddx ** 2 + ddy ** 2) > rad ** 2
+        c["mask"] = wet
+        h = np.where(wet, h, 0.0)
+        a = np.where(wet, a, 0.0)
     c.update(h=h, a=a, u=u, v=v)
     if field_forcing:
         c["top_u"] = 0.01 * (1 + 0.5 * np.sin(2 * np.pi * X)) * np.ones((nyu, 1))[:, :1] * np.ones((1, 1))
@@ -97,6 +111,17 @@ def oracle_problem(case, omp=False):
             p.set_stress("top", O.STRESS_CONST, tau=case["top"])
         if case["bottom"] == "semi":
             p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    if case.get("mask") is not None:
+        s_ = p.s
+        full = np.zeros(p.f["h"].shape, dtype=np.uint8)
+        full[s_.Hy:s_.Hy + s_.Ny, s_.Hx:s_.Hx + s_.Nx] = case["mask"]
+        if topo[0] == O.PERIODIC:
+            full[:, :s_.Hx] = full[:, s_.Nx:s_.Nx + s_.Hx]
+            full[:, s_.Nx + s_.Hx:] = full[:, s_.Hx:2 * s_.Hx]
+        if topo[1] == O.PERIODIC:
+            full[:s_.Hy, :] = full[s_.Ny:s_.Ny + s_.Hy, :]
+            full[s_.Ny + s_.Hy:, :] = full[s_.Hy:2 * s_.Hy, :]
+        p.set_mask(full)
     p.interior("h")[...] = case["h"]
     p.interior("aice")[...] = case["a"]
     p.interior("u")[...] = case["u"]
@@ -124,5 +149,7 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
         for slot in ("TOP", "BOT"):
             for comp in ("U", "V"):
                 model.ctx.call("csi_fill_halo_local", csi._lib.F[f"{slot}_{comp}"])
+    if case.get("mask") is not None:
+        model.set_mask(case["mask"])
     csi.set_(model, h=case["h"], aice=case["a"], u=case["u"], v=case["v"])
     return model

@@ -1,0 +1,66 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/generate_golden.py with the C oracle):
+CPU: the oracle reproduces them bit for bit and the seeded inputs are reproducible;
+GPU: the STRICT HIP kernels reproduce them bit for bit, the FAST kernels to the stated tolerance."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+OUT_FIELDS = ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta")
+
+
+def test_fixtures_present():
+    assert len(FILES) >= 3
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_oracle_reproduces_golden(path, oracle_lib):
+    d = np.load(path)
+    kw = json.loads(str(d["case_json"]))
+    kw["topo"] = tuple(kw["topo"])
+    for nsub in (1, 10):
+        c = cases.make_case(substeps=nsub, **kw)
+        for k in ("h", "a", "u", "v"):
+            assert np.array_equal(c[k], d[f"in_{k}"]), "seeded inputs changed"
+        p = cases.oracle_problem(c)
+        p.initialize_rheology()
+        assert np.abs(p.f["P"] - d["P"]).max() <= 4e-16 * np.abs(d["P"]).max()   # exp(): libm build dependent
+        p.f["P"][...] = d["P"]
+        p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
+        p.subcycle(c["dt"], 1, nsub)
+        p.L.ora_finalize_rheology(p.ptr)
+        for k in OUT_FIELDS:
+            assert np.array_equal(p.f[k], d[f"{k}_after{nsub}"]), (k, nsub)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_hip_kernels_reproduce_golden(path, mode):
+    import climaseaice_jl_amd as csi
+    from test_gpu_evp import EVP_FIELDS
+    d = np.load(path)
+    kw = json.loads(str(d["case_json"]))
+    kw["topo"] = tuple(kw["topo"])
+    for nsub in (1, 10):
+        c = cases.make_case(substeps=nsub, **kw)
+        m = cases.csi_model(c, mode=mode)
+        m.ctx.call("csi_evp_initialize")
+        m.copy_to_field(m.dynamics.auxiliaries.fields.P, d["P"])
+        m.ctx.call("csi_evp_subcycle", c["dt"], nsub, 1)
+        m.ctx.call("csi_evp_finalize")
+        m.synchronize()
+        vmax = max(np.abs(d[f"u_after{nsub}"]).max(), np.abs(d[f"v_after{nsub}"]).max())
+        for k in OUT_FIELDS:
+            got, want = EVP_FIELDS[k](m).numpy(), d[f"{k}_after{nsub}"]
+            if mode == "strict":
+                assert np.array_equal(got, want), (k, nsub)
+            else:
+                scale = vmax if k in ("u", "v") else np.abs(want).max()
+                assert np.abs(got - want).max() <= 1e-11 * scale, (k, nsub, np.abs(got - want).max(), scale)

@@ -1,0 +1,173 @@
+"""GPU parity of the phases around the sub-cycle and of whole model steps against the oracle:
+WENO / upwind tracer tendencies, tracer update (FE and RK3 forms), immersed masks, FE and RK3
+time_step!, bare-ice slab thermodynamics."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import climaseaice_jl_amd as csi
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def anticyclone_case(N, H=4, **kw):
+    """Config 2 (BASELINE.json): periodic N^2, 1 km spacing, prescribed cyclonic eddy, h0 sinusoid, aice < 1."""
+    c = cases.make_case(Nx=N, Ny=N, H=H, spacing=1000.0, topo=("periodic", "periodic"), patches=False, noise=0.0, **kw)
+    L = N * 1000.0
+    g = c["g"]
+    xf, yc = g.xnodes(csi.Face), g.ynodes(csi.Center)
+    xc, yf = g.xnodes(csi.Center), g.ynodes(csi.Face)
+    V = 0.5
+    c["u"] = np.broadcast_to(V * np.sin(2 * np.pi * yc / L)[:, None], (N, N)) * np.cos(2 * np.pi * xf / L)[None, :]
+    c["v"] = -np.broadcast_to(V * np.sin(2 * np.pi * xc / L)[None, :], (N, N)) * np.cos(2 * np.pi * yf / L)[:, None]
+    X, Y = np.meshgrid(xc, yc)
+    c["h"] = 0.3 + 0.005 * (np.sin(60 * X / 1000e3) + np.sin(30 * Y / 1000e3)) + 0.2 * np.exp(-((X - L / 3) ** 2 + (Y - L / 2) ** 2) / (L / 20) ** 2)
+    rng = np.random.default_rng(2)
+    c["a"] = np.clip(1 - 0.1 * rng.random((N, N)), 0, 1)
+    c["a"][N // 4:N // 3, N // 4:N // 3] = 0.0      # open water: sharp edges exercise the WENO weights
+    c["h"][N // 4:N // 3, N // 4:N // 3] = 0.0
+    return c
+
+
+@pytest.mark.parametrize("scheme", [7, 5, -5, 1])
+@pytest.mark.parametrize("N", [48, 512])
+def test_tracer_tendencies_and_update_bitwise(scheme, N, oracle_lib):
+    c = anticyclone_case(N)
+    p = cases.oracle_problem(c)
+    m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3")
+    p.compute_tracer_tendencies(scheme)
+    m.ctx.call("csi_compute_tracer_tendencies", scheme)
+    m.synchronize()
+    for k, f in (("Gh", m.timestepper.Gn.h), ("Ga", m.timestepper.Gn.aice)):
+        got, want = f.interior_numpy(), p.interior(k)
+        assert np.all(np.isfinite(got))
+        assert np.abs(want).max() > 0
+        assert np.array_equal(got, want), (k, np.abs(got - want).max())
+    # tracer update, FE form (in place) then RK form (from Psi^-)
+    p.L.ora_dynamic_step_tracers(p.ptr, 120.0, 0)
+    m.ctx.call("csi_dynamic_step_tracers", 120.0, 0)
+    m.synchronize()
+    assert np.array_equal(m.ice_thickness.interior_numpy(), p.interior("h"))
+    assert np.array_equal(m.ice_concentration.interior_numpy(), p.interior("aice"))
+    p.f["hm"][...] = p.f["h"]; p.f["am"][...] = p.f["aice"]
+    m.ctx.call("csi_cache_current_fields")
+    p.L.ora_dynamic_step_tracers(p.ptr, 40.0, 1)
+    m.ctx.call("csi_dynamic_step_tracers", 40.0, 1)
+    m.synchronize()
+    assert np.array_equal(m.ice_thickness.interior_numpy(), p.interior("h"))
+    assert np.array_equal(m.ice_concentration.interior_numpy(), p.interior("aice"))
+    # ridging / clipping happened somewhere and respected the bounds
+    a = m.ice_concentration.interior_numpy()
+    assert a.min() >= 0.0 and a.max() <= 1.0
+
+
+def test_advection_conserves_volume_at_full_size():
+    """Config 2 at 512^2: flux-form divergence on a periodic grid conserves sum(h) and sum(aice) to rounding
+    (a size-independent property, checked without the oracle)."""
+    c = anticyclone_case(512)
+    m = cases.csi_model(c, mode="fast")
+    m.ctx.call("csi_compute_tracer_tendencies", 7)
+    m.synchronize()
+    Gh = m.timestepper.Gn.h.interior_numpy()
+    assert abs(Gh.sum()) <= 1e-9 * np.abs(Gh).sum()
+
+
+STEP_CASES = {
+    "periodic": dict(Nx=48, Ny=40, topo=("periodic", "periodic"), patches=True, random_uv=0.02),
+    "masked": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.02, land=0.3),
+    "masked_channel": dict(Nx=48, Ny=48, topo=("periodic", "bounded"), patches=False, random_uv=0.02, land=0.25),
+}
+
+
+@pytest.mark.parametrize("name", ["masked", "masked_channel"])
+def test_masked_subcycle_strict_bitwise_and_fast(name, oracle_lib):
+    """Immersed land mask: peripheral-node masking of u, v (split_explicit:226,261), masked stresses in the
+    divergence (ice_stress_divergence.jl:21-24), mask_immersed_field_xy! in update_state!."""
+    c = cases.make_case(substeps=8, **STEP_CASES[name])
+    p = cases.oracle_problem(c)
+    ms = cases.csi_model(c, mode="strict")
+    mf = cases.csi_model(c, mode="fast")
+    for m in (ms, mf):
+        assert np.array_equal(m.velocities.u.numpy(), p.f["u"]) and np.array_equal(m.velocities.v.numpy(), p.f["v"])
+    p.initialize_rheology()
+    for m in (ms, mf):
+        m.ctx.call("csi_evp_initialize")
+        m.copy_to_field(m.dynamics.auxiliaries.fields.P, p.f["P"])
+    p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
+    p.subcycle(c["dt"], 1, 8)
+    for m in (ms, mf):
+        m.ctx.call("csi_evp_subcycle", c["dt"], 8, 1)
+        m.synchronize()
+    vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+    for k, get in (("u", lambda m: m.velocities.u), ("v", lambda m: m.velocities.v),
+                   ("s11", lambda m: m.dynamics.auxiliaries.fields.s11), ("s12", lambda m: m.dynamics.auxiliaries.fields.s12)):
+        assert np.array_equal(get(ms).numpy(), p.f[k]), k
+        scale = vmax if k in ("u", "v") else np.abs(p.f[k]).max()
+        assert np.abs(get(mf).numpy() - p.f[k]).max() <= 1e-11 * scale, k
+    # bit-exact masks: velocities vanish exactly on the peripheral nodes of the immersed grid
+    wet = c["mask"]
+    land_u = ~wet | ~np.roll(wet, 1, axis=1)
+    assert np.all(mf.velocities.u.interior_numpy()[:, :wet.shape[1]][land_u] == 0.0)
+
+
+@pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
+@pytest.mark.parametrize("name", ["periodic", "masked"])
+def test_full_time_step_vs_oracle(stepper, name, oracle_lib):
+    """time_step!(model, dt) with WENO(order = 7) advection: FE (sea_ice_fe_step.jl:13-34) and the RK3 stage loop."""
+    c = cases.make_case(substeps=12, **STEP_CASES[name])
+    p = cases.oracle_problem(c)
+    for mode, tol in (("strict", 1e-12), ("fast", 1e-11)):
+        p = cases.oracle_problem(c)
+        m = cases.csi_model(c, mode=mode, timestepper=stepper, advection=csi.WENO(order=7))
+        for n in range(2):
+            if stepper == "ForwardEuler":
+                p.time_step_fe(c["dt"], 7, n == 0)
+            else:
+                p.time_step_rk3(c["dt"], 7)
+            csi.time_step(m, c["dt"])
+        m.synchronize()
+        vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+        for k, f in (("u", m.velocities.u), ("v", m.velocities.v)):
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * vmax, (mode, k)
+        for k, f in (("h", m.ice_thickness), ("aice", m.ice_concentration)):
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * np.abs(p.f[k]).max(), (mode, k)
+            assert np.array_equal(f.numpy() == 0.0, p.f[k] == 0.0), (mode, k, "zero set")
+
+
+def _slab(**kw):
+    d = dict(conductivity=2.0, sea_ice_density=900.0, density=917.0, liquid_density=999.8, liquid_heat_capacity=4186.0,
+             heat_capacity=2000.0, reference_latent_heat=334e3, reference_temperature=0.0, liquidus_slope=0.054,
+             freshwater_melting_temperature=0.0, bottom_salinity=0.0, ice_consolidation_thickness=0.05,
+             top_temperature=-10.0, top_flux_kind=1, bottom_flux_kind=0, top_heat_flux=0.0, bottom_heat_flux=0.0)
+    d.update(kw)
+    return d
+
+
+def test_slab_thermodynamics_vs_oracle():
+    """Config 1 plumbing (freezing_bucket) on a 16x8 grid with per-cell different states, 50 steps; and the
+    constant-flux case of test/test_thermodynamic_mass_fluxes.jl:56."""
+    g = csi.RectilinearGrid((16, 8), x=(0, 1), y=(0, 1), halo=(3, 3))
+    rng = np.random.default_rng(7)
+    for params, okw in ((_slab(heat_capacity=2100.0, bottom_flux_kind=1, bottom_heat_flux=1.0),
+                         dict(c_ice=2100.0, Tu=-10.0, top_flux_kind=1, bot_flux_kind=1, Qb=1.0)),
+                        (_slab(top_flux_kind=0, top_heat_flux=100.0, bottom_heat_flux=10.0, top_temperature=-5.0),
+                         dict(Tu=-5.0, top_flux_kind=0, Qu=100.0, Qb=10.0))):
+        model = csi.SeaIceModel(g, dynamics=None)
+        h0 = rng.random((8, 16)) * (rng.random((8, 16)) > 0.3)
+        a0 = np.where(h0 > 0, rng.random((8, 16)), 0.0)
+        h0[0, 0], a0[0, 0] = 0.0, 0.0
+        csi.set_(model, h=h0, aice=a0)
+        mf = csi.CenterField(g, model.device, "mass_flux")
+        model.ctx.call("csi_field_bind", csi._lib.F["MASS_FLUX"], C.c_void_p(mf.data.data_ptr()), mf.ni, mf.ni, mf.nj)
+        sp = csi._lib.SlabParams(**params)
+        h, a = h0.ravel().copy(), a0.ravel().copy()
+        for n in range(50):
+            h, a, flux = O.slab_step(h, a, 600.0, **okw)
+            model.ctx.call("csi_slab_thermo_step", C.byref(sp), 600.0)
+        model.synchronize()
+        assert np.array_equal(model.ice_thickness.interior_numpy().ravel(), h)
+        assert np.array_equal(model.ice_concentration.interior_numpy().ravel(), a)
+        assert np.array_equal(mf.interior_numpy().ravel(), flux)

@@ -1,0 +1,124 @@
+"""CPU tests that pin the oracle with what the reference's own tests pin for this path
+(SURVEY.md 8c): the strain / stress-divergence adjoint identity, the drag bound, the slab
+known answer; plus the bit-for-bit cross-check of the two independent restatements."""
+import numpy as np
+import pytest
+
+import cases
+import climaseaice_jl_amd as csi
+import oracle as O
+import oracle_np as ONP
+
+
+def _latlon_problem(N):
+    g = csi.LatitudeLongitudeGrid((N, N), longitude=(0, 60), latitude=(20, 70), topology=(csi.Bounded, csi.Bounded), halo=(4, 4))
+    p = O.Problem(N, N, 4, 4, (O.BOUNDED, O.BOUNDED), per_j=g.metrics())
+    return g, p
+
+
+@pytest.mark.parametrize("N", [40, 80])
+def test_discrete_energy_budget_of_the_stress_divergence(N, oracle_lib):
+    """test/test_rheology_energy_budget.jl:50-125: sum u d_j s_1j Az + v d_j s_2j Az = - sum sigma:eps Az to 1e-10
+    on a 40^2 / 80^2 lat-lon grid (lon 0..60, lat 20..70, halo 4); the old flux-form operator must fail (> 1e-3)."""
+    g, p = _latlon_problem(N)
+    lam = lambda l: (l - 0) / 60 * 2 * np.pi
+    phi = lambda f: (f - 20) / 50 * 2 * np.pi
+
+    def set_smooth(name, LX, LY, fn, margin=2):
+        x, y = g.xnodes(LX), g.ynodes(LY)
+        a = p.interior(name)
+        a[...] = 0
+        # 1-based i in 1+margin : Nx-margin
+        sl_i = slice(margin, N - margin)
+        sl_j = slice(margin, N - margin)
+        a[sl_j, sl_i] = fn(x[None, sl_i], y[sl_j, None])
+
+    set_smooth("u", csi.Face, csi.Center, lambda l, f: np.sin(2 * lam(l)) * np.cos(3 * phi(f)))
+    set_smooth("v", csi.Center, csi.Face, lambda l, f: np.cos(3 * lam(l)) * np.sin(2 * phi(f)))
+    set_smooth("s11", csi.Center, csi.Center, lambda l, f: np.sin(lam(l)) * np.sin(2 * phi(f)))
+    set_smooth("s22", csi.Center, csi.Center, lambda l, f: np.cos(2 * lam(l)) * np.cos(phi(f)))
+    set_smooth("s12", csi.Face, csi.Face, lambda l, f: np.sin(3 * lam(l)) * np.cos(2 * phi(f)))
+    L, P = p.L, p.ptr
+    Wn = Wo = D = 0.0
+    C_, F_ = O.CENTER, O.FACE
+    u, v, s11, s22, s12 = (p.interior(k) for k in ("u", "v", "s11", "s22", "s12"))
+    for i in range(1, N + 1):
+        for j in range(1, N + 1):
+            Wn += u[j - 1, i - 1] * L.ora_div_sigma_1(P, i, j) * L.ora_az(P, F_, C_, i, j)
+            Wn += v[j - 1, i - 1] * L.ora_div_sigma_2(P, i, j) * L.ora_az(P, C_, F_, i, j)
+            Wo += u[j - 1, i - 1] * L.ora_old_div_sigma_1(P, i, j) * L.ora_az(P, F_, C_, i, j)
+            Wo += v[j - 1, i - 1] * L.ora_old_div_sigma_2(P, i, j) * L.ora_az(P, C_, F_, i, j)
+            D += s11[j - 1, i - 1] * L.ora_strain_xx(P, i, j) * L.ora_az(P, C_, C_, i, j)
+            D += s22[j - 1, i - 1] * L.ora_strain_yy(P, i, j) * L.ora_az(P, C_, C_, i, j)
+            D += 2 * s12[j - 1, i - 1] * L.ora_strain_xy(P, i, j) * L.ora_az(P, F_, F_, i, j)
+    imb = lambda W: abs(W + D) / max(abs(W), abs(D))
+    assert imb(Wn) < 1e-10
+    assert imb(Wo) > 1e-3
+    assert imb(Wn) < 1e-6 * imb(Wo)
+
+
+def test_semi_implicit_ocean_drag_bound(oracle_lib):
+    """test/test_time_stepping.jl:56-80: 8x8 periodic 10 km box, h = aice = 1, ocean u = 0.1 through
+    SemiImplicitStress, 20 steps of 60 s, substeps = 10: finite, 0 < max(u) <= 0.1 (RK3 and FE)."""
+    for stepper in ("rk3", "fe"):
+        p = O.Problem(8, 8, 4, 4, (O.PERIODIC, O.PERIODIC), dx=1250.0, dy=1250.0, substeps=10)
+        p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=0.1)
+        p.f["h"][...] = 1.0
+        p.f["aice"][...] = 1.0
+        p.update_state()
+        for n in range(20):
+            p.time_step_rk3(60.0, 0) if stepper == "rk3" else p.time_step_fe(60.0, 0, n == 0)
+        u = p.interior("u")
+        assert np.all(np.isfinite(u)) and u.max() > 0 and u.max() <= 0.1
+
+
+def test_freezing_bucket_first_step_known_answer(oracle_lib):
+    """Config 1 (examples/freezing_bucket.jl:43-99): h = aice = 0 at t = 0, Tu = -10 prescribed, bottom flux
+    -(1 - aice), dt = 600 s.  Closed form from thermodynamic_time_step.jl:304-324,358-370:
+    V = dt / (900 * 334e3), aice = V / 0.05, h = 0.05."""
+    h, a, mf = O.slab_step(np.zeros(1), np.zeros(1), 600.0, c_ice=2100.0, Tu=-10.0, top_flux_kind=1,
+                           bot_flux_kind=1, Qb=1.0)
+    V = 600.0 / (900.0 * 334e3)
+    assert np.isclose(a[0], V / 0.05, rtol=1e-14) and np.isclose(h[0], 0.05, rtol=1e-14)
+    assert np.isclose(mf[0], 900.0 * V / 600.0, rtol=1e-13)
+
+
+def test_slab_mass_closure_and_melt_to_extinction(oracle_lib):
+    """test/test_thermodynamic_mass_fluxes.jl:51-170: the recorded ice mass flux closes the mass change; a slab that
+    melts completely ends at exact zeros."""
+    h0, a0 = np.array([1.0, 0.3, 0.02]), np.array([1.0, 0.5, 0.2])
+    h, a, mf = O.slab_step(h0, a0, 3600.0, top_flux_kind=0, Qu=100.0, Qb=10.0, Tu=-5.0)
+    assert np.allclose(mf, 900.0 * (h * a - h0 * a0) / 3600.0, rtol=0, atol=1e-12)
+    h, a, mf = O.slab_step(np.array([0.01]), np.array([0.5]), 3600.0 * 24 * 30, top_flux_kind=0, Qu=-500.0, Qb=500.0, Tu=0.0)
+    assert h[0] == 0.0 and a[0] == 0.0
+
+
+CROSS = {
+    "periodic": dict(topo=("periodic", "periodic")),
+    "bounded": dict(topo=("bounded", "bounded")),
+    "channel": dict(topo=("periodic", "bounded")),
+    "latlon": dict(topo=("bounded", "bounded"), grid="latlon"),
+}
+
+
+@pytest.mark.parametrize("name", list(CROSS))
+def test_c_oracle_equals_numpy_restatement_bitwise(name, oracle_lib):
+    c = cases.make_case(Nx=28, Ny=22, substeps=6, random_uv=0.05, ue=0.05, ve=-0.02, top=(0.01, 0.02), **CROSS[name])
+    p = cases.oracle_problem(c)
+    g = c["g"]
+    topo = tuple(0 if t == "periodic" else 1 for t in c["topo"])
+    m = g.metrics()
+    n = ONP.NP(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m.get("dx"), dy=m.get("dy"), per_j=m if m["kind"] == "per_j" else None)
+    n.f, n.top, n.bottom = c["coriolis"], ("const",) + tuple(c["top"]), ("semi", c["ue"], c["ve"], 1026.0, 5.5e-3)
+    for k, v in p.f.items():
+        n.fld[k] = v.copy()
+    p.initialize_rheology()
+    n.initialize()
+    assert np.abs(p.f["P"] - n.fld["P"]).max() <= 4e-16 * np.abs(p.f["P"]).max()   # exp(): libm vs numpy
+    n.fld["P"][...] = p.f["P"]
+    p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
+    n.fill_halo("u", 1, 0); n.fill_halo("v", 0, 1)
+    p.subcycle(c["dt"], 1, 6)
+    n.subcycle(c["dt"], 1, 6)
+    for k in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
+        assert np.array_equal(p.f[k], n.fld[k]), k
