@@ -6,11 +6,12 @@ host-side mirror of the reference's `SeaIceModel` / `time_step!` surface.  The d
 contains a dot, so import it through the repo-root shim: `import climaseaice_jl_amd as csi`.
 """
 from . import _lib
-from ._lib import Context, CsiError
+from ._lib import Context, CsiError, plan_exchange, plan_ranges
 from .dynamics import (Auxiliaries, ElastoViscoPlasticRheology, FPlane, IceStrength, ReplacementPressure,
                        SeaIceMomentumEquation, SemiImplicitStress, SplitExplicitSolver)
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
-from .grids import Bounded, Center, Face, Flat, LatitudeLongitudeGrid, Periodic, RectilinearGrid
+from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected, Periodic,
+                    RectilinearGrid, RightConnected, TileGrid)
 from .model import SeaIceModel, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -30,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
-           "csi_last_subcycle_ms", "csi_launches_per_substep"]
+           "csi_plan_exchange", "csi_plan_ranges", "csi_last_subcycle_ms", "csi_launches_per_substep"]
 
 
 class Metrics(C.Structure):
@@ -104,6 +104,8 @@ def load():
         "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],
         "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
+        "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
+        "csi_plan_exchange": [i32] * 14 + [C.POINTER(i32)],
         "csi_last_subcycle_ms": [vp, C.POINTER(dbl)], "csi_launches_per_substep": [vp, C.POINTER(i32)],
     }
     for name, args in sig.items():
@@ -112,6 +114,26 @@ def load():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y):
+    """(stress, u-first, v-first, owned) index ranges of the launch loop (pure host function of the library)."""
+    out = (C.c_int32 * 16)()
+    rc = load().csi_plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y, out)
+    if rc != OK:
+        raise CsiError(rc, "csi_plan_ranges")
+    v = list(out)
+    return tuple(tuple(v[4 * k:4 * k + 4]) for k in range(4))
+
+
+def plan_exchange(Nx, Ny, Hx, Hy, topo_x, topo_y, rx, ry, Rx, Ry, periodic_x, periodic_y, width, halo):
+    """Eight (peer, i0, j0, ni, nj) entries of the library's exchange plan (pure host function)."""
+    out = (C.c_int32 * 40)()
+    rc = load().csi_plan_exchange(Nx, Ny, Hx, Hy, topo_x, topo_y, rx, ry, Rx, Ry, int(periodic_x), int(periodic_y), width, int(halo), out)
+    if rc != OK:
+        raise CsiError(rc, "csi_plan_exchange")
+    v = list(out)
+    return [tuple(v[5 * k:5 * k + 5]) for k in range(8)]
 
 
 class Context:

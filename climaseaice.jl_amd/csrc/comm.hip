@@ -1,0 +1,95 @@
+// comm.hip -- multi-GPU halo exchange: one process per GPU, RCCL point-to-point over xGMI.
+//
+// Replaces the MPI halo passes hidden in the reference's fill_halo_regions! on distributed grids
+// (sea_ice_model.jl:381-384, elasto_visco_plastic_rheology.jl:275-280,
+// sea_ice_external_stress.jl:72-78) and -- unlike the reference, which widens the halo to
+// 2*substeps+3 and never communicates inside the sub-cycle
+// (split_explicit_momentum_equations.jl:51-64) -- exchanges u, v (width 2) once per sub-step
+// (SURVEY.md A.5, 8e).  No collective: every message is neighbour-to-neighbour.
+//
+// One pack kernel gathers all strips of all fields for the (up to 8) neighbours into one
+// contiguous send buffer, one grouped ncclSend/ncclRecv moves them, one unpack kernel scatters
+// the received strips into the halos.
+#include "csi_comm.h"
+
+#include <cstdio>
+
+namespace csi {
+
+__global__ void __launch_bounds__(256) k_pack(ExPlan pl, double* buf, int unpack) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pl.total) return;
+    int s = 0;
+#pragma unroll 1
+    while (s + 1 < pl.nseg && t >= pl.seg[s + 1].off) ++s;
+    const ExSeg& g = pl.seg[s];
+    const long r = t - g.off;
+    const int jj = (int)(r / g.ni), ii = (int)(r - (long)jj * g.ni);
+    double* fp = g.f.p + (g.i0 + ii) + (long)(g.j0 + jj) * g.f.ld;
+    if (unpack) *fp = buf[t];
+    else buf[t] = *fp;
+}
+
+void launch_pack(const ExPlan& pl, double* buf, int unpack, hipStream_t s) {
+    if (pl.total == 0) return;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((pl.total + 255) / 256)), dim3(256), 0, s, pl, buf, unpack);
+}
+
+// Neighbour in direction (dx, dy) of tile (rx, ry); -1 if none.
+int tile_neighbor(const TileInfo& t, int dx, int dy, int xlo, int xhi, int ylo, int yhi) {
+    if (dx == 0 && dy == 0) return -1;
+    if (dx < 0 && xlo != SIDE_CONNECTED) return -1;
+    if (dx > 0 && xhi != SIDE_CONNECTED) return -1;
+    if (dy < 0 && ylo != SIDE_CONNECTED) return -1;
+    if (dy > 0 && yhi != SIDE_CONNECTED) return -1;
+    int nx = t.rx + dx, ny = t.ry + dy;
+    if (nx < 0 || nx >= t.Rx) { if (!t.periodic_x) return -1; nx = (nx + t.Rx) % t.Rx; }
+    if (ny < 0 || ny >= t.Ry) { if (!t.periodic_y) return -1; ny = (ny + t.Ry) % t.Ry; }
+    return ny * t.Rx + nx;
+}
+
+// Build the send (halo = 0: owned strips) or receive (halo = 1: halo strips) plan for `nf` fields.
+// Direction order is fixed (dy outer, dx inner); the receive plan lists, in the same order e, the
+// strip that arrives from the neighbour in direction -e (that neighbour's send number e), which
+// keeps multiple messages between the same pair of ranks in matching FIFO order.
+void build_plan(const GridDev& g, const TileInfo& t, const FRef* fields, int nf, int W, int halo,
+                ExPlan& pl, long* dir_off, long* dir_cnt, int* dir_peer) {
+    pl.nseg = 0;
+    pl.total = 0;
+    int k = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            // send: towards (dx, dy).  recv (same loop index): from the neighbour at (-dx, -dy)
+            const int ndx = halo ? -dx : dx, ndy = halo ? -dy : dy;
+            const int peer = tile_neighbor(t, ndx, ndy, g.xlo, g.xhi, g.ylo, g.yhi);
+            dir_peer[k] = peer;
+            dir_off[k] = pl.total;
+            dir_cnt[k] = 0;
+            if (peer >= 0) {
+                int i0, ni, j0, nj;
+                // the strip lies on my side `ndx`: owned cells next to that edge (send) or the halo beyond it (recv)
+                if (ndx < 0) { i0 = halo ? 1 - W : 1; ni = W; }
+                else if (ndx > 0) { i0 = halo ? g.Nx + 1 : g.Nx - W + 1; ni = W; }
+                else {
+                    const int a = (g.xlo == SIDE_CONNECTED) ? 1 : 1 - W, b = (g.xhi == SIDE_CONNECTED) ? g.Nx : g.Nx + W;
+                    i0 = a; ni = b - a + 1;
+                }
+                if (ndy < 0) { j0 = halo ? 1 - W : 1; nj = W; }
+                else if (ndy > 0) { j0 = halo ? g.Ny + 1 : g.Ny - W + 1; nj = W; }
+                else {
+                    const int a = (g.ylo == SIDE_CONNECTED) ? 1 : 1 - W, b = (g.yhi == SIDE_CONNECTED) ? g.Ny : g.Ny + W;
+                    j0 = a; nj = b - a + 1;
+                }
+                for (int f = 0; f < nf; ++f) {
+                    ExSeg& s = pl.seg[pl.nseg++];
+                    s.f = fields[f]; s.i0 = i0; s.j0 = j0; s.ni = ni; s.nj = nj; s.off = pl.total;
+                    pl.total += (long)ni * nj;
+                }
+                dir_cnt[k] = pl.total - dir_off[k];
+            }
+            ++k;
+        }
+}
+
+}  // namespace csi

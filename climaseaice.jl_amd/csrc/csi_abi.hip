@@ -9,6 +9,9 @@
 #include "../../include/csi.h"
 #include "csi_dev.h"
 #include "csi_kernels.h"
+#include "csi_comm.h"
+
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -62,6 +65,12 @@ struct csi_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int launches_per_substep = 0;
+    // multi-GPU tiles
+    TileInfo tile;
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    size_t buf_cap = 0;   // elements per buffer
 };
 
 namespace {
@@ -167,9 +176,74 @@ EvpDev evp_dev(const csi_context* c, double dt) {
 // Index ranges (1-based, inclusive).  Stress kernels: Auxiliaries kernel parameters
 // -H+2 : N+H-1 (elasto_visco_plastic_rheology.jl:145); velocity kernels: :xy on a serial grid,
 // split_explicit_kernel_size on connected (tile) sides (split_explicit_momentum_equations.jl:40-46).
-Range stress_range(const csi_context* c) { return Range{-c->Hx + 2, c->Nx + c->Hx - 1, -c->Hy + 2, c->Ny + c->Hy - 1}; }
+// On a connected (tile) side only u, v of width 2 are valid, so the stress kernel covers ring 1 there and the
+// first velocity of the sub-step is recomputed on the ring the second one reads.
+Range stress_range(const csi_context* c) {
+    const GridDev& g = c->g;
+    return Range{g.xlo == SIDE_CONNECTED ? 0 : -c->Hx + 2, g.xhi == SIDE_CONNECTED ? c->Nx + 1 : c->Nx + c->Hx - 1,
+                 g.ylo == SIDE_CONNECTED ? 0 : -c->Hy + 2, g.yhi == SIDE_CONNECTED ? c->Ny + 1 : c->Ny + c->Hy - 1};
+}
+Range first_u_range(const csi_context* c) {   // u first: the v step reads new u at (i..i+1, j-1..j)
+    const GridDev& g = c->g;
+    return Range{1, c->Nx + (g.xhi == SIDE_CONNECTED ? 1 : 0), 1 - (g.ylo == SIDE_CONNECTED ? 1 : 0), c->Ny};
+}
+Range first_v_range(const csi_context* c) {   // v first: the u step reads new v at (i-1..i, j..j+1)
+    const GridDev& g = c->g;
+    return Range{1 - (g.xlo == SIDE_CONNECTED ? 1 : 0), c->Nx, 1, c->Ny + (g.yhi == SIDE_CONNECTED ? 1 : 0)};
+}
+bool is_tiled(const csi_context* c) {
+    const GridDev& g = c->g;
+    return g.xlo == SIDE_CONNECTED || g.xhi == SIDE_CONNECTED || g.ylo == SIDE_CONNECTED || g.yhi == SIDE_CONNECTED;
+}
 Range interior_range(const csi_context* c) { return Range{1, c->Nx, 1, c->Ny}; }
 Range parent_range(const csi_context* c) { return Range{1 - c->Hx, c->Nx + c->Hx, 1 - c->Hy, c->Ny + c->Hy}; }
+
+#define NCCL_TRY(c, expr)                                                                       \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return fail(c, CSI_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));   \
+    } while (0)
+
+// Exchange `W` halo layers of the given fields with the neighbouring tiles (no-op on an untiled grid).
+int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
+    if (!is_tiled(c)) return CSI_OK;
+    if (!c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
+    if (!c->comm) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
+    if (nf > MAX_EX_FIELDS) return fail(c, CSI_ERR_INVALID_ARGUMENT, "too many fields in one exchange");
+    if (W < 1 || W > c->Hx || W > c->Hy || W > c->Nx || W > c->Ny) return fail(c, CSI_ERR_INVALID_ARGUMENT, "exchange width out of range");
+    FRef fr[MAX_EX_FIELDS];
+    for (int k = 0; k < nf; ++k) {
+        if (!c->f[fids[k]].p) return fail(c, CSI_ERR_NOT_BOUND, std::string("field not bound: ") + kName[fids[k]]);
+        fr[k] = ref_of(c, fids[k]);
+    }
+    ExPlan sp, rp;
+    long soff[8], scnt[8], roff[8], rcnt[8];
+    int speer[8], rpeer[8];
+    build_plan(c->g, c->tile, fr, nf, W, 0, sp, soff, scnt, speer);
+    build_plan(c->g, c->tile, fr, nf, W, 1, rp, roff, rcnt, rpeer);
+    const size_t need_elems = (size_t)(sp.total > rp.total ? sp.total : rp.total);
+    if (need_elems > c->buf_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->sendbuf) hipFree(c->sendbuf);
+        if (c->recvbuf) hipFree(c->recvbuf);
+        c->sendbuf = c->recvbuf = nullptr;
+        const size_t cap = need_elems * 2;
+        HIP_TRY(c, hipMalloc((void**)&c->sendbuf, cap * sizeof(double)));
+        HIP_TRY(c, hipMalloc((void**)&c->recvbuf, cap * sizeof(double)));
+        c->buf_cap = cap;
+    }
+    launch_pack(sp, c->sendbuf, 0, c->stream);
+    NCCL_TRY(c, ncclGroupStart());
+    for (int k = 0; k < 8; ++k)
+        if (speer[k] >= 0 && scnt[k] > 0) NCCL_TRY(c, ncclSend(c->sendbuf + soff[k], (size_t)scnt[k], ncclDouble, speer[k], c->comm, c->stream));
+    for (int k = 0; k < 8; ++k)
+        if (rpeer[k] >= 0 && rcnt[k] > 0) NCCL_TRY(c, ncclRecv(c->recvbuf + roff[k], (size_t)rcnt[k], ncclDouble, rpeer[k], c->comm, c->stream));
+    NCCL_TRY(c, ncclGroupEnd());
+    launch_pack(rp, c->recvbuf, 1, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
 
 int32_t fill_halo(csi_context* c, int fid) {
     launch_fill_halo(ref_of(c, fid), c->g, image_spec(c, fid), c->stream);
@@ -196,8 +270,11 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     int32_t rc;
     if ((rc = fill_halo(c, CSI_F_U))) return rc;     // :170
     if ((rc = fill_halo(c, CSI_F_V))) return rc;     // :171
+    const bool tiled = is_tiled(c);
+    const int uv[2] = {CSI_F_U, CSI_F_V};
+    if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;
     EvpDev P = evp_dev(c, dt);
-    const Range rs = stress_range(c), rv = interior_range(c);
+    const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const bool fast = c->mode == CSI_MODE_FAST;
     FastCoef fc = c->coef;
@@ -218,17 +295,19 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
             launch_strict_stress(P, rs, c->stream);
         }
         if ((s % 2) == 0) {                                // :178-182
-            if (fast) { launch_fast_ustep(P, rv, imu, fc, c->stream); launch_fast_vstep(P, rv, imv, fc, c->stream); }
-            else { launch_strict_ustep(P, rv, imu, c->stream); launch_strict_vstep(P, rv, imv, c->stream); }
+            if (fast) { launch_fast_ustep(P, ru1, imu, fc, c->stream); launch_fast_vstep(P, rv, imv, fc, c->stream); }
+            else { launch_strict_ustep(P, ru1, imu, c->stream); launch_strict_vstep(P, rv, imv, c->stream); }
         } else {                                           // :184-187
-            if (fast) { launch_fast_vstep(P, rv, imv, fc, c->stream); launch_fast_ustep(P, rv, imu, fc, c->stream); }
-            else { launch_strict_vstep(P, rv, imv, c->stream); launch_strict_ustep(P, rv, imu, c->stream); }
+            if (fast) { launch_fast_vstep(P, rv1, imv, fc, c->stream); launch_fast_ustep(P, rv, imu, fc, c->stream); }
+            else { launch_strict_vstep(P, rv1, imv, c->stream); launch_strict_ustep(P, rv, imu, c->stream); }
         }
+        // tiles: u, v halos of width 2 from the neighbours, once per sub-step (RCCL send/recv)
+        if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipGetLastError());
     c->timed = true;
-    c->launches_per_substep = fast ? 3 : 4;
+    c->launches_per_substep = (fast ? 3 : 4) + (tiled ? 3 : 0);
     return CSI_OK;
 }
 
@@ -237,7 +316,8 @@ int32_t do_finalize(csi_context* c) {
     if ((rc = fill_halo(c, CSI_F_S11))) return rc;
     if ((rc = fill_halo(c, CSI_F_S12))) return rc;
     if ((rc = fill_halo(c, CSI_F_S22))) return rc;
-    return CSI_OK;
+    const int sg[3] = {CSI_F_S11, CSI_F_S12, CSI_F_S22};
+    return exchange(c, sg, 3, c->Hx < c->Hy ? c->Hx : c->Hy);
 }
 
 int32_t need_evp(csi_context* c) {
@@ -249,6 +329,7 @@ int32_t need_evp(csi_context* c) {
     if ((rc = check_stress_fields(c, CSI_STRESS_BOTTOM))) return rc;
     if (c->Hx < 2 || c->Hy < 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "EVP needs halo >= 2");
     if (c->Nx < c->Hx || c->Ny < c->Hy) return fail(c, CSI_ERR_UNSUPPORTED, "tile smaller than its halo");
+    if (is_tiled(c) && (c->Hx < 3 || c->Hy < 3)) return fail(c, CSI_ERR_INVALID_ARGUMENT, "tiled EVP needs halo >= 3");
     return CSI_OK;
 }
 
@@ -260,6 +341,11 @@ int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_re
         if ((rc = copy_parent(c, CSI_F_V, CSI_F_VM))) return rc;
     }
     if ((rc = do_initialize(c))) return rc;                 // :130
+    if (is_tiled(c)) {                                      // update_external_stress! :133-134 (forcing halos)
+        int ff[4], n = 0;
+        for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V}) if (c->f[id].p) ff[n++] = id;
+        if (n && (rc = exchange(c, ff, n, 2))) return rc;
+    }
     if ((rc = do_subcycle(c, dt, substeps, 1))) return rc;  // :170-189
     return do_finalize(c);                                  // :192
 }
@@ -287,6 +373,11 @@ int32_t do_update_state(csi_context* c) {
         if ((rc = fill_halo(c, CSI_F_V))) return rc;
     }
     HIP_TRY(c, hipGetLastError());
+    if (is_tiled(c)) {                                      // the MPI part of fill_halo_regions!, sea_ice_model.jl:383
+        int ff[4] = {CSI_F_H, CSI_F_A, CSI_F_U, CSI_F_V};
+        const int n = (c->f[CSI_F_U].p && c->f[CSI_F_V].p) ? 4 : 2;
+        if ((rc = exchange(c, ff, n, c->Hx < c->Hy ? c->Hx : c->Hy))) return rc;
+    }
     return CSI_OK;
 }
 
@@ -354,6 +445,9 @@ int32_t csi_context_destroy(csi_context* c) {
     hipStreamSynchronize(c->stream);
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_coef) hipFree(c->dev_coef);
+    if (c->sendbuf) hipFree(c->sendbuf);
+    if (c->recvbuf) hipFree(c->recvbuf);
+    if (c->comm) ncclCommDestroy(c->comm);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -582,15 +676,80 @@ int32_t csi_slab_thermo_step(csi_context* c, const csi_slab_params* p, double dt
     return CSI_OK;
 }
 
-int32_t csi_tile_set(csi_context* c, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) {
-    return fail(c, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet");
+int32_t csi_tile_set(csi_context* c, int32_t rx, int32_t ry, int32_t Rx, int32_t Ry, int32_t periodic_x, int32_t periodic_y) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (Rx < 1 || Ry < 1 || rx < 0 || rx >= Rx || ry < 0 || ry >= Ry) return fail(c, CSI_ERR_INVALID_ARGUMENT, "tile coordinates out of range");
+    c->tile.rx = rx; c->tile.ry = ry; c->tile.Rx = Rx; c->tile.Ry = Ry;
+    c->tile.periodic_x = periodic_x != 0; c->tile.periodic_y = periodic_y != 0;
+    c->tile.set = true;
+    return CSI_OK;
 }
-int32_t csi_comm_unique_id(uint8_t*) { return fail(nullptr, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet"); }
-int32_t csi_comm_init(csi_context* c, int32_t, int32_t, const uint8_t*) {
-    return fail(c, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet");
+
+int32_t csi_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(nullptr, CSI_ERR_INVALID_ARGUMENT, "id128 == NULL");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, CSI_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    memcpy(id128, &id, 128);
+    return CSI_OK;
 }
-int32_t csi_halo_exchange(csi_context* c, const int32_t*, int32_t, int32_t) {
-    return fail(c, CSI_ERR_UNSUPPORTED, "multi-GPU tiles are not implemented yet");
+
+int32_t csi_comm_init(csi_context* c, int32_t world_size, int32_t rank, const uint8_t* id128) {
+    if (!c || !id128) return CSI_ERR_INVALID_ARGUMENT;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank / world_size out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    NCCL_TRY(c, ncclCommInitRank(&c->comm, world_size, id, rank));
+    c->world = world_size; c->rank = rank;
+    return CSI_OK;
+}
+
+int32_t csi_halo_exchange(csi_context* c, const int32_t* field_ids, int32_t nfields, int32_t width) {
+    if (!c || !field_ids) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");
+    for (int k = 0; k < nfields; ++k)
+        if (field_ids[k] < 0 || field_ids[k] >= CSI_F_COUNT) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown field id");
+    return exchange(c, field_ids, nfields, width);
+}
+
+int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y,
+                          int32_t rx, int32_t ry, int32_t Rx, int32_t Ry, int32_t periodic_x, int32_t periodic_y,
+                          int32_t width, int32_t halo, int32_t* out40) {
+    if (!out40 || Nx < 1 || Ny < 1 || Rx < 1 || Ry < 1) return CSI_ERR_INVALID_ARGUMENT;
+    GridDev g{};
+    g.Nx = Nx; g.Ny = Ny; g.Hx = Hx; g.Hy = Hy;
+    g.xlo = side_lo(topo_x); g.xhi = side_hi(topo_x); g.ylo = side_lo(topo_y); g.yhi = side_hi(topo_y);
+    TileInfo t;
+    t.rx = rx; t.ry = ry; t.Rx = Rx; t.Ry = Ry; t.periodic_x = periodic_x != 0; t.periodic_y = periodic_y != 0; t.set = true;
+    FRef dummy{nullptr, 0};
+    ExPlan pl;
+    long off[8], cnt[8];
+    int peer[8];
+    build_plan(g, t, &dummy, 1, width, halo, pl, off, cnt, peer);
+    int s = 0;
+    for (int k = 0; k < 8; ++k) {
+        out40[5 * k] = peer[k];
+        if (peer[k] >= 0) {
+            const ExSeg& e = pl.seg[s++];
+            out40[5 * k + 1] = e.i0; out40[5 * k + 2] = e.j0; out40[5 * k + 3] = e.ni; out40[5 * k + 4] = e.nj;
+        } else {
+            out40[5 * k + 1] = out40[5 * k + 2] = out40[5 * k + 3] = out40[5 * k + 4] = 0;
+        }
+    }
+    return CSI_OK;
+}
+
+int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t* out16) {
+    if (!out16 || Nx < 1 || Ny < 1) return CSI_ERR_INVALID_ARGUMENT;
+    csi_context tmp;
+    tmp.Nx = Nx; tmp.Ny = Ny; tmp.Hx = Hx; tmp.Hy = Hy;
+    tmp.g.xlo = side_lo(topo_x); tmp.g.xhi = side_hi(topo_x); tmp.g.ylo = side_lo(topo_y); tmp.g.yhi = side_hi(topo_y);
+    const Range r[4] = {stress_range(&tmp), first_u_range(&tmp), first_v_range(&tmp), interior_range(&tmp)};
+    for (int k = 0; k < 4; ++k) { out16[4 * k] = r[k].i0; out16[4 * k + 1] = r[k].i1; out16[4 * k + 2] = r[k].j0; out16[4 * k + 3] = r[k].j1; }
+    return CSI_OK;
 }
 
 int32_t csi_last_subcycle_ms(csi_context* c, double* ms) {

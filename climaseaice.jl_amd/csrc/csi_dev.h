@@ -104,20 +104,27 @@ __device__ __forceinline__ int image_hi(int mode, int i, int N, int H, bool& has
 }
 __device__ __forceinline__ void store_with_images(const FRef& f, const GridDev& g, const ImageSpec& im, int i, int j, double val) {
     f(i, j) = val;
-    // only interior elements have images; the test is cheap and almost always false
-    const bool near_x = (i <= g.Hx) | (i > g.Nx - g.Hx);
-    const bool near_y = (j <= g.Hy) | (j > g.Ny - g.Hy);
+    // Elements within H of an edge have halo images; the test is cheap and almost always false.
+    // x-images exist for interior columns (any row, including the ring rows a tile recomputes for
+    // its neighbours), y-images for interior rows; corners are the product of the two.
+    const bool in_x = (i >= 1) & (i <= g.Nx), in_y = (j >= 1) & (j <= g.Ny);
+    const bool near_x = in_x & ((i <= g.Hx) | (i > g.Nx - g.Hx));
+    const bool near_y = in_y & ((j <= g.Hy) | (j > g.Ny - g.Hy));
     if (!(near_x | near_y)) return;
-    if (i < 1 || i > g.Nx || j < 1 || j > g.Ny) return;
     int xi[3], yj[3];
     int nx = 0, ny = 0;
     xi[nx++] = i;
     yj[ny++] = j;
     bool has;
-    int t = image_lo(im.xlo, i, g.Nx, g.Hx, has); if (has) xi[nx++] = t;
-    t = image_hi(im.xhi, i, g.Nx, g.Hx, has);     if (has) xi[nx++] = t;
-    t = image_lo(im.ylo, j, g.Ny, g.Hy, has);     if (has) yj[ny++] = t;
-    t = image_hi(im.yhi, j, g.Ny, g.Hy, has);     if (has) yj[ny++] = t;
+    int t;
+    if (in_x) {
+        t = image_lo(im.xlo, i, g.Nx, g.Hx, has); if (has) xi[nx++] = t;
+        t = image_hi(im.xhi, i, g.Nx, g.Hx, has); if (has) xi[nx++] = t;
+    }
+    if (in_y) {
+        t = image_lo(im.ylo, j, g.Ny, g.Hy, has); if (has) yj[ny++] = t;
+        t = image_hi(im.yhi, j, g.Ny, g.Hy, has); if (has) yj[ny++] = t;
+    }
     for (int b = 0; b < ny; ++b)
         for (int a = 0; a < nx; ++a)
             if (a | b) f(xi[a], yj[b]) = val;

@@ -19,6 +19,18 @@ class Flat:
     pass
 
 
+class FullyConnected:
+    """Tile edge pair whose halos come from the neighbouring tiles on both sides."""
+
+
+class LeftConnected:
+    """Low side exchanged with a neighbour tile, high side is a wall (the last tile of a Bounded direction)."""
+
+
+class RightConnected:
+    """Low side is a wall (the first tile of a Bounded direction), high side exchanged."""
+
+
 class Center:
     pass
 
@@ -35,6 +47,24 @@ def _topo2(topology):
     return t
 
 
+def hi_wall(T):
+    """True when the high side of a direction with topology T is a wall (Face fields then hold N + 1 points)."""
+    return T in (Bounded, LeftConnected)
+
+
+def local_topology(T, r, R):
+    """Topology of tile r of R along a direction of global topology T (one rank: unchanged)."""
+    if R == 1:
+        return T
+    if T is Periodic:
+        return FullyConnected
+    if r == 0:
+        return RightConnected
+    if r == R - 1:
+        return LeftConnected
+    return FullyConnected
+
+
 class _Grid2D:
     Nx: int
     Ny: int
@@ -43,13 +73,13 @@ class _Grid2D:
 
     def field_size(self, LX, LY):
         """Parent-array extents (ni, nj) of a field at (LX, LY): Oceananigans' rule, SURVEY.md A.0."""
-        ni = self.Nx + 2 * self.Hx + (1 if (LX is Face and self.topology[0] is Bounded) else 0)
-        nj = self.Ny + 2 * self.Hy + (1 if (LY is Face and self.topology[1] is Bounded) else 0)
+        ni = self.Nx + 2 * self.Hx + (1 if (LX is Face and hi_wall(self.topology[0])) else 0)
+        nj = self.Ny + 2 * self.Hy + (1 if (LY is Face and hi_wall(self.topology[1])) else 0)
         return ni, nj
 
     def interior_size(self, LX, LY):
-        nx = self.Nx + (1 if (LX is Face and self.topology[0] is Bounded) else 0)
-        ny = self.Ny + (1 if (LY is Face and self.topology[1] is Bounded) else 0)
+        nx = self.Nx + (1 if (LX is Face and hi_wall(self.topology[0])) else 0)
+        ny = self.Ny + (1 if (LY is Face and hi_wall(self.topology[1])) else 0)
         return nx, ny
 
     def stress_kernel_range(self):
@@ -73,11 +103,11 @@ class RectilinearGrid(_Grid2D):
         self.dy = (self.y[1] - self.y[0]) / self.Ny
 
     def xnodes(self, LX):
-        i = np.arange(1, self.Nx + 1 + (1 if (LX is Face and self.topology[0] is Bounded) else 0))
+        i = np.arange(1, self.Nx + 1 + (1 if (LX is Face and hi_wall(self.topology[0])) else 0))
         return self.x[0] + (i - 1) * self.dx if LX is Face else self.x[0] + (i - 0.5) * self.dx
 
     def ynodes(self, LY):
-        j = np.arange(1, self.Ny + 1 + (1 if (LY is Face and self.topology[1] is Bounded) else 0))
+        j = np.arange(1, self.Ny + 1 + (1 if (LY is Face and hi_wall(self.topology[1])) else 0))
         return self.y[0] + (j - 1) * self.dy if LY is Face else self.y[0] + (j - 0.5) * self.dy
 
     def metrics(self):
@@ -115,12 +145,65 @@ class LatitudeLongitudeGrid(_Grid2D):
         self.azf = R * R * dl * (np.sin(np.deg2rad(phic)) - np.sin(np.deg2rad(phic - self.dphi)))
 
     def xnodes(self, LX):
-        i = np.arange(1, self.Nx + 1 + (1 if (LX is Face and self.topology[0] is Bounded) else 0))
+        i = np.arange(1, self.Nx + 1 + (1 if (LX is Face and hi_wall(self.topology[0])) else 0))
         return self.longitude[0] + (i - 1) * self.dlam if LX is Face else self.longitude[0] + (i - 0.5) * self.dlam
 
     def ynodes(self, LY):
-        j = np.arange(1, self.Ny + 1 + (1 if (LY is Face and self.topology[1] is Bounded) else 0))
+        j = np.arange(1, self.Ny + 1 + (1 if (LY is Face and hi_wall(self.topology[1])) else 0))
         return self.latitude[0] + (j - 1) * self.dphi if LY is Face else self.latitude[0] + (j - 0.5) * self.dphi
 
     def metrics(self):
         return dict(kind="per_j", dy=self.dy, dxc=self.dxc, dxf=self.dxf, azc=self.azc, azf=self.azf)
+
+
+class TileGrid(_Grid2D):
+    """One tile of an Rx x Ry decomposition of a global grid (the analogue of an Oceananigans grid built on
+    Distributed(arch; partition = Partition(Rx, Ry)), test/distributed_tests_utils.jl:60-62).
+
+    Metrics are SLICES of the global grid's metric vectors, so a tiled run uses bit-identical metric values."""
+
+    def __init__(self, global_grid, Rx, Ry, rx, ry, force_connected=False):
+        G = global_grid
+        if G.Nx % Rx or G.Ny % Ry:
+            raise ValueError("grid size must be divisible by the partition")
+        self.global_grid, self.Rx, self.Ry, self.rx, self.ry = G, Rx, Ry, rx, ry
+        self.Nx, self.Ny, self.Hx, self.Hy = G.Nx // Rx, G.Ny // Ry, G.Hx, G.Hy
+        self.topology = (local_topology(G.topology[0], rx, Rx), local_topology(G.topology[1], ry, Ry))
+        if force_connected:   # testing aid: a Periodic direction with one tile exchanges with itself
+            fc = force_connected if isinstance(force_connected, tuple) else (True, True)
+            self.topology = tuple(FullyConnected if (T is Periodic and f) else t for T, t, f in zip(G.topology, self.topology, fc))
+        self.periodic = (G.topology[0] is Periodic, G.topology[1] is Periodic)
+        self.i_off, self.j_off = rx * self.Nx, ry * self.Ny
+        self.metric_kind = G.metric_kind
+        self.rank = ry * Rx + rx
+
+    def _nodes(self, full, off, n, L, T):
+        m = n + (1 if (L is Face and hi_wall(T)) else 0)
+        return full[off:off + m]
+
+    def xnodes(self, LX):
+        G = self.global_grid
+        x = G.xnodes(LX)
+        if LX is Face and not hi_wall(G.topology[0]):
+            x = np.append(x, x[-1] + (x[-1] - x[-2]))
+        return self._nodes(x, self.i_off, self.Nx, LX, self.topology[0])
+
+    def ynodes(self, LY):
+        G = self.global_grid
+        y = G.ynodes(LY)
+        if LY is Face and not hi_wall(G.topology[1]):
+            y = np.append(y, y[-1] + (y[-1] - y[-2]))
+        return self._nodes(y, self.j_off, self.Ny, LY, self.topology[1])
+
+    def metrics(self):
+        m = dict(self.global_grid.metrics())
+        if m["kind"] == "per_j":
+            n = self.Ny + 2 * self.Hy + 1
+            for k in ("dxc", "dxf", "azc", "azf"):
+                m[k] = np.ascontiguousarray(m[k][self.j_off:self.j_off + n])
+        return m
+
+    def local_interior(self, global_interior, LX, LY):
+        """The part of a global (ny, nx) interior array this tile owns (plus the wall face, if any)."""
+        nx, ny = self.interior_size(LX, LY)
+        return np.ascontiguousarray(global_interior[self.j_off:self.j_off + ny, self.i_off:self.i_off + nx])

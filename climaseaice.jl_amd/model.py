@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .dynamics import (ElastoViscoPlasticRheology, FPlane, IceStrength, SeaIceMomentumEquation, SemiImplicitStress)
 from .fields import CenterField, Field, XFaceField, YFaceField
-from .grids import Bounded, Periodic
+from .grids import Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
 
 
 class WENO:
@@ -35,7 +35,8 @@ class UpwindBiased:
         self.scheme = 1 if order == 1 else -5
 
 
-_TOPO = {Periodic: _lib.PERIODIC, Bounded: _lib.BOUNDED}
+_TOPO = {Periodic: _lib.PERIODIC, Bounded: _lib.BOUNDED, FullyConnected: _lib.FULLY_CONNECTED,
+         LeftConnected: _lib.LEFT_CONNECTED, RightConnected: _lib.RIGHT_CONNECTED}
 
 
 def _dptr(a):
@@ -93,6 +94,8 @@ class SeaIceModel:
                 self._keep.append(a)
                 setattr(met, k, _dptr(a))
         self.ctx.call("csi_grid_set", g.Nx, g.Ny, g.Hx, g.Hy, _TOPO[g.topology[0]], _TOPO[g.topology[1]], kind, C.byref(met))
+        if isinstance(g, TileGrid):
+            self._init_tiles(g)
         self._bind("H", self.ice_thickness)
         self._bind("A", self.ice_concentration)
         self._bind("U", self.velocities.u)
@@ -124,6 +127,32 @@ class SeaIceModel:
         self.ctx.call("csi_evp_params_set", C.byref(p))
         self._set_stress(_lib.STRESS_TOP, d.external_momentum_stresses.top, "TOP")
         self._set_stress(_lib.STRESS_BOTTOM, d.external_momentum_stresses.bottom, "BOT")
+
+    def _init_tiles(self, g):
+        """csi_tile_set + RCCL communicator: rank 0 makes the unique id, the host broadcasts it
+        (torch.distributed when there is more than one process; plumbing only)."""
+        self.ctx.call("csi_tile_set", g.rx, g.ry, g.Rx, g.Ry, int(g.periodic[0]), int(g.periodic[1]))
+        world = g.Rx * g.Ry
+        idbuf = (C.c_uint8 * 128)()
+        if world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("a tiled model with more than one tile needs torch.distributed to be initialised")
+            if dist.get_world_size() != world or dist.get_rank() != g.rank:
+                raise RuntimeError("tile rank / partition do not match torch.distributed")
+            payload = [None]
+            if g.rank == 0:
+                rc = self.ctx.L.csi_comm_unique_id(idbuf)
+                if rc != _lib.OK:
+                    raise _lib.CsiError(rc, self.ctx.L.csi_last_error(None).decode())
+                payload = [bytes(idbuf)]
+            dist.broadcast_object_list(payload, src=0)
+            idbuf = (C.c_uint8 * 128).from_buffer_copy(payload[0])
+        else:
+            rc = self.ctx.L.csi_comm_unique_id(idbuf)
+            if rc != _lib.OK:
+                raise _lib.CsiError(rc, self.ctx.L.csi_last_error(None).decode())
+        self.ctx.call("csi_comm_init", world, g.rank, idbuf)
 
     def _stress_field(self, slot, comp, value):
         """materialize_stress (sea_ice_external_stress.jl:63-69,132-137): a device copy on the model grid."""

@@ -236,6 +236,24 @@ int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const 
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 
+/* Index ranges (1-based, inclusive: i0, i1, j0, j1) the launch loop uses for a grid of this shape and
+ * topology, four ranges: [0..3] stress kernel (Auxiliaries kernel parameters -H+2:N+H-1,
+ * elasto_visco_plastic_rheology.jl:145; ring 1 on connected sides), [4..7] the u step when u is
+ * updated first, [8..11] the v step when v is updated first (both extended by the ring the second
+ * velocity reads on connected sides, cf. split_explicit_kernel_size,
+ * split_explicit_momentum_equations.jl:40-46), [12..15] the owned cells.  Pure host function. */
+int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t* out16);
+
+/* The halo-exchange plan of one tile for one field, eight directions in the library's fixed order
+ * (dy outer, dx inner, both -1..1, (0,0) skipped).  For k = 0..7, out40[5k..5k+4] = peer rank (-1: none),
+ * i0, j0, ni, nj (1-based start and extents of the strip).  halo = 0: the owned strips this tile SENDS, in
+ * send order; halo = 1: the halo strips it RECEIVES, in the order the matching sends were issued (message k
+ * arrives from the neighbour in direction -k).  Pure host function: the CPU multi-process tests drive a gloo
+ * exchange with exactly the plan the RCCL path uses. */
+int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y,
+                          int32_t rank_x, int32_t rank_y, int32_t Rx, int32_t Ry, int32_t periodic_x, int32_t periodic_y,
+                          int32_t width, int32_t halo, int32_t* out40);
+
 /* ---- introspection used by bench.py / tests ------------------------------------------------ */
 /* Device time (ms) of the last csi_evp_subcycle / csi_time_step_momentum call measured with HIP
  * events on the context's stream; valid after csi_sync. */

@@ -48,10 +48,19 @@ double ora_az(const ora_problem* g, int lx, int ly, int i, int j) {
     return (ly == C_) ? g->azc[j + g->Hy - 1] : g->azf[j + g->Hy - 1];
 }
 
+/* walls of a (tile of a) domain: Bounded has both; a tile at the end of a Bounded direction has one
+ * (ORA_RIGHT_CONNECTED: low side wall, ORA_LEFT_CONNECTED: high side wall; connected sides are filled by the
+ * halo exchange of the multi-process tests, never by a local boundary condition) */
+static int wall_lo(int topo) { return topo == ORA_BOUNDED || topo == ORA_RIGHT_CONNECTED; }
+static int wall_hi(int topo) { return topo == ORA_BOUNDED || topo == ORA_LEFT_CONNECTED; }
+static int outside_walls(const ora_problem* g, int i, int j) {
+    if ((wall_lo(g->topo_x) && i < 1) || (wall_hi(g->topo_x) && i > g->Nx)) return 1;
+    if ((wall_lo(g->topo_y) && j < 1) || (wall_hi(g->topo_y) && j > g->Ny)) return 1;
+    return 0;
+}
 /* inactive_cell: outside a Bounded domain or immersed (upstream Grids.inactive_cell) */
 static int inactive_cell(const ora_problem* g, int i, int j) {
-    if (g->topo_x == ORA_BOUNDED && (i < 1 || i > g->Nx)) return 1;
-    if (g->topo_y == ORA_BOUNDED && (j < 1 || j > g->Ny)) return 1;
+    if (outside_walls(g, i, j)) return 1;
     if (g->has_mask) {
         /* clamp into the stored array; halos of the mask are filled by the caller */
         if (i < 1 - g->Hx || i > g->Nx + g->Hx || j < 1 - g->Hy || j > g->Ny + g->Hy) return 1;
@@ -60,11 +69,7 @@ static int inactive_cell(const ora_problem* g, int i, int j) {
     return 0;
 }
 /* the same for the underlying (non-immersed) grid */
-static int inactive_cell_underlying(const ora_problem* g, int i, int j) {
-    if (g->topo_x == ORA_BOUNDED && (i < 1 || i > g->Nx)) return 1;
-    if (g->topo_y == ORA_BOUNDED && (j < 1 || j > g->Ny)) return 1;
-    return 0;
-}
+static int inactive_cell_underlying(const ora_problem* g, int i, int j) { return outside_walls(g, i, j); }
 /* peripheral_node(i,j,k,grid,Face,Center,Center), split_explicit_momentum_equations.jl:226 */
 int32_t ora_peripheral_u(const ora_problem* g, int i, int j) {
     return inactive_cell(g, i, j) | inactive_cell(g, i - 1, j);
@@ -432,52 +437,52 @@ void ora_v_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
 /*   c[1-m] = c[m], c[N+m] = c[N+1-m].  NONE: nothing (Face location in a     */
 /*   Bounded direction: impenetrable / auxiliary default).                    */
 /* ------------------------------------------------------------------------ */
-void ora_fill_halo(const ora_problem* g, ora_field f, int lx, int ly, int bcx, int bcy) {
+void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int bylo, int byhi) {
     int Nx = g->Nx, Ny = g->Ny, Hx = g->Hx, Hy = g->Hy;
-    (void)lx; (void)ly;
-    if (bcx == ORA_BC_PERIODIC) {
-        for (int j = 1; j <= Ny; ++j)
-            for (int m = 1; m <= Hx; ++m) {
-                AT(g, f, 1 - m, j) = AT(g, f, Nx + 1 - m, j);
-                AT(g, f, Nx + m, j) = AT(g, f, m, j);
-            }
-    } else if (bcx == ORA_BC_MIRROR) {
-        for (int j = 1; j <= Ny; ++j)
-            for (int m = 1; m <= Hx; ++m) {
-                AT(g, f, 1 - m, j) = AT(g, f, m, j);
-                AT(g, f, Nx + m, j) = AT(g, f, Nx + 1 - m, j);
-            }
-    }
+    /* x sides over the interior rows (upstream order: x first, then y over the whole x extent); on a tile
+     * whose y side is connected (no local y pass there) the rows beyond it are included, because the ring
+     * rows recomputed for the neighbours need their x images too. */
+    int jlo = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_LEFT_CONNECTED) ? 1 - Hy : 1;
+    int jhi = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_RIGHT_CONNECTED) ? Ny + Hy : Ny;
+    for (int j = jlo; j <= jhi; ++j)
+        for (int m = 1; m <= Hx; ++m) {
+            if (bxlo == ORA_BC_PERIODIC) AT(g, f, 1 - m, j) = AT(g, f, Nx + 1 - m, j);
+            else if (bxlo == ORA_BC_MIRROR) AT(g, f, 1 - m, j) = AT(g, f, m, j);
+            if (bxhi == ORA_BC_PERIODIC) AT(g, f, Nx + m, j) = AT(g, f, m, j);
+            else if (bxhi == ORA_BC_MIRROR) AT(g, f, Nx + m, j) = AT(g, f, Nx + 1 - m, j);
+        }
     /* y sides cover the full stored x extent (including the extra Face column, if any) */
     int64_t nxs = f.ld;
-    if (bcy == ORA_BC_PERIODIC) {
-        for (int m = 1; m <= Hy; ++m)
-            for (int64_t ii = 0; ii < nxs; ++ii) {
-                int i = (int)ii - Hx + 1;
-                AT(g, f, i, 1 - m) = AT(g, f, i, Ny + 1 - m);
-                AT(g, f, i, Ny + m) = AT(g, f, i, m);
-            }
-    } else if (bcy == ORA_BC_MIRROR) {
-        for (int m = 1; m <= Hy; ++m)
-            for (int64_t ii = 0; ii < nxs; ++ii) {
-                int i = (int)ii - Hx + 1;
-                AT(g, f, i, 1 - m) = AT(g, f, i, m);
-                AT(g, f, i, Ny + m) = AT(g, f, i, Ny + 1 - m);
-            }
-    }
+    for (int m = 1; m <= Hy; ++m)
+        for (int64_t ii = 0; ii < nxs; ++ii) {
+            int i = (int)ii - Hx + 1;
+            if (bylo == ORA_BC_PERIODIC) AT(g, f, i, 1 - m) = AT(g, f, i, Ny + 1 - m);
+            else if (bylo == ORA_BC_MIRROR) AT(g, f, i, 1 - m) = AT(g, f, i, m);
+            if (byhi == ORA_BC_PERIODIC) AT(g, f, i, Ny + m) = AT(g, f, i, m);
+            else if (byhi == ORA_BC_MIRROR) AT(g, f, i, Ny + m) = AT(g, f, i, Ny + 1 - m);
+        }
 }
-static int bc_of(int topo, int loc) {
+void ora_fill_halo(const ora_problem* g, ora_field f, int lx, int ly, int bcx, int bcy) {
+    (void)lx; (void)ly;
+    ora_fill_halo4(g, f, bcx, bcx, bcy, bcy);
+}
+static int bc_side(int topo, int loc, int high) {
     if (topo == ORA_PERIODIC) return ORA_BC_PERIODIC;
+    int wall = high ? wall_hi(topo) : wall_lo(topo);
+    if (!wall) return ORA_BC_NONE;              /* connected: left to the exchange */
     return loc == C_ ? ORA_BC_MIRROR : ORA_BC_NONE;
 }
-void ora_fill_halo_u(ora_problem* g) { ora_fill_halo(g, g->u, F_, C_, bc_of(g->topo_x, F_), bc_of(g->topo_y, C_)); }
-void ora_fill_halo_v(ora_problem* g) { ora_fill_halo(g, g->v, C_, F_, bc_of(g->topo_x, C_), bc_of(g->topo_y, F_)); }
-void ora_fill_halo_center(ora_problem* g, ora_field f) { ora_fill_halo(g, f, C_, C_, bc_of(g->topo_x, C_), bc_of(g->topo_y, C_)); }
+static void fill_loc(const ora_problem* g, ora_field f, int lx, int ly) {
+    ora_fill_halo4(g, f, bc_side(g->topo_x, lx, 0), bc_side(g->topo_x, lx, 1), bc_side(g->topo_y, ly, 0), bc_side(g->topo_y, ly, 1));
+}
+void ora_fill_halo_u(ora_problem* g) { fill_loc(g, g->u, F_, C_); }
+void ora_fill_halo_v(ora_problem* g) { fill_loc(g, g->v, C_, F_); }
+void ora_fill_halo_center(ora_problem* g, ora_field f) { fill_loc(g, f, C_, C_); }
 
 /* finalize_rheology!, evp:275-280: halo fill of sigma11, sigma12, sigma22 */
 void ora_finalize_rheology(ora_problem* g) {
     ora_fill_halo_center(g, g->s11);
-    ora_fill_halo(g, g->s12, F_, F_, bc_of(g->topo_x, F_), bc_of(g->topo_y, F_));
+    fill_loc(g, g->s12, F_, F_);
     ora_fill_halo_center(g, g->s22);
 }
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-enum { ORA_PERIODIC = 0, ORA_BOUNDED = 1 };
+enum { ORA_PERIODIC = 0, ORA_BOUNDED = 1, ORA_FULLY_CONNECTED = 2, ORA_LEFT_CONNECTED = 3, ORA_RIGHT_CONNECTED = 4 };
 enum { ORA_METRIC_UNIFORM = 0, ORA_METRIC_PER_J = 1 };
 enum { ORA_STRESS_NONE = 0, ORA_STRESS_CONST = 1, ORA_STRESS_FIELD = 2, ORA_STRESS_SEMI_IMPLICIT = 3 };
 enum { ORA_VEL_ZERO = 0, ORA_VEL_CONST = 1, ORA_VEL_FIELD = 2 };
@@ -121,6 +121,7 @@ void ora_u_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
 void ora_v_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int j1);  /* split_explicit:231-264 */
 /* fill_halo_regions!(...; only_local_halos=true) for one field (upstream) */
 void ora_fill_halo(const ora_problem* g, ora_field f, int lx, int ly, int bcx, int bcy);
+void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int bylo, int byhi);
 void ora_fill_halo_u(ora_problem* g);
 void ora_fill_halo_v(ora_problem* g);
 void ora_fill_halo_center(ora_problem* g, ora_field f);

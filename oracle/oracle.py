@@ -16,7 +16,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-PERIODIC, BOUNDED = 0, 1
+PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3, 4
+
+
+def hi_wall(t):
+    return t in (BOUNDED, LEFT_CONNECTED)
 METRIC_UNIFORM, METRIC_PER_J = 0, 1
 STRESS_NONE, STRESS_CONST, STRESS_FIELD, STRESS_SEMI_IMPLICIT = 0, 1, 2, 3
 VEL_ZERO, VEL_CONST, VEL_FIELD = 0, 1, 2
@@ -176,8 +180,8 @@ class Problem:
         self.f = {}
         for n in _FIELD_NAMES:
             lx, ly = LOCATION[n]
-            ni = Nx + 2 * Hx + (1 if (lx == FACE and topo[0] == BOUNDED) else 0)
-            nj = Ny + 2 * Hy + (1 if (ly == FACE and topo[1] == BOUNDED) else 0)
+            ni = Nx + 2 * Hx + (1 if (lx == FACE and hi_wall(topo[0])) else 0)
+            nj = Ny + 2 * Hy + (1 if (ly == FACE and hi_wall(topo[1])) else 0)
             a = np.zeros((nj, ni), dtype=np.float64)
             self.f[n] = a
             fld = getattr(s, n)
@@ -194,8 +198,8 @@ class Problem:
         s = self.s
         a = self.f[name]
         lx, ly = LOCATION[name]
-        nx = s.Nx + (1 if (lx == FACE and s.topo_x == BOUNDED) else 0)
-        ny = s.Ny + (1 if (ly == FACE and s.topo_y == BOUNDED) else 0)
+        nx = s.Nx + (1 if (lx == FACE and hi_wall(s.topo_x)) else 0)
+        ny = s.Ny + (1 if (ly == FACE and hi_wall(s.topo_y)) else 0)
         return a[s.Hy:s.Hy + ny, s.Hx:s.Hx + nx]
 
     def field_struct(self, name):

@@ -130,8 +130,22 @@ def oracle_problem(case, omp=False):
     return p
 
 
-def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0"):
+def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0", tile=None):
+    """tile = (Rx, Ry, rank[, force_connected]): build the model of one tile of the global case."""
     g = case["g"]
+    if tile is not None:
+        Rx, Ry, rank = tile[:3]
+        g = csi.TileGrid(g, Rx, Ry, rank % Rx, rank // Rx, force_connected=tile[3] if len(tile) > 3 else False)
+        case = dict(case)
+        for key, loc in (("h", (csi.Center, csi.Center)), ("a", (csi.Center, csi.Center)), ("u", (csi.Face, csi.Center)),
+                         ("v", (csi.Center, csi.Face))):
+            case[key] = g.local_interior(case[key], *loc)
+        if case.get("field_forcing"):
+            for key, loc in (("top_u", (csi.Face, csi.Center)), ("ue_f", (csi.Face, csi.Center)),
+                             ("top_v", (csi.Center, csi.Face)), ("ve_f", (csi.Center, csi.Face))):
+                case[key] = g.local_interior(case[key], *loc)
+        if case.get("mask") is not None:
+            raise NotImplementedError("masked tiles")
     if case.get("field_forcing"):
         top = (case["top_u"], case["top_v"])
         bottom = csi.SemiImplicitStress(ue=case["ue_f"], ve=case["ve_f"])

@@ -1,0 +1,99 @@
+"""Multi-GPU tiling logic on CPU: the library's index ranges and exchange plan (pure host functions of
+libcsi_hip.so) drive a tiled run of the oracle; owned cells must be BITWISE equal to the single-domain run
+(stronger than the reference's `isapprox`, test/distributed_tests_utils.jl:83-86).  world_size-2 runs use
+torch.distributed (gloo) between two processes; single-process self-exchange covers the FIFO matching."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+import climaseaice_jl_amd as csi
+import tiled
+
+FIELDS = ("u", "v", "s11", "s22", "s12")
+LOC = tiled._LOC
+
+
+def _global_reference(c):
+    p = cases.oracle_problem(c)
+    p.time_step_momentum(c["dt"])
+    return p
+
+
+def _check_tile(tg, p, ref, c):
+    for k in FIELDS:
+        LX, LY = LOC[k]
+        nx, ny = tg.Nx, tg.Ny
+        got = p.interior(k)[:ny, :nx]
+        want = ref.interior(k)[tg.j_off:tg.j_off + ny, tg.i_off:tg.i_off + nx]
+        assert np.array_equal(got, want), (k, tg.rank, np.abs(got - want).max())
+
+
+def test_plan_ranges_match_reference_kernel_parameters():
+    L = csi._lib
+    # serial grid: stress range -H+2 : N+H-1 (evp:145), velocity kernels :xy
+    assert csi.plan_ranges(48, 8, 4, 4, L.PERIODIC, L.BOUNDED) == ((-2, 51, -2, 11), (1, 48, 1, 8), (1, 48, 1, 8), (1, 48, 1, 8))
+    # tile: ring 1 on connected sides, first velocity extended by the ring the second one reads
+    rs, ru, rv, own = csi.plan_ranges(32, 16, 4, 4, L.FULLY_CONNECTED, L.RIGHT_CONNECTED)
+    assert rs == (0, 33, -2, 17) and ru == (1, 33, 1, 16) and rv == (0, 32, 1, 17) and own == (1, 32, 1, 16)
+
+
+def test_self_connected_single_process_bitwise():
+    """One tile, both periodic directions forced to exchange with itself (every neighbour is this rank, two
+    messages per peer pair in each direction: exercises the FIFO ordering of the plan)."""
+    c = cases.make_case(Nx=40, Ny=32, substeps=9, topo=("periodic", "periodic"), random_uv=0.05)
+    ref = _global_reference(c)
+    tg, p = tiled.tile_problem(c, 1, 1, 0, force_connected=True)
+    tiled.tiled_time_step_momentum(tg, p, c["dt"], tiled.Exchanger(tg, None))
+    _check_tile(tg, p, ref, c)
+
+
+def _worker(rank, world, Rx, Ry, case_kw, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = cases.make_case(**case_kw)
+        tg, p = tiled.tile_problem(c, Rx, Ry, rank)
+        tiled.tiled_time_step_momentum(tg, p, c["dt"], tiled.Exchanger(tg, dist))
+        out = {k: p.interior(k)[:tg.Ny, :tg.Nx].copy() for k in FIELDS}
+        q.put((rank, tg.i_off, tg.j_off, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+PARTITIONS = [
+    ("x2_periodic", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "periodic"))),
+    ("y2_periodic", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"))),
+    ("y2_bounded", 1, 2, dict(Nx=40, Ny=48, topo=("bounded", "bounded"))),
+    ("x2_channel_latlon", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "bounded"), grid="latlon")),
+]
+
+
+@pytest.mark.parametrize("name,Rx,Ry,kw", PARTITIONS, ids=[p[0] for p in PARTITIONS])
+def test_two_process_gloo_tiles_bitwise(name, Rx, Ry, kw):
+    """world_size = 2 (gloo): tiled == single domain, bit for bit, on the owned cells of both tiles."""
+    case_kw = dict(substeps=8, random_uv=0.05, patches=True, **kw)
+    c = cases.make_case(**case_kw)
+    ref = _global_reference(c)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + PARTITIONS.index((name, Rx, Ry, kw))
+    procs = [ctx.Process(target=_worker, args=(r, 2, Rx, Ry, case_kw, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, i_off, j_off, out in results:
+        for k in FIELDS:
+            ny, nx = out[k].shape
+            want = ref.interior(k)[j_off:j_off + ny, i_off:i_off + nx]
+            assert np.array_equal(out[k], want), (name, rank, k, np.abs(out[k] - want).max())

@@ -1,0 +1,119 @@
+"""Tiled (multi-process) runs of the EVP sub-cycle with the CPU oracle as the per-tile compute and an
+explicit halo exchange driven by THE LIBRARY'S OWN exchange plan and index ranges (csi_plan_exchange,
+csi_plan_ranges: pure host functions of libcsi_hip.so).  The GPU path runs the same plan over RCCL;
+here the transport is torch.distributed (gloo) so the N > 1 logic is covered on CPU."""
+import numpy as np
+
+import cases
+import climaseaice_jl_amd as csi
+import oracle as O
+
+_TOPO_CODE = {csi.Periodic: O.PERIODIC, csi.Bounded: O.BOUNDED, csi.FullyConnected: O.FULLY_CONNECTED,
+              csi.LeftConnected: O.LEFT_CONNECTED, csi.RightConnected: O.RIGHT_CONNECTED}
+_LOC = {"u": (csi.Face, csi.Center), "v": (csi.Center, csi.Face), "h": (csi.Center, csi.Center),
+        "aice": (csi.Center, csi.Center), "s11": (csi.Center, csi.Center), "s22": (csi.Center, csi.Center),
+        "s12": (csi.Face, csi.Face)}
+
+
+def tile_problem(case, Rx, Ry, rank, force_connected=False):
+    """Oracle problem of tile `rank` of the global case (fields sliced from the global arrays)."""
+    g = case["g"]
+    tg = csi.TileGrid(g, Rx, Ry, rank % Rx, rank // Rx, force_connected=force_connected)
+    topo = tuple(_TOPO_CODE[t] for t in tg.topology)
+    m = tg.metrics()
+    if m["kind"] == "uniform":
+        p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"])
+    else:
+        p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, per_j=m, substeps=case["substeps"])
+    p.set_coriolis(case["coriolis"])
+    if case["top"] is not None:
+        p.set_stress("top", O.STRESS_CONST, tau=case["top"])
+    if case["bottom"] == "semi":
+        p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    for name, key in (("h", "h"), ("aice", "a"), ("u", "u"), ("v", "v")):
+        p.interior(name)[...] = tg.local_interior(case[key], *_LOC[name])
+    return tg, p
+
+
+class Exchanger:
+    """Halo exchange of oracle fields through torch.distributed, following csi_plan_exchange."""
+
+    def __init__(self, tg, dist=None):
+        self.tg, self.dist = tg, dist
+        L = csi._lib
+        self.topo = ({csi.Periodic: L.PERIODIC, csi.Bounded: L.BOUNDED, csi.FullyConnected: L.FULLY_CONNECTED,
+                      csi.LeftConnected: L.LEFT_CONNECTED, csi.RightConnected: L.RIGHT_CONNECTED}[tg.topology[0]],
+                     {csi.Periodic: L.PERIODIC, csi.Bounded: L.BOUNDED, csi.FullyConnected: L.FULLY_CONNECTED,
+                      csi.LeftConnected: L.LEFT_CONNECTED, csi.RightConnected: L.RIGHT_CONNECTED}[tg.topology[1]])
+
+    def plan(self, W, halo):
+        t = self.tg
+        return csi.plan_exchange(t.Nx, t.Ny, t.Hx, t.Hy, self.topo[0], self.topo[1], t.rx, t.ry, t.Rx, t.Ry,
+                                 t.periodic[0], t.periodic[1], W, halo)
+
+    def __call__(self, p, names, W):
+        import torch
+        t = self.tg
+        sp, rp = self.plan(W, 0), self.plan(W, 1)
+
+        def view(a, i0, j0, ni, nj):
+            return a[j0 + t.Hy - 1:j0 + t.Hy - 1 + nj, i0 + t.Hx - 1:i0 + t.Hx - 1 + ni]
+
+        sends = []
+        for (peer, i0, j0, ni, nj) in sp:
+            if peer >= 0:
+                sends.append((peer, torch.from_numpy(np.concatenate([view(p.f[n], i0, j0, ni, nj).ravel() for n in names]))))
+        recvs = [(peer, i0, j0, ni, nj, torch.empty(ni * nj * len(names), dtype=torch.float64))
+                 for (peer, i0, j0, ni, nj) in rp if peer >= 0]
+        me = t.rank
+        if self.dist is None:
+            # one process: every neighbour is this tile itself; FIFO matching per peer
+            assert all(peer == me for peer, _ in sends)
+            for (peer, buf), r in zip(sends, recvs):
+                r[5].copy_(buf)
+        else:
+            reqs = []
+            # messages between one pair of ranks match in FIFO order: post them in plan order
+            for peer, buf in sends:
+                if peer == me:
+                    continue
+                reqs.append(self.dist.isend(buf, dst=peer))
+            self_msgs = [buf for peer, buf in sends if peer == me]
+            k = 0
+            for r in recvs:
+                if r[0] == me:
+                    r[5].copy_(self_msgs[k]); k += 1
+                else:
+                    reqs.append(self.dist.irecv(r[5], src=r[0]))
+            for q in reqs:
+                q.wait()
+        for (peer, i0, j0, ni, nj, buf) in recvs:
+            b = buf.numpy()
+            for k, n in enumerate(names):
+                view(p.f[n], i0, j0, ni, nj)[...] = b[k * ni * nj:(k + 1) * ni * nj].reshape(nj, ni)
+
+
+def tiled_time_step_momentum(tg, p, dt, ex):
+    """time_step_momentum! on one tile: the launch loop of csi_abi.hip (do_time_step_momentum) restated with
+    the oracle's kernels, the library's ranges and an explicit exchange."""
+    L = csi._lib
+    rs, ru1, rv1, own = csi.plan_ranges(tg.Nx, tg.Ny, tg.Hx, tg.Hy, ex.topo[0], ex.topo[1])
+    Hmin = min(tg.Hx, tg.Hy)
+    # update_state!
+    p.update_state()
+    ex(p, ["h", "aice", "u", "v"], Hmin)
+    p.initialize_rheology()
+    p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
+    ex(p, ["u", "v"], 2)
+    for s in range(1, p.s.substeps + 1):
+        p.L.ora_compute_viscosities(p.ptr, *rs)
+        p.L.ora_compute_stresses(p.ptr, dt, *rs)
+        if s % 2 == 0:
+            p.L.ora_u_velocity_step(p.ptr, dt, *ru1); p.L.ora_fill_halo_u(p.ptr)
+            p.L.ora_v_velocity_step(p.ptr, dt, *own); p.L.ora_fill_halo_v(p.ptr)
+        else:
+            p.L.ora_v_velocity_step(p.ptr, dt, *rv1); p.L.ora_fill_halo_v(p.ptr)
+            p.L.ora_u_velocity_step(p.ptr, dt, *own); p.L.ora_fill_halo_u(p.ptr)
+        ex(p, ["u", "v"], 2)
+    p.L.ora_finalize_rheology(p.ptr)
+    ex(p, ["s11", "s12", "s22"], Hmin)
