@@ -30,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
-           "csi_plan_exchange", "csi_plan_ranges", "csi_last_subcycle_ms", "csi_launches_per_substep"]
+           "csi_plan_exchange", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_subcycle_ms", "csi_launches_per_substep"]
 
 
 class Metrics(C.Structure):
@@ -104,8 +104,10 @@ def load():
         "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],
         "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
-        "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
+        "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
+        "csi_set_exchange_interval": [vp, i32],
         "csi_plan_exchange": [i32] * 14 + [C.POINTER(i32)],
+        "csi_profile_substeps": [vp, dbl, i32, C.POINTER(dbl)],
         "csi_last_subcycle_ms": [vp, C.POINTER(dbl)], "csi_launches_per_substep": [vp, C.POINTER(i32)],
     }
     for name, args in sig.items():
@@ -116,10 +118,10 @@ def load():
     return L
 
 
-def plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y):
-    """(stress, u-first, v-first, owned) index ranges of the launch loop (pure host function of the library)."""
+def plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y, valid_width=2):
+    """(stress, u-first, v-first, second-velocity) index ranges of the launch loop (pure host function)."""
     out = (C.c_int32 * 16)()
-    rc = load().csi_plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y, out)
+    rc = load().csi_plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y, valid_width, out)
     if rc != OK:
         raise CsiError(rc, "csi_plan_ranges")
     v = list(out)
@@ -168,6 +170,11 @@ class Context:
         v = C.c_double()
         self.call("csi_last_subcycle_ms", C.byref(v))
         return v.value
+
+    def profile_substeps(self, dt, substeps=16):
+        out = (C.c_double * 4)()
+        self.call("csi_profile_substeps", float(dt), int(substeps), out)
+        return dict(stress=out[0], ustep=out[1], vstep=out[2], exchange=out[3])
 
     def launches_per_substep(self):
         v = C.c_int32()

@@ -71,6 +71,8 @@ struct csi_context {
     int world = 1, rank = 0;
     double *sendbuf = nullptr, *recvbuf = nullptr;
     size_t buf_cap = 0;   // elements per buffer
+    int last_exchanges = 0, last_k = 1;
+    int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
 };
 
 namespace {
@@ -176,20 +178,33 @@ EvpDev evp_dev(const csi_context* c, double dt) {
 // Index ranges (1-based, inclusive).  Stress kernels: Auxiliaries kernel parameters
 // -H+2 : N+H-1 (elasto_visco_plastic_rheology.jl:145); velocity kernels: :xy on a serial grid,
 // split_explicit_kernel_size on connected (tile) sides (split_explicit_momentum_equations.jl:40-46).
-// On a connected (tile) side only u, v of width 2 are valid, so the stress kernel covers ring 1 there and the
-// first velocity of the sub-step is recomputed on the ring the second one reads.
-Range stress_range(const csi_context* c) {
+// Connected (tile) sides.  Between two halo exchanges only V layers of u, v beyond the owned cells are
+// valid (V = exchange width at the start of a batch, shrinking by 2 per sub-step):
+//   stress                       [2-V, N+V-1]
+//   first velocity  (u first)    x [3-V, N+V-1], y [2-V, N+V-2]      (v first: x and y swapped)
+//   second velocity              [3-V, N+V-2]
+// recomputed redundantly on the ring so that sigma, alpha never need exchanging inside the sub-cycle.
+// V = 2 (exchange every sub-step) gives stress [0, N+1], first velocity [1, N+1] x [0, N], second [1, N].
+// Sides with a local boundary condition keep the reference's ranges (-H+2 : N+H-1 and 1 : N).
+Range stress_range(const csi_context* c, int V = 2) {
     const GridDev& g = c->g;
-    return Range{g.xlo == SIDE_CONNECTED ? 0 : -c->Hx + 2, g.xhi == SIDE_CONNECTED ? c->Nx + 1 : c->Nx + c->Hx - 1,
-                 g.ylo == SIDE_CONNECTED ? 0 : -c->Hy + 2, g.yhi == SIDE_CONNECTED ? c->Ny + 1 : c->Ny + c->Hy - 1};
+    return Range{g.xlo == SIDE_CONNECTED ? 2 - V : -c->Hx + 2, g.xhi == SIDE_CONNECTED ? c->Nx + V - 1 : c->Nx + c->Hx - 1,
+                 g.ylo == SIDE_CONNECTED ? 2 - V : -c->Hy + 2, g.yhi == SIDE_CONNECTED ? c->Ny + V - 1 : c->Ny + c->Hy - 1};
 }
-Range first_u_range(const csi_context* c) {   // u first: the v step reads new u at (i..i+1, j-1..j)
+Range first_u_range(const csi_context* c, int V = 2) {
     const GridDev& g = c->g;
-    return Range{1, c->Nx + (g.xhi == SIDE_CONNECTED ? 1 : 0), 1 - (g.ylo == SIDE_CONNECTED ? 1 : 0), c->Ny};
+    return Range{g.xlo == SIDE_CONNECTED ? 3 - V : 1, g.xhi == SIDE_CONNECTED ? c->Nx + V - 1 : c->Nx,
+                 g.ylo == SIDE_CONNECTED ? 2 - V : 1, g.yhi == SIDE_CONNECTED ? c->Ny + V - 2 : c->Ny};
 }
-Range first_v_range(const csi_context* c) {   // v first: the u step reads new v at (i-1..i, j..j+1)
+Range first_v_range(const csi_context* c, int V = 2) {
     const GridDev& g = c->g;
-    return Range{1 - (g.xlo == SIDE_CONNECTED ? 1 : 0), c->Nx, 1, c->Ny + (g.yhi == SIDE_CONNECTED ? 1 : 0)};
+    return Range{g.xlo == SIDE_CONNECTED ? 2 - V : 1, g.xhi == SIDE_CONNECTED ? c->Nx + V - 2 : c->Nx,
+                 g.ylo == SIDE_CONNECTED ? 3 - V : 1, g.yhi == SIDE_CONNECTED ? c->Ny + V - 1 : c->Ny};
+}
+Range second_range(const csi_context* c, int V = 2) {
+    const GridDev& g = c->g;
+    return Range{g.xlo == SIDE_CONNECTED ? 3 - V : 1, g.xhi == SIDE_CONNECTED ? c->Nx + V - 2 : c->Nx,
+                 g.ylo == SIDE_CONNECTED ? 3 - V : 1, g.yhi == SIDE_CONNECTED ? c->Ny + V - 2 : c->Ny};
 }
 bool is_tiled(const csi_context* c) {
     const GridDev& g = c->g;
@@ -272,9 +287,24 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     if ((rc = fill_halo(c, CSI_F_V))) return rc;     // :171
     const bool tiled = is_tiled(c);
     const int uv[2] = {CSI_F_U, CSI_F_V};
-    if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;
+    // halo exchange of u, v every k sub-steps with width 2k (k = 1: every sub-step; the reference is the
+    // k = substeps extreme with its 2*substeps+3 halo, split_explicit_momentum_equations.jl:51-64)
+    int k = 1;
+    if (tiled) {
+        const int hmin = c->Hx < c->Hy ? c->Hx : c->Hy, nmin = c->Nx < c->Ny ? c->Nx : c->Ny;
+        k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 4 ? hmin / 2 : 4);
+        while (k > 1 && (2 * k > hmin || 2 * k > nmin)) --k;
+        if (k < 1) k = 1;
+    }
+    const int W = 2 * k;
+    // sigma is history dependent (sigma += (sigma' - sigma) / gamma): with k = 1 the ring-1 values are
+    // recomputed every sub-step and stay identical to the neighbour's; with k > 1 the outer rings skip
+    // updates inside a batch, so sigma travels with u, v.  alpha is recomputed before every use.
+    const int uvs[5] = {CSI_F_U, CSI_F_V, CSI_F_S11, CSI_F_S22, CSI_F_S12};
+    const int nxf = k > 1 ? 5 : 2;
+    (void)uv;
+    if (tiled && (rc = exchange(c, uvs, nxf, W))) return rc;
     EvpDev P = evp_dev(c, dt);
-    const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const bool fast = c->mode == CSI_MODE_FAST;
     FastCoef fc = c->coef;
@@ -286,7 +316,10 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     }
     if (fast && !fast_supported(P)) return fail(c, CSI_ERR_UNSUPPORTED, "CSI_MODE_FAST does not support this configuration yet; use CSI_MODE_STRICT");
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    int m = 0, nex = 0;   // position inside the exchange batch
     for (int s = first; s < first + substeps; ++s) {
+        const int V = W - 2 * m;
+        const Range rs = stress_range(c, V), ru1 = first_u_range(c, V), rv1 = first_v_range(c, V), r2 = second_range(c, V);
         if (fast) {
             P.write_diag = (s == first + substeps - 1);
             launch_fast_stress(P, rs, fc, c->stream);
@@ -295,19 +328,25 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
             launch_strict_stress(P, rs, c->stream);
         }
         if ((s % 2) == 0) {                                // :178-182
-            if (fast) { launch_fast_ustep(P, ru1, imu, fc, c->stream); launch_fast_vstep(P, rv, imv, fc, c->stream); }
-            else { launch_strict_ustep(P, ru1, imu, c->stream); launch_strict_vstep(P, rv, imv, c->stream); }
+            if (fast) { launch_fast_ustep(P, ru1, imu, fc, c->stream); launch_fast_vstep(P, r2, imv, fc, c->stream); }
+            else { launch_strict_ustep(P, ru1, imu, c->stream); launch_strict_vstep(P, r2, imv, c->stream); }
         } else {                                           // :184-187
-            if (fast) { launch_fast_vstep(P, rv1, imv, fc, c->stream); launch_fast_ustep(P, rv, imu, fc, c->stream); }
-            else { launch_strict_vstep(P, rv1, imv, c->stream); launch_strict_ustep(P, rv, imu, c->stream); }
+            if (fast) { launch_fast_vstep(P, rv1, imv, fc, c->stream); launch_fast_ustep(P, r2, imu, fc, c->stream); }
+            else { launch_strict_vstep(P, rv1, imv, c->stream); launch_strict_ustep(P, r2, imu, c->stream); }
         }
-        // tiles: u, v halos of width 2 from the neighbours, once per sub-step (RCCL send/recv)
-        if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;
+        ++m;
+        if (tiled && (m == k || s == first + substeps - 1)) {   // RCCL send/recv of the u, v halos
+            if ((rc = exchange(c, uvs, nxf, W))) return rc;
+            m = 0;
+            ++nex;
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipGetLastError());
     c->timed = true;
-    c->launches_per_substep = (fast ? 3 : 4) + (tiled ? 3 : 0);
+    c->launches_per_substep = (fast ? 3 : 4) + ((tiled && k == 1) ? 3 : 0);
+    c->last_exchanges = nex;
+    c->last_k = k;
     return CSI_OK;
 }
 
@@ -329,7 +368,7 @@ int32_t need_evp(csi_context* c) {
     if ((rc = check_stress_fields(c, CSI_STRESS_BOTTOM))) return rc;
     if (c->Hx < 2 || c->Hy < 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "EVP needs halo >= 2");
     if (c->Nx < c->Hx || c->Ny < c->Hy) return fail(c, CSI_ERR_UNSUPPORTED, "tile smaller than its halo");
-    if (is_tiled(c) && (c->Hx < 3 || c->Hy < 3)) return fail(c, CSI_ERR_INVALID_ARGUMENT, "tiled EVP needs halo >= 3");
+    if (is_tiled(c) && !c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
     return CSI_OK;
 }
 
@@ -344,7 +383,7 @@ int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_re
     if (is_tiled(c)) {                                      // update_external_stress! :133-134 (forcing halos)
         int ff[4], n = 0;
         for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V}) if (c->f[id].p) ff[n++] = id;
-        if (n && (rc = exchange(c, ff, n, 2))) return rc;
+        if (n && (rc = exchange(c, ff, n, c->Hx < c->Hy ? c->Hx : c->Hy))) return rc;
     }
     if ((rc = do_subcycle(c, dt, substeps, 1))) return rc;  // :170-189
     return do_finalize(c);                                  // :192
@@ -742,13 +781,63 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
     return CSI_OK;
 }
 
-int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t* out16) {
-    if (!out16 || Nx < 1 || Ny < 1) return CSI_ERR_INVALID_ARGUMENT;
+int32_t csi_set_exchange_interval(csi_context* c, int32_t k) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (k < 0 || k > 64) return fail(c, CSI_ERR_INVALID_ARGUMENT, "0 <= k <= 64");
+    c->exch_k = k;
+    return CSI_OK;
+}
+
+int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t V, int32_t* out16) {
+    if (!out16 || Nx < 1 || Ny < 1 || V < 2) return CSI_ERR_INVALID_ARGUMENT;
     csi_context tmp;
     tmp.Nx = Nx; tmp.Ny = Ny; tmp.Hx = Hx; tmp.Hy = Hy;
     tmp.g.xlo = side_lo(topo_x); tmp.g.xhi = side_hi(topo_x); tmp.g.ylo = side_lo(topo_y); tmp.g.yhi = side_hi(topo_y);
-    const Range r[4] = {stress_range(&tmp), first_u_range(&tmp), first_v_range(&tmp), interior_range(&tmp)};
+    const Range r[4] = {stress_range(&tmp, V), first_u_range(&tmp, V), first_v_range(&tmp, V), second_range(&tmp, V)};
     for (int k = 0; k < 4; ++k) { out16[4 * k] = r[k].i0; out16[4 * k + 1] = r[k].i1; out16[4 * k + 2] = r[k].j0; out16[4 * k + 3] = r[k].j1; }
+    return CSI_OK;
+}
+
+int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double* out_ms4) {
+    if (!c || !out_ms4) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = need_evp(c);
+    if (rc) return rc;
+    if (substeps < 2 || substeps > 64) return fail(c, CSI_ERR_INVALID_ARGUMENT, "2 <= substeps <= 64");
+    EvpDev P = evp_dev(c, dt);
+    FastCoef fc = c->coef;
+    { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = P.ca * dt; fc.rdt = 1.0 / dt; }
+    const bool fast = c->mode == CSI_MODE_FAST, tiled = is_tiled(c);
+    const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
+    const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
+    const int uv[2] = {CSI_F_U, CSI_F_V};
+    std::vector<hipEvent_t> ev((size_t)substeps * 4 + 1);
+    for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
+    if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;    // sizes the buffers outside the timed part
+    size_t k = 0;
+    HIP_TRY(c, hipEventRecord(ev[k++], c->stream));
+    for (int s = 1; s <= substeps; ++s) {
+        if (fast) launch_fast_stress(P, rs, fc, c->stream);
+        else { launch_strict_visc(P, rs, c->stream); launch_strict_stress(P, rs, c->stream); }
+        HIP_TRY(c, hipEventRecord(ev[k++], c->stream));
+        // u then v on every sub-step here (the order only permutes which kernel has the ring range)
+        if (fast) launch_fast_ustep(P, ru1, imu, fc, c->stream); else launch_strict_ustep(P, ru1, imu, c->stream);
+        HIP_TRY(c, hipEventRecord(ev[k++], c->stream));
+        if (fast) launch_fast_vstep(P, rv, imv, fc, c->stream); else launch_strict_vstep(P, rv, imv, c->stream);
+        HIP_TRY(c, hipEventRecord(ev[k++], c->stream));
+        if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;
+        HIP_TRY(c, hipEventRecord(ev[k++], c->stream));
+        (void)rv1;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double acc[4] = {0, 0, 0, 0};
+    for (int s = 0; s < substeps; ++s)
+        for (int q = 0; q < 4; ++q) {
+            float t = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&t, ev[(size_t)s * 4 + q], ev[(size_t)s * 4 + q + 1]));
+            acc[q] += t;
+        }
+    for (int q = 0; q < 4; ++q) out_ms4[q] = acc[q] / substeps;
+    for (auto& e : ev) hipEventDestroy(e);
     return CSI_OK;
 }
 

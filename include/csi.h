@@ -236,13 +236,19 @@ int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const 
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 
+/* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
+ * k <= 4 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
+ * k = substeps extreme (halo 2*substeps+3, split_explicit_momentum_equations.jl:51-64). */
+int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
+
 /* Index ranges (1-based, inclusive: i0, i1, j0, j1) the launch loop uses for a grid of this shape and
- * topology, four ranges: [0..3] stress kernel (Auxiliaries kernel parameters -H+2:N+H-1,
- * elasto_visco_plastic_rheology.jl:145; ring 1 on connected sides), [4..7] the u step when u is
- * updated first, [8..11] the v step when v is updated first (both extended by the ring the second
- * velocity reads on connected sides, cf. split_explicit_kernel_size,
- * split_explicit_momentum_equations.jl:40-46), [12..15] the owned cells.  Pure host function. */
-int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t* out16);
+ * topology when `valid_width` (V >= 2) layers of u, v beyond the owned cells are valid on connected sides:
+ * [0..3] stress kernel (Auxiliaries kernel parameters -H+2:N+H-1, elasto_visco_plastic_rheology.jl:145, on
+ * local sides; 2-V : N+V-1 on connected sides), [4..7] the u step when u is updated first, [8..11] the v step
+ * when v is updated first, [12..15] the velocity updated second (cf. split_explicit_kernel_size,
+ * split_explicit_momentum_equations.jl:40-46).  Pure host function. */
+int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y,
+                        int32_t valid_width, int32_t* out16);
 
 /* The halo-exchange plan of one tile for one field, eight directions in the library's fixed order
  * (dy outer, dx inner, both -1..1, (0,0) skipped).  For k = 0..7, out40[5k..5k+4] = peer rank (-1: none),
@@ -258,6 +264,11 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
 /* Device time (ms) of the last csi_evp_subcycle / csi_time_step_momentum call measured with HIP
  * events on the context's stream; valid after csi_sync. */
 int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
+/* Per-phase device time: runs `substeps` (2..64) further EVP sub-steps from the current state with HIP
+ * events between the launches on the context's stream and returns the average milliseconds of
+ * [0] the stress phase, [1] the u step, [2] the v step, [3] the halo exchange (0 on an untiled grid).
+ * Synchronises; for bench.py's roofline only, never on the timed path. */
+int32_t csi_profile_substeps(csi_context* ctx, double dt, int32_t substeps, double* out_ms4);
 /* Number of kernel launches issued for one sub-step in the current configuration. */
 int32_t csi_launches_per_substep(csi_context* ctx, int32_t* n);
 

@@ -41,26 +41,30 @@ def test_plan_ranges_match_reference_kernel_parameters():
     # tile: ring 1 on connected sides, first velocity extended by the ring the second one reads
     rs, ru, rv, own = csi.plan_ranges(32, 16, 4, 4, L.FULLY_CONNECTED, L.RIGHT_CONNECTED)
     assert rs == (0, 33, -2, 17) and ru == (1, 33, 1, 16) and rv == (0, 32, 1, 17) and own == (1, 32, 1, 16)
+    # exchange every 2 sub-steps (valid width 4 at the start of the batch): one ring more everywhere
+    rs, ru, rv, sec = csi.plan_ranges(32, 16, 4, 4, L.FULLY_CONNECTED, L.FULLY_CONNECTED, 4)
+    assert rs == (-2, 35, -2, 19) and ru == (-1, 35, -2, 18) and rv == (-2, 34, -1, 19) and sec == (-1, 34, -1, 18)
 
 
-def test_self_connected_single_process_bitwise():
+@pytest.mark.parametrize("k", [1, 2])
+def test_self_connected_single_process_bitwise(k):
     """One tile, both periodic directions forced to exchange with itself (every neighbour is this rank, two
     messages per peer pair in each direction: exercises the FIFO ordering of the plan)."""
     c = cases.make_case(Nx=40, Ny=32, substeps=9, topo=("periodic", "periodic"), random_uv=0.05)
     ref = _global_reference(c)
     tg, p = tiled.tile_problem(c, 1, 1, 0, force_connected=True)
-    tiled.tiled_time_step_momentum(tg, p, c["dt"], tiled.Exchanger(tg, None))
+    tiled.tiled_time_step_momentum(tg, p, c["dt"], tiled.Exchanger(tg, None), k=k)
     _check_tile(tg, p, ref, c)
 
 
-def _worker(rank, world, Rx, Ry, case_kw, port, q):
+def _worker(rank, world, Rx, Ry, case_kw, port, q, k=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         c = cases.make_case(**case_kw)
         tg, p = tiled.tile_problem(c, Rx, Ry, rank)
-        tiled.tiled_time_step_momentum(tg, p, c["dt"], tiled.Exchanger(tg, dist))
+        tiled.tiled_time_step_momentum(tg, p, c["dt"], tiled.Exchanger(tg, dist), k=k)
         out = {k: p.interior(k)[:tg.Ny, :tg.Nx].copy() for k in FIELDS}
         q.put((rank, tg.i_off, tg.j_off, out))
         dist.barrier()
@@ -76,16 +80,17 @@ PARTITIONS = [
 ]
 
 
+@pytest.mark.parametrize("k", [1, 2])
 @pytest.mark.parametrize("name,Rx,Ry,kw", PARTITIONS, ids=[p[0] for p in PARTITIONS])
-def test_two_process_gloo_tiles_bitwise(name, Rx, Ry, kw):
+def test_two_process_gloo_tiles_bitwise(name, Rx, Ry, kw, k):
     """world_size = 2 (gloo): tiled == single domain, bit for bit, on the owned cells of both tiles."""
-    case_kw = dict(substeps=8, random_uv=0.05, patches=True, **kw)
+    case_kw = dict(substeps=9, random_uv=0.05, patches=True, **kw)
     c = cases.make_case(**case_kw)
     ref = _global_reference(c)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + PARTITIONS.index((name, Rx, Ry, kw))
-    procs = [ctx.Process(target=_worker, args=(r, 2, Rx, Ry, case_kw, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + 2 * PARTITIONS.index((name, Rx, Ry, kw)) + k
+    procs = [ctx.Process(target=_worker, args=(r, 2, Rx, Ry, case_kw, port, q, k)) for r in range(2)]
     for pr in procs:
         pr.start()
     results = [q.get(timeout=180) for _ in range(2)]

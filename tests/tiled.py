@@ -93,27 +93,35 @@ class Exchanger:
                 view(p.f[n], i0, j0, ni, nj)[...] = b[k * ni * nj:(k + 1) * ni * nj].reshape(nj, ni)
 
 
-def tiled_time_step_momentum(tg, p, dt, ex):
-    """time_step_momentum! on one tile: the launch loop of csi_abi.hip (do_time_step_momentum) restated with
-    the oracle's kernels, the library's ranges and an explicit exchange."""
-    L = csi._lib
-    rs, ru1, rv1, own = csi.plan_ranges(tg.Nx, tg.Ny, tg.Hx, tg.Hy, ex.topo[0], ex.topo[1])
+def tiled_time_step_momentum(tg, p, dt, ex, k=1):
+    """time_step_momentum! on one tile: the launch loop of csi_abi.hip (do_time_step_momentum / do_subcycle)
+    restated with the oracle's kernels, the library's ranges and an explicit exchange of width 2k every k
+    sub-steps."""
     Hmin = min(tg.Hx, tg.Hy)
-    # update_state!
+    W = 2 * k
+    assert W <= Hmin
     p.update_state()
     ex(p, ["h", "aice", "u", "v"], Hmin)
     p.initialize_rheology()
     p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
-    ex(p, ["u", "v"], 2)
-    for s in range(1, p.s.substeps + 1):
+    xf = ["u", "v"] if k == 1 else ["u", "v", "s11", "s22", "s12"]   # sigma is history dependent (csi_abi.hip)
+    ex(p, xf, W)
+    m = 0
+    nsub = p.s.substeps
+    for s in range(1, nsub + 1):
+        V = W - 2 * m
+        rs, ru1, rv1, r2 = csi.plan_ranges(tg.Nx, tg.Ny, tg.Hx, tg.Hy, ex.topo[0], ex.topo[1], V)
         p.L.ora_compute_viscosities(p.ptr, *rs)
         p.L.ora_compute_stresses(p.ptr, dt, *rs)
         if s % 2 == 0:
             p.L.ora_u_velocity_step(p.ptr, dt, *ru1); p.L.ora_fill_halo_u(p.ptr)
-            p.L.ora_v_velocity_step(p.ptr, dt, *own); p.L.ora_fill_halo_v(p.ptr)
+            p.L.ora_v_velocity_step(p.ptr, dt, *r2); p.L.ora_fill_halo_v(p.ptr)
         else:
             p.L.ora_v_velocity_step(p.ptr, dt, *rv1); p.L.ora_fill_halo_v(p.ptr)
-            p.L.ora_u_velocity_step(p.ptr, dt, *own); p.L.ora_fill_halo_u(p.ptr)
-        ex(p, ["u", "v"], 2)
+            p.L.ora_u_velocity_step(p.ptr, dt, *r2); p.L.ora_fill_halo_u(p.ptr)
+        m += 1
+        if m == k or s == nsub:
+            ex(p, xf, W)
+            m = 0
     p.L.ora_finalize_rheology(p.ptr)
     ex(p, ["s11", "s12", "s22"], Hmin)
