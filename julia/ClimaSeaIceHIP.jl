@@ -1,0 +1,183 @@
+# ClimaSeaIceHIP.jl -- the Julia-side binding a ClimaSeaIce.jl maintainer adds to route the hot path
+# through libcsi_hip.so (include/csi.h).  NOT executed in this repository: the build image has no Julia
+# and no Oceananigans (SURVEY.md section 0); it is kept thin and mechanical so it can be checked by eye
+# against include/csi.h.  Everything outside these methods (SeaIceModel construction, set!, Simulation,
+# output writers, checkpointing) is untouched: the fields stay Oceananigans Fields whose parents are
+# AMDGPU.jl ROCArrays, and the library only receives their device pointers.
+module ClimaSeaIceHIP
+
+using ClimaSeaIce
+using ClimaSeaIce: SeaIceModel
+using ClimaSeaIce.SeaIceDynamics: SeaIceMomentumEquation, SplitExplicitSolver, SemiImplicitStress
+using ClimaSeaIce.Rheologies: ElastoViscoPlasticRheology, ReplacementPressure
+using Oceananigans
+using Oceananigans.Grids: topology, halo_size, Periodic, Bounded, RectilinearGrid, LatitudeLongitudeGrid
+using Oceananigans.TimeSteppers: SplitRungeKuttaTimeStepper
+using AMDGPU
+
+const libcsi = get(ENV, "LIBCSI_HIP", "libcsi_hip.so")
+
+# ---- plain-C structs of include/csi.h --------------------------------------------------------------
+struct CsiMetrics
+    dx::Cdouble; dy::Cdouble
+    dxc::Ptr{Cdouble}; dxf::Ptr{Cdouble}; azc::Ptr{Cdouble}; azf::Ptr{Cdouble}
+end
+struct CsiEvpParams
+    ice_compressive_strength::Cdouble; ice_compaction_hardening::Cdouble; yield_curve_eccentricity::Cdouble
+    minimum_plastic_stress::Cdouble; min_relaxation_parameter::Cdouble; max_relaxation_parameter::Cdouble
+    relaxation_strength::Cdouble; pressure_formulation::Int32; has_coriolis::Int32; coriolis_f::Cdouble
+    minimum_concentration::Cdouble; minimum_mass::Cdouble; sea_ice_density::Cdouble
+end
+struct CsiStress
+    kind::Int32; ue_kind::Int32; ve_kind::Int32; reserved::Int32
+    tau_u::Cdouble; tau_v::Cdouble; ue::Cdouble; ve::Cdouble; rho_e::Cdouble; Cd::Cdouble
+end
+
+# field slots, in the order of csi_field_id
+const F = (U=0, V=1, H=2, A=3, S11=4, S22=5, S12=6, UN=7, VN=8, P=9, ALPHA=10, DELTA=11, ZETA_F=12, ZETA_C=13,
+           GH=14, GA=15, HM=16, AM=17, UM=18, VM=19, TOP_U=20, TOP_V=21, BOT_U=22, BOT_V=23, MASS_FLUX=24)
+
+mutable struct Context
+    handle::Ptr{Cvoid}
+end
+
+function check(ctx, rc)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:csi_last_error, libcsi), Cstring, (Ptr{Cvoid},), ctx === nothing ? C_NULL : ctx.handle))
+    error("libcsi_hip error $rc: $msg")
+end
+
+function Context(device_id = AMDGPU.device_id(AMDGPU.device()) - 1; stream = AMDGPU.stream())
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    # pass AMDGPU.jl's HIP stream so library work is ordered with the rest of the Julia program
+    rc = ccall((:csi_context_create, libcsi), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device_id, stream.stream, h)
+    check(nothing, rc)
+    ctx = Context(h[])
+    finalizer(c -> ccall((:csi_context_destroy, libcsi), Int32, (Ptr{Cvoid},), c.handle), ctx)
+    return ctx
+end
+
+topo_code(::Type{Periodic}) = Int32(0)
+topo_code(::Type{Bounded}) = Int32(1)
+
+# Oceananigans parent array: column-major (ni, nj, 1); ld = ni
+function bind!(ctx, slot, field)
+    p = parent(field)
+    ni, nj = size(p, 1), size(p, 2)
+    rc = ccall((:csi_field_bind, libcsi), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int32, Int32),
+               ctx.handle, slot, pointer(p), ni, ni, nj)
+    check(ctx, rc)
+end
+
+function set_grid!(ctx, grid::RectilinearGrid)
+    Nx, Ny, _ = size(grid); Hx, Hy, _ = halo_size(grid); TX, TY, _ = topology(grid)
+    m = Ref(CsiMetrics(grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, C_NULL, C_NULL, C_NULL, C_NULL))
+    check(ctx, ccall((:csi_grid_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Ref{CsiMetrics}),
+                     ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), topo_code(TY), 0, m))
+end
+
+function set_grid!(ctx, grid::LatitudeLongitudeGrid)
+    Nx, Ny, _ = size(grid); Hx, Hy, _ = halo_size(grid); TX, TY, _ = topology(grid)
+    rows = (1 - Hy):(Ny + Hy + 1)
+    dxc = Array(grid.Δxᶜᶜᵃ[rows]); dxf = Array(grid.Δxᶜᶠᵃ[rows]); azc = Array(grid.Azᶜᶜᵃ[rows]); azf = Array(grid.Azᶜᶠᵃ[rows])
+    GC.@preserve dxc dxf azc azf begin
+        m = Ref(CsiMetrics(0.0, grid.Δyᶜᶠᵃ, pointer(dxc), pointer(dxf), pointer(azc), pointer(azf)))
+        check(ctx, ccall((:csi_grid_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Ref{CsiMetrics}),
+                         ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), topo_code(TY), 1, m))
+    end
+end
+
+stress_struct(::Nothing) = CsiStress(0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+stress_struct(τ::NamedTuple{(:u, :v), <:Tuple{Number, Number}}) = CsiStress(1, 0, 0, 0, τ.u, τ.v, 0, 0, 0, 0)
+function stress_struct(τ::SemiImplicitStress)
+    kind(x) = x isa Oceananigans.Fields.ZeroField ? Int32(0) : x isa Oceananigans.Fields.ConstantField ? Int32(1) : Int32(2)
+    val(x) = x isa Oceananigans.Fields.ConstantField ? Float64(x.constant) : 0.0
+    return CsiStress(3, kind(τ.uₑ), kind(τ.vₑ), 0, 0, 0, val(τ.uₑ), val(τ.vₑ), τ.ρₑ, τ.Cᴰ)
+end
+
+"""
+    attach!(model) -> Context
+
+Describe `model` to the library once (grid, fields, parameters).  Field memory stays owned by Julia.
+"""
+function attach!(model::SeaIceModel)
+    ctx = Context()
+    dyn = model.dynamics
+    grid = model.velocities.u.grid
+    set_grid!(ctx, grid)
+    a = dyn.auxiliaries.fields
+    for (slot, f) in ((F.U, model.velocities.u), (F.V, model.velocities.v), (F.H, model.ice_thickness),
+                      (F.A, model.ice_concentration), (F.S11, a.σ₁₁), (F.S22, a.σ₂₂), (F.S12, a.σ₁₂), (F.UN, a.uⁿ),
+                      (F.VN, a.vⁿ), (F.P, a.P), (F.ALPHA, a.α), (F.DELTA, a.Δ), (F.ZETA_F, a.ζᶠᶠᶜ), (F.ZETA_C, a.ζᶜᶜᶜ),
+                      (F.GH, model.timestepper.Gⁿ.h), (F.GA, model.timestepper.Gⁿ.ℵ))
+        bind!(ctx, slot, f)
+    end
+    if model.timestepper isa SplitRungeKuttaTimeStepper
+        Ψ = model.timestepper.Ψ⁻
+        bind!(ctx, F.HM, Ψ.h); bind!(ctx, F.AM, Ψ.ℵ); bind!(ctx, F.UM, Ψ.u); bind!(ctx, F.VM, Ψ.v)
+    end
+    r = dyn.rheology
+    cor = dyn.coriolis
+    p = Ref(CsiEvpParams(r.ice_compressive_strength, r.ice_compaction_hardening, r.yield_curve_eccentricity,
+                         r.minimum_plastic_stress, r.min_relaxation_parameter, r.max_relaxation_parameter,
+                         r.relaxation_strength, r.pressure_formulation isa ReplacementPressure ? 0 : 1,
+                         isnothing(cor) ? 0 : 1, isnothing(cor) ? 0.0 : cor.f,
+                         dyn.minimum_concentration, dyn.minimum_mass, model.sea_ice_density[1, 1, 1]))
+    check(ctx, ccall((:csi_evp_params_set, libcsi), Int32, (Ptr{Cvoid}, Ref{CsiEvpParams}), ctx.handle, p))
+    for (side, τ) in ((0, dyn.external_momentum_stresses.top), (1, dyn.external_momentum_stresses.bottom))
+        s = Ref(stress_struct(τ))
+        check(ctx, ccall((:csi_stress_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Ref{CsiStress}), ctx.handle, side, s))
+        if τ isa SemiImplicitStress    # field-valued external velocities
+            τ.uₑ isa Field && bind!(ctx, side == 0 ? F.TOP_U : F.BOT_U, τ.uₑ)
+            τ.vₑ isa Field && bind!(ctx, side == 0 ? F.TOP_V : F.BOT_V, τ.vₑ)
+        end
+    end
+    check(ctx, ccall((:csi_set_mode, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, 1))   # CSI_MODE_FAST
+    return ctx
+end
+
+# One context per model, created on first use.
+const CONTEXTS = IdDict{Any, Context}()
+context(model) = get!(() -> attach!(model), CONTEXTS, model)
+
+# ---- a solver tag that selects the HIP path by dispatch -------------------------------------------
+"""
+    HIPSplitExplicitSolver(; substeps = 120)
+
+Drop-in for `SplitExplicitSolver`: `SeaIceMomentumEquation(grid; solver = HIPSplitExplicitSolver())`.
+"""
+struct HIPSplitExplicitSolver
+    substeps::Int
+end
+HIPSplitExplicitSolver(; substeps = 120) = HIPSplitExplicitSolver(substeps)
+const HIPMomentumEquation = SeaIceMomentumEquation{<:HIPSplitExplicitSolver}
+
+# time_step_momentum!, SeaIceDynamics/split_explicit_momentum_equations.jl:103-195
+function ClimaSeaIce.SeaIceDynamics.time_step_momentum!(model, dynamics::HIPMomentumEquation, Δt)
+    ctx = context(model)
+    rk = model.timestepper isa SplitRungeKuttaTimeStepper
+    # GC.@preserve exactly as the reference does around its own loop (:150)
+    GC.@preserve model begin
+        check(ctx, ccall((:csi_time_step_momentum, libcsi), Int32, (Ptr{Cvoid}, Cdouble, Int32, Int32),
+                         ctx.handle, Δt, dynamics.solver.substeps, rk ? 1 : 0))
+    end
+    return nothing
+end
+
+# compute_tracer_tendencies!, tracer_tendency_kernel_functions.jl:9-25
+function ClimaSeaIce.compute_tracer_tendencies!(model::SeaIceModel{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPMomentumEquation})
+    ctx = context(model)
+    order = Oceananigans.Advection.required_halo_size_x(model.advection) == 4 ? 7 : 5     # WENO(order = 7 | 5)
+    GC.@preserve model check(ctx, ccall((:csi_compute_tracer_tendencies, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, order))
+    return nothing
+end
+
+# dynamic_time_step!, sea_ice_fe_step.jl:36-50 and sea_ice_rk_substep.jl:134-152
+function ClimaSeaIce.dynamic_time_step!(model::SeaIceModel{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPMomentumEquation}, Δt)
+    ctx = context(model)
+    from_cache = model.timestepper isa SplitRungeKuttaTimeStepper ? 1 : 0
+    GC.@preserve model check(ctx, ccall((:csi_dynamic_step_tracers, libcsi), Int32, (Ptr{Cvoid}, Cdouble, Int32), ctx.handle, Δt, from_cache))
+    return nothing
+end
+
+end # module
