@@ -72,6 +72,12 @@ struct csi_context {
     double *sendbuf = nullptr, *recvbuf = nullptr;
     size_t buf_cap = 0;   // elements per buffer
     int last_exchanges = 0, last_k = 1;
+    // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
+    double* dev_consts = nullptr;   // uniform-scalar table of the fused kernel
+    double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t alt_elems[5] = {0, 0, 0, 0, 0};
+    int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
+    int last_fused = 0;
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
 };
 
@@ -240,7 +246,9 @@ int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     const size_t need_elems = (size_t)(sp.total > rp.total ? sp.total : rp.total);
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->sendbuf) hipFree(c->sendbuf);
+        for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
+    if (c->dev_consts) hipFree(c->dev_consts);
+    if (c->sendbuf) hipFree(c->sendbuf);
         if (c->recvbuf) hipFree(c->recvbuf);
         c->sendbuf = c->recvbuf = nullptr;
         const size_t cap = need_elems * 2;
@@ -281,6 +289,111 @@ int32_t do_initialize(csi_context* c) {
     return CSI_OK;
 }
 
+// ---- fused sub-step path (evp_fused.hip) -----------------------------------------------------------------
+const int kPing[5] = {CSI_F_U, CSI_F_V, CSI_F_S11, CSI_F_S22, CSI_F_S12};
+
+FRef alt_ref(const csi_context* c, int k) {
+    FRef r;
+    const Bound& b = c->f[kPing[k]];
+    r.p = c->alt[k] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * b.ld;
+    r.ld = (int)b.ld;
+    return r;
+}
+
+FusedArgs fused_args(const csi_context* c, const EvpDev& P, int V) {
+    FusedArgs A{};
+    A.h = P.h; A.a = P.a; A.P = P.P; A.un = P.un; A.vn = P.vn;
+    A.al = P.al; A.zc = P.zc; A.zf = P.zf; A.Dl = P.Dl;
+    A.g = P.g;
+    A.rs = stress_range(c, V);
+    A.imu = image_spec(c, CSI_F_U); A.imv = image_spec(c, CSI_F_V);
+    A.pressure_kind = P.pressure_kind; A.has_cor = P.has_cor;
+    A.top_kind = P.top.kind; A.bot_kind = P.bot.kind;
+    A.consts = c->dev_consts;
+    // decomposition of the stress range into (60-column strip) x (rows) wave tiles: enough waves to fill the
+    // chip (>= ~10 per CU), rows long enough to amortise the 3 ring rows
+    const int width = A.rs.i1 - A.rs.i0 + 1, height = A.rs.j1 - A.rs.j0 + 1;
+    A.nstrips = (width + 59) / 60;
+    long strip_rows = (long)A.nstrips * height;
+    int rows = (int)(strip_rows / 2816);
+    if (rows < 12) rows = 12;
+    if (rows > 48) rows = 48;
+    if (rows > height) rows = height;
+    A.rows = rows;
+    A.nchunks = (height + rows - 1) / rows;
+    return A;
+}
+
+void set_velocity_ranges(const csi_context* c, FusedArgs& A, bool ufirst, int V) {
+    const GridDev& g = c->g;
+    A.r1 = ufirst ? first_u_range(c, V) : first_v_range(c, V);
+    A.r2 = second_range(c, V);
+    A.r1c = A.r1;
+    // a periodic side keeps halo images of the first velocity; the second velocity next to that edge reads
+    // them, so the ring recomputation there extends one cell into the halo (inputs in the halo are images too)
+    if (ufirst) {
+        if (g.ylo == SIDE_PERIODIC) A.r1c.j0 -= 1;
+        if (g.xhi == SIDE_PERIODIC) A.r1c.i1 += 1;
+    } else {
+        if (g.xlo == SIDE_PERIODIC) A.r1c.i0 -= 1;
+        if (g.yhi == SIDE_PERIODIC) A.r1c.j1 += 1;
+    }
+}
+
+int32_t ensure_alt(csi_context* c) {
+    for (int k = 0; k < 5; ++k) {
+        const Bound& b = c->f[kPing[k]];
+        const size_t n = (size_t)b.ld * (size_t)b.nj;
+        if (c->alt_elems[k] != n) {
+            if (c->alt[k]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); hipFree(c->alt[k]); c->alt[k] = nullptr; }
+            HIP_TRY(c, hipMalloc((void**)&c->alt[k], n * sizeof(double)));
+            c->alt_elems[k] = n;
+        }
+    }
+    return CSI_OK;
+}
+
+int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first) {
+    int32_t rc;
+    if ((rc = ensure_alt(c))) return rc;
+    // both buffers start identical, so cells no sub-step ever writes (wall halos) agree in both
+    for (int k = 0; k < 5; ++k) {
+        const Bound& b = c->f[kPing[k]];
+        HIP_TRY(c, hipMemcpyAsync(c->alt[k], b.p, c->alt_elems[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (!c->dev_consts) HIP_TRY(c, hipMalloc((void**)&c->dev_consts, sizeof(double) * FUSED_NCONST));
+    {
+        double table[FUSED_NCONST];
+        fused_fill_consts(P, fc, table);
+        // pageable-memory async copy: the host buffer is consumed before the call returns
+        HIP_TRY(c, hipMemcpyAsync(c->dev_consts, table, sizeof(table), hipMemcpyHostToDevice, c->stream));
+    }
+    FusedArgs A = fused_args(c, P, 2);
+    FRef orig[5], alt[5];
+    for (int k = 0; k < 5; ++k) { orig[k] = ref_of(c, kPing[k]); alt[k] = alt_ref(c, k); }
+    int cur = 0;   // 0: the caller's arrays hold the current state
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (int s = first; s < first + substeps; ++s) {
+        const FRef* in = cur == 0 ? orig : alt;
+        const FRef* out = cur == 0 ? alt : orig;
+        A.u_in = in[0]; A.v_in = in[1]; A.s11_in = in[2]; A.s22_in = in[3]; A.s12_in = in[4];
+        A.u_out = out[0]; A.v_out = out[1]; A.s11_out = out[2]; A.s22_out = out[3]; A.s12_out = out[4];
+        A.write_diag = (s == first + substeps - 1);
+        const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
+        set_velocity_ranges(c, A, ufirst, 2);
+        launch_fused_substep(A, fc, ufirst, c->stream);
+        cur ^= 1;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (cur == 1)   // odd number of sub-steps: the result sits in the library's buffers
+        for (int k = 0; k < 5; ++k) {
+            const Bound& b = c->f[kPing[k]];
+            HIP_TRY(c, hipMemcpyAsync(b.p, c->alt[k], c->alt_elems[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
 int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     int32_t rc;
     if ((rc = fill_halo(c, CSI_F_U))) return rc;     // :170
@@ -313,8 +426,20 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         fc.em2 = ie * ie;
         fc.ca_dt = P.ca * dt;
         fc.rdt = 1.0 / dt;
+        fc.Dmin2 = P.Dmin * P.Dmin; fc.rDmin = 1.0 / P.Dmin;
+        fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax;
     }
     if (fast && !fast_supported(P)) return fail(c, CSI_ERR_UNSUPPORTED, "CSI_MODE_FAST does not support this configuration yet; use CSI_MODE_STRICT");
+    if (fast && c->fusion && !tiled && fused_supported(P) && substeps > 0) {
+        if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
+        c->timed = true;
+        c->launches_per_substep = 1;
+        c->last_exchanges = 0;
+        c->last_k = 1;
+        c->last_fused = 1;
+        return CSI_OK;
+    }
+    c->last_fused = 0;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int m = 0, nex = 0;   // position inside the exchange batch
     for (int s = first; s < first + substeps; ++s) {
@@ -484,6 +609,8 @@ int32_t csi_context_destroy(csi_context* c) {
     hipStreamSynchronize(c->stream);
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_coef) hipFree(c->dev_coef);
+    for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
+    if (c->dev_consts) hipFree(c->dev_consts);
     if (c->sendbuf) hipFree(c->sendbuf);
     if (c->recvbuf) hipFree(c->recvbuf);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -554,6 +681,8 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
         HIP_TRY(c, hipMemcpy(c->dev_coef, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
         c->coef.vec = c->dev_coef + (Hy - 1);
         c->coef.stride = n;
+        c->coef.jmin = 1 - Hy;
+        c->coef.jmax = Ny + Hy + 1;
     }
     for (auto& b : c->f) b = Bound{};   // bindings refer to the previous grid
     c->grid_set = true;
@@ -781,6 +910,12 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
     return CSI_OK;
 }
 
+int32_t csi_set_fusion(csi_context* c, int32_t on) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    c->fusion = on != 0;
+    return CSI_OK;
+}
+
 int32_t csi_set_exchange_interval(csi_context* c, int32_t k) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     if (k < 0 || k > 64) return fail(c, CSI_ERR_INVALID_ARGUMENT, "0 <= k <= 64");
@@ -805,7 +940,9 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     if (substeps < 2 || substeps > 64) return fail(c, CSI_ERR_INVALID_ARGUMENT, "2 <= substeps <= 64");
     EvpDev P = evp_dev(c, dt);
     FastCoef fc = c->coef;
-    { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = P.ca * dt; fc.rdt = 1.0 / dt; }
+    { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = P.ca * dt; fc.rdt = 1.0 / dt;
+      fc.Dmin2 = P.Dmin * P.Dmin; fc.rDmin = 1.0 / P.Dmin;
+      fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax; }
     const bool fast = c->mode == CSI_MODE_FAST, tiled = is_tiled(c);
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);

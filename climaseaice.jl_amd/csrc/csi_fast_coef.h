@@ -41,9 +41,11 @@ struct FastCoef {
     const double* vec;      // per-j: device array [FC_COUNT][stride], pre-offset so vec[w*stride + j] is row j
     int stride;
     int uniform;
+    int jmin, jmax;         // valid row range of `vec`
     double em2;             // e^-2
     double ca_dt;           // c_alpha * dt (stage step)
     double rdt;             // 1 / dt
+    double Dmin2, rDmin, amin2, amax2, ramin, ramax;   // Delta_min^2, 1/Delta_min, alpha-^2, alpha+^2, 1/alpha-, 1/alpha+
 };
 
 // Host: fill `uni` (uniform) or `out` ([FC_COUNT][n], n = Ny + 2Hy + 1, entry for row j at [j + Hy - 1]).

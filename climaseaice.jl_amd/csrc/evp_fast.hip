@@ -21,19 +21,16 @@
 #include "csi_dev.h"
 #include "csi_kernels.h"
 #include "csi_fast_coef.h"
+#include "evp_fast_math.h"
 
 namespace csi {
 namespace fast {
-
-#define EPS64 2.220446049250313e-16
 
 template <bool UNI>
 __device__ __forceinline__ double coef(const FastCoef& c, int which, int j) {
     if (UNI) return c.uni[which];
     return c.vec[(long)which * c.stride + j];
 }
-
-__device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // Block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an
 // XCD, MI355X_MICROARCH.md "Workgroup dispatch"); each XCD has its own L2, so a tile's halo rows
@@ -68,6 +65,20 @@ __global__ void __launch_bounds__(256) k_init(EvpDev P, Range r) {
 // ------------------------------------------------------------------------------------------------
 // stress phase
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ fm::StressConst stress_const(const EvpDev& P, const FastCoef& c) {
+    fm::StressConst k;
+    k.em2 = c.em2; k.Dmin = P.Dmin; k.Dmin2 = c.Dmin2; k.rDmin = c.rDmin;
+    k.amin = P.amin; k.amax = P.amax; k.amin2 = c.amin2; k.amax2 = c.amax2;
+    k.ramin = c.ramin; k.ramax = c.ramax;
+    k.pressure_kind = P.pressure_kind;
+    return k;
+}
+__device__ __forceinline__ fm::VelConst vel_const(const EvpDev& P, const FastCoef& c) {
+    fm::VelConst k;
+    k.dt = P.dt; k.rdt = c.rdt; k.fcor = P.fcor; k.min_mass = P.min_mass; k.min_conc = P.min_conc; k.has_cor = P.has_cor;
+    return k;
+}
+
 template <bool UNI>
 __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
@@ -91,107 +102,63 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
     const double Sn0 = coef<UNI>(c, FC_SN, j), Ss0 = coef<UNI>(c, FC_SS, j), Sv0 = coef<UNI>(c, FC_SV, j);
     const double Snp = coef<UNI>(c, FC_SN, j + 1), Ssp = coef<UNI>(c, FC_SS, j + 1), Svp = coef<UNI>(c, FC_SV, j + 1);
 
-    // strain rates at the four cells (i-1..i, j-1..j): e11 = A du + Bn vn - Bs vs ; e22 = Cn vn - Cs vs
-    const double e11_00 = A0 * (u_p0 - u_00) + (Bn0 * v_0p - Bs0 * v_00);
-    const double e22_00 = Cn0 * v_0p - Cs0 * v_00;
-    const double e11_m0 = A0 * (u_00 - u_m0) + (Bn0 * v_mp - Bs0 * v_m0);
-    const double e22_m0 = Cn0 * v_mp - Cs0 * v_m0;
-    const double e11_0m = Am * (u_pm - u_0m) + (Bnm * v_00 - Bsm * v_0m);
-    const double e22_0m = Cnm * v_00 - Csm * v_0m;
-    const double e11_mm = Am * (u_0m - u_mm) + (Bnm * v_m0 - Bsm * v_mm);
-    const double e22_mm = Cnm * v_m0 - Csm * v_mm;
-    // e12 at the four corners (i..i+1, j..j+1): e12 = Sn u(jj) - Ss u(jj-1) + Sv (v(ii) - v(ii-1))
-    const double e12_00 = (Sn0 * u_00 - Ss0 * u_0m) + Sv0 * (v_00 - v_m0);
-    const double e12_p0 = (Sn0 * u_p0 - Ss0 * u_pm) + Sv0 * (v_p0 - v_00);
-    const double e12_0p = (Snp * u_0p - Ssp * u_00) + Svp * (v_0p - v_mp);
-    const double e12_pp = (Snp * u_pp - Ssp * u_p0) + Svp * (v_pp - v_0p);
+    // strain rates at the four cells (i-1..i, j-1..j) and the four corners (i..i+1, j..j+1)
+    double e11_00, e22_00, e11_m0, e22_m0, e11_0m, e22_0m, e11_mm, e22_mm;
+    fm::strain_cell(A0, Bn0, Bs0, Cn0, Cs0, u_p0, u_00, v_0p, v_00, e11_00, e22_00);
+    fm::strain_cell(A0, Bn0, Bs0, Cn0, Cs0, u_00, u_m0, v_mp, v_m0, e11_m0, e22_m0);
+    fm::strain_cell(Am, Bnm, Bsm, Cnm, Csm, u_pm, u_0m, v_00, v_0m, e11_0m, e22_0m);
+    fm::strain_cell(Am, Bnm, Bsm, Cnm, Csm, u_0m, u_mm, v_m0, v_mm, e11_mm, e22_mm);
+    const double e12_00 = fm::strain_corner(Sn0, Ss0, Sv0, u_00, u_0m, v_00, v_m0);
+    const double e12_p0 = fm::strain_corner(Sn0, Ss0, Sv0, u_p0, u_pm, v_p0, v_00);
+    const double e12_0p = fm::strain_corner(Snp, Ssp, Svp, u_0p, u_00, v_0p, v_mp);
+    const double e12_pp = fm::strain_corner(Snp, Ssp, Svp, u_pp, u_p0, v_pp, v_0p);
 
-    // 4-point averages (y-average of x-averages), evp:250-252
-    const double e11f = 0.5 * (0.5 * (e11_mm + e11_0m) + 0.5 * (e11_m0 + e11_00));
-    const double e22f = 0.5 * (0.5 * (e22_mm + e22_0m) + 0.5 * (e22_m0 + e22_00));
-    const double e12c = 0.5 * (0.5 * (e12_00 + e12_p0) + 0.5 * (e12_0p + e12_pp));
-
-    const double em2 = c.em2;
-    // evp:255-272
-    const double dc = e11_00 + e22_00, df = e11f + e22f;
-    const double tc = e11_00 - e22_00, tf = e11f - e22f;
-    const double sc2 = tc * tc + 4.0 * (e12c * e12c);
-    const double sf2 = tf * tf + 4.0 * (e12_00 * e12_00);
-    const double Dc = fmax(sqrt(dc * dc + sc2 * em2), P.Dmin);
-    const double Df = fmax(sqrt(df * df + sf2 * em2), P.Dmin);
-    const double Pf = 0.5 * (0.5 * (P_mm + P_0m) + 0.5 * (P_m0 + P_00));
-    const double zc = P_00 * (0.5 / Dc);
-    const double zf = Pf * (0.5 / Df);
-
-    // evp:318-327
-    const double Pr = (P.pressure_kind == 0) ? P_00 * Dc / (Dc + P.Dmin) : P_00;
-    const double etac = zc * em2, etaf = zf * em2;
-    const double bulk = (zc - etac) * dc - 0.5 * Pr;
-    const double s11n = 2.0 * etac * e11_00 + bulk;
-    const double s22n = 2.0 * etac * e22_00 + bulk;
-    const double s12n = 2.0 * etaf * e12_00;
-
-    // evp:329-340
+    // 4-point averages (y-average of x-averages), evp:250-252, :268, :330
+    const double e11f = fm::avg4(e11_mm, e11_0m, e11_m0, e11_00);
+    const double e22f = fm::avg4(e22_mm, e22_0m, e22_m0, e22_00);
+    const double e12c = fm::avg4(e12_00, e12_p0, e12_0p, e12_pp);
+    const double Pf = fm::avg4(P_mm, P_0m, P_m0, P_00);
     const double m_00 = h_00 * P.rho * a_00, m_m0 = h_m0 * P.rho * a_m0, m_0m = h_0m * P.rho * a_0m, m_mm = h_mm * P.rho * a_mm;
-    const double mf = 0.5 * (0.5 * (m_mm + m_0m) + 0.5 * (m_m0 + m_00));
+    const double mf = fm::avg4(m_mm, m_0m, m_m0, m_00);
     const double kc = c.ca_dt * coef<UNI>(c, FC_RAZC, j), kf = c.ca_dt * coef<UNI>(c, FC_RAZF, j);
-    double g2c = zc * kc / m_00;
-    g2c = isnan(g2c) ? P.amax * P.amax : g2c;
-    const double gc = clampd(sqrt(g2c), P.amin, P.amax);
-    double g2f = zf * kf / mf;
-    g2f = isnan(g2f) ? P.amax * P.amax : g2f;
-    const double gf = clampd(sqrt(g2f), P.amin, P.amax);
-    const double rgc = 1.0 / gc, rgf = 1.0 / gf;
 
-    // evp:345-352
-    P.s11(i, j) = s11 + ((m_00 > 0) ? (s11n - s11) * rgc : 0.0);
-    P.s22(i, j) = s22 + ((m_00 > 0) ? (s22n - s22) * rgc : 0.0);
-    P.s12(i, j) = s12 + ((mf > 0) ? (s12n - s12) * rgf : 0.0);
-    P.al(i, j) = gc;
+    const fm::StressOut o = fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
+                                              m_00, mf, kc, kf, s11, s22, s12);
+    P.s11(i, j) = o.s11;
+    P.s22(i, j) = o.s22;
+    P.s12(i, j) = o.s12;
+    P.al(i, j) = o.alpha;
     if (P.write_diag) {   // leave zeta, Delta as the reference's viscosity kernel would (evp:270-272)
-        P.zf(i, j) = zf;
-        P.zc(i, j) = zc;
-        P.Dl(i, j) = Dc;
+        P.zf(i, j) = o.zf;
+        P.zc(i, j) = o.zc;
+        P.Dl(i, j) = o.Dc;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// external stresses
+// external stresses: gather the scalars fm::ext_stress needs
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double ext_ue(const StressDev& s, int i, int j) {
-    return s.ue_kind == 2 ? s.fu(i, j) : (s.ue_kind == 1 ? s.ue : 0.0);
-}
-__device__ __forceinline__ double ext_ve(const StressDev& s, int i, int j) {
-    return s.ve_kind == 2 ? s.fv(i, j) : (s.ve_kind == 1 ? s.ve : 0.0);
-}
-// explicit part and implicit coefficient of one stress at the u point; vbar = Ixy^{fc}(v)
 __device__ __forceinline__ void stress_x(const StressDev& s, int i, int j, double u, double vbar, double& ex, double& im) {
-    ex = 0.0; im = 0.0;
-    if (s.kind == 1) ex = s.tau_u;
-    else if (s.kind == 2) ex = s.fu(i, j);
+    double tau = 0.0, ue = 0.0, vebar = 0.0;
+    if (s.kind == 1) tau = s.tau_u;
+    else if (s.kind == 2) tau = s.fu(i, j);
     else if (s.kind == 3) {
-        const double ue = ext_ue(s, i, j);
-        double vebar;
-        if (s.ve_kind == 2) vebar = 0.5 * (0.5 * (s.fv(i - 1, j) + s.fv(i, j)) + 0.5 * (s.fv(i - 1, j + 1) + s.fv(i, j + 1)));
+        ue = s.ue_kind == 2 ? s.fu(i, j) : (s.ue_kind == 1 ? s.ue : 0.0);
+        if (s.ve_kind == 2) vebar = fm::avg4(s.fv(i - 1, j), s.fv(i, j), s.fv(i - 1, j + 1), s.fv(i, j + 1));
         else vebar = (s.ve_kind == 1) ? s.ve : 0.0;
-        const double du = ue - u, dv = vebar - vbar;
-        im = s.rho_e * s.Cd * sqrt(du * du + dv * dv);
-        ex = im * ue;
     }
+    fm::ext_stress(s.kind, tau, s.rho_e * s.Cd, ue, vebar, u, vbar, ex, im);
 }
 __device__ __forceinline__ void stress_y(const StressDev& s, int i, int j, double v, double ubar, double& ex, double& im) {
-    ex = 0.0; im = 0.0;
-    if (s.kind == 1) ex = s.tau_v;
-    else if (s.kind == 2) ex = s.fv(i, j);
+    double tau = 0.0, ve = 0.0, uebar = 0.0;
+    if (s.kind == 1) tau = s.tau_v;
+    else if (s.kind == 2) tau = s.fv(i, j);
     else if (s.kind == 3) {
-        const double ve = ext_ve(s, i, j);
-        double uebar;
-        if (s.ue_kind == 2) uebar = 0.5 * (0.5 * (s.fu(i, j - 1) + s.fu(i + 1, j - 1)) + 0.5 * (s.fu(i, j) + s.fu(i + 1, j)));
+        ve = s.ve_kind == 2 ? s.fv(i, j) : (s.ve_kind == 1 ? s.ve : 0.0);
+        if (s.ue_kind == 2) uebar = fm::avg4(s.fu(i, j - 1), s.fu(i + 1, j - 1), s.fu(i, j), s.fu(i + 1, j));
         else uebar = (s.ue_kind == 1) ? s.ue : 0.0;
-        const double dv = ve - v, du = uebar - ubar;
-        im = s.rho_e * s.Cd * sqrt(du * du + dv * dv);
-        ex = im * ve;
     }
+    fm::ext_stress(s.kind, tau, s.rho_e * s.Cd, ve, uebar, v, ubar, ex, im);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -211,29 +178,14 @@ __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img,
         if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
         if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
     }
-    const double mi = 0.5 * (hm * P.rho * am + h0 * P.rho * a0);
-    const double ai = 0.5 * (am + a0);
-    const double abar = 0.5 * (alm + al0);
-    const double dtau = P.dt / abar;
-    const double rm = 1.0 / mi;
-    const double vbar = 0.5 * (0.5 * (v_m0 + v_00) + 0.5 * (v_mp + v_0p));
-    // d_j sigma_1j with constant dy: E (s11_i - s11_{i-1}) + Fn s12(j+1) - Fs s12(j)   (isd:39-44)
-    const double div = coef<UNI>(c, FC_E, j) * (s11_0 - s11_m) + (coef<UNI>(c, FC_FN, j) * s12_p - coef<UNI>(c, FC_FS, j) * s12_0);
+    const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
+    const double div = fm::div1(coef<UNI>(c, FC_E, j), coef<UNI>(c, FC_FN, j), coef<UNI>(c, FC_FS, j), s11_0, s11_m, s12_p, s12_0);
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
     const double cor = P.has_cor ? P.fcor * vbar : 0.0;           // -x_f_cross_U = +f vbar
-    const double rai = rm * ai;
-    double G = cor + (exb - ext) * rai + div * rm + (un - u) * c.rdt;
-    double tau_i = (imb - imt) * rai;
-    G = (mi <= 0) ? 0.0 : G;
-    tau_i = (mi <= 0) ? 0.0 : tau_i;
-    const double uD = (u + dtau * G) / (1.0 + dtau * tau_i);
-    const bool marginal = (mi > EPS64) & (ai > EPS64);
-    const bool active_ice = (mi >= P.min_mass) & (ai >= P.min_conc);
-    (void)marginal;                                                // free drift `nothing` -> 0 either way
-    double res = active_ice ? uD : 0.0;
-    if (peripheral_u(P.g, i, j)) res = 0.0;                        // NaN * 0 cannot occur: uD finite wherever mi > 0
+    const double res = fm::vel_update(vel_const(P, c), u, un, hm * P.rho * am, h0 * P.rho * a0, am, a0, alm, al0, div, cor,
+                                      ext, imt, exb, imb, peripheral_u(P.g, i, j));
     store_with_images(P.u, P.g, img, i, j, res);
 }
 
@@ -252,29 +204,15 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
         if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
         if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
     }
-    const double mi = 0.5 * (hm * P.rho * am + h0 * P.rho * a0);
-    const double ai = 0.5 * (am + a0);
-    const double abar = 0.5 * (alm + al0);
-    const double dtau = P.dt / abar;
-    const double rm = 1.0 / mi;
-    const double ubar = 0.5 * (0.5 * (u_0m + u_pm) + 0.5 * (u_00 + u_p0));
-    // d_j sigma_2j (isd:46-51): Q1n s11(j) + Q2n s22(j) - Q1s s11(j-1) - Q2s s22(j-1) + K (s12(i+1) - s12(i))
-    const double div = (coef<UNI>(c, FC_Q1N, j) * s11_0 + coef<UNI>(c, FC_Q2N, j) * s22_0)
-                     - (coef<UNI>(c, FC_Q1S, j) * s11_m + coef<UNI>(c, FC_Q2S, j) * s22_m)
-                     + coef<UNI>(c, FC_K, j) * (s12_p - s12_0);
+    const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
+    const double div = fm::div2(coef<UNI>(c, FC_Q1N, j), coef<UNI>(c, FC_Q2N, j), coef<UNI>(c, FC_Q1S, j), coef<UNI>(c, FC_Q2S, j),
+                                coef<UNI>(c, FC_K, j), s11_0, s22_0, s11_m, s22_m, s12_p, s12_0);
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
     const double cor = P.has_cor ? -P.fcor * ubar : 0.0;          // -y_f_cross_U = -f ubar
-    const double rai = rm * ai;
-    double G = cor + (exb - ext) * rai + div * rm + (vn - v) * c.rdt;
-    double tau_i = (imb - imt) * rai;
-    G = (mi <= 0) ? 0.0 : G;
-    tau_i = (mi <= 0) ? 0.0 : tau_i;
-    const double vD = (v + dtau * G) / (1.0 + dtau * tau_i);
-    const bool active_ice = (mi >= P.min_mass) & (ai >= P.min_conc);
-    double res = active_ice ? vD : 0.0;
-    if (peripheral_v(P.g, i, j)) res = 0.0;
+    const double res = fm::vel_update(vel_const(P, c), v, vn, hm * P.rho * am, h0 * P.rho * a0, am, a0, alm, al0, div, cor,
+                                      ext, imt, exb, imb, peripheral_v(P.g, i, j));
     store_with_images(P.v, P.g, img, i, j, res);
 }
 

@@ -1,0 +1,188 @@
+// evp_fast_math.h -- the per-cell arithmetic of the FAST-mode EVP kernels, as register-level inline
+// functions shared by the three-kernel path (evp_fast.hip) and the fused sub-step kernel
+// (evp_fused.hip).  Both translation units are compiled with -ffp-contract=off and every fused
+// multiply-add is written explicitly, so the two paths execute the SAME floating-point operations in
+// the SAME order on the same inputs: their results are bit-identical by construction (tested).
+//
+// Reference arithmetic restated here (paths relative to /root/reference/src):
+//   strain rates            Rheologies/elasto_visco_plastic_rheology.jl:360-375
+//   viscosities             :236-273        stresses / alpha   :294-354 (ice_pressure :282-289)
+//   stress divergence       Rheologies/ice_stress_divergence.jl:39-51
+//   velocity tendencies     SeaIceDynamics/momentum_tendencies_kernel_functions.jl:11-74
+//   semi-implicit drag      SeaIceDynamics/sea_ice_external_stress.jl:176-202
+//   velocity update         SeaIceDynamics/split_explicit_momentum_equations.jl:197-264
+// Metric weights are folded into per-row stencil coefficients (csi_fast_coef.h); this changes rounding
+// only (tolerance in DESIGN.md section 6).
+#pragma once
+#include "csi_dev.h"
+
+namespace csi {
+namespace fm {
+
+#define CSI_EPS64 2.220446049250313e-16
+
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+__device__ __forceinline__ double avg4(double a, double b, double c, double d) {   // y-average of x-averages
+    return 0.5 * (0.5 * (a + b) + 0.5 * (c + d));
+}
+
+// Reciprocal and square root without the IEEE special-case scaffolding of the library versions
+// (v_div_scale / v_div_fixup, denormal rescaling): hardware seed (v_rcp_f64 / v_rsq_f64) + Newton /
+// Goldschmidt refinement, about 1 ulp.  Arguments are positive finite where the result is used; zero,
+// infinite and NaN arguments may yield NaN, which every caller absorbs with the same selects the
+// reference uses (m <= 0 ? 0 : ..., isnan(gamma^2) ? alpha+^2 : ...) or an explicit guard.
+__device__ __forceinline__ double rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma_(fma_(-x, r, 1.0), r, r);
+    r = fma_(fma_(-x, r, 1.0), r, r);
+    return r;
+}
+// s = sqrt(x), rs = 1 / sqrt(x) for x > 0
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma_(-h, g, 0.5);
+    g = fma_(g, r, g);
+    h = fma_(h, r, h);
+    double d = fma_(-g, g, x);
+    g = fma_(d, h, g);
+    d = fma_(-g, g, x);
+    g = fma_(d, h, g);
+    // one more step for the reciprocal: h ~ 1 / (2 sqrt(x))
+    const double e = fma_(-h, g, 0.5);
+    h = fma_(h, e, h);
+    s = g;
+    rs = 2.0 * h;
+}
+
+// e11 = A (u_e - u_w) + Bn v_n - Bs v_s ; e22 = Cn v_n - Cs v_s        (cell)
+__device__ __forceinline__ void strain_cell(double A, double Bn, double Bs, double Cn, double Cs,
+                                            double u_e, double u_w, double v_n, double v_s, double& e11, double& e22) {
+    e11 = fma_(A, u_e - u_w, fma_(Bn, v_n, -(Bs * v_s)));
+    e22 = fma_(Cn, v_n, -(Cs * v_s));
+}
+// e12 = Sn u_n - Ss u_s + Sv (v_e - v_w)                                  (corner)
+__device__ __forceinline__ double strain_corner(double Sn, double Ss, double Sv, double u_n, double u_s, double v_e, double v_w) {
+    return fma_(Sv, v_e - v_w, fma_(Sn, u_n, -(Ss * u_s)));
+}
+
+struct StressConst {
+    double em2, Dmin, Dmin2, rDmin, amin, amax, amin2, amax2, ramin, ramax;
+    int pressure_kind;
+};
+
+struct StressOut {
+    double s11, s22, s12, alpha, zc, zf, Dc;
+};
+
+// One stress index (cell (i,j) + corner (i,j)): viscosities and sigma relaxation.
+//   e11c, e22c : cell strain rates; e12f : corner strain rate
+//   e11f, e22f : 4-point averages of the cell strain rates at the corner; e12c : of the corner rate at the cell
+//   Pc, Pf : ice strength at the cell / averaged to the corner; mc, mf : ice mass likewise
+//   kc, kf : c_alpha * dt / Az at the cell / corner
+__device__ __forceinline__ StressOut stress_update(const StressConst& k, double e11c, double e22c, double e12f,
+                                                   double e11f, double e22f, double e12c, double Pc, double Pf,
+                                                   double mc, double mf, double kc, double kf,
+                                                   double s11, double s22, double s12) {
+    StressOut o;
+    const double dc = e11c + e22c, df = e11f + e22f;
+    const double tc = e11c - e22c, tf = e11f - e22f;
+    const double sc2 = fma_(tc, tc, 4.0 * (e12c * e12c));
+    const double sf2 = fma_(tf, tf, 4.0 * (e12f * e12f));
+    // Delta = max(sqrt(x), Dmin) and 1 / Delta from one rsqrt refinement (evp:265-266, 270-271)
+    const double xc = fma_(dc, dc, sc2 * k.em2), xf = fma_(df, df, sf2 * k.em2);
+    double Dc, rDc, Df, rDf;
+    sqrt_rsqrt(xc, Dc, rDc);
+    sqrt_rsqrt(xf, Df, rDf);
+    const bool cc = !(xc > k.Dmin2), cf = !(xf > k.Dmin2);     // also catches x == 0 (NaN from the seed)
+    Dc = cc ? k.Dmin : Dc; rDc = cc ? k.rDmin : rDc;
+    Df = cf ? k.Dmin : Df; rDf = cf ? k.rDmin : rDf;
+    const double zc = Pc * (0.5 * rDc);
+    const double zf = Pf * (0.5 * rDf);
+    const double Pr = (k.pressure_kind == 0) ? Pc * Dc * rcp(Dc + k.Dmin) : Pc;
+    const double etac = zc * k.em2, etaf = zf * k.em2;
+    const double bulk = fma_(zc - etac, dc, -0.5 * Pr);
+    const double s11n = fma_(2.0 * etac, e11c, bulk);
+    const double s22n = fma_(2.0 * etac, e22c, bulk);
+    const double s12n = 2.0 * etaf * e12f;
+    // gamma = clamp(sqrt(gamma^2), alpha-, alpha+) with NaN -> alpha+ (evp:334-340); the clamp is applied to
+    // gamma^2 so that the refinement only ever sees finite positive arguments
+    double g2c = zc * kc * rcp(mc);
+    double g2f = zf * kf * rcp(mf);
+    double gc, rgc, gf, rgf;
+    sqrt_rsqrt(g2c, gc, rgc);
+    sqrt_rsqrt(g2f, gf, rgf);
+    const bool hic = !(g2c < k.amax2), loc = g2c <= k.amin2;   // !(x < a): NaN and +inf go to alpha+
+    const bool hif = !(g2f < k.amax2), lof = g2f <= k.amin2;
+    gc = hic ? k.amax : (loc ? k.amin : gc); rgc = hic ? k.ramax : (loc ? k.ramin : rgc);
+    gf = hif ? k.amax : (lof ? k.amin : gf); rgf = hif ? k.ramax : (lof ? k.ramin : rgf);
+    o.s11 = s11 + ((mc > 0) ? (s11n - s11) * rgc : 0.0);
+    o.s22 = s22 + ((mc > 0) ? (s22n - s22) * rgc : 0.0);
+    o.s12 = s12 + ((mf > 0) ? (s12n - s12) * rgf : 0.0);
+    o.alpha = gc;
+    o.zc = zc; o.zf = zf; o.Dc = Dc;
+    return o;
+}
+
+struct VelConst {
+    double dt, rdt, fcor, min_mass, min_conc;
+    int has_cor;
+};
+
+// explicit part `ex` and implicit coefficient `im` of one external stress at a velocity point
+//   kind 1: constant tau ; kind 2: tau from an array (passed in `tau`) ; kind 3: SemiImplicitStress with
+//   own-component external velocity `we` and cross-component average `webar`
+__device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, double we, double webar, double w, double wbar,
+                                           double& ex, double& im) {
+    ex = 0.0; im = 0.0;
+    if (kind == 1 || kind == 2) ex = tau;
+    else if (kind == 3) {
+        const double d1 = we - w, d2 = webar - wbar;
+        const double n2 = fma_(d1, d1, d2 * d2);
+        double n, rn;
+        sqrt_rsqrt(n2, n, rn);
+        im = rhoCd * ((n2 > 0) ? n : 0.0);
+        ex = im * we;
+    }
+}
+
+// Semi-implicit velocity update of one component.
+//   w, wn   : this component now and at the start of the stage (u, u^n)
+//   m_a, m_b, a_a, a_b, al_a, al_b : ice mass, concentration, alpha at the two cells the face separates
+//   div     : stress divergence ; cor : Coriolis acceleration (+f vbar for u, -f ubar for v)
+//   ext/imt, exb/imb : explicit / implicit parts of the top and bottom stresses
+//   peripheral : the face touches an inactive cell
+__device__ __forceinline__ double vel_update(const VelConst& k, double w, double wn, double m_a, double m_b, double a_a, double a_b,
+                                             double al_a, double al_b, double div, double cor,
+                                             double ext, double imt, double exb, double imb, bool peripheral) {
+    const double mi = 0.5 * (m_a + m_b);
+    const double ai = 0.5 * (a_a + a_b);
+    const double abar = 0.5 * (al_a + al_b);
+    const double dtau = k.dt * rcp(abar);
+    const double rm = rcp(mi);
+    const double rai = rm * ai;
+    double G = fma_(wn - w, k.rdt, fma_(div, rm, fma_(exb - ext, rai, cor)));
+    double tau_i = (imb - imt) * rai;
+    G = (mi <= 0) ? 0.0 : G;
+    tau_i = (mi <= 0) ? 0.0 : tau_i;
+    const double wD = fma_(dtau, G, w) * rcp(fma_(dtau, tau_i, 1.0));
+    const bool active_ice = (mi >= k.min_mass) & (ai >= k.min_conc);
+    double res = active_ice ? wD : 0.0;     // free drift `nothing`: marginal ice -> 0 as well
+    return peripheral ? 0.0 : res;
+}
+
+// d_j sigma_1j = E (s11_i - s11_{i-1}) + Fn s12(j+1) - Fs s12(j)          (constant dy)
+__device__ __forceinline__ double div1(double E, double Fn, double Fs, double s11_0, double s11_m, double s12_p, double s12_0) {
+    return fma_(E, s11_0 - s11_m, fma_(Fn, s12_p, -(Fs * s12_0)));
+}
+// d_j sigma_2j = Q1n s11(j) + Q2n s22(j) - Q1s s11(j-1) - Q2s s22(j-1) + K (s12(i+1) - s12(i))
+__device__ __forceinline__ double div2(double Q1n, double Q2n, double Q1s, double Q2s, double K,
+                                       double s11_0, double s22_0, double s11_m, double s22_m, double s12_p, double s12_0) {
+    const double n = fma_(Q1n, s11_0, Q2n * s22_0);
+    const double s = fma_(Q1s, s11_m, Q2s * s22_m);
+    return fma_(K, s12_p - s12_0, n - s);
+}
+
+}  // namespace fm
+}  // namespace csi

@@ -236,6 +236,12 @@ int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const 
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 
+/* FAST mode only.  on != 0 (default): a sub-step is ONE launch of the fused kernel (stress + both velocity
+ * updates, ring recomputation per wavefront, double-buffered u, v, sigma in library scratch) whenever the
+ * configuration allows it (csrc/evp_fused.hip); on == 0: always the three-kernel path.  Both paths execute
+ * the same floating-point operations and give bit-identical results. */
+int32_t csi_set_fusion(csi_context* ctx, int32_t on);
+
 /* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
  * k <= 4 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
  * k = substeps extreme (halo 2*substeps+3, split_explicit_momentum_equations.jl:51-64). */

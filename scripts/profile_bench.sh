@@ -1,14 +1,16 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace stats + HBM traffic counters for bench.py.
-# Usage: scripts/profile_bench.sh <round-tag>   -> writes gpurun_out/prof_<tag>/...
+# Usage: scripts/profile_bench.sh <tag> [extra bench args]   -> writes gpurun_out/prof_<tag>/...
 set -u
-TAG=${1:-r01}
+TAG=${1:-r01}; shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 REPO=$GRAFT_REPO_ROOT
-ARGS="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-step $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head -20
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcc -- python3 $ARGS > $OUT/pmc_tcc.log 2>&1
+find $OUT -name "*.csv" | wc -l
