@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
     ap.add_argument("--halo", type=int, default=4)
+    ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernel")
     ap.add_argument("--force-connected", action="store_true",
                     help="debug: on one GPU, route the periodic halos through the RCCL exchange (to self)")
     args = ap.parse_args()
@@ -120,6 +121,7 @@ def main():
                                      solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
     model = csi.SeaIceModel(tg, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
     model.set_exchange_interval(args.exchange_interval)
+    model.set_fusion(not args.no_fusion)
     csi.set_(model, h=f["h"], aice=f["a"], u=f["u"], v=f["v"])
     dt = 120.0
 
@@ -147,16 +149,25 @@ def main():
     subcycle_ms = model.ctx.last_subcycle_ms()            # HIP events on the launch stream, last step
 
     # ---- outside the timed region: per-kernel HIP-event times (roofline) and whole model steps ----
+    path = model.ctx.last_path()
     phases = model.ctx.profile_substeps(dt, 32)
-    dom = max(("stress", "ustep", "vstep"), key=lambda k: phases[k])
     cells_launch = nx_l * ny_l
-    achieved = cells_launch * ALGO_BYTES[dom] / (phases[dom] * 1e-3) / 1e9
-    sub_ms = phases["stress"] + phases["ustep"] + phases["vstep"]
+    if path["fused"]:
+        # one launch performs the whole sub-step: its algorithmic bytes are the 256 B per cell-update of SURVEY.md 8(d)
+        dom = "substep"
+        algo = 256.0
+        phases = {"substep": phases["stress"], "exchange": phases["exchange"]}
+        sub_ms = phases["substep"]
+    else:
+        dom = max(("stress", "ustep", "vstep"), key=lambda k: phases[k])
+        algo = ALGO_BYTES[dom]
+        sub_ms = phases["stress"] + phases["ustep"] + phases["vstep"]
+    achieved = cells_launch * algo / (phases[dom] * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tfile) and world == 1 and args.size == 2048 and args.mode == "fast":
         tj = json.load(open(tfile))
-        traffic = tj.get("bytes_per_launch", {}).get(dom)
+        traffic = tj.get("bytes_per_launch", {}).get(dom)   # PMC passes of profiles/ (FETCH_SIZE doubled, gfx950 rule)
     model_days_per_hr = None
     if not args.no_full_step:
         nfull = 2
@@ -187,11 +198,14 @@ def main():
         "model_days_per_hr": model_days_per_hr,
         "model_days_per_hr_config": "full RK3 time_step! (3 stages x [WENO7 advection of h, aice + sub-cycle + tracer update]), dt = 120 s",
         "subcycle_ms_hip_events": subcycle_ms,
+        "path": path,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": {"stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}[dom]
-                     if args.mode == "fast" else dom,
-                     "algorithmic_bytes_per_launch": cells_launch * ALGO_BYTES[dom],
+                     "kernel": {"substep": "csi::fused::k_substep (stress + u + v in one launch)", "stress": "csi::fast::k_stress",
+                                "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}[dom] if args.mode == "fast" else dom,
+                     "algorithmic_bytes_per_launch": cells_launch * algo,
+                     "kernel_minimum_bytes_per_launch": cells_launch * (120.0 if path["fused"] else algo),
+                     "frac_of_kernel_minimum": cells_launch * (120.0 if path["fused"] else algo) / (phases[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "avg_launch_ms": phases[dom],
                      "all_phases_ms": phases,
                      "substep_frac": cells_launch * 256.0 / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

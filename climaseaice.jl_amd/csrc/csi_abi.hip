@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -73,7 +74,7 @@ struct csi_context {
     size_t buf_cap = 0;   // elements per buffer
     int last_exchanges = 0, last_k = 1;
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
-    double* dev_consts = nullptr;   // uniform-scalar table of the fused kernel
+    FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t alt_elems[5] = {0, 0, 0, 0, 0};
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
@@ -247,7 +248,7 @@ int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
-    if (c->dev_consts) hipFree(c->dev_consts);
+    if (c->dev_tables) hipFree(c->dev_tables);
     if (c->sendbuf) hipFree(c->sendbuf);
         if (c->recvbuf) hipFree(c->recvbuf);
         c->sendbuf = c->recvbuf = nullptr;
@@ -300,43 +301,40 @@ FRef alt_ref(const csi_context* c, int k) {
     return r;
 }
 
-FusedArgs fused_args(const csi_context* c, const EvpDev& P, int V) {
-    FusedArgs A{};
-    A.h = P.h; A.a = P.a; A.P = P.P; A.un = P.un; A.vn = P.vn;
-    A.al = P.al; A.zc = P.zc; A.zf = P.zf; A.Dl = P.Dl;
-    A.g = P.g;
-    A.rs = stress_range(c, V);
-    A.imu = image_spec(c, CSI_F_U); A.imv = image_spec(c, CSI_F_V);
-    A.pressure_kind = P.pressure_kind; A.has_cor = P.has_cor;
-    A.top_kind = P.top.kind; A.bot_kind = P.bot.kind;
-    A.consts = c->dev_consts;
+struct FusedGeom { Range rs; int nstrips, nchunks, rows; };
+
+FusedGeom fused_geom(const csi_context* c, int V) {
+    FusedGeom G;
+    G.rs = stress_range(c, V);
     // decomposition of the stress range into (60-column strip) x (rows) wave tiles: enough waves to fill the
     // chip (>= ~10 per CU), rows long enough to amortise the 3 ring rows
-    const int width = A.rs.i1 - A.rs.i0 + 1, height = A.rs.j1 - A.rs.j0 + 1;
-    A.nstrips = (width + 59) / 60;
-    long strip_rows = (long)A.nstrips * height;
+    const int width = G.rs.i1 - G.rs.i0 + 1, height = G.rs.j1 - G.rs.j0 + 1;
+    G.nstrips = (width + 59) / 60;
+    long strip_rows = (long)G.nstrips * height;
     int rows = (int)(strip_rows / 2816);
     if (rows < 12) rows = 12;
     if (rows > 48) rows = 48;
+    if (const char* e = getenv("CSI_FUSED_ROWS")) rows = atoi(e);   // tuning aid
     if (rows > height) rows = height;
-    A.rows = rows;
-    A.nchunks = (height + rows - 1) / rows;
-    return A;
+    if (rows < 1) rows = 1;
+    G.rows = rows;
+    G.nchunks = (height + rows - 1) / rows;
+    return G;
 }
 
-void set_velocity_ranges(const csi_context* c, FusedArgs& A, bool ufirst, int V) {
+void velocity_ranges(const csi_context* c, bool ufirst, int V, Range& r1, Range& r1c, Range& r2) {
     const GridDev& g = c->g;
-    A.r1 = ufirst ? first_u_range(c, V) : first_v_range(c, V);
-    A.r2 = second_range(c, V);
-    A.r1c = A.r1;
+    r1 = ufirst ? first_u_range(c, V) : first_v_range(c, V);
+    r2 = second_range(c, V);
+    r1c = r1;
     // a periodic side keeps halo images of the first velocity; the second velocity next to that edge reads
     // them, so the ring recomputation there extends one cell into the halo (inputs in the halo are images too)
     if (ufirst) {
-        if (g.ylo == SIDE_PERIODIC) A.r1c.j0 -= 1;
-        if (g.xhi == SIDE_PERIODIC) A.r1c.i1 += 1;
+        if (g.ylo == SIDE_PERIODIC) r1c.j0 -= 1;
+        if (g.xhi == SIDE_PERIODIC) r1c.i1 += 1;
     } else {
-        if (g.xlo == SIDE_PERIODIC) A.r1c.i0 -= 1;
-        if (g.yhi == SIDE_PERIODIC) A.r1c.j1 += 1;
+        if (g.xlo == SIDE_PERIODIC) r1c.i0 -= 1;
+        if (g.yhi == SIDE_PERIODIC) r1c.j1 += 1;
     }
 }
 
@@ -361,27 +359,29 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         const Bound& b = c->f[kPing[k]];
         HIP_TRY(c, hipMemcpyAsync(c->alt[k], b.p, c->alt_elems[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
-    if (!c->dev_consts) HIP_TRY(c, hipMalloc((void**)&c->dev_consts, sizeof(double) * FUSED_NCONST));
-    {
-        double table[FUSED_NCONST];
-        fused_fill_consts(P, fc, table);
-        // pageable-memory async copy: the host buffer is consumed before the call returns
-        HIP_TRY(c, hipMemcpyAsync(c->dev_consts, table, sizeof(table), hipMemcpyHostToDevice, c->stream));
-    }
-    FusedArgs A = fused_args(c, P, 2);
     FRef orig[5], alt[5];
     for (int k = 0; k < 5; ++k) { orig[k] = ref_of(c, kPing[k]); alt[k] = alt_ref(c, k); }
+    const FusedGeom G = fused_geom(c, 2);
+    const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
+    // four tables: (which buffer is current) x (u first / v first)
+    if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, 4 * sizeof(FusedTable)));
+    {
+        static thread_local FusedTable host[4];
+        for (int cur = 0; cur < 2; ++cur)
+            for (int uf = 0; uf < 2; ++uf) {
+                Range r1, r1c, r2;
+                velocity_ranges(c, uf != 0, 2, r1, r1c, r2);
+                fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, G.rs, r1, r1c, r2, imu, imv, &host[cur * 2 + uf]);
+            }
+        HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(host), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // `host` is reused by the next call; tiny, once per stage
+    }
     int cur = 0;   // 0: the caller's arrays hold the current state
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int s = first; s < first + substeps; ++s) {
-        const FRef* in = cur == 0 ? orig : alt;
-        const FRef* out = cur == 0 ? alt : orig;
-        A.u_in = in[0]; A.v_in = in[1]; A.s11_in = in[2]; A.s22_in = in[3]; A.s12_in = in[4];
-        A.u_out = out[0]; A.v_out = out[1]; A.s11_out = out[2]; A.s22_out = out[3]; A.s12_out = out[4];
-        A.write_diag = (s == first + substeps - 1);
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
-        set_velocity_ranges(c, A, ufirst, 2);
-        launch_fused_substep(A, fc, ufirst, c->stream);
+        launch_fused_substep(c->dev_tables + (cur * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst, G.nstrips, G.nchunks, G.rows,
+                             s == first + substeps - 1, c->stream);
         cur ^= 1;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -610,7 +610,7 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
-    if (c->dev_consts) hipFree(c->dev_consts);
+    if (c->dev_tables) hipFree(c->dev_tables);
     if (c->sendbuf) hipFree(c->sendbuf);
     if (c->recvbuf) hipFree(c->recvbuf);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -947,6 +947,16 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};
+    if (fast && c->fusion && !tiled && fused_supported(P)) {
+        // the fused path: one launch per sub-step; bracket the whole run with two events
+        if (substeps & 1) ++substeps;                      // even count: the state ends in the caller's arrays
+        if ((rc = run_fused(c, P, fc, substeps, 1))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
+        out_ms4[0] = t / substeps; out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.0;
+        return CSI_OK;
+    }
     std::vector<hipEvent_t> ev((size_t)substeps * 4 + 1);
     for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
     if (tiled && (rc = exchange(c, uv, 2, 2))) return rc;    // sizes the buffers outside the timed part
@@ -985,6 +995,14 @@ int32_t csi_last_subcycle_ms(csi_context* c, double* ms) {
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
     *ms = (double)t;
+    return CSI_OK;
+}
+
+int32_t csi_last_path(csi_context* c, int32_t* fused, int32_t* exchange_interval, int32_t* exchanges) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (fused) *fused = c->last_fused;
+    if (exchange_interval) *exchange_interval = c->last_k;
+    if (exchanges) *exchanges = c->last_exchanges;
     return CSI_OK;
 }
 

@@ -19,23 +19,28 @@ void launch_fast_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, con
 void launch_fast_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s);
 bool fast_supported(const EvpDev& P);
 
-// fused sub-step (evp_fused.hip): stress + both velocities in one launch, double-buffered u, v, sigma
-struct FusedArgs {
-    FRef u_in, v_in, s11_in, s22_in, s12_in;
-    FRef u_out, v_out, s11_out, s22_out, s12_out;
-    FRef h, a, P, un, vn;
-    FRef al, zc, zf, Dl;                 // diagnostics, stored when write_diag
-    GridDev g;
-    Range rs, r1, r1c, r2;               // stress; first velocity (stored / computed incl. image ring); second velocity
-    ImageSpec imu, imv;
-    const double* consts;                // device table of uniform scalars (evp_fused.hip, K_* indices)
-    int pressure_kind, has_cor, top_kind, bot_kind, write_diag;
-    int nstrips, nchunks, rows, blocks_per_xcd;
+// fused sub-step (evp_fused.hip): stress + both velocities in one launch, double-buffered u, v, sigma.
+// All uniform inputs live in a device table read through the constant address space.
+enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_RDMIN, FK_AMIN, FK_AMAX, FK_AMIN2, FK_AMAX2, FK_RAMIN, FK_RAMAX,
+             FK_DT, FK_RDT, FK_FCOR, FK_MIN_MASS, FK_MIN_CONC, FK_RHO, FK_CA_DT,
+             FK_TOP_TAU_U, FK_TOP_TAU_V, FK_TOP_RHOCD, FK_TOP_UE, FK_TOP_VE,
+             FK_BOT_TAU_U, FK_BOT_TAU_V, FK_BOT_RHOCD, FK_BOT_UE, FK_BOT_VE, FK_COEF0, FK_COUNT = FK_COEF0 + FC_COUNT };
+enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUT, FP_V_OUT,
+             FP_P, FP_H, FP_A, FP_UN, FP_VN, FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_COUNT };
+enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_LD_C, FI_LD_F,
+             FI_RS, FI_R1 = FI_RS + 4, FI_R1C = FI_R1 + 4, FI_R2 = FI_R1C + 4, FI_IMU = FI_R2 + 4, FI_IMV = FI_IMU + 4,
+             FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX, FI_COUNT };
+struct FusedTable {
+    double K[FK_COUNT];
+    unsigned long P[FP_COUNT];
+    int I[FI_COUNT + (FI_COUNT & 1)];
 };
 bool fused_supported(const EvpDev& P);
-void launch_fused_substep(const FusedArgs& A, const FastCoef& c, bool ufirst, hipStream_t s);
-constexpr int FUSED_NCONST = 27 + FC_COUNT;
-void fused_fill_consts(const EvpDev& P, const FastCoef& c, double* host_table);
+void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const FRef* out,
+                      const Range& rs, const Range& r1, const Range& r1c, const Range& r2,
+                      const ImageSpec& imu, const ImageSpec& imv, FusedTable* host_table);
+void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst, int nstrips, int nchunks, int rows,
+                          int write_diag, hipStream_t s);
 
 // halo / masks / copies (halo.hip)
 void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipStream_t s);

@@ -23,8 +23,9 @@ namespace fm {
 
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+__device__ __forceinline__ double avg2(double a, double b) { return 0.5 * (a + b); }
 __device__ __forceinline__ double avg4(double a, double b, double c, double d) {   // y-average of x-averages
-    return 0.5 * (0.5 * (a + b) + 0.5 * (c + d));
+    return 0.5 * (avg2(a, b) + avg2(c, d));
 }
 
 // Reciprocal and square root without the IEEE special-case scaffolding of the library versions
@@ -149,16 +150,12 @@ __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, d
 
 // Semi-implicit velocity update of one component.
 //   w, wn   : this component now and at the start of the stage (u, u^n)
-//   m_a, m_b, a_a, a_b, al_a, al_b : ice mass, concentration, alpha at the two cells the face separates
+//   mi, ai, abar : ice mass, concentration, alpha averaged to the velocity point
 //   div     : stress divergence ; cor : Coriolis acceleration (+f vbar for u, -f ubar for v)
 //   ext/imt, exb/imb : explicit / implicit parts of the top and bottom stresses
 //   peripheral : the face touches an inactive cell
-__device__ __forceinline__ double vel_update(const VelConst& k, double w, double wn, double m_a, double m_b, double a_a, double a_b,
-                                             double al_a, double al_b, double div, double cor,
-                                             double ext, double imt, double exb, double imb, bool peripheral) {
-    const double mi = 0.5 * (m_a + m_b);
-    const double ai = 0.5 * (a_a + a_b);
-    const double abar = 0.5 * (al_a + al_b);
+__device__ __forceinline__ double vel_update_avg(const VelConst& k, double w, double wn, double mi, double ai, double abar,
+                                                 double div, double cor, double ext, double imt, double exb, double imb, bool peripheral) {
     const double dtau = k.dt * rcp(abar);
     const double rm = rcp(mi);
     const double rai = rm * ai;
@@ -170,6 +167,12 @@ __device__ __forceinline__ double vel_update(const VelConst& k, double w, double
     const bool active_ice = (mi >= k.min_mass) & (ai >= k.min_conc);
     double res = active_ice ? wD : 0.0;     // free drift `nothing`: marginal ice -> 0 as well
     return peripheral ? 0.0 : res;
+}
+//   m_a, m_b, a_a, a_b, al_a, al_b : ice mass, concentration, alpha at the two cells the face separates
+__device__ __forceinline__ double vel_update(const VelConst& k, double w, double wn, double m_a, double m_b, double a_a, double a_b,
+                                             double al_a, double al_b, double div, double cor,
+                                             double ext, double imt, double exb, double imb, bool peripheral) {
+    return vel_update_avg(k, w, wn, avg2(m_a, m_b), avg2(a_a, a_b), avg2(al_a, al_b), div, cor, ext, imt, exb, imb, peripheral);
 }
 
 // d_j sigma_1j = E (s11_i - s11_{i-1}) + Fn s12(j+1) - Fs s12(j)          (constant dy)

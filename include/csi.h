@@ -272,9 +272,13 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
 int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
 /* Per-phase device time: runs `substeps` (2..64) further EVP sub-steps from the current state with HIP
  * events between the launches on the context's stream and returns the average milliseconds of
- * [0] the stress phase, [1] the u step, [2] the v step, [3] the halo exchange (0 on an untiled grid).
+ * [0] the stress phase (or the whole fused sub-step kernel when the fused path is active, then [1] = [2] = 0),
+ * [1] the u step, [2] the v step, [3] the halo exchange (0 on an untiled grid).
  * Synchronises; for bench.py's roofline only, never on the timed path. */
 int32_t csi_profile_substeps(csi_context* ctx, double dt, int32_t substeps, double* out_ms4);
+/* Which path the last sub-cycle took: fused kernel (1) or three kernels (0), the halo-exchange interval k and the
+ * number of exchanges issued.  Any pointer may be NULL. */
+int32_t csi_last_path(csi_context* ctx, int32_t* fused, int32_t* exchange_interval, int32_t* exchanges);
 /* Number of kernel launches issued for one sub-step in the current configuration. */
 int32_t csi_launches_per_substep(csi_context* ctx, int32_t* n);
 
