@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
-    ap.add_argument("--halo", type=int, default=4)
+    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 8 on tiles so that k = 4)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernel")
     ap.add_argument("--force-connected", action="store_true",
                     help="debug: on one GPU, route the periodic halos through the RCCL exchange (to self)")
@@ -114,6 +114,8 @@ def main():
         if args.size % Rx or args.size % Ry:
             raise SystemExit("--size must be divisible by the partition")
         nx_l, ny_l = args.size // Rx, args.size // Ry
+    if args.halo == 0:
+        args.halo = 8 if (world > 1 or args.force_connected) else 4
     device = f"cuda:{local_rank}"
     tg, f = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=args.halo)
     dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),

@@ -228,17 +228,26 @@ Range parent_range(const csi_context* c) { return Range{1 - c->Hx, c->Nx + c->Hx
     } while (0)
 
 // Exchange `W` halo layers of the given fields with the neighbouring tiles (no-op on an untiled grid).
+int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W);
+
 int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     if (!is_tiled(c)) return CSI_OK;
-    if (!c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
-    if (!c->comm) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
     if (nf > MAX_EX_FIELDS) return fail(c, CSI_ERR_INVALID_ARGUMENT, "too many fields in one exchange");
-    if (W < 1 || W > c->Hx || W > c->Hy || W > c->Nx || W > c->Ny) return fail(c, CSI_ERR_INVALID_ARGUMENT, "exchange width out of range");
     FRef fr[MAX_EX_FIELDS];
     for (int k = 0; k < nf; ++k) {
         if (!c->f[fids[k]].p) return fail(c, CSI_ERR_NOT_BOUND, std::string("field not bound: ") + kName[fids[k]]);
         fr[k] = ref_of(c, fids[k]);
     }
+    return exchange_refs(c, fr, nf, W);
+}
+
+// the same on explicit array references (the fused path exchanges whichever ping-pong buffer is current)
+int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
+    if (!is_tiled(c)) return CSI_OK;
+    if (!c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
+    if (!c->comm) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
+    if (nf > MAX_EX_FIELDS) return fail(c, CSI_ERR_INVALID_ARGUMENT, "too many fields in one exchange");
+    if (W < 1 || W > c->Hx || W > c->Hy || W > c->Nx || W > c->Ny) return fail(c, CSI_ERR_INVALID_ARGUMENT, "exchange width out of range");
     ExPlan sp, rp;
     long soff[8], scnt[8], roff[8], rcnt[8];
     int speer[8], rpeer[8];
@@ -351,46 +360,76 @@ int32_t ensure_alt(csi_context* c) {
     return CSI_OK;
 }
 
+int exchange_interval(const csi_context* c) {
+    if (!is_tiled(c)) return 1;
+    const int hmin = c->Hx < c->Hy ? c->Hx : c->Hy, nmin = c->Nx < c->Ny ? c->Nx : c->Ny;
+    int k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 4 ? hmin / 2 : 4);
+    while (k > 1 && (2 * k > hmin || 2 * k > nmin)) --k;
+    return k < 1 ? 1 : k;
+}
+
 int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first) {
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
-    // both buffers start identical, so cells no sub-step ever writes (wall halos) agree in both
-    for (int k = 0; k < 5; ++k) {
-        const Bound& b = c->f[kPing[k]];
-        HIP_TRY(c, hipMemcpyAsync(c->alt[k], b.p, c->alt_elems[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
+    const bool tiled = is_tiled(c);
+    const int k = exchange_interval(c), W = 2 * k;
+    const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
     FRef orig[5], alt[5];
-    for (int k = 0; k < 5; ++k) { orig[k] = ref_of(c, kPing[k]); alt[k] = alt_ref(c, k); }
-    const FusedGeom G = fused_geom(c, 2);
+    for (int q = 0; q < 5; ++q) { orig[q] = ref_of(c, kPing[q]); alt[q] = alt_ref(c, q); }
+    if (tiled && (rc = exchange_refs(c, orig, nxf, W))) return rc;
+    // both buffers start identical, so cells no sub-step ever writes (wall halos) agree in both
+    for (int q = 0; q < 5; ++q) {
+        const Bound& b = c->f[kPing[q]];
+        HIP_TRY(c, hipMemcpyAsync(c->alt[q], b.p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
-    // four tables: (which buffer is current) x (u first / v first)
-    if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, 4 * sizeof(FusedTable)));
+    // tables: (position in the exchange batch) x (which buffer is current) x (u first / v first)
+    constexpr int KMAX = 8;
+    if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
+    if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, KMAX * 4 * sizeof(FusedTable)));
+    FusedGeom G[KMAX];
     {
-        static thread_local FusedTable host[4];
-        for (int cur = 0; cur < 2; ++cur)
-            for (int uf = 0; uf < 2; ++uf) {
-                Range r1, r1c, r2;
-                velocity_ranges(c, uf != 0, 2, r1, r1c, r2);
-                fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, G.rs, r1, r1c, r2, imu, imv, &host[cur * 2 + uf]);
-            }
-        HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(host), hipMemcpyHostToDevice, c->stream));
+        static thread_local FusedTable host[KMAX * 4];
+        for (int m = 0; m < k; ++m) {
+            const int V = W - 2 * m;
+            G[m] = fused_geom(c, V);
+            for (int cur = 0; cur < 2; ++cur)
+                for (int uf = 0; uf < 2; ++uf) {
+                    Range r1, r1c, r2;
+                    velocity_ranges(c, uf != 0, V, r1, r1c, r2);
+                    fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, G[m].rs, r1, r1c, r2, imu, imv,
+                                     &host[(m * 2 + cur) * 2 + uf]);
+                }
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(FusedTable) * 4 * k, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // `host` is reused by the next call; tiny, once per stage
     }
     int cur = 0;   // 0: the caller's arrays hold the current state
+    int m = 0, nex = 0;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int s = first; s < first + substeps; ++s) {
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
-        launch_fused_substep(c->dev_tables + (cur * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst, G.nstrips, G.nchunks, G.rows,
-                             s == first + substeps - 1, c->stream);
+        launch_fused_substep(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
+                             G[m].nstrips, G[m].nchunks, G[m].rows, s == first + substeps - 1, c->stream);
         cur ^= 1;
+        ++m;
+        if (tiled && (m == k || s == first + substeps - 1)) {
+            if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
+            m = 0;
+            ++nex;
+        } else if (m == k) {
+            m = 0;
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (cur == 1)   // odd number of sub-steps: the result sits in the library's buffers
-        for (int k = 0; k < 5; ++k) {
-            const Bound& b = c->f[kPing[k]];
-            HIP_TRY(c, hipMemcpyAsync(b.p, c->alt[k], c->alt_elems[k] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        for (int q = 0; q < 5; ++q) {
+            const Bound& b = c->f[kPing[q]];
+            HIP_TRY(c, hipMemcpyAsync(b.p, c->alt[q], c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         }
     HIP_TRY(c, hipGetLastError());
+    c->last_exchanges = nex;
+    c->last_k = k;
     return CSI_OK;
 }
 
@@ -402,13 +441,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     const int uv[2] = {CSI_F_U, CSI_F_V};
     // halo exchange of u, v every k sub-steps with width 2k (k = 1: every sub-step; the reference is the
     // k = substeps extreme with its 2*substeps+3 halo, split_explicit_momentum_equations.jl:51-64)
-    int k = 1;
-    if (tiled) {
-        const int hmin = c->Hx < c->Hy ? c->Hx : c->Hy, nmin = c->Nx < c->Ny ? c->Nx : c->Ny;
-        k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 4 ? hmin / 2 : 4);
-        while (k > 1 && (2 * k > hmin || 2 * k > nmin)) --k;
-        if (k < 1) k = 1;
-    }
+    const int k = exchange_interval(c);
     const int W = 2 * k;
     // sigma is history dependent (sigma += (sigma' - sigma) / gamma): with k = 1 the ring-1 values are
     // recomputed every sub-step and stay identical to the neighbour's; with k > 1 the outer rings skip
@@ -416,7 +449,6 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     const int uvs[5] = {CSI_F_U, CSI_F_V, CSI_F_S11, CSI_F_S22, CSI_F_S12};
     const int nxf = k > 1 ? 5 : 2;
     (void)uv;
-    if (tiled && (rc = exchange(c, uvs, nxf, W))) return rc;
     EvpDev P = evp_dev(c, dt);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const bool fast = c->mode == CSI_MODE_FAST;
@@ -430,16 +462,15 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax;
     }
     if (fast && !fast_supported(P)) return fail(c, CSI_ERR_UNSUPPORTED, "CSI_MODE_FAST does not support this configuration yet; use CSI_MODE_STRICT");
-    if (fast && c->fusion && !tiled && fused_supported(P) && substeps > 0) {
+    if (fast && c->fusion && fused_supported(P) && substeps > 0) {
         if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
-        c->launches_per_substep = 1;
-        c->last_exchanges = 0;
-        c->last_k = 1;
+        c->launches_per_substep = 1 + ((tiled && k == 1) ? 3 : 0);
         c->last_fused = 1;
         return CSI_OK;
     }
     c->last_fused = 0;
+    if (tiled && (rc = exchange(c, uvs, nxf, W))) return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int m = 0, nex = 0;   // position inside the exchange batch
     for (int s = first; s < first + substeps; ++s) {
@@ -947,7 +978,7 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};
-    if (fast && c->fusion && !tiled && fused_supported(P)) {
+    if (fast && c->fusion && fused_supported(P)) {
         // the fused path: one launch per sub-step; bracket the whole run with two events
         if (substeps & 1) ++substeps;                      // even count: the state ends in the caller's arrays
         if ((rc = run_fused(c, P, fc, substeps, 1))) return rc;

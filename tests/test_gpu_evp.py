@@ -222,20 +222,25 @@ def test_full_size_properties(N):
 
 @pytest.mark.parametrize("k", [1, 2, 0])
 @pytest.mark.parametrize("fc", [(True, True), (True, False), (False, True)], ids=["xy", "x", "y"])
-@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("mode", ["strict", "fast", "fused"])
 def test_rccl_self_exchange_bitwise(mode, fc, k):
     """The multi-GPU path on one GPU: a periodic domain whose tile edges are CONNECTED to itself, so every halo
     comes through pack -> ncclSend/ncclRecv (to self) -> unpack and the ring recomputation of SURVEY.md A.5.
     Owned cells must equal the plain periodic run bit for bit (same kernels, same arithmetic)."""
+    # "fast": field-valued forcing -> three-kernel path; "fused": numeric forcing -> fused sub-step kernel on the tile
+    fused = mode == "fused"
     c = cases.make_case(Nx=96, Ny=64, substeps=13, topo=("periodic", "periodic"), patches=True, random_uv=0.05,
                         field_forcing=(mode == "fast"))
+    mode = "fast" if fused else mode
     ref = cases.csi_model(c, mode=mode)
+    ref.set_fusion(False)
     csi.time_step_momentum(ref, c["dt"])
     til = cases.csi_model(c, mode=mode, tile=(1, 1, 0, fc))
     til.set_exchange_interval(k)        # k sub-steps per exchange of width 2k (0: automatic = 2 with halo 4)
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
-    assert til.ctx.launches_per_substep() == (3 if mode == "fast" else 4) + (3 if k == 1 else 0)
+    assert til.ctx.last_path()["fused"] == fused
+    assert til.ctx.launches_per_substep() == (1 if fused else (3 if mode == "fast" else 4)) + (3 if k == 1 else 0)
     for k in ("u", "v", "s11", "s22", "s12", "alpha"):
         a, b = EVP_FIELDS[k](ref).interior_numpy(), EVP_FIELDS[k](til).interior_numpy()
         assert np.array_equal(a, b), (k, np.abs(a - b).max())
