@@ -12,6 +12,6 @@ from .dynamics import (Auxiliaries, ElastoViscoPlasticRheology, FPlane, IceStren
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
 from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected, Periodic,
                     RectilinearGrid, RightConnected, TileGrid)
-from .model import SeaIceModel, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state
+from .model import SeaIceModel, SlabThermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state
 
 __all__ = [n for n in dir() if not n.startswith("_")]

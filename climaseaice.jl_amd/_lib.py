@@ -29,7 +29,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_evp_initialize", "csi_evp_subcycle", "csi_evp_finalize", "csi_time_step_momentum",
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
-           "csi_slab_thermo_step", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
+           "csi_slab_thermo_step", "csi_slab_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep"]
 
 
@@ -100,6 +100,7 @@ def load():
         "csi_cache_current_fields": [vp], "csi_update_state": [vp], "csi_fill_halo_local": [vp, i32],
         "csi_time_step_fe": [vp, dbl, i32, i32, i32], "csi_time_step_rk3": [vp, dbl, i32, i32],
         "csi_slab_thermo_step": [vp, C.POINTER(SlabParams), dbl],
+        "csi_slab_params_set": [vp, C.POINTER(SlabParams)],
         "csi_tile_set": [vp, i32, i32, i32, i32, i32, i32],
         "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],

@@ -77,6 +77,8 @@ struct csi_context {
     FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t alt_elems[5] = {0, 0, 0, 0, 0};
+    bool slab_set = false;   // thermodynamic step inside csi_time_step_fe / _rk3
+    SlabDev slab{};
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
     int last_fused = 0;
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
@@ -536,7 +538,10 @@ int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_re
         if ((rc = copy_parent(c, CSI_F_V, CSI_F_VM))) return rc;
     }
     if ((rc = do_initialize(c))) return rc;                 // :130
-    if (is_tiled(c)) {                                      // update_external_stress! :133-134 (forcing halos)
+    // update_external_stress! :133-134: halos of the forcing fields (local boundary conditions, then tiles)
+    for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V})
+        if (c->f[id].p && (rc = fill_halo(c, id))) return rc;
+    if (is_tiled(c)) {
         int ff[4], n = 0;
         for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V}) if (c->f[id].p) ff[n++] = id;
         if (n && (rc = exchange(c, ff, n, c->Hx < c->Hy ? c->Hx : c->Hy))) return rc;
@@ -600,6 +605,23 @@ int32_t do_tracer_step(csi_context* c, double dt, int from_cache) {
 }
 
 }  // namespace
+
+static SlabDev slab_dev(const csi_slab_params* p) {
+    SlabDev S{};
+    S.k = p->conductivity; S.rho_bulk = p->sea_ice_density; S.rho_pure = p->density; S.rho_l = p->liquid_density;
+    S.c_l = p->liquid_heat_capacity; S.c_i = p->heat_capacity; S.L0 = p->reference_latent_heat; S.T0 = p->reference_temperature;
+    S.liq_slope = p->liquidus_slope; S.liq_T0 = p->freshwater_melting_temperature; S.S = p->bottom_salinity;
+    S.hc = p->ice_consolidation_thickness; S.Tu = p->top_temperature; S.Qu = p->top_heat_flux; S.Qb = p->bottom_heat_flux;
+    S.top_flux_kind = p->top_flux_kind; S.bot_flux_kind = p->bottom_flux_kind;
+    return S;
+}
+static int32_t do_slab(csi_context* c, const SlabDev& S, double dt) {
+    const bool has_mf = c->f[CSI_F_MASS_FLUX].p != nullptr;
+    launch_slab_step(S, c->g, ref_of(c, CSI_F_H), ref_of(c, CSI_F_A), ref_of(c, CSI_F_MASS_FLUX), has_mf, dt, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+
 
 // ============================================================================================
 extern "C" {
@@ -840,6 +862,7 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
     if (scheme && (rc = do_tendencies(c, scheme))) return rc;             // :19
     if ((rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
     if (scheme && (rc = do_tracer_step(c, dt, 0))) return rc;             // :25
+    if (c->slab_set && (rc = do_slab(c, c->slab, dt))) return rc;         // :28 thermodynamic_time_step!
     return do_update_state(c);                                            // :31
 }
 
@@ -854,6 +877,7 @@ int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t s
         if (scheme && (rc = do_tendencies(c, scheme))) return rc;         // :84
         if ((rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
         if (scheme && (rc = do_tracer_step(c, dtau, 1))) return rc;       // :89
+        if (c->slab_set && (rc = do_slab(c, c->slab, dtau))) return rc;   // :91 thermodynamic_time_step!
         if ((rc = do_update_state(c))) return rc;
     }
     return CSI_OK;
@@ -863,15 +887,13 @@ int32_t csi_slab_thermo_step(csi_context* c, const csi_slab_params* p, double dt
     if (!c || !p) return CSI_ERR_INVALID_ARGUMENT;
     int32_t rc = need(c, {CSI_F_H, CSI_F_A});
     if (rc) return rc;
-    SlabDev S{};
-    S.k = p->conductivity; S.rho_bulk = p->sea_ice_density; S.rho_pure = p->density; S.rho_l = p->liquid_density;
-    S.c_l = p->liquid_heat_capacity; S.c_i = p->heat_capacity; S.L0 = p->reference_latent_heat; S.T0 = p->reference_temperature;
-    S.liq_slope = p->liquidus_slope; S.liq_T0 = p->freshwater_melting_temperature; S.S = p->bottom_salinity;
-    S.hc = p->ice_consolidation_thickness; S.Tu = p->top_temperature; S.Qu = p->top_heat_flux; S.Qb = p->bottom_heat_flux;
-    S.top_flux_kind = p->top_flux_kind; S.bot_flux_kind = p->bottom_flux_kind;
-    const bool has_mf = c->f[CSI_F_MASS_FLUX].p != nullptr;
-    launch_slab_step(S, c->g, ref_of(c, CSI_F_H), ref_of(c, CSI_F_A), ref_of(c, CSI_F_MASS_FLUX), has_mf, dt, c->stream);
-    HIP_TRY(c, hipGetLastError());
+    return do_slab(c, slab_dev(p), dt);
+}
+
+int32_t csi_slab_params_set(csi_context* c, const csi_slab_params* p) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    c->slab_set = p != nullptr;
+    if (p) c->slab = slab_dev(p);
     return CSI_OK;
 }
 

@@ -19,6 +19,30 @@ from .fields import CenterField, Field, XFaceField, YFaceField
 from .grids import Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
 
 
+class SlabThermodynamics:
+    """Bare-ice SlabThermodynamics with a PrescribedTemperature top boundary condition and IceWaterThermalEquilibrium
+    at the bottom (SeaIceThermodynamics/slab_sea_ice_thermodynamics.jl:82-109); PhaseTransitions defaults
+    (SeaIceThermodynamics.jl:106-124).  Heat fluxes: numbers; top_heat_flux=None is the reference's default for a
+    prescribed temperature (external flux in equilibrium with the internal conductive flux, sea_ice_model.jl:248-256);
+    bottom_heat_flux="frazil" is the -(1 - aice) W m^-2 flux of examples/freezing_bucket.jl:79-81."""
+
+    def __init__(self, top_temperature=-10.0, conductivity=2.0, top_heat_flux=None, bottom_heat_flux=0.0,
+                 heat_capacity=2000.0, density=917.0, liquid_density=999.8, liquid_heat_capacity=4186.0,
+                 reference_latent_heat=334e3, reference_temperature=0.0, liquidus_slope=0.054,
+                 freshwater_melting_temperature=0.0, bottom_salinity=0.0, ice_consolidation_thickness=0.05):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    def params(self, sea_ice_density):
+        frazil = self.bottom_heat_flux == "frazil"
+        return _lib.SlabParams(self.conductivity, sea_ice_density, self.density, self.liquid_density, self.liquid_heat_capacity,
+                               self.heat_capacity, self.reference_latent_heat, self.reference_temperature, self.liquidus_slope,
+                               self.freshwater_melting_temperature, self.bottom_salinity, self.ice_consolidation_thickness,
+                               self.top_temperature, 1 if self.top_heat_flux is None else 0, 1 if frazil else 0,
+                               0.0 if self.top_heat_flux is None else float(self.top_heat_flux),
+                               1.0 if frazil else float(self.bottom_heat_flux))
+
+
 class WENO:
     def __init__(self, order=5):
         if order not in (5, 7):
@@ -45,10 +69,11 @@ def _dptr(a):
 
 class SeaIceModel:
     def __init__(self, grid, dynamics=None, advection=None, timestepper="SplitRungeKutta3", sea_ice_density=900.0,
-                 device="cuda:0", mode="fast", stream=None):
+                 ice_thermodynamics=None, device="cuda:0", mode="fast", stream=None):
         self.grid = grid
         self.dynamics = dynamics
         self.advection = advection
+        self.ice_thermodynamics = ice_thermodynamics
         if timestepper not in ("SplitRungeKutta3", "ForwardEuler"):
             raise ValueError("timestepper must be 'SplitRungeKutta3' or 'ForwardEuler'")
         self.timestepper_kind = timestepper
@@ -105,6 +130,9 @@ class SeaIceModel:
         if self.timestepper.Psi_minus is not None:
             pm = self.timestepper.Psi_minus
             self._bind("HM", pm.h); self._bind("AM", pm.aice); self._bind("UM", pm.u); self._bind("VM", pm.v)
+        if self.ice_thermodynamics is not None:
+            sp = self.ice_thermodynamics.params(self.sea_ice_density)
+            self.ctx.call("csi_slab_params_set", C.byref(sp))
         d = self.dynamics
         if d is None:
             return
@@ -211,19 +239,26 @@ class SeaIceModel:
         self.ctx.call("csi_set_exchange_interval", int(k))
 
     def set_mask(self, active):
-        """ImmersedBoundaryGrid stand-in: `active` is a (Ny, Nx) boolean array of wet cells."""
+        """ImmersedBoundaryGrid stand-in: `active` is a (Ny, Nx) boolean array of wet cells of the WHOLE domain (for a
+        tile: of the global grid; the tile's mask, halo included, is sliced from it -- the mask is static, so no
+        exchange is needed)."""
         g = self.grid
-        full = torch.zeros((g.Ny + 2 * g.Hy, g.Nx + 2 * g.Hx), dtype=torch.uint8)
-        full[g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx] = torch.from_numpy(np.ascontiguousarray(active).astype(np.uint8))
-        # halos of the mask follow the topology (periodic wrap; walls are inactive by definition)
-        a = full.numpy()
-        if g.topology[0] is Periodic:
-            a[:, :g.Hx] = a[:, g.Nx:g.Nx + g.Hx]
-            a[:, g.Nx + g.Hx:] = a[:, g.Hx:2 * g.Hx]
-        if g.topology[1] is Periodic:
-            a[:g.Hy, :] = a[g.Ny:g.Ny + g.Hy, :]
-            a[g.Ny + g.Hy:, :] = a[g.Hy:2 * g.Hy, :]
-        self.mask = full.to(self.device)
+        G = g.global_grid if isinstance(g, TileGrid) else g
+        act = np.ascontiguousarray(active).astype(np.uint8)
+        if act.shape != (G.Ny, G.Nx):
+            raise ValueError("mask must have the shape (Ny, Nx) of the (global) grid")
+        # global mask with halos: periodic wrap; cells beyond a wall are inactive by definition
+        full = np.zeros((G.Ny + 2 * G.Hy, G.Nx + 2 * G.Hx), dtype=np.uint8)
+        full[G.Hy:G.Hy + G.Ny, G.Hx:G.Hx + G.Nx] = act
+        if G.topology[0] is Periodic:
+            full[:, :G.Hx] = full[:, G.Nx:G.Nx + G.Hx]
+            full[:, G.Nx + G.Hx:] = full[:, G.Hx:2 * G.Hx]
+        if G.topology[1] is Periodic:
+            full[:G.Hy, :] = full[G.Ny:G.Ny + G.Hy, :]
+            full[G.Ny + G.Hy:, :] = full[G.Hy:2 * G.Hy, :]
+        if isinstance(g, TileGrid):
+            full = np.ascontiguousarray(full[g.j_off:g.j_off + g.Ny + 2 * g.Hy, g.i_off:g.i_off + g.Nx + 2 * g.Hx])
+        self.mask = torch.from_numpy(full).to(self.device)
         self.ctx.call("csi_mask_set", C.c_void_p(self.mask.data_ptr()), self.mask.shape[1])
 
     # ---- convenience ----------------------------------------------------------------------------

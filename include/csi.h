@@ -224,6 +224,9 @@ typedef struct {
     double top_heat_flux, bottom_heat_flux;
 } csi_slab_params;
 int32_t csi_slab_thermo_step(csi_context* ctx, const csi_slab_params* p, double dt);
+/* Make csi_time_step_fe / csi_time_step_rk3 run the slab step where the reference does (after the tracer update of
+ * every stage: sea_ice_fe_step.jl:28, sea_ice_rk_substep.jl:91).  NULL removes it. */
+int32_t csi_slab_params_set(csi_context* ctx, const csi_slab_params* p);
 
 /* ---- multi-GPU tiles (one process per GPU; RCCL point-to-point over xGMI) ----------------- */
 /* Position of this context's tile in an Rx x Ry decomposition of a global grid; the

@@ -707,36 +707,65 @@ static double concentration_step(double dtV, double an, double hn, double hc, do
 }
 /* _ice_thermodynamic_time_step! :75-118 with thermodynamic_tendency (slab_thermodynamics_tendencies.jl:74-135,
  * PrescribedTemperature branch), ice_melt_freeze_tendency (:28-68), ice_volume_update (:304-324) */
+static void slab_cell(const ora_slab* s, double* hp_, double* ap_, double* mf_, double dt) {
+    double hn = *hp_, an = *ap_, hc = s->h_consolidation;
+    int consolidated = hn >= hc;
+    double Tb = s->liq_T0 - s->liq_slope * s->salinity;       /* IceWaterThermalEquilibrium: Tm(S) */
+    double Tu = s->Tu;                                        /* PrescribedTemperature */
+    double Eb = s->rho_bulk * latent_heat(s, Tb);
+    double Eu = s->rho_bulk * latent_heat(s, Tu);
+    double Qi_fun = slab_internal_flux(s, Tu, Tb, hn);        /* internal_flux_function at Tu */
+    double Qu = (s->top_flux_kind == 1) ? Qi_fun : s->Qu;     /* sea_ice_model.jl:248-256 default */
+    double Qb = (s->bot_flux_kind == 1) ? (-(1 - an)) * s->Qb : s->Qb;
+    double Qi = consolidated ? Qi_fun : 0.0;                  /* ice_interior_heat_flux :10-18 */
+    double wu = (Qu - Qi) / Eu;
+    double wb = (Qi - Qb) / Eb;
+    double dtV = wu + wb;
+    /* ice_volume_update :304-324 */
+    double V1 = hn * an + dt * dtV;
+    V1 = jmax(0.0, V1);
+    dtV = (V1 - hn * an) / dt;
+    double ap = concentration_step(dtV, an, hn, hc, dt);
+    double hp = V1 / ap;
+    hp = (ap <= 0) ? 0.0 : hp;
+    ap = (dtV == 0) ? an : ap;
+    hp = (dtV == 0) ? hn : hp;
+    ap = (hp == 0) ? 0.0 : ap;
+    hp = (ap == 0) ? 0.0 : hp;
+    double a1 = (ap > 1) ? 1.0 : ap;
+    double h1 = (ap > 1) ? hp * ap : hp;
+    *ap_ = a1;
+    *hp_ = h1;
+    if (mf_) *mf_ = s->rho_bulk * (h1 * a1 - hn * an) / dt;   /* :111 */
+}
 void ora_slab_thermo_step(const ora_slab* s, int64_t n, double* h, double* aice, double* mass_flux, double dt) {
-    for (int64_t c = 0; c < n; ++c) {
-        double hn = h[c], an = aice[c], hc = s->h_consolidation;
-        int consolidated = hn >= hc;
-        double Tb = s->liq_T0 - s->liq_slope * s->salinity;       /* IceWaterThermalEquilibrium: Tm(S) */
-        double Tu = s->Tu;                                        /* PrescribedTemperature */
-        double Eb = s->rho_bulk * latent_heat(s, Tb);
-        double Eu = s->rho_bulk * latent_heat(s, Tu);
-        double Qi_fun = slab_internal_flux(s, Tu, Tb, hn);        /* internal_flux_function at Tu */
-        double Qu = (s->top_flux_kind == 1) ? Qi_fun : s->Qu;     /* sea_ice_model.jl:248-256 default */
-        double Qb = (s->bot_flux_kind == 1) ? (-(1 - an)) * s->Qb : s->Qb;
-        double Qi = consolidated ? Qi_fun : 0.0;                  /* ice_interior_heat_flux :10-18 */
-        double wu = (Qu - Qi) / Eu;
-        double wb = (Qi - Qb) / Eb;
-        double dtV = wu + wb;
-        /* ice_volume_update :304-324 */
-        double V1 = hn * an + dt * dtV;
-        V1 = jmax(0.0, V1);
-        dtV = (V1 - hn * an) / dt;
-        double ap = concentration_step(dtV, an, hn, hc, dt);
-        double hp = V1 / ap;
-        hp = (ap <= 0) ? 0.0 : hp;
-        ap = (dtV == 0) ? an : ap;
-        hp = (dtV == 0) ? hn : hp;
-        ap = (hp == 0) ? 0.0 : ap;
-        hp = (ap == 0) ? 0.0 : hp;
-        double a1 = (ap > 1) ? 1.0 : ap;
-        double h1 = (ap > 1) ? hp * ap : hp;
-        aice[c] = a1;
-        h[c] = h1;
-        if (mass_flux) mass_flux[c] = s->rho_bulk * (h1 * a1 - hn * an) / dt;   /* :111 */
+    for (int64_t c = 0; c < n; ++c) slab_cell(s, h + c, aice + c, mass_flux ? mass_flux + c : 0, dt);
+}
+/* thermodynamic_time_step!(model, ::SlabThermodynamics, ::Nothing, dt) over the interior, thermodynamic_time_step.jl:10-31 */
+void ora_slab_step_fields(ora_problem* g, const ora_slab* s, double dt) {
+    for (int j = 1; j <= g->Ny; ++j)
+        for (int i = 1; i <= g->Nx; ++i) slab_cell(s, &AT(g, g->h, i, j), &AT(g, g->aice, i, j), 0, dt);
+}
+/* whole steps with the thermodynamic step in its place (sea_ice_fe_step.jl:28, sea_ice_rk_substep.jl:91) */
+void ora_time_step_fe_thermo(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s) {
+    if (first_iteration) ora_update_state(g);
+    if (scheme) ora_compute_tracer_tendencies(g, scheme);
+    ora_time_step_momentum(g, dt, 0);
+    if (scheme) ora_dynamic_step_tracers(g, dt, 0);
+    if (s) ora_slab_step_fields(g, s, dt);
+    ora_update_state(g);
+}
+void ora_time_step_rk3_thermo(ora_problem* g, double dt, int scheme, const ora_slab* s) {
+    copy_parent(g, g->hm, g->h);
+    copy_parent(g, g->am, g->aice);
+    copy_parent(g, g->um, g->u);
+    copy_parent(g, g->vm, g->v);
+    for (int beta = 3; beta >= 1; --beta) {
+        double dtau = dt / beta;
+        if (scheme) ora_compute_tracer_tendencies(g, scheme);
+        ora_time_step_momentum(g, dtau, 1);
+        if (scheme) ora_dynamic_step_tracers(g, dtau, 1);
+        if (s) ora_slab_step_fields(g, s, dtau);
+        ora_update_state(g);
     }
 }

@@ -164,6 +164,9 @@ typedef struct {
     double Tu, Qu, Qb;
 } ora_slab;
 void ora_slab_thermo_step(const ora_slab* s, int64_t n, double* h, double* aice, double* mass_flux, double dt);
+void ora_slab_step_fields(ora_problem* g, const ora_slab* s, double dt);
+void ora_time_step_fe_thermo(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s);
+void ora_time_step_rk3_thermo(ora_problem* g, double dt, int scheme, const ora_slab* s);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,8 @@ def lib(omp=False):
         L.ora_update_state.argtypes = [P]
         L.ora_time_step_fe.argtypes = [P, dbl, i32, i32]
         L.ora_time_step_rk3.argtypes = [P, dbl, i32]
+        L.ora_time_step_fe_thermo.argtypes = [P, dbl, i32, i32, C.POINTER(Slab)]
+        L.ora_time_step_rk3_thermo.argtypes = [P, dbl, i32, C.POINTER(Slab)]
         L.ora_slab_thermo_step.argtypes = [C.POINTER(Slab), C.c_int64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), dbl]
         for fn in dir(L):
             pass
@@ -280,11 +282,24 @@ class Problem:
     def dynamic_step_tracers(self, dt, from_cache=False):
         self.L.ora_dynamic_step_tracers(self.ptr, dt, int(from_cache))
 
-    def time_step_fe(self, dt, scheme=0, first_iteration=False):
-        self.L.ora_time_step_fe(self.ptr, dt, scheme, int(first_iteration))
+    def time_step_fe(self, dt, scheme=0, first_iteration=False, slab=None):
+        if slab is None:
+            self.L.ora_time_step_fe(self.ptr, dt, scheme, int(first_iteration))
+        else:
+            self.L.ora_time_step_fe_thermo(self.ptr, dt, scheme, int(first_iteration), C.byref(slab))
 
-    def time_step_rk3(self, dt, scheme=0):
-        self.L.ora_time_step_rk3(self.ptr, dt, scheme)
+    def time_step_rk3(self, dt, scheme=0, slab=None):
+        if slab is None:
+            self.L.ora_time_step_rk3(self.ptr, dt, scheme)
+        else:
+            self.L.ora_time_step_rk3_thermo(self.ptr, dt, scheme, C.byref(slab))
+
+
+def make_slab(*, k_ice=2.0, rho_bulk=900.0, rho_pure=917.0, rho_liquid=999.8, c_liquid=4186.0, c_ice=2000.0, L0=334e3,
+              T0=0.0, liq_slope=0.054, liq_T0=0.0, salinity=0.0, h_consolidation=0.05, Tu=-10.0, top_flux_kind=1, Qu=0.0,
+              bot_flux_kind=0, Qb=0.0):
+    return Slab(k_ice, rho_bulk, rho_pure, rho_liquid, c_liquid, c_ice, L0, T0, liq_slope, liq_T0, salinity,
+                h_consolidation, 0, top_flux_kind, bot_flux_kind, 0, Tu, Qu, Qb)
 
 
 def slab_step(h, aice, dt, *, k_ice=2.0, rho_bulk=900.0, rho_pure=917.0, rho_liquid=999.8, c_liquid=4186.0,

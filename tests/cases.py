@@ -144,8 +144,7 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
             for key, loc in (("top_u", (csi.Face, csi.Center)), ("ue_f", (csi.Face, csi.Center)),
                              ("top_v", (csi.Center, csi.Face)), ("ve_f", (csi.Center, csi.Face))):
                 case[key] = g.local_interior(case[key], *loc)
-        if case.get("mask") is not None:
-            raise NotImplementedError("masked tiles")
+        # the mask stays global: SeaIceModel.set_mask slices the tile (halo included) out of it
     if case.get("field_forcing"):
         top = (case["top_u"], case["top_v"])
         bottom = csi.SemiImplicitStress(ue=case["ue_f"], ve=case["ve_f"])

@@ -171,3 +171,26 @@ def test_slab_thermodynamics_vs_oracle():
         assert np.array_equal(model.ice_thickness.interior_numpy().ravel(), h)
         assert np.array_equal(model.ice_concentration.interior_numpy().ravel(), a)
         assert np.array_equal(mf.interior_numpy().ravel(), flux)
+
+
+def test_config4_style_latlon_evp_plus_slab_thermodynamics(oracle_lib):
+    """BASELINE config 4 in miniature: lat-lon (lon 0..60, lat 20..70) channel, EVP + WENO7 + bare-ice slab
+    thermodynamics (top 100 W m^-2, bottom 10 W m^-2, test/test_thermodynamic_mass_fluxes.jl:56), RK3, 2 steps."""
+    c = cases.make_case(Nx=48, Ny=40, substeps=12, topo=("periodic", "bounded"), grid="latlon", patches=True, random_uv=0.02)
+    slab_o = O.make_slab(Tu=-5.0, top_flux_kind=0, Qu=100.0, Qb=10.0)
+    for mode, tol in (("strict", 1e-12), ("fast", 1e-11)):
+        p = cases.oracle_problem(c)
+        thermo = csi.SlabThermodynamics(top_temperature=-5.0, top_heat_flux=100.0, bottom_heat_flux=10.0)
+        g = c["g"]
+        dyn = csi.SeaIceMomentumEquation(g, coriolis=csi.FPlane(f=c["coriolis"]), top_momentum_stress=c["top"],
+                                         bottom_momentum_stress=csi.SemiImplicitStress(), solver=csi.SplitExplicitSolver(substeps=12))
+        m = csi.SeaIceModel(g, dynamics=dyn, advection=csi.UpwindBiased(order=1), ice_thermodynamics=thermo, mode=mode)
+        csi.set_(m, h=c["h"], aice=c["a"], u=c["u"], v=c["v"])
+        for _ in range(2):
+            p.time_step_rk3(c["dt"], 1, slab=slab_o)
+            csi.time_step(m, c["dt"])
+        m.synchronize()
+        for k, f in (("h", m.ice_thickness), ("aice", m.ice_concentration), ("u", m.velocities.u), ("v", m.velocities.v)):
+            scale = max(np.abs(p.f[k]).max(), 1e-30)
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * scale, (mode, k)
+        assert np.abs(p.interior("h") - c["h"]).max() > 1e-6      # the slab step really changed the ice
