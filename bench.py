@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
     ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 8 on tiles so that k = 4)")
-    ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernel")
+    ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
+    ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
+                    help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
     ap.add_argument("--force-connected", action="store_true",
                     help="debug: on one GPU, route the periodic halos through the RCCL exchange (to self)")
     args = ap.parse_args()
@@ -123,7 +125,7 @@ def main():
                                      solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
     model = csi.SeaIceModel(tg, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
     model.set_exchange_interval(args.exchange_interval)
-    model.set_fusion(not args.no_fusion)
+    model.set_fusion(0 if args.no_fusion else args.fusion_level)
     csi.set_(model, h=f["h"], aice=f["a"], u=f["u"], v=f["v"])
     dt = 120.0
 

@@ -30,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
-           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep"]
+           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches"]
 
 
 class Metrics(C.Structure):
@@ -112,6 +112,7 @@ def load():
         "csi_profile_substeps": [vp, dbl, i32, C.POINTER(dbl)],
         "csi_last_path": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "csi_last_subcycle_ms": [vp, C.POINTER(dbl)], "csi_launches_per_substep": [vp, C.POINTER(i32)],
+        "csi_last_launches": [vp, C.POINTER(i32), C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -182,7 +183,13 @@ class Context:
     def last_path(self):
         f, k, n = C.c_int32(), C.c_int32(), C.c_int32()
         self.call("csi_last_path", C.byref(f), C.byref(k), C.byref(n))
-        return dict(fused=bool(f.value), exchange_interval=k.value, exchanges=n.value)
+        return dict(fused=bool(f.value), level=f.value, exchange_interval=k.value, exchanges=n.value)
+
+    def last_launches(self):
+        """(kernel launches, sub-steps) of the last fused sub-cycle."""
+        a, b = C.c_int32(), C.c_int32()
+        self.call("csi_last_launches", C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def launches_per_substep(self):
         v = C.c_int32()

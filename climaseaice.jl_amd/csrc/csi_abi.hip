@@ -80,6 +80,8 @@ struct csi_context {
     bool slab_set = false;   // thermodynamic step inside csi_time_step_fe / _rk3
     SlabDev slab{};
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
+    int pairing = 1;      // 1: two sub-steps per launch where supported (csi_set_fusion level 2)
+    int last_launches = 0, last_substeps = 0;   // kernel launches / sub-steps of the last fused sub-cycle
     int last_fused = 0;
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
 };
@@ -370,12 +372,64 @@ int exchange_interval(const csi_context* c) {
     return k < 1 ? 1 : k;
 }
 
+// ---- two sub-steps per launch (evp_fused2.hip) -----------------------------------------------------------
+// Valid halo width per side at the start of a sub-step: connected sides follow the exchange batch (W - 2m),
+// periodic sides are refreshed by the owner's halo images after every pair (4 for the first sub-step of a pair,
+// 2 for the second).
+struct SideV { int xlo, xhi, ylo, yhi; };
+SideV pair_side_v(const csi_context* c, int v_connected, int v_periodic) {
+    const GridDev& g = c->g;
+    auto v = [&](int side) { return side == SIDE_CONNECTED ? v_connected : v_periodic; };
+    return SideV{v(g.xlo), v(g.xhi), v(g.ylo), v(g.yhi)};
+}
+Range v_stress_range(const csi_context* c, const SideV& v) { return Range{2 - v.xlo, c->Nx + v.xhi - 1, 2 - v.ylo, c->Ny + v.yhi - 1}; }
+Range v_first_range(const csi_context* c, const SideV& v, bool ufirst) {
+    return ufirst ? Range{3 - v.xlo, c->Nx + v.xhi - 1, 2 - v.ylo, c->Ny + v.yhi - 2}
+                  : Range{2 - v.xlo, c->Nx + v.xhi - 2, 3 - v.ylo, c->Ny + v.yhi - 1};
+}
+Range v_second_range(const csi_context* c, const SideV& v) { return Range{3 - v.xlo, c->Nx + v.xhi - 2, 3 - v.ylo, c->Ny + v.yhi - 2}; }
+// periodic sides: the owner stores interior cells only, the halo copies are written as images of that store
+Range clip_periodic(const csi_context* c, Range r) {
+    const GridDev& g = c->g;
+    if (g.xlo == SIDE_PERIODIC && r.i0 < 1) r.i0 = 1;
+    if (g.xhi == SIDE_PERIODIC && r.i1 > c->Nx) r.i1 = c->Nx;
+    if (g.ylo == SIDE_PERIODIC && r.j0 < 1) r.j0 = 1;
+    if (g.yhi == SIDE_PERIODIC && r.j1 > c->Ny) r.j1 = c->Ny;
+    return r;
+}
+bool pair_supported(const csi_context* c) {
+    if (!c->pairing) return false;
+    const GridDev& g = c->g;
+    auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED; };
+    return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
+}
+FusedGeom pair_geom(const csi_context* c, const Range& dec) {
+    FusedGeom G;
+    G.rs = dec;
+    // (56-column strip) x (rows) wave tiles; the kernel runs 2 waves per SIMD (2048 resident), each tile pays
+    // 6 ring rows, so: one full round of long tiles when the grid allows it
+    const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
+    G.nstrips = (width + 55) / 56;
+    const long strip_rows = (long)G.nstrips * height;
+    int rows = (int)((strip_rows + 2047) / 2048);
+    if (rows < 16) rows = 16;
+    if (rows > 128) rows = 128;
+    if (const char* e = getenv("CSI_PAIR_ROWS")) rows = atoi(e);   // tuning aid
+    if (rows > height) rows = height;
+    if (rows < 1) rows = 1;
+    G.rows = rows;
+    G.nchunks = (height + rows - 1) / rows;
+    return G;
+}
+
 int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first) {
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
     const bool tiled = is_tiled(c);
     const int k = exchange_interval(c), W = 2 * k;
     const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
+    const bool pairs = pair_supported(c) && (!tiled || k % 2 == 0);
+    const int kb = tiled ? k : (pairs ? 2 : 1);             // batch length: positions 0 .. kb-1
     FRef orig[5], alt[5];
     for (int q = 0; q < 5; ++q) { orig[q] = ref_of(c, kPing[q]); alt[q] = alt_ref(c, q); }
     if (tiled && (rc = exchange_refs(c, orig, nxf, W))) return rc;
@@ -385,15 +439,16 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipMemcpyAsync(c->alt[q], b.p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
-    // tables: (position in the exchange batch) x (which buffer is current) x (u first / v first)
-    constexpr int KMAX = 8;
+    // tables: singles (position in the exchange batch) x (which buffer is current) x (u first / v first), then
+    // pairs (pair position) x (buffer) x (first sub-step u first / v first)
+    constexpr int KMAX = 8, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4;
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
-    if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, KMAX * 4 * sizeof(FusedTable)));
-    FusedGeom G[KMAX];
+    if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
+    FusedGeom G[KMAX], GP[KMAX / 2];
     {
-        static thread_local FusedTable host[KMAX * 4];
-        for (int m = 0; m < k; ++m) {
-            const int V = W - 2 * m;
+        static thread_local FusedTable host[NSINGLE + NPAIR];
+        for (int m = 0; m < kb; ++m) {
+            const int V = tiled ? W - 2 * m : 2;
             G[m] = fused_geom(c, V);
             for (int cur = 0; cur < 2; ++cur)
                 for (int uf = 0; uf < 2; ++uf) {
@@ -403,28 +458,54 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                                      &host[(m * 2 + cur) * 2 + uf]);
                 }
         }
-        HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(FusedTable) * 4 * k, hipMemcpyHostToDevice, c->stream));
+        if (pairs) {
+            const ImageSpec ims11 = image_spec(c, CSI_F_S11), ims22 = image_spec(c, CSI_F_S22), ims12 = image_spec(c, CSI_F_S12);
+            for (int mp = 0; 2 * mp + 1 < kb; ++mp) {
+                const SideV va = pair_side_v(c, W - 4 * mp, 4), vb = pair_side_v(c, W - 4 * mp - 2, 2);
+                const Range dec = v_stress_range(c, vb), ra = v_stress_range(c, va);
+                GP[mp] = pair_geom(c, dec);
+                for (int cur = 0; cur < 2; ++cur)
+                    for (int auf = 0; auf < 2; ++auf) {
+                        const bool buf = auf == 0;                  // the second sub-step has the other order
+                        const Range rs = clip_periodic(c, dec), r1 = clip_periodic(c, v_first_range(c, vb, buf)),
+                                    r2 = clip_periodic(c, v_second_range(c, vb));
+                        FusedTable* t = &host[NSINGLE + (mp * 2 + cur) * 2 + auf];
+                        fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
+                        fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
+                    }
+            }
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(FusedTable) * (NSINGLE + NPAIR), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // `host` is reused by the next call; tiny, once per stage
     }
     int cur = 0;   // 0: the caller's arrays hold the current state
-    int m = 0, nex = 0;
+    int m = 0, nex = 0, nlaunch = 0;
+    const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (int s = first; s < first + substeps; ++s) {
+    for (int s = first; s < end;) {
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
-        launch_fused_substep(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
-                             G[m].nstrips, G[m].nchunks, G[m].rows, s == first + substeps - 1, c->stream);
+        if (pairs && end - s >= 2 && m + 1 < kb) {
+            const int mp = m / 2;
+            launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
+                              GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+            m += 2; s += 2;
+        } else {
+            launch_fused_substep(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
+                                 G[m].nstrips, G[m].nchunks, G[m].rows, s + 1 == end, c->stream);
+            m += 1; s += 1;
+        }
         cur ^= 1;
-        ++m;
-        if (tiled && (m == k || s == first + substeps - 1)) {
+        ++nlaunch;
+        if (tiled && (m == kb || s == end)) {
             if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
             m = 0;
             ++nex;
-        } else if (m == k) {
+        } else if (m >= kb) {
             m = 0;
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    if (cur == 1)   // odd number of sub-steps: the result sits in the library's buffers
+    if (cur == 1)   // the result sits in the library's buffers
         for (int q = 0; q < 5; ++q) {
             const Bound& b = c->f[kPing[q]];
             HIP_TRY(c, hipMemcpyAsync(b.p, c->alt[q], c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -432,6 +513,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     HIP_TRY(c, hipGetLastError());
     c->last_exchanges = nex;
     c->last_k = k;
+    c->last_launches = nlaunch;
+    c->last_substeps = substeps;
     return CSI_OK;
 }
 
@@ -468,7 +551,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
         c->launches_per_substep = 1 + ((tiled && k == 1) ? 3 : 0);
-        c->last_fused = 1;
+        c->last_fused = c->last_launches < substeps ? 2 : 1;
         return CSI_OK;
     }
     c->last_fused = 0;
@@ -966,6 +1049,7 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
 int32_t csi_set_fusion(csi_context* c, int32_t on) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     c->fusion = on != 0;
+    c->pairing = on != 1;         // 1: one sub-step per launch only; any other non-zero value: pairs where supported
     return CSI_OK;
 }
 
@@ -1001,13 +1085,13 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};
     if (fast && c->fusion && fused_supported(P)) {
-        // the fused path: one launch per sub-step; bracket the whole run with two events
+        // the fused path: one launch per sub-step or per pair (csi_last_launches); bracket the whole run with two events
         if (substeps & 1) ++substeps;                      // even count: the state ends in the caller's arrays
         if ((rc = run_fused(c, P, fc, substeps, 1))) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         float t = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
-        out_ms4[0] = t / substeps; out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.0;
+        out_ms4[0] = t / (c->last_launches > 0 ? c->last_launches : substeps); out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.0;
         return CSI_OK;
     }
     std::vector<hipEvent_t> ev((size_t)substeps * 4 + 1);
@@ -1056,6 +1140,13 @@ int32_t csi_last_path(csi_context* c, int32_t* fused, int32_t* exchange_interval
     if (fused) *fused = c->last_fused;
     if (exchange_interval) *exchange_interval = c->last_k;
     if (exchanges) *exchanges = c->last_exchanges;
+    return CSI_OK;
+}
+
+int32_t csi_last_launches(csi_context* c, int32_t* launches, int32_t* substeps) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (launches) *launches = c->last_launches;
+    if (substeps) *substeps = c->last_substeps;
     return CSI_OK;
 }
 

@@ -25,11 +25,14 @@ enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_RDMIN, FK_AMIN, FK_AMAX, FK_AMIN2
              FK_DT, FK_RDT, FK_FCOR, FK_MIN_MASS, FK_MIN_CONC, FK_RHO, FK_CA_DT,
              FK_TOP_TAU_U, FK_TOP_TAU_V, FK_TOP_RHOCD, FK_TOP_UE, FK_TOP_VE,
              FK_BOT_TAU_U, FK_BOT_TAU_V, FK_BOT_RHOCD, FK_BOT_UE, FK_BOT_VE, FK_COEF0, FK_COUNT = FK_COEF0 + FC_COUNT };
-enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUT, FP_V_OUT,
-             FP_P, FP_H, FP_A, FP_UN, FP_VN, FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_COUNT };
+enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, FP_A, FP_UN, FP_VN,     // 10 inputs, contiguous
+             FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUTP, FP_V_OUTP,                                // 5 outputs (parent addresses), contiguous
+             FP_U_OUT, FP_V_OUT, FP_S11_OUT0, FP_S22_OUT0, FP_S12_OUT0,                               // (0,0)-offset addresses for stores with halo images
+             FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_COUNT };
 enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_LD_C, FI_LD_F,
              FI_RS, FI_R1 = FI_RS + 4, FI_R1C = FI_R1 + 4, FI_R2 = FI_R1C + 4, FI_IMU = FI_R2 + 4, FI_IMV = FI_IMU + 4,
-             FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX, FI_COUNT };
+             FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX,
+             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_COUNT = FI_IMS12 + 4 };
 struct FusedTable {
     double K[FK_COUNT];
     unsigned long P[FP_COUNT];
@@ -41,6 +44,13 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
                       const ImageSpec& imu, const ImageSpec& imv, FusedTable* host_table);
 void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst, int nstrips, int nchunks, int rows,
                           int write_diag, hipStream_t s);
+// two sub-steps per launch (evp_fused2.hip).  The table is one filled by fused_fill_table for the SECOND
+// sub-step's store ranges (rs, r1, r2; r1c unused) plus: dec = the second sub-step's compute (stress) range that
+// the wave tiles decompose, a_j0 / a_j1 = the first sub-step's stress rows, sigma image specs.
+void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
+                           const ImageSpec& ims12, FusedTable* host_table);
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
+                       int write_diag, hipStream_t s);
 
 // halo / masks / copies (halo.hip)
 void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipStream_t s);

@@ -20,10 +20,7 @@
 // HBM traffic per cell-update: reads u, v, P, h, aice, sigma x3, u^n, v^n; writes sigma x3, u, v = 120 B
 // (+ ring re-reads, mostly L2 hits) instead of 256 B.  The arithmetic is that of evp_fast_math.h, shared
 // with the three-kernel path; tests demand bit-for-bit equality of the two.
-#include "csi_dev.h"
-#include "csi_kernels.h"
-#include "csi_fast_coef.h"
-#include "evp_fast_math.h"
+#include "evp_fused_common.h"
 
 #include <cstring>
 
@@ -31,62 +28,6 @@ namespace csi {
 namespace fused {
 
 constexpr int OWN_LO = 2, OWN_HI = 61, OWN_W = OWN_HI - OWN_LO + 1;   // owned lanes of a 64-lane strip
-
-// value of `x` in lane - 1 / lane + 1 (DPP wave shifts; edge lanes receive their own value: they are ring)
-__device__ __forceinline__ double from_left(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double from_right(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// Everything uniform (rheology constants, forcing, uniform-grid stencil coefficients, array bases, index ranges)
-// lives in a small device table (FusedTable, csi_kernels.h) read through the constant address space (s_load,
-// scalar cache) INSIDE the row loop.  As kernel arguments these ~250 dwords are hoisted into SGPRs, spill to
-// VGPR lanes and come back as v_readlane (measured: 418 of 1015 VALU instructions per row iteration).
-typedef const __attribute__((address_space(4))) FusedTable* tptr_t;
-
-template <bool UNI>
-__device__ __forceinline__ double coef(tptr_t T, int which, int j) {
-    if (UNI) return T->K[FK_COEF0 + which];
-    typedef const __attribute__((address_space(4))) double* vptr_t;
-    vptr_t vec = (vptr_t)T->P[FP_COEF_VEC];
-    return vec[(long)which * T->I[FI_COEF_STRIDE] + min(max(j, T->I[FI_COEF_JMIN]), T->I[FI_COEF_JMAX])];   // ring rows may fall off the table
-}
-
-// Addressing: uniform base = parent array start, per-lane unsigned byte offset in a VGPR ->
-// `global_load v, v_off, s[base]` with no 64-bit address arithmetic.  All Center-in-x fields share one leading
-// dimension and all Face-in-x fields another (dense Oceananigans parents; checked on the host), so two running
-// offsets (oc, of) address every field.
-typedef __attribute__((address_space(1))) char* gptr_t;     // global address space: global_load / global_store, not flat
-__device__ __forceinline__ double ldg(unsigned long base, unsigned off) {
-    return *(const __attribute__((address_space(1))) double*)((gptr_t)base + off);
-}
-__device__ __forceinline__ void stg(unsigned long base, unsigned off, double v) {
-    *(__attribute__((address_space(1))) double*)((gptr_t)base + off) = v;
-}
-
-// Velocity store: plain, or with halo images when this wave's tile touches an edge band (wave-uniform test).
-__device__ __forceinline__ void store_vel(tptr_t T, int which_ptr, int which_ld, int img0, bool near_edge, int i, int j, double val) {
-    FRef f;
-    f.p = (double*)(__attribute__((address_space(1))) double*)T->P[which_ptr];      // element (0, 0), global memory
-    f.ld = T->I[which_ld];
-    if (near_edge) {
-        GridDev g;
-        g.Nx = T->I[FI_NX]; g.Ny = T->I[FI_NY]; g.Hx = T->I[FI_HX]; g.Hy = T->I[FI_HY];
-        ImageSpec im;
-        im.xlo = T->I[img0]; im.xhi = T->I[img0 + 1]; im.ylo = T->I[img0 + 2]; im.yhi = T->I[img0 + 3];
-        store_with_images(f, g, im, i, j, val);
-    } else {
-        f(i, j) = val;
-    }
-}
 
 template <bool UNI, bool UFIRST>
 __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
@@ -377,6 +318,8 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     Q[FP_UN] = parent_addr(P.un, g); Q[FP_VN] = parent_addr(P.vn, g);
     Q[FP_AL] = parent_addr(P.al, g); Q[FP_ZC] = parent_addr(P.zc, g); Q[FP_ZF] = parent_addr(P.zf, g); Q[FP_DL] = parent_addr(P.Dl, g);
     Q[FP_COEF_VEC] = (unsigned long)c.vec;
+    Q[FP_S11_OUT0] = (unsigned long)out[2].p; Q[FP_S22_OUT0] = (unsigned long)out[3].p; Q[FP_S12_OUT0] = (unsigned long)out[4].p;
+    Q[FP_U_OUTP] = parent_addr(out[0], g); Q[FP_V_OUTP] = parent_addr(out[1], g);
     int* I = t->I;
     I[FI_NX] = g.Nx; I[FI_NY] = g.Ny; I[FI_HX] = g.Hx; I[FI_HY] = g.Hy;
     I[FI_XLO] = g.xlo; I[FI_XHI] = g.xhi; I[FI_YLO] = g.ylo; I[FI_YHI] = g.yhi;
@@ -388,6 +331,16 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     I[FI_IMV] = imv.xlo; I[FI_IMV + 1] = imv.xhi; I[FI_IMV + 2] = imv.ylo; I[FI_IMV + 3] = imv.yhi;
     I[FI_PRESSURE_KIND] = P.pressure_kind; I[FI_HAS_COR] = P.has_cor; I[FI_TOP_KIND] = P.top.kind; I[FI_BOT_KIND] = P.bot.kind;
     I[FI_COEF_STRIDE] = c.stride; I[FI_COEF_JMIN] = c.jmin; I[FI_COEF_JMAX] = c.jmax;
+}
+
+void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
+                           const ImageSpec& ims12, FusedTable* t) {
+    int* I = t->I;
+    I[FI_DEC] = dec.i0; I[FI_DEC + 1] = dec.i1; I[FI_DEC + 2] = dec.j0; I[FI_DEC + 3] = dec.j1;
+    I[FI_AJ0] = a_j0; I[FI_AJ1] = a_j1;
+    const ImageSpec* im[3] = {&ims11, &ims22, &ims12};
+    const int base[3] = {FI_IMS11, FI_IMS22, FI_IMS12};
+    for (int k = 0; k < 3; ++k) { I[base[k]] = im[k]->xlo; I[base[k] + 1] = im[k]->xhi; I[base[k] + 2] = im[k]->ylo; I[base[k] + 3] = im[k]->yhi; }
 }
 
 void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst, int nstrips, int nchunks, int rows,

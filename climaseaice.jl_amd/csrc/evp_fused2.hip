@@ -1,0 +1,417 @@
+// evp_fused2.hip -- TWO EVP sub-steps in one launch (FAST arithmetic, bit-identical to evp_fast.hip and to
+// evp_fused.hip applied twice).
+//
+// The one-sub-step kernel (evp_fused.hip) moves 120 B per cell-update and runs at the bandwidth this access
+// pattern can reach (profiles/r01e: a copy kernel with the same 10-read / 5-write row march gets 4.5 TB/s; the
+// kernel gets 4.4).  The only way further down is fewer bytes: this kernel carries the state of sub-step s in
+// registers into sub-step s + 1 (temporal blocking), so u, v, sigma cross HBM once per PAIR of sub-steps
+// (60 B per cell-update).  The dependency ring doubles (radius 2 per sub-step):
+//
+//   * a 64-lane wave owns 56 columns (lanes 4..59) x `rows` rows; lanes 0..3 / 60..63 and 3 + 3 rows above and
+//     below are recomputed redundantly (bit-identical to their owner's results: same code, same inputs);
+//   * stage A (sub-step s) runs row r, stage B (sub-step s + 1) runs row r - 2 in the same loop iteration, fed
+//     from A's registers (new u, v of row r - 1, new sigma / P / mass of row r - 2 from short delay lines);
+//     nothing A computes is stored;
+//   * the halo cells B's neighbours need next are refreshed by the owner's store (periodic sides: halo images
+//     of u, v AND sigma -- sigma is history dependent, so its halo copies must follow the owner) or by the tile
+//     exchange (connected sides, every k sub-steps, k even);
+//   * sides must be periodic or connected and the halo >= 4; walls (mirror images inside the ring) stay with
+//     the one-sub-step kernel.
+//
+// Ranges follow csi_abi.hip (stress [2-V, N+V-1], ...) with V = 4 for A and V = 2 for B on periodic sides and
+// the batch position's V on connected sides; every in-range value depends on in-range values only, so the
+// stages compute unconditionally and only B's stores are predicated.
+// Reference: SeaIceDynamics/split_explicit_momentum_equations.jl:173-189 (two trips of the sub-step loop).
+#include "evp_fused_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace csi {
+namespace fused {
+
+constexpr int P_LO = 4, P_HI = 59, P_W = P_HI - P_LO + 1;
+#ifdef CSI_PAIR_PROBE
+__device__ unsigned long long g_probe[4096 * 16];
+#endif
+
+struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; };
+
+// One sub-step as a row pipeline.  step(r) consumes row r of P, m, a, sigma, rows r+1 of u, v and produces
+// sigma(r) and  UFIRST: u(r-1) ["first"], v(r-1) ["second"]   /   v first: v(r) ["first"], u(r-1) ["second"].
+// The arithmetic (operations and their order) is that of evp_fused.hip's loop body.
+template <bool UNI, bool UFIRST>
+struct Stage {
+    double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
+    double a_mm, a_m, m_mm, m_m;
+    double XP_m, Xm_m, Xa_m, Xe11_m, Xe22_m, Ye12_0, e12_0;
+    double XAL_m, XS11L_m, XW, Wprev;
+    double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
+    // results of the last step()
+    double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, first, second;
+    // pending window updates
+    double Xv_p, Xa_0, Xm_0, e12_p, XW_next;
+
+    __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
+                                         double u_p, double v_p, double P_0, double m_0, double a_0,
+                                         double s11, double s22, double s12, double un_m, double vn_x) {
+        Xa_0 = fm::avg2(from_left(a_0), a_0);
+        Xv_p = fm::avg2(from_left(v_p), v_p);
+        double e11_0, e22_0;
+        fm::strain_cell(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
+                        coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
+        e12_p = fm::strain_corner(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
+                                  u_p, u_0, v_p, from_left(v_p));
+        {
+            const double Xe11_0 = fm::avg2(from_left(e11_0), e11_0), Xe22_0 = fm::avg2(from_left(e22_0), e22_0);
+            const double Ye12_p = fm::avg2(e12_p, from_right(e12_p));
+            const double XP_0 = fm::avg2(from_left(P_0), P_0);
+            Xm_0 = fm::avg2(from_left(m_0), m_0);
+            const double e11f = 0.5 * (Xe11_m + Xe11_0);
+            const double e22f = 0.5 * (Xe22_m + Xe22_0);
+            const double e12c = 0.5 * (Ye12_0 + Ye12_p);
+            const double Pf = 0.5 * (XP_m + XP_0);
+            const double mf = 0.5 * (Xm_m + Xm_0);
+            Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
+            const double kc = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
+            const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
+            S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc; zf = o.zf; Dc = o.Dc;
+        }
+        if (UFIRST) {
+            const int j = r - 1;
+            double W_0;
+            {
+                const double vbar = 0.5 * (Xv_m + Xv_0);
+                const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
+                                            S11_m, XS11L_m, S12_0, S12_m);
+                double ext, imt, exb, imb;
+                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
+                const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
+                W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, false);
+            }
+            const double XW_0 = fm::avg2(W_0, from_right(W_0));
+            {
+                const double ubar = 0.5 * (XW + XW_0);
+                const double div = fm::div2(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
+                                            coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
+                                            S11_m, S22_m, S11_mm, S22_mm, from_right(S12_m), S12_m);
+                double ext, imt, exb, imb;
+                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_m, ubar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_m, ubar, exb, imb);
+                const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
+                second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, false);
+            }
+            first = W_0;
+            XW_next = XW_0;
+        } else {
+            double W_0;
+            {
+                const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
+                const double div = fm::div2(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
+                                            coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
+                                            S11_0, S22_0, S11_m, S22_m, from_right(S12_0), S12_0);
+                double ext, imt, exb, imb;
+                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_0, ubar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_0, ubar, exb, imb);
+                const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
+                W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, false);
+            }
+            const double XW_0 = fm::avg2(from_left(W_0), W_0);
+            {
+                const int j = r - 1;
+                const double vbar = 0.5 * (XW + XW_0);
+                const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
+                                            S11_m, XS11L_m, S12_0, S12_m);
+                double ext, imt, exb, imb;
+                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
+                const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
+                second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, false);
+            }
+            first = W_0;
+            XW_next = XW_0;
+        }
+    }
+
+    // slide the row window: row r becomes row r-1 (inputs of the step just done are passed again)
+    __device__ __forceinline__ void shift(double u_p, double v_p, double m_0, double a_0) {
+        u_m = u_0; u_0 = u_p; v_m = v_0; v_0 = v_p;
+        Xv_m = Xv_0; Xv_0 = Xv_p;
+        a_mm = a_m; a_m = a_0; m_mm = m_m; m_m = m_0;
+        Xm_m = Xm_0; Xa_m = Xa_0;
+        e12_0 = e12_p;
+        S11_mm = S11_m; S22_mm = S22_m; S12_mm = S12_m; AL_mm = AL_m;
+        S11_m = S11_0; S22_m = S22_0; S12_m = S12_0; AL_m = AL_0;
+        XAL_m = fm::avg2(from_left(AL_0), AL_0); XS11L_m = from_left(S11_0);
+        XW = XW_next;
+        Wprev = first;
+    }
+};
+
+template <bool UNI, bool AUF>
+__global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+                                               int blocks_per_xcd, int write_diag) {
+    const int b = (int)blockIdx.x;
+    const int blk = (b & 7) * blocks_per_xcd + (b >> 3);
+    if ((b >> 3) >= blocks_per_xcd) return;
+    const int w = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
+    if (w >= nstrips * nchunks) return;
+    const int chunk = w / nstrips, strip = w - chunk * nstrips;
+    const int lane = (int)(threadIdx.x & 63);
+    tptr_t T = (tptr_t)table;
+
+    int ja, jb, rstart, rend;
+    unsigned loff, oc, of, sc, sf;
+    int i;
+    unsigned flags;
+    int dx;                  // byte offset of this column's halo image (0: none)
+    bool wave_has_dx;        // any lane of the wave has one
+    bool lanes_uniform;      // fast store path allowed (see flush)
+    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4 };
+    {
+        const int Nx = T->I[FI_NX], Ny = T->I[FI_NY], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
+        const int i0s = T->I[FI_DEC + 0] - P_LO + strip * P_W;
+        i = i0s + lane;
+        ja = T->I[FI_DEC + 2] + chunk * rows;
+        jb = min(ja + rows - 1, T->I[FI_DEC + 3]);
+        const int ic = min(max(i, 1 - Hx), Nx + Hx);
+        loff = (unsigned)(ic - (1 - Hx)) * 8u;
+        const bool own = (lane >= P_LO) & (lane <= P_HI) & (i <= T->I[FI_DEC + 1]);
+        flags = 0;
+        if (own & (i >= T->I[FI_RS + 0]) & (i <= T->I[FI_RS + 1])) flags |= L_RS;
+        if (own & (i >= T->I[FI_R1 + 0]) & (i <= T->I[FI_R1 + 1])) flags |= L_R1;
+        if (own & (i >= T->I[FI_R2 + 0]) & (i <= T->I[FI_R2 + 1])) flags |= L_R2;
+        // halo images of a periodic side (the pair kernel only runs on periodic / connected sides, N >= 2H):
+        // column i in [1, H] is also stored at i + N, column in (N - H, N] at i - N; rows likewise
+        dx = 0;
+        if (T->I[FI_XLO] == SIDE_PERIODIC) {
+            if ((i >= 1) & (i <= Hx)) dx = Nx * 8;
+            else if ((i > Nx - Hx) & (i <= Nx)) dx = -Nx * 8;
+        }
+        wave_has_dx = __builtin_amdgcn_ballot_w64(dx != 0) != 0;
+        // every lane stores all three kinds or none, and no lane has an image: the common store path
+        const bool same = ((flags & L_RS) != 0) == ((flags & L_R1) != 0) && ((flags & L_RS) != 0) == ((flags & L_R2) != 0);
+        lanes_uniform = !wave_has_dx && (__builtin_amdgcn_ballot_w64(!same) == 0);
+        rstart = max(ja - 3, T->I[FI_AJ0]);
+        rend = min(jb + 3, T->I[FI_AJ1]);
+        sc = (unsigned)T->I[FI_LD_C] * 8u;
+        sf = (unsigned)T->I[FI_LD_F] * 8u;
+        oc = loff + (unsigned)(rstart - (1 - Hy)) * sc;
+        of = loff + (unsigned)(rstart - (1 - Hy)) * sf;
+    }
+    int r = rstart;
+
+    Stage<UNI, AUF> A;
+    Stage<UNI, !AUF> B;
+    // ---- stage A prologue: rows r-1, r (as evp_fused.hip) ------------------------------------------------------
+    double P_d1, P_d2 = 0.0;                       // P of rows r-1, r-2
+    double un_d1 = 0.0, un_d2 = 0.0;               // u^n of rows r-2, r-3
+    double vn_d1 = 0.0, vn_d2 = 0.0, vn_d3 = 0.0;  // A u-first: v^n of row r-2 ; A v-first: rows r-1, r-2, r-3
+    {
+        const double rho0 = T->K[FK_RHO];
+        A.u_m = ldg(T->P[FP_U_IN], of - sf); A.v_m = ldg(T->P[FP_V_IN], oc - sc);
+        A.u_0 = ldg(T->P[FP_U_IN], of); A.v_0 = ldg(T->P[FP_V_IN], oc);
+        A.a_mm = 0.0; A.a_m = ldg(T->P[FP_A], oc - sc);
+        A.m_mm = 0.0; A.m_m = ldg(T->P[FP_H], oc - sc) * rho0 * A.a_m;
+        P_d1 = ldg(T->P[FP_P], oc - sc);
+        A.XP_m = fm::avg2(from_left(P_d1), P_d1);
+        A.Xm_m = fm::avg2(from_left(A.m_m), A.m_m);
+        A.Xa_m = fm::avg2(from_left(A.a_m), A.a_m);
+        A.Xv_m = fm::avg2(from_left(A.v_m), A.v_m);
+        A.Xv_0 = fm::avg2(from_left(A.v_0), A.v_0);
+        double e11_m, e22_m;
+        const int jm = r - 1;
+        fm::strain_cell(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
+                        coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
+        A.e12_0 = fm::strain_corner(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
+        A.Xe11_m = fm::avg2(from_left(e11_m), e11_m);
+        A.Xe22_m = fm::avg2(from_left(e22_m), e22_m);
+        A.Ye12_0 = fm::avg2(A.e12_0, from_right(A.e12_0));
+        A.XAL_m = 0; A.XS11L_m = 0; A.XW = 0; A.Wprev = 0;
+        A.S11_mm = 0; A.S22_mm = 0; A.S12_mm = 0; A.AL_mm = 0; A.S11_m = 0; A.S22_m = 0; A.S12_m = 0; A.AL_m = 0;
+    }
+    // ---- stage B starts empty: its window fills from A's output during the first iterations ---------------------
+    B.u_m = 0; B.u_0 = 0; B.v_m = 0; B.v_0 = 0; B.Xv_m = 0; B.Xv_0 = 0;
+    B.a_mm = 0; B.a_m = 0; B.m_mm = 0; B.m_m = 0;
+    B.XP_m = 0; B.Xm_m = 0; B.Xa_m = 0; B.Xe11_m = 0; B.Xe22_m = 0; B.Ye12_0 = 0; B.e12_0 = 0;
+    B.XAL_m = 0; B.XS11L_m = 0; B.XW = 0; B.Wprev = 0;
+    B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
+
+    auto load_row = [&](RowIn& R) __attribute__((always_inline)) {
+        R.u_p = ldg(T->P[FP_U_IN], of + sf); R.v_p = ldg(T->P[FP_V_IN], oc + sc);
+        R.P_0 = ldg(T->P[FP_P], oc); R.h_0 = ldg(T->P[FP_H], oc); R.a_0 = ldg(T->P[FP_A], oc);
+        R.s11 = ldg(T->P[FP_S11_IN], oc); R.s22 = ldg(T->P[FP_S22_IN], oc); R.s12 = ldg(T->P[FP_S12_IN], of);
+        R.un_m = ldg(T->P[FP_UN], of - sf); R.vn_x = ldg(T->P[FP_VN], AUF ? oc - sc : oc);
+    };
+    // B's results of the iteration that ran row rr (q = rr - 2) are stored at the top of the NEXT iteration:
+    // vmcnt counts loads and stores in one in-order queue, and the number of stores is data dependent, so a wait
+    // for prefetched loads placed after fresh stores degenerates to "wait for those stores" -- a full write round
+    // trip per row.  Order per iteration: wait for everything issued one iteration ago -> stores -> prefetch ->
+    // arithmetic.  sigma / first velocity are still in B's window after shift() (S11_m.., Wprev).
+    double pend_second = 0.0;
+    // rows of this tile each kind of store covers (wave-uniform, fixed for the whole march)
+    const int rs_lo = max(ja, T->I[FI_RS + 2]), rs_hi = min(jb, T->I[FI_RS + 3]);
+    const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
+    const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
+    struct OutPtrs { unsigned long s11, s22, s12, u, v; };
+    const bool wrap_y = T->I[FI_YLO] == SIDE_PERIODIC;
+    const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
+    // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
+    auto yimg = [&](int j) __attribute__((always_inline)) {
+        return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
+    };
+    // one value -> its cell and the halo images of that cell (same semantics as store_with_images for wrap sides)
+    auto put = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
+        stg(base, off, val);
+        if (dy != 0u) stg(base, off + dy, val);
+        if (wave_has_dx) {
+            if (dx != 0) {
+                stg(base, off + (unsigned)dx, val);
+                if (dy != 0u) stg(base, off + (unsigned)dx + dy, val);
+            }
+        }
+    };
+    auto flush = [&](int rr, unsigned oc_rr, unsigned of_rr) __attribute__((always_inline)) {
+        const int q = rr - 2;
+        const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
+        const bool do_s = (q >= rs_lo) & (q <= rs_hi), do_1 = (j1 >= r1_lo) & (j1 <= r1_hi), do_2 = (j2 >= r2_lo) & (j2 <= r2_hi);
+        if (!(do_s | do_1 | do_2)) return;
+        const unsigned ocq = oc_rr - 2u * sc, ofq = of_rr - 2u * sf;
+        const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
+        const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
+        OutPtrs P;                                                // adjacent table slots: one wide scalar load
+        P.s11 = T->P[FP_S11_OUT]; P.s22 = T->P[FP_S22_OUT]; P.s12 = T->P[FP_S12_OUT]; P.u = T->P[FP_U_OUTP]; P.v = T->P[FP_V_OUTP];
+        const int yq = yimg(q), y1 = yimg(j1), y2 = yimg(j2);
+        if (lanes_uniform & do_s & do_1 & do_2 & ((yq | y1 | y2) == 0)) {
+            // interior tile, interior rows (nearly every call): the owned lanes store five values, no images
+            if (flags & L_RS) {
+                stg(P.s11, ocq, B.S11_m); stg(P.s22, ocq, B.S22_m); stg(P.s12, ofq, B.S12_m);
+                stg(AUF ? P.v : P.u, o1, B.Wprev); stg(AUF ? P.u : P.v, o2, pend_second);
+            }
+            return;
+        }
+        if (do_s & ((flags & L_RS) != 0)) {
+            put(P.s11, ocq, (unsigned)yq * sc, B.S11_m);
+            put(P.s22, ocq, (unsigned)yq * sc, B.S22_m);
+            put(P.s12, ofq, (unsigned)yq * sf, B.S12_m);
+        }
+        if (do_1 & ((flags & L_R1) != 0)) put(AUF ? P.v : P.u, o1, (unsigned)y1 * (AUF ? sc : sf), B.Wprev);
+        if (do_2 & ((flags & L_R2) != 0)) put(AUF ? P.u : P.v, o2, (unsigned)y2 * (AUF ? sf : sc), pend_second);
+    };
+#ifdef CSI_PAIR_PROBE
+    const unsigned long long wall0 = wall_clock64();
+    unsigned long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, tprev = 0;
+#define PROBE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                        __builtin_amdgcn_sched_barrier(0); acc += t_ - tprev; tprev = t_; } while (0)
+#else
+#define PROBE(acc) do { } while (0)
+#endif
+    RowIn C, N;
+    auto body = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+s"(T));
+#ifdef CSI_PAIR_PROBE
+        { __builtin_amdgcn_sched_barrier(0); tprev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): row r's inputs and every older store
+        PROBE(acc0);
+        C = N;
+        flush(r - 1, oc - sc, of - sf);
+        PROBE(acc1);
+        const unsigned oc_cur = oc, of_cur = of;
+        // Unconditional prefetch of the next row (the last iteration re-reads its own row): a conditional one
+        // would hide the number of loads in flight from the compiler's wait-count bookkeeping.
+        {
+            const bool more = r < rend;
+            oc += more ? sc : 0u; of += more ? sf : 0u;
+            load_row(N);
+        }
+        PROBE(acc2);
+        fm::StressConst ks;
+        ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
+        ks.amin = T->K[FK_AMIN]; ks.amax = T->K[FK_AMAX]; ks.amin2 = T->K[FK_AMIN2]; ks.amax2 = T->K[FK_AMAX2];
+        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+        fm::VelConst kv;
+        kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.fcor = T->K[FK_FCOR]; kv.min_mass = T->K[FK_MIN_MASS];
+        kv.min_conc = T->K[FK_MIN_CONC]; kv.has_cor = T->I[FI_HAS_COR];
+
+        // ---- stage A: sub-step s, row r ------------------------------------------------------------------------
+        const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
+        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x);
+
+        PROBE(acc3);
+        // ---- stage B: sub-step s + 1, row q = r - 2, fed from A ---------------------------------------------------
+        const int q = r - 2;
+        const double bu_p = AUF ? A.first : A.second;          // new u of row r-1
+        const double bv_p = AUF ? A.second : A.Wprev;          // new v of row r-1
+        const double bm_0 = A.m_mm, ba_0 = A.a_mm;             // row r-2
+        B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3);
+        pend_second = B.second;
+        PROBE(acc4);
+
+        // diagnostics: last launch of the sub-cycle only, stored at once
+        if (write_diag) {
+            if (((flags & L_RS) != 0) & (q >= ja) & (q <= jb) & (q >= T->I[FI_RS + 2]) & (q <= T->I[FI_RS + 3])) {
+                const unsigned ocq = oc_cur - 2u * sc, ofq = of_cur - 2u * sf;
+                stg(T->P[FP_AL], ocq, B.AL_0);
+                stg(T->P[FP_ZF], ofq, B.zf);
+                stg(T->P[FP_ZC], ocq, B.zc);
+                stg(T->P[FP_DL], ocq, B.Dc);
+            }
+        }
+
+        // ---- slide both windows and the delay lines ---------------------------------------------------------------
+        B.shift(bu_p, bv_p, bm_0, ba_0);
+        A.shift(C.u_p, C.v_p, m_0, C.a_0);
+        P_d2 = P_d1; P_d1 = C.P_0;
+        un_d2 = un_d1; un_d1 = C.un_m;
+        if (AUF) { vn_d1 = C.vn_x; }
+        else { vn_d3 = vn_d2; vn_d2 = vn_d1; vn_d1 = C.vn_x; }
+        PROBE(acc5);
+    };
+    load_row(N);
+    for (; r <= rend; ++r) body();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    flush(rend, oc, of);
+#ifdef CSI_PAIR_PROBE
+    if (lane == 0 && w < 4096) {
+        unsigned long long* dbg = g_probe + (size_t)w * 16;
+        dbg[8] = wall0; dbg[9] = wall_clock64();
+        dbg[0] = acc0; dbg[1] = acc1; dbg[2] = acc2; dbg[3] = acc3; dbg[4] = acc4; dbg[5] = acc5; dbg[6] = (unsigned long long)(rend - rstart + 1);
+        dbg[7] = __builtin_readcyclecounter();
+    }
+#endif
+}
+
+}  // namespace fused
+
+#ifdef CSI_PAIR_PROBE
+extern "C" int csi_debug_probe(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_probe), sizeof(unsigned long long) * 4096 * 16);
+}
+#endif
+
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
+                       int write_diag, hipStream_t s) {
+    const int nw = nstrips * nchunks;
+    const int nblocks = (nw + 3) / 4;
+    const int per_xcd = (nblocks + 7) / 8;
+    dim3 grid((unsigned)(per_xcd * 8)), block(256);
+    if (getenv("CSI_DEBUG_OCC")) {
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fused::k_pair<true, true>, 256, 0);
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, (const void*)fused::k_pair<true, true>);
+        fprintf(stderr, "k_pair<true,true>: blocks/CU %d (err %d) regs %d shared %zu local %zu grid %u\n", nb, (int)e, fa.numRegs,
+                fa.sharedSizeBytes, fa.localSizeBytes, grid.x);
+    }
+    if (uniform) {
+        if (a_ufirst) hipLaunchKernelGGL((fused::k_pair<true, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
+        else hipLaunchKernelGGL((fused::k_pair<true, false>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
+    } else {
+        if (a_ufirst) hipLaunchKernelGGL((fused::k_pair<false, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
+        else hipLaunchKernelGGL((fused::k_pair<false, false>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
+    }
+}
+
+}  // namespace csi

@@ -230,9 +230,11 @@ class SeaIceModel:
         self.mode = mode
         self.ctx.call("csi_set_mode", _lib.MODE_FAST if mode == "fast" else _lib.MODE_STRICT)
 
-    def set_fusion(self, on):
-        """FAST mode: one fused launch per sub-step (default) or the three-kernel path; bit-identical results."""
-        self.ctx.call("csi_set_fusion", int(bool(on)))
+    def set_fusion(self, level):
+        """FAST mode: 0 / False = three-kernel path, 1 = one fused launch per sub-step, 2 / True (default) = two
+        sub-steps per launch where the configuration allows it; bit-identical results."""
+        level = 2 if level is True else int(level)
+        self.ctx.call("csi_set_fusion", level)
 
     def set_exchange_interval(self, k):
         """Tiles: exchange u, v halos of width 2k every k sub-steps (0 = automatic from the halo size)."""

@@ -239,11 +239,14 @@ int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const 
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 
-/* FAST mode only.  on != 0 (default): a sub-step is ONE launch of the fused kernel (stress + both velocity
- * updates, ring recomputation per wavefront, double-buffered u, v, sigma in library scratch) whenever the
- * configuration allows it (csrc/evp_fused.hip); on == 0: always the three-kernel path.  Both paths execute
- * the same floating-point operations and give bit-identical results. */
-int32_t csi_set_fusion(csi_context* ctx, int32_t on);
+/* FAST mode only.  level 0: always the three-kernel path.  level 1: a sub-step is ONE launch of the fused
+ * kernel (stress + both velocity updates, ring recomputation per wavefront, double-buffered u, v, sigma in
+ * library scratch) whenever the configuration allows it (csrc/evp_fused.hip).  level 2 (default): in addition
+ * TWO consecutive sub-steps share one launch (csrc/evp_fused2.hip: the first sub-step's results stay in
+ * registers) where all four sides are periodic or connected, the halo is >= 4 and, on tiles, the exchange
+ * interval is even; an odd trailing sub-step uses the level-1 kernel.  All paths execute the same
+ * floating-point operations and give bit-identical results. */
+int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
 /* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
  * k <= 4 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
@@ -275,14 +278,17 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
 int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
 /* Per-phase device time: runs `substeps` (2..64) further EVP sub-steps from the current state with HIP
  * events between the launches on the context's stream and returns the average milliseconds of
- * [0] the stress phase (or the whole fused sub-step kernel when the fused path is active, then [1] = [2] = 0),
+ * [0] the stress phase (or, when the fused path is active, one LAUNCH of the fused kernel -- one or two
+ *     sub-steps, see csi_last_launches -- then [1] = [2] = 0),
  * [1] the u step, [2] the v step, [3] the halo exchange (0 on an untiled grid).
  * Synchronises; for bench.py's roofline only, never on the timed path. */
 int32_t csi_profile_substeps(csi_context* ctx, double dt, int32_t substeps, double* out_ms4);
-/* Which path the last sub-cycle took: fused kernel (1) or three kernels (0), the halo-exchange interval k and the
- * number of exchanges issued.  Any pointer may be NULL. */
+/* Which path the last sub-cycle took: three kernels (0), fused kernel (1), fused pairs of sub-steps (2); the
+ * halo-exchange interval k and the number of exchanges issued.  Any pointer may be NULL. */
 int32_t csi_last_path(csi_context* ctx, int32_t* fused, int32_t* exchange_interval, int32_t* exchanges);
-/* Number of kernel launches issued for one sub-step in the current configuration. */
+/* Kernel launches and sub-steps of the last fused sub-cycle (sub-steps / launches = sub-steps per launch). */
+int32_t csi_last_launches(csi_context* ctx, int32_t* launches, int32_t* substeps);
+/* Number of kernel launches issued for one sub-step in the current configuration (upper bound). */
 int32_t csi_launches_per_substep(csi_context* ctx, int32_t* n);
 
 #ifdef __cplusplus

@@ -43,6 +43,9 @@ CASES = {
     "ice_strength_nocoriolis": dict(Nx=32, Ny=32, topo=("periodic", "periodic"), pressure="ice_strength", coriolis=None,
                                     top=None, ue=0.1, patches=False),
     "ragged": dict(Nx=67, Ny=5, H=3, topo=("periodic", "periodic"), patches=False, random_uv=0.05),
+    # several 56- / 60-column strips and several row chunks per wave tile: seams of the fused kernels
+    "periodic_seams": dict(Nx=150, Ny=100, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
+    "periodic_halo6": dict(Nx=70, Ny=37, H=6, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
 }
 
 
@@ -250,29 +253,68 @@ def test_rccl_self_exchange_bitwise(mode, fc, k):
     assert np.array_equal(u_ref[H - 2:-(H - 2), H - 2:-(H - 2)], u_til[H - 2:-(H - 2), H - 2:-(H - 2)])
 
 
+@pytest.mark.parametrize("nsub", [12, 15])
+@pytest.mark.parametrize("k", [4, 2, 3])
+@pytest.mark.parametrize("fc", [(True, True), (True, False), (False, True)], ids=["xy", "x", "y"])
+def test_pair_kernel_on_tiles_halo8(fc, k, nsub):
+    """Two sub-steps per launch on a self-connected tile with halo 8: exchange of width 2k every k sub-steps, the
+    pairs sit at batch positions (0,1), (2,3); k = 3 is odd, so the library must fall back to one sub-step per
+    launch.  Mixed sides ("x": connected in x, periodic in y) combine exchange and halo images.  Owned cells equal
+    the untiled three-kernel run bit for bit."""
+    c = cases.make_case(Nx=120, Ny=72, H=8, substeps=nsub, topo=("periodic", "periodic"), patches=True, random_uv=0.05)
+    ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
+    csi.time_step_momentum(ref, c["dt"])
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, fc))
+    til.set_exchange_interval(k)
+    csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    path = til.ctx.last_path()
+    assert path["exchange_interval"] == k and path["level"] == (2 if k % 2 == 0 else 1), path
+    for f in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+
+
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
-               "ice_strength_nocoriolis", "ragged"]
+               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6"]
+PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6"}
 
 
 @pytest.mark.parametrize("nsub", [1, 2, 7, 120])
 @pytest.mark.parametrize("name", FUSED_CASES)
-def test_fused_substep_kernel_bitwise_equals_three_kernel_path(name, nsub):
-    """csrc/evp_fused.hip (one launch per sub-step, per-wave ring recomputation, double-buffered u, v, sigma) must
-    reproduce the three-kernel FAST path bit for bit on every field, halos included: same arithmetic
-    (evp_fast_math.h), different schedule.  Odd sub-step counts exercise the copy-back of the ping-pong buffers."""
+def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
+    """csrc/evp_fused.hip (one launch per sub-step, per-wave ring recomputation, double-buffered u, v, sigma) and
+    csrc/evp_fused2.hip (two sub-steps per launch, the first one's results kept in registers) must reproduce the
+    three-kernel FAST path bit for bit: same arithmetic (evp_fast_math.h), different schedule.  Level 1 is
+    compared on every field, halos included.  Level 2 leaves the halo cells of the diagnostics (alpha, zeta,
+    Delta: written on the last sub-step only, never read) to the second sub-step's range, so those are compared
+    on the interior.  Odd sub-step counts exercise the trailing single sub-step and the ping-pong copy-back."""
     c = cases.make_case(substeps=nsub, **CASES[name])
-    out = {}
-    for fusion in (0, 1):
+    out, level = {}, {}
+    for fusion in (0, 1, 2):
         m = cases.csi_model(c, mode="fast")
         m.set_fusion(fusion)
         csi.time_step_momentum(m, c["dt"])
         m.synchronize()
         assert m.ctx.launches_per_substep() == (1 if fusion else 3)
-        out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta")}
-    for k in out[0]:
-        a, b = out[0][k], out[1][k]
-        assert np.all(np.isfinite(b)), k
-        assert np.array_equal(a, b), (name, nsub, k, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+        level[fusion] = m.ctx.last_path()["level"]
+        diag = (lambda f: f.numpy()) if fusion < 2 else (lambda f: f.interior_numpy())
+        out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22", "s12")}
+        out[fusion].update({k: (EVP_FIELDS[k](m).numpy().copy(), EVP_FIELDS[k](m).interior_numpy().copy())
+                            for k in ("alpha", "zeta_c", "zeta_f", "Delta")})
+    assert level[0] == 0 and level[1] == 1
+    assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else 1), level
+    if level[2] == 2:
+        launches, substeps = m.ctx.last_launches()
+        assert substeps == nsub and launches == (nsub + 1) // 2
+    for fusion in (1, 2):
+        for k in out[0]:
+            a, b = out[0][k], out[fusion][k]
+            if isinstance(a, tuple):
+                a, b = (a[1], b[1]) if level[fusion] == 2 else (a[0], b[0])
+            assert np.all(np.isfinite(b)), k
+            assert np.array_equal(a, b), (name, nsub, fusion, k, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
 @pytest.mark.parametrize("k", [1, 2])
