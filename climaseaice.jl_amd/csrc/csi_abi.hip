@@ -406,13 +406,15 @@ bool pair_supported(const csi_context* c) {
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     FusedGeom G;
     G.rs = dec;
-    // (56-column strip) x (rows) wave tiles; the kernel runs 2 waves per SIMD (2048 resident), each tile pays
-    // 6 ring rows, so: one full round of long tiles when the grid allows it
+    // (56-column strip) x (rows) wave tiles.  The kernel runs 2 waves per SIMD (2048 resident) and is bound by
+    // FP64 VALU issue; the SIMD favours its older wave, so a launch of exactly one round leaves every SIMD with a
+    // single wave for its last third.  About 1.5 rounds measured best (2048^2: rows 25 -> 3034 waves, 40.5 G
+    // cell-updates/s; rows 38 -> 1998 waves, 34.4 G; rows 22 -> 3478 waves, 35.5 G), each tile pays 6 ring rows.
     const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
     G.nstrips = (width + 55) / 56;
     const long strip_rows = (long)G.nstrips * height;
-    int rows = (int)((strip_rows + 2047) / 2048);
-    if (rows < 16) rows = 16;
+    int rows = (int)((strip_rows + 3029) / 3030);
+    if (rows < 12) rows = 12;
     if (rows > 128) rows = 128;
     if (const char* e = getenv("CSI_PAIR_ROWS")) rows = atoi(e);   // tuning aid
     if (rows > height) rows = height;

@@ -52,9 +52,12 @@ struct Stage {
     // pending window updates
     double Xv_p, Xa_0, Xm_0, e12_p, XW_next;
 
+    // do_stress / do_vel (wave-uniform): the rows at the start of a tile only fill the window (strain rates and
+    // x-averages); their stresses / velocities would never be used
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
-                                         double s11, double s22, double s12, double un_m, double vn_x) {
+                                         double s11, double s22, double s12, double un_m, double vn_x,
+                                         bool do_stress, bool do_vel) {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
         Xv_p = fm::avg2(from_left(v_p), v_p);
         double e11_0, e22_0;
@@ -73,11 +76,15 @@ struct Stage {
             const double Pf = 0.5 * (XP_m + XP_0);
             const double mf = 0.5 * (Xm_m + Xm_0);
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
-            const double kc = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
-            const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
-            S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc; zf = o.zf; Dc = o.Dc;
+            if (do_stress) {
+                const double kc = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
+                const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
+                S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc; zf = o.zf; Dc = o.Dc;
+            }
         }
-        if (UFIRST) {
+        if (!do_vel) {
+            XW_next = XW;
+        } else if (UFIRST) {
             const int j = r - 1;
             double W_0;
             {
@@ -337,7 +344,7 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
 
         // ---- stage A: sub-step s, row r ------------------------------------------------------------------------
         const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
-        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x);
+        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart);
 
         PROBE(acc3);
         // ---- stage B: sub-step s + 1, row q = r - 2, fed from A ---------------------------------------------------
@@ -345,7 +352,8 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         const double bu_p = AUF ? A.first : A.second;          // new u of row r-1
         const double bv_p = AUF ? A.second : A.Wprev;          // new v of row r-1
         const double bm_0 = A.m_mm, ba_0 = A.a_mm;             // row r-2
-        B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3);
+        B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3,
+               q >= ja - 1, q >= ja);
         pend_second = B.second;
         PROBE(acc4);
 

@@ -9,17 +9,18 @@
 namespace csi {
 namespace fused {
 
-// value of `x` in lane - 1 / lane + 1 (DPP wave shifts; edge lanes receive their own value: they are ring)
+// value of `x` in lane - 1 / lane + 1 (DPP wave shifts).  bound_ctrl: the lane without a source (lane 0 / lane 63)
+// reads 0 -- it is a ring lane whose results are never used -- so no copy of the old value is needed.
 __device__ __forceinline__ double from_left(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);   // wave_shr:1
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double from_right(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
