@@ -22,6 +22,8 @@ namespace fm {
 #define CSI_EPS64 2.220446049250313e-16
 
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// v_max_f64; only used where neither operand can be NaN unless the inputs already are
+__device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 __device__ __forceinline__ double avg2(double a, double b) { return 0.5 * (a + b); }
 __device__ __forceinline__ double avg4(double a, double b, double c, double d) {   // y-average of x-averages
@@ -39,22 +41,32 @@ __device__ __forceinline__ double rcp(double x) {
     r = fma_(fma_(-x, r, 1.0), r, r);
     return r;
 }
-// s = sqrt(x), rs = 1 / sqrt(x) for x > 0
+// s = sqrt(x), rs = 1 / sqrt(x) for x > 0.  Measured on gfx950 over 120 binades (scripts/microbench/seed_acc.hip):
+// the seed has 2^-25 relative error; coupled Goldschmidt step + one residual correction gives sqrt to 0.5 ulp
+// (a second correction changes nothing), the reciprocal to 0.6 ulp mean / 10 ulp max.
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     const double r = fma_(-h, g, 0.5);
     g = fma_(g, r, g);
     h = fma_(h, r, h);
-    double d = fma_(-g, g, x);
-    g = fma_(d, h, g);
-    d = fma_(-g, g, x);
+    const double d = fma_(-g, g, x);
     g = fma_(d, h, g);
     // one more step for the reciprocal: h ~ 1 / (2 sqrt(x))
     const double e = fma_(-h, g, 0.5);
     h = fma_(h, e, h);
     s = g;
     rs = 2.0 * h;
+}
+// sqrt(x) alone (same operations as sqrt_rsqrt up to s)
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma_(-h, g, 0.5);
+    g = fma_(g, r, g);
+    h = fma_(h, r, h);
+    const double d = fma_(-g, g, x);
+    return fma_(d, h, g);
 }
 
 // e11 = A (u_e - u_w) + Bn v_n - Bs v_s ; e22 = Cn v_n - Cs v_s        (cell)
@@ -91,14 +103,12 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     const double tc = e11c - e22c, tf = e11f - e22f;
     const double sc2 = fma_(tc, tc, 4.0 * (e12c * e12c));
     const double sf2 = fma_(tf, tf, 4.0 * (e12f * e12f));
-    // Delta = max(sqrt(x), Dmin) and 1 / Delta from one rsqrt refinement (evp:265-266, 270-271)
-    const double xc = fma_(dc, dc, sc2 * k.em2), xf = fma_(df, df, sf2 * k.em2);
+    // Delta = max(sqrt(x), Dmin) and 1 / Delta (evp:265-266, 270-271): sqrt is monotone, so the argument is
+    // clamped instead of the result and no select follows
+    const double xc = fmax_(fma_(dc, dc, sc2 * k.em2), k.Dmin2), xf = fmax_(fma_(df, df, sf2 * k.em2), k.Dmin2);
     double Dc, rDc, Df, rDf;
     sqrt_rsqrt(xc, Dc, rDc);
     sqrt_rsqrt(xf, Df, rDf);
-    const bool cc = !(xc > k.Dmin2), cf = !(xf > k.Dmin2);     // also catches x == 0 (NaN from the seed)
-    Dc = cc ? k.Dmin : Dc; rDc = cc ? k.rDmin : rDc;
-    Df = cf ? k.Dmin : Df; rDf = cf ? k.rDmin : rDf;
     const double zc = Pc * (0.5 * rDc);
     const double zf = Pf * (0.5 * rDf);
     const double Pr = (k.pressure_kind == 0) ? Pc * Dc * rcp(Dc + k.Dmin) : Pc;
@@ -107,17 +117,16 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     const double s11n = fma_(2.0 * etac, e11c, bulk);
     const double s22n = fma_(2.0 * etac, e22c, bulk);
     const double s12n = 2.0 * etaf * e12f;
-    // gamma = clamp(sqrt(gamma^2), alpha-, alpha+) with NaN -> alpha+ (evp:334-340); the clamp is applied to
-    // gamma^2 so that the refinement only ever sees finite positive arguments
-    double g2c = zc * kc * rcp(mc);
-    double g2f = zf * kf * rcp(mf);
+    // gamma = clamp(sqrt(gamma^2), alpha-, alpha+) with NaN -> alpha+ (evp:334-340): gamma^2 is clamped to
+    // [alpha-^2, alpha+^2], so the refinement only ever sees finite positive arguments and gamma, 1 / gamma need
+    // no select.  The upper side is an explicit select, !(x < a): NaN (0 * inf where there is no ice) and +inf
+    // go to alpha+^2 whatever the min / max NaN convention of the hardware mode.
+    const double g2c_raw = zc * kc * rcp(mc), g2f_raw = zf * kf * rcp(mf);
+    const double g2c = fmax_((g2c_raw < k.amax2) ? g2c_raw : k.amax2, k.amin2);
+    const double g2f = fmax_((g2f_raw < k.amax2) ? g2f_raw : k.amax2, k.amin2);
     double gc, rgc, gf, rgf;
     sqrt_rsqrt(g2c, gc, rgc);
     sqrt_rsqrt(g2f, gf, rgf);
-    const bool hic = !(g2c < k.amax2), loc = g2c <= k.amin2;   // !(x < a): NaN and +inf go to alpha+
-    const bool hif = !(g2f < k.amax2), lof = g2f <= k.amin2;
-    gc = hic ? k.amax : (loc ? k.amin : gc); rgc = hic ? k.ramax : (loc ? k.ramin : rgc);
-    gf = hif ? k.amax : (lof ? k.amin : gf); rgf = hif ? k.ramax : (lof ? k.ramin : rgf);
     o.s11 = s11 + ((mc > 0) ? (s11n - s11) * rgc : 0.0);
     o.s22 = s22 + ((mc > 0) ? (s22n - s22) * rgc : 0.0);
     o.s12 = s12 + ((mf > 0) ? (s12n - s12) * rgf : 0.0);
@@ -141,8 +150,7 @@ __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, d
     else if (kind == 3) {
         const double d1 = we - w, d2 = webar - wbar;
         const double n2 = fma_(d1, d1, d2 * d2);
-        double n, rn;
-        sqrt_rsqrt(n2, n, rn);
+        const double n = sqrt_pos(n2);
         im = rhoCd * ((n2 > 0) ? n : 0.0);
         ex = im * we;
     }

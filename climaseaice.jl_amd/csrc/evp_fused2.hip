@@ -357,14 +357,16 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         pend_second = B.second;
         PROBE(acc4);
 
-        // diagnostics: last launch of the sub-cycle only, stored at once
+        // diagnostics: last launch of the sub-cycle only, stored at once (with their halo images on periodic sides,
+        // where the reference computes them from halo data: same values)
         if (write_diag) {
-            if (((flags & L_RS) != 0) & (q >= ja) & (q <= jb) & (q >= T->I[FI_RS + 2]) & (q <= T->I[FI_RS + 3])) {
+            if (((flags & L_RS) != 0) & (q >= rs_lo) & (q <= rs_hi)) {
                 const unsigned ocq = oc_cur - 2u * sc, ofq = of_cur - 2u * sf;
-                stg(T->P[FP_AL], ocq, B.AL_0);
-                stg(T->P[FP_ZF], ofq, B.zf);
-                stg(T->P[FP_ZC], ocq, B.zc);
-                stg(T->P[FP_DL], ocq, B.Dc);
+                const int yq = yimg(q);
+                put(T->P[FP_AL], ocq, (unsigned)yq * sc, B.AL_0);
+                put(T->P[FP_ZF], ofq, (unsigned)yq * sf, B.zf);
+                put(T->P[FP_ZC], ocq, (unsigned)yq * sc, B.zc);
+                put(T->P[FP_DL], ocq, (unsigned)yq * sc, B.Dc);
             }
         }
 

@@ -127,14 +127,17 @@ def test_fast_vs_oracle_full_cycle(name, oracle_lib):
     assert np.array_equal(g["u"] == 0.0, p.f["u"] == 0.0)
     assert np.array_equal(g["v"] == 0.0, p.f["v"] == 0.0)
     if well_conditioned:
+        # Diagnostics of the last sub-step: the reference computes them on -H+2 : N+H-1 (the outermost halo layer is
+        # never written); the two-sub-steps-per-launch kernel writes the interior and all H periodic images.
+        # Compare where both define a value.
+        inner = lambda x: x[1:-1, 1:-1]
         # alpha clamp decisions agree (alpha- / alpha+ plateaus are the same cells)
         for bound in (50.0, 300.0):
-            assert np.array_equal(g["alpha"] == bound, p.f["alpha"] == bound)
-        assert np.abs(g["alpha"] - p.f["alpha"]).max() <= 1e-11 * 300.0
-        # diagnostics of the last sub-step (the reference leaves zeta, Delta of the last viscosity kernel)
+            assert np.array_equal(inner(g["alpha"]) == bound, inner(p.f["alpha"]) == bound)
+        assert np.abs(inner(g["alpha"]) - inner(p.f["alpha"])).max() <= 1e-11 * 300.0
         for k in ("zeta_c", "zeta_f", "Delta"):
             scale = np.abs(p.f[k]).max()
-            assert np.abs(g[k] - p.f[k]).max() <= 1e-10 * scale, k
+            assert np.abs(inner(g[k]) - inner(p.f[k])).max() <= 1e-10 * scale, k
 
 
 @pytest.mark.parametrize("name", ["periodic_full_ice", "ice_strength_nocoriolis", "periodic_patches", "latlon_bounded"])
