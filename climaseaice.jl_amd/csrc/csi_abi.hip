@@ -406,16 +406,17 @@ bool pair_supported(const csi_context* c) {
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     FusedGeom G;
     G.rs = dec;
-    // (56-column strip) x (rows) wave tiles.  The kernel runs 2 waves per SIMD (2048 resident) and is bound by
-    // FP64 VALU issue; the SIMD favours its older wave, so a launch of exactly one round leaves every SIMD with a
-    // single wave for its last third.  About 1.5 rounds measured best (2048^2: rows 25 -> 3034 waves, 40.5 G
-    // cell-updates/s; rows 38 -> 1998 waves, 34.4 G; rows 22 -> 3478 waves, 35.5 G), each tile pays 6 ring rows.
+    // (56-column strip) x (rows) wave tiles.  The kernel runs 2 waves per SIMD (256 CUs x 2 workgroups x 4 waves
+    // = 2048 resident) and is bound by FP64 VALU issue.  Exactly one round of tiles, as tall as possible: every
+    // SIMD keeps its two waves from start to end (they trade issue priority every row, evp_fused2.hip) and each
+    // tile pays its 6 ring rows once.  Measured at 2048^2: rows 38 -> 1998 waves, 48.5 G cell-updates/s;
+    // rows 36 -> 2109 waves (a second round of 61), 36.5 G; rows 25 -> 3034 waves, 45.7 G.
     const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
     G.nstrips = (width + 55) / 56;
-    const long strip_rows = (long)G.nstrips * height;
-    int rows = (int)((strip_rows + 3029) / 3030);
-    if (rows < 12) rows = 12;
-    if (rows > 128) rows = 128;
+    int max_chunks = 2048 / G.nstrips;
+    if (max_chunks < 1) max_chunks = 1;
+    int rows = (height + max_chunks - 1) / max_chunks;
+    if (rows < 16) rows = 16;          // small grids: fewer, not shorter, tiles (ring rows would dominate)
     if (const char* e = getenv("CSI_PAIR_ROWS")) rows = atoi(e);   // tuning aid
     if (rows > height) rows = height;
     if (rows < 1) rows = 1;

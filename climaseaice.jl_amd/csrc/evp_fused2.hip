@@ -314,9 +314,15 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
 #else
 #define PROBE(acc) do { } while (0)
 #endif
+    // Issue arbitration favours the older wave of a SIMD; with two resident waves the older one then finishes early
+    // and the younger runs alone (a single wave cannot fill the FP64 pipe).  The two workgroups of a CU therefore
+    // trade the user priority every row: dispatch fills the 32 CUs of an XCD once before it doubles up, so the
+    // parity of (local workgroup index / 32) tells the first from the second resident workgroup.
+    const int prio_phase = (((b >> 3) >> 5) & 1);
     RowIn C, N;
     auto body = [&]() __attribute__((always_inline)) {
         asm volatile("" : "+s"(T));
+        if ((r + prio_phase) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #ifdef CSI_PAIR_PROBE
         { __builtin_amdgcn_sched_barrier(0); tprev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #endif
@@ -380,7 +386,31 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         PROBE(acc5);
     };
     load_row(N);
-    for (; r <= rend; ++r) body();
+    // unrolled by hand (runtime trip count): the row windows are 2 and 3 deep, so after 3 copies of the body most
+    // loop-carried values are back in their registers and the window shifts cost no moves
+#ifndef CSI_PAIR_UNROLL
+#define CSI_PAIR_UNROLL 3
+#endif
+    for (;;) {
+        body();
+        if (++r > rend) break;
+#if CSI_PAIR_UNROLL >= 2
+        body();
+        if (++r > rend) break;
+#endif
+#if CSI_PAIR_UNROLL >= 3
+        body();
+        if (++r > rend) break;
+#endif
+#if CSI_PAIR_UNROLL >= 6
+        body();
+        if (++r > rend) break;
+        body();
+        if (++r > rend) break;
+        body();
+        if (++r > rend) break;
+#endif
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     flush(rend, oc, of);
 #ifdef CSI_PAIR_PROBE

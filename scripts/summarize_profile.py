@@ -1,48 +1,59 @@
-"""Summarise gpurun_out/prof_<tag> (scripts/profile_bench.sh) into profiles/<name>.md + traffic json."""
-import collections, csv, glob, json, sys, os
+"""Summarise gpurun_out/prof_<tag> (scripts/profile_bench.sh) into profiles/<name>.md + profiles/traffic_latest.json.
+
+usage: python scripts/summarize_profile.py <tag> <name> ["note"]
+"""
+import collections, csv, glob, json, sys
 tag, name = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 base = f"gpurun_out/prof_{tag}"
 cells = 2048 * 2048
-algo = {"k_stress": 96, "k_ustep": 80, "k_vstep": 80}
+# kernel -> (key, algorithmic bytes per cell per launch [SURVEY.md 8d], the kernel's own minimum bytes per cell per launch)
+KERNELS = {"fast::k_stress": ("stress", 96, 96), "fast::k_ustep": ("ustep", 80, 80), "fast::k_vstep": ("vstep", 80, 80),
+           "fused::k_substep": ("substep", 256, 120), "fused::k_pair": ("pair", 512, 120)}
+
+
+def classify(kname):
+    for pat, v in KERNELS.items():
+        if pat in kname:
+            return v
+    return None
+
+
 out = [f"# rocprofv3 summary: {name}\n\n{note}\n\n",
        "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-step`\n"
        "(2048x2048 periodic f-plane, 120 sub-steps, FAST mode; counters in separate `--pmc` passes)\n\n## kernel stats\n\n",
        "| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n"]
 ks = glob.glob(base + "/trace/*/*_kernel_stats.csv")[0]
-avg = {}
+avg = collections.defaultdict(list)
 for r in csv.DictReader(open(ks)):
-    out.append(f"| {r['Name'][:80]} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |\n")
-    for a in algo:
-        if "fast::" + a in r["Name"]:
-            avg[a] = float(r["AverageNs"]) / 1e3
-agg = collections.defaultdict(dict)
+    out.append(f"| {r['Name'][:96]} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |\n")
+    c = classify(r["Name"])
+    if c:
+        avg[c[0]].append((float(r["AverageNs"]) / 1e3, int(r["Calls"])))
+avg = {k: sum(a * n for a, n in v) / sum(n for _, n in v) for k, v in avg.items()}
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(base + "/pmc_*/*/*_counter_collection.csv"):
-    tmp = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        tmp[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (k, c), v in tmp.items():
-        agg[k][c] = sum(v) / len(v)
+        c = classify(r["Kernel_Name"])
+        if c:
+            agg[c[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+agg = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items()}
 out.append("\n## HBM-side traffic per launch (FETCH_SIZE, WRITE_SIZE in KB; gfx950: FETCH_SIZE reports 1/2 of the bytes read)\n\n")
-out.append("| kernel | FETCH_SIZE | WRITE_SIZE | corrected traffic MB | algorithmic MB | ratio | avg us | algorithmic GB/s | traffic GB/s |\n|---|---|---|---|---|---|---|---|---|\n")
+out.append("| kernel | FETCH_SIZE | WRITE_SIZE | corrected traffic MB | algorithmic MB | kernel minimum MB | avg us | algorithmic GB/s | traffic GB/s |\n|---|---|---|---|---|---|---|---|---|\n")
 traffic = {}
+byname = {v[0]: v for v in KERNELS.values()}
 for k, v in agg.items():
-    kk = [a for a in algo if "fast::" + a in k]
-    if not kk or "FETCH_SIZE" not in v:
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v or k not in avg:
         continue
-    kk = kk[0]
     tr = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-    al = algo[kk] * cells
-    traffic[kk.replace("k_", "")] = tr
-    out.append(f"| {kk} | {v['FETCH_SIZE']:.0f} | {v['WRITE_SIZE']:.0f} | {tr/1e6:.1f} | {al/1e6:.1f} | {tr/al:.2f} | {avg.get(kk, 0):.1f} | {al/avg[kk]/1e3:.0f} | {tr/avg[kk]/1e3:.0f} |\n")
+    al, mn = byname[k][1] * cells, byname[k][2] * cells
+    traffic[k] = tr
+    out.append(f"| {k} | {v['FETCH_SIZE']:.0f} | {v['WRITE_SIZE']:.0f} | {tr/1e6:.1f} | {al/1e6:.1f} | {mn/1e6:.1f} | {avg[k]:.1f} | {al/avg[k]/1e3:.0f} | {tr/avg[k]/1e3:.0f} |\n")
 out.append("\n## other counters (mean per launch)\n\n| kernel | counter | value |\n|---|---|---|\n")
 for k, v in agg.items():
-    if "csi::fast::k_" not in k or "k_init" in k:
-        continue
     for c, x in sorted(v.items()):
-        if c in ("FETCH_SIZE", "WRITE_SIZE"):
-            continue
-        out.append(f"| {k[:40]} | {c} | {x:.4g} |\n")
+        if c not in ("FETCH_SIZE", "WRITE_SIZE"):
+            out.append(f"| {k} | {c} | {x:.4g} |\n")
 open(f"profiles/{name}.md", "w").write("".join(out))
 json.dump({"source": f"profiles/{name}.md", "workload": "2048x2048 periodic f-plane, FAST", "bytes_per_launch": traffic},
           open("profiles/traffic_latest.json", "w"), indent=1)
