@@ -367,7 +367,7 @@ int32_t ensure_alt(csi_context* c) {
 int exchange_interval(const csi_context* c) {
     if (!is_tiled(c)) return 1;
     const int hmin = c->Hx < c->Hy ? c->Hx : c->Hy, nmin = c->Nx < c->Ny ? c->Nx : c->Ny;
-    int k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 4 ? hmin / 2 : 4);
+    int k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 8 ? hmin / 2 : 8);   // automatic: as rare as the halo allows (<= 8)
     while (k > 1 && (2 * k > hmin || 2 * k > nmin)) --k;
     return k < 1 ? 1 : k;
 }

@@ -249,7 +249,7 @@ int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nf
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
 /* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
- * k <= 4 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
+ * k <= 8 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
  * k = substeps extreme (halo 2*substeps+3, split_explicit_momentum_equations.jl:51-64). */
 int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 

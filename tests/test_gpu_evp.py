@@ -257,7 +257,7 @@ def test_rccl_self_exchange_bitwise(mode, fc, k):
 
 
 @pytest.mark.parametrize("nsub", [12, 15])
-@pytest.mark.parametrize("k", [4, 2, 3])
+@pytest.mark.parametrize("k", [4, 2, 3, 0])
 @pytest.mark.parametrize("fc", [(True, True), (True, False), (False, True)], ids=["xy", "x", "y"])
 def test_pair_kernel_on_tiles_halo8(fc, k, nsub):
     """Two sub-steps per launch on a self-connected tile with halo 8: exchange of width 2k every k sub-steps, the
@@ -273,7 +273,25 @@ def test_pair_kernel_on_tiles_halo8(fc, k, nsub):
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
     path = til.ctx.last_path()
-    assert path["exchange_interval"] == k and path["level"] == (2 if k % 2 == 0 else 1), path
+    kk = k or 4                     # automatic: min(halo / 2, 8) = 4 with halo 8
+    assert path["exchange_interval"] == kk and path["level"] == (2 if kk % 2 == 0 else 1), path
+    for f in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+
+
+def test_pair_kernel_on_tiles_halo16_auto_interval():
+    """bench.py's tile configuration: halo 16, automatic exchange interval (8): four pairs per batch with shrinking
+    valid widths 16/14, 12/10, 8/6, 4/2; 20 sub-steps = 2 full batches + half a batch."""
+    c = cases.make_case(Nx=130, Ny=96, H=16, substeps=20, topo=("periodic", "periodic"), patches=True, random_uv=0.05)
+    ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
+    csi.time_step_momentum(ref, c["dt"])
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, True)))
+    csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    path = til.ctx.last_path()
+    assert path["exchange_interval"] == 8 and path["level"] == 2 and path["exchanges"] == 3, path
     for f in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
         a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
