@@ -260,9 +260,7 @@ int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
     const size_t need_elems = (size_t)(sp.total > rp.total ? sp.total : rp.total);
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
-    if (c->dev_tables) hipFree(c->dev_tables);
-    if (c->sendbuf) hipFree(c->sendbuf);
+        if (c->sendbuf) hipFree(c->sendbuf);
         if (c->recvbuf) hipFree(c->recvbuf);
         c->sendbuf = c->recvbuf = nullptr;
         const size_t cap = need_elems * 2;
