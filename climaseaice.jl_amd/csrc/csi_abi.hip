@@ -372,8 +372,9 @@ int exchange_interval(const csi_context* c) {
 
 // ---- two sub-steps per launch (evp_fused2.hip) -----------------------------------------------------------
 // Valid halo width per side at the start of a sub-step: connected sides follow the exchange batch (W - 2m),
-// periodic sides are refreshed by the owner's halo images after every pair (4 for the first sub-step of a pair,
-// 2 for the second).
+// periodic and wall sides are refreshed by the owner's halo images after every pair (4 for the first sub-step of a
+// pair, 2 for the second; beyond a wall the "valid" cells are mirror images or never-written zeros, exactly what
+// the reference's kernels read there).
 struct SideV { int xlo, xhi, ylo, yhi; };
 SideV pair_side_v(const csi_context* c, int v_connected, int v_periodic) {
     const GridDev& g = c->g;
@@ -386,19 +387,28 @@ Range v_first_range(const csi_context* c, const SideV& v, bool ufirst) {
                   : Range{2 - v.xlo, c->Nx + v.xhi - 2, 3 - v.ylo, c->Ny + v.yhi - 1};
 }
 Range v_second_range(const csi_context* c, const SideV& v) { return Range{3 - v.xlo, c->Nx + v.xhi - 2, 3 - v.ylo, c->Ny + v.yhi - 2}; }
-// periodic sides: the owner stores interior cells only, the halo copies are written as images of that store
-Range clip_periodic(const csi_context* c, Range r) {
+// periodic sides: the owner stores interior cells only, the halo copies are written as images of that store;
+// wall sides: velocities on 1 : N (split_explicit_momentum_equations.jl:40-46, the wall face N + 1 is never
+// written), stresses on 1 : N + 1 (sigma12 lives on the wall corners)
+Range clip_store(const csi_context* c, Range r, bool sigma) {
     const GridDev& g = c->g;
-    if (g.xlo == SIDE_PERIODIC && r.i0 < 1) r.i0 = 1;
+    const int ex = sigma ? 1 : 0;
+    if (g.xlo != SIDE_CONNECTED && r.i0 < 1) r.i0 = 1;
     if (g.xhi == SIDE_PERIODIC && r.i1 > c->Nx) r.i1 = c->Nx;
-    if (g.ylo == SIDE_PERIODIC && r.j0 < 1) r.j0 = 1;
+    if (g.xhi == SIDE_WALL && r.i1 > c->Nx + ex) r.i1 = c->Nx + ex;
+    if (g.ylo != SIDE_CONNECTED && r.j0 < 1) r.j0 = 1;
     if (g.yhi == SIDE_PERIODIC && r.j1 > c->Ny) r.j1 = c->Ny;
+    if (g.yhi == SIDE_WALL && r.j1 > c->Ny + ex) r.j1 = c->Ny + ex;
     return r;
+}
+bool has_walls(const csi_context* c) {
+    const GridDev& g = c->g;
+    return g.xlo == SIDE_WALL || g.xhi == SIDE_WALL || g.ylo == SIDE_WALL || g.yhi == SIDE_WALL;
 }
 bool pair_supported(const csi_context* c) {
     if (!c->pairing) return false;
     const GridDev& g = c->g;
-    auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED; };
+    auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED || s == SIDE_WALL; };
     return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
 }
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
@@ -468,8 +478,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                 for (int cur = 0; cur < 2; ++cur)
                     for (int auf = 0; auf < 2; ++auf) {
                         const bool buf = auf == 0;                  // the second sub-step has the other order
-                        const Range rs = clip_periodic(c, dec), r1 = clip_periodic(c, v_first_range(c, vb, buf)),
-                                    r2 = clip_periodic(c, v_second_range(c, vb));
+                        const Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vb, buf), false),
+                                    r2 = clip_store(c, v_second_range(c, vb), false);
                         FusedTable* t = &host[NSINGLE + (mp * 2 + cur) * 2 + auf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
@@ -488,7 +498,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
-                              GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+                              has_walls(c), GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
             m += 2; s += 2;
         } else {
             launch_fused_substep(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,

@@ -49,7 +49,7 @@ void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst
 // the wave tiles decompose, a_j0 / a_j1 = the first sub-step's stress rows, sigma image specs.
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
                            const ImageSpec& ims12, FusedTable* host_table);
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, int nstrips, int nchunks, int rows,
                        int write_diag, hipStream_t s);
 
 // halo / masks / copies (halo.hip)

@@ -57,7 +57,7 @@ struct Stage {
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
-                                         bool do_stress, bool do_vel) {
+                                         bool do_stress, bool do_vel, bool per_first, bool per_second) {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
         Xv_p = fm::avg2(from_left(v_p), v_p);
         double e11_0, e22_0;
@@ -95,7 +95,7 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
                 const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
-                W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, false);
+                W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::avg2(W_0, from_right(W_0));
             {
@@ -107,7 +107,7 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_m, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_m, ubar, exb, imb);
                 const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
-                second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, false);
+                second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
             XW_next = XW_0;
@@ -122,7 +122,7 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_0, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_0, ubar, exb, imb);
                 const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
-                W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, false);
+                W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::avg2(from_left(W_0), W_0);
             {
@@ -134,7 +134,7 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
                 const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
-                second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, false);
+                second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
             XW_next = XW_0;
@@ -156,7 +156,7 @@ struct Stage {
     }
 };
 
-template <bool UNI, bool AUF>
+template <bool UNI, bool AUF, bool WALLS>
 __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                int blocks_per_xcd, int write_diag) {
     const int b = (int)blockIdx.x;
@@ -172,10 +172,11 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
     unsigned loff, oc, of, sc, sf;
     int i;
     unsigned flags;
-    int dx;                  // byte offset of this column's halo image (0: none)
+    int dx;                  // byte offset of this column's halo image on a periodic side (0: none): every field
+    int dxv;                 // the same for v, which also has mirror images across x walls (Center in x)
     bool wave_has_dx;        // any lane of the wave has one
     bool lanes_uniform;      // fast store path allowed (see flush)
-    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4 };
+    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64 };
     {
         const int Nx = T->I[FI_NX], Ny = T->I[FI_NY], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
         const int i0s = T->I[FI_DEC + 0] - P_LO + strip * P_W;
@@ -196,7 +197,20 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
             if ((i >= 1) & (i <= Hx)) dx = Nx * 8;
             else if ((i > Nx - Hx) & (i <= Nx)) dx = -Nx * 8;
         }
-        wave_has_dx = __builtin_amdgcn_ballot_w64(dx != 0) != 0;
+        dxv = dx;
+        if (WALLS) {
+            // Walls (Bounded sides): faces on / beyond the wall are peripheral nodes (velocity 0); v, Center in x, is
+            // mirrored across an x wall: column i in [1, H] -> 1 - i, column in (N - H, N] -> 2N + 1 - i.  Lanes at
+            // columns 0 and N + 1 are the first mirror cells: stage B takes their v from the neighbouring lane.
+            const bool xlo_wall = T->I[FI_XLO] == SIDE_WALL, xhi_wall = T->I[FI_XHI] == SIDE_WALL;
+            if ((xlo_wall & (i <= 1)) | (xhi_wall & (i > Nx))) flags |= L_WALL_U;
+            if ((xlo_wall & (i < 1)) | (xhi_wall & (i > Nx))) flags |= L_WALL_V;
+            if (xlo_wall & (i == 0)) flags |= L_MIR_LO;
+            if (xhi_wall & (i == Nx + 1)) flags |= L_MIR_HI;
+            if (xlo_wall & (i >= 1) & (i <= Hx)) dxv = (1 - 2 * i) * 8;
+            if (xhi_wall & (i > Nx - Hx) & (i <= Nx)) dxv = (2 * Nx + 1 - 2 * i) * 8;
+        }
+        wave_has_dx = __builtin_amdgcn_ballot_w64((dx != 0) | (dxv != 0)) != 0;
         // every lane stores all three kinds or none, and no lane has an image: the common store path
         const bool same = ((flags & L_RS) != 0) == ((flags & L_R1) != 0) && ((flags & L_RS) != 0) == ((flags & L_R2) != 0);
         lanes_uniform = !wave_has_dx && (__builtin_amdgcn_ballot_w64(!same) == 0);
@@ -268,14 +282,24 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
     auto yimg = [&](int j) __attribute__((always_inline)) {
         return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
     };
+    // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
+    const bool ylo_wall = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall = WALLS && T->I[FI_YHI] == SIDE_WALL;
+    auto yimg_u = [&](int j) __attribute__((always_inline)) {
+        int d = yimg(j);
+        if (WALLS) {
+            if (ylo_wall & (j >= 1) & (j <= HyW)) d = 1 - 2 * j;
+            if (yhi_wall & (j > NyW - HyW) & (j <= NyW)) d = 2 * NyW + 1 - 2 * j;
+        }
+        return d;
+    };
     // one value -> its cell and the halo images of that cell (same semantics as store_with_images for wrap sides)
-    auto put = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
+    auto put = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val) __attribute__((always_inline)) {
         stg(base, off, val);
         if (dy != 0u) stg(base, off + dy, val);
         if (wave_has_dx) {
-            if (dx != 0) {
-                stg(base, off + (unsigned)dx, val);
-                if (dy != 0u) stg(base, off + (unsigned)dx + dy, val);
+            if (dxl != 0) {
+                stg(base, off + (unsigned)dxl, val);
+                if (dy != 0u) stg(base, off + (unsigned)dxl + dy, val);
             }
         }
     };
@@ -289,7 +313,8 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
         OutPtrs P;                                                // adjacent table slots: one wide scalar load
         P.s11 = T->P[FP_S11_OUT]; P.s22 = T->P[FP_S22_OUT]; P.s12 = T->P[FP_S12_OUT]; P.u = T->P[FP_U_OUTP]; P.v = T->P[FP_V_OUTP];
-        const int yq = yimg(q), y1 = yimg(j1), y2 = yimg(j2);
+        // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
+        const int yq = yimg(q), y1 = AUF ? yimg(j1) : yimg_u(j1), y2 = AUF ? yimg_u(j2) : yimg(j2);
         if (lanes_uniform & do_s & do_1 & do_2 & ((yq | y1 | y2) == 0)) {
             // interior tile, interior rows (nearly every call): the owned lanes store five values, no images
             if (flags & L_RS) {
@@ -299,12 +324,12 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
             return;
         }
         if (do_s & ((flags & L_RS) != 0)) {
-            put(P.s11, ocq, (unsigned)yq * sc, B.S11_m);
-            put(P.s22, ocq, (unsigned)yq * sc, B.S22_m);
-            put(P.s12, ofq, (unsigned)yq * sf, B.S12_m);
+            put(P.s11, ocq, (unsigned)yq * sc, dx, B.S11_m);
+            put(P.s22, ocq, (unsigned)yq * sc, dx, B.S22_m);
+            put(P.s12, ofq, (unsigned)yq * sf, dx, B.S12_m);
         }
-        if (do_1 & ((flags & L_R1) != 0)) put(AUF ? P.v : P.u, o1, (unsigned)y1 * (AUF ? sc : sf), B.Wprev);
-        if (do_2 & ((flags & L_R2) != 0)) put(AUF ? P.u : P.v, o2, (unsigned)y2 * (AUF ? sf : sc), pend_second);
+        if (do_1 & ((flags & L_R1) != 0)) put(AUF ? P.v : P.u, o1, (unsigned)y1 * (AUF ? sc : sf), AUF ? dxv : dx, B.Wprev);
+        if (do_2 & ((flags & L_R2) != 0)) put(AUF ? P.u : P.v, o2, (unsigned)y2 * (AUF ? sf : sc), AUF ? dx : dxv, pend_second);
     };
 #ifdef CSI_PAIR_PROBE
     const unsigned long long wall0 = wall_clock64();
@@ -350,16 +375,34 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
 
         // ---- stage A: sub-step s, row r ------------------------------------------------------------------------
         const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
-        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart);
+        // peripheral nodes of a row (walls only): u faces of rows beyond a y wall, v faces on / beyond it
+        auto wall_row = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j < 1)) | (yhi_wall & (j > NyW)); };
+        auto wall_vrow = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j <= 1)) | (yhi_wall & (j > NyW)); };
+        const bool lane_wu = WALLS && (flags & L_WALL_U) != 0, lane_wv = WALLS && (flags & L_WALL_V) != 0;
+        // first / second velocity of a stage that ran row rr: u-first: u(rr-1), v(rr-1); v-first: v(rr), u(rr-1)
+        const bool pa1 = WALLS && (AUF ? (lane_wu | wall_row(r - 1)) : (lane_wv | wall_vrow(r)));
+        const bool pa2 = WALLS && (AUF ? (lane_wv | wall_vrow(r - 1)) : (lane_wu | wall_row(r - 1)));
+        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2);
 
         PROBE(acc3);
         // ---- stage B: sub-step s + 1, row q = r - 2, fed from A ---------------------------------------------------
         const int q = r - 2;
-        const double bu_p = AUF ? A.first : A.second;          // new u of row r-1
-        const double bv_p = AUF ? A.second : A.Wprev;          // new v of row r-1
+        double bu_p = AUF ? A.first : A.second;                // new u of row r-1
+        double bv_p = AUF ? A.second : A.Wprev;                // new v of row r-1
+        if (WALLS) {
+            // What the reference reads from mirror halos, stage B reads from A's registers: v of the first cell
+            // beyond an x wall is its neighbour's; u of the first row beyond a y wall is the wall row's (row 0 is
+            // patched when row 1 arrives, row N + 1 copies row N).  Deeper halo cells only feed halo results.
+            const double vl = from_left(bv_p), vr = from_right(bv_p);
+            bv_p = (flags & L_MIR_LO) ? vr : ((flags & L_MIR_HI) ? vl : bv_p);
+            if (ylo_wall & (q == 0)) B.u_0 = bu_p;
+            if (yhi_wall & (q == NyW)) bu_p = B.u_0;
+        }
         const double bm_0 = A.m_mm, ba_0 = A.a_mm;             // row r-2
+        const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
+        const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3,
-               q >= ja - 1, q >= ja);
+               q >= ja - 1, q >= ja, pb1, pb2);
         pend_second = B.second;
         PROBE(acc4);
 
@@ -369,10 +412,10 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
             if (((flags & L_RS) != 0) & (q >= rs_lo) & (q <= rs_hi)) {
                 const unsigned ocq = oc_cur - 2u * sc, ofq = of_cur - 2u * sf;
                 const int yq = yimg(q);
-                put(T->P[FP_AL], ocq, (unsigned)yq * sc, B.AL_0);
-                put(T->P[FP_ZF], ofq, (unsigned)yq * sf, B.zf);
-                put(T->P[FP_ZC], ocq, (unsigned)yq * sc, B.zc);
-                put(T->P[FP_DL], ocq, (unsigned)yq * sc, B.Dc);
+                put(T->P[FP_AL], ocq, (unsigned)yq * sc, dx, B.AL_0);
+                put(T->P[FP_ZF], ofq, (unsigned)yq * sf, dx, B.zf);
+                put(T->P[FP_ZC], ocq, (unsigned)yq * sc, dx, B.zc);
+                put(T->P[FP_DL], ocq, (unsigned)yq * sc, dx, B.Dc);
             }
         }
 
@@ -431,27 +474,21 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 }
 #endif
 
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, int nstrips, int nchunks, int rows,
                        int write_diag, hipStream_t s) {
     const int nw = nstrips * nchunks;
     const int nblocks = (nw + 3) / 4;
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
-    if (getenv("CSI_DEBUG_OCC")) {
-        int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fused::k_pair<true, true>, 256, 0);
-        hipFuncAttributes fa;
-        hipFuncGetAttributes(&fa, (const void*)fused::k_pair<true, true>);
-        fprintf(stderr, "k_pair<true,true>: blocks/CU %d (err %d) regs %d shared %zu local %zu grid %u\n", nb, (int)e, fa.numRegs,
-                fa.sharedSizeBytes, fa.localSizeBytes, grid.x);
-    }
+#define CSI_LAUNCH_PAIR(U, A, W) hipLaunchKernelGGL((fused::k_pair<U, A, W>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
     if (uniform) {
-        if (a_ufirst) hipLaunchKernelGGL((fused::k_pair<true, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
-        else hipLaunchKernelGGL((fused::k_pair<true, false>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
+        if (walls) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true, true); else CSI_LAUNCH_PAIR(true, false, true); }
+        else { if (a_ufirst) CSI_LAUNCH_PAIR(true, true, false); else CSI_LAUNCH_PAIR(true, false, false); }
     } else {
-        if (a_ufirst) hipLaunchKernelGGL((fused::k_pair<false, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
-        else hipLaunchKernelGGL((fused::k_pair<false, false>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag);
+        if (walls) { if (a_ufirst) CSI_LAUNCH_PAIR(false, true, true); else CSI_LAUNCH_PAIR(false, false, true); }
+        else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true, false); else CSI_LAUNCH_PAIR(false, false, false); }
     }
+#undef CSI_LAUNCH_PAIR
 }
 
 }  // namespace csi

@@ -1,0 +1,39 @@
+"""Throughput of the EVP sub-cycle on the other SURVEY.md 8(d) style configurations (not the bench.py headline):
+2048^2, 120 sub-steps, FAST mode, fusion levels 0 / 1 / 2.  Run on the GPU box: python scripts/bench_cases.py"""
+import sys, time, json
+import numpy as np
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import climaseaice_jl_amd as csi
+import cases
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+CONFIGS = {
+    "periodic f-plane": dict(topo=("periodic", "periodic")),
+    "channel (periodic x, walls y)": dict(topo=("periodic", "bounded")),
+    "bounded": dict(topo=("bounded", "bounded")),
+    "lat-lon bounded (per-row metrics)": dict(topo=("bounded", "bounded"), grid="latlon"),
+    "lat-lon channel": dict(topo=("periodic", "bounded"), grid="latlon"),
+}
+out = {}
+for name, kw in CONFIGS.items():
+    c = cases.make_case(Nx=N, Ny=N, substeps=120, patches=False, noise=0.05, **kw)
+    row = {}
+    for level in (0, 1, 2):
+        m = cases.csi_model(c, mode="fast")
+        m.set_fusion(level)
+        for _ in range(2):
+            csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        row[f"level{level}"] = round(N * N * 120 / dt / 1e9, 2)
+        row[f"path{level}"] = m.ctx.last_path()["level"]
+        del m
+    out[name] = row
+    print(name, row, flush=True)
+print(json.dumps(out))

@@ -46,6 +46,7 @@ CASES = {
     # several 56- / 60-column strips and several row chunks per wave tile: seams of the fused kernels
     "periodic_seams": dict(Nx=150, Ny=100, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
     "periodic_halo6": dict(Nx=70, Ny=37, H=6, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
+    "bounded_seams": dict(Nx=141, Ny=90, topo=("bounded", "bounded"), patches=True, random_uv=0.05),
 }
 
 
@@ -53,6 +54,25 @@ def ulp_diff(a, b):
     ia = a.view(np.int64).astype(np.float64)
     ib = b.view(np.int64).astype(np.float64)
     return np.abs(ia - ib).max()
+
+
+DIAG = ("alpha", "zeta_c", "zeta_f", "Delta")
+
+
+def cmp_region(c, k, a):
+    """The part of a parent array every path defines.
+    * sigma12 (Face, Face) beyond a wall is never filled nor read: the reference's kernels leave by-products of their
+      -H+2 : N+H-1 range there, the two-sub-steps-per-launch kernel leaves them alone -> interior (wall corners included).
+    * diagnostics (alpha, zeta, Delta; written on the last sub-step, never read): the reference computes them on
+      -H+2 : N+H-1; the two-sub-steps-per-launch kernel writes the interior plus all H periodic images and nothing
+      beyond walls -> periodic directions without the outermost layer, bounded directions interior only."""
+    H = c["H"]
+    if k == "s12" and "bounded" in c["topo"]:
+        return a[H:a.shape[0] - H, H:a.shape[1] - H]
+    if k in DIAG:
+        cut = [H if t == "bounded" else 1 for t in c["topo"]]          # (x, y)
+        return a[cut[1]:a.shape[0] - cut[1], cut[0]:a.shape[1] - cut[0]]
+    return a
 
 
 def gpu_fields(model):
@@ -121,23 +141,21 @@ def test_fast_vs_oracle_full_cycle(name, oracle_lib):
         d = np.abs(g[k] - p.f[k]).max()
         assert d <= max(FAST_TOL_VEL * vmax, 10 * sens[k]), (k, d, vmax, sens[k])
     for k in ("s11", "s22", "s12"):
-        d = np.abs(g[k] - p.f[k]).max()
+        d = np.abs(cmp_region(c, k, g[k]) - cmp_region(c, k, p.f[k])).max()
         assert d <= max(FAST_TOL_SIG * smax, 10 * sens[k]), (k, d, smax, sens[k])
     # masks / threshold decisions: zero velocity cells (no ice, peripheral nodes) are bit-identical sets
     assert np.array_equal(g["u"] == 0.0, p.f["u"] == 0.0)
     assert np.array_equal(g["v"] == 0.0, p.f["v"] == 0.0)
     if well_conditioned:
-        # Diagnostics of the last sub-step: the reference computes them on -H+2 : N+H-1 (the outermost halo layer is
-        # never written); the two-sub-steps-per-launch kernel writes the interior and all H periodic images.
-        # Compare where both define a value.
-        inner = lambda x: x[1:-1, 1:-1]
+        # diagnostics of the last sub-step, where every path defines them (cmp_region)
+        ga, pa = cmp_region(c, "alpha", g["alpha"]), cmp_region(c, "alpha", p.f["alpha"])
         # alpha clamp decisions agree (alpha- / alpha+ plateaus are the same cells)
         for bound in (50.0, 300.0):
-            assert np.array_equal(inner(g["alpha"]) == bound, inner(p.f["alpha"]) == bound)
-        assert np.abs(inner(g["alpha"]) - inner(p.f["alpha"])).max() <= 1e-11 * 300.0
+            assert np.array_equal(ga == bound, pa == bound)
+        assert np.abs(ga - pa).max() <= 1e-11 * 300.0
         for k in ("zeta_c", "zeta_f", "Delta"):
             scale = np.abs(p.f[k]).max()
-            assert np.abs(inner(g[k]) - inner(p.f[k])).max() <= 1e-10 * scale, k
+            assert np.abs(cmp_region(c, k, g[k]) - cmp_region(c, k, p.f[k])).max() <= 1e-10 * scale, k
 
 
 @pytest.mark.parametrize("name", ["periodic_full_ice", "ice_strength_nocoriolis", "periodic_patches", "latlon_bounded"])
@@ -156,7 +174,7 @@ def test_fast_few_substeps_tight(name, k, oracle_lib):
     for f in ("u", "v"):
         assert np.abs(g[f] - p.f[f]).max() <= 1e-13 * vmax
     for f in ("s11", "s22", "s12"):
-        assert np.abs(g[f] - p.f[f]).max() <= 1e-10 * smax
+        assert np.abs(cmp_region(c, f, g[f]) - cmp_region(c, f, p.f[f])).max() <= 1e-10 * smax
 
 
 def test_strict_full_time_step_momentum_matches_oracle(oracle_lib):
@@ -280,6 +298,25 @@ def test_pair_kernel_on_tiles_halo8(fc, k, nsub):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
+@pytest.mark.parametrize("k", [4, 2])
+def test_pair_kernel_on_channel_tile(k):
+    """A tile with two kinds of edges: x connected (to itself), y walls.  Exchange in x, mirror images and in-register
+    wall conditions in y; owned cells equal the untiled three-kernel run bit for bit."""
+    c = cases.make_case(Nx=120, Ny=72, H=8, substeps=14, topo=("periodic", "bounded"), patches=True, random_uv=0.05)
+    ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
+    csi.time_step_momentum(ref, c["dt"])
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, False)))
+    til.set_exchange_interval(k)
+    csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    path = til.ctx.last_path()
+    assert path["exchange_interval"] == k and path["level"] == 2, path
+    for f in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+
+
 def test_pair_kernel_on_tiles_halo16_auto_interval():
     """bench.py's tile configuration: halo 16, automatic exchange interval (8): four pairs per batch with shrinking
     valid widths 16/14, 12/10, 8/6, 4/2; 20 sub-steps = 2 full batches + half a batch."""
@@ -298,8 +335,9 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
 
 
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
-               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6"]
-PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6"}
+               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams"]
+PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6",
+              "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams"}
 
 
 @pytest.mark.parametrize("nsub", [1, 2, 7, 120])
@@ -310,7 +348,9 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
     three-kernel FAST path bit for bit: same arithmetic (evp_fast_math.h), different schedule.  Level 1 is
     compared on every field, halos included.  Level 2 leaves the halo cells of the diagnostics (alpha, zeta,
     Delta: written on the last sub-step only, never read) to the second sub-step's range, so those are compared
-    on the interior.  Odd sub-step counts exercise the trailing single sub-step and the ping-pong copy-back."""
+    on the interior; so is sigma12 next to walls (its cells beyond a wall are never filled nor read; the
+    three-kernel path leaves by-products of its -H+2 : N+H-1 range there).  Odd sub-step counts exercise the
+    trailing single sub-step and the ping-pong copy-back."""
     c = cases.make_case(substeps=nsub, **CASES[name])
     out, level = {}, {}
     for fusion in (0, 1, 2):
@@ -321,9 +361,10 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
         assert m.ctx.launches_per_substep() == (1 if fusion else 3)
         level[fusion] = m.ctx.last_path()["level"]
         diag = (lambda f: f.numpy()) if fusion < 2 else (lambda f: f.interior_numpy())
-        out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22", "s12")}
+        walls = "bounded" in CASES[name]["topo"]
+        out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22") + (() if walls else ("s12",))}
         out[fusion].update({k: (EVP_FIELDS[k](m).numpy().copy(), EVP_FIELDS[k](m).interior_numpy().copy())
-                            for k in ("alpha", "zeta_c", "zeta_f", "Delta")})
+                            for k in ("alpha", "zeta_c", "zeta_f", "Delta") + (("s12",) if walls else ())})
     assert level[0] == 0 and level[1] == 1
     assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else 1), level
     if level[2] == 2:
