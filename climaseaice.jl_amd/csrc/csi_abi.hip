@@ -439,6 +439,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const bool tiled = is_tiled(c);
     const int k = exchange_interval(c), W = 2 * k;
     const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
+    const bool masked = P.g.has_mask != 0;
     const bool pairs = pair_supported(c) && (!tiled || k % 2 == 0);
     const int kb = tiled ? k : (pairs ? 2 : 1);             // batch length: positions 0 .. kb-1
     FRef orig[5], alt[5];
@@ -498,8 +499,22 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
-                              has_walls(c), GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+                              has_walls(c) || masked, masked, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
             m += 2; s += 2;
+        } else if (masked) {
+            // the one-sub-step kernel takes no mask: a trailing single sub-step runs the three kernels in place on
+            // whichever buffer is current
+            EvpDev Q = P;
+            const FRef* b = cur == 0 ? orig : alt;
+            Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
+            Q.write_diag = (s + 1 == end);
+            const int V = tiled ? W - 2 * m : 2;
+            launch_fast_stress(Q, stress_range(c, V), fc, c->stream);
+            if (ufirst) { launch_fast_ustep(Q, first_u_range(c, V), imu, fc, c->stream); launch_fast_vstep(Q, second_range(c, V), imv, fc, c->stream); }
+            else { launch_fast_vstep(Q, first_v_range(c, V), imv, fc, c->stream); launch_fast_ustep(Q, second_range(c, V), imu, fc, c->stream); }
+            m += 1; s += 1;
+            cur ^= 1;           // undone below: this sub-step did not switch buffers
+            nlaunch += 2;
         } else {
             launch_fused_substep(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
                                  G[m].nstrips, G[m].nchunks, G[m].rows, s + 1 == end, c->stream);
@@ -558,7 +573,12 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax;
     }
     if (fast && !fast_supported(P)) return fail(c, CSI_ERR_UNSUPPORTED, "CSI_MODE_FAST does not support this configuration yet; use CSI_MODE_STRICT");
-    if (fast && c->fusion && fused_supported(P) && substeps > 0) {
+    // immersed masks: only the two-sub-steps-per-launch kernel takes them (a trailing odd sub-step falls back to the
+    // three kernels inside run_fused)
+    const bool fuse = fast && c->fusion && substeps > 0 &&
+                      (P.g.has_mask ? (fused_supported_forcing(P) && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
+                                    : fused_supported(P));
+    if (fuse) {
         if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
         c->launches_per_substep = 1 + ((tiled && k == 1) ? 3 : 0);

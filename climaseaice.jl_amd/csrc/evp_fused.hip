@@ -272,6 +272,19 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
 
 }  // namespace fused
 
+// forcing given by numbers (array-valued stresses / ocean velocities run the three-kernel FAST path)
+bool fused_supported_forcing(const EvpDev& P) {
+    auto ok = [](const StressDev& s) {
+        if (s.kind == 2) return false;
+        if (s.kind == 3 && (s.ue_kind == 2 || s.ve_kind == 2)) return false;
+        return true;
+    };
+    const int lc = P.h.ld, lf = P.u.ld;
+    if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return false;
+    if (P.un.ld != lf || P.s12.ld != lf) return false;
+    return ok(P.top) && ok(P.bot);
+}
+
 bool fused_supported(const EvpDev& P) {
     // two row strides: Center-x fields and Face-x fields (dense Oceananigans parents always satisfy this)
     const int lc = P.h.ld, lf = P.u.ld;
@@ -331,6 +344,10 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     I[FI_IMV] = imv.xlo; I[FI_IMV + 1] = imv.xhi; I[FI_IMV + 2] = imv.ylo; I[FI_IMV + 3] = imv.yhi;
     I[FI_PRESSURE_KIND] = P.pressure_kind; I[FI_HAS_COR] = P.has_cor; I[FI_TOP_KIND] = P.top.kind; I[FI_BOT_KIND] = P.bot.kind;
     I[FI_COEF_STRIDE] = c.stride; I[FI_COEF_JMIN] = c.jmin; I[FI_COEF_JMAX] = c.jmax;
+    if (g.has_mask) {
+        Q[FP_MASK] = (unsigned long)(g.mask - ((g.Hx - 1) + (long)(g.Hy - 1) * g.mask_ld));
+        I[FI_MASK_LD] = g.mask_ld;
+    }
 }
 
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,

@@ -35,12 +35,18 @@ constexpr int P_LO = 4, P_HI = 59, P_W = P_HI - P_LO + 1;
 __device__ unsigned long long g_probe[4096 * 16];
 #endif
 
-struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; };
+struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; };
 
 // One sub-step as a row pipeline.  step(r) consumes row r of P, m, a, sigma, rows r+1 of u, v and produces
 // sigma(r) and  UFIRST: u(r-1) ["first"], v(r-1) ["second"]   /   v first: v(r) ["first"], u(r-1) ["second"].
 // The arithmetic (operations and their order) is that of evp_fused.hip's loop body.
-template <bool UNI, bool UFIRST>
+// MASK: immersed boundary (GridFittedBoundary).  mh carries, per lane, two bits per row -- bit 0: the cell is inactive
+// (immersed or beyond a wall), bit 1: it is beyond a wall -- for rows r, r-1, r-2 at bit positions 0, 2, 4.  As in
+// evp_fast.hip (k_ustep / k_vstep): stresses of immersed cells / corners are zero in the divergence
+// (ice_stress_divergence.jl:57-123), faces next to an inactive cell are peripheral nodes.
+__device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xf, 0xf, true); }
+
+template <bool UNI, bool UFIRST, bool MASK>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
     double a_mm, a_m, m_mm, m_m;
@@ -57,7 +63,7 @@ struct Stage {
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
-                                         bool do_stress, bool do_vel, bool per_first, bool per_second) {
+                                         bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh) {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
         Xv_p = fm::avg2(from_left(v_p), v_p);
         double e11_0, e22_0;
@@ -82,6 +88,26 @@ struct Stage {
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc; zf = o.zf; Dc = o.Dc;
             }
         }
+        // stresses as the divergence sees them, peripheral flags
+        double d11_0 = S11_0, d22_0 = S22_0, d12_0 = S12_0, d11_m = S11_m, d22_m = S22_m, d12_m = S12_m, d11_mm = S11_mm, d22_mm = S22_mm;
+        double d11_mL = XS11L_m;
+        if (MASK) {
+            const unsigned m0 = mh & 3u, m1 = (mh >> 2) & 3u, m2 = (mh >> 4) & 3u;
+            const bool pcc_0 = m0 == 1u, pcc_m = m1 == 1u, pcc_mm = m2 == 1u;        // immersed, not beyond a wall
+            unsigned c0 = m0 | m1, c1 = m1 | m2;                                      // corners of rows r, r-1: 4 cells
+            c0 |= left_bits(c0); c1 |= left_bits(c1);
+            const bool pff_0 = (c0 & 3u) == 1u, pff_m = (c1 & 3u) == 1u;
+            d11_0 = pcc_0 ? 0.0 : S11_0; d22_0 = pcc_0 ? 0.0 : S22_0;
+            d11_m = pcc_m ? 0.0 : S11_m; d22_m = pcc_m ? 0.0 : S22_m;
+            d11_mm = pcc_mm ? 0.0 : S11_mm; d22_mm = pcc_mm ? 0.0 : S22_mm;
+            d12_0 = pff_0 ? 0.0 : S12_0; d12_m = pff_m ? 0.0 : S12_m;
+            d11_mL = from_left(d11_m);
+            const bool ia_0 = (m0 & 1u) != 0, ia_m = (m1 & 1u) != 0, ia_mm = (m2 & 1u) != 0;
+            const bool ia_mL = (left_bits(m1) & 1u) != 0;
+            const bool per_u = ia_m | ia_mL;                                          // u(i, r-1): cells (i, r-1), (i-1, r-1)
+            per_first = UFIRST ? per_u : (ia_0 | ia_m);                               // v(i, r): cells (i, r), (i, r-1)
+            per_second = UFIRST ? (ia_m | ia_mm) : per_u;                             // v(i, r-1): cells (i, r-1), (i, r-2)
+        }
         if (!do_vel) {
             XW_next = XW;
         } else if (UFIRST) {
@@ -90,7 +116,7 @@ struct Stage {
             {
                 const double vbar = 0.5 * (Xv_m + Xv_0);
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
-                                            S11_m, XS11L_m, S12_0, S12_m);
+                                            d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
@@ -102,7 +128,7 @@ struct Stage {
                 const double ubar = 0.5 * (XW + XW_0);
                 const double div = fm::div2(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
-                                            S11_m, S22_m, S11_mm, S22_mm, from_right(S12_m), S12_m);
+                                            d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_m, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_m, ubar, exb, imb);
@@ -117,7 +143,7 @@ struct Stage {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
                 const double div = fm::div2(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
-                                            S11_0, S22_0, S11_m, S22_m, from_right(S12_0), S12_0);
+                                            d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_0, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_0, ubar, exb, imb);
@@ -129,7 +155,7 @@ struct Stage {
                 const int j = r - 1;
                 const double vbar = 0.5 * (XW + XW_0);
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
-                                            S11_m, XS11L_m, S12_0, S12_m);
+                                            d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
@@ -156,7 +182,7 @@ struct Stage {
     }
 };
 
-template <bool UNI, bool AUF, bool WALLS>
+template <bool UNI, bool AUF, bool WALLS, bool MASK>
 __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                int blocks_per_xcd, int write_diag) {
     const int b = (int)blockIdx.x;
@@ -170,6 +196,7 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
 
     int ja, jb, rstart, rend;
     unsigned loff, oc, of, sc, sf;
+    unsigned om = 0, sm = 0;  // MASK: byte offset / row stride into the uint8 activity mask
     int i;
     unsigned flags;
     int dx;                  // byte offset of this column's halo image on a periodic side (0: none): every field
@@ -220,11 +247,15 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         sf = (unsigned)T->I[FI_LD_F] * 8u;
         oc = loff + (unsigned)(rstart - (1 - Hy)) * sc;
         of = loff + (unsigned)(rstart - (1 - Hy)) * sf;
+        if (MASK) {
+            sm = (unsigned)T->I[FI_MASK_LD];
+            om = (unsigned)(ic - (1 - Hx)) + (unsigned)(rstart - (1 - Hy)) * sm;
+        }
     }
     int r = rstart;
 
-    Stage<UNI, AUF> A;
-    Stage<UNI, !AUF> B;
+    Stage<UNI, AUF, MASK> A;
+    Stage<UNI, !AUF, MASK> B;
     // ---- stage A prologue: rows r-1, r (as evp_fused.hip) ------------------------------------------------------
     double P_d1, P_d2 = 0.0;                       // P of rows r-1, r-2
     double un_d1 = 0.0, un_d2 = 0.0;               // u^n of rows r-2, r-3
@@ -264,6 +295,7 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         R.P_0 = ldg(T->P[FP_P], oc); R.h_0 = ldg(T->P[FP_H], oc); R.a_0 = ldg(T->P[FP_A], oc);
         R.s11 = ldg(T->P[FP_S11_IN], oc); R.s22 = ldg(T->P[FP_S22_IN], oc); R.s12 = ldg(T->P[FP_S12_IN], of);
         R.un_m = ldg(T->P[FP_UN], of - sf); R.vn_x = ldg(T->P[FP_VN], AUF ? oc - sc : oc);
+        R.mk = MASK ? ldub(T->P[FP_MASK], om) : 1u;
     };
     // B's results of the iteration that ran row rr (q = rr - 2) are stored at the top of the NEXT iteration:
     // vmcnt counts loads and stores in one in-order queue, and the number of stores is data dependent, so a wait
@@ -344,6 +376,14 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
     // trade the user priority every row: dispatch fills the 32 CUs of an XCD once before it doubles up, so the
     // parity of (local workgroup index / 32) tells the first from the second resident workgroup.
     const int prio_phase = (((b >> 3) >> 5) & 1);
+    // MASK: two bits per row (bit 0 inactive, bit 1 beyond a wall), newest row in bits 1:0; row rstart-1 from memory,
+    // older rows count as beyond the domain (their results are never used)
+    unsigned mhist = 0xffffffffu;
+    if (MASK) {
+        const bool wi = ((flags & L_WALL_V) != 0) | (ylo_wall & (rstart - 1 < 1)) | (yhi_wall & (rstart - 1 > NyW));
+        const unsigned act = ldub(T->P[FP_MASK], om - sm);
+        mhist = (mhist << 2) | (wi ? 3u : (act ? 0u : 1u));
+    }
     RowIn C, N;
     auto body = [&]() __attribute__((always_inline)) {
         asm volatile("" : "+s"(T));
@@ -362,6 +402,7 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         {
             const bool more = r < rend;
             oc += more ? sc : 0u; of += more ? sf : 0u;
+            if (MASK) om += more ? sm : 0u;
             load_row(N);
         }
         PROBE(acc2);
@@ -382,7 +423,11 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         // first / second velocity of a stage that ran row rr: u-first: u(rr-1), v(rr-1); v-first: v(rr), u(rr-1)
         const bool pa1 = WALLS && (AUF ? (lane_wu | wall_row(r - 1)) : (lane_wv | wall_vrow(r)));
         const bool pa2 = WALLS && (AUF ? (lane_wv | wall_vrow(r - 1)) : (lane_wu | wall_row(r - 1)));
-        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2);
+        if (MASK) {
+            const bool wi = lane_wv | wall_row(r);
+            mhist = (mhist << 2) | (wi ? 3u : (C.mk ? 0u : 1u));
+        }
+        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist);
 
         PROBE(acc3);
         // ---- stage B: sub-step s + 1, row q = r - 2, fed from A ---------------------------------------------------
@@ -402,7 +447,7 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3,
-               q >= ja - 1, q >= ja, pb1, pb2);
+               q >= ja - 1, q >= ja, pb1, pb2, mhist >> 4);
         pend_second = B.second;
         PROBE(acc4);
 
@@ -468,27 +513,51 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
 
 }  // namespace fused
 
-#ifdef CSI_PAIR_PROBE
+#if defined(CSI_PAIR_PROBE) && (!defined(CSI_PAIR_VARIANT) || CSI_PAIR_VARIANT == 0)
 extern "C" int csi_debug_probe(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_probe), sizeof(unsigned long long) * 4096 * 16);
 }
 #endif
 
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, int nstrips, int nchunks, int rows,
-                       int write_diag, hipStream_t s) {
+// One translation unit per variant (CSI_PAIR_VARIANT: 0 plain, 1 walls, 2 walls + immersed mask) so that the twelve
+// instantiations compile in parallel.
+#ifndef CSI_PAIR_VARIANT
+#define CSI_PAIR_VARIANT 0
+#endif
+#if CSI_PAIR_VARIANT == 0
+#define CSI_PAIR_NAME launch_fused_pair_plain
+#define CSI_PAIR_WALLS false
+#define CSI_PAIR_MASK false
+#elif CSI_PAIR_VARIANT == 1
+#define CSI_PAIR_NAME launch_fused_pair_walls
+#define CSI_PAIR_WALLS true
+#define CSI_PAIR_MASK false
+#else
+#define CSI_PAIR_NAME launch_fused_pair_mask
+#define CSI_PAIR_WALLS true
+#define CSI_PAIR_MASK true
+#endif
+void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
+                   int write_diag, hipStream_t s) {
     const int nw = nstrips * nchunks;
     const int nblocks = (nw + 3) / 4;
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
-#define CSI_LAUNCH_PAIR(U, A, W) hipLaunchKernelGGL((fused::k_pair<U, A, W>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
-    if (uniform) {
-        if (walls) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true, true); else CSI_LAUNCH_PAIR(true, false, true); }
-        else { if (a_ufirst) CSI_LAUNCH_PAIR(true, true, false); else CSI_LAUNCH_PAIR(true, false, false); }
-    } else {
-        if (walls) { if (a_ufirst) CSI_LAUNCH_PAIR(false, true, true); else CSI_LAUNCH_PAIR(false, false, true); }
-        else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true, false); else CSI_LAUNCH_PAIR(false, false, false); }
-    }
+#define CSI_LAUNCH_PAIR(U, A) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_WALLS, CSI_PAIR_MASK>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
+    if (uniform) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
+    else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true); else CSI_LAUNCH_PAIR(false, false); }
 #undef CSI_LAUNCH_PAIR
 }
+
+#if CSI_PAIR_VARIANT == 0
+void launch_fused_pair_walls(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, int nstrips, int nchunks, int rows,
+                       int write_diag, hipStream_t s) {
+    if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+    else if (walls) launch_fused_pair_walls(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+    else launch_fused_pair_plain(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+}
+#endif
 
 }  // namespace csi

@@ -46,6 +46,9 @@ typedef __attribute__((address_space(1))) char* gptr_t;     // global address sp
 __device__ __forceinline__ double ldg(unsigned long base, unsigned off) {
     return *(const __attribute__((address_space(1))) double*)((gptr_t)base + off);
 }
+__device__ __forceinline__ unsigned ldub(unsigned long base, unsigned off) {
+    return *(const __attribute__((address_space(1))) unsigned char*)((gptr_t)base + off);
+}
 __device__ __forceinline__ void stg(unsigned long base, unsigned off, double v) {
     *(__attribute__((address_space(1))) double*)((gptr_t)base + off) = v;
 }

@@ -14,7 +14,10 @@ CONFIGS = {
     "bounded": dict(topo=("bounded", "bounded")),
     "lat-lon bounded (per-row metrics)": dict(topo=("bounded", "bounded"), grid="latlon"),
     "lat-lon channel": dict(topo=("periodic", "bounded"), grid="latlon"),
+    "masked channel (30 % land, config 5 style)": dict(topo=("periodic", "bounded"), land=0.3),
 }
+if len(sys.argv) > 2:
+    CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}
 out = {}
 for name, kw in CONFIGS.items():
     c = cases.make_case(Nx=N, Ny=N, substeps=120, patches=False, noise=0.05, **kw)

@@ -47,13 +47,19 @@ CASES = {
     "periodic_seams": dict(Nx=150, Ny=100, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
     "periodic_halo6": dict(Nx=70, Ny=37, H=6, topo=("periodic", "periodic"), patches=True, random_uv=0.05),
     "bounded_seams": dict(Nx=141, Ny=90, topo=("bounded", "bounded"), patches=True, random_uv=0.05),
+    # immersed land (SURVEY.md 8d config 5 style: discs covering ~30 %); only the two-sub-steps-per-launch kernel takes masks
+    "masked_periodic": dict(Nx=130, Ny=84, topo=("periodic", "periodic"), patches=True, random_uv=0.05, land=0.3),
+    "masked_channel": dict(Nx=96, Ny=120, topo=("periodic", "bounded"), patches=True, random_uv=0.05, land=0.3),
+    "masked_latlon": dict(Nx=72, Ny=64, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, land=0.25),
 }
+MASKED = {"masked_periodic", "masked_channel", "masked_latlon"}
 
 
 def ulp_diff(a, b):
-    ia = a.view(np.int64).astype(np.float64)
-    ib = b.view(np.int64).astype(np.float64)
-    return np.abs(ia - ib).max()
+    """largest distance in units in the last place (same-sign finite doubles: difference of the bit patterns)"""
+    ia = np.ascontiguousarray(a).view(np.int64)
+    ib = np.ascontiguousarray(b).view(np.int64)
+    return int(np.abs(ia - ib).max())
 
 
 DIAG = ("alpha", "zeta_c", "zeta_f", "Delta")
@@ -335,9 +341,9 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
 
 
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
-               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams"]
+               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams"] + sorted(MASKED)
 PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6",
-              "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams"}
+              "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams"} | MASKED
 
 
 @pytest.mark.parametrize("nsub", [1, 2, 7, 120])
@@ -358,18 +364,19 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
         m.set_fusion(fusion)
         csi.time_step_momentum(m, c["dt"])
         m.synchronize()
-        assert m.ctx.launches_per_substep() == (1 if fusion else 3)
         level[fusion] = m.ctx.last_path()["level"]
+        assert m.ctx.launches_per_substep() == (1 if level[fusion] else 3)
         diag = (lambda f: f.numpy()) if fusion < 2 else (lambda f: f.interior_numpy())
         walls = "bounded" in CASES[name]["topo"]
         out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22") + (() if walls else ("s12",))}
         out[fusion].update({k: (EVP_FIELDS[k](m).numpy().copy(), EVP_FIELDS[k](m).interior_numpy().copy())
                             for k in ("alpha", "zeta_c", "zeta_f", "Delta") + (("s12",) if walls else ())})
-    assert level[0] == 0 and level[1] == 1
-    assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else 1), level
+    single = 0 if name in MASKED else 1           # the one-sub-step kernel takes no immersed mask
+    assert level[0] == 0 and level[1] == single
+    assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else single), level
     if level[2] == 2:
         launches, substeps = m.ctx.last_launches()
-        assert substeps == nsub and launches == (nsub + 1) // 2
+        assert substeps == nsub and launches == (nsub // 2 + 3 * (nsub % 2) if name in MASKED else (nsub + 1) // 2)
     for fusion in (1, 2):
         for k in out[0]:
             a, b = out[0][k], out[fusion][k]
@@ -382,15 +389,17 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
 @pytest.mark.parametrize("k", [1, 2])
 def test_masked_tile_self_exchange_bitwise(k):
     """Immersed mask + tile edges: the tile's mask (halo included) is sliced from the global one; owned cells equal
-    the untiled masked run bit for bit (three-kernel FAST path; the fused kernel does not take masks yet)."""
+    the untiled masked three-kernel run bit for bit (k = 1: three-kernel path on the tile; k = 2: two sub-steps per
+    launch with the mask)."""
     c = cases.make_case(Nx=64, Ny=48, substeps=10, topo=("periodic", "periodic"), patches=True, random_uv=0.03, land=0.3)
     ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
     csi.time_step_momentum(ref, c["dt"])
     til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, True))
     til.set_exchange_interval(k)
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
-    assert not til.ctx.last_path()["fused"]
+    assert til.ctx.last_path()["level"] == (2 if k == 2 else 0)
     for f in ("u", "v", "s11", "s22", "s12"):
         a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
         assert np.array_equal(a, b), f

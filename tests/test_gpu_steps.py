@@ -9,6 +9,7 @@ import pytest
 import cases
 import climaseaice_jl_amd as csi
 import oracle as O
+from test_gpu_evp import cmp_region
 
 pytestmark = pytest.mark.gpu
 
@@ -98,15 +99,17 @@ def test_masked_subcycle_strict_bitwise_and_fast(name, oracle_lib):
         m.copy_to_field(m.dynamics.auxiliaries.fields.P, p.f["P"])
     p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
     p.subcycle(c["dt"], 1, 8)
+    p.L.ora_finalize_rheology(p.ptr)            # sigma halos: the fused FAST kernels only define them after the fill
     for m in (ms, mf):
         m.ctx.call("csi_evp_subcycle", c["dt"], 8, 1)
+        m.ctx.call("csi_evp_finalize")
         m.synchronize()
     vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
     for k, get in (("u", lambda m: m.velocities.u), ("v", lambda m: m.velocities.v),
                    ("s11", lambda m: m.dynamics.auxiliaries.fields.s11), ("s12", lambda m: m.dynamics.auxiliaries.fields.s12)):
         assert np.array_equal(get(ms).numpy(), p.f[k]), k
         scale = vmax if k in ("u", "v") else np.abs(p.f[k]).max()
-        assert np.abs(get(mf).numpy() - p.f[k]).max() <= 1e-11 * scale, k
+        assert np.abs(cmp_region(c, k, get(mf).numpy()) - cmp_region(c, k, p.f[k])).max() <= 1e-11 * scale, k
     # bit-exact masks: velocities vanish exactly on the peripheral nodes of the immersed grid
     wet = c["mask"]
     land_u = ~wet | ~np.roll(wet, 1, axis=1)
