@@ -76,6 +76,8 @@ struct csi_context {
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
     FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
+    size_t fbar_elems[2] = {0, 0};
     size_t alt_elems[5] = {0, 0, 0, 0, 0};
     bool slab_set = false;   // thermodynamic step inside csi_time_step_fe / _rk3
     SlabDev slab{};
@@ -440,7 +442,25 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const int k = exchange_interval(c), W = 2 * k;
     const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
     const bool masked = P.g.has_mask != 0;
+    const bool force = pair_forcing_kind(P) == 1;           // array-valued forcing: two-sub-steps kernel only
     const bool pairs = pair_supported(c) && (!tiled || k % 2 == 0);
+    FRef ubar_v{nullptr, 0}, vbar_u{nullptr, 0};
+    if (force && P.bot.kind == 3 && (P.bot.ue_kind == 2 || P.bot.ve_kind == 2)) {
+        // cross components of the ocean velocity averaged to the velocity points, once per sub-cycle
+        const Bound* src[2] = {&c->f[CSI_F_V], &c->f[CSI_F_U]};       // shapes: ubar lives at v points, vbar at u points
+        for (int q = 0; q < 2; ++q) {
+            const size_t n = (size_t)src[q]->ld * (size_t)src[q]->nj;
+            if (c->fbar_elems[q] != n) {
+                if (c->fbar[q]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); hipFree(c->fbar[q]); c->fbar[q] = nullptr; }
+                HIP_TRY(c, hipMalloc((void**)&c->fbar[q], n * sizeof(double)));
+                HIP_TRY(c, hipMemsetAsync(c->fbar[q], 0, n * sizeof(double), c->stream));
+                c->fbar_elems[q] = n;
+            }
+        }
+        ubar_v.p = c->fbar[0] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[0]->ld; ubar_v.ld = (int)src[0]->ld;
+        vbar_u.p = c->fbar[1] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[1]->ld; vbar_u.ld = (int)src[1]->ld;
+        launch_forcing_bars(P, ubar_v, vbar_u, c->stream);
+    }
     const int kb = tiled ? k : (pairs ? 2 : 1);             // batch length: positions 0 .. kb-1
     FRef orig[5], alt[5];
     for (int q = 0; q < 5; ++q) { orig[q] = ref_of(c, kPing[q]); alt[q] = alt_ref(c, q); }
@@ -484,6 +504,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         FusedTable* t = &host[NSINGLE + (mp * 2 + cur) * 2 + auf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
+                        if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
                     }
             }
         }
@@ -499,11 +520,11 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
-                              has_walls(c) || masked, masked, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+                              has_walls(c) || masked || force, masked, force, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
             m += 2; s += 2;
-        } else if (masked) {
-            // the one-sub-step kernel takes no mask: a trailing single sub-step runs the three kernels in place on
-            // whichever buffer is current
+        } else if (masked || force) {
+            // the one-sub-step kernel takes neither masks nor array-valued forcing: a trailing single sub-step runs the
+            // three kernels in place on whichever buffer is current
             EvpDev Q = P;
             const FRef* b = cur == 0 ? orig : alt;
             Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
@@ -575,9 +596,11 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     if (fast && !fast_supported(P)) return fail(c, CSI_ERR_UNSUPPORTED, "CSI_MODE_FAST does not support this configuration yet; use CSI_MODE_STRICT");
     // immersed masks: only the two-sub-steps-per-launch kernel takes them (a trailing odd sub-step falls back to the
     // three kernels inside run_fused)
+    const int pfk = pair_forcing_kind(P);
+    const bool pair_only = P.g.has_mask || pfk == 1;      // configurations only the two-sub-steps kernel takes
     const bool fuse = fast && c->fusion && substeps > 0 &&
-                      (P.g.has_mask ? (fused_supported_forcing(P) && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
-                                    : fused_supported(P));
+                      (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
+                                 : fused_supported(P));
     if (fuse) {
         if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
@@ -777,6 +800,7 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
+    for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
     if (c->dev_tables) hipFree(c->dev_tables);
     if (c->sendbuf) hipFree(c->sendbuf);
     if (c->recvbuf) hipFree(c->recvbuf);

@@ -222,6 +222,24 @@ static inline dim3 grid_for(const Range& r, dim3 b) {
     return dim3((unsigned)((r.i1 - r.i0 + 1 + b.x - 1) / b.x), (unsigned)((r.j1 - r.j0 + 1 + b.y - 1) / b.y), 1);
 }
 
+// cross component of an array-valued external velocity averaged to the velocity points (what stress_x / stress_y
+// compute per call): vbar at u points from fv, ubar at v points from fu; same avg4, so the values are identical
+__global__ void __launch_bounds__(256) k_forcing_bars(FRef fu, FRef fv, FRef ubar_v, FRef vbar_u, int has_u, int has_v, Range r) {
+    const int i = r.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = r.j0 + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    if (i > r.i1 || j > r.j1) return;
+    if (has_v) vbar_u(i, j) = fm::avg4(fv(i - 1, j), fv(i, j), fv(i - 1, j + 1), fv(i, j + 1));
+    if (has_u) ubar_v(i, j) = fm::avg4(fu(i, j - 1), fu(i + 1, j - 1), fu(i, j), fu(i + 1, j));
+}
+
+void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s) {
+    const StressDev& b = P.bot;
+    if (b.kind != 3 || (b.ue_kind != 2 && b.ve_kind != 2)) return;
+    // every point whose four neighbours lie inside the parent arrays
+    const Range r{2 - P.g.Hx, P.g.Nx + P.g.Hx - 1, 2 - P.g.Hy, P.g.Ny + P.g.Hy - 1};
+    dim3 blk(64, 4), grd((unsigned)((r.i1 - r.i0 + 64) / 64), (unsigned)((r.j1 - r.j0 + 4) / 4));
+    hipLaunchKernelGGL(k_forcing_bars, grd, blk, 0, s, b.fu, b.fv, ubar_v, vbar_u, b.ue_kind == 2, b.ve_kind == 2, r);
+}
+
 bool fast_supported(const EvpDev& P) {
     // free-drift closed forms and field-valued forcing besides the bound stress slots are "next"
     (void)P;

@@ -285,6 +285,35 @@ bool fused_supported_forcing(const EvpDev& P) {
     return ok(P.top) && ok(P.bot);
 }
 
+static unsigned long parent_addr(const FRef& f, const GridDev& g) {
+    return (unsigned long)(f.p + (1 - g.Hx) + (long)(1 - g.Hy) * f.ld);
+}
+
+// Array-valued forcing the two-sub-steps-per-launch kernel takes (FORCE variant): top stress given as arrays
+// (kind 2) and / or a bottom SemiImplicitStress whose ocean velocities are arrays -- the coupled-model case.
+int pair_forcing_kind(const EvpDev& P) {
+    const int lc = P.h.ld, lf = P.u.ld;
+    if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return -1;
+    if (P.un.ld != lf || P.s12.ld != lf) return -1;
+    const StressDev &t = P.top, &b = P.bot;
+    const bool t_arr = t.kind == 2, b_arr = b.kind == 3 && (b.ue_kind == 2 || b.ve_kind == 2);
+    if (t.kind == 3 && (t.ue_kind == 2 || t.ve_kind == 2)) return -1;      // array-valued wind drag: three kernels
+    if (b.kind == 2) return -1;
+    if (t_arr && (t.fu.ld != lf || t.fv.ld != lc)) return -1;
+    if (b_arr && ((b.ue_kind == 2 && b.fu.ld != lf) || (b.ve_kind == 2 && b.fv.ld != lc))) return -1;
+    return (t_arr || b_arr) ? 1 : 0;
+}
+
+void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, FusedTable* t) {
+    const GridDev& g = P.g;
+    unsigned long* Q = t->P;
+    if (P.top.kind == 2) { Q[FP_FT_U] = parent_addr(P.top.fu, g); Q[FP_FT_V] = parent_addr(P.top.fv, g); }
+    t->I[FI_BOT_UEK] = P.bot.kind == 3 ? P.bot.ue_kind : 0;
+    t->I[FI_BOT_VEK] = P.bot.kind == 3 ? P.bot.ve_kind : 0;
+    if (P.bot.kind == 3 && P.bot.ue_kind == 2) { Q[FP_FB_U] = parent_addr(P.bot.fu, g); Q[FP_FB_UBAR] = parent_addr(ubar_v, g); }
+    if (P.bot.kind == 3 && P.bot.ve_kind == 2) { Q[FP_FB_V] = parent_addr(P.bot.fv, g); Q[FP_FB_VBAR] = parent_addr(vbar_u, g); }
+}
+
 bool fused_supported(const EvpDev& P) {
     // two row strides: Center-x fields and Face-x fields (dense Oceananigans parents always satisfy this)
     const int lc = P.h.ld, lf = P.u.ld;
@@ -301,9 +330,6 @@ bool fused_supported(const EvpDev& P) {
     return ok(P.top) && ok(P.bot);
 }
 
-static unsigned long parent_addr(const FRef& f, const GridDev& g) {
-    return (unsigned long)(f.p + (1 - g.Hx) + (long)(1 - g.Hy) * f.ld);
-}
 
 // Fill one table: `in` / `out` = the five double-buffered fields (u, v, s11, s22, s12) as (0,0)-offset references.
 void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const FRef* out,

@@ -35,6 +35,10 @@ constexpr int P_LO = 4, P_HI = 59, P_W = P_HI - P_LO + 1;
 __device__ unsigned long long g_probe[4096 * 16];
 #endif
 
+// what fm::ext_stress needs at a u point and at a v point, for the top (t_) and bottom (b_) stress: tau (constant /
+// array-valued stress), we (external velocity, own component), wb (cross component averaged to the point)
+struct Forcing { double t_tau_u, t_we_u, t_wb_u, b_tau_u, b_we_u, b_wb_u, t_tau_v, t_we_v, t_wb_v, b_tau_v, b_we_v, b_wb_v; };
+
 struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; };
 
 // One sub-step as a row pipeline.  step(r) consumes row r of P, m, a, sigma, rows r+1 of u, v and produces
@@ -63,7 +67,8 @@ struct Stage {
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
-                                         bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh) {
+                                         bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
+                                         const Forcing& F) {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
         Xv_p = fm::avg2(from_left(v_p), v_p);
         double e11_0, e22_0;
@@ -118,8 +123,8 @@ struct Stage {
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
+                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
                 W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -130,8 +135,8 @@ struct Stage {
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_m, ubar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_m, ubar, exb, imb);
+                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
                 const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
                 second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
@@ -145,8 +150,8 @@ struct Stage {
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_0, ubar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_0, ubar, exb, imb);
+                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
                 const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
                 W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -157,8 +162,8 @@ struct Stage {
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
+                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
+                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
                 second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
@@ -182,8 +187,8 @@ struct Stage {
     }
 };
 
-template <bool UNI, bool AUF, bool WALLS, bool MASK>
-__global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE>
+__global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                int blocks_per_xcd, int write_diag) {
     const int b = (int)blockIdx.x;
     const int blk = (b & 7) * blocks_per_xcd + (b >> 3);
@@ -427,7 +432,37 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
             const bool wi = lane_wv | wall_row(r);
             mhist = (mhist << 2) | (wi ? 3u : (C.mk ? 0u : 1u));
         }
-        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist);
+        // External stresses.  Numbers come from the table; FORCE: an array-valued top stress (tau at the u / v points)
+        // and / or a bottom SemiImplicitStress whose ocean velocities are arrays (own component at the point, cross
+        // component pre-averaged to the point once per sub-cycle: csi_abi.hip) are loaded here, one value per lane,
+        // for the rows the two stages update: u points of rows r-1 (A) and r-3 (B), v points of rows
+        // r-1 / r (A, u first / v first) and r-2 / r-3 (B, v first / u first).
+        Forcing FA, FB;
+        FA.t_tau_u = T->K[FK_TOP_TAU_U]; FA.t_we_u = T->K[FK_TOP_UE]; FA.t_wb_u = T->K[FK_TOP_VE];
+        FA.b_tau_u = T->K[FK_BOT_TAU_U]; FA.b_we_u = T->K[FK_BOT_UE]; FA.b_wb_u = T->K[FK_BOT_VE];
+        FA.t_tau_v = T->K[FK_TOP_TAU_V]; FA.t_we_v = T->K[FK_TOP_VE]; FA.t_wb_v = T->K[FK_TOP_UE];
+        FA.b_tau_v = T->K[FK_BOT_TAU_V]; FA.b_we_v = T->K[FK_BOT_VE]; FA.b_wb_v = T->K[FK_BOT_UE];
+        FB = FA;
+        if (FORCE) {
+            // (B's first rows of a tile only fill its window: clamp their row to the array instead of running off it)
+            const unsigned below = (unsigned)(r - (1 - HyW));                                     // rows between r and the array's first row
+            const unsigned k3 = min(3u, below), k2 = min(2u, below);
+            const unsigned ua = of_cur - sf, ub = of_cur - k3 * sf;                               // u points: rows r-1, r-3
+            const unsigned va = AUF ? oc_cur - sc : oc_cur, vb = AUF ? oc_cur - k2 * sc : oc_cur - k3 * sc;   // v points
+            if (T->I[FI_TOP_KIND] == 2) {
+                FA.t_tau_u = ldg(T->P[FP_FT_U], ua); FA.t_tau_v = ldg(T->P[FP_FT_V], va);
+                FB.t_tau_u = ldg(T->P[FP_FT_U], ub); FB.t_tau_v = ldg(T->P[FP_FT_V], vb);
+            }
+            if (T->I[FI_BOT_UEK] == 2) {       // u_e array: own component at u points, averaged to v points
+                FA.b_we_u = ldg(T->P[FP_FB_U], ua); FA.b_wb_v = ldg(T->P[FP_FB_UBAR], va);
+                FB.b_we_u = ldg(T->P[FP_FB_U], ub); FB.b_wb_v = ldg(T->P[FP_FB_UBAR], vb);
+            }
+            if (T->I[FI_BOT_VEK] == 2) {       // v_e array: own component at v points, averaged to u points
+                FA.b_we_v = ldg(T->P[FP_FB_V], va); FA.b_wb_u = ldg(T->P[FP_FB_VBAR], ua);
+                FB.b_we_v = ldg(T->P[FP_FB_V], vb); FB.b_wb_u = ldg(T->P[FP_FB_VBAR], ub);
+            }
+        }
+        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
 
         PROBE(acc3);
         // ---- stage B: sub-step s + 1, row q = r - 2, fed from A ---------------------------------------------------
@@ -447,7 +482,7 @@ __global__ void __launch_bounds__(256) k_pair(const FusedTable* __restrict__ tab
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3,
-               q >= ja - 1, q >= ja, pb1, pb2, mhist >> 4);
+               q >= ja - 1, q >= ja, pb1, pb2, mhist >> 4, FB);
         pend_second = B.second;
         PROBE(acc4);
 
@@ -519,23 +554,26 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 }
 #endif
 
-// One translation unit per variant (CSI_PAIR_VARIANT: 0 plain, 1 walls, 2 walls + immersed mask) so that the twelve
-// instantiations compile in parallel.
+// One translation unit per variant so that the instantiations compile in parallel.  CSI_PAIR_VARIANT:
+// 0 plain, 1 walls, 2 walls + immersed mask, 3 walls + array-valued forcing, 4 walls + mask + array-valued forcing.
 #ifndef CSI_PAIR_VARIANT
 #define CSI_PAIR_VARIANT 0
 #endif
 #if CSI_PAIR_VARIANT == 0
 #define CSI_PAIR_NAME launch_fused_pair_plain
-#define CSI_PAIR_WALLS false
-#define CSI_PAIR_MASK false
+#define CSI_PAIR_FLAGS false, false, false
 #elif CSI_PAIR_VARIANT == 1
 #define CSI_PAIR_NAME launch_fused_pair_walls
-#define CSI_PAIR_WALLS true
-#define CSI_PAIR_MASK false
-#else
+#define CSI_PAIR_FLAGS true, false, false
+#elif CSI_PAIR_VARIANT == 2
 #define CSI_PAIR_NAME launch_fused_pair_mask
-#define CSI_PAIR_WALLS true
-#define CSI_PAIR_MASK true
+#define CSI_PAIR_FLAGS true, true, false
+#elif CSI_PAIR_VARIANT == 3
+#define CSI_PAIR_NAME launch_fused_pair_force
+#define CSI_PAIR_FLAGS true, false, true
+#else
+#define CSI_PAIR_NAME launch_fused_pair_mask_force
+#define CSI_PAIR_FLAGS true, true, true
 #endif
 void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
                    int write_diag, hipStream_t s) {
@@ -543,7 +581,7 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, int
     const int nblocks = (nw + 3) / 4;
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
-#define CSI_LAUNCH_PAIR(U, A) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_WALLS, CSI_PAIR_MASK>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
+#define CSI_LAUNCH_PAIR(U, A) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
     if (uniform) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
     else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true); else CSI_LAUNCH_PAIR(false, false); }
 #undef CSI_LAUNCH_PAIR
@@ -552,9 +590,13 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, int
 #if CSI_PAIR_VARIANT == 0
 void launch_fused_pair_walls(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
 void launch_fused_pair_mask(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, int nstrips, int nchunks, int rows,
-                       int write_diag, hipStream_t s) {
-    if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+void launch_fused_pair_force(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, int nstrips,
+                       int nchunks, int rows, int write_diag, hipStream_t s) {
+    if (force && mask) launch_fused_pair_mask_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+    else if (force) launch_fused_pair_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+    else if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
     else if (walls) launch_fused_pair_walls(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
     else launch_fused_pair_plain(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
 }

@@ -244,7 +244,8 @@ int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nf
  * library scratch) whenever the configuration allows it (no immersed mask, forcing given by numbers;
  * csrc/evp_fused.hip).  level 2 (default): in addition
  * TWO consecutive sub-steps share one launch (csrc/evp_fused2.hip: the first sub-step's results stay in
- * registers; immersed masks supported) where the halo is >= 4 (and N >= 2 halo) and, on tiles, the exchange
+ * registers; immersed masks, array-valued top stress and array-valued ocean velocities in the bottom drag
+ * supported) where the halo is >= 4 (and N >= 2 halo) and, on tiles, the exchange
  * interval is even; an odd trailing sub-step uses the level-1 kernel (the three kernels when masked).  All paths execute the same
  * floating-point operations and give bit-identical results. */
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);

@@ -15,6 +15,8 @@ CONFIGS = {
     "lat-lon bounded (per-row metrics)": dict(topo=("bounded", "bounded"), grid="latlon"),
     "lat-lon channel": dict(topo=("periodic", "bounded"), grid="latlon"),
     "masked channel (30 % land, config 5 style)": dict(topo=("periodic", "bounded"), land=0.3),
+    "coupled channel (wind-stress arrays, ocean-velocity arrays, 30 % land)": dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True),
+    "coupled periodic (arrays, no land)": dict(topo=("periodic", "periodic"), field_forcing=True),
 }
 if len(sys.argv) > 2:
     CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}

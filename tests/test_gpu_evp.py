@@ -51,8 +51,12 @@ CASES = {
     "masked_periodic": dict(Nx=130, Ny=84, topo=("periodic", "periodic"), patches=True, random_uv=0.05, land=0.3),
     "masked_channel": dict(Nx=96, Ny=120, topo=("periodic", "bounded"), patches=True, random_uv=0.05, land=0.3),
     "masked_latlon": dict(Nx=72, Ny=64, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, land=0.25),
+    # array-valued forcing (the coupled-model case: wind stress arrays on top, ocean velocity arrays in the bottom drag)
+    "forced_seams": dict(Nx=150, Ny=70, topo=("periodic", "periodic"), patches=True, field_forcing=True, random_uv=0.03),
+    "coupled_channel": dict(Nx=100, Ny=90, topo=("periodic", "bounded"), patches=True, field_forcing=True, random_uv=0.03, land=0.3),
+    "coupled_latlon": dict(Nx=64, Ny=72, topo=("bounded", "bounded"), grid="latlon", patches=True, field_forcing=True, random_uv=0.03, land=0.2),
 }
-MASKED = {"masked_periodic", "masked_channel", "masked_latlon"}
+MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon"}
 
 
 def ulp_diff(a, b):
@@ -269,8 +273,14 @@ def test_rccl_self_exchange_bitwise(mode, fc, k):
     til.set_exchange_interval(k)        # k sub-steps per exchange of width 2k (0: automatic = 2 with halo 4)
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
-    assert til.ctx.last_path()["fused"] == fused
-    assert til.ctx.launches_per_substep() == (1 if fused else (3 if mode == "fast" else 4)) + (3 if k == 1 else 0)
+    # numeric forcing: fused kernels (pairs inside an even exchange batch); array-valued forcing: only the
+    # two-sub-steps-per-launch kernel takes it, so k = 1 runs the three kernels
+    level = til.ctx.last_path()["level"]
+    if mode == "strict":
+        assert level == 0
+    else:
+        assert level == ((2 if k != 1 else 1) if fused else (2 if k != 1 else 0))
+    assert til.ctx.launches_per_substep() == (1 if level else (3 if mode == "fast" else 4)) + (3 if k == 1 else 0)
     for k in ("u", "v", "s11", "s22", "s12", "alpha"):
         a, b = EVP_FIELDS[k](ref).interior_numpy(), EVP_FIELDS[k](til).interior_numpy()
         assert np.array_equal(a, b), (k, np.abs(a - b).max())
@@ -371,7 +381,7 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
         out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22") + (() if walls else ("s12",))}
         out[fusion].update({k: (EVP_FIELDS[k](m).numpy().copy(), EVP_FIELDS[k](m).interior_numpy().copy())
                             for k in ("alpha", "zeta_c", "zeta_f", "Delta") + (("s12",) if walls else ())})
-    single = 0 if name in MASKED else 1           # the one-sub-step kernel takes no immersed mask
+    single = 0 if name in MASKED else 1           # the one-sub-step kernel takes neither masks nor array-valued forcing
     assert level[0] == 0 and level[1] == single
     assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else single), level
     if level[2] == 2:
