@@ -437,12 +437,15 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         // component pre-averaged to the point once per sub-cycle: csi_abi.hip) are loaded here, one value per lane,
         // for the rows the two stages update: u points of rows r-1 (A) and r-3 (B), v points of rows
         // r-1 / r (A, u first / v first) and r-2 / r-3 (B, v first / u first).
+        auto numbers = [&](Forcing& F) __attribute__((always_inline)) {
+            F.t_tau_u = T->K[FK_TOP_TAU_U]; F.t_we_u = T->K[FK_TOP_UE]; F.t_wb_u = T->K[FK_TOP_VE];
+            F.b_tau_u = T->K[FK_BOT_TAU_U]; F.b_we_u = T->K[FK_BOT_UE]; F.b_wb_u = T->K[FK_BOT_VE];
+            F.t_tau_v = T->K[FK_TOP_TAU_V]; F.t_we_v = T->K[FK_TOP_VE]; F.t_wb_v = T->K[FK_TOP_UE];
+            F.b_tau_v = T->K[FK_BOT_TAU_V]; F.b_we_v = T->K[FK_BOT_VE]; F.b_wb_v = T->K[FK_BOT_UE];
+        };
         Forcing FA, FB;
-        FA.t_tau_u = T->K[FK_TOP_TAU_U]; FA.t_we_u = T->K[FK_TOP_UE]; FA.t_wb_u = T->K[FK_TOP_VE];
-        FA.b_tau_u = T->K[FK_BOT_TAU_U]; FA.b_we_u = T->K[FK_BOT_UE]; FA.b_wb_u = T->K[FK_BOT_VE];
-        FA.t_tau_v = T->K[FK_TOP_TAU_V]; FA.t_we_v = T->K[FK_TOP_VE]; FA.t_wb_v = T->K[FK_TOP_UE];
-        FA.b_tau_v = T->K[FK_BOT_TAU_V]; FA.b_we_v = T->K[FK_BOT_VE]; FA.b_wb_v = T->K[FK_BOT_UE];
-        FB = FA;
+        numbers(FA);
+        double fb[6] = {0, 0, 0, 0, 0, 0};          // FORCE: B's array values, loaded early, merged after stage A
         if (FORCE) {
             // (B's first rows of a tile only fill its window: clamp their row to the array instead of running off it)
             const unsigned below = (unsigned)(r - (1 - HyW));                                     // rows between r and the array's first row
@@ -451,15 +454,15 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             const unsigned va = AUF ? oc_cur - sc : oc_cur, vb = AUF ? oc_cur - k2 * sc : oc_cur - k3 * sc;   // v points
             if (T->I[FI_TOP_KIND] == 2) {
                 FA.t_tau_u = ldg(T->P[FP_FT_U], ua); FA.t_tau_v = ldg(T->P[FP_FT_V], va);
-                FB.t_tau_u = ldg(T->P[FP_FT_U], ub); FB.t_tau_v = ldg(T->P[FP_FT_V], vb);
+                fb[0] = ldg(T->P[FP_FT_U], ub); fb[1] = ldg(T->P[FP_FT_V], vb);
             }
             if (T->I[FI_BOT_UEK] == 2) {       // u_e array: own component at u points, averaged to v points
                 FA.b_we_u = ldg(T->P[FP_FB_U], ua); FA.b_wb_v = ldg(T->P[FP_FB_UBAR], va);
-                FB.b_we_u = ldg(T->P[FP_FB_U], ub); FB.b_wb_v = ldg(T->P[FP_FB_UBAR], vb);
+                fb[2] = ldg(T->P[FP_FB_U], ub); fb[3] = ldg(T->P[FP_FB_UBAR], vb);
             }
             if (T->I[FI_BOT_VEK] == 2) {       // v_e array: own component at v points, averaged to u points
                 FA.b_we_v = ldg(T->P[FP_FB_V], va); FA.b_wb_u = ldg(T->P[FP_FB_VBAR], ua);
-                FB.b_we_v = ldg(T->P[FP_FB_V], vb); FB.b_wb_u = ldg(T->P[FP_FB_VBAR], ub);
+                fb[4] = ldg(T->P[FP_FB_V], vb); fb[5] = ldg(T->P[FP_FB_VBAR], ub);
             }
         }
         A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
@@ -479,6 +482,13 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             if (yhi_wall & (q == NyW)) bu_p = B.u_0;
         }
         const double bm_0 = A.m_mm, ba_0 = A.a_mm;             // row r-2
+        asm volatile("" : "+s"(T));      // re-read the forcing numbers for stage B instead of holding 24 SGPRs across stage A
+        numbers(FB);
+        if (FORCE) {
+            if (T->I[FI_TOP_KIND] == 2) { FB.t_tau_u = fb[0]; FB.t_tau_v = fb[1]; }
+            if (T->I[FI_BOT_UEK] == 2) { FB.b_we_u = fb[2]; FB.b_wb_v = fb[3]; }
+            if (T->I[FI_BOT_VEK] == 2) { FB.b_we_v = fb[4]; FB.b_wb_u = fb[5]; }
+        }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3,
