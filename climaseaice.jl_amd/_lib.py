@@ -30,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
-           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches"]
+           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair"]
 
 
 class Metrics(C.Structure):
@@ -106,6 +106,7 @@ def load():
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],
         "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
         "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
+        "csi_plan_pair": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_set_exchange_interval": [vp, i32],
         "csi_set_fusion": [vp, i32],
         "csi_plan_exchange": [i32] * 14 + [C.POINTER(i32)],
@@ -130,6 +131,20 @@ def plan_ranges(Nx, Ny, Hx, Hy, topo_x, topo_y, valid_width=2):
         raise CsiError(rc, "csi_plan_ranges")
     v = list(out)
     return tuple(tuple(v[4 * k:4 * k + 4]) for k in range(4))
+
+
+def plan_pair(Nx, Ny, Hx, Hy, topo_x, topo_y, k=1, m=0):
+    """csi_plan_pair as a dict (None when the two-sub-steps-per-launch kernel does not apply)."""
+    L = load()
+    out = (C.c_int32 * 32)()
+    rc = L.csi_plan_pair(Nx, Ny, Hx, Hy, topo_x, topo_y, k, m, out)
+    if rc != OK:
+        raise CsiError(rc, "csi_plan_pair")
+    if not out[0]:
+        return None
+    r = lambda q: tuple(out[4 + 4 * q: 8 + 4 * q])
+    return dict(nstrips=out[1], nchunks=out[2], rows=out[3], first_compute=r(0), second_compute=r(1), store_sigma=r(2),
+                store_first_u=r(3), store_first_v=r(4), store_second=r(5), walls=bool(out[28]))
 
 
 def plan_exchange(Nx, Ny, Hx, Hy, topo_x, topo_y, rx, ry, Rx, Ry, periodic_x, periodic_y, width, halo):

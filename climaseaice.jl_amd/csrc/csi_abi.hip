@@ -1125,6 +1125,28 @@ int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t 
     return CSI_OK;
 }
 
+int32_t csi_plan_pair(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t k, int32_t m,
+                      int32_t* out32) {
+    if (!out32 || Nx < 1 || Ny < 1 || k < 1 || m < 0 || m + 1 >= 2 * ((k + 1) / 2) + (k == 1 ? 1 : 0)) return CSI_ERR_INVALID_ARGUMENT;
+    csi_context tmp;
+    tmp.Nx = Nx; tmp.Ny = Ny; tmp.Hx = Hx; tmp.Hy = Hy;
+    tmp.g.xlo = side_lo(topo_x); tmp.g.xhi = side_hi(topo_x); tmp.g.ylo = side_lo(topo_y); tmp.g.yhi = side_hi(topo_y);
+    const bool tiled = is_tiled(&tmp);
+    memset(out32, 0, 32 * sizeof(int32_t));
+    out32[0] = (pair_supported(&tmp) && (!tiled || k % 2 == 0)) ? 1 : 0;
+    if (!out32[0]) return CSI_OK;
+    const int W = 2 * k;
+    const SideV va = pair_side_v(&tmp, W - 2 * m, 4), vb = pair_side_v(&tmp, W - 2 * m - 2, 2);
+    const Range ra = v_stress_range(&tmp, va), dec = v_stress_range(&tmp, vb);
+    const FusedGeom G = pair_geom(&tmp, dec);
+    out32[1] = G.nstrips; out32[2] = G.nchunks; out32[3] = G.rows;
+    const Range r[6] = {ra, dec, clip_store(&tmp, dec, true), clip_store(&tmp, v_first_range(&tmp, vb, true), false),
+                        clip_store(&tmp, v_first_range(&tmp, vb, false), false), clip_store(&tmp, v_second_range(&tmp, vb), false)};
+    for (int q = 0; q < 6; ++q) { out32[4 + 4 * q] = r[q].i0; out32[5 + 4 * q] = r[q].i1; out32[6 + 4 * q] = r[q].j0; out32[7 + 4 * q] = r[q].j1; }
+    out32[28] = has_walls(&tmp) ? 1 : 0;
+    return CSI_OK;
+}
+
 int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double* out_ms4) {
     if (!c || !out_ms4) return CSI_ERR_INVALID_ARGUMENT;
     int32_t rc = need_evp(c);

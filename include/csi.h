@@ -278,6 +278,17 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
 /* Device time (ms) of the last csi_evp_subcycle / csi_time_step_momentum call measured with HIP
  * events on the context's stream; valid after csi_sync. */
 int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
+/* How the launch loop would run one PAIR of sub-steps (csi_set_fusion level 2) at position m (even) of an exchange
+ * batch of k sub-steps on a grid of this shape: out32[0] = 1 if the pair kernel applies (0: the rest is zero),
+ * [1..3] wave-tile geometry (56-column strips, row chunks, rows per chunk), then six index ranges (i0, i1, j0, j1):
+ * [4..7] rows / columns the first sub-step computes, [8..11] the second sub-step's compute range (what the wave tiles
+ * decompose), [12..15] cells whose stresses are stored, [16..19] / [20..23] first velocity stored when the second
+ * sub-step is u-first / v-first, [24..27] second velocity stored; [28] = 1 if a side is a wall.  Periodic and wall
+ * sides store the interior (the wall corners of sigma12 included) and refresh halos as images of those stores;
+ * connected sides store the ring the next pair needs.  Pure host function. */
+int32_t csi_plan_pair(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t k, int32_t m,
+                      int32_t* out32);
+
 /* Per-phase device time: runs `substeps` (2..64) further EVP sub-steps from the current state with HIP
  * events between the launches on the context's stream and returns the average milliseconds of
  * [0] the stress phase (or, when the fused path is active, one LAUNCH of the fused kernel -- one or two

@@ -39,3 +39,36 @@ def test_rheology_and_solver_defaults_match_reference():
     d = csi.SeaIceMomentumEquation(g, device="cpu")
     assert d.solver.substeps == 150 and d.minimum_mass == 1.0 and d.minimum_concentration == 1e-3
     assert float(d.auxiliaries.fields.alpha.data.min()) == 300.0   # fill!(alpha, alpha+)
+
+
+def test_pair_plan_geometry_and_ranges():
+    """csi_plan_pair: how the two-sub-steps-per-launch kernel tiles a grid and which cells it stores (pure host logic,
+    csrc/csi_abi.hip).  Properties: one round of at most 2048 wave tiles that covers the second sub-step's compute range;
+    the first sub-step computes 2 more layers on every side and stays inside the parent arrays; periodic / wall sides store
+    the interior only (sigma also the wall corners), connected sides the ring of the next pair."""
+    from climaseaice_jl_amd import _lib
+    P, B, FC = _lib.PERIODIC, _lib.BOUNDED, _lib.FULLY_CONNECTED
+    for (Nx, Ny, H, tx, ty, k, m) in [(2048, 2048, 4, P, P, 1, 0), (2048, 2048, 4, P, B, 1, 0), (2048, 2048, 4, B, B, 1, 0),
+                                      (4096, 4096, 4, P, P, 1, 0), (1024, 512, 6, P, B, 1, 0), (2048, 2048, 16, FC, FC, 8, 0),
+                                      (2048, 2048, 16, FC, FC, 8, 6), (2048, 2048, 8, FC, P, 4, 2), (300, 200, 4, B, P, 1, 0)]:
+        p = _lib.plan_pair(Nx, Ny, H, H, tx, ty, k, m)
+        assert p is not None
+        i0, i1, j0, j1 = p["second_compute"]
+        assert p["nstrips"] == -(-(i1 - i0 + 1) // 56) and p["nchunks"] == -(-(j1 - j0 + 1) // p["rows"])
+        assert p["nstrips"] * p["nchunks"] <= 2048 or p["rows"] == 16          # one round (small grids: fewer, not shorter, tiles)
+        a = p["first_compute"]
+        assert a == (i0 - 2, i1 + 2, j0 - 2, j1 + 2)
+        assert a[0] - 1 >= 1 - H and a[1] + 1 <= Nx + H and a[2] - 1 >= 1 - H and a[3] + 1 <= Ny + H   # loads stay in the parent
+        V = 2 * k - 2 * m - 2                                               # valid layers the second sub-step starts from
+        for axis, topo, N in ((0, tx, Nx), (1, ty, Ny)):
+            lo, hi = p["store_second"][2 * axis], p["store_second"][2 * axis + 1]
+            slo, shi = p["store_sigma"][2 * axis], p["store_sigma"][2 * axis + 1]
+            if topo == FC:
+                assert (lo, hi) == (3 - V, N + V - 2) and (slo, shi) == (2 - V, N + V - 1)
+            else:
+                assert (lo, hi) == (1, N) and (slo, shi) == (1, N + (1 if topo == B else 0))
+        assert p["walls"] == (B in (tx, ty))
+    # not applicable: halo < 4, domain smaller than two halos, odd exchange interval on tiles
+    assert _lib.plan_pair(64, 64, 3, 3, P, P) is None
+    assert _lib.plan_pair(7, 64, 4, 4, P, P) is None
+    assert _lib.plan_pair(256, 256, 8, 8, FC, FC, 3, 0) is None
