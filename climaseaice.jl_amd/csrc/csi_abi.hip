@@ -182,7 +182,8 @@ EvpDev evp_dev(const csi_context* c, double dt) {
     P.P_star = e.ice_compressive_strength; P.C_star = e.ice_compaction_hardening; P.ecc = e.yield_curve_eccentricity;
     P.Dmin = e.minimum_plastic_stress; P.amin = e.min_relaxation_parameter; P.amax = e.max_relaxation_parameter;
     P.ca = e.relaxation_strength; P.min_mass = e.minimum_mass; P.min_conc = e.minimum_concentration;
-    P.rho = e.sea_ice_density; P.fcor = e.coriolis_f; P.has_cor = e.has_coriolis; P.pressure_kind = e.pressure_formulation;
+    P.rho = e.sea_ice_density; P.fcor = e.has_coriolis ? e.coriolis_f : 0.0; P.has_cor = e.has_coriolis;   // FAST kernels multiply by fcor unconditionally
+    P.pressure_kind = e.pressure_formulation;
     P.dt = dt;
     P.write_diag = 0;
     return P;

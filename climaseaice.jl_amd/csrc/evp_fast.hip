@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img,
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
-    const double cor = P.has_cor ? P.fcor * vbar : 0.0;           // -x_f_cross_U = +f vbar
+    const double cor = P.fcor * vbar;                         // -x_f_cross_U = +f vbar
     const double res = fm::vel_update(vel_const(P, c), u, un, hm * P.rho * am, h0 * P.rho * a0, am, a0, alm, al0, div, cor,
                                       ext, imt, exb, imb, peripheral_u(P.g, i, j));
     store_with_images(P.u, P.g, img, i, j, res);
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
-    const double cor = P.has_cor ? -P.fcor * ubar : 0.0;          // -y_f_cross_U = -f ubar
+    const double cor = -P.fcor * ubar;                       // -y_f_cross_U = -f ubar
     const double res = fm::vel_update(vel_const(P, c), v, vn, hm * P.rho * am, h0 * P.rho * a0, am, a0, alm, al0, div, cor,
                                       ext, imt, exb, imb, peripheral_v(P.g, i, j));
     store_with_images(P.v, P.g, img, i, j, res);

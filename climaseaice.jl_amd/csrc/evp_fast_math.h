@@ -145,14 +145,14 @@ struct VelConst {
 //   own-component external velocity `we` and cross-component average `webar`
 __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, double we, double webar, double w, double wbar,
                                            double& ex, double& im) {
-    ex = 0.0; im = 0.0;
-    if (kind == 1 || kind == 2) ex = tau;
-    else if (kind == 3) {
+    if (kind == 3) {
         const double d1 = we - w, d2 = webar - wbar;
         const double n2 = fma_(d1, d1, d2 * d2);
         const double n = sqrt_pos(n2);
         im = rhoCd * ((n2 > 0) ? n : 0.0);
         ex = im * we;
+    } else {            // kind 1 / 2: tau; kind 0 (no stress): the caller passes tau = 0
+        ex = tau; im = 0.0;
     }
 }
 
@@ -164,14 +164,14 @@ __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, d
 //   peripheral : the face touches an inactive cell
 __device__ __forceinline__ double vel_update_avg(const VelConst& k, double w, double wn, double mi, double ai, double abar,
                                                  double div, double cor, double ext, double imt, double exb, double imb, bool peripheral) {
-    const double dtau = k.dt * rcp(abar);
     const double rm = rcp(mi);
     const double rai = rm * ai;
     double G = fma_(wn - w, k.rdt, fma_(div, rm, fma_(exb - ext, rai, cor)));
     double tau_i = (imb - imt) * rai;
     G = (mi <= 0) ? 0.0 : G;
     tau_i = (mi <= 0) ? 0.0 : tau_i;
-    const double wD = fma_(dtau, G, w) * rcp(fma_(dtau, tau_i, 1.0));
+    // (w + dtau G) / (1 + dtau tau_i) with dtau = dt / abar, as one quotient: (abar w + dt G) / (abar + dt tau_i)
+    const double wD = fma_(k.dt, G, abar * w) * rcp(fma_(k.dt, tau_i, abar));
     const bool active_ice = (mi >= k.min_mass) & (ai >= k.min_conc);
     double res = active_ice ? wD : 0.0;     // free drift `nothing`: marginal ice -> 0 as well
     return peripheral ? 0.0 : res;

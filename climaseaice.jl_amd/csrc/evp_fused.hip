@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
-                const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
+                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
                 const double unew = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor,
                                                        ext, imt, exb, imb, ((flags & L_WALL_U) != 0) | wall_row);
                 W_0 = (flags & L_R1C) ? unew : u_m;
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_m, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_m, ubar, exb, imb);
-                const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
+                const double cor = -kv.fcor * ubar;
                 const double vnew = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor,
                                                    ext, imt, exb, imb, ((flags & L_WALL_V) != 0) | wall_vrow);
                 if (flags & L_R2) store_vel(T, FP_V_OUT, FI_LD_C, FI_IMV, near_edge, i, j, vnew);
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_0, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_0, ubar, exb, imb);
-                const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
+                const double cor = -kv.fcor * ubar;
                 const double vnew = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor,
                                                    ext, imt, exb, imb, ((flags & L_WALL_V) != 0) | wall_vrow);
                 W_0 = (flags & L_R1C) ? vnew : v_0;
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
-                const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
+                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
                 const double unew = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor,
                                                        ext, imt, exb, imb, ((flags & L_WALL_U) != 0) | wall_row);
                 if (flags & L_R2) store_vel(T, FP_U_OUT, FI_LD_F, FI_IMU, near_edge, i, j, unew);
@@ -343,9 +343,10 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     K[FK_AMIN] = P.amin; K[FK_AMAX] = P.amax; K[FK_AMIN2] = c.amin2; K[FK_AMAX2] = c.amax2; K[FK_RAMIN] = c.ramin; K[FK_RAMAX] = c.ramax;
     K[FK_DT] = P.dt; K[FK_RDT] = c.rdt; K[FK_FCOR] = P.fcor; K[FK_MIN_MASS] = P.min_mass; K[FK_MIN_CONC] = P.min_conc;
     K[FK_RHO] = P.rho; K[FK_CA_DT] = c.ca_dt;
-    K[FK_TOP_TAU_U] = P.top.tau_u; K[FK_TOP_TAU_V] = P.top.tau_v; K[FK_TOP_RHOCD] = P.top.rho_e * P.top.Cd;
+    // (ext_stress treats every kind but 3 as an explicit stress: no stress = 0)
+    K[FK_TOP_TAU_U] = P.top.kind == 1 ? P.top.tau_u : 0.0; K[FK_TOP_TAU_V] = P.top.kind == 1 ? P.top.tau_v : 0.0; K[FK_TOP_RHOCD] = P.top.rho_e * P.top.Cd;
     K[FK_TOP_UE] = eff(P.top.ue_kind, P.top.ue); K[FK_TOP_VE] = eff(P.top.ve_kind, P.top.ve);
-    K[FK_BOT_TAU_U] = P.bot.tau_u; K[FK_BOT_TAU_V] = P.bot.tau_v; K[FK_BOT_RHOCD] = P.bot.rho_e * P.bot.Cd;
+    K[FK_BOT_TAU_U] = P.bot.kind == 1 ? P.bot.tau_u : 0.0; K[FK_BOT_TAU_V] = P.bot.kind == 1 ? P.bot.tau_v : 0.0; K[FK_BOT_RHOCD] = P.bot.rho_e * P.bot.Cd;
     K[FK_BOT_UE] = eff(P.bot.ue_kind, P.bot.ue); K[FK_BOT_VE] = eff(P.bot.ve_kind, P.bot.ve);
     for (int k = 0; k < FC_COUNT; ++k) K[FK_COEF0 + k] = c.uni[k];
     unsigned long* Q = t->P;

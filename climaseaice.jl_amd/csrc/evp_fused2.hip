@@ -125,7 +125,7 @@ struct Stage {
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
-                const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
+                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
                 W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::avg2(W_0, from_right(W_0));
@@ -137,7 +137,7 @@ struct Stage {
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
-                const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
+                const double cor = -kv.fcor * ubar;
                 second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
@@ -152,7 +152,7 @@ struct Stage {
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
-                const double cor = kv.has_cor ? -kv.fcor * ubar : 0.0;
+                const double cor = -kv.fcor * ubar;
                 W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::avg2(from_left(W_0), W_0);
@@ -164,7 +164,7 @@ struct Stage {
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
-                const double cor = kv.has_cor ? kv.fcor * vbar : 0.0;
+                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
                 second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
