@@ -340,8 +340,29 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             }
         }
     };
+    // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
+    // store path (two scalar compares per row instead of the full bookkeeping)
+    int fast_lo, fast_hi;
+    {
+        const int d1 = AUF ? 0 : 1;                                            // first velocity row = q - d1, second = q - 1
+        fast_lo = max(rs_lo, max(r1_lo + d1, r2_lo + 1));
+        fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
+        if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
+        if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
+        if (!lanes_uniform) fast_hi = fast_lo - 1;
+    }
     auto flush = [&](int rr, unsigned oc_rr, unsigned of_rr) __attribute__((always_inline)) {
         const int q = rr - 2;
+        if ((q >= fast_lo) & (q <= fast_hi)) {
+            // interior tile, interior rows (nearly every call): the owned lanes store five values, no images
+            if (flags & L_RS) {
+                const unsigned ocq = oc_rr - 2u * sc, ofq = of_rr - 2u * sf;
+                stg(T->P[FP_S11_OUT], ocq, B.S11_m); stg(T->P[FP_S22_OUT], ocq, B.S22_m); stg(T->P[FP_S12_OUT], ofq, B.S12_m);
+                stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, B.Wprev);
+                stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, pend_second);
+            }
+            return;
+        }
         const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
         const bool do_s = (q >= rs_lo) & (q <= rs_hi), do_1 = (j1 >= r1_lo) & (j1 <= r1_hi), do_2 = (j2 >= r2_lo) & (j2 <= r2_hi);
         if (!(do_s | do_1 | do_2)) return;
@@ -352,14 +373,6 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         P.s11 = T->P[FP_S11_OUT]; P.s22 = T->P[FP_S22_OUT]; P.s12 = T->P[FP_S12_OUT]; P.u = T->P[FP_U_OUTP]; P.v = T->P[FP_V_OUTP];
         // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
         const int yq = yimg(q), y1 = AUF ? yimg(j1) : yimg_u(j1), y2 = AUF ? yimg_u(j2) : yimg(j2);
-        if (lanes_uniform & do_s & do_1 & do_2 & ((yq | y1 | y2) == 0)) {
-            // interior tile, interior rows (nearly every call): the owned lanes store five values, no images
-            if (flags & L_RS) {
-                stg(P.s11, ocq, B.S11_m); stg(P.s22, ocq, B.S22_m); stg(P.s12, ofq, B.S12_m);
-                stg(AUF ? P.v : P.u, o1, B.Wprev); stg(AUF ? P.u : P.v, o2, pend_second);
-            }
-            return;
-        }
         if (do_s & ((flags & L_RS) != 0)) {
             put(P.s11, ocq, (unsigned)yq * sc, dx, B.S11_m);
             put(P.s22, ocq, (unsigned)yq * sc, dx, B.S22_m);
@@ -392,7 +405,9 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     RowIn C, N;
     auto body = [&]() __attribute__((always_inline)) {
         asm volatile("" : "+s"(T));
+#ifdef CSI_PAIR_PRIO_PER_ROW
         if ((r + prio_phase) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef CSI_PAIR_PROBE
         { __builtin_amdgcn_sched_barrier(0); tprev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #endif
@@ -524,7 +539,10 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
 #ifndef CSI_PAIR_UNROLL
 #define CSI_PAIR_UNROLL 3
 #endif
-    for (;;) {
+    for (int trip = prio_phase;; ++trip) {
+#ifndef CSI_PAIR_PRIO_PER_ROW
+        if (trip & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);     // trade once per trip (3 rows)
+#endif
         body();
         if (++r > rend) break;
 #if CSI_PAIR_UNROLL >= 2
