@@ -63,18 +63,55 @@ __device__ __forceinline__ double weno7(const double* p) {
     return (a0 * q0 + a1 * q1 + a2 * q2 + a3 * q3) / s;
 }
 
+__device__ __forceinline__ double weno3(const double* p) {
+    double q0 = (p[1] + p[2]) / 2;
+    double q1 = (-p[0] + 3 * p[1]) / 2;
+    double b0 = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
+    double b1 = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
+    double tau = fabs(b0 - b1);
+    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS);
+    double a0 = (2.0 / 3) * (1 + r0 * r0);
+    double a1 = (1.0 / 3) * (1 + r1 * r1);
+    double s = a0 + a1;
+    return (a0 * q0 + a1 * q1) / s;
+}
+__device__ __forceinline__ double upwind3(const double* p) { return (-p[0] + 5 * p[1] + 2 * p[2]) / 6; }
+
+// Boundary-order reduction next to walls (upstream topologically_conditional_interpolation, recalled -- SURVEY.md
+// App. B; same rule as oracle/csi_oracle.c::reduced_buffer): the scheme with buffer B (order 2B-1) is used at face
+// idx only if its biased stencil stays inside the domain, else the buffer scheme of order 2B-3, down to upwind 1.
+__device__ __forceinline__ int reduced_buffer(int B, int idx, int N, bool left, bool wall_lo, bool wall_hi) {
+    while (B > 1) {
+        const bool lo_ok = !wall_lo || idx >= (left ? B + 1 : B);
+        const bool hi_ok = !wall_hi || idx <= (left ? N + 2 - B : N + 1 - B);
+        if (lo_ok && hi_ok) break;
+        --B;
+    }
+    return B;
+}
+
 // reconstruct at a face from the line of values through `base` (cell on the high side of the
 // face); st = element stride of the line; left bias (vel > 0): upwind cell is base - st.
+// idx / N / walls: position of the face along the line for the boundary-order reduction.
 template <int SCHEME>
-__device__ __forceinline__ double reconstruct(const double* base, long st, bool left) {
+__device__ __forceinline__ double reconstruct(const double* base, long st, bool left, int idx, int N, bool wall_lo, bool wall_hi) {
     const double* up = left ? base - st : base;
     const long s = left ? st : -st;
     if (SCHEME == 1) return up[0];
-    if (SCHEME == 5 || SCHEME == -5) {
+    constexpr bool WENO = SCHEME > 0;
+    const int B = (wall_lo | wall_hi) ? reduced_buffer(SCHEME == 7 ? 4 : 3, idx, N, left, wall_lo, wall_hi) : (SCHEME == 7 ? 4 : 3);
+    if (B == 1) return up[0];
+    if (B == 2) {
+        double p[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = up[(k - 1) * s];
+        return WENO ? weno3(p) : upwind3(p);
+    }
+    if (B == 3 || SCHEME != 7) {
         double p[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) p[k] = up[(k - 2) * s];
-        return SCHEME == 5 ? weno5(p) : upwind5(p);
+        return WENO ? weno5(p) : upwind5(p);
     }
     double p[7];
 #pragma unroll
@@ -101,16 +138,18 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
         if (ty < TY && j <= g.Ny) {
             const double uu = A.u(i, j);
             const bool left = uu > 0;
-            const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left);
-            const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left);
+            const bool wl = g.xlo == SIDE_WALL, wh = g.xhi == SIDE_WALL;
+            const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left, i, g.Nx, wl, wh);
+            const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left, i, g.Nx, wl, wh);
             sFxh[ty][tx] = g.dy * uu * ch;
             sFxa[ty][tx] = g.dy * uu * ca;
         }
         if (tx < TX && i <= g.Nx) {
             const double vv = A.v(i, j);
             const bool left = vv > 0;
-            const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left);
-            const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left);
+            const bool wl = g.ylo == SIDE_WALL, wh = g.yhi == SIDE_WALL;
+            const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left, j, g.Ny, wl, wh);
+            const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left, j, g.Ny, wl, wh);
             const double dxf = dxf_row(g, j);
             sFyh[ty][tx] = dxf * vv * ch;
             sFya[ty][tx] = dxf * vv * ca;

@@ -727,9 +727,6 @@ int32_t do_tendencies(csi_context* c, int scheme) {
     if (scheme != CSI_ADVECT_UPWIND1 && scheme != CSI_ADVECT_WENO5 && scheme != CSI_ADVECT_WENO7 && scheme != CSI_ADVECT_UPWIND5)
         return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown advection scheme");
     if (c->Hx < need_h || c->Hy < need_h) return fail(c, CSI_ERR_INVALID_ARGUMENT, "halo too small for the advection scheme");
-    if (c->g.xlo == SIDE_WALL || c->g.ylo == SIDE_WALL || c->g.xhi == SIDE_WALL || c->g.yhi == SIDE_WALL)
-        if (scheme != CSI_ADVECT_UPWIND1)
-            return fail(c, CSI_ERR_UNSUPPORTED, "high-order advection next to walls (upstream boundary-order reduction) is not implemented");
     launch_tracer_tendencies(adv_dev(c, scheme, 0.0, 0), c->mode, c->stream);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;

@@ -582,14 +582,51 @@ static double weno7(const double* p) {
     double s = a0 + a1 + a2 + a3;
     return (a0 * q0 + a1 * q1 + a2 * q2 + a3 * q3) / s;
 }
+static double weno3(const double* p) {
+    /* p[0..2] = psi at (upwind-1, upwind, downwind): WENO(order = 3), the buffer scheme of order 5 */
+    double q0 = (p[1] + p[2]) / 2;                     /* stencil 0: (upwind, dw) */
+    double q1 = (-p[0] + 3 * p[1]) / 2;                /* stencil 1: (upwind-1, upwind) */
+    double b0 = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
+    double b1 = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
+    double tau = fabs(b0 - b1);
+    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS);
+    double a0 = (2.0 / 3) * (1 + r0 * r0);
+    double a1 = (1.0 / 3) * (1 + r1 * r1);
+    double s = a0 + a1;
+    return (a0 * q0 + a1 * q1) / s;
+}
+static double upwind3(const double* p) {
+    /* UpwindBiased(order = 3), the buffer scheme of UpwindBiased(order = 5) */
+    return (-p[0] + 5 * p[1] + 2 * p[2]) / 6;
+}
+/* Boundary-order reduction next to walls (upstream topologically_conditional_interpolation, recalled -- SURVEY.md
+ * App. B): a scheme with buffer B (order 2B-1) is used at face `idx` (1-based along the line, N cells) only if its
+ * biased stencil stays inside the domain, otherwise its buffer scheme (order 2B-3) is tried, down to first-order
+ * upwind: left bias needs idx >= B+1 (low wall) and idx <= N+2-B (high wall), right bias idx >= B and idx <= N+1-B. */
+static int reduced_buffer(int B, int idx, int N, int left, int wall_lo, int wall_hi) {
+    while (B > 1) {
+        int lo_ok = !wall_lo || idx >= (left ? B + 1 : B);
+        int hi_ok = !wall_hi || idx <= (left ? N + 2 - B : N + 1 - B);
+        if (lo_ok && hi_ok) break;
+        --B;
+    }
+    return B;
+}
 /* reconstruct c at a face from a 1-D line of values; `up` is the upwind cell value index
  * stepping `st` (= +1 for left bias reading towards increasing index). */
-static double reconstruct(int scheme, const double* line, int64_t up, int64_t st) {
+static double reconstruct(int scheme, const double* line, int64_t up, int64_t st, int idx, int N, int left, int wall_lo, int wall_hi) {
     double p[7];
     if (scheme == 1) return line[up];
-    if (scheme == 5 || scheme == -5) {
+    const int weno = scheme > 0;
+    const int B = reduced_buffer(scheme == 7 ? 4 : 3, idx, N, left, wall_lo, wall_hi);
+    if (B == 1) return line[up];
+    if (B == 2) {
+        for (int k = 0; k < 3; ++k) p[k] = line[up + (k - 1) * st];
+        return weno ? weno3(p) : upwind3(p);
+    }
+    if (B == 3) {
         for (int k = 0; k < 5; ++k) p[k] = line[up + (k - 2) * st];
-        return scheme == 5 ? weno5(p) : upwind5(p);
+        return weno ? weno5(p) : upwind5(p);
     }
     for (int k = 0; k < 7; ++k) p[k] = line[up + (k - 3) * st];
     return weno7(p);
@@ -598,14 +635,16 @@ static double reconstruct(int scheme, const double* line, int64_t up, int64_t st
 double ora_weno_flux_x(const ora_problem* g, int scheme, ora_field c, int i, int j) {
     double uu = AT(g, g->u, i, j);
     const double* base = &AT(g, c, i, j);   /* cell i; upwind of a left-biased face i is cell i-1 */
-    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1) : reconstruct(scheme, base, 0, -1);
+    const int wl = wall_lo(g->topo_x), wh = wall_hi(g->topo_x);
+    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1, i, g->Nx, 1, wl, wh) : reconstruct(scheme, base, 0, -1, i, g->Nx, 0, wl, wh);
     return ora_dy(g, F_, C_, i, j) * uu * ct;    /* Ax = dy * dz, dz = 1 */
 }
 double ora_weno_flux_y(const ora_problem* g, int scheme, ora_field c, int i, int j) {
     double vv = AT(g, g->v, i, j);
     const double* base = &AT(g, c, i, j);
     int64_t ld = c.ld;
-    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld) : reconstruct(scheme, base, 0, -ld);
+    const int wl = wall_lo(g->topo_y), wh = wall_hi(g->topo_y);
+    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld, j, g->Ny, 1, wl, wh) : reconstruct(scheme, base, 0, -ld, j, g->Ny, 0, wl, wh);
     return ora_dx(g, C_, F_, i, j) * vv * ct;    /* Ay = dx^{cf} * dz */
 }
 /* horizontal_div_Uc, sea_ice_advection.jl:51-54 ; G = -div, tracer_tendency_kernel_functions.jl:39-42 */

@@ -122,3 +122,71 @@ def test_c_oracle_equals_numpy_restatement_bitwise(name, oracle_lib):
     n.subcycle(c["dt"], 1, 6)
     for k in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
         assert np.array_equal(p.f[k], n.fld[k]), k
+
+
+def _bounded_advection_case(topo, scheme_seed=0):
+    rng = np.random.default_rng(5 + scheme_seed)
+    c = cases.make_case(Nx=40, Ny=32, H=4, topo=topo, spacing=1000.0, patches=False, noise=0.0)
+    g = c["g"]
+    nyu, nxu = c["u"].shape
+    nyv, nxv = c["v"].shape
+    c["u"] = 0.4 * rng.standard_normal((nyu, nxu))
+    c["v"] = 0.4 * rng.standard_normal((nyv, nxv))
+    if topo[0] == "bounded":
+        c["u"][:, 0] = 0.0; c["u"][:, -1] = 0.0          # impenetrable walls
+    if topo[1] == "bounded":
+        c["v"][0, :] = 0.0; c["v"][-1, :] = 0.0
+    c["h"] = 0.3 + 0.2 * rng.random(c["h"].shape)
+    c["a"] = np.clip(0.5 + 0.6 * rng.random(c["a"].shape), 0, 1)
+    return c
+
+
+@pytest.mark.parametrize("scheme", [7, 5, -5])
+@pytest.mark.parametrize("topo", [("bounded", "bounded"), ("periodic", "bounded"), ("bounded", "periodic")])
+def test_advection_next_to_walls_reduces_its_order_and_conserves(topo, scheme, oracle_lib):
+    """Boundary-order reduction (upstream topologically_conditional_interpolation, recalled): next to a wall the
+    reconstruction drops to the highest order whose biased stencil stays inside the domain.  Pinned here by two
+    properties that do not depend on the recollection of the coefficients: (1) no stencil reads across a wall --
+    1e300 planted in every cell beyond the walls never reaches a tendency (the wall faces themselves multiply their
+    halo neighbour by u = 0, as upstream does); (2) with closed walls the flux-form divergence conserves the
+    tracer sums to rounding."""
+    c = _bounded_advection_case(topo)
+    p = cases.oracle_problem(c)
+    H, Nx, Ny = c["H"], c["Nx"], c["Ny"]
+    for k in ("h", "aice"):
+        a = p.f[k]
+        if topo[0] == "bounded":
+            a[:, :H] = 1e300; a[:, H + Nx:] = 1e300
+        if topo[1] == "bounded":
+            a[:H, :] = 1e300; a[H + Ny:, :] = 1e300
+    p.compute_tracer_tendencies(scheme)
+    for k in ("Gh", "Ga"):
+        G = p.interior(k)
+        assert np.all(np.isfinite(G)) and np.abs(G).max() < 1.0, (k, topo, scheme, np.abs(G).max())
+        assert np.abs(G).max() > 0
+        assert abs(G.sum()) <= 1e-9 * np.abs(G).sum(), (k, G.sum())        # uniform cells: plain sums
+
+
+@pytest.mark.parametrize("scheme", [7, 5, -5])
+def test_boundary_order_reduction_rule(scheme, oracle_lib):
+    """Which faces fall back to first-order upwind, read off a linear profile on a bounded line of N = 12 cells: every
+    scheme of order >= 3 reconstructs it exactly whatever its nonlinear weights (all candidate stencils agree), first
+    order returns the upwind cell value.  Flow towards +x: only face 2 (one upwind cell before the wall) is first
+    order; flow towards -x: only face N."""
+    N = 12
+    for sign in (+1.0, -1.0):
+        c = cases.make_case(Nx=N, Ny=8, H=4, topo=("bounded", "periodic"), spacing=1.0, patches=False, noise=0.0)
+        xc = np.arange(N) + 0.5
+        prof = 1.0 + 0.25 * xc
+        c["h"] = np.broadcast_to(prof[None, :], c["h"].shape).copy()
+        c["a"] = np.ones_like(c["h"])
+        c["u"] = sign * np.ones_like(c["u"]); c["u"][:, 0] = 0.0; c["u"][:, -1] = 0.0
+        c["v"] = np.zeros_like(c["v"])
+        p = cases.oracle_problem(c)
+        got = np.array([p.L.ora_weno_flux_x(p.ptr, scheme, p.field_struct("h"), int(i), 1) for i in range(2, N + 1)]) / sign
+        exact = 1.0 + 0.25 * np.arange(1, N)                    # the profile at faces 2 .. N (x = 1 .. N-1)
+        upwind = prof[:-1] if sign > 0 else prof[1:]            # cell on the upwind side of each face
+        first_order = np.zeros(N - 1, dtype=bool)
+        first_order[0 if sign > 0 else -1] = True
+        assert np.allclose(got[~first_order], exact[~first_order], rtol=0, atol=1e-13)
+        assert np.array_equal(got[first_order], upwind[first_order])
