@@ -77,6 +77,9 @@ struct csi_context {
     FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
+    double* fd[2] = {nullptr, nullptr};     // free-drift velocities at u / v points (StressBalanceFreeDrift)
+    size_t fd_elems[2] = {0, 0};
+    int free_drift = 0;                     // csi_free_drift_set
     size_t fbar_elems[2] = {0, 0};
     size_t alt_elems[5] = {0, 0, 0, 0, 0};
     bool slab_set = false;   // thermodynamic step inside csi_time_step_fe / _rk3
@@ -186,6 +189,11 @@ EvpDev evp_dev(const csi_context* c, double dt) {
     P.pressure_kind = e.pressure_formulation;
     P.dt = dt;
     P.write_diag = 0;
+    P.free_drift = c->free_drift;
+    if (c->free_drift && c->fd[0] && c->fd[1]) {
+        P.ufd.p = c->fd[0] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * c->f[CSI_F_U].ld; P.ufd.ld = (int)c->f[CSI_F_U].ld;
+        P.vfd.p = c->fd[1] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * c->f[CSI_F_V].ld; P.vfd.ld = (int)c->f[CSI_F_V].ld;
+    }
     return P;
 }
 
@@ -583,6 +591,21 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     const int uvs[5] = {CSI_F_U, CSI_F_V, CSI_F_S11, CSI_F_S22, CSI_F_S12};
     const int nxf = k > 1 ? 5 : 2;
     (void)uv;
+    if (c->free_drift) {
+        // free-drift velocities of marginal ice depend on the forcing only: once per sub-cycle, every point whose
+        // four-point averages stay inside the parent arrays
+        const int src[2] = {CSI_F_U, CSI_F_V};
+        for (int q = 0; q < 2; ++q) {
+            const size_t n = (size_t)c->f[src[q]].ld * (size_t)c->f[src[q]].nj;
+            if (c->fd_elems[q] != n) {
+                if (c->fd[q]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); hipFree(c->fd[q]); c->fd[q] = nullptr; }
+                HIP_TRY(c, hipMalloc((void**)&c->fd[q], n * sizeof(double)));
+                HIP_TRY(c, hipMemsetAsync(c->fd[q], 0, n * sizeof(double), c->stream));
+                c->fd_elems[q] = n;
+            }
+        }
+        launch_free_drift(evp_dev(c, dt), Range{2 - c->Hx, c->Nx + c->Hx - 1, 2 - c->Hy, c->Ny + c->Hy - 1}, c->stream);
+    }
     EvpDev P = evp_dev(c, dt);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const bool fast = c->mode == CSI_MODE_FAST;
@@ -600,7 +623,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // three kernels inside run_fused)
     const int pfk = pair_forcing_kind(P);
     const bool pair_only = P.g.has_mask || pfk == 1;      // configurations only the two-sub-steps kernel takes
-    const bool fuse = fast && c->fusion && substeps > 0 &&
+    const bool fuse = fast && c->fusion && substeps > 0 && !c->free_drift &&     // free drift: three-kernel path
                       (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                  : fused_supported(P));
     if (fuse) {
@@ -664,6 +687,10 @@ int32_t need_evp(csi_context* c) {
     if ((rc = check_stress_fields(c, CSI_STRESS_TOP))) return rc;
     if ((rc = check_stress_fields(c, CSI_STRESS_BOTTOM))) return rc;
     if (c->Hx < 2 || c->Hy < 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "EVP needs halo >= 2");
+    if (c->free_drift) {   // stress_balance_free_drift.jl:21-35: exactly one of the two stresses is a SemiImplicitStress
+        const bool ts = c->stress[CSI_STRESS_TOP].kind == CSI_STRESS_SEMI_IMPLICIT, bs = c->stress[CSI_STRESS_BOTTOM].kind == CSI_STRESS_SEMI_IMPLICIT;
+        if (ts == bs) return fail(c, CSI_ERR_INVALID_ARGUMENT, "StressBalanceFreeDrift needs exactly one SemiImplicitStress (top or bottom)");
+    }
     if (c->Nx < c->Hx || c->Ny < c->Hy) return fail(c, CSI_ERR_UNSUPPORTED, "tile smaller than its halo");
     if (is_tiled(c) && !c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
     return CSI_OK;
@@ -800,6 +827,7 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
     for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
+    for (int k = 0; k < 2; ++k) if (c->fd[k]) hipFree(c->fd[k]);
     if (c->dev_tables) hipFree(c->dev_tables);
     if (c->sendbuf) hipFree(c->sendbuf);
     if (c->recvbuf) hipFree(c->recvbuf);
@@ -1097,6 +1125,13 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
             out40[5 * k + 1] = out40[5 * k + 2] = out40[5 * k + 3] = out40[5 * k + 4] = 0;
         }
     }
+    return CSI_OK;
+}
+
+int32_t csi_free_drift_set(csi_context* c, int32_t kind) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (kind != 0 && kind != 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "free drift kind: 0 (nothing) or 1 (StressBalanceFreeDrift)");
+    c->free_drift = kind;
     return CSI_OK;
 }
 

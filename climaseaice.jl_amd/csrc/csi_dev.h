@@ -44,6 +44,8 @@ struct EvpDev {
     double P_star, C_star, ecc, Dmin, amin, amax, ca;
     double min_mass, min_conc, rho, fcor;
     int pressure_kind, has_cor;
+    int free_drift;           // 1: StressBalanceFreeDrift, velocities of marginal ice from ufd / vfd
+    FRef ufd, vfd;            // free-drift velocities at u / v points (library scratch, once per sub-cycle)
     double dt;
     int write_diag;   // FAST: also store zeta_c, zeta_f, Delta (last sub-step only)
 };

@@ -12,6 +12,9 @@ void launch_strict_stress(const EvpDev& P, const Range& r, hipStream_t s);
 void launch_strict_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, hipStream_t s);
 void launch_strict_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, hipStream_t s);
 
+// free-drift velocities of marginal ice (StressBalanceFreeDrift), once per sub-cycle, both modes (evp_strict.hip)
+void launch_free_drift(const EvpDev& P, const Range& r, hipStream_t s);
+
 // FAST mode (evp_fast.hip): fused viscosity + stress phase, u step, v step
 void launch_fast_init(const EvpDev& P, const Range& r, hipStream_t s);
 void launch_fast_stress(const EvpDev& P, const Range& r, const FastCoef& c, hipStream_t s);

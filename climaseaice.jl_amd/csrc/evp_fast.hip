@@ -184,8 +184,10 @@ __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img,
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
     const double cor = P.fcor * vbar;                         // -x_f_cross_U = +f vbar
-    const double res = fm::vel_update(vel_const(P, c), u, un, hm * P.rho * am, h0 * P.rho * a0, am, a0, alm, al0, div, cor,
-                                      ext, imt, exb, imb, peripheral_u(P.g, i, j));
+    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
+    const double res = P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
+        : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j));
     store_with_images(P.u, P.g, img, i, j, res);
 }
 
@@ -211,8 +213,10 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
     const double cor = -P.fcor * ubar;                       // -y_f_cross_U = -f ubar
-    const double res = fm::vel_update(vel_const(P, c), v, vn, hm * P.rho * am, h0 * P.rho * a0, am, a0, alm, al0, div, cor,
-                                      ext, imt, exb, imb, peripheral_v(P.g, i, j));
+    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
+    const double res = P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))
+        : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j));
     store_with_images(P.v, P.g, img, i, j, res);
 }
 

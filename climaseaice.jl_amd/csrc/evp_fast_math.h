@@ -176,6 +176,16 @@ __device__ __forceinline__ double vel_update_avg(const VelConst& k, double w, do
     double res = active_ice ? wD : 0.0;     // free drift `nothing`: marginal ice -> 0 as well
     return peripheral ? 0.0 : res;
 }
+// the same with a free-drift velocity `wf` for marginal ice (split_explicit_momentum_equations.jl:219-228)
+__device__ __forceinline__ double vel_update_avg_fd(const VelConst& k, double w, double wn, double mi, double ai, double abar,
+                                                    double div, double cor, double ext, double imt, double exb, double imb,
+                                                    bool peripheral, double wf) {
+    const double wD = vel_update_avg(k, w, wn, mi, ai, abar, div, cor, ext, imt, exb, imb, false);
+    const bool active_ice = (mi >= k.min_mass) & (ai >= k.min_conc);
+    const bool marginal = (mi > CSI_EPS64) & (ai > CSI_EPS64);
+    const double res = active_ice ? wD : (marginal ? wf : 0.0);
+    return peripheral ? 0.0 : res;
+}
 //   m_a, m_b, a_a, a_b, al_a, al_b : ice mass, concentration, alpha at the two cells the face separates
 __device__ __forceinline__ double vel_update(const VelConst& k, double w, double wn, double m_a, double m_b, double a_a, double a_b,
                                              double al_a, double al_b, double div, double cor,

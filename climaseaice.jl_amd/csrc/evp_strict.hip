@@ -215,6 +215,32 @@ __device__ __forceinline__ double explicit_tau_y(const EvpDev& P, const StressDe
         default: return 0.0;
     }
 }
+// ---- StressBalanceFreeDrift closed forms, stress_balance_free_drift.jl:61-129 --------------------------------
+// exactly one stress is a SemiImplicitStress (checked on the host); the other one gives tau.  The result depends on
+// the forcing only, so it is evaluated once per sub-cycle into ufd / vfd (strict arithmetic in both modes).
+__device__ __forceinline__ double free_drift_u(const EvpDev& P, int i, int j) {
+    const StressDev& semi = P.bot.kind == 3 ? P.bot : P.top;
+    const StressDev& expl = P.bot.kind == 3 ? P.top : P.bot;
+    const double tx = explicit_tau_x(P, expl, i, j);
+#define TY_(ii, jj) explicit_tau_y(P, expl, ii, jj)
+    const double ty = AVG4_FC(TY_);
+#undef TY_
+    const double t = sqrt(tx * tx + ty * ty);
+    const double C = semi.rho_e * semi.Cd;
+    return ext_ue(semi, i, j) - ((t == 0) ? t : tx / sqrt(C * t));
+}
+__device__ __forceinline__ double free_drift_v(const EvpDev& P, int i, int j) {
+    const StressDev& semi = P.bot.kind == 3 ? P.bot : P.top;
+    const StressDev& expl = P.bot.kind == 3 ? P.top : P.bot;
+#define TX_(ii, jj) explicit_tau_x(P, expl, ii, jj)
+    const double tx = AVG4_CF(TX_);
+#undef TX_
+    const double ty = explicit_tau_y(P, expl, i, j);
+    const double t = sqrt(tx * tx + ty * ty);
+    const double C = semi.rho_e * semi.Cd;
+    return ext_ve(semi, i, j) - ((t == 0) ? t : ty / sqrt(C * t));
+}
+
 __device__ __forceinline__ double implicit_tau_x(const EvpDev& P, const StressDev& s, int i, int j) {
     return s.kind == 3 ? s.rho_e * s.Cd * drag_norm_u(P, s, i, j) : 0.0;
 }
@@ -250,7 +276,7 @@ __global__ void k_ustep(EvpDev P, Range r, ImageSpec im) {
     double tau_i = (implicit_tau_x(P, P.bot, i, j) - implicit_tau_x(P, P.top, i, j)) / mi * ai;
     tau_i = (mi <= 0) ? 0.0 : tau_i;
     double uD = (P.u(i, j) + dtau * G) / (1 + dtau * tau_i);
-    double uF = 0.0;
+    double uF = P.free_drift ? P.ufd(i, j) : 0.0;                       // free_drift_u, :219
     bool marginal = (mi > EPS64) & (ai > EPS64);
     bool active_ice = (mi >= P.min_mass) & (ai >= P.min_conc);
     // `... * active` with a Julia Bool: false is a strong zero (sign kept), :228
@@ -284,7 +310,7 @@ __global__ void k_vstep(EvpDev P, Range r, ImageSpec im) {
     double tau_i = (implicit_tau_y(P, P.bot, i, j) - implicit_tau_y(P, P.top, i, j)) / mi * ai;
     tau_i = (mi <= 0) ? 0.0 : tau_i;
     double vD = (P.v(i, j) + dtau * G) / (1 + dtau * tau_i);
-    double vF = 0.0;
+    double vF = P.free_drift ? P.vfd(i, j) : 0.0;
     bool marginal = (mi > EPS64) & (ai > EPS64);
     bool active_ice = (mi >= P.min_mass) & (ai >= P.min_conc);
     double sel = active_ice ? vD : (marginal ? vF : 0.0);
@@ -298,6 +324,19 @@ static inline dim3 grid_for(const Range& r, dim3 b) {
     return dim3((unsigned)((r.i1 - r.i0 + 1 + b.x - 1) / b.x), (unsigned)((r.j1 - r.j0 + 1 + b.y - 1) / b.y), 1);
 }
 
+namespace strict {
+__global__ void __launch_bounds__(256) k_free_drift(EvpDev P, Range r) {
+    const int i = r.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = r.j0 + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    if (i > r.i1 || j > r.j1) return;
+    P.ufd(i, j) = free_drift_u(P, i, j);
+    P.vfd(i, j) = free_drift_v(P, i, j);
+}
+}  // namespace strict
+
+void launch_free_drift(const EvpDev& P, const Range& r, hipStream_t s) {
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(strict::k_free_drift, grid_for(r, b), b, 0, s, P, r);
+}
 void launch_strict_init(const EvpDev& P, const Range& r, hipStream_t s) {
     dim3 b(64, 4);
     hipLaunchKernelGGL(strict::k_init, grid_for(r, b), b, 0, s, P, r, P.un, P.vn);

@@ -67,6 +67,16 @@ def Auxiliaries(rheology, grid, device=None):
     return SimpleNamespace(fields=f)
 
 
+class StressBalanceFreeDrift:
+    """Free-drift velocity of marginal ice from the balance of the top and bottom stresses
+    (SeaIceDynamics/stress_balance_free_drift.jl:3-121).  Exactly one of the model's two stresses must be a
+    SemiImplicitStress; the arguments are accepted for API parity and replaced by the model's stresses."""
+
+    def __init__(self, top_momentum_stress=None, bottom_momentum_stress=None):
+        self.top_momentum_stress = top_momentum_stress
+        self.bottom_momentum_stress = bottom_momentum_stress
+
+
 class SeaIceMomentumEquation:
     def __init__(self, grid, coriolis=None, rheology=None, top_momentum_stress=None, bottom_momentum_stress=None,
                  free_drift=None, solver=None, minimum_concentration=1e-3, minimum_mass=1.0, device=None):
@@ -76,9 +86,11 @@ class SeaIceMomentumEquation:
         if not isinstance(self.rheology, ElastoViscoPlasticRheology):
             raise NotImplementedError("only ElastoViscoPlasticRheology is on the accelerated path (SURVEY.md 2, row 3)")
         self.solver = solver if solver is not None else SplitExplicitSolver(substeps=150)
-        if free_drift is not None:
-            raise NotImplementedError("free_drift closed forms are 'next' (SURVEY.md 8f-4); only `nothing` is supported")
-        self.free_drift = None
+        # free_drift: None (`nothing`: marginal ice is at rest) or StressBalanceFreeDrift(); like the reference's
+        # materialize_free_drift (stress_balance_free_drift.jl:44-46) the balance uses the model's own stresses
+        if free_drift is not None and not isinstance(free_drift, StressBalanceFreeDrift):
+            raise NotImplementedError("free_drift: None or StressBalanceFreeDrift() (prescribed free-drift velocity fields are not on the accelerated path)")
+        self.free_drift = free_drift
         self.external_momentum_stresses = SimpleNamespace(top=top_momentum_stress, bottom=bottom_momentum_stress)
         self.minimum_concentration = float(minimum_concentration)
         self.minimum_mass = float(minimum_mass)

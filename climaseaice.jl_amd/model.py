@@ -155,6 +155,7 @@ class SeaIceModel:
         self.ctx.call("csi_evp_params_set", C.byref(p))
         self._set_stress(_lib.STRESS_TOP, d.external_momentum_stresses.top, "TOP")
         self._set_stress(_lib.STRESS_BOTTOM, d.external_momentum_stresses.bottom, "BOT")
+        self.ctx.call("csi_free_drift_set", 1 if d.free_drift is not None else 0)
 
     def _init_tiles(self, g):
         """csi_tile_set + RCCL communicator: rank 0 makes the unique id, the host broadcasts it

@@ -239,6 +239,13 @@ int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const 
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 
+/* Velocity of marginal ice (0 < mass, concentration below minimum_mass / minimum_concentration;
+ * split_explicit_momentum_equations.jl:219-228).  kind 0 (default): `free_drift = nothing`, zero.  kind 1:
+ * StressBalanceFreeDrift built on the model's own top / bottom stresses (stress_balance_free_drift.jl:61-121,
+ * materialize_free_drift :44-46): exactly one of them must be a SemiImplicitStress, U = U_e - tau / sqrt(C |tau|).
+ * Evaluated once per sub-cycle; runs on the three-kernel paths. */
+int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
+
 /* FAST mode only.  level 0: always the three-kernel path.  level 1: a sub-step is ONE launch of the fused
  * kernel (stress + both velocity updates, ring recomputation per wavefront, double-buffered u, v, sigma in
  * library scratch) whenever the configuration allows it (no immersed mask, forcing given by numbers;

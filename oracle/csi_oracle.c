@@ -338,6 +338,42 @@ static double implicit_tau_y(const ora_problem* g, const ora_stress* s, int i, i
 }
 
 /* ------------------------------------------------------------------------ */
+/* StressBalanceFreeDrift closed forms, stress_balance_free_drift.jl:61-129   */
+/* kind 1: exactly one of the two stresses is a SemiImplicitStress (which one  */
+/* is read off the stress kinds: bottom semi-implicit = TISB :73-95, top       */
+/* semi-implicit = BISB :99-121); the other one must not depend on the ice     */
+/* velocity.  U_i = U_e - tau / sqrt(C ||tau||), zero where ||tau|| == 0.       */
+/* ------------------------------------------------------------------------ */
+static double free_drift_u(const ora_problem* g, int i, int j) {
+    if (g->free_drift_kind == 0) return 0.0;                                 /* `nothing` :129 */
+    const ora_stress* semi = (g->bottom.kind == ORA_STRESS_SEMI_IMPLICIT) ? &g->bottom : &g->top;
+    const ora_stress* expl = (g->bottom.kind == ORA_STRESS_SEMI_IMPLICIT) ? &g->top : &g->bottom;
+    double tx = explicit_tau_x(g, expl, i, j);                               /* x_momentum_stress :74 */
+#define TY_(ii, jj) explicit_tau_y(g, expl, ii, jj)
+    double ty = AVG4_FC(TY_);                                                /* Ixy^{fc}(y_momentum_stress) :75 */
+#undef TY_
+    double t = sqrt(tx * tx + ty * ty);                                      /* :76 */
+    double ue = ext_ue(g, semi, i, j);                                       /* :79 */
+    double C = semi->rho_e * semi->Cd;                                       /* :80 */
+    return ue - ((t == 0) ? t : tx / sqrt(C * t));                           /* :82 */
+}
+static double free_drift_v(const ora_problem* g, int i, int j) {
+    if (g->free_drift_kind == 0) return 0.0;
+    const ora_stress* semi = (g->bottom.kind == ORA_STRESS_SEMI_IMPLICIT) ? &g->bottom : &g->top;
+    const ora_stress* expl = (g->bottom.kind == ORA_STRESS_SEMI_IMPLICIT) ? &g->top : &g->bottom;
+#define TX_(ii, jj) explicit_tau_x(g, expl, ii, jj)
+    double tx = AVG4_CF(TX_);                                                /* Ixy^{cf}(x_momentum_stress) :86 */
+#undef TX_
+    double ty = explicit_tau_y(g, expl, i, j);                               /* :87 */
+    double t = sqrt(tx * tx + ty * ty);
+    double ve = ext_ve(g, semi, i, j);
+    double C = semi->rho_e * semi->Cd;
+    return ve - ((t == 0) ? t : ty / sqrt(C * t));                           /* :94 */
+}
+double ora_free_drift_u(const ora_problem* g, int i, int j) { return free_drift_u(g, i, j); }
+double ora_free_drift_v(const ora_problem* g, int i, int j) { return free_drift_v(g, i, j); }
+
+/* ------------------------------------------------------------------------ */
 /* u_velocity_tendency, momentum_tendencies_kernel_functions.jl:11-41         */
 /* ------------------------------------------------------------------------ */
 static double u_tendency(const ora_problem* g, int i, int j, double dtau) {
@@ -399,7 +435,7 @@ void ora_u_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
             double tau_i = (implicit_tau_x(g, &g->bottom, i, j) - implicit_tau_x(g, &g->top, i, j)) / mi * ai;  /* :214-215 */
             tau_i = (mi <= 0) ? 0.0 : tau_i;                                             /* :217 */
             double uD = (AT(g, g->u, i, j) + dtau * Gu) / (1 + dtau * tau_i);            /* :218 */
-            double uF = 0.0;                                                             /* free_drift `nothing`, sbfd:129 */
+            double uF = free_drift_u(g, i, j);                                           /* :219 */
             int marginal = (mi > EPS64) & (ai > EPS64);                                  /* :224 */
             int active_ice = (mi >= g->min_mass) & (ai >= g->min_conc);                  /* :225 */
             int active = !ora_peripheral_u(g, i, j);                                     /* :226 */
@@ -421,7 +457,7 @@ void ora_v_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
             double tau_i = (implicit_tau_y(g, &g->bottom, i, j) - implicit_tau_y(g, &g->top, i, j)) / mi * ai;
             tau_i = (mi <= 0) ? 0.0 : tau_i;
             double vD = (AT(g, g->v, i, j) + dtau * Gv) / (1 + dtau * tau_i);
-            double vF = 0.0;
+            double vF = free_drift_v(g, i, j);
             int marginal = (mi > EPS64) & (ai > EPS64);
             int active_ice = (mi >= g->min_mass) & (ai >= g->min_conc);
             int active = !ora_peripheral_v(g, i, j);

@@ -82,7 +82,7 @@ typedef struct {
     double rho_ice;              /* sea_ice_density (ConstantField), sea_ice_model.jl:142-145,193 */
     double f_coriolis;           /* FPlane f; 0 with has_coriolis = 0 means `nothing` */
     int32_t has_coriolis;
-    int32_t free_drift_kind;     /* 0 = nothing (zero) */
+    int32_t free_drift_kind;     /* 0 = nothing (zero), 1 = StressBalanceFreeDrift (exactly one stress semi-implicit) */
     ora_stress top, bottom;
 
     /* ---- fields ---- */

@@ -121,6 +121,10 @@ def lib(omp=False):
         L.ora_subcycle.argtypes = [P, dbl, i32, i32]
         L.ora_compute_tracer_tendencies.argtypes = [P, i32]
         L.ora_dynamic_step_tracers.argtypes = [P, dbl, i32]
+        L.ora_free_drift_u.restype = dbl
+        L.ora_free_drift_u.argtypes = [P, i32, i32]
+        L.ora_free_drift_v.restype = dbl
+        L.ora_free_drift_v.argtypes = [P, i32, i32]
         L.ora_weno_flux_x.restype = dbl
         L.ora_weno_flux_x.argtypes = [P, i32, Field, i32, i32]
         L.ora_weno_flux_y.restype = dbl

@@ -186,7 +186,15 @@ class NP:
             i0 = r[0]
             cols = np.arange(i0, r[1] + 1)
             active[:, (cols == 1) | (cols == self.Nx + 1)] = 0.0
-        sel = np.where(active_ice, uD, 0.0)
+        uF = 0.0
+        if getattr(self, "free_drift", False):          # StressBalanceFreeDrift, bottom semi-implicit, top constant
+            tx, ty0 = (self.top[1], self.top[2]) if self.top else (0.0, 0.0)
+            ty = ((ty0 + ty0) / 2 + (ty0 + ty0) / 2) / 2
+            t = np.sqrt(tx * tx + ty * ty)
+            _, ue, ve, rho_e, Cd = self.bottom
+            uF = ue - (t if t == 0 else tx / np.sqrt(rho_e * Cd * t))
+        marginal = (mi > np.finfo(np.float64).eps) & (ai > np.finfo(np.float64).eps)
+        sel = np.where(active_ice, uD, np.where(marginal, uF, 0.0))
         V(u, r)[...] = np.where(active != 0, sel, np.copysign(0.0, sel))   # Julia Bool: strong zero
 
     def v_step(self, dt, r=None):
@@ -230,7 +238,15 @@ class NP:
         if self.topo[1] == 1:
             rows = np.arange(r[2], r[3] + 1)
             active[(rows == 1) | (rows == self.Ny + 1), :] = 0.0
-        sel = np.where(active_ice, vD, 0.0)
+        vF = 0.0
+        if getattr(self, "free_drift", False):
+            tx0, ty = (self.top[1], self.top[2]) if self.top else (0.0, 0.0)
+            tx = ((tx0 + tx0) / 2 + (tx0 + tx0) / 2) / 2
+            t = np.sqrt(tx * tx + ty * ty)
+            _, ue, ve, rho_e, Cd = self.bottom
+            vF = ve - (t if t == 0 else ty / np.sqrt(rho_e * Cd * t))
+        marginal = (mi > np.finfo(np.float64).eps) & (ai > np.finfo(np.float64).eps)
+        sel = np.where(active_ice, vD, np.where(marginal, vF, 0.0))
         V(v, r)[...] = np.where(active != 0, sel, np.copysign(0.0, sel))
 
     # ---- local halo fill (upstream) ------------------------------------------------

@@ -14,10 +14,11 @@ import climaseaice_jl_amd as csi
 def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
-              field_forcing=False, land=0.0):
+              field_forcing=False, land=0.0, free_drift=False):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
-             top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing)
+             top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
+             free_drift=free_drift)
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded}
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
@@ -111,6 +112,8 @@ def oracle_problem(case, omp=False):
             p.set_stress("top", O.STRESS_CONST, tau=case["top"])
         if case["bottom"] == "semi":
             p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    if case.get("free_drift"):
+        p.s.free_drift_kind = 1                     # StressBalanceFreeDrift on the model's own stresses
     if case.get("mask") is not None:
         s_ = p.s
         full = np.zeros(p.f["h"].shape, dtype=np.uint8)
@@ -156,6 +159,7 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
         rheo.pressure_formulation = csi.IceStrength()
     dyn = csi.SeaIceMomentumEquation(g, coriolis=None if case["coriolis"] is None else csi.FPlane(f=case["coriolis"]),
                                      rheology=rheo, top_momentum_stress=top, bottom_momentum_stress=bottom,
+                                     free_drift=csi.StressBalanceFreeDrift() if case.get("free_drift") else None,
                                      solver=csi.SplitExplicitSolver(substeps=case["substeps"]), device=device)
     model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode)
     if case.get("field_forcing"):

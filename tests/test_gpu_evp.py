@@ -55,6 +55,11 @@ CASES = {
     "forced_seams": dict(Nx=150, Ny=70, topo=("periodic", "periodic"), patches=True, field_forcing=True, random_uv=0.03),
     "coupled_channel": dict(Nx=100, Ny=90, topo=("periodic", "bounded"), patches=True, field_forcing=True, random_uv=0.03, land=0.3),
     "coupled_latlon": dict(Nx=64, Ny=72, topo=("bounded", "bounded"), grid="latlon", patches=True, field_forcing=True, random_uv=0.03, land=0.2),
+    # StressBalanceFreeDrift for marginal ice (three-kernel paths only)
+    "free_drift": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05, ue=0.05, ve=-0.02, top=(0.03, -0.02),
+                       free_drift=True),
+    "free_drift_coupled": dict(Nx=60, Ny=44, topo=("periodic", "bounded"), patches=True, random_uv=0.03, field_forcing=True,
+                               free_drift=True),
 }
 MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon"}
 

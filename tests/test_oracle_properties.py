@@ -101,15 +101,18 @@ CROSS = {
 }
 
 
+@pytest.mark.parametrize("free_drift", [False, True])
 @pytest.mark.parametrize("name", list(CROSS))
-def test_c_oracle_equals_numpy_restatement_bitwise(name, oracle_lib):
-    c = cases.make_case(Nx=28, Ny=22, substeps=6, random_uv=0.05, ue=0.05, ve=-0.02, top=(0.01, 0.02), **CROSS[name])
+def test_c_oracle_equals_numpy_restatement_bitwise(name, free_drift, oracle_lib):
+    c = cases.make_case(Nx=28, Ny=22, substeps=6, random_uv=0.05, ue=0.05, ve=-0.02, top=(0.01, 0.02), free_drift=free_drift,
+                        **CROSS[name])
     p = cases.oracle_problem(c)
     g = c["g"]
     topo = tuple(0 if t == "periodic" else 1 for t in c["topo"])
     m = g.metrics()
     n = ONP.NP(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m.get("dx"), dy=m.get("dy"), per_j=m if m["kind"] == "per_j" else None)
     n.f, n.top, n.bottom = c["coriolis"], ("const",) + tuple(c["top"]), ("semi", c["ue"], c["ve"], 1026.0, 5.5e-3)
+    n.free_drift = free_drift
     for k, v in p.f.items():
         n.fld[k] = v.copy()
     p.initialize_rheology()
@@ -190,3 +193,24 @@ def test_boundary_order_reduction_rule(scheme, oracle_lib):
         first_order[0 if sign > 0 else -1] = True
         assert np.allclose(got[~first_order], exact[~first_order], rtol=0, atol=1e-13)
         assert np.array_equal(got[first_order], upwind[first_order])
+
+
+def test_stress_balance_free_drift_closed_form(oracle_lib):
+    """StressBalanceFreeDrift (stress_balance_free_drift.jl:73-95): where the ice is marginal (present, but below
+    minimum_mass / minimum_concentration) the velocity after a step is U_e - tau / sqrt(rho_e C_D |tau|), whatever
+    the rheology did; with `nothing` it is zero.  Constant wind stress, constant ocean velocity."""
+    tau, ue, ve = (0.03, -0.04), 0.05, -0.02
+    for fd in (False, True):
+        c = cases.make_case(Nx=32, Ny=24, substeps=4, random_uv=0.02, top=tau, ue=ue, ve=ve, patches=True, free_drift=fd)
+        p = cases.oracle_problem(c)
+        p.time_step_momentum(c["dt"])
+        h, a = p.interior("h"), p.interior("aice")
+        m = 900.0 * h * a
+        mi = 0.5 * (m + np.roll(m, 1, axis=1)); ai = 0.5 * (a + np.roll(a, 1, axis=1))       # u points (periodic)
+        marginal_u = (mi > 2.3e-16) & (ai > 2.3e-16) & ~((mi >= 1.0) & (ai >= 1e-3))
+        assert marginal_u.any()
+        t = np.hypot(*tau)
+        want = ue - tau[0] / np.sqrt(1026.0 * 5.5e-3 * t) if fd else 0.0
+        got = p.interior("u")[marginal_u]
+        assert np.allclose(got, want, rtol=1e-15, atol=0), (fd, got[:3], want)
+        assert p.L.ora_free_drift_u(p.ptr, 3, 3) == (want if fd else 0.0) or fd
