@@ -107,7 +107,6 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
     double XW_mm = 0, XW_m = 0;                        // x-averages of the first velocity (rows as W_mm / W_m)
     // new sigma / alpha of rows r-2, r-1 and the first velocity of rows r-2, r-1 (filled as the march proceeds)
     double S11_mm = 0, S22_mm = 0, AL_mm = 0, S11_m = 0, S22_m = 0, S12_m = 0, AL_m = 0;
-    double W_mm = 0, W_m = 0;                          // UFIRST: new u rows r-2, r-1 ; else: new v rows r-1, r (W_m = row r-1)
 
     // Software prefetch: the loads of row iteration r + 1 are issued before the arithmetic of iteration r, so a
     // wave hides its own HBM latency (there are only ~3 waves per SIMD to hide it otherwise).  The loop is
@@ -211,7 +210,6 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                                                    ext, imt, exb, imb, ((flags & L_WALL_V) != 0) | wall_vrow);
                 if (flags & L_R2) store_vel(T, FP_V_OUT, FI_LD_C, FI_IMV, near_edge, i, j, vnew);
             }
-            W_mm = W_0;
             XW_mm = XW_0;
         } else {
             // ---- v of row r (needs sigma rows r-1, r) then u of row r-1 (needs new v rows r-1, r) ----------------
@@ -246,7 +244,6 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                                                        ext, imt, exb, imb, ((flags & L_WALL_U) != 0) | wall_row);
                 if (flags & L_R2) store_vel(T, FP_U_OUT, FI_LD_F, FI_IMU, near_edge, i, j, unew);
             }
-            W_m = W_0;
             XW_m = fm::avg2(from_left(W_0), W_0);
         }
 

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     bool lanes_uniform;      // fast store path allowed (see flush)
     enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64 };
     {
-        const int Nx = T->I[FI_NX], Ny = T->I[FI_NY], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
+        const int Nx = T->I[FI_NX], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
         const int i0s = T->I[FI_DEC + 0] - P_LO + strip * P_W;
         i = i0s + lane;
         ja = T->I[FI_DEC + 2] + chunk * rows;
