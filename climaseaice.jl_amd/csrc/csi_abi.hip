@@ -86,7 +86,7 @@ struct csi_context {
     SlabDev slab{};
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
     int pairing = 1;      // 1: two sub-steps per launch where supported (csi_set_fusion level 2)
-    int last_launches = 0, last_substeps = 0;   // kernel launches / sub-steps of the last fused sub-cycle
+    int last_launches = 0, last_substeps = 0, last_used_pairs = 0;   // kernel launches / sub-steps of the last fused sub-cycle
     int last_fused = 0;
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
 };
@@ -133,6 +133,8 @@ ImageSpec image_spec(const csi_context* c, int fid) {
     im.xhi = img_of(c->g.xhi, kLoc[fid][0]);
     im.ylo = img_of(c->g.ylo, kLoc[fid][1]);
     im.yhi = img_of(c->g.yhi, kLoc[fid][1]);
+    im.ex = (kLoc[fid][0] == LOC_F && c->g.xhi == SIDE_WALL) ? 1 : 0;
+    im.ey = (kLoc[fid][1] == LOC_F && c->g.yhi == SIDE_WALL) ? 1 : 0;
     return im;
 }
 // a Face-located field has one extra point where the HIGH side of that direction is a wall
@@ -420,6 +422,9 @@ bool pair_supported(const csi_context* c) {
     if (!c->pairing) return false;
     const GridDev& g = c->g;
     auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED || s == SIDE_WALL; };
+    // per-row metrics with a periodic y side: the ring rows recomputed beyond the seam would use other metrics than
+    // their owners (an unphysical grid anyway) -- three kernels
+    if (!c->coef.uniform && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;
     return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
 }
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
@@ -572,6 +577,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     c->last_k = k;
     c->last_launches = nlaunch;
     c->last_substeps = substeps;
+    c->last_used_pairs = pairs && substeps >= 2;
     return CSI_OK;
 }
 
@@ -630,7 +636,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
         c->launches_per_substep = 1 + ((tiled && k == 1) ? 3 : 0);
-        c->last_fused = c->last_launches < substeps ? 2 : 1;
+        c->last_fused = c->last_used_pairs ? 2 : 1;
         return CSI_OK;
     }
     c->last_fused = 0;

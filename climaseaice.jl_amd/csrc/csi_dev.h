@@ -92,6 +92,8 @@ __device__ __forceinline__ bool immersed_peripheral_ff(const GridDev& g, int i, 
 // A mirrored low side and a connected high side (tile edges) are encoded per side.
 struct ImageSpec {
     int xlo, xhi, ylo, yhi;   // IMG_* per side
+    int ex, ey;               // 1: the field has an extra column / row of points on a high wall (Face location): the
+                              // wall faces have images in the OTHER direction like any interior point
 };
 __device__ __forceinline__ int image_lo(int mode, int i, int N, int H, bool& has) {
     // halo index on the LOW side that copies from interior index i

@@ -319,6 +319,8 @@ bool fused_supported(const EvpDev& P) {
     // first version: no immersed mask, forcing given by numbers (the benchmark configuration); everything else
     // runs the three-kernel FAST path
     if (P.g.has_mask) return false;
+    // per-row metrics with a periodic y side: ring rows beyond the seam would not reproduce their owners
+    if (P.g.metric_kind != 0 && (P.g.ylo == SIDE_PERIODIC || P.g.yhi == SIDE_PERIODIC)) return false;
     auto ok = [](const StressDev& s) {
         if (s.kind == 2) return false;
         if (s.kind == 3 && (s.ue_kind == 2 || s.ve_kind == 2)) return false;

@@ -63,6 +63,7 @@ __device__ __forceinline__ void store_vel(tptr_t T, int which_ptr, int which_ld,
         g.Nx = T->I[FI_NX]; g.Ny = T->I[FI_NY]; g.Hx = T->I[FI_HX]; g.Hy = T->I[FI_HY];
         ImageSpec im;
         im.xlo = T->I[img0]; im.xhi = T->I[img0 + 1]; im.ylo = T->I[img0 + 2]; im.yhi = T->I[img0 + 3];
+        im.ex = 0; im.ey = 0;        // velocities are never stored on the wall faces
         store_with_images(f, g, im, i, j, val);
     } else {
         f(i, j) = val;

@@ -480,6 +480,8 @@ void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int b
      * rows recomputed for the neighbours need their x images too. */
     int jlo = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_LEFT_CONNECTED) ? 1 - Hy : 1;
     int jhi = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_RIGHT_CONNECTED) ? Ny + Hy : Ny;
+    /* a Face-in-y field on a high y wall has one more row of points (the wall faces, row Ny + 1): its x images too */
+    if (wall_hi(g->topo_y) && byhi == ORA_BC_NONE && bylo == ORA_BC_NONE) jhi = Ny + 1;
     for (int j = jlo; j <= jhi; ++j)
         for (int m = 1; m <= Hx; ++m) {
             if (bxlo == ORA_BC_PERIODIC) AT(g, f, 1 - m, j) = AT(g, f, Nx + 1 - m, j);

@@ -1,0 +1,14 @@
+import sys, numpy as np, traceback
+sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+import test_gpu_evp as T
+bad = 0
+for seed in range(24, 200):
+    try:
+        T.test_fused_paths_fuzz_bitwise(seed)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", seed, str(e)[:300])
+    except Exception as e:
+        bad += 1
+        print("ERR", seed, type(e).__name__, str(e)[:200])
+print("done, failures:", bad)
