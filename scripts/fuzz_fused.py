@@ -1,3 +1,4 @@
+"""Extended fuzz of the fused EVP paths against the three-kernel path (run on the GPU box; 24 seeds of the same test are in the suite)."""
 import sys, numpy as np, traceback
 sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
 import test_gpu_evp as T
