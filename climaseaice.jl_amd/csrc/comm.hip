@@ -19,9 +19,13 @@ namespace csi {
 __global__ void __launch_bounds__(256) k_pack(ExPlan pl, double* buf, int unpack) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= pl.total) return;
-    int s = 0;
+    // the segment that holds element t: offsets are ascending, at most 8 directions x 5 fields -> binary search
+    int s = 0, hi = pl.nseg - 1;
 #pragma unroll 1
-    while (s + 1 < pl.nseg && t >= pl.seg[s + 1].off) ++s;
+    while (s < hi) {
+        const int mid = (s + hi + 1) >> 1;
+        if (t >= pl.seg[mid].off) s = mid; else hi = mid - 1;
+    }
     const ExSeg& g = pl.seg[s];
     const long r = t - g.off;
     const int jj = (int)(r / g.ni), ii = (int)(r - (long)jj * g.ni);
