@@ -1171,6 +1171,7 @@ int32_t csi_plan_pair(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t to
     csi_context tmp;
     tmp.Nx = Nx; tmp.Ny = Ny; tmp.Hx = Hx; tmp.Hy = Hy;
     tmp.g.xlo = side_lo(topo_x); tmp.g.xhi = side_hi(topo_x); tmp.g.ylo = side_lo(topo_y); tmp.g.yhi = side_hi(topo_y);
+    tmp.coef.uniform = 1;             // (per-row metrics with a periodic y side are the one grid kind that never pairs)
     const bool tiled = is_tiled(&tmp);
     memset(out32, 0, 32 * sizeof(int32_t));
     out32[0] = (pair_supported(&tmp) && (!tiled || k % 2 == 0)) ? 1 : 0;
