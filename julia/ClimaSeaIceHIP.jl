@@ -39,6 +39,8 @@ const F = (U=0, V=1, H=2, A=3, S11=4, S22=5, S12=6, UN=7, VN=8, P=9, ALPHA=10, D
 
 mutable struct Context
     handle::Ptr{Cvoid}
+    mask::Any            # UInt8 activity mask of an immersed grid (owned here so that it outlives the library's pointer)
+    Context(handle) = new(handle, nothing)
 end
 
 function check(ctx, rc)
@@ -132,7 +134,17 @@ function attach!(model::SeaIceModel)
             τ.vₑ isa Field && bind!(ctx, side == 0 ? F.TOP_V : F.BOT_V, τ.vₑ)
         end
     end
+    # free_drift = StressBalanceFreeDrift(...): the library rebuilds the balance on the model's own stresses, like
+    # materialize_free_drift (stress_balance_free_drift.jl:44-46)
+    check(ctx, ccall((:csi_free_drift_set, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle,
+                     dyn.free_drift isa StressBalanceFreeDrift ? 1 : 0))
+    # immersed boundary: the activity mask (1 = active) as a UInt8 ROCArray with the parent shape of a Center field
+    if grid isa ImmersedBoundaryGrid
+        ctx.mask = active_cells_mask(grid)                       # kept alive by the context
+        check(ctx, ccall((:csi_mask_set, libcsi), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64), ctx.handle, pointer(ctx.mask), size(ctx.mask, 1)))
+    end
     check(ctx, ccall((:csi_set_mode, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, 1))   # CSI_MODE_FAST
+    check(ctx, ccall((:csi_set_fusion, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, 2)) # two sub-steps per launch (default)
     return ctx
 end
 
