@@ -309,8 +309,14 @@ def time_step_momentum(model, dt, rk_reset=False):
 def time_step(model, dt):
     """time_step!(model, dt)."""
     if model.dynamics is None:
-        raise NotImplementedError("time_step! without dynamics is not on the accelerated path")
-    if model.timestepper_kind == "ForwardEuler":
+        # dynamics = nothing, advection = nothing: the step is the thermodynamic update alone
+        # (sea_ice_fe_step.jl:13-34 with time_step_momentum!, compute_tendencies! and dynamic_time_step! no-ops)
+        if model.ice_thermodynamics is None or model.scheme not in (0, None):
+            raise NotImplementedError("without dynamics only the slab thermodynamics step is on the accelerated path")
+        sp = model.ice_thermodynamics.params(model.sea_ice_density)
+        model.ctx.call("csi_slab_thermo_step", C.byref(sp), float(dt))
+        model.ctx.call("csi_update_state")
+    elif model.timestepper_kind == "ForwardEuler":
         model.ctx.call("csi_time_step_fe", float(dt), model.substeps, model.scheme, int(model.clock.iteration == 0))
     else:
         model.ctx.call("csi_time_step_rk3", float(dt), model.substeps, model.scheme)

@@ -224,3 +224,23 @@ def test_config4_style_latlon_evp_plus_slab_thermodynamics(oracle_lib):
             scale = max(np.abs(p.f[k]).max(), 1e-30)
             assert np.abs(f.numpy() - p.f[k]).max() <= tol * scale, (mode, k)
         assert np.abs(p.interior("h") - c["h"]).max() > 1e-6      # the slab step really changed the ice
+
+
+def test_freezing_bucket_full_run_matches_oracle(oracle_lib):
+    """examples/freezing_bucket.py (the reference's examples/freezing_bucket.jl: 1440 steps of 10 minutes): thickness
+    and concentration after every model day equal the oracle's slab step bit for bit; the first step is the known
+    answer of SURVEY.md 8(d) config 1 (tests/test_oracle_properties.py), and the ice ends up consolidated and growing."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("freezing_bucket", os.path.join(os.path.dirname(__file__), "..", "examples", "freezing_bucket.py"))
+    fb = importlib.util.module_from_spec(spec); spec.loader.exec_module(fb)
+    m = fb.build()
+    series = fb.run(m, steps=1440, dt=600.0, every=144)
+    h = np.zeros((1, 1)); a = np.zeros((1, 1))
+    want = []
+    for n in range(1440):
+        h, a, _ = O.slab_step(h, a, 600.0, Tu=-10.0, c_ice=2100.0, top_flux_kind=1, bot_flux_kind=1, Qb=1.0)
+        if (n + 1) % 144 == 0:
+            want.append((float(h[0, 0]), float(a[0, 0])))
+    got = [(hh, aa) for _, hh, aa in series]
+    assert got == want, (got[:2], want[:2])
+    assert 0.99 < got[-1][1] <= 1.0 and got[-1][0] > got[0][0] > 0.05        # consolidated, still thickening
