@@ -59,6 +59,11 @@ struct csi_context {
     double* dev_metrics = nullptr;   // 8 vectors of length Ny + 2Hy + 1
     double* dev_coef = nullptr;      // FAST per-row stencil coefficients [FC_COUNT][Ny + 2Hy + 1]
     FastCoef coef{};
+    std::vector<double> coef_host;       // host copy of the per-row table built from PER_J metrics (empty: uniform metrics)
+    std::vector<double> fcor_rows[2];    // csi_coriolis_rows_set: f per row at u / v points (empty: FPlane scalar)
+    double* dev_fcor = nullptr;          // the same on the device (STRICT kernels), 2 x (Ny + 2Hy + 1)
+    bool cor_dirty = true;               // Coriolis columns of the FAST table need (re)building
+    double cor_synced = 0.0;             // FPlane value they were built with
     Bound f[CSI_F_COUNT];
     csi_evp_params evp{};
     csi_stress stress[2]{};
@@ -174,6 +179,40 @@ int32_t check_stress_fields(csi_context* c, int side) {
     return CSI_OK;
 }
 
+// Coriolis parameter of the FAST kernels: two columns of the per-row coefficient table (uniform metrics + FPlane:
+// two of the table's constants).  Rebuilt when the FPlane value, the BetaPlane rows or the grid changed; a
+// BetaPlane on uniform metrics switches the kernels to their per-row-coefficient instantiation.
+int32_t sync_coriolis(csi_context* c) {
+    const csi_evp_params& e = c->evp;
+    const double f0 = e.has_coriolis ? e.coriolis_f : 0.0;
+    if (!c->cor_dirty && f0 == c->cor_synced) return CSI_OK;
+    const bool rows = e.has_coriolis && !c->fcor_rows[0].empty();
+    const bool metrics_uniform = c->metric_kind == CSI_METRIC_UNIFORM;
+    c->coef.uni[FC_FU] = f0; c->coef.uni[FC_FV] = f0;
+    c->coef.uniform = metrics_uniform && !rows;
+    if (!c->coef.uniform) {
+        const int n = c->Ny + 2 * c->Hy + 1;
+        std::vector<double> host((size_t)FC_COUNT * n);
+        for (int w = 0; w < FC_COUNT; ++w)
+            for (int t = 0; t < n; ++t)
+                host[(size_t)w * n + t] = metrics_uniform ? c->coef.uni[w] : c->coef_host[(size_t)w * n + t];
+        for (int t = 0; t < n; ++t) {
+            host[(size_t)FC_FU * n + t] = rows ? c->fcor_rows[0][t] : f0;
+            host[(size_t)FC_FV * n + t] = rows ? c->fcor_rows[1][t] : f0;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!c->dev_coef) HIP_TRY(c, hipMalloc((void**)&c->dev_coef, sizeof(double) * host.size()));
+        HIP_TRY(c, hipMemcpy(c->dev_coef, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+        c->coef.vec = c->dev_coef + (c->Hy - 1);
+        c->coef.stride = n;
+        c->coef.jmin = 1 - c->Hy;
+        c->coef.jmax = c->Ny + c->Hy + 1;
+    }
+    c->cor_dirty = false;
+    c->cor_synced = f0;
+    return CSI_OK;
+}
+
 EvpDev evp_dev(const csi_context* c, double dt) {
     EvpDev P{};
     P.g = c->g;
@@ -188,6 +227,10 @@ EvpDev evp_dev(const csi_context* c, double dt) {
     P.Dmin = e.minimum_plastic_stress; P.amin = e.min_relaxation_parameter; P.amax = e.max_relaxation_parameter;
     P.ca = e.relaxation_strength; P.min_mass = e.minimum_mass; P.min_conc = e.minimum_concentration;
     P.rho = e.sea_ice_density; P.fcor = e.has_coriolis ? e.coriolis_f : 0.0; P.has_cor = e.has_coriolis;   // FAST kernels multiply by fcor unconditionally
+    if (c->dev_fcor && e.has_coriolis) {
+        const size_t n = (size_t)c->Ny + 2 * (size_t)c->Hy + 1;
+        P.fcor_u = c->dev_fcor + (c->Hy - 1); P.fcor_v = c->dev_fcor + n + (c->Hy - 1);   // ptr[j] is row j
+    }
     P.pressure_kind = e.pressure_formulation;
     P.dt = dt;
     P.write_diag = 0;
@@ -424,7 +467,7 @@ bool pair_supported(const csi_context* c) {
     auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED || s == SIDE_WALL; };
     // per-row metrics with a periodic y side: the ring rows recomputed beyond the seam would use other metrics than
     // their owners (an unphysical grid anyway) -- three kernels
-    if (!c->coef.uniform && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;
+    if (c->metric_kind != CSI_METRIC_UNIFORM && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;   // (BetaPlane rows wrap: csi.h)
     return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
 }
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
@@ -699,7 +742,7 @@ int32_t need_evp(csi_context* c) {
     }
     if (c->Nx < c->Hx || c->Ny < c->Hy) return fail(c, CSI_ERR_UNSUPPORTED, "tile smaller than its halo");
     if (is_tiled(c) && !c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
-    return CSI_OK;
+    return sync_coriolis(c);
 }
 
 int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_reset) {
@@ -830,6 +873,7 @@ int32_t csi_context_destroy(csi_context* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->dev_metrics) hipFree(c->dev_metrics);
+    if (c->dev_fcor) hipFree(c->dev_fcor);
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
     for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
@@ -893,6 +937,9 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
     }
     // FAST-mode stencil coefficients
     if (c->dev_coef) { hipFree(c->dev_coef); c->dev_coef = nullptr; }
+    if (c->dev_fcor) { hipFree(c->dev_fcor); c->dev_fcor = nullptr; }
+    c->coef_host.clear(); c->fcor_rows[0].clear(); c->fcor_rows[1].clear();
+    c->cor_dirty = true;
     c->coef = FastCoef{};
     c->coef.uniform = metric_kind == CSI_METRIC_UNIFORM;
     if (metric_kind == CSI_METRIC_UNIFORM) {
@@ -901,12 +948,7 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
         const int n = Ny + 2 * Hy + 1;
         std::vector<double> host;
         build_fast_coef_per_j(n, m->dy, m->dxc, m->dxf, m->azc, m->azf, host);
-        HIP_TRY(c, hipMalloc((void**)&c->dev_coef, sizeof(double) * host.size()));
-        HIP_TRY(c, hipMemcpy(c->dev_coef, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
-        c->coef.vec = c->dev_coef + (Hy - 1);
-        c->coef.stride = n;
-        c->coef.jmin = 1 - Hy;
-        c->coef.jmax = Ny + Hy + 1;
+        c->coef_host = host;          // uploaded, with the Coriolis columns, by sync_coriolis
     }
     for (auto& b : c->f) b = Bound{};   // bindings refer to the previous grid
     c->grid_set = true;
@@ -948,6 +990,26 @@ int32_t csi_evp_params_set(csi_context* c, const csi_evp_params* p) {
         return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown pressure formulation");
     c->evp = *p;
     c->evp_set = true;
+    return CSI_OK;
+}
+
+int32_t csi_coriolis_rows_set(csi_context* c, const double* f_u, const double* f_v, int32_t n) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");
+    if ((f_u == nullptr) != (f_v == nullptr)) return fail(c, CSI_ERR_INVALID_ARGUMENT, "f_u and f_v: both or neither");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->cor_dirty = true;
+    if (c->dev_fcor) { hipFree(c->dev_fcor); c->dev_fcor = nullptr; }
+    c->fcor_rows[0].clear(); c->fcor_rows[1].clear();
+    if (!f_u) return CSI_OK;
+    const int need = c->Ny + 2 * c->Hy + 1;
+    if (n != need) return fail(c, CSI_ERR_INVALID_ARGUMENT, "coriolis rows: n must be Ny + 2Hy + 1");
+    c->fcor_rows[0].assign(f_u, f_u + n); c->fcor_rows[1].assign(f_v, f_v + n);
+    std::vector<double> host(2 * (size_t)n);
+    for (int t = 0; t < n; ++t) { host[t] = f_u[t]; host[(size_t)n + t] = f_v[t]; }
+    HIP_TRY(c, hipMalloc((void**)&c->dev_fcor, sizeof(double) * host.size()));
+    HIP_TRY(c, hipMemcpy(c->dev_fcor, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
     return CSI_OK;
 }
 
@@ -1171,7 +1233,7 @@ int32_t csi_plan_pair(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t to
     csi_context tmp;
     tmp.Nx = Nx; tmp.Ny = Ny; tmp.Hx = Hx; tmp.Hy = Hy;
     tmp.g.xlo = side_lo(topo_x); tmp.g.xhi = side_hi(topo_x); tmp.g.ylo = side_lo(topo_y); tmp.g.yhi = side_hi(topo_y);
-    tmp.coef.uniform = 1;             // (per-row metrics with a periodic y side are the one grid kind that never pairs)
+    tmp.coef.uniform = 1; tmp.metric_kind = CSI_METRIC_UNIFORM;   // (per-row metrics with a periodic y side are the one grid kind that never pairs)
     const bool tiled = is_tiled(&tmp);
     memset(out32, 0, 32 * sizeof(int32_t));
     out32[0] = (pair_supported(&tmp) && (!tiled || k % 2 == 0)) ? 1 : 0;

@@ -43,6 +43,7 @@ struct EvpDev {
     StressDev top, bot;
     double P_star, C_star, ecc, Dmin, amin, amax, ca;
     double min_mass, min_conc, rho, fcor;
+    const double *fcor_u, *fcor_v;   // BetaPlane: f per row at the u / v points (ptr[j] = row j); NULL: fcor
     int pressure_kind, has_cor;
     int free_drift;           // 1: StressBalanceFreeDrift, velocities of marginal ice from ufd / vfd
     FRef ufd, vfd;            // free-drift velocities at u / v points (library scratch, once per sub-cycle)

@@ -33,6 +33,9 @@ enum : int {
     FC_Q2S,
     FC_K,
     FC_RAZF,    // 1 / Az^ff
+    // Coriolis parameter of the row (FPlane: the same value in every row; BetaPlane: csi_coriolis_rows_set)
+    FC_FU,      // at the u points of centre row j
+    FC_FV,      // at the v points of face row j
     FC_COUNT
 };
 

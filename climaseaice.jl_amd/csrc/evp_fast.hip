@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img,
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
-    const double cor = P.fcor * vbar;                         // -x_f_cross_U = +f vbar
+    const double cor = coef<UNI>(c, FC_FU, j) * vbar;         // -x_f_cross_U = +f vbar (f = 0 without Coriolis)
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
         ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
-    const double cor = -P.fcor * ubar;                       // -y_f_cross_U = -f ubar
+    const double cor = -coef<UNI>(c, FC_FV, j) * ubar;       // -y_f_cross_U = -f ubar
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
         ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))

@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
-                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
+                const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 const double unew = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor,
                                                        ext, imt, exb, imb, ((flags & L_WALL_U) != 0) | wall_row);
                 W_0 = (flags & L_R1C) ? unew : u_m;
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_m, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_m, ubar, exb, imb);
-                const double cor = -kv.fcor * ubar;
+                const double cor = -coef<UNI>(T, FC_FV, j) * ubar;
                 const double vnew = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor,
                                                    ext, imt, exb, imb, ((flags & L_WALL_V) != 0) | wall_vrow);
                 if (flags & L_R2) store_vel(T, FP_V_OUT, FI_LD_C, FI_IMV, near_edge, i, j, vnew);
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_V], T->K[FK_TOP_RHOCD], T->K[FK_TOP_VE], T->K[FK_TOP_UE], v_0, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_V], T->K[FK_BOT_RHOCD], T->K[FK_BOT_VE], T->K[FK_BOT_UE], v_0, ubar, exb, imb);
-                const double cor = -kv.fcor * ubar;
+                const double cor = -coef<UNI>(T, FC_FV, r) * ubar;
                 const double vnew = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor,
                                                    ext, imt, exb, imb, ((flags & L_WALL_V) != 0) | wall_vrow);
                 W_0 = (flags & L_R1C) ? vnew : v_0;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 double ext, imt, exb, imb;
                 fm::ext_stress(T->I[FI_TOP_KIND], T->K[FK_TOP_TAU_U], T->K[FK_TOP_RHOCD], T->K[FK_TOP_UE], T->K[FK_TOP_VE], u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], T->K[FK_BOT_TAU_U], T->K[FK_BOT_RHOCD], T->K[FK_BOT_UE], T->K[FK_BOT_VE], u_m, vbar, exb, imb);
-                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
+                const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 const double unew = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor,
                                                        ext, imt, exb, imb, ((flags & L_WALL_U) != 0) | wall_row);
                 if (flags & L_R2) store_vel(T, FP_U_OUT, FI_LD_F, FI_IMU, near_edge, i, j, unew);

@@ -22,7 +22,7 @@
 // the batch position's V on connected sides; every in-range value depends on in-range values only, so the
 // stages compute unconditionally and only B's stores are predicated.
 // Reference: SeaIceDynamics/split_explicit_momentum_equations.jl:173-189 (two trips of the sub-step loop).
-#include "evp_fused_common.h"
+#include "evp_pair_stage.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -30,162 +30,9 @@
 namespace csi {
 namespace fused {
 
-constexpr int P_LO = 4, P_HI = 59, P_W = P_HI - P_LO + 1;
 #ifdef CSI_PAIR_PROBE
 __device__ unsigned long long g_probe[4096 * 16];
 #endif
-
-// what fm::ext_stress needs at a u point and at a v point, for the top (t_) and bottom (b_) stress: tau (constant /
-// array-valued stress), we (external velocity, own component), wb (cross component averaged to the point)
-struct Forcing { double t_tau_u, t_we_u, t_wb_u, b_tau_u, b_we_u, b_wb_u, t_tau_v, t_we_v, t_wb_v, b_tau_v, b_we_v, b_wb_v; };
-
-struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; };
-
-// One sub-step as a row pipeline.  step(r) consumes row r of P, m, a, sigma, rows r+1 of u, v and produces
-// sigma(r) and  UFIRST: u(r-1) ["first"], v(r-1) ["second"]   /   v first: v(r) ["first"], u(r-1) ["second"].
-// The arithmetic (operations and their order) is that of evp_fused.hip's loop body.
-// MASK: immersed boundary (GridFittedBoundary).  mh carries, per lane, two bits per row -- bit 0: the cell is inactive
-// (immersed or beyond a wall), bit 1: it is beyond a wall -- for rows r, r-1, r-2 at bit positions 0, 2, 4.  As in
-// evp_fast.hip (k_ustep / k_vstep): stresses of immersed cells / corners are zero in the divergence
-// (ice_stress_divergence.jl:57-123), faces next to an inactive cell are peripheral nodes.
-__device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xf, 0xf, true); }
-
-template <bool UNI, bool UFIRST, bool MASK>
-struct Stage {
-    double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
-    double a_mm, a_m, m_mm, m_m;
-    double XP_m, Xm_m, Xa_m, Xe11_m, Xe22_m, Ye12_0, e12_0;
-    double XAL_m, XS11L_m, XW, Wprev;
-    double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
-    // results of the last step()
-    double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, first, second;
-    // pending window updates
-    double Xv_p, Xa_0, Xm_0, e12_p, XW_next;
-
-    // do_stress / do_vel (wave-uniform): the rows at the start of a tile only fill the window (strain rates and
-    // x-averages); their stresses / velocities would never be used
-    __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
-                                         double u_p, double v_p, double P_0, double m_0, double a_0,
-                                         double s11, double s22, double s12, double un_m, double vn_x,
-                                         bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
-                                         const Forcing& F) {
-        Xa_0 = fm::avg2(from_left(a_0), a_0);
-        Xv_p = fm::avg2(from_left(v_p), v_p);
-        double e11_0, e22_0;
-        fm::strain_cell(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
-                        coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
-        e12_p = fm::strain_corner(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
-                                  u_p, u_0, v_p, from_left(v_p));
-        {
-            const double Xe11_0 = fm::avg2(from_left(e11_0), e11_0), Xe22_0 = fm::avg2(from_left(e22_0), e22_0);
-            const double Ye12_p = fm::avg2(e12_p, from_right(e12_p));
-            const double XP_0 = fm::avg2(from_left(P_0), P_0);
-            Xm_0 = fm::avg2(from_left(m_0), m_0);
-            const double e11f = 0.5 * (Xe11_m + Xe11_0);
-            const double e22f = 0.5 * (Xe22_m + Xe22_0);
-            const double e12c = 0.5 * (Ye12_0 + Ye12_p);
-            const double Pf = 0.5 * (XP_m + XP_0);
-            const double mf = 0.5 * (Xm_m + Xm_0);
-            Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
-            if (do_stress) {
-                const double kc = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
-                const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
-                S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc; zf = o.zf; Dc = o.Dc;
-            }
-        }
-        // stresses as the divergence sees them, peripheral flags
-        double d11_0 = S11_0, d22_0 = S22_0, d12_0 = S12_0, d11_m = S11_m, d22_m = S22_m, d12_m = S12_m, d11_mm = S11_mm, d22_mm = S22_mm;
-        double d11_mL = XS11L_m;
-        if (MASK) {
-            const unsigned m0 = mh & 3u, m1 = (mh >> 2) & 3u, m2 = (mh >> 4) & 3u;
-            const bool pcc_0 = m0 == 1u, pcc_m = m1 == 1u, pcc_mm = m2 == 1u;        // immersed, not beyond a wall
-            unsigned c0 = m0 | m1, c1 = m1 | m2;                                      // corners of rows r, r-1: 4 cells
-            c0 |= left_bits(c0); c1 |= left_bits(c1);
-            const bool pff_0 = (c0 & 3u) == 1u, pff_m = (c1 & 3u) == 1u;
-            d11_0 = pcc_0 ? 0.0 : S11_0; d22_0 = pcc_0 ? 0.0 : S22_0;
-            d11_m = pcc_m ? 0.0 : S11_m; d22_m = pcc_m ? 0.0 : S22_m;
-            d11_mm = pcc_mm ? 0.0 : S11_mm; d22_mm = pcc_mm ? 0.0 : S22_mm;
-            d12_0 = pff_0 ? 0.0 : S12_0; d12_m = pff_m ? 0.0 : S12_m;
-            d11_mL = from_left(d11_m);
-            const bool ia_0 = (m0 & 1u) != 0, ia_m = (m1 & 1u) != 0, ia_mm = (m2 & 1u) != 0;
-            const bool ia_mL = (left_bits(m1) & 1u) != 0;
-            const bool per_u = ia_m | ia_mL;                                          // u(i, r-1): cells (i, r-1), (i-1, r-1)
-            per_first = UFIRST ? per_u : (ia_0 | ia_m);                               // v(i, r): cells (i, r), (i, r-1)
-            per_second = UFIRST ? (ia_m | ia_mm) : per_u;                             // v(i, r-1): cells (i, r-1), (i, r-2)
-        }
-        if (!do_vel) {
-            XW_next = XW;
-        } else if (UFIRST) {
-            const int j = r - 1;
-            double W_0;
-            {
-                const double vbar = 0.5 * (Xv_m + Xv_0);
-                const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
-                                            d11_m, d11_mL, d12_0, d12_m);
-                double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
-                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
-                W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
-            }
-            const double XW_0 = fm::avg2(W_0, from_right(W_0));
-            {
-                const double ubar = 0.5 * (XW + XW_0);
-                const double div = fm::div2(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
-                                            coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
-                                            d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
-                double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
-                const double cor = -kv.fcor * ubar;
-                second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
-            }
-            first = W_0;
-            XW_next = XW_0;
-        } else {
-            double W_0;
-            {
-                const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
-                const double div = fm::div2(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
-                                            coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
-                                            d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
-                double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
-                const double cor = -kv.fcor * ubar;
-                W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
-            }
-            const double XW_0 = fm::avg2(from_left(W_0), W_0);
-            {
-                const int j = r - 1;
-                const double vbar = 0.5 * (XW + XW_0);
-                const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
-                                            d11_m, d11_mL, d12_0, d12_m);
-                double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
-                const double cor = kv.fcor * vbar;              // fcor = 0 without Coriolis (csi_abi.hip)
-                second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
-            }
-            first = W_0;
-            XW_next = XW_0;
-        }
-    }
-
-    // slide the row window: row r becomes row r-1 (inputs of the step just done are passed again)
-    __device__ __forceinline__ void shift(double u_p, double v_p, double m_0, double a_0) {
-        u_m = u_0; u_0 = u_p; v_m = v_0; v_0 = v_p;
-        Xv_m = Xv_0; Xv_0 = Xv_p;
-        a_mm = a_m; a_m = a_0; m_mm = m_m; m_m = m_0;
-        Xm_m = Xm_0; Xa_m = Xa_0;
-        e12_0 = e12_p;
-        S11_mm = S11_m; S22_mm = S22_m; S12_mm = S12_m; AL_mm = AL_m;
-        S11_m = S11_0; S22_m = S22_0; S12_m = S12_0; AL_m = AL_0;
-        XAL_m = fm::avg2(from_left(AL_0), AL_0); XS11L_m = from_left(S11_0);
-        XW = XW_next;
-        Wprev = first;
-    }
-};
 
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE>
 __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,

@@ -261,7 +261,7 @@ __global__ void k_ustep(EvpDev P, Range r, ImageSpec im) {
     double cor = 0.0;
     if (P.has_cor) {
 #define V_(ii, jj) P.v(ii, jj)
-        cor = -P.fcor * AVG4_FC(V_);
+        cor = -(P.fcor_u ? P.fcor_u[j] : P.fcor) * AVG4_FC(V_);     // FPlane / BetaPlane (f at this row's u points)
 #undef V_
     }
     double forcing = 0.0 + (P.un(i, j) - P.u(i, j)) / dtau / abar;   // sum_of_forcing_u, evp:391-395
@@ -295,7 +295,7 @@ __global__ void k_vstep(EvpDev P, Range r, ImageSpec im) {
     double cor = 0.0;
     if (P.has_cor) {
 #define U_(ii, jj) P.u(ii, jj)
-        cor = P.fcor * AVG4_CF(U_);
+        cor = (P.fcor_v ? P.fcor_v[j] : P.fcor) * AVG4_CF(U_);
 #undef U_
     }
     double forcing = 0.0 + (P.vn(i, j) - P.v(i, j)) / dtau / abar;

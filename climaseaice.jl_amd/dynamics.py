@@ -5,13 +5,16 @@ Auxiliaries                  :140-173
 SplitExplicitSolver          SeaIceDynamics/split_explicit_momentum_equations.jl:18-46
 SemiImplicitStress           SeaIceDynamics/sea_ice_external_stress.jl:84-130
 SeaIceMomentumEquation       SeaIceDynamics/sea_ice_momentum_equations.jl:3-12,67-94
-FPlane                       upstream Oceananigans.Coriolis (f-plane only)
+FPlane, BetaPlane            upstream Oceananigans.Coriolis
 """
 import math
+
+import numpy as np
 from dataclasses import dataclass, field as dc_field
 from types import SimpleNamespace
 
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
+from .grids import Center, Face
 
 
 class ReplacementPressure:
@@ -40,9 +43,39 @@ class SplitExplicitSolver:
     substeps: int = 120
 
 
-@dataclass
+_OMEGA_EARTH, _R_EARTH = 7.292115e-5, 6371.0e3      # Oceananigans defaults
+
+
 class FPlane:
-    f: float = 1e-4
+    """FPlane(f = ...) or FPlane(latitude = ..., rotation_rate = Omega_Earth): f = 2 Omega sin(latitude)."""
+
+    def __init__(self, f=None, latitude=None, rotation_rate=_OMEGA_EARTH):
+        if (f is None) == (latitude is None):
+            if f is None:
+                f = 1e-4
+            else:
+                raise ValueError("FPlane: give f or latitude, not both")
+        self.f = float(f) if f is not None else 2.0 * rotation_rate * float(np.sin(np.deg2rad(latitude)))
+
+
+class BetaPlane:
+    """BetaPlane(f0 = ..., beta = ...) or BetaPlane(latitude = ..., rotation_rate, radius): f = f0 + beta * y with
+    f0 = 2 Omega sin(latitude), beta = 2 Omega cos(latitude) / R (upstream Coriolis; test/test_time_stepping.jl:35).
+    y is the node's y coordinate: (Face, Center) nodes for the u equation, (Center, Face) nodes for v."""
+
+    def __init__(self, f0=None, beta=None, latitude=None, rotation_rate=_OMEGA_EARTH, radius=_R_EARTH):
+        if latitude is not None:
+            if f0 is not None or beta is not None:
+                raise ValueError("BetaPlane: give (f0, beta) or latitude, not both")
+            f0 = 2.0 * rotation_rate * float(np.sin(np.deg2rad(latitude)))
+            beta = 2.0 * rotation_rate * float(np.cos(np.deg2rad(latitude))) / radius
+        if f0 is None or beta is None:
+            raise ValueError("BetaPlane needs f0 and beta, or latitude")
+        self.f0, self.beta = float(f0), float(beta)
+
+    def rows(self, grid):
+        """(f at u points, f at v points) per row, rows 1-Hy .. Ny+Hy+1."""
+        return (self.f0 + self.beta * grid.ynodes_with_halo(Center), self.f0 + self.beta * grid.ynodes_with_halo(Face))
 
 
 @dataclass

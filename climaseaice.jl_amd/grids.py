@@ -82,6 +82,15 @@ class _Grid2D:
         ny = self.Ny + (1 if (LY is Face and hi_wall(self.topology[1])) else 0)
         return nx, ny
 
+    def ynodes_with_halo(self, LY):
+        """y nodes of rows 1-Hy .. Ny+Hy+1 (the layout of the per-row metric vectors: row j at [j + Hy - 1]).
+        Halo rows of a Periodic direction hold the node of the row they image, so that a tile recomputing its ring
+        uses the owner's value; beyond a wall the spacing continues."""
+        j = np.arange(1 - self.Hy, self.Ny + self.Hy + 2)
+        if self.topology[1] is Periodic:
+            j = (j - 1) % self.Ny + 1
+        return self._ynode(j, LY)
+
     def stress_kernel_range(self):
         """KernelParameters(-Hx+2:Nx+Hx-1, -Hy+2:Ny+Hy-1), elasto_visco_plastic_rheology.jl:145."""
         return (-self.Hx + 2, self.Nx + self.Hx - 1, -self.Hy + 2, self.Ny + self.Hy - 1)
@@ -108,6 +117,9 @@ class RectilinearGrid(_Grid2D):
 
     def ynodes(self, LY):
         j = np.arange(1, self.Ny + 1 + (1 if (LY is Face and hi_wall(self.topology[1])) else 0))
+        return self.y[0] + (j - 1) * self.dy if LY is Face else self.y[0] + (j - 0.5) * self.dy
+
+    def _ynode(self, j, LY):
         return self.y[0] + (j - 1) * self.dy if LY is Face else self.y[0] + (j - 0.5) * self.dy
 
     def metrics(self):
@@ -152,6 +164,9 @@ class LatitudeLongitudeGrid(_Grid2D):
         j = np.arange(1, self.Ny + 1 + (1 if (LY is Face and hi_wall(self.topology[1])) else 0))
         return self.latitude[0] + (j - 1) * self.dphi if LY is Face else self.latitude[0] + (j - 0.5) * self.dphi
 
+    def _ynode(self, j, LY):
+        return self.latitude[0] + (j - 1) * self.dphi if LY is Face else self.latitude[0] + (j - 0.5) * self.dphi
+
     def metrics(self):
         return dict(kind="per_j", dy=self.dy, dxc=self.dxc, dxf=self.dxf, azc=self.azc, azf=self.azf)
 
@@ -194,6 +209,10 @@ class TileGrid(_Grid2D):
         if LY is Face and not hi_wall(G.topology[1]):
             y = np.append(y, y[-1] + (y[-1] - y[-2]))
         return self._nodes(y, self.j_off, self.Ny, LY, self.topology[1])
+
+    def ynodes_with_halo(self, LY):
+        n = self.Ny + 2 * self.Hy + 1
+        return np.ascontiguousarray(self.global_grid.ynodes_with_halo(LY)[self.j_off:self.j_off + n])
 
     def metrics(self):
         m = dict(self.global_grid.metrics())

@@ -150,9 +150,14 @@ class SeaIceModel:
                            r.minimum_plastic_stress, r.min_relaxation_parameter, r.max_relaxation_parameter,
                            r.relaxation_strength,
                            _lib.PRESSURE_ICE_STRENGTH if isinstance(r.pressure_formulation, IceStrength) else _lib.PRESSURE_REPLACEMENT,
-                           0 if d.coriolis is None else 1, 0.0 if d.coriolis is None else float(d.coriolis.f),
+                           0 if d.coriolis is None else 1, float(getattr(d.coriolis, "f", 0.0)),
                            d.minimum_concentration, d.minimum_mass, self.sea_ice_density)
         self.ctx.call("csi_evp_params_set", C.byref(p))
+        if hasattr(d.coriolis, "rows"):            # BetaPlane: f per row, evaluated here like the metric vectors
+            fu, fv = (np.ascontiguousarray(a, dtype=np.float64) for a in d.coriolis.rows(g))
+            self.ctx.call("csi_coriolis_rows_set", _dptr(fu), _dptr(fv), fu.size)
+        else:
+            self.ctx.call("csi_coriolis_rows_set", None, None, 0)
         self._set_stress(_lib.STRESS_TOP, d.external_momentum_stresses.top, "TOP")
         self._set_stress(_lib.STRESS_BOTTOM, d.external_momentum_stresses.bottom, "BOT")
         self.ctx.call("csi_free_drift_set", 1 if d.free_drift is not None else 0)

@@ -174,6 +174,14 @@ int32_t csi_mask_set(csi_context* ctx, const uint8_t* dev_mask, int64_t ld);
 int32_t csi_field_bind(csi_context* ctx, int32_t field_id, void* dev_ptr, int64_t ld, int32_t ni, int32_t nj);
 int32_t csi_evp_params_set(csi_context* ctx, const csi_evp_params* p);
 int32_t csi_stress_set(csi_context* ctx, int32_t side, const csi_stress* s);
+/* Row-dependent Coriolis parameter: BetaPlane, f = f0 + beta * ynode (upstream x_f_cross_U / y_f_cross_U called at
+ * momentum_tendencies_kernel_functions.jl:31,64; in the reference's test matrix, test/test_time_stepping.jl:35).
+ * f_u: f at the (Face, Center) nodes of each row (u points), f_v: at the (Center, Face) nodes (v points); HOST
+ * arrays laid out like the PER_J metric vectors (value for row j at [j + Hy - 1], n = Ny + 2Hy + 1; halo rows hold the
+ * value of the row they image: the neighbouring tile's row, the wrapped row of a Periodic direction -- the fused
+ * kernels recompute ring rows there and must see their owner's f).  They replace csi_evp_params.coriolis_f while set (has_coriolis must be 1);
+ * NULL, NULL returns to the FPlane value.  Call after csi_grid_set (a new grid drops them). */
+int32_t csi_coriolis_rows_set(csi_context* ctx, const double* f_u, const double* f_v, int32_t n);
 
 /* ---- the reference's verbs ----------------------------------------------------------------- */
 /* initialize_rheology!(model, ::ElastoViscoPlasticRheology), elasto_visco_plastic_rheology.jl:192-219 */

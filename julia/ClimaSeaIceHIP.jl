@@ -123,9 +123,21 @@ function attach!(model::SeaIceModel)
     p = Ref(CsiEvpParams(r.ice_compressive_strength, r.ice_compaction_hardening, r.yield_curve_eccentricity,
                          r.minimum_plastic_stress, r.min_relaxation_parameter, r.max_relaxation_parameter,
                          r.relaxation_strength, r.pressure_formulation isa ReplacementPressure ? 0 : 1,
-                         isnothing(cor) ? 0 : 1, isnothing(cor) ? 0.0 : cor.f,
+                         isnothing(cor) ? 0 : 1, cor isa FPlane ? cor.f : 0.0,
                          dyn.minimum_concentration, dyn.minimum_mass, model.sea_ice_density[1, 1, 1]))
     check(ctx, ccall((:csi_evp_params_set, libcsi), Int32, (Ptr{Cvoid}, Ref{CsiEvpParams}), ctx.handle, p))
+    if cor isa BetaPlane
+        # f = f₀ + β y at the (Face, Center) / (Center, Face) nodes of every row, halo rows included (ynode follows the
+        # halo of a distributed or periodic grid, so ring rows see their owner's value); host vectors like the metrics
+        Hy, Ny = grid.Hy, grid.Ny
+        rows = (1 - Hy):(Ny + Hy + 1)
+        fu = Float64[cor.f₀ + cor.β * ynode(1, wrap_row(grid, j), 1, grid, Face(), Center(), Center()) for j in rows]
+        fv = Float64[cor.f₀ + cor.β * ynode(1, wrap_row(grid, j), 1, grid, Center(), Face(), Center()) for j in rows]
+        check(ctx, ccall((:csi_coriolis_rows_set, libcsi), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32),
+                         ctx.handle, fu, fv, length(fu)))
+    elseif !(isnothing(cor) || cor isa FPlane)
+        error("ClimaSeaIceHIP: coriolis must be nothing, FPlane or BetaPlane")
+    end
     for (side, τ) in ((0, dyn.external_momentum_stresses.top), (1, dyn.external_momentum_stresses.bottom))
         s = Ref(stress_struct(τ))
         check(ctx, ccall((:csi_stress_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Ref{CsiStress}), ctx.handle, side, s))
@@ -147,6 +159,9 @@ function attach!(model::SeaIceModel)
     check(ctx, ccall((:csi_set_fusion, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, 2)) # two sub-steps per launch (default)
     return ctx
 end
+
+# row whose value a halo row images: the wrapped row of a Periodic y direction, the row itself otherwise
+wrap_row(grid, j) = topology(grid, 2) == Periodic ? mod1(j, grid.Ny) : j
 
 # One context per model, created on first use.
 const CONTEXTS = IdDict{Any, Context}()

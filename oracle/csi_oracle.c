@@ -382,7 +382,8 @@ static double u_tendency(const ora_problem* g, int i, int j, double dtau) {
     double cor = 0.0;                                                        /* x_f_cross_U, `nothing` -> zero */
     if (g->has_coriolis) {
 #define V_(ii, jj) AT(g, g->v, ii, jj)
-        cor = -g->f_coriolis * AVG4_FC(V_);                                  /* FPlane: -f * Ixy^{fc}(v) */
+        double f = g->fu_rows ? g->fu_rows[j + g->Hy - 1] : g->f_coriolis;   /* BetaPlane: f0 + beta * y^{fc}(j) */
+        cor = -f * AVG4_FC(V_);                                              /* FPlane: -f * Ixy^{fc}(v) */
 #undef V_
     }
     double abar = (AT(g, g->alpha, i - 1, j) + AT(g, g->alpha, i, j)) / 2;  /* Ix^f(alpha), evp:393 */
@@ -403,7 +404,8 @@ static double v_tendency(const ora_problem* g, int i, int j, double dtau) {  /* 
     double cor = 0.0;
     if (g->has_coriolis) {
 #define U_(ii, jj) AT(g, g->u, ii, jj)
-        cor = g->f_coriolis * AVG4_CF(U_);                                   /* FPlane: +f * Ixy^{cf}(u) */
+        double f = g->fv_rows ? g->fv_rows[j + g->Hy - 1] : g->f_coriolis;   /* BetaPlane: f0 + beta * y^{cf}(j) */
+        cor = f * AVG4_CF(U_);                                               /* FPlane: +f * Ixy^{cf}(u) */
 #undef U_
     }
     double abar = (AT(g, g->alpha, i, j - 1) + AT(g, g->alpha, i, j)) / 2;  /* evp:399 */

@@ -83,6 +83,11 @@ typedef struct {
     double f_coriolis;           /* FPlane f; 0 with has_coriolis = 0 means `nothing` */
     int32_t has_coriolis;
     int32_t free_drift_kind;     /* 0 = nothing (zero), 1 = StressBalanceFreeDrift (exactly one stress semi-implicit) */
+    /* BetaPlane (upstream Coriolis; reference test matrix test/test_time_stepping.jl:35):
+     * f = f0 + beta * ynode, evaluated at the (Face, Center) nodes for x_f_cross_U and at the (Center, Face) nodes
+     * for y_f_cross_U.  The caller evaluates it per row: fu_rows / fv_rows, element for row j at [j + Hy - 1],
+     * length Ny + 2Hy + 1; NULL = FPlane (f_coriolis). */
+    const double *fu_rows, *fv_rows;
     ora_stress top, bottom;
 
     /* ---- fields ---- */

@@ -64,6 +64,7 @@ class ProblemStruct(C.Structure):
                  ("pressure_kind", C.c_int32), ("substeps", C.c_int32),
                  ("min_mass", C.c_double), ("min_conc", C.c_double), ("rho_ice", C.c_double),
                  ("f_coriolis", C.c_double), ("has_coriolis", C.c_int32), ("free_drift_kind", C.c_int32),
+                 ("fu_rows", C.POINTER(C.c_double)), ("fv_rows", C.POINTER(C.c_double)),
                  ("top", Stress), ("bottom", Stress)] +
                 [(n, Field) for n in _FIELD_NAMES])
 
@@ -246,9 +247,19 @@ class Problem:
                 fld.p = _dptr(a)
                 fld.ld = a.shape[1]
 
-    def set_coriolis(self, f):
-        self.s.has_coriolis = 0 if f is None else 1
+    def set_coriolis(self, f, rows=None):
+        """f: None | FPlane f.  rows = (fu, fv): BetaPlane values per row (entry for row j at [j + Hy - 1],
+        length Ny + 2Hy + 1), evaluated by the caller as f0 + beta * ynode."""
+        self.s.has_coriolis = 0 if (f is None and rows is None) else 1
         self.s.f_coriolis = 0.0 if f is None else float(f)
+        self.s.fu_rows = self.s.fv_rows = None
+        if rows is not None:
+            n = self.s.Ny + 2 * self.s.Hy + 1
+            for name, val in zip(("fu_rows", "fv_rows"), rows):
+                a = np.ascontiguousarray(val, dtype=np.float64)
+                assert a.shape == (n,)
+                self._keep.append(a)
+                setattr(self.s, name, _dptr(a))
 
     # ---- the reference's verbs -----------------------------------------------------------
     def update_state(self):

@@ -33,6 +33,7 @@ class NP:
         self.replacement = True
         self.min_mass, self.min_conc, self.rho = 1.0, 1e-3, 900.0
         self.f = None
+        self.f_rows = None        # BetaPlane: (fu, fv) per row, entry for row j at [j + Hy - 1]
         self.top = None           # None | ("const", tu, tv)
         self.bottom = None        # None | ("semi", ue, ve, rho_e, Cd) with scalar ue, ve
         self.fld = {}
@@ -155,7 +156,10 @@ class NP:
         dtau = dt / abar
         u, v = f["u"], f["v"]
         vbar = ((V(v, r, -1, 0) + V(v, r)) / 2 + (V(v, r, -1, 1) + V(v, r, 0, 1)) / 2) / 2
-        cor = -self.f * vbar if self.f is not None else np.zeros_like(vbar)
+        if self.f_rows is not None:
+            cor = -self.f_rows[0][r[2] + self.Hy - 1:r[3] + self.Hy][:, None] * vbar
+        else:
+            cor = -self.f * vbar if self.f is not None else np.zeros_like(vbar)
         sD = f["s11"] + f["s22"]
         sT = f["s11"] - f["s22"]
         d = dy * (V(sD, r) - V(sD, r, -1, 0)) / 2
@@ -207,7 +211,10 @@ class NP:
         dtau = dt / abar
         u, v = f["u"], f["v"]
         ubar = ((V(u, r, 0, -1) + V(u, r, 1, -1)) / 2 + (V(u, r) + V(u, r, 1, 0)) / 2) / 2
-        cor = self.f * ubar if self.f is not None else np.zeros_like(ubar)
+        if self.f_rows is not None:
+            cor = self.f_rows[1][r[2] + self.Hy - 1:r[3] + self.Hy][:, None] * ubar
+        else:
+            cor = self.f * ubar if self.f is not None else np.zeros_like(ubar)
         sD = f["s11"] + f["s22"]
         sT = f["s11"] - f["s22"]
         dxcf = rv("dxf", r)

@@ -14,11 +14,11 @@ import climaseaice_jl_amd as csi
 def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
-              field_forcing=False, land=0.0, free_drift=False):
+              field_forcing=False, land=0.0, free_drift=False, beta=None):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
-             free_drift=free_drift)
+             free_drift=free_drift, beta=beta)     # beta: BetaPlane(f0 = coriolis, beta)
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded}
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
@@ -84,6 +84,21 @@ def _fill_parent_like(p, name, interior):
     return arr
 
 
+def coriolis_rows(case, grid):
+    """BetaPlane cases: f0 + beta * ynode per row of `grid` (u points, v points); None for FPlane / no Coriolis."""
+    if case.get("beta") is None:
+        return None
+    return csi.BetaPlane(f0=case["coriolis"], beta=case["beta"]).rows(grid)
+
+
+def coriolis_of(case):
+    if case["coriolis"] is None:
+        return None
+    if case.get("beta") is not None:
+        return csi.BetaPlane(f0=case["coriolis"], beta=case["beta"])
+    return csi.FPlane(f=case["coriolis"])
+
+
 def oracle_problem(case, omp=False):
     import oracle as O
     g = case["g"]
@@ -93,7 +108,7 @@ def oracle_problem(case, omp=False):
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"], omp=omp)
     else:
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, per_j=m, substeps=case["substeps"], omp=omp)
-    p.set_coriolis(case["coriolis"])
+    p.set_coriolis(case["coriolis"], rows=coriolis_rows(case, g))
     if case["pressure"] != "replacement":
         p.s.pressure_kind = O.PRESSURE_ICE_STRENGTH
     if case.get("field_forcing"):
@@ -157,7 +172,7 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
     rheo = csi.ElastoViscoPlasticRheology()
     if case["pressure"] != "replacement":
         rheo.pressure_formulation = csi.IceStrength()
-    dyn = csi.SeaIceMomentumEquation(g, coriolis=None if case["coriolis"] is None else csi.FPlane(f=case["coriolis"]),
+    dyn = csi.SeaIceMomentumEquation(g, coriolis=coriolis_of(case),
                                      rheology=rheo, top_momentum_stress=top, bottom_momentum_stress=bottom,
                                      free_drift=csi.StressBalanceFreeDrift() if case.get("free_drift") else None,
                                      solver=csi.SplitExplicitSolver(substeps=case["substeps"]), device=device)

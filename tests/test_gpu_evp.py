@@ -60,8 +60,17 @@ CASES = {
                        free_drift=True),
     "free_drift_coupled": dict(Nx=60, Ny=44, topo=("periodic", "bounded"), patches=True, random_uv=0.03, field_forcing=True,
                                free_drift=True),
+    # BetaPlane: f = f0 + beta * y per row (test/test_time_stepping.jl:35); per-row coefficient instantiation of the
+    # FAST kernels on a uniform grid (halo rows of a periodic y side carry the wrapped row's f)
+    "beta_bounded": dict(Nx=100, Ny=90, topo=("bounded", "bounded"), patches=True, random_uv=0.05, beta=2e-10),
+    "beta_channel": dict(Nx=130, Ny=64, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=-1.5e-10),
+    "beta_latlon": dict(Nx=48, Ny=56, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, beta=1e-6),
+    "beta_periodic": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05, beta=2e-10),
+    "beta_masked": dict(Nx=96, Ny=80, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=2e-10, land=0.25),
 }
-MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon"}
+MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
+          "beta_masked"}
+THREE_KERNEL_ONLY = set()
 
 
 def ulp_diff(a, b):
@@ -356,9 +365,11 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
 
 
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
-               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams"] + sorted(MASKED)
+               "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
+               "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic"] + sorted(MASKED)
 PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6",
-              "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams"} | MASKED
+              "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams",
+              "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic"} | MASKED
 
 
 @pytest.mark.parametrize("nsub", [1, 2, 7, 120])
@@ -386,7 +397,7 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
         out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22") + (() if walls else ("s12",))}
         out[fusion].update({k: (EVP_FIELDS[k](m).numpy().copy(), EVP_FIELDS[k](m).interior_numpy().copy())
                             for k in ("alpha", "zeta_c", "zeta_f", "Delta") + (("s12",) if walls else ())})
-    single = 0 if name in MASKED else 1           # the one-sub-step kernel takes neither masks nor array-valued forcing
+    single = 0 if (name in MASKED or name in THREE_KERNEL_ONLY) else 1   # the one-sub-step kernel takes neither masks nor array-valued forcing
     assert level[0] == 0 and level[1] == single
     assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else single), level
     if level[2] == 2:
@@ -432,6 +443,8 @@ def test_fused_paths_fuzz_bitwise(seed):
               grid=("rectilinear", "latlon")[rng.integers(2)] if topo[1] == "bounded" else "rectilinear",
               field_forcing=bool(rng.integers(2)), land=(0.0, 0.25)[rng.integers(2)],
               coriolis=(1e-4, None)[rng.integers(2)], pressure=("replacement", "ice_strength")[rng.integers(2)])
+    if kw["coriolis"] is not None and topo[1] == "bounded" and rng.integers(3) == 0:
+        kw["beta"] = 2e-10 if kw["grid"] == "rectilinear" else 1e-6
     nsub = int(rng.integers(2, 12))
     c = cases.make_case(substeps=nsub, **kw)
     out = {}

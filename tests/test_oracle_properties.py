@@ -98,6 +98,8 @@ CROSS = {
     "bounded": dict(topo=("bounded", "bounded")),
     "channel": dict(topo=("periodic", "bounded")),
     "latlon": dict(topo=("bounded", "bounded"), grid="latlon"),
+    "beta_bounded": dict(topo=("bounded", "bounded"), beta=3e-10),
+    "beta_channel": dict(topo=("periodic", "bounded"), beta=-2e-10),
 }
 
 
@@ -111,6 +113,7 @@ def test_c_oracle_equals_numpy_restatement_bitwise(name, free_drift, oracle_lib)
     topo = tuple(0 if t == "periodic" else 1 for t in c["topo"])
     m = g.metrics()
     n = ONP.NP(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m.get("dx"), dy=m.get("dy"), per_j=m if m["kind"] == "per_j" else None)
+    n.f_rows = cases.coriolis_rows(c, g)
     n.f, n.top, n.bottom = c["coriolis"], ("const",) + tuple(c["top"]), ("semi", c["ue"], c["ve"], 1026.0, 5.5e-3)
     n.free_drift = free_drift
     for k, v in p.f.items():
@@ -125,6 +128,46 @@ def test_c_oracle_equals_numpy_restatement_bitwise(name, free_drift, oracle_lib)
     n.subcycle(c["dt"], 1, 6)
     for k in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
         assert np.array_equal(p.f[k], n.fld[k]), k
+
+
+def test_beta_plane_rows_and_limits(oracle_lib):
+    """BetaPlane: f = f0 + beta * y at the (Face, Center) / (Center, Face) nodes of each row (upstream Coriolis;
+    reference test matrix test/test_time_stepping.jl:35).  Known values of the host mirror's rows, beta = 0 is the
+    FPlane bit for bit, and the Coriolis term of one sub-step changes by exactly (f(y) - f0) * vbar * dtau."""
+    bp = csi.BetaPlane(latitude=45)
+    assert abs(bp.f0 - 2 * 7.292115e-5 * np.sin(np.pi / 4)) < 1e-19
+    assert abs(bp.beta - 2 * 7.292115e-5 * np.cos(np.pi / 4) / 6371e3) < 1e-25
+    assert abs(csi.FPlane(latitude=45).f - bp.f0) < 1e-19
+    g = csi.RectilinearGrid((8, 6), x=(0, 8e3), y=(1e3, 7e3), topology=(csi.Bounded, csi.Bounded), halo=(3, 3))
+    fu, fv = csi.BetaPlane(f0=1e-4, beta=2e-10).rows(g)
+    j = np.arange(1 - 3, 6 + 3 + 2)
+    assert fu.shape == fv.shape == (6 + 2 * 3 + 1,)
+    assert np.array_equal(fu, 1e-4 + 2e-10 * (1e3 + (j - 0.5) * 1e3)) and np.array_equal(fv, 1e-4 + 2e-10 * (1e3 + (j - 1) * 1e3))
+    gp = csi.RectilinearGrid((8, 6), x=(0, 8e3), y=(0, 6e3), topology=(csi.Periodic, csi.Periodic), halo=(3, 3))
+    fup, _ = csi.BetaPlane(f0=1e-4, beta=2e-10).rows(gp)
+    assert np.array_equal(fup[:3], fup[6:9]) and np.array_equal(fup[9:12], fup[3:6])      # halo rows image their owners
+    # beta = 0 == FPlane
+    out = {}
+    for beta in (None, 0.0):
+        c = cases.make_case(Nx=24, Ny=20, substeps=5, topo=("bounded", "bounded"), random_uv=0.05, beta=beta)
+        p = cases.oracle_problem(c)
+        p.time_step_momentum(c["dt"])
+        out[beta] = {k: p.f[k].copy() for k in ("u", "v", "s11")}
+    for k in out[None]:
+        assert np.array_equal(out[None][k], out[0.0][k]), k
+    # a beta plane rotates the ice differently where y is large: the u difference after one sub-step is the Coriolis
+    # difference, row by row (same sigma, same drag: only the -f x U term differs)
+    c0 = cases.make_case(Nx=24, Ny=20, substeps=1, topo=("periodic", "bounded"), patches=False, v0=0.2, u0=0.0, beta=None)
+    c1 = dict(c0, beta=4e-10)
+    u = {}
+    for key, c in (("f", c0), ("b", c1)):
+        p = cases.oracle_problem(c)
+        p.time_step_momentum(c["dt"])
+        u[key] = p.interior("u").copy()
+    d = u["b"] - u["f"]
+    yc = c0["g"].ynodes(csi.Center)
+    rel = d[2:-2, :] / (4e-10 * yc[2:-2, None])            # proportional to y (away from the walls, where vbar = v0)
+    assert np.all(d[2:-2] > 0) and rel.std() / rel.mean() < 2e-2, (rel.mean(), rel.std())
 
 
 def _bounded_advection_case(topo, scheme_seed=0):

@@ -77,6 +77,9 @@ PARTITIONS = [
     ("y2_periodic", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"))),
     ("y2_bounded", 1, 2, dict(Nx=40, Ny=48, topo=("bounded", "bounded"))),
     ("x2_channel_latlon", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "bounded"), grid="latlon")),
+    # BetaPlane: each tile evaluates f = f0 + beta * y on its own rows (halo rows: the neighbour's / the wrapped row's)
+    ("y2_beta_bounded", 1, 2, dict(Nx=40, Ny=48, topo=("bounded", "bounded"), beta=2e-10)),
+    ("y2_beta_periodic", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"), beta=2e-10)),
 ]
 
 

@@ -25,7 +25,8 @@ def tile_problem(case, Rx, Ry, rank, force_connected=False):
         p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"])
     else:
         p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, per_j=m, substeps=case["substeps"])
-    p.set_coriolis(case["coriolis"])
+    from cases import coriolis_rows
+    p.set_coriolis(case["coriolis"], rows=coriolis_rows(case, tg))
     if case["top"] is not None:
         p.set_stress("top", O.STRESS_CONST, tau=case["top"])
     if case["bottom"] == "semi":
