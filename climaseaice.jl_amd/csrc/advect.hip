@@ -3,7 +3,8 @@
 //   k_tendencies  _compute_dynamic_tracer_tendencies!  tracer_tendency_kernel_functions.jl:27-45
 //                 = - horizontal_div_Uc (sea_ice_advection.jl:51-54) with the upstream
 //                 Oceananigans upwind-biased reconstructions (WENO(order = 5 | 7) in the WENO-Z
-//                 form, UpwindBiased(order = 5), first-order upwind).
+//                 form, UpwindBiased(order = 5), first-order upwind), their
+//                 order reduction next to walls and immersed cells, zero flux through immersed faces.
 //   k_tracer_step _dynamic_step_tracers!               sea_ice_fe_step.jl:56-82
 //                 (RK3: h^n, aice^n = Psi^-, sea_ice_rk_substep.jl:140-149)
 //
@@ -90,16 +91,28 @@ __device__ __forceinline__ int reduced_buffer(int B, int idx, int N, bool left, 
     return B;
 }
 
+// Immersed boundaries (upstream immersed reconstruction, recalled; oracle/csi_oracle.c::reduced_buffer_immersed):
+// the scheme with buffer B needs the 2B cells idx-B .. idx+B-1 around the face to be active (not immersed, not
+// beyond a wall); here as distances: dl = cells below the face up to the first inactive one, dr likewise above.
+__device__ __forceinline__ int reduced_buffer_immersed(const GridDev& g, int B, int i, int j, bool along_y) {
+    int dl = B, dr = B;
+    for (int k = B; k >= 1; --k) {
+        if (along_y ? inactive_cell(g, i, j - k) : inactive_cell(g, i - k, j)) dl = k - 1;
+        if (along_y ? inactive_cell(g, i, j + k - 1) : inactive_cell(g, i + k - 1, j)) dr = k - 1;
+    }
+    const int b = dl < dr ? dl : dr;
+    return b < 1 ? 1 : b;
+}
+
 // reconstruct at a face from the line of values through `base` (cell on the high side of the
 // face); st = element stride of the line; left bias (vel > 0): upwind cell is base - st.
-// idx / N / walls: position of the face along the line for the boundary-order reduction.
+// B: buffer of the scheme to use at this face (after the boundary-order reduction).
 template <int SCHEME>
-__device__ __forceinline__ double reconstruct(const double* base, long st, bool left, int idx, int N, bool wall_lo, bool wall_hi) {
+__device__ __forceinline__ double reconstruct(const double* base, long st, bool left, int B) {
     const double* up = left ? base - st : base;
     const long s = left ? st : -st;
     if (SCHEME == 1) return up[0];
     constexpr bool WENO = SCHEME > 0;
-    const int B = (wall_lo | wall_hi) ? reduced_buffer(SCHEME == 7 ? 4 : 3, idx, N, left, wall_lo, wall_hi) : (SCHEME == 7 ? 4 : 3);
     if (B == 1) return up[0];
     if (B == 2) {
         double p[3];
@@ -117,6 +130,17 @@ __device__ __forceinline__ double reconstruct(const double* base, long st, bool 
 #pragma unroll
     for (int k = 0; k < 7; ++k) p[k] = up[(k - 3) * s];
     return weno7(p);
+}
+// buffer at face (i, j) of the x / y direction: immersed grid -> the immersed rule (it covers the walls: cells beyond
+// them are inactive); else the topological rule next to walls; else the full scheme
+template <int SCHEME>
+__device__ __forceinline__ int buffer_at(const GridDev& g, int i, int j, bool along_y, bool left) {
+    constexpr int B0 = SCHEME == 7 ? 4 : (SCHEME == 1 ? 1 : 3);
+    if (SCHEME == 1) return 1;
+    if (g.has_mask) return reduced_buffer_immersed(g, B0, i, j, along_y);
+    const bool wl = (along_y ? g.ylo : g.xlo) == SIDE_WALL, wh = (along_y ? g.yhi : g.xhi) == SIDE_WALL;
+    if (!(wl | wh)) return B0;
+    return reduced_buffer(B0, along_y ? j : i, along_y ? g.Ny : g.Nx, left, wl, wh);
 }
 
 __device__ __forceinline__ double dxf_row(const GridDev& g, int j) { return g.metric_kind == 0 ? g.dx : g.dxf[j]; }
@@ -138,21 +162,23 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
         if (ty < TY && j <= g.Ny) {
             const double uu = A.u(i, j);
             const bool left = uu > 0;
-            const bool wl = g.xlo == SIDE_WALL, wh = g.xhi == SIDE_WALL;
-            const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left, i, g.Nx, wl, wh);
-            const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left, i, g.Nx, wl, wh);
-            sFxh[ty][tx] = g.dy * uu * ch;
-            sFxa[ty][tx] = g.dy * uu * ca;
+            const int B = buffer_at<SCHEME>(g, i, j, false, left);
+            const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left, B);
+            const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left, B);
+            const bool closed = g.has_mask && peripheral_u(g, i, j);          // conditional_flux_fcc
+            sFxh[ty][tx] = closed ? 0.0 : g.dy * uu * ch;
+            sFxa[ty][tx] = closed ? 0.0 : g.dy * uu * ca;
         }
         if (tx < TX && i <= g.Nx) {
             const double vv = A.v(i, j);
             const bool left = vv > 0;
-            const bool wl = g.ylo == SIDE_WALL, wh = g.yhi == SIDE_WALL;
-            const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left, j, g.Ny, wl, wh);
-            const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left, j, g.Ny, wl, wh);
+            const int B = buffer_at<SCHEME>(g, i, j, true, left);
+            const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left, B);
+            const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left, B);
             const double dxf = dxf_row(g, j);
-            sFyh[ty][tx] = dxf * vv * ch;
-            sFya[ty][tx] = dxf * vv * ca;
+            const bool closed = g.has_mask && peripheral_v(g, i, j);          // conditional_flux_cfc
+            sFyh[ty][tx] = closed ? 0.0 : dxf * vv * ch;
+            sFya[ty][tx] = closed ? 0.0 : dxf * vv * ca;
         }
     }
     __syncthreads();

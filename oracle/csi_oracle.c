@@ -652,13 +652,26 @@ static int reduced_buffer(int B, int idx, int N, int left, int wall_lo, int wall
     }
     return B;
 }
-/* reconstruct c at a face from a 1-D line of values; `up` is the upwind cell value index
+/* Immersed boundaries (ImmersedBoundaryGrid; upstream immersed reconstruction, recalled -- SURVEY.md App. B, used by
+ * the reference through _advective_tracer_flux_x/y, sea_ice_advection.jl:1-5,51-54): a biased scheme with buffer B is
+ * used at a face only if none of the 2B cells i-B .. i+B-1 around it (the union of its left and right stencils) is
+ * inactive -- immersed OR beyond a wall --, otherwise its buffer scheme is tried, down to first-order upwind, which
+ * is never reduced.  This replaces the topological rule above on such a grid.  dir: 0 along x, 1 along y. */
+static int reduced_buffer_immersed(const ora_problem* g, int B, int i, int j, int dir) {
+    while (B > 1) {
+        int near = 0;
+        for (int k = -B; k <= B - 1; ++k) near |= dir == 0 ? inactive_cell(g, i + k, j) : inactive_cell(g, i, j + k);
+        if (!near) break;
+        --B;
+    }
+    return B;
+}
+/* reconstruct c at a face from a 1-D line of values with the scheme of buffer B; `up` is the upwind cell value index
  * stepping `st` (= +1 for left bias reading towards increasing index). */
-static double reconstruct(int scheme, const double* line, int64_t up, int64_t st, int idx, int N, int left, int wall_lo, int wall_hi) {
+static double reconstruct(int scheme, const double* line, int64_t up, int64_t st, int B) {
     double p[7];
     if (scheme == 1) return line[up];
     const int weno = scheme > 0;
-    const int B = reduced_buffer(scheme == 7 ? 4 : 3, idx, N, left, wall_lo, wall_hi);
     if (B == 1) return line[up];
     if (B == 2) {
         for (int k = 0; k < 3; ++k) p[k] = line[up + (k - 1) * st];
@@ -671,20 +684,29 @@ static double reconstruct(int scheme, const double* line, int64_t up, int64_t st
     for (int k = 0; k < 7; ++k) p[k] = line[up + (k - 3) * st];
     return weno7(p);
 }
-/* _advective_tracer_flux_x = Ax^{fcc} * U * c~ (upstream; bias = left iff U > 0) */
+static int buffer_at(const ora_problem* g, int scheme, int i, int j, int dir, int left) {
+    const int B0 = scheme == 7 ? 4 : (scheme == 1 ? 1 : 3);
+    if (g->has_mask) return reduced_buffer_immersed(g, B0, i, j, dir);
+    const int topo = dir == 0 ? g->topo_x : g->topo_y;
+    return reduced_buffer(B0, dir == 0 ? i : j, dir == 0 ? g->Nx : g->Ny, left, wall_lo(topo), wall_hi(topo));
+}
+/* _advective_tracer_flux_x = Ax^{fcc} * U * c~ (upstream; bias = left iff U > 0); on an immersed grid
+ * conditional_flux_fcc: zero at peripheral faces */
 double ora_weno_flux_x(const ora_problem* g, int scheme, ora_field c, int i, int j) {
     double uu = AT(g, g->u, i, j);
     const double* base = &AT(g, c, i, j);   /* cell i; upwind of a left-biased face i is cell i-1 */
-    const int wl = wall_lo(g->topo_x), wh = wall_hi(g->topo_x);
-    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1, i, g->Nx, 1, wl, wh) : reconstruct(scheme, base, 0, -1, i, g->Nx, 0, wl, wh);
+    if (g->has_mask && ora_peripheral_u(g, i, j)) return 0.0;
+    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1, buffer_at(g, scheme, i, j, 0, 1))
+                         : reconstruct(scheme, base, 0, -1, buffer_at(g, scheme, i, j, 0, 0));
     return ora_dy(g, F_, C_, i, j) * uu * ct;    /* Ax = dy * dz, dz = 1 */
 }
 double ora_weno_flux_y(const ora_problem* g, int scheme, ora_field c, int i, int j) {
     double vv = AT(g, g->v, i, j);
     const double* base = &AT(g, c, i, j);
     int64_t ld = c.ld;
-    const int wl = wall_lo(g->topo_y), wh = wall_hi(g->topo_y);
-    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld, j, g->Ny, 1, wl, wh) : reconstruct(scheme, base, 0, -ld, j, g->Ny, 0, wl, wh);
+    if (g->has_mask && ora_peripheral_v(g, i, j)) return 0.0;
+    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld, buffer_at(g, scheme, i, j, 1, 1))
+                         : reconstruct(scheme, base, 0, -ld, buffer_at(g, scheme, i, j, 1, 0));
     return ora_dx(g, C_, F_, i, j) * vv * ct;    /* Ay = dx^{cf} * dz */
 }
 /* horizontal_div_Uc, sea_ice_advection.jl:51-54 ; G = -div, tracer_tendency_kernel_functions.jl:39-42 */

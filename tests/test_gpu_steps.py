@@ -92,6 +92,48 @@ def test_tracer_tendencies_next_to_walls_bitwise(topo, scheme, oracle_lib):
         assert abs(got.sum()) <= 1e-9 * np.abs(got).sum()           # closed walls: flux form conserves
 
 
+@pytest.mark.parametrize("scheme", [7, 5, -5, 1])
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("periodic", "bounded"), ("bounded", "bounded")])
+def test_tracer_tendencies_next_to_immersed_cells_bitwise(topo, scheme, oracle_lib):
+    """ImmersedBoundaryGrid: closed faces next to land and the order reduction of the reconstructions around immersed
+    cells (and walls, which the immersed rule covers): HIP kernel == oracle bit for bit; land cells poisoned with 1e300
+    never reach a wet cell's tendency."""
+    rng = np.random.default_rng(19)
+    c = cases.make_case(Nx=150, Ny=45, H=4, topo=topo, spacing=1000.0, patches=False, noise=0.0, land=0.3)
+    wet = c["mask"].astype(bool)
+    c["u"] = 0.4 * rng.standard_normal(c["u"].shape)
+    c["v"] = 0.4 * rng.standard_normal(c["v"].shape)
+    if topo[0] == "bounded":
+        c["u"][:, 0] = 0.0; c["u"][:, -1] = 0.0
+    if topo[1] == "bounded":
+        c["v"][0, :] = 0.0; c["v"][-1, :] = 0.0
+    c["h"] = np.where(wet, 0.3 + 0.2 * rng.random(wet.shape), 0.0)
+    c["a"] = np.where(wet, np.clip(0.5 + 0.6 * rng.random(wet.shape), 0, 1), 0.0)
+    p = cases.oracle_problem(c)
+    m = cases.csi_model(c, mode="fast")
+    p.compute_tracer_tendencies(scheme)
+    m.ctx.call("csi_compute_tracer_tendencies", scheme)
+    m.synchronize()
+    first = {}
+    for k, f in (("Gh", m.timestepper.Gn.h), ("Ga", m.timestepper.Gn.aice)):
+        got, want = f.interior_numpy(), p.interior(k)
+        assert np.all(np.isfinite(got)) and np.abs(want).max() > 0
+        assert np.array_equal(got, want), (k, np.abs(got - want).max(), np.argwhere(got != want)[:4])
+        assert np.all(got[~wet] == 0.0)
+        assert abs(got.sum()) <= 1e-9 * np.abs(got).sum()
+        first[k] = got.copy()
+    # poison the land (interior and halo images), recompute: wet cells unchanged
+    for fld in (m.ice_thickness, m.ice_concentration):
+        a = fld.interior_numpy().copy()
+        a[~wet] = 1e300
+        fld.set(a)
+        m.ctx.call("csi_fill_halo_local", csi._lib.F["H" if fld is m.ice_thickness else "A"])
+    m.ctx.call("csi_compute_tracer_tendencies", scheme)
+    m.synchronize()
+    for k, f in (("Gh", m.timestepper.Gn.h), ("Ga", m.timestepper.Gn.aice)):
+        assert np.array_equal(f.interior_numpy()[wet], first[k][wet]), k
+
+
 def test_advection_conserves_volume_at_full_size():
     """Config 2 at 512^2: flux-form divergence on a periodic grid conserves sum(h) and sum(aice) to rounding
     (a size-independent property, checked without the oracle)."""

@@ -238,6 +238,78 @@ def test_boundary_order_reduction_rule(scheme, oracle_lib):
         assert np.array_equal(got[first_order], upwind[first_order])
 
 
+def _masked_advection_case(topo, seed=0):
+    rng = np.random.default_rng(11 + seed)
+    c = cases.make_case(Nx=48, Ny=40, H=4, topo=topo, spacing=1000.0, patches=False, noise=0.0, land=0.3)
+    wet = c["mask"].astype(bool)
+    c["u"] = 0.4 * rng.standard_normal(c["u"].shape)
+    c["v"] = 0.4 * rng.standard_normal(c["v"].shape)
+    if topo[0] == "bounded":
+        c["u"][:, 0] = 0.0; c["u"][:, -1] = 0.0
+    if topo[1] == "bounded":
+        c["v"][0, :] = 0.0; c["v"][-1, :] = 0.0
+    c["h"] = np.where(wet, 0.3 + 0.2 * rng.random(wet.shape), 0.0)
+    c["a"] = np.where(wet, np.clip(0.5 + 0.6 * rng.random(wet.shape), 0, 1), 0.0)
+    return c
+
+
+@pytest.mark.parametrize("scheme", [7, 5, -5, 1])
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("periodic", "bounded"), ("bounded", "bounded")])
+def test_advection_next_to_immersed_cells(topo, scheme, oracle_lib):
+    """ImmersedBoundaryGrid (the reference's horizontal_div_Uc goes through upstream's _advective_tracer_flux_x/y,
+    sea_ice_advection.jl:1-5,51-54): no flux through faces next to land, and a reconstruction never reads a land
+    cell (its order drops until the stencil fits: recalled upstream rule).  Land cells poisoned with
+    1e300 therefore change nothing, whatever the velocities at the coast; the scheme conserves the tracer."""
+    c = _masked_advection_case(topo)
+    wet = c["mask"].astype(bool)
+    G = {}
+    for poison in (0.0, 1e300):
+        p = cases.oracle_problem(c)
+        for k in ("h", "aice"):
+            p.interior(k)[~wet] = poison
+        for k in ("h", "aice"):                         # halos again (update_state would wipe the poison)
+            p.L.ora_fill_halo_center(p.ptr, p.field_struct(k))
+        p.compute_tracer_tendencies(scheme)
+        G[poison] = {k: p.interior(k).copy() for k in ("Gh", "Ga")}
+    for k in ("Gh", "Ga"):
+        a, b = G[0.0][k], G[1e300][k]
+        assert np.all(np.isfinite(b[wet])), (k, topo, scheme)
+        assert np.array_equal(a[wet], b[wet]), (k, topo, scheme, np.abs(a[wet] - b[wet]).max())
+        assert np.abs(a[wet]).max() > 0
+        assert abs(a[wet].sum()) <= 1e-9 * np.abs(a[wet]).sum(), (k, a[wet].sum())      # uniform cells: plain sums
+        assert np.all(a[~wet] == 0.0)                                                    # every face of a land cell is closed
+
+
+@pytest.mark.parametrize("scheme", [7, 5, -5])
+def test_immersed_order_reduction_rule(scheme, oracle_lib):
+    """Which order each face gets next to an immersed cell, read off a cubic profile on a periodic line with one land
+    cell at i = L: buffer B (order 2B-1) needs the 2B cells i-B .. i+B-1 around face i to be wet.  A cubic is exact
+    for order >= 5 linear weights only approximately under WENO, so the test uses the schemes' exactness classes on a
+    LINEAR profile (orders >= 3 exact, order 1 = upwind value) plus the count of first-order faces: faces L-1 and L+2
+    (one wet cell between face and land on one side) are first order, L and L+1 are closed, the rest exact."""
+    N, L = 24, 12
+    for sign in (+1.0, -1.0):
+        c = cases.make_case(Nx=N, Ny=8, H=4, topo=("periodic", "periodic"), spacing=1.0, patches=False, noise=0.0)
+        prof = 1.0 + 0.25 * (np.arange(N) + 0.5)
+        c["h"] = np.broadcast_to(prof[None, :], c["h"].shape).copy()
+        c["a"] = np.ones_like(c["h"])
+        c["u"] = sign * np.ones_like(c["u"]); c["v"] = np.zeros_like(c["v"])
+        wet = np.ones((8, N), dtype=np.uint8); wet[:, L - 1] = 0          # land cell i = L (1-based)
+        c["mask"] = wet
+        c["u"][:, L - 1] = 0.0; c["u"][:, L] = 0.0                        # its two faces L, L+1
+        p = cases.oracle_problem(c)
+        faces = np.arange(6, N - 4)                                       # away from the periodic seam
+        got = np.array([p.L.ora_weno_flux_x(p.ptr, scheme, p.field_struct("h"), int(i), 3) for i in faces]) / sign
+        exact = 1.0 + 0.25 * (faces - 1.0)
+        upwind = prof[faces - 2] if sign > 0 else prof[faces - 1]
+        closed = (faces == L) | (faces == L + 1)
+        first = (faces == L - 1) | (faces == L + 2)
+        assert np.all(got[closed] == 0.0)
+        assert np.array_equal(got[first], upwind[first]), (got[first], upwind[first])
+        rest = ~(closed | first)
+        assert np.allclose(got[rest], exact[rest], rtol=0, atol=1e-13)
+
+
 def test_stress_balance_free_drift_closed_form(oracle_lib):
     """StressBalanceFreeDrift (stress_balance_free_drift.jl:73-95): where the ice is marginal (present, but below
     minimum_mass / minimum_concentration) the velocity after a step is U_e - tau / sqrt(rho_e C_D |tau|), whatever
