@@ -578,7 +578,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
-                              has_walls(c) || masked || force, masked, force, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
             m += 2; s += 2;
         } else if (masked || force) {
             // the one-sub-step kernel takes neither masks nor array-valued forcing: a trailing single sub-step runs the
@@ -672,7 +672,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // three kernels inside run_fused)
     const int pfk = pair_forcing_kind(P);
     const bool pair_only = P.g.has_mask || pfk == 1;      // configurations only the two-sub-steps kernel takes
-    const bool fuse = fast && c->fusion && substeps > 0 && !c->free_drift &&     // free drift: three-kernel path
+    const bool fuse = fast && c->fusion && substeps > 0 &&
                       (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                  : fused_supported(P));
     if (fuse) {

@@ -32,11 +32,11 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
              FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUTP, FP_V_OUTP,                                // 5 outputs (parent addresses), contiguous
              FP_U_OUT, FP_V_OUT, FP_S11_OUT0, FP_S22_OUT0, FP_S12_OUT0,                               // (0,0)-offset addresses for stores with halo images
              FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_MASK,
-             FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_COUNT };   // forcing arrays (parent addresses)                            // FP_MASK: parent address of the uint8 mask
+             FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_FD_U, FP_FD_V, FP_COUNT };   // forcing arrays (parent addresses)                            // FP_MASK: parent address of the uint8 mask
 enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_LD_C, FI_LD_F,
              FI_RS, FI_R1 = FI_RS + 4, FI_R1C = FI_R1 + 4, FI_R2 = FI_R1C + 4, FI_IMU = FI_R2 + 4, FI_IMV = FI_IMU + 4,
              FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX,
-             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_COUNT };
+             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_FREE_DRIFT, FI_COUNT };
 struct FusedTable {
     double K[FK_COUNT];
     unsigned long P[FP_COUNT];
@@ -54,9 +54,10 @@ void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst
 // the wave tiles decompose, a_j0 / a_j1 = the first sub-step's stress rows, sigma image specs.
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
                            const ImageSpec& ims12, FusedTable* host_table);
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, int nstrips,
-                       int nchunks, int rows, int write_diag, hipStream_t s);
-// array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
+                       int nstrips, int nchunks, int rows, int write_diag, hipStream_t s);
+// array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported;
+// StressBalanceFreeDrift (P.free_drift: free-drift velocity arrays P.ufd / P.vfd) also selects the FORCE variant
 int pair_forcing_kind(const EvpDev& P);
 // bottom SemiImplicitStress with array-valued ocean velocities: the cross component averaged to the u / v points
 // (ubar at v points from fu, vbar at u points from fv), once per sub-cycle (evp_fast.hip)

@@ -192,6 +192,11 @@ __device__ __forceinline__ double vel_update(const VelConst& k, double w, double
                                              double ext, double imt, double exb, double imb, bool peripheral) {
     return vel_update_avg(k, w, wn, avg2(m_a, m_b), avg2(a_a, a_b), avg2(al_a, al_b), div, cor, ext, imt, exb, imb, peripheral);
 }
+__device__ __forceinline__ double vel_update_fd(const VelConst& k, double w, double wn, double m_a, double m_b, double a_a, double a_b,
+                                                double al_a, double al_b, double div, double cor,
+                                                double ext, double imt, double exb, double imb, bool peripheral, double wf) {
+    return vel_update_avg_fd(k, w, wn, avg2(m_a, m_b), avg2(a_a, a_b), avg2(al_a, al_b), div, cor, ext, imt, exb, imb, peripheral, wf);
+}
 
 // d_j sigma_1j = E (s11_i - s11_{i-1}) + Fn s12(j+1) - Fs s12(j)          (constant dy)
 __device__ __forceinline__ double div1(double E, double Fn, double Fs, double s11_0, double s11_m, double s12_p, double s12_0) {

@@ -298,7 +298,8 @@ int pair_forcing_kind(const EvpDev& P) {
     if (b.kind == 2) return -1;
     if (t_arr && (t.fu.ld != lf || t.fv.ld != lc)) return -1;
     if (b_arr && ((b.ue_kind == 2 && b.fu.ld != lf) || (b.ve_kind == 2 && b.fv.ld != lc))) return -1;
-    return (t_arr || b_arr) ? 1 : 0;
+    if (P.free_drift && (P.ufd.ld != lf || P.vfd.ld != lc)) return -1;
+    return (t_arr || b_arr || P.free_drift) ? 1 : 0;
 }
 
 void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, FusedTable* t) {
@@ -309,6 +310,8 @@ void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u,
     t->I[FI_BOT_VEK] = P.bot.kind == 3 ? P.bot.ve_kind : 0;
     if (P.bot.kind == 3 && P.bot.ue_kind == 2) { Q[FP_FB_U] = parent_addr(P.bot.fu, g); Q[FP_FB_UBAR] = parent_addr(ubar_v, g); }
     if (P.bot.kind == 3 && P.bot.ve_kind == 2) { Q[FP_FB_V] = parent_addr(P.bot.fv, g); Q[FP_FB_VBAR] = parent_addr(vbar_u, g); }
+    t->I[FI_FREE_DRIFT] = P.free_drift ? 1 : 0;
+    if (P.free_drift) { Q[FP_FD_U] = parent_addr(P.ufd, g); Q[FP_FD_V] = parent_addr(P.vfd, g); }
 }
 
 bool fused_supported(const EvpDev& P) {
@@ -318,7 +321,7 @@ bool fused_supported(const EvpDev& P) {
     if (P.un.ld != lf || P.s12.ld != lf) return false;
     // first version: no immersed mask, forcing given by numbers (the benchmark configuration); everything else
     // runs the three-kernel FAST path
-    if (P.g.has_mask) return false;
+    if (P.g.has_mask || P.free_drift) return false;
     // per-row metrics with a periodic y side: ring rows beyond the seam would not reproduce their owners
     if (P.g.metric_kind != 0 && (P.g.ylo == SIDE_PERIODIC || P.g.yhi == SIDE_PERIODIC)) return false;
     auto ok = [](const StressDev& s) {

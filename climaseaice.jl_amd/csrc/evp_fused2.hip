@@ -34,7 +34,7 @@ namespace fused {
 __device__ unsigned long long g_probe[4096 * 16];
 #endif
 
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD>
 __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                int blocks_per_xcd, int write_diag) {
     const int b = (int)blockIdx.x;
@@ -304,10 +304,12 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             F.b_tau_u = T->K[FK_BOT_TAU_U]; F.b_we_u = T->K[FK_BOT_UE]; F.b_wb_u = T->K[FK_BOT_VE];
             F.t_tau_v = T->K[FK_TOP_TAU_V]; F.t_we_v = T->K[FK_TOP_VE]; F.t_wb_v = T->K[FK_TOP_UE];
             F.b_tau_v = T->K[FK_BOT_TAU_V]; F.b_we_v = T->K[FK_BOT_VE]; F.b_wb_v = T->K[FK_BOT_UE];
+            F.fd_u = 0.0; F.fd_v = 0.0; F.fd = FD;
         };
         Forcing FA, FB;
         numbers(FA);
         double fb[6] = {0, 0, 0, 0, 0, 0};          // FORCE: B's array values, loaded early, merged after stage A
+        unsigned fd_ub = 0, fd_vb = 0;
         if (FORCE) {
             // (B's first rows of a tile only fill its window: clamp their row to the array instead of running off it)
             const unsigned below = (unsigned)(r - (1 - HyW));                                     // rows between r and the array's first row
@@ -325,6 +327,10 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             if (T->I[FI_BOT_VEK] == 2) {       // v_e array: own component at v points, averaged to u points
                 FA.b_we_v = ldg(T->P[FP_FB_V], va); FA.b_wb_u = ldg(T->P[FP_FB_VBAR], ua);
                 fb[4] = ldg(T->P[FP_FB_V], vb); fb[5] = ldg(T->P[FP_FB_VBAR], ub);
+            }
+            if (FD) {                          // StressBalanceFreeDrift: free-drift velocities (once per sub-cycle, csi_abi.hip)
+                FA.fd_u = ldg(T->P[FP_FD_U], ua); FA.fd_v = ldg(T->P[FP_FD_V], va);
+                fd_ub = ub; fd_vb = vb;            // B's values are loaded after stage A: they are not needed before B's velocity update
             }
         }
         A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
@@ -350,6 +356,7 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             if (T->I[FI_TOP_KIND] == 2) { FB.t_tau_u = fb[0]; FB.t_tau_v = fb[1]; }
             if (T->I[FI_BOT_UEK] == 2) { FB.b_we_u = fb[2]; FB.b_wb_v = fb[3]; }
             if (T->I[FI_BOT_VEK] == 2) { FB.b_we_v = fb[4]; FB.b_wb_u = fb[5]; }
+            if (FD) { FB.fd_u = ldg(T->P[FP_FD_U], fd_ub); FB.fd_v = ldg(T->P[FP_FD_V], fd_vb); }
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
@@ -430,25 +437,32 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 #endif
 
 // One translation unit per variant so that the instantiations compile in parallel.  CSI_PAIR_VARIANT:
-// 0 plain, 1 walls, 2 walls + immersed mask, 3 walls + array-valued forcing, 4 walls + mask + array-valued forcing.
+// 0 plain, 1 walls, 2 walls + immersed mask, 3 walls + array-valued forcing, 4 walls + mask + array-valued forcing,
+// 5 / 6: 3 / 4 with StressBalanceFreeDrift (free-drift velocity arrays).
 #ifndef CSI_PAIR_VARIANT
 #define CSI_PAIR_VARIANT 0
 #endif
 #if CSI_PAIR_VARIANT == 0
 #define CSI_PAIR_NAME launch_fused_pair_plain
-#define CSI_PAIR_FLAGS false, false, false
+#define CSI_PAIR_FLAGS false, false, false, false
 #elif CSI_PAIR_VARIANT == 1
 #define CSI_PAIR_NAME launch_fused_pair_walls
-#define CSI_PAIR_FLAGS true, false, false
+#define CSI_PAIR_FLAGS true, false, false, false
 #elif CSI_PAIR_VARIANT == 2
 #define CSI_PAIR_NAME launch_fused_pair_mask
-#define CSI_PAIR_FLAGS true, true, false
+#define CSI_PAIR_FLAGS true, true, false, false
 #elif CSI_PAIR_VARIANT == 3
 #define CSI_PAIR_NAME launch_fused_pair_force
-#define CSI_PAIR_FLAGS true, false, true
-#else
+#define CSI_PAIR_FLAGS true, false, true, false
+#elif CSI_PAIR_VARIANT == 4
 #define CSI_PAIR_NAME launch_fused_pair_mask_force
-#define CSI_PAIR_FLAGS true, true, true
+#define CSI_PAIR_FLAGS true, true, true, false
+#elif CSI_PAIR_VARIANT == 5
+#define CSI_PAIR_NAME launch_fused_pair_force_fd
+#define CSI_PAIR_FLAGS true, false, true, true
+#else
+#define CSI_PAIR_NAME launch_fused_pair_mask_force_fd
+#define CSI_PAIR_FLAGS true, true, true, true
 #endif
 void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
                    int write_diag, hipStream_t s) {
@@ -467,9 +481,13 @@ void launch_fused_pair_walls(const FusedTable*, bool, bool, int, int, int, int, 
 void launch_fused_pair_mask(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
 void launch_fused_pair_force(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
 void launch_fused_pair_mask_force(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, int nstrips,
-                       int nchunks, int rows, int write_diag, hipStream_t s) {
-    if (force && mask) launch_fused_pair_mask_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+void launch_fused_pair_force_fd(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force_fd(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
+                       int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
+    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+    else if (free_drift) launch_fused_pair_force_fd(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+    else if (force && mask) launch_fused_pair_mask_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
     else if (force) launch_fused_pair_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
     else if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
     else if (walls) launch_fused_pair_walls(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);

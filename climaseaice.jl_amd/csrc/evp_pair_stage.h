@@ -10,7 +10,12 @@ constexpr int P_LO = 4, P_HI = 59, P_W = P_HI - P_LO + 1;
 
 // what fm::ext_stress needs at a u point and at a v point, for the top (t_) and bottom (b_) stress: tau (constant /
 // array-valued stress), we (external velocity, own component), wb (cross component averaged to the point)
-struct Forcing { double t_tau_u, t_we_u, t_wb_u, b_tau_u, b_we_u, b_wb_u, t_tau_v, t_we_v, t_wb_v, b_tau_v, b_we_v, b_wb_v; };
+struct Forcing {
+    double t_tau_u, t_we_u, t_wb_u, b_tau_u, b_we_u, b_wb_u, t_tau_v, t_we_v, t_wb_v, b_tau_v, b_we_v, b_wb_v;
+    // StressBalanceFreeDrift: velocity of marginal ice at the u / v point being updated (fd: enabled, wave-uniform)
+    double fd_u, fd_v;
+    bool fd;
+};
 
 struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; };
 
@@ -99,7 +104,8 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
-                W_0 = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
+                W_0 = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
+                           : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::avg2(W_0, from_right(W_0));
             {
@@ -111,7 +117,8 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
                 const double cor = -coef<UNI>(T, FC_FV, j) * ubar;
-                second = fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
+                second = F.fd ? fm::vel_update_fd(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
+                              : fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
             XW_next = XW_0;
@@ -126,7 +133,8 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
                 const double cor = -coef<UNI>(T, FC_FV, r) * ubar;
-                W_0 = fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
+                W_0 = F.fd ? fm::vel_update_fd(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
+                           : fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::avg2(from_left(W_0), W_0);
             {
@@ -138,7 +146,8 @@ struct Stage {
                 fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
                 fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
-                second = fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
+                second = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
+                              : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
             XW_next = XW_0;

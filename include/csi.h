@@ -251,7 +251,8 @@ int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nf
  * split_explicit_momentum_equations.jl:219-228).  kind 0 (default): `free_drift = nothing`, zero.  kind 1:
  * StressBalanceFreeDrift built on the model's own top / bottom stresses (stress_balance_free_drift.jl:61-121,
  * materialize_free_drift :44-46): exactly one of them must be a SemiImplicitStress, U = U_e - tau / sqrt(C |tau|).
- * Evaluated once per sub-cycle; runs on the three-kernel paths. */
+ * Evaluated once per sub-cycle into library-owned arrays (it depends on the forcing only); the three-kernel paths and
+ * the two-sub-steps-per-launch kernel read them. */
 int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
 
 /* FAST mode only.  level 0: always the three-kernel path.  level 1: a sub-step is ONE launch of the fused

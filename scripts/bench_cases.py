@@ -17,6 +17,9 @@ CONFIGS = {
     "masked channel (30 % land, config 5 style)": dict(topo=("periodic", "bounded"), land=0.3),
     "coupled channel (wind-stress arrays, ocean-velocity arrays, 30 % land)": dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True),
     "coupled periodic (arrays, no land)": dict(topo=("periodic", "periodic"), field_forcing=True),
+    "OMIP style (arrays, 30 % land, StressBalanceFreeDrift; test/distributed_tests_utils.jl:190-212)":
+        dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True),
+    "beta-plane channel (per-row f on uniform metrics)": dict(topo=("periodic", "bounded"), beta=1.6e-11),
 }
 if len(sys.argv) > 2:
     CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}

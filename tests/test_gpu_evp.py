@@ -55,11 +55,14 @@ CASES = {
     "forced_seams": dict(Nx=150, Ny=70, topo=("periodic", "periodic"), patches=True, field_forcing=True, random_uv=0.03),
     "coupled_channel": dict(Nx=100, Ny=90, topo=("periodic", "bounded"), patches=True, field_forcing=True, random_uv=0.03, land=0.3),
     "coupled_latlon": dict(Nx=64, Ny=72, topo=("bounded", "bounded"), grid="latlon", patches=True, field_forcing=True, random_uv=0.03, land=0.2),
-    # StressBalanceFreeDrift for marginal ice (three-kernel paths only)
+    # StressBalanceFreeDrift for marginal ice (two-sub-steps kernel, FORCE variant; the reference's own tripolar test
+    # combines it with stress / ocean-velocity arrays and an immersed grid, test/distributed_tests_utils.jl:190-212)
     "free_drift": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05, ue=0.05, ve=-0.02, top=(0.03, -0.02),
                        free_drift=True),
     "free_drift_coupled": dict(Nx=60, Ny=44, topo=("periodic", "bounded"), patches=True, random_uv=0.03, field_forcing=True,
                                free_drift=True),
+    "free_drift_omip": dict(Nx=120, Ny=84, topo=("periodic", "bounded"), patches=True, random_uv=0.03, field_forcing=True,
+                            free_drift=True, land=0.25),
     # BetaPlane: f = f0 + beta * y per row (test/test_time_stepping.jl:35); per-row coefficient instantiation of the
     # FAST kernels on a uniform grid (halo rows of a periodic y side carry the wrapped row's f)
     "beta_bounded": dict(Nx=100, Ny=90, topo=("bounded", "bounded"), patches=True, random_uv=0.05, beta=2e-10),
@@ -69,7 +72,7 @@ CASES = {
     "beta_masked": dict(Nx=96, Ny=80, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=2e-10, land=0.25),
 }
 MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
-          "beta_masked"}
+          "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
 THREE_KERNEL_ONLY = set()
 
 
@@ -443,6 +446,10 @@ def test_fused_paths_fuzz_bitwise(seed):
               grid=("rectilinear", "latlon")[rng.integers(2)] if topo[1] == "bounded" else "rectilinear",
               field_forcing=bool(rng.integers(2)), land=(0.0, 0.25)[rng.integers(2)],
               coriolis=(1e-4, None)[rng.integers(2)], pressure=("replacement", "ice_strength")[rng.integers(2)])
+    if rng.integers(4) == 0:
+        kw["free_drift"] = True
+        if not kw["field_forcing"]:
+            kw.update(ue=0.05, ve=-0.02, top=(0.03, -0.02))
     if kw["coriolis"] is not None and topo[1] == "bounded" and rng.integers(3) == 0:
         kw["beta"] = 2e-10 if kw["grid"] == "rectilinear" else 1e-6
     nsub = int(rng.integers(2, 12))
