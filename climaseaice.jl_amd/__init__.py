@@ -12,6 +12,7 @@ from .dynamics import (Auxiliaries, BetaPlane, ElastoViscoPlasticRheology, FPlan
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
 from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected, Periodic,
                     RectilinearGrid, RightConnected, TileGrid)
-from .model import SeaIceModel, SlabThermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state
+from .model import (MeltingConstrainedFluxBalance, PrescribedTemperature, SeaIceModel, SlabThermodynamics, SnowSlabThermodynamics,
+                    snow_slab_thermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

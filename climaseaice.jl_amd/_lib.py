@@ -15,7 +15,8 @@ OK = 0
 PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3, 4
 METRIC_UNIFORM, METRIC_PER_J = 0, 1
 FIELD_IDS = ["U", "V", "H", "A", "S11", "S22", "S12", "UN", "VN", "P", "ALPHA", "DELTA", "ZETA_F", "ZETA_C",
-             "GH", "GA", "HM", "AM", "UM", "VM", "TOP_U", "TOP_V", "BOT_U", "BOT_V", "MASS_FLUX"]
+             "GH", "GA", "HM", "AM", "UM", "VM", "TOP_U", "TOP_V", "BOT_U", "BOT_V", "MASS_FLUX",
+             "HS", "GHS", "HSM", "MASS_FLUX_SNOW", "SNOWFALL_INTERCEPTED", "TU", "TUS"]
 F = {n: k for k, n in enumerate(FIELD_IDS)}
 STRESS_NONE, STRESS_CONST, STRESS_FIELD, STRESS_SEMI_IMPLICIT = 0, 1, 2, 3
 VEL_ZERO, VEL_CONST, VEL_FIELD = 0, 1, 2
@@ -29,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_evp_initialize", "csi_evp_subcycle", "csi_evp_finalize", "csi_time_step_momentum",
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
-           "csi_slab_thermo_step", "csi_slab_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
+           "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set"]
 
 
@@ -61,7 +62,13 @@ class SlabParams(C.Structure):
                 ("liquidus_slope", C.c_double), ("freshwater_melting_temperature", C.c_double),
                 ("bottom_salinity", C.c_double), ("ice_consolidation_thickness", C.c_double),
                 ("top_temperature", C.c_double), ("top_flux_kind", C.c_int32), ("bottom_flux_kind", C.c_int32),
-                ("top_heat_flux", C.c_double), ("bottom_heat_flux", C.c_double)]
+                ("top_heat_flux", C.c_double), ("bottom_heat_flux", C.c_double),
+                ("top_bc_kind", C.c_int32), ("pad_", C.c_int32), ("ice_salinity", C.c_double)]
+
+
+class SnowParams(C.Structure):
+    _fields_ = [("conductivity", C.c_double), ("snow_density", C.c_double), ("snowfall", C.c_double),
+                ("top_temperature", C.c_double), ("top_bc_kind", C.c_int32), ("pad_", C.c_int32)]
 
 
 class CsiError(RuntimeError):
@@ -101,6 +108,8 @@ def load():
         "csi_time_step_fe": [vp, dbl, i32, i32, i32], "csi_time_step_rk3": [vp, dbl, i32, i32],
         "csi_slab_thermo_step": [vp, C.POINTER(SlabParams), dbl],
         "csi_slab_params_set": [vp, C.POINTER(SlabParams)],
+        "csi_layered_thermo_step": [vp, C.POINTER(SlabParams), C.POINTER(SnowParams), dbl],
+        "csi_snow_params_set": [vp, C.POINTER(SnowParams)],
         "csi_tile_set": [vp, i32, i32, i32, i32, i32, i32],
         "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],

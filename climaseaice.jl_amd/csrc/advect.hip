@@ -153,6 +153,7 @@ constexpr int TX = 64, TY = 4;
 template <int SCHEME>
 __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_tendencies(AdvDev A) {
     __shared__ double sFxh[TY + 1][TX + 2], sFxa[TY + 1][TX + 2], sFyh[TY + 1][TX + 2], sFya[TY + 1][TX + 2];
+    __shared__ double sFxs[TY + 1][TX + 2], sFys[TY + 1][TX + 2];      // snow thickness, the third tracer (has_snow)
     const GridDev& g = A.g;
     const int tx = threadIdx.x, ty = threadIdx.y;          // tx in [0, TX], ty in [0, TY]
     const int i = 1 + blockIdx.x * TX + tx, j = 1 + blockIdx.y * TY + ty;
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
             const bool closed = g.has_mask && peripheral_u(g, i, j);          // conditional_flux_fcc
             sFxh[ty][tx] = closed ? 0.0 : g.dy * uu * ch;
             sFxa[ty][tx] = closed ? 0.0 : g.dy * uu * ca;
+            if (A.has_snow) sFxs[ty][tx] = closed ? 0.0 : g.dy * uu * reconstruct<SCHEME>(&A.hs(i, j), 1, left, B);
         }
         if (tx < TX && i <= g.Nx) {
             const double vv = A.v(i, j);
@@ -179,6 +181,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
             const bool closed = g.has_mask && peripheral_v(g, i, j);          // conditional_flux_cfc
             sFyh[ty][tx] = closed ? 0.0 : dxf * vv * ch;
             sFya[ty][tx] = closed ? 0.0 : dxf * vv * ca;
+            if (A.has_snow) sFys[ty][tx] = closed ? 0.0 : dxf * vv * reconstruct<SCHEME>(&A.hs(i, j), A.hs.ld, left, B);
         }
     }
     __syncthreads();
@@ -188,6 +191,10 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
         const double fxa = sFxa[ty][tx + 1] - sFxa[ty][tx], fya = sFya[ty + 1][tx] - sFya[ty][tx];
         A.Gh(i, j) = -(1 / V * (fxh + fyh));
         A.Ga(i, j) = -(1 / V * (fxa + fya));
+        if (A.has_snow) {            // compute_snow_advection_tendency!, tracer_tendency_kernel_functions.jl:49-52
+            const double fxs = sFxs[ty][tx + 1] - sFxs[ty][tx], fys = sFys[ty + 1][tx] - sFys[ty][tx];
+            A.Ghs(i, j) = -(1 / V * (fxs + fys));
+        }
     }
 }
 
@@ -203,8 +210,15 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
     ap = (hp == 0) ? 0.0 : ap;
     hp = (ap == 0) ? 0.0 : hp;
     const double Vp = hp * ap;
-    A.a(i, j) = (ap > 1) ? 1.0 : ap;
+    const double a1 = (ap > 1) ? 1.0 : ap;
+    A.a(i, j) = a1;
     A.h(i, j) = (ap > 1) ? Vp : hp;
+    if (A.has_snow) {                // dynamic_step_snow!, sea_ice_fe_step.jl:86-94
+        const double sn = A.from_cache ? A.hsm(i, j) : A.hs(i, j);
+        double sp = sn + A.dt * A.Ghs(i, j);
+        sp = jmax(0.0, sp);
+        A.hs(i, j) = (a1 <= 0) ? 0.0 : sp;
+    }
 }
 
 }  // namespace adv

@@ -39,10 +39,13 @@ const int kLoc[CSI_F_COUNT][2] = {
     {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C},   // GH GA HM AM
     {LOC_F, LOC_C}, {LOC_C, LOC_F},                                   // UM VM
     {LOC_F, LOC_C}, {LOC_C, LOC_F}, {LOC_F, LOC_C}, {LOC_C, LOC_F},   // TOP_U TOP_V BOT_U BOT_V
-    {LOC_C, LOC_C}};                                                  // MASS_FLUX
+    {LOC_C, LOC_C},                                                   // MASS_FLUX
+    {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C},                   // HS GHS HSM
+    {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}};  // MASS_FLUX_SNOW SNOWFALL_INTERCEPTED TU TUS
 const char* kName[CSI_F_COUNT] = {"u", "v", "h", "aice", "sigma11", "sigma22", "sigma12", "un", "vn", "P", "alpha",
                                   "Delta", "zeta_f", "zeta_c", "Gh", "Gaice", "h-", "aice-", "u-", "v-",
-                                  "top_u", "top_v", "bottom_u", "bottom_v", "mass_flux"};
+                                  "top_u", "top_v", "bottom_u", "bottom_v", "mass_flux",
+                                  "hs", "Ghs", "hs-", "mass_flux_snow", "intercepted_snowfall", "Tu", "Tu_snow"};
 
 std::string g_create_error;
 
@@ -89,6 +92,8 @@ struct csi_context {
     size_t alt_elems[5] = {0, 0, 0, 0, 0};
     bool slab_set = false;   // thermodynamic step inside csi_time_step_fe / _rk3
     SlabDev slab{};
+    bool snow_set = false;   // layered (snow + ice) step instead of the bare-ice one
+    SnowDev snow{};
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
     int pairing = 1;      // 1: two sub-steps per launch where supported (csi_set_fusion level 2)
     int last_launches = 0, last_substeps = 0, last_used_pairs = 0;   // kernel launches / sub-steps of the last fused sub-cycle
@@ -770,6 +775,8 @@ AdvDev adv_dev(const csi_context* c, int scheme, double dt, int from_cache) {
     A.g = c->g;
     A.u = ref_of(c, CSI_F_U); A.v = ref_of(c, CSI_F_V); A.h = ref_of(c, CSI_F_H); A.a = ref_of(c, CSI_F_A);
     A.Gh = ref_of(c, CSI_F_GH); A.Ga = ref_of(c, CSI_F_GA); A.hm = ref_of(c, CSI_F_HM); A.am = ref_of(c, CSI_F_AM);
+    A.has_snow = c->f[CSI_F_HS].p != nullptr && c->f[CSI_F_GHS].p != nullptr;     // snow thickness: the third tracer
+    if (A.has_snow) { A.hs = ref_of(c, CSI_F_HS); A.Ghs = ref_of(c, CSI_F_GHS); A.hsm = ref_of(c, CSI_F_HSM); }
     A.scheme = scheme; A.dt = dt; A.from_cache = from_cache;
     return A;
 }
@@ -781,6 +788,11 @@ int32_t do_update_state(csi_context* c) {
     launch_mask_center(ref_of(c, CSI_F_A), c->g, c->stream);
     if ((rc = fill_halo(c, CSI_F_H))) return rc;
     if ((rc = fill_halo(c, CSI_F_A))) return rc;
+    const bool snow = c->f[CSI_F_HS].p != nullptr;
+    if (snow) {
+        launch_mask_center(ref_of(c, CSI_F_HS), c->g, c->stream);
+        if ((rc = fill_halo(c, CSI_F_HS))) return rc;
+    }
     if (c->f[CSI_F_U].p && c->f[CSI_F_V].p) {
         launch_mask_u(ref_of(c, CSI_F_U), c->g, c->stream);
         launch_mask_v(ref_of(c, CSI_F_V), c->g, c->stream);
@@ -789,8 +801,9 @@ int32_t do_update_state(csi_context* c) {
     }
     HIP_TRY(c, hipGetLastError());
     if (is_tiled(c)) {                                      // the MPI part of fill_halo_regions!, sea_ice_model.jl:383
-        int ff[4] = {CSI_F_H, CSI_F_A, CSI_F_U, CSI_F_V};
-        const int n = (c->f[CSI_F_U].p && c->f[CSI_F_V].p) ? 4 : 2;
+        int ff[5] = {CSI_F_H, CSI_F_A, CSI_F_U, CSI_F_V, CSI_F_HS};
+        int n = (c->f[CSI_F_U].p && c->f[CSI_F_V].p) ? 4 : 2;
+        if (snow) ff[n++] = CSI_F_HS;
         if ((rc = exchange(c, ff, n, c->Hx < c->Hy ? c->Hx : c->Hy))) return rc;
     }
     return CSI_OK;
@@ -811,6 +824,7 @@ int32_t do_tracer_step(csi_context* c, double dt, int from_cache) {
     int32_t rc;
     if ((rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA}))) return rc;
     if (from_cache && (rc = need(c, {CSI_F_HM, CSI_F_AM}))) return rc;
+    if (from_cache && c->f[CSI_F_HS].p && c->f[CSI_F_GHS].p && (rc = need(c, {CSI_F_HSM}))) return rc;
     launch_tracer_step(adv_dev(c, 0, dt, from_cache), c->stream);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
@@ -825,13 +839,38 @@ static SlabDev slab_dev(const csi_slab_params* p) {
     S.liq_slope = p->liquidus_slope; S.liq_T0 = p->freshwater_melting_temperature; S.S = p->bottom_salinity;
     S.hc = p->ice_consolidation_thickness; S.Tu = p->top_temperature; S.Qu = p->top_heat_flux; S.Qb = p->bottom_heat_flux;
     S.top_flux_kind = p->top_flux_kind; S.bot_flux_kind = p->bottom_flux_kind;
+    S.top_bc_kind = p->top_bc_kind; S.ice_salinity = p->ice_salinity;
     return S;
 }
+static SnowDev snow_dev(const csi_snow_params* p) {
+    SnowDev W{};
+    W.k = p->conductivity; W.rho = p->snow_density; W.snowfall = p->snowfall; W.Tu = p->top_temperature; W.top_bc_kind = p->top_bc_kind;
+    return W;
+}
+static int32_t do_layered(csi_context* c, const SlabDev& S, const SnowDev& W, double dt) {
+    int32_t rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_HS});
+    if (rc) return rc;
+    if (S.top_flux_kind != 0) return fail(c, CSI_ERR_UNSUPPORTED, "the layered (snow) step takes a numeric top heat flux (top_flux_kind 0)");
+    LayeredOut o{};
+    o.mf_ice = ref_of(c, CSI_F_MASS_FLUX); o.mf_snow = ref_of(c, CSI_F_MASS_FLUX_SNOW); o.mf_int = ref_of(c, CSI_F_SNOWFALL_INTERCEPTED);
+    o.tu_ice = ref_of(c, CSI_F_TU); o.tu_snow = ref_of(c, CSI_F_TUS);
+    launch_layered_step(S, W, c->g, ref_of(c, CSI_F_H), ref_of(c, CSI_F_A), ref_of(c, CSI_F_HS), o, dt, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return CSI_OK;
+}
+// thermodynamic_time_step!(model, ice_thermodynamics, snow_thermodynamics, dt): dispatch on the snow layer
+static int32_t do_thermo(csi_context* c, double dt);
 static int32_t do_slab(csi_context* c, const SlabDev& S, double dt) {
     const bool has_mf = c->f[CSI_F_MASS_FLUX].p != nullptr;
+    if (S.top_bc_kind == 1 && S.top_flux_kind != 0)
+        return fail(c, CSI_ERR_UNSUPPORTED, "MeltingConstrainedFluxBalance takes a numeric top heat flux (top_flux_kind 0)");
     launch_slab_step(S, c->g, ref_of(c, CSI_F_H), ref_of(c, CSI_F_A), ref_of(c, CSI_F_MASS_FLUX), has_mf, dt, c->stream);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
+}
+static int32_t do_thermo(csi_context* c, double dt) {
+    if (!c->slab_set) return CSI_OK;                       // thermodynamic_time_step!(model, ::Nothing, ...) = nothing
+    return c->snow_set ? do_layered(c, c->slab, c->snow, dt) : do_slab(c, c->slab, dt);
 }
 
 
@@ -1067,6 +1106,7 @@ int32_t csi_cache_current_fields(csi_context* c) {
     if (rc) return rc;
     if ((rc = copy_parent(c, CSI_F_HM, CSI_F_H))) return rc;
     if ((rc = copy_parent(c, CSI_F_AM, CSI_F_A))) return rc;
+    if (c->f[CSI_F_HS].p && c->f[CSI_F_HSM].p && (rc = copy_parent(c, CSI_F_HSM, CSI_F_HS))) return rc;
     if (c->f[CSI_F_U].p && c->f[CSI_F_UM].p) {
         if ((rc = copy_parent(c, CSI_F_UM, CSI_F_U))) return rc;
         if ((rc = copy_parent(c, CSI_F_VM, CSI_F_V))) return rc;
@@ -1095,7 +1135,7 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
     if (scheme && (rc = do_tendencies(c, scheme))) return rc;             // :19
     if ((rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
     if (scheme && (rc = do_tracer_step(c, dt, 0))) return rc;             // :25
-    if (c->slab_set && (rc = do_slab(c, c->slab, dt))) return rc;         // :28 thermodynamic_time_step!
+    if ((rc = do_thermo(c, dt))) return rc;                               // :28 thermodynamic_time_step!
     return do_update_state(c);                                            // :31
 }
 
@@ -1110,7 +1150,7 @@ int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t s
         if (scheme && (rc = do_tendencies(c, scheme))) return rc;         // :84
         if ((rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
         if (scheme && (rc = do_tracer_step(c, dtau, 1))) return rc;       // :89
-        if (c->slab_set && (rc = do_slab(c, c->slab, dtau))) return rc;   // :91 thermodynamic_time_step!
+        if ((rc = do_thermo(c, dtau))) return rc;                         // :91 thermodynamic_time_step!
         if ((rc = do_update_state(c))) return rc;
     }
     return CSI_OK;
@@ -1121,6 +1161,18 @@ int32_t csi_slab_thermo_step(csi_context* c, const csi_slab_params* p, double dt
     int32_t rc = need(c, {CSI_F_H, CSI_F_A});
     if (rc) return rc;
     return do_slab(c, slab_dev(p), dt);
+}
+
+int32_t csi_layered_thermo_step(csi_context* c, const csi_slab_params* p, const csi_snow_params* w, double dt) {
+    if (!c || !p || !w) return CSI_ERR_INVALID_ARGUMENT;
+    return do_layered(c, slab_dev(p), snow_dev(w), dt);
+}
+
+int32_t csi_snow_params_set(csi_context* c, const csi_snow_params* p) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    c->snow_set = p != nullptr;
+    if (p) c->snow = snow_dev(p);
+    return CSI_OK;
 }
 
 int32_t csi_slab_params_set(csi_context* c, const csi_slab_params* p) {

@@ -74,6 +74,8 @@ void launch_mask_v(const FRef& f, const GridDev& g, hipStream_t s);
 struct AdvDev {
     GridDev g;
     FRef u, v, h, a, Gh, Ga, hm, am;
+    FRef hs, Ghs, hsm;      // snow thickness as a third tracer (has_snow)
+    int has_snow;
     int scheme;
     double dt;
     int from_cache;
@@ -85,7 +87,16 @@ void launch_tracer_step(const AdvDev& A, hipStream_t s);
 struct SlabDev {
     double k, rho_bulk, rho_pure, rho_l, c_l, c_i, L0, T0, liq_slope, liq_T0, S, hc, Tu, Qu, Qb;
     int top_flux_kind, bot_flux_kind;
+    int top_bc_kind;         // 0 PrescribedTemperature, 1 MeltingConstrainedFluxBalance (numeric flux, closed form)
+    double ice_salinity;
 };
+struct SnowDev {
+    double k, rho, snowfall, Tu;
+    int top_bc_kind;
+};
+struct LayeredOut { FRef mf_ice, mf_snow, mf_int, tu_ice, tu_snow; };   // optional outputs (p == nullptr: absent)
+void launch_layered_step(const SlabDev& S, const SnowDev& W, const GridDev& g, const FRef& h, const FRef& a, const FRef& hs,
+                         const LayeredOut& o, double dt, hipStream_t s);
 void launch_slab_step(const SlabDev& S, const GridDev& g, const FRef& h, const FRef& a, const FRef& mf, int has_mf,
                       double dt, hipStream_t s);
 

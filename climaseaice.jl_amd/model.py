@@ -19,28 +19,68 @@ from .fields import CenterField, Field, XFaceField, YFaceField
 from .grids import Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
 
 
+class PrescribedTemperature:
+    """HeatBoundaryConditions.PrescribedTemperature(T)."""
+
+    def __init__(self, temperature):
+        self.temperature = float(temperature)
+
+
+class MeltingConstrainedFluxBalance:
+    """HeatBoundaryConditions.MeltingConstrainedFluxBalance (top_heat_boundary_conditions.jl:5-52): the top temperature
+    balances the external and conductive fluxes, capped at the melting temperature.  On the accelerated path the
+    external flux is a number, for which the reference's secant solve has a closed-form root (include/csi.h)."""
+
+
 class SlabThermodynamics:
-    """Bare-ice SlabThermodynamics with a PrescribedTemperature top boundary condition and IceWaterThermalEquilibrium
+    """SlabThermodynamics of the ice layer with a PrescribedTemperature (top_temperature = number) or
+    MeltingConstrainedFluxBalance (top_heat_boundary_condition) top boundary condition and IceWaterThermalEquilibrium
     at the bottom (SeaIceThermodynamics/slab_sea_ice_thermodynamics.jl:82-109); PhaseTransitions defaults
-    (SeaIceThermodynamics.jl:106-124).  Heat fluxes: numbers; top_heat_flux=None is the reference's default for a
-    prescribed temperature (external flux in equilibrium with the internal conductive flux, sea_ice_model.jl:248-256);
-    bottom_heat_flux="frazil" is the -(1 - aice) W m^-2 flux of examples/freezing_bucket.jl:79-81."""
+    (SeaIceThermodynamics.jl:106-124).  Heat fluxes: numbers; top_heat_flux=None is the reference's default: for a
+    prescribed temperature the external flux in equilibrium with the internal conductive flux, otherwise 0
+    (sea_ice_model.jl:243-256); bottom_heat_flux="frazil" is the -(1 - aice) W m^-2 flux of
+    examples/freezing_bucket.jl:79-81."""
 
     def __init__(self, top_temperature=-10.0, conductivity=2.0, top_heat_flux=None, bottom_heat_flux=0.0,
                  heat_capacity=2000.0, density=917.0, liquid_density=999.8, liquid_heat_capacity=4186.0,
                  reference_latent_heat=334e3, reference_temperature=0.0, liquidus_slope=0.054,
-                 freshwater_melting_temperature=0.0, bottom_salinity=0.0, ice_consolidation_thickness=0.05):
+                 freshwater_melting_temperature=0.0, bottom_salinity=0.0, ice_consolidation_thickness=0.05,
+                 top_heat_boundary_condition=None, ice_salinity=0.0):
         self.__dict__.update(locals())
         del self.__dict__["self"]
+        if isinstance(top_heat_boundary_condition, PrescribedTemperature):
+            self.top_temperature = top_heat_boundary_condition.temperature
+        self.flux_balance = isinstance(top_heat_boundary_condition, MeltingConstrainedFluxBalance)
 
-    def params(self, sea_ice_density):
+    def params(self, sea_ice_density, snow=False):
         frazil = self.bottom_heat_flux == "frazil"
+        equilibrium = self.top_heat_flux is None and not self.flux_balance and not snow     # sea_ice_model.jl:245-256
         return _lib.SlabParams(self.conductivity, sea_ice_density, self.density, self.liquid_density, self.liquid_heat_capacity,
                                self.heat_capacity, self.reference_latent_heat, self.reference_temperature, self.liquidus_slope,
                                self.freshwater_melting_temperature, self.bottom_salinity, self.ice_consolidation_thickness,
-                               self.top_temperature, 1 if self.top_heat_flux is None else 0, 1 if frazil else 0,
+                               self.top_temperature, 1 if equilibrium else 0, 1 if frazil else 0,
                                0.0 if self.top_heat_flux is None else float(self.top_heat_flux),
-                               1.0 if frazil else float(self.bottom_heat_flux))
+                               1.0 if frazil else float(self.bottom_heat_flux),
+                               1 if self.flux_balance else 0, 0, float(self.ice_salinity))
+
+
+class SnowSlabThermodynamics:
+    """snow_slab_thermodynamics(grid; conductivity = 0.31) (slab_sea_ice_thermodynamics.jl:42-49): the snow layer of
+    the layered step.  Top boundary condition: MeltingConstrainedFluxBalance (the default) or PrescribedTemperature."""
+
+    def __init__(self, conductivity=0.31, top_heat_boundary_condition=None):
+        self.conductivity = float(conductivity)
+        self.top_heat_boundary_condition = top_heat_boundary_condition or MeltingConstrainedFluxBalance()
+
+    def params(self, snow_density, snowfall):
+        bc = self.top_heat_boundary_condition
+        prescribed = isinstance(bc, PrescribedTemperature)
+        return _lib.SnowParams(self.conductivity, float(snow_density), float(snowfall),
+                               bc.temperature if prescribed else 0.0, 0 if prescribed else 1, 0)
+
+
+def snow_slab_thermodynamics(grid=None, conductivity=0.31, **kw):
+    return SnowSlabThermodynamics(conductivity=conductivity, **kw)
 
 
 class WENO:
@@ -69,11 +109,16 @@ def _dptr(a):
 
 class SeaIceModel:
     def __init__(self, grid, dynamics=None, advection=None, timestepper="SplitRungeKutta3", sea_ice_density=900.0,
-                 ice_thermodynamics=None, device="cuda:0", mode="fast", stream=None):
+                 ice_thermodynamics=None, snow_thermodynamics=None, snow_density=330.0, snowfall=0.0,
+                 device="cuda:0", mode="fast", stream=None):
         self.grid = grid
         self.dynamics = dynamics
         self.advection = advection
         self.ice_thermodynamics = ice_thermodynamics
+        self.snow_thermodynamics = snow_thermodynamics
+        self.snow_density, self.snowfall = float(snow_density), float(snowfall)
+        if snow_thermodynamics is not None and ice_thermodynamics is None:
+            raise ValueError("a snow layer needs ice_thermodynamics")
         if timestepper not in ("SplitRungeKutta3", "ForwardEuler"):
             raise ValueError("timestepper must be 'SplitRungeKutta3' or 'ForwardEuler'")
         self.timestepper_kind = timestepper
@@ -92,6 +137,19 @@ class SeaIceModel:
         if timestepper == "SplitRungeKutta3":
             self.timestepper.Psi_minus = SimpleNamespace(h=CenterField(grid, dev, "h-"), aice=CenterField(grid, dev, "aice-"),
                                                          u=XFaceField(grid, dev, "u-"), v=YFaceField(grid, dev, "v-"))
+        # snow layer: hs is a prognostic field with its own tendency and cache (sea_ice_model.jl:201-224)
+        self.snow_thickness = None
+        self.mass_fluxes = None
+        if snow_thermodynamics is not None:
+            self.snow_thickness = CenterField(grid, dev, "hs")
+            Gn.hs = CenterField(grid, dev, "Ghs")
+            if self.timestepper.Psi_minus is not None:
+                self.timestepper.Psi_minus.hs = CenterField(grid, dev, "hs-")
+            self.mass_fluxes = SimpleNamespace(thermodynamics=SimpleNamespace(ice=CenterField(grid, dev, "mass_flux"),
+                                                                              snow=CenterField(grid, dev, "mass_flux_snow")),
+                                               intercepted_snowfall=CenterField(grid, dev, "intercepted_snowfall"))
+            self.snow_top_temperature = CenterField(grid, dev, "Tu_snow")
+            self.ice_top_temperature = CenterField(grid, dev, "Tu")
         self.clock = SimpleNamespace(time=0.0, iteration=0)
         self._keep = []
         self._stress_fields = {}
@@ -131,8 +189,20 @@ class SeaIceModel:
             pm = self.timestepper.Psi_minus
             self._bind("HM", pm.h); self._bind("AM", pm.aice); self._bind("UM", pm.u); self._bind("VM", pm.v)
         if self.ice_thermodynamics is not None:
-            sp = self.ice_thermodynamics.params(self.sea_ice_density)
+            sp = self.ice_thermodynamics.params(self.sea_ice_density, snow=self.snow_thermodynamics is not None)
             self.ctx.call("csi_slab_params_set", C.byref(sp))
+        if self.snow_thermodynamics is not None:
+            self._bind("HS", self.snow_thickness)
+            self._bind("GHS", self.timestepper.Gn.hs)
+            if self.timestepper.Psi_minus is not None:
+                self._bind("HSM", self.timestepper.Psi_minus.hs)
+            self._bind("MASS_FLUX", self.mass_fluxes.thermodynamics.ice)
+            self._bind("MASS_FLUX_SNOW", self.mass_fluxes.thermodynamics.snow)
+            self._bind("SNOWFALL_INTERCEPTED", self.mass_fluxes.intercepted_snowfall)
+            self._bind("TU", self.ice_top_temperature)
+            self._bind("TUS", self.snow_top_temperature)
+            wp = self.snow_thermodynamics.params(self.snow_density, self.snowfall)
+            self.ctx.call("csi_snow_params_set", C.byref(wp))
         d = self.dynamics
         if d is None:
             return
@@ -294,6 +364,8 @@ def set_(model, **kw):
     # Python NFKC-normalises identifiers, so the keyword `ℵ` (U+2135) arrives as U+05D0
     names = {"h": model.ice_thickness, "aice": model.ice_concentration, "\u2135": model.ice_concentration,
              "\u05d0": model.ice_concentration, "u": model.velocities.u, "v": model.velocities.v}
+    if model.snow_thickness is not None:
+        names["hs"] = model.snow_thickness
     for k, val in kw.items():
         if k not in names:
             raise KeyError(f"set!: unknown field {k}")
@@ -318,8 +390,13 @@ def time_step(model, dt):
         # (sea_ice_fe_step.jl:13-34 with time_step_momentum!, compute_tendencies! and dynamic_time_step! no-ops)
         if model.ice_thermodynamics is None or model.scheme not in (0, None):
             raise NotImplementedError("without dynamics only the slab thermodynamics step is on the accelerated path")
-        sp = model.ice_thermodynamics.params(model.sea_ice_density)
-        model.ctx.call("csi_slab_thermo_step", C.byref(sp), float(dt))
+        snow = model.snow_thermodynamics
+        sp = model.ice_thermodynamics.params(model.sea_ice_density, snow=snow is not None)
+        if snow is None:
+            model.ctx.call("csi_slab_thermo_step", C.byref(sp), float(dt))
+        else:
+            wp = snow.params(model.snow_density, model.snowfall)
+            model.ctx.call("csi_layered_thermo_step", C.byref(sp), C.byref(wp), float(dt))
         model.ctx.call("csi_update_state")
     elif model.timestepper_kind == "ForwardEuler":
         model.ctx.call("csi_time_step_fe", float(dt), model.substeps, model.scheme, int(model.clock.iteration == 0))

@@ -96,6 +96,13 @@ typedef enum {
     CSI_F_BOT_U,      /* (f,c) bottom stress array or bottom external velocity u_e */
     CSI_F_BOT_V,      /* (c,f) */
     CSI_F_MASS_FLUX,  /* (c,c) mass_fluxes.thermodynamics.ice */
+    CSI_F_HS,         /* (c,c) model.snow_thickness (snow layer; optional) */
+    CSI_F_GHS,        /* (c,c) timestepper.G^n.hs */
+    CSI_F_HSM,        /* (c,c) timestepper.Psi^-.hs */
+    CSI_F_MASS_FLUX_SNOW,   /* (c,c) mass_fluxes.thermodynamics.snow (optional) */
+    CSI_F_SNOWFALL_INTERCEPTED, /* (c,c) mass_fluxes.intercepted_snowfall (optional) */
+    CSI_F_TU,         /* (c,c) ice_thermodynamics.top_surface_temperature (optional output) */
+    CSI_F_TUS,        /* (c,c) snow_thermodynamics.top_surface_temperature (optional output) */
     CSI_F_COUNT
 } csi_field_id;
 
@@ -230,7 +237,30 @@ typedef struct {
     int32_t top_flux_kind;           /* 0: constant Qu ; 1: internal-flux equilibrium (sea_ice_model.jl:248-256) */
     int32_t bottom_flux_kind;        /* 0: constant Qb ; 1: -(1 - aice) * Qb (examples/freezing_bucket.jl:79-81) */
     double top_heat_flux, bottom_heat_flux;
+    /* top boundary condition (slab_thermodynamics_tendencies.jl:107-119).  0: PrescribedTemperature(top_temperature).
+     * 1: MeltingConstrainedFluxBalance with a NUMERIC top_heat_flux: the reference's secant solve of
+     * Qx - Qi(T) = 0 (top_heat_boundary_conditions.jl:80-97) has, for the linear conductive flux, the closed-form
+     * root T = Tb - Qx R (R = h / k, with snow hs / ks + h / k), capped at the melting temperature. */
+    int32_t top_bc_kind;
+    int32_t pad_;
+    double ice_salinity;             /* model.ice_salinity: Tm = melting_temperature(liquidus, S), 0 */
 } csi_slab_params;
+/* Snow layer on the slab: snow_slab_thermodynamics (slab_sea_ice_thermodynamics.jl:42-49) + snow_density / snowfall
+ * of SeaIceModel.  The layered step is _layered_thermodynamic_time_step! (thermodynamic_time_step.jl:131-298); hs is
+ * advected and updated like h (tracer_tendency_kernel_functions.jl:49-52, sea_ice_fe_step.jl:86-94) when
+ * CSI_F_HS / CSI_F_GHS (/ CSI_F_HSM for RK3) are bound. */
+typedef struct {
+    double conductivity;             /* 0.31 */
+    double snow_density;             /* 330 */
+    double snowfall;                 /* kg m^-2 s^-1, constant */
+    double top_temperature;          /* PrescribedTemperature of the snow surface (top_bc_kind 0) */
+    int32_t top_bc_kind;             /* as csi_slab_params.top_bc_kind, for the snow surface */
+    int32_t pad_;
+} csi_snow_params;
+/* thermodynamic_time_step!(model, ::SlabThermodynamics, ::SlabThermodynamics, dt): needs CSI_F_H, CSI_F_A, CSI_F_HS */
+int32_t csi_layered_thermo_step(csi_context* ctx, const csi_slab_params* ice, const csi_snow_params* snow, double dt);
+/* With slab parameters set: csi_time_step_fe / _rk3 run the layered step instead of the bare-ice one.  NULL removes it. */
+int32_t csi_snow_params_set(csi_context* ctx, const csi_snow_params* p);
 int32_t csi_slab_thermo_step(csi_context* ctx, const csi_slab_params* p, double dt);
 /* Make csi_time_step_fe / csi_time_step_rk3 run the slab step where the reference does (after the tracer update of
  * every stage: sea_ice_fe_step.jl:28, sea_ice_rk_substep.jl:91).  NULL removes it. */

@@ -35,7 +35,8 @@ end
 
 # field slots, in the order of csi_field_id
 const F = (U=0, V=1, H=2, A=3, S11=4, S22=5, S12=6, UN=7, VN=8, P=9, ALPHA=10, DELTA=11, ZETA_F=12, ZETA_C=13,
-           GH=14, GA=15, HM=16, AM=17, UM=18, VM=19, TOP_U=20, TOP_V=21, BOT_U=22, BOT_V=23, MASS_FLUX=24)
+           GH=14, GA=15, HM=16, AM=17, UM=18, VM=19, TOP_U=20, TOP_V=21, BOT_U=22, BOT_V=23, MASS_FLUX=24,
+           HS=25, GHS=26, HSM=27, MASS_FLUX_SNOW=28, SNOWFALL_INTERCEPTED=29, TU=30, TUS=31)
 
 mutable struct Context
     handle::Ptr{Cvoid}
@@ -117,6 +118,12 @@ function attach!(model::SeaIceModel)
     if model.timestepper isa SplitRungeKuttaTimeStepper
         Ψ = model.timestepper.Ψ⁻
         bind!(ctx, F.HM, Ψ.h); bind!(ctx, F.AM, Ψ.ℵ); bind!(ctx, F.UM, Ψ.u); bind!(ctx, F.VM, Ψ.v)
+    end
+    # snow layer: hs is advected and updated with h and ℵ (tracer_tendency_kernel_functions.jl:49-52,
+    # sea_ice_fe_step.jl:86-94); the thermodynamic step itself stays with the Julia kernel unless csi_snow_params_set is used
+    if !isnothing(model.snow_thickness)
+        bind!(ctx, F.HS, model.snow_thickness); bind!(ctx, F.GHS, model.timestepper.Gⁿ.hs)
+        model.timestepper isa SplitRungeKuttaTimeStepper && bind!(ctx, F.HSM, model.timestepper.Ψ⁻.hs)
     end
     r = dyn.rheology
     cor = dyn.coriolis

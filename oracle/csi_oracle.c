@@ -177,6 +177,7 @@ void ora_compute_viscosities(ora_problem* g, int i0, int i1, int j0, int j1) {
 
 /* Julia's max(a, b) for floats: NaN if either is NaN (C's fmax would drop the NaN) */
 static inline double jmax(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
+static inline double jmin(double a, double b) { return (a != a || b != b) ? a + b : (b < a ? b : a); }
 static inline double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 /* ------------------------------------------------------------------------ */
@@ -720,6 +721,7 @@ void ora_compute_tracer_tendencies(ora_problem* g, int scheme) {
     OMP_ROWS
     for (int j = 1; j <= g->Ny; ++j)
         for (int i = 1; i <= g->Nx; ++i) {
+            if (g->has_snow) AT(g, g->Ghs, i, j) = tendency_of(g, scheme, g->hs, i, j);   /* compute_snow_advection_tendency! :49-52 */
             AT(g, g->Gh, i, j) = tendency_of(g, scheme, g->h, i, j);
             AT(g, g->Ga, i, j) = tendency_of(g, scheme, g->aice, i, j);
         }
@@ -741,6 +743,13 @@ void ora_dynamic_step_tracers(ora_problem* g, double dt, int from_cache) {
             double Vp = hp * ap;
             AT(g, g->aice, i, j) = (ap > 1) ? 1.0 : ap;
             AT(g, g->h, i, j) = (ap > 1) ? Vp : hp;
+            if (g->has_snow) {                                       /* dynamic_step_snow!, sea_ice_fe_step.jl:86-94 */
+                double sn = from_cache ? AT(g, g->hsm, i, j) : AT(g, g->hs, i, j);
+                double sp = sn + dt * AT(g, g->Ghs, i, j);
+                sp = jmax(0.0, sp);
+                sp = (AT(g, g->aice, i, j) <= 0) ? 0.0 : sp;
+                AT(g, g->hs, i, j) = sp;
+            }
         }
 }
 
@@ -749,13 +758,14 @@ void ora_update_state(ora_problem* g) {
     if (g->has_mask) {
         for (int j = 1; j <= g->Ny; ++j)
             for (int i = 1; i <= g->Nx; ++i) {
-                if (inactive_cell(g, i, j)) { AT(g, g->h, i, j) = 0; AT(g, g->aice, i, j) = 0; }
+                if (inactive_cell(g, i, j)) { AT(g, g->h, i, j) = 0; AT(g, g->aice, i, j) = 0; if (g->has_snow) AT(g, g->hs, i, j) = 0; }
                 if (ora_peripheral_u(g, i, j)) AT(g, g->u, i, j) = 0;   /* mask_immersed_field_xy! on (f,c): peripheral nodes */
                 if (ora_peripheral_v(g, i, j)) AT(g, g->v, i, j) = 0;
             }
     }
     ora_fill_halo_center(g, g->h);
     ora_fill_halo_center(g, g->aice);
+    if (g->has_snow) ora_fill_halo_center(g, g->hs);
     ora_fill_halo_u(g);
     ora_fill_halo_v(g);
 }
@@ -813,6 +823,13 @@ static void slab_cell(const ora_slab* s, double* hp_, double* ap_, double* mf_, 
     int consolidated = hn >= hc;
     double Tb = s->liq_T0 - s->liq_slope * s->salinity;       /* IceWaterThermalEquilibrium: Tm(S) */
     double Tu = s->Tu;                                        /* PrescribedTemperature */
+    if (s->top_bc_kind == 1) {
+        /* MeltingConstrainedFluxBalance, slab_thermodynamics_tendencies.jl:107-119: consolidated ice solves
+         * Qx - Qi(T) = 0 with Qi(T) = -k (T - Tb) / h (numeric Qx: closed-form root), capped at Tm(S_ice);
+         * an unconsolidated slab takes the bottom temperature */
+        double Tm = s->liq_T0 - s->liq_slope * s->ice_salinity;
+        Tu = consolidated ? jmin(Tb - s->Qu * hn / s->k_ice, Tm) : Tb;
+    }
     double Eb = s->rho_bulk * latent_heat(s, Tb);
     double Eu = s->rho_bulk * latent_heat(s, Tu);
     double Qi_fun = slab_internal_flux(s, Tu, Tb, hn);        /* internal_flux_function at Tu */
@@ -839,6 +856,105 @@ static void slab_cell(const ora_slab* s, double* hp_, double* ap_, double* mf_, 
     *hp_ = h1;
     if (mf_) *mf_ = s->rho_bulk * (h1 * a1 - hn * an) / dt;   /* :111 */
 }
+/* ice_volume_update, thermodynamic_time_step.jl:304-324 */
+static void ice_volume_update(double dtV, double hn, double an, double hc, double dt, double* h1, double* a1) {
+    double V1 = hn * an + dt * dtV;
+    V1 = jmax(0.0, V1);
+    dtV = (V1 - hn * an) / dt;
+    double ap = concentration_step(dtV, an, hn, hc, dt);
+    double hp = V1 / ap;
+    hp = (ap <= 0) ? 0.0 : hp;
+    ap = (dtV == 0) ? an : ap;
+    hp = (dtV == 0) ? hn : hp;
+    ap = (hp == 0) ? 0.0 : ap;
+    hp = (ap == 0) ? 0.0 : hp;
+    *a1 = (ap > 1) ? 1.0 : ap;
+    *h1 = (ap > 1) ? hp * ap : hp;
+}
+/* _layered_thermodynamic_time_step!, thermodynamic_time_step.jl:131-298 (snow on ice, resistors in series) */
+static void layered_cell(const ora_slab* s, const ora_snow* w, double* hi_, double* a_, double* hs_,
+                         double* mfi, double* mfs, double* mfp, double* tui, double* tus, double dt) {
+    const double hin = *hi_, an = *a_, hc = s->h_consolidation;
+    double hsn = *hs_;
+    const double Vin = hin * an, Vsn = hsn * an;                                 /* :158-159 */
+    const int consolidated = hin >= hc;
+    const double Tb = s->liq_T0 - s->liq_slope * s->salinity;                    /* bottom_temperature :167 */
+    double Tm = s->liq_T0 - s->liq_slope * s->ice_salinity;                      /* melting_temperature :168 */
+    const double ks = w->k_snow, ki = s->k_ice;
+    const double Qu = s->Qu;                                                     /* numeric top_external_heat_flux */
+    Tm = (hsn > 0) ? 0.0 : Tm;                                                   /* :188 */
+    const double R = hsn / ks + hin / ki;                                        /* ice_snow_conductive_flux :61-62 */
+    double Tus = w->Tu;
+    if (w->top_bc_kind == 1) {                                                   /* :190-199, closed-form root of Qu - (Tb - T) / R */
+        double Tn = consolidated ? jmin(Tb - Qu * R, Tm) : Tb;
+        Tus = Tn;
+    }
+    /* interface_temperature, slab_heat_and_tracer_fluxes.jl:69-84 */
+    const double Ri = hin / ki, Rs = hsn / ks, Rt = Rs + Ri;
+    const double Tsi = (Rt <= 0) ? Tb : Tb + (Tus - Tb) * Ri / Rt;
+    const double Qic = (R <= 0) ? 0.0 : (Tb - Tus) / R;
+    const double Qis = consolidated ? Qic : 0.0;                                 /* :211 */
+    const double Qui = Qu;
+    const double Qui_per_ice = (an > 0) ? Qui / an : 0.0;                        /* :214 */
+    const double dQ = Qui_per_ice - Qis;
+    const double melt_energy = jmax(0.0, -dQ);
+    const double rs = w->rho_snow, Ls = s->L0;                                   /* reference_latent_heat */
+    const double cap = rs * Ls * hsn / dt;
+    const double Qs = jmin(melt_energy, cap);
+    const double Gsm = Qs / (rs * Ls);
+    const double ri = s->rho_bulk, riL = ri * Ls;
+    const double Qbi = (s->bot_flux_kind == 1) ? (-(1 - an)) * s->Qb : s->Qb;
+    const double alpha = (Qui - Qbi) / riL, beta = Qs / riL;                     /* :238-239 */
+    const double Cm = (hin > 0) ? an / (2 * hin) : 0.0;
+    const double Cf = (hc > 0) ? (1 - an) / hc : 0.0;
+    const double Km = dt * Cm, Kf = dt * Cf;
+    const double eps = 2.220446049250313e-16;
+    const double Dm = 1 - Km * beta, Df = 1 - Kf * beta;
+    const double am = (fabs(Dm) > eps) ? (an + Km * alpha) / Dm : an + Km * alpha;
+    const double af = (fabs(Df) > eps) ? (an + Kf * alpha) / Df : an + Kf * alpha;
+    const double dtVm = alpha + beta * am;
+    const int melting = dtVm < 0;
+    const double atmp = melting ? am : af;
+    const double Qeff = Qui + Qs * atmp;                                         /* :259 */
+    /* ice_melt_freeze_tendency at Tui = Tsi, slab_thermodynamics_tendencies.jl:28-68 */
+    const double Eb = ri * latent_heat(s, Tb), Eu = ri * latent_heat(s, Tsi);
+    const double Qii = consolidated ? slab_internal_flux(s, Tsi, Tb, hin) : 0.0;
+    const double wu = (Qeff - Qii) / Eu, wb = (Qii - Qbi) / Eb;
+    double hi1, a1;
+    ice_volume_update(wu + wb, hin, an, hc, dt, &hi1, &a1);
+    hsn = (a1 > 0) ? hsn * an / a1 : 0.0;                                        /* :274 */
+    const double Gsp = (a1 > 0) ? w->snowfall / rs : 0.0;                        /* snow_accumulation :331-334 */
+    double hs1 = hsn + dt * (Gsp - Gsm);
+    hs1 = jmax(0.0, hs1);
+    {   /* snow_ice_formation :336-353 */
+        const double rw = s->rho_liquid;
+        const double hf = hi1 * (1 - ri / rw) - hs1 * rs / rw;
+        double dhs = (hf < 0) ? -hf * ri / rs : 0.0;
+        const double hsp = jmax(0.0, hs1 - dhs);
+        dhs = hs1 - hsp;
+        hi1 = hi1 + dhs * rs / ri;
+        hs1 = hsp;
+    }
+    hs1 = (a1 <= 0) ? 0.0 : hs1;
+    *a_ = a1; *hi_ = hi1; *hs_ = hs1;
+    const double Pabs = rs * Gsp * a1;
+    if (mfi) *mfi = ri * (hi1 * a1 - Vin) / dt;
+    if (mfs) *mfs = rs * (hs1 * a1 - Vsn) / dt - Pabs;
+    if (mfp) *mfp = Pabs;
+    if (tui) *tui = Tsi;
+    if (tus) *tus = Tus;
+}
+void ora_layered_thermo_step(const ora_slab* s, const ora_snow* w, int64_t n, double* h, double* aice, double* hs,
+                             double* mf_ice, double* mf_snow, double* mf_int, double* tu_ice, double* tu_snow, double dt) {
+    for (int64_t c = 0; c < n; ++c)
+        layered_cell(s, w, h + c, aice + c, hs + c, mf_ice ? mf_ice + c : 0, mf_snow ? mf_snow + c : 0, mf_int ? mf_int + c : 0,
+                     tu_ice ? tu_ice + c : 0, tu_snow ? tu_snow + c : 0, dt);
+}
+void ora_layered_step_fields(ora_problem* g, const ora_slab* s, const ora_snow* w, double dt) {
+    for (int j = 1; j <= g->Ny; ++j)
+        for (int i = 1; i <= g->Nx; ++i)
+            layered_cell(s, w, &AT(g, g->h, i, j), &AT(g, g->aice, i, j), &AT(g, g->hs, i, j), 0, 0, 0, 0, 0, dt);
+}
 void ora_slab_thermo_step(const ora_slab* s, int64_t n, double* h, double* aice, double* mass_flux, double dt) {
     for (int64_t c = 0; c < n; ++c) slab_cell(s, h + c, aice + c, mass_flux ? mass_flux + c : 0, dt);
 }
@@ -855,6 +971,30 @@ void ora_time_step_fe_thermo(ora_problem* g, double dt, int scheme, int first_it
     if (scheme) ora_dynamic_step_tracers(g, dt, 0);
     if (s) ora_slab_step_fields(g, s, dt);
     ora_update_state(g);
+}
+/* the same with a snow layer: hs is a third advected tracer and joins the Psi^- cache (sea_ice_rk_substep.jl:29-42) */
+void ora_time_step_fe_snow(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s, const ora_snow* w) {
+    if (first_iteration) ora_update_state(g);
+    if (scheme) ora_compute_tracer_tendencies(g, scheme);
+    ora_time_step_momentum(g, dt, 0);
+    if (scheme) ora_dynamic_step_tracers(g, dt, 0);
+    ora_layered_step_fields(g, s, w, dt);
+    ora_update_state(g);
+}
+void ora_time_step_rk3_snow(ora_problem* g, double dt, int scheme, const ora_slab* s, const ora_snow* w) {
+    copy_parent(g, g->hm, g->h);
+    copy_parent(g, g->am, g->aice);
+    copy_parent(g, g->hsm, g->hs);
+    copy_parent(g, g->um, g->u);
+    copy_parent(g, g->vm, g->v);
+    for (int beta = 3; beta >= 1; --beta) {
+        double dtau = dt / beta;
+        if (scheme) ora_compute_tracer_tendencies(g, scheme);
+        ora_time_step_momentum(g, dtau, 1);
+        if (scheme) ora_dynamic_step_tracers(g, dtau, 1);
+        ora_layered_step_fields(g, s, w, dtau);
+        ora_update_state(g);
+    }
 }
 void ora_time_step_rk3_thermo(ora_problem* g, double dt, int scheme, const ora_slab* s) {
     copy_parent(g, g->hm, g->h);

@@ -98,6 +98,8 @@ typedef struct {
     ora_field un, vn;            /* (f,c),(c,f) */
     ora_field Gh, Ga;            /* tracer tendencies (c,c) */
     ora_field hm, am, um, vm;    /* Psi^- cache for RK3: h, aice, u, v */
+    ora_field hs, Ghs, hsm;      /* snow thickness, its tendency and Psi^- copy (used when has_snow) */
+    int32_t has_snow, pad_snow;
 } ora_problem;
 
 /* ---- grid metric accessors (Oceananigans operators) ---- */
@@ -162,12 +164,33 @@ typedef struct {
     double liq_slope, liq_T0;                   /* LinearLiquidus: Tm = T0 - slope * S */
     double salinity;
     double h_consolidation;
-    int32_t top_bc_kind;   /* 0 = PrescribedTemperature(Tu), 1 = MeltingConstrainedFluxBalance not supported */
+    int32_t top_bc_kind;   /* 0 = PrescribedTemperature(Tu); 1 = MeltingConstrainedFluxBalance with a NUMERIC external flux:
+                            * the secant solve of Qx - Qi(T) = 0 (top_heat_boundary_conditions.jl:80-97, RootSolvers, absent)
+                            * has the closed-form root T = Tb - Qx R of the linear conductive flux, capped at Tm */
     int32_t top_flux_kind; /* 0 = const Qu, 1 = internal-flux equilibrium (default for PrescribedTemperature) */
     int32_t bot_flux_kind; /* 0 = const Qb, 1 = FluxFunction -(1 - aice) * Qb (examples/freezing_bucket.jl:79-81, Qb = 1) */
     int32_t pad;
     double Tu, Qu, Qb;
+    double ice_salinity;   /* model.ice_salinity (fields.S): Tm = melting_temperature(liquidus, S) caps the solved Tu */
 } ora_slab;
+/* snow layer on top of the slab: snow_slab_thermodynamics (slab_sea_ice_thermodynamics.jl:42-49), snow_density and
+ * snowfall of SeaIceModel (sea_ice_model.jl) */
+typedef struct {
+    double k_snow;       /* conductivity 0.31 */
+    double rho_snow;     /* snow_density 330 */
+    double snowfall;     /* kg m^-2 s^-1, constant */
+    double Tu;           /* PrescribedTemperature of the snow surface (top_bc_kind 0) */
+    int32_t top_bc_kind; /* as ora_slab.top_bc_kind, for the snow surface */
+    int32_t pad;
+} ora_snow;
+/* _layered_thermodynamic_time_step!, thermodynamic_time_step.jl:131-298, on n independent cells; the mass_flux
+ * arrays (thermodynamics.ice, thermodynamics.snow, intercepted_snowfall) and the two temperature outputs (ice top =
+ * snow-ice interface, snow top) may be NULL */
+void ora_layered_thermo_step(const ora_slab* s, const ora_snow* w, int64_t n, double* h, double* aice, double* hs,
+                             double* mf_ice, double* mf_snow, double* mf_int, double* tu_ice, double* tu_snow, double dt);
+void ora_layered_step_fields(ora_problem* g, const ora_slab* s, const ora_snow* w, double dt);
+void ora_time_step_fe_snow(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s, const ora_snow* w);
+void ora_time_step_rk3_snow(ora_problem* g, double dt, int scheme, const ora_slab* s, const ora_snow* w);
 void ora_slab_thermo_step(const ora_slab* s, int64_t n, double* h, double* aice, double* mass_flux, double dt);
 void ora_slab_step_fields(ora_problem* g, const ora_slab* s, double dt);
 void ora_time_step_fe_thermo(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s);

@@ -41,7 +41,7 @@ class Stress(C.Structure):
 
 
 _FIELD_NAMES = ["u", "v", "h", "aice", "s11", "s22", "s12", "zeta_c", "zeta_f", "Delta", "alpha", "P",
-                "un", "vn", "Gh", "Ga", "hm", "am", "um", "vm"]
+                "un", "vn", "Gh", "Ga", "hm", "am", "um", "vm", "hs", "Ghs", "hsm"]
 
 # staggering of every field: (x location, y location)
 LOCATION = {"u": (FACE, CENTER), "v": (CENTER, FACE), "h": (CENTER, CENTER), "aice": (CENTER, CENTER),
@@ -49,7 +49,8 @@ LOCATION = {"u": (FACE, CENTER), "v": (CENTER, FACE), "h": (CENTER, CENTER), "ai
             "zeta_c": (CENTER, CENTER), "zeta_f": (FACE, FACE), "Delta": (CENTER, CENTER),
             "alpha": (CENTER, CENTER), "P": (CENTER, CENTER), "un": (FACE, CENTER), "vn": (CENTER, FACE),
             "Gh": (CENTER, CENTER), "Ga": (CENTER, CENTER), "hm": (CENTER, CENTER), "am": (CENTER, CENTER),
-            "um": (FACE, CENTER), "vm": (CENTER, FACE)}
+            "um": (FACE, CENTER), "vm": (CENTER, FACE),
+            "hs": (CENTER, CENTER), "Ghs": (CENTER, CENTER), "hsm": (CENTER, CENTER)}
 
 
 class ProblemStruct(C.Structure):
@@ -66,7 +67,7 @@ class ProblemStruct(C.Structure):
                  ("f_coriolis", C.c_double), ("has_coriolis", C.c_int32), ("free_drift_kind", C.c_int32),
                  ("fu_rows", C.POINTER(C.c_double)), ("fv_rows", C.POINTER(C.c_double)),
                  ("top", Stress), ("bottom", Stress)] +
-                [(n, Field) for n in _FIELD_NAMES])
+                [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("pad_snow", C.c_int32)])
 
 
 class Slab(C.Structure):
@@ -75,7 +76,12 @@ class Slab(C.Structure):
                 ("L0", C.c_double), ("T0", C.c_double), ("liq_slope", C.c_double), ("liq_T0", C.c_double),
                 ("salinity", C.c_double), ("h_consolidation", C.c_double),
                 ("top_bc_kind", C.c_int32), ("top_flux_kind", C.c_int32), ("bot_flux_kind", C.c_int32), ("pad", C.c_int32),
-                ("Tu", C.c_double), ("Qu", C.c_double), ("Qb", C.c_double)]
+                ("Tu", C.c_double), ("Qu", C.c_double), ("Qb", C.c_double), ("ice_salinity", C.c_double)]
+
+
+class Snow(C.Structure):
+    _fields_ = [("k_snow", C.c_double), ("rho_snow", C.c_double), ("snowfall", C.c_double), ("Tu", C.c_double),
+                ("top_bc_kind", C.c_int32), ("pad", C.c_int32)]
 
 
 _lib_cache = {}
@@ -136,6 +142,10 @@ def lib(omp=False):
         L.ora_time_step_fe_thermo.argtypes = [P, dbl, i32, i32, C.POINTER(Slab)]
         L.ora_time_step_rk3_thermo.argtypes = [P, dbl, i32, C.POINTER(Slab)]
         L.ora_slab_thermo_step.argtypes = [C.POINTER(Slab), C.c_int64, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl), dbl]
+        pd = C.POINTER(dbl)
+        L.ora_layered_thermo_step.argtypes = [C.POINTER(Slab), C.POINTER(Snow), C.c_int64, pd, pd, pd, pd, pd, pd, pd, pd, dbl]
+        L.ora_time_step_fe_snow.argtypes = [P, dbl, i32, i32, C.POINTER(Slab), C.POINTER(Snow)]
+        L.ora_time_step_rk3_snow.argtypes = [P, dbl, i32, C.POINTER(Slab), C.POINTER(Snow)]
         for fn in dir(L):
             pass
         _lib_cache[key] = L
@@ -297,14 +307,18 @@ class Problem:
     def dynamic_step_tracers(self, dt, from_cache=False):
         self.L.ora_dynamic_step_tracers(self.ptr, dt, int(from_cache))
 
-    def time_step_fe(self, dt, scheme=0, first_iteration=False, slab=None):
-        if slab is None:
+    def time_step_fe(self, dt, scheme=0, first_iteration=False, slab=None, snow=None):
+        if snow is not None:
+            self.L.ora_time_step_fe_snow(self.ptr, dt, scheme, int(first_iteration), C.byref(slab), C.byref(snow))
+        elif slab is None:
             self.L.ora_time_step_fe(self.ptr, dt, scheme, int(first_iteration))
         else:
             self.L.ora_time_step_fe_thermo(self.ptr, dt, scheme, int(first_iteration), C.byref(slab))
 
-    def time_step_rk3(self, dt, scheme=0, slab=None):
-        if slab is None:
+    def time_step_rk3(self, dt, scheme=0, slab=None, snow=None):
+        if snow is not None:
+            self.L.ora_time_step_rk3_snow(self.ptr, dt, scheme, C.byref(slab), C.byref(snow))
+        elif slab is None:
             self.L.ora_time_step_rk3(self.ptr, dt, scheme)
         else:
             self.L.ora_time_step_rk3_thermo(self.ptr, dt, scheme, C.byref(slab))
@@ -312,9 +326,27 @@ class Problem:
 
 def make_slab(*, k_ice=2.0, rho_bulk=900.0, rho_pure=917.0, rho_liquid=999.8, c_liquid=4186.0, c_ice=2000.0, L0=334e3,
               T0=0.0, liq_slope=0.054, liq_T0=0.0, salinity=0.0, h_consolidation=0.05, Tu=-10.0, top_flux_kind=1, Qu=0.0,
-              bot_flux_kind=0, Qb=0.0):
+              bot_flux_kind=0, Qb=0.0, top_bc_kind=0, ice_salinity=0.0):
+    """top_bc_kind 0: PrescribedTemperature(Tu); 1: MeltingConstrainedFluxBalance with the numeric top flux Qu."""
     return Slab(k_ice, rho_bulk, rho_pure, rho_liquid, c_liquid, c_ice, L0, T0, liq_slope, liq_T0, salinity,
-                h_consolidation, 0, top_flux_kind, bot_flux_kind, 0, Tu, Qu, Qb)
+                h_consolidation, top_bc_kind, top_flux_kind, bot_flux_kind, 0, Tu, Qu, Qb, ice_salinity)
+
+
+def make_snow(*, k_snow=0.31, rho_snow=330.0, snowfall=0.0, Tu=-10.0, top_bc_kind=1):
+    """snow_slab_thermodynamics defaults (slab_sea_ice_thermodynamics.jl:42-49); top_bc_kind as make_slab."""
+    return Snow(k_snow, rho_snow, snowfall, Tu, top_bc_kind, 0)
+
+
+def layered_step(h, aice, hs, dt, slab, snow):
+    """_layered_thermodynamic_time_step! on arrays of independent cells; returns a dict of new h, aice, hs, the three
+    mass fluxes and the two surface temperatures."""
+    out = {k: np.ascontiguousarray(v, dtype=np.float64).copy() for k, v in (("h", h), ("aice", aice), ("hs", hs))}
+    for k in ("mf_ice", "mf_snow", "mf_int", "tu_ice", "tu_snow"):
+        out[k] = np.zeros_like(out["h"])
+    lib().ora_layered_thermo_step(C.byref(slab), C.byref(snow), out["h"].size, _dptr(out["h"]), _dptr(out["aice"]), _dptr(out["hs"]),
+                                  _dptr(out["mf_ice"]), _dptr(out["mf_snow"]), _dptr(out["mf_int"]), _dptr(out["tu_ice"]),
+                                  _dptr(out["tu_snow"]), dt)
+    return out
 
 
 def slab_step(h, aice, dt, *, k_ice=2.0, rho_bulk=900.0, rho_pure=917.0, rho_liquid=999.8, c_liquid=4186.0,
@@ -322,7 +354,7 @@ def slab_step(h, aice, dt, *, k_ice=2.0, rho_bulk=900.0, rho_pure=917.0, rho_liq
               Tu=-10.0, top_flux_kind=1, Qu=0.0, bot_flux_kind=0, Qb=0.0):
     """Bare-ice slab step with PrescribedTemperature top BC (oracle for csi_slab_thermo_step)."""
     s = Slab(k_ice, rho_bulk, rho_pure, rho_liquid, c_liquid, c_ice, L0, T0, liq_slope, liq_T0, salinity,
-             h_consolidation, 0, top_flux_kind, bot_flux_kind, 0, Tu, Qu, Qb)
+             h_consolidation, 0, top_flux_kind, bot_flux_kind, 0, Tu, Qu, Qb, 0.0)
     h = np.ascontiguousarray(h, dtype=np.float64).copy()
     a = np.ascontiguousarray(aice, dtype=np.float64).copy()
     mf = np.zeros_like(h)

@@ -245,6 +245,97 @@ def test_slab_thermodynamics_vs_oracle():
         assert np.array_equal(mf.interior_numpy().ravel(), flux)
 
 
+@pytest.mark.parametrize("bc", [0, 1])
+def test_layered_snow_step_bitwise(bc):
+    """_layered_thermodynamic_time_step! (thermodynamic_time_step.jl:131-298): every cell of a 64 x 32 grid in a
+    different regime (open water, thin / consolidated ice, with / without snow), 20 steps of melting, freezing and
+    snowfall; the bare-ice step with the MeltingConstrainedFluxBalance top boundary condition likewise.  HIP == oracle
+    bit for bit on h, aice, hs, the three mass fluxes and the two surface temperatures."""
+    g = csi.RectilinearGrid((64, 32), x=(0, 1), y=(0, 1), halo=(3, 3))
+    rng = np.random.default_rng(31 + bc)
+    shape = (32, 64)
+    h0 = rng.random(shape) * 2.0 * (rng.random(shape) > 0.15)
+    a0 = np.where(h0 > 0, rng.random(shape), 0.0)
+    hs0 = rng.random(shape) * 0.5 * (rng.random(shape) > 0.4) * (h0 > 0)
+    for Qu, Qb, Ps in ((-150.0, 5.0, 2e-5), (80.0, -10.0, 0.0), (0.0, "frazil", 1e-5)):
+        ice = csi.SlabThermodynamics(top_temperature=-8.0, top_heat_flux=Qu, bottom_heat_flux=Qb, bottom_salinity=30.0,
+                                     top_heat_boundary_condition=csi.MeltingConstrainedFluxBalance() if bc else None)
+        snow = csi.snow_slab_thermodynamics(top_heat_boundary_condition=None if bc else csi.PrescribedTemperature(-8.0))
+        model = csi.SeaIceModel(g, dynamics=None, ice_thermodynamics=ice, snow_thermodynamics=snow, snowfall=Ps,
+                                timestepper="ForwardEuler")
+        csi.set_(model, h=h0, aice=a0, hs=hs0)
+        slab_o = O.make_slab(top_bc_kind=bc, Tu=-8.0, top_flux_kind=0, Qu=Qu, salinity=30.0,
+                             bot_flux_kind=1 if Qb == "frazil" else 0, Qb=1.0 if Qb == "frazil" else Qb)
+        snow_o = O.make_snow(top_bc_kind=bc, Tu=-8.0, snowfall=Ps)
+        r = dict(h=h0.ravel(), aice=a0.ravel(), hs=hs0.ravel())
+        for n in range(20):
+            r = O.layered_step(r["h"], r["aice"], r["hs"], 600.0, slab_o, snow_o)
+            csi.time_step(model, 600.0)
+        model.synchronize()
+        got = dict(h=model.ice_thickness, aice=model.ice_concentration, hs=model.snow_thickness,
+                   mf_ice=model.mass_fluxes.thermodynamics.ice, mf_snow=model.mass_fluxes.thermodynamics.snow,
+                   mf_int=model.mass_fluxes.intercepted_snowfall, tu_ice=model.ice_top_temperature, tu_snow=model.snow_top_temperature)
+        for k, f in got.items():
+            a = f.interior_numpy().ravel()
+            assert np.all(np.isfinite(a)), k
+            assert np.array_equal(a, r[k]), (bc, Qu, k, np.abs(a - r[k]).max())
+        assert (r["hs"] > 0).any()
+    # bare ice with the flux-balance boundary condition
+    ice = csi.SlabThermodynamics(top_heat_flux=-60.0, bottom_heat_flux=4.0, bottom_salinity=30.0, ice_salinity=5.0,
+                                 top_heat_boundary_condition=csi.MeltingConstrainedFluxBalance())
+    model = csi.SeaIceModel(g, dynamics=None, ice_thermodynamics=ice, timestepper="ForwardEuler")
+    csi.set_(model, h=h0, aice=a0)
+    slab_o = O.make_slab(top_bc_kind=1, top_flux_kind=0, Qu=-60.0, Qb=4.0, salinity=30.0, ice_salinity=5.0)
+    h, a = h0.ravel().copy(), a0.ravel().copy()
+    mf = np.zeros_like(h)
+    for n in range(20):
+        O.lib().ora_slab_thermo_step(C.byref(slab_o), h.size, O._dptr(h), O._dptr(a), O._dptr(mf), 600.0)
+        csi.time_step(model, 600.0)
+    model.synchronize()
+    assert np.array_equal(model.ice_thickness.interior_numpy().ravel(), h)
+    assert np.array_equal(model.ice_concentration.interior_numpy().ravel(), a)
+
+
+@pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
+def test_full_time_step_with_snow_vs_oracle(stepper, oracle_lib):
+    """time_step! with EVP dynamics, WENO7 advection of h, aice AND hs (tracer_tendency_kernel_functions.jl:49-52,
+    sea_ice_fe_step.jl:86-94), the layered thermodynamic step and update_state! on an immersed channel
+    (the configuration of test/test_snow_thermodynamics.jl:171-187 with dynamics switched on)."""
+    c = cases.make_case(Nx=48, Ny=40, substeps=12, topo=("periodic", "bounded"), patches=True, random_uv=0.02, land=0.2)
+    rng = np.random.default_rng(41)
+    hs0 = np.where(c["a"] > 0, 0.3 * rng.random(c["a"].shape), 0.0)
+    slab_o = O.make_slab(top_bc_kind=1, top_flux_kind=0, Qu=-80.0, Qb=6.0, salinity=30.0)
+    snow_o = O.make_snow(snowfall=3e-5)
+    for mode, tol in (("strict", 1e-12), ("fast", 1e-11)):
+        p = cases.oracle_problem(c)
+        p.s.has_snow = 1
+        p.interior("hs")[...] = hs0
+        p.update_state()
+        g = c["g"]
+        ice = csi.SlabThermodynamics(top_heat_flux=-80.0, bottom_heat_flux=6.0, bottom_salinity=30.0,
+                                     top_heat_boundary_condition=csi.MeltingConstrainedFluxBalance())
+        dyn = csi.SeaIceMomentumEquation(g, coriolis=csi.FPlane(f=c["coriolis"]), top_momentum_stress=c["top"],
+                                         bottom_momentum_stress=csi.SemiImplicitStress(), solver=csi.SplitExplicitSolver(substeps=12))
+        m = csi.SeaIceModel(g, dynamics=dyn, advection=csi.WENO(order=7), ice_thermodynamics=ice,
+                            snow_thermodynamics=csi.snow_slab_thermodynamics(), snowfall=3e-5, timestepper=stepper, mode=mode)
+        m.set_mask(c["mask"])
+        csi.set_(m, h=c["h"], aice=c["a"], u=c["u"], v=c["v"], hs=hs0)
+        for n in range(2):
+            if stepper == "ForwardEuler":
+                p.time_step_fe(c["dt"], 7, n == 0, slab=slab_o, snow=snow_o)
+            else:
+                p.time_step_rk3(c["dt"], 7, slab=slab_o, snow=snow_o)
+            csi.time_step(m, c["dt"])
+        m.synchronize()
+        vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+        for k, f in (("u", m.velocities.u), ("v", m.velocities.v)):
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * vmax, (mode, k)
+        for k, f in (("h", m.ice_thickness), ("aice", m.ice_concentration), ("hs", m.snow_thickness)):
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * np.abs(p.f[k]).max(), (mode, k, np.abs(f.numpy() - p.f[k]).max())
+            assert np.array_equal(f.numpy() == 0.0, p.f[k] == 0.0), (mode, k, "zero set")
+        assert np.abs(p.interior("hs") - hs0).max() > 1e-4            # the snow did something
+
+
 def test_config4_style_latlon_evp_plus_slab_thermodynamics(oracle_lib):
     """BASELINE config 4 in miniature: lat-lon (lon 0..60, lat 20..70) channel, EVP + WENO7 (order reduced next to
     the walls) + bare-ice slab thermodynamics (top 100 W m^-2, bottom 10 W m^-2, test/test_thermodynamic_mass_fluxes.jl:56), RK3, 2 steps."""

@@ -1,6 +1,8 @@
 """CPU tests that pin the oracle with what the reference's own tests pin for this path
 (SURVEY.md 8c): the strain / stress-divergence adjoint identity, the drag bound, the slab
 known answer; plus the bit-for-bit cross-check of the two independent restatements."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -329,3 +331,61 @@ def test_stress_balance_free_drift_closed_form(oracle_lib):
         got = p.interior("u")[marginal_u]
         assert np.allclose(got, want, rtol=1e-15, atol=0), (fd, got[:3], want)
         assert p.L.ora_free_drift_u(p.ptr, 3, 3) == (want if fd else 0.0) or fd
+
+
+# ---- snow layer (thermodynamic_time_step.jl:131-298) -------------------------------------------------------------------
+def test_snow_layer_reference_scenarios(oracle_lib):
+    """The scenarios of test/test_snow_thermodynamics.jl on the oracle's layered step: flooding (:99-122), snowfall
+    accumulation (:124-144), snow melts before ice (:146-169), interface temperature (:76-97)."""
+    # flooding: heavy snow on thin ice -> ice grows, snow shrinks, mass moves from snow to ice
+    r = O.layered_step([0.5], [1.0], [1.0], 1.0, O.make_slab(top_bc_kind=0, Tu=-5.0, top_flux_kind=0), O.make_snow())
+    assert r["h"][0] > 0.5 and r["hs"][0] < 1.0
+    assert abs(900.0 * (r["h"][0] - 0.5) + 330.0 * (r["hs"][0] - 1.0)) < 1e-10
+    hf = r["h"][0] * (1 - 900.0 / 999.8) - r["hs"][0] * 330.0 / 999.8
+    assert abs(hf) < 1e-13                                        # freeboard back to zero
+    # snowfall: hs = Ps / rho_s * dt on full ice cover, recorded as intercepted snowfall
+    r = O.layered_step([1.0], [1.0], [0.0], 3600.0, O.make_slab(top_bc_kind=1, top_flux_kind=0), O.make_snow(snowfall=1e-5))
+    assert r["hs"][0] == 1e-5 / 330.0 * 3600.0 and r["mf_int"][0] == 1e-5 and r["h"][0] == 1.0
+    # incoming heat melts snow first: hs drops by Q dt / (rho_s L), the ice is untouched, the surface sits at 0 C
+    r = O.layered_step([2.0], [1.0], [0.1], 3600.0, O.make_slab(top_bc_kind=1, top_flux_kind=0, Qu=-100.0), O.make_snow())
+    assert abs((0.1 - r["hs"][0]) - 100.0 * 3600.0 / (330.0 * 334e3)) < 1e-15 and r["h"][0] == 2.0 and r["tu_snow"][0] == 0.0
+    # interface temperature of a cold prescribed surface: between Tu and Tb, resistors in series
+    slab = O.make_slab(top_bc_kind=0, top_flux_kind=0, salinity=1.8 / 0.054)
+    r = O.layered_step([1.0], [1.0], [0.3], 1.0, slab, O.make_snow(top_bc_kind=0, Tu=-10.0))
+    Tb, Ri, Rs = -0.054 * (1.8 / 0.054), 1.0 / 2.0, 0.3 / 0.31
+    assert abs(r["tu_ice"][0] - (Tb + (-10.0 - Tb) * Ri / (Rs + Ri))) < 1e-14 and -10.0 < r["tu_ice"][0] < Tb
+
+
+@pytest.mark.parametrize("bc", [0, 1])
+def test_snow_layer_mass_fluxes_close_and_bare_limit(bc, oracle_lib):
+    """Random cells in every regime (open water, thin / consolidated ice, with and without snow, melting and
+    freezing): the recorded mass fluxes close the ice and snow volume changes (thermodynamic_time_step.jl:293-297);
+    with no snow and no snowfall the layered step is the bare-ice step with the same boundary condition."""
+    rng = np.random.default_rng(23 + bc)
+    n = 4000
+    h = rng.random(n) * 2.0 * (rng.random(n) > 0.15)
+    a = np.where(h > 0, rng.random(n), 0.0)
+    hs = rng.random(n) * 0.5 * (rng.random(n) > 0.4) * (h > 0)
+    dt = 600.0
+    for Qu, Qb, Ps in ((-150.0, 5.0, 2e-5), (80.0, -10.0, 0.0), (0.0, 0.0, 1e-5)):
+        slab = O.make_slab(top_bc_kind=bc, Tu=-8.0, top_flux_kind=0, Qu=Qu, Qb=Qb, salinity=30.0)
+        snow = O.make_snow(top_bc_kind=bc, Tu=-8.0, snowfall=Ps)
+        r = O.layered_step(h, a, hs, dt, slab, snow)
+        for k in r:
+            assert np.all(np.isfinite(r[k])), k
+        assert np.all((r["aice"] >= 0) & (r["aice"] <= 1) & (r["h"] >= 0) & (r["hs"] >= 0))
+        assert np.all(r["hs"][r["aice"] == 0] == 0)
+        dVi = 900.0 * (r["h"] * r["aice"] - h * a) / dt
+        dVs = 330.0 * (r["hs"] * r["aice"] - hs * a) / dt
+        assert np.array_equal(r["mf_ice"], dVi)
+        assert np.abs(r["mf_snow"] + r["mf_int"] - dVs).max() <= 1e-12 * max(1e-30, np.abs(dVs).max())
+        assert np.array_equal(r["mf_int"], 330.0 * np.where(r["aice"] > 0, Ps / 330.0, 0.0) * r["aice"])
+        assert (r["hs"] < hs).any() or Qu >= 0
+    # bare limit
+    slab = O.make_slab(top_bc_kind=bc, Tu=-8.0, top_flux_kind=0, Qu=-40.0, Qb=3.0, salinity=30.0)
+    r = O.layered_step(h, a, 0 * hs, dt, slab, O.make_snow(top_bc_kind=bc, Tu=-8.0))
+    hb, ab = h.copy(), a.copy()
+    mf = np.zeros(n)
+    O.lib().ora_slab_thermo_step(C.byref(slab), n, O._dptr(hb), O._dptr(ab), O._dptr(mf), dt)
+    assert np.all(r["hs"] == 0)
+    assert np.abs(r["h"] - hb).max() <= 1e-13 and np.abs(r["aice"] - ab).max() <= 1e-13
