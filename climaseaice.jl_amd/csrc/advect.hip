@@ -135,7 +135,7 @@ __device__ __forceinline__ double reconstruct(const double* base, long st, bool 
 // them are inactive); else the topological rule next to walls; else the full scheme
 template <int SCHEME>
 __device__ __forceinline__ int buffer_at(const GridDev& g, int i, int j, bool along_y, bool left) {
-    constexpr int B0 = SCHEME == 7 ? 4 : (SCHEME == 1 ? 1 : 3);
+    constexpr int B0 = SCHEME == 7 ? 4 : (SCHEME == 1 ? 1 : ((SCHEME == 3 || SCHEME == -3) ? 2 : 3));   // order 2B - 1
     if (SCHEME == 1) return 1;
     if (g.has_mask) return reduced_buffer_immersed(g, B0, i, j, along_y);
     const bool wl = (along_y ? g.ylo : g.xlo) == SIDE_WALL, wh = (along_y ? g.yhi : g.xhi) == SIDE_WALL;
@@ -229,6 +229,8 @@ void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
     dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY - 1) / adv::TY));
     switch (A.scheme) {
         case 1: hipLaunchKernelGGL(adv::k_tendencies<1>, gr, b, 0, s, A); break;
+        case 3: hipLaunchKernelGGL(adv::k_tendencies<3>, gr, b, 0, s, A); break;
+        case -3: hipLaunchKernelGGL(adv::k_tendencies<-3>, gr, b, 0, s, A); break;
         case 5: hipLaunchKernelGGL(adv::k_tendencies<5>, gr, b, 0, s, A); break;
         case -5: hipLaunchKernelGGL(adv::k_tendencies<-5>, gr, b, 0, s, A); break;
         default: hipLaunchKernelGGL(adv::k_tendencies<7>, gr, b, 0, s, A); break;

@@ -812,8 +812,9 @@ int32_t do_update_state(csi_context* c) {
 int32_t do_tendencies(csi_context* c, int scheme) {
     int32_t rc;
     if ((rc = need(c, {CSI_F_U, CSI_F_V, CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA}))) return rc;
-    int need_h = scheme == CSI_ADVECT_WENO7 ? 4 : (scheme == CSI_ADVECT_UPWIND1 ? 1 : 3);
-    if (scheme != CSI_ADVECT_UPWIND1 && scheme != CSI_ADVECT_WENO5 && scheme != CSI_ADVECT_WENO7 && scheme != CSI_ADVECT_UPWIND5)
+    const bool third = scheme == CSI_ADVECT_WENO3 || scheme == CSI_ADVECT_UPWIND3;
+    int need_h = scheme == CSI_ADVECT_WENO7 ? 4 : (scheme == CSI_ADVECT_UPWIND1 ? 1 : (third ? 2 : 3));
+    if (scheme != CSI_ADVECT_UPWIND1 && scheme != CSI_ADVECT_WENO5 && scheme != CSI_ADVECT_WENO7 && scheme != CSI_ADVECT_UPWIND5 && !third)
         return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown advection scheme");
     if (c->Hx < need_h || c->Hy < need_h) return fail(c, CSI_ERR_INVALID_ARGUMENT, "halo too small for the advection scheme");
     launch_tracer_tendencies(adv_dev(c, scheme, 0.0, 0), c->mode, c->stream);

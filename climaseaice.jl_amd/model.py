@@ -85,18 +85,18 @@ def snow_slab_thermodynamics(grid=None, conductivity=0.31, **kw):
 
 class WENO:
     def __init__(self, order=5):
-        if order not in (5, 7):
-            raise NotImplementedError("WENO order 5 or 7")
+        if order not in (3, 5, 7):
+            raise NotImplementedError("WENO order 3, 5 or 7")
         self.order = order
         self.scheme = order
 
 
 class UpwindBiased:
     def __init__(self, order=5):
-        if order not in (1, 5):
-            raise NotImplementedError("UpwindBiased order 1 or 5")
+        if order not in (1, 3, 5):
+            raise NotImplementedError("UpwindBiased order 1, 3 or 5")
         self.order = order
-        self.scheme = 1 if order == 1 else -5
+        self.scheme = 1 if order == 1 else -order
 
 
 _TOPO = {Periodic: _lib.PERIODIC, Bounded: _lib.BOUNDED, FullyConnected: _lib.FULLY_CONNECTED,

@@ -152,8 +152,8 @@ typedef struct {
  *         by rounding only (tolerance stated in DESIGN.md and enforced in tests/). */
 typedef enum { CSI_MODE_STRICT = 0, CSI_MODE_FAST = 1 } csi_mode;
 
-typedef enum { CSI_ADVECT_NONE = 0, CSI_ADVECT_UPWIND1 = 1, CSI_ADVECT_WENO5 = 5, CSI_ADVECT_WENO7 = 7,
-               CSI_ADVECT_UPWIND5 = -5 } csi_advection_scheme;
+typedef enum { CSI_ADVECT_NONE = 0, CSI_ADVECT_UPWIND1 = 1, CSI_ADVECT_WENO3 = 3, CSI_ADVECT_WENO5 = 5, CSI_ADVECT_WENO7 = 7,
+               CSI_ADVECT_UPWIND3 = -3, CSI_ADVECT_UPWIND5 = -5 } csi_advection_scheme;
 
 typedef struct csi_context csi_context;
 

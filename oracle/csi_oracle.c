@@ -686,7 +686,7 @@ static double reconstruct(int scheme, const double* line, int64_t up, int64_t st
     return weno7(p);
 }
 static int buffer_at(const ora_problem* g, int scheme, int i, int j, int dir, int left) {
-    const int B0 = scheme == 7 ? 4 : (scheme == 1 ? 1 : 3);
+    const int B0 = scheme == 7 ? 4 : (scheme == 1 ? 1 : ((scheme == 3 || scheme == -3) ? 2 : 3));   /* order 2B - 1 */
     if (g->has_mask) return reduced_buffer_immersed(g, B0, i, j, dir);
     const int topo = dir == 0 ? g->topo_x : g->topo_y;
     return reduced_buffer(B0, dir == 0 ? i : j, dir == 0 ? g->Nx : g->Ny, left, wall_lo(topo), wall_hi(topo));

@@ -33,7 +33,7 @@ def anticyclone_case(N, H=4, **kw):
     return c
 
 
-@pytest.mark.parametrize("scheme", [7, 5, -5, 1])
+@pytest.mark.parametrize("scheme", [7, 5, -5, 3, -3, 1])
 @pytest.mark.parametrize("N", [48, 512])
 def test_tracer_tendencies_and_update_bitwise(scheme, N, oracle_lib):
     c = anticyclone_case(N)
@@ -92,7 +92,7 @@ def test_tracer_tendencies_next_to_walls_bitwise(topo, scheme, oracle_lib):
         assert abs(got.sum()) <= 1e-9 * np.abs(got).sum()           # closed walls: flux form conserves
 
 
-@pytest.mark.parametrize("scheme", [7, 5, -5, 1])
+@pytest.mark.parametrize("scheme", [7, 5, -5, 3, -3, 1])
 @pytest.mark.parametrize("topo", [("periodic", "periodic"), ("periodic", "bounded"), ("bounded", "bounded")])
 def test_tracer_tendencies_next_to_immersed_cells_bitwise(topo, scheme, oracle_lib):
     """ImmersedBoundaryGrid: closed faces next to land and the order reduction of the reconstructions around immersed

@@ -255,7 +255,7 @@ def _masked_advection_case(topo, seed=0):
     return c
 
 
-@pytest.mark.parametrize("scheme", [7, 5, -5, 1])
+@pytest.mark.parametrize("scheme", [7, 5, -5, 3, -3, 1])
 @pytest.mark.parametrize("topo", [("periodic", "periodic"), ("periodic", "bounded"), ("bounded", "bounded")])
 def test_advection_next_to_immersed_cells(topo, scheme, oracle_lib):
     """ImmersedBoundaryGrid (the reference's horizontal_div_Uc goes through upstream's _advective_tracer_flux_x/y,
