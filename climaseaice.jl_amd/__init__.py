@@ -10,7 +10,8 @@ from ._lib import Context, CsiError, plan_exchange, plan_ranges
 from .dynamics import (Auxiliaries, BetaPlane, ElastoViscoPlasticRheology, FPlane, IceStrength, ReplacementPressure,
                        SeaIceMomentumEquation, SemiImplicitStress, SplitExplicitSolver, StressBalanceFreeDrift)
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
-from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected, Periodic,
+from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected,
+                    OrthogonalCurvilinearGrid, Periodic,
                     RectilinearGrid, RightConnected, TileGrid)
 from .model import (MeltingConstrainedFluxBalance, PrescribedTemperature, SeaIceModel, SlabThermodynamics, SnowSlabThermodynamics,
                     snow_slab_thermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state)

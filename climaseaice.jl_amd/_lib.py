@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcsi_hip.so")
 # ---- enums (include/csi.h) ---------------------------------------------------------------------
 OK = 0
 PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3, 4
-METRIC_UNIFORM, METRIC_PER_J = 0, 1
+METRIC_UNIFORM, METRIC_PER_J, METRIC_FULL = 0, 1, 2
 FIELD_IDS = ["U", "V", "H", "A", "S11", "S22", "S12", "UN", "VN", "P", "ALPHA", "DELTA", "ZETA_F", "ZETA_C",
              "GH", "GA", "HM", "AM", "UM", "VM", "TOP_U", "TOP_V", "BOT_U", "BOT_V", "MASS_FLUX",
              "HS", "GHS", "HSM", "MASS_FLUX_SNOW", "SNOWFALL_INTERCEPTED", "TU", "TUS"]
@@ -37,7 +37,8 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
 class Metrics(C.Structure):
     _fields_ = [("dx", C.c_double), ("dy", C.c_double),
                 ("dxc", C.POINTER(C.c_double)), ("dxf", C.POINTER(C.c_double)),
-                ("azc", C.POINTER(C.c_double)), ("azf", C.POINTER(C.c_double))]
+                ("azc", C.POINTER(C.c_double)), ("azf", C.POINTER(C.c_double)),
+                ("full", C.POINTER(C.c_double) * 12), ("full_ld", C.c_int64)]
 
 
 class EvpParams(C.Structure):

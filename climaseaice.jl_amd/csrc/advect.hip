@@ -143,8 +143,6 @@ __device__ __forceinline__ int buffer_at(const GridDev& g, int i, int j, bool al
     return reduced_buffer(B0, along_y ? j : i, along_y ? g.Ny : g.Nx, left, wl, wh);
 }
 
-__device__ __forceinline__ double dxf_row(const GridDev& g, int j) { return g.metric_kind == 0 ? g.dx : g.dxf[j]; }
-__device__ __forceinline__ double azc_row(const GridDev& g, int j) { return g.metric_kind == 0 ? g.dx * g.dy : g.azc[j]; }
 
 constexpr int TX = 64, TY = 4;
 
@@ -167,9 +165,10 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
             const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left, B);
             const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left, B);
             const bool closed = g.has_mask && peripheral_u(g, i, j);          // conditional_flux_fcc
-            sFxh[ty][tx] = closed ? 0.0 : g.dy * uu * ch;
-            sFxa[ty][tx] = closed ? 0.0 : g.dy * uu * ca;
-            if (A.has_snow) sFxs[ty][tx] = closed ? 0.0 : g.dy * uu * reconstruct<SCHEME>(&A.hs(i, j), 1, left, B);
+            const double ax = dym(g, LOC_F, LOC_C, i, j);                    // Ax^{fcc} = dy^{fcc} * dz
+            sFxh[ty][tx] = closed ? 0.0 : ax * uu * ch;
+            sFxa[ty][tx] = closed ? 0.0 : ax * uu * ca;
+            if (A.has_snow) sFxs[ty][tx] = closed ? 0.0 : ax * uu * reconstruct<SCHEME>(&A.hs(i, j), 1, left, B);
         }
         if (tx < TX && i <= g.Nx) {
             const double vv = A.v(i, j);
@@ -177,7 +176,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
             const int B = buffer_at<SCHEME>(g, i, j, true, left);
             const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left, B);
             const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left, B);
-            const double dxf = dxf_row(g, j);
+            const double dxf = dxm(g, LOC_C, LOC_F, i, j);                   // Ay^{cfc} = dx^{cfc} * dz
             const bool closed = g.has_mask && peripheral_v(g, i, j);          // conditional_flux_cfc
             sFyh[ty][tx] = closed ? 0.0 : dxf * vv * ch;
             sFya[ty][tx] = closed ? 0.0 : dxf * vv * ca;
@@ -186,7 +185,7 @@ __global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_ten
     }
     __syncthreads();
     if (tx < TX && ty < TY && i <= g.Nx && j <= g.Ny) {
-        const double V = azc_row(g, j);
+        const double V = azm(g, LOC_C, LOC_C, i, j);
         const double fxh = sFxh[ty][tx + 1] - sFxh[ty][tx], fyh = sFyh[ty + 1][tx] - sFyh[ty][tx];
         const double fxa = sFxa[ty][tx + 1] - sFxa[ty][tx], fya = sFya[ty + 1][tx] - sFya[ty][tx];
         A.Gh(i, j) = -(1 / V * (fxh + fyh));

@@ -59,7 +59,7 @@ struct csi_context {
     bool grid_set = false, evp_set = false;
     int Nx = 0, Ny = 0, Hx = 0, Hy = 0, topo_x = 0, topo_y = 0, metric_kind = 0;
     GridDev g{};
-    double* dev_metrics = nullptr;   // 8 vectors of length Ny + 2Hy + 1
+    double* dev_metrics = nullptr;   // 8 vectors of length Ny + 2Hy + 1 (PER_J) or 12 planes (FULL)
     double* dev_coef = nullptr;      // FAST per-row stencil coefficients [FC_COUNT][Ny + 2Hy + 1]
     FastCoef coef{};
     std::vector<double> coef_host;       // host copy of the per-row table built from PER_J metrics (empty: uniform metrics)
@@ -191,6 +191,7 @@ int32_t sync_coriolis(csi_context* c) {
     const csi_evp_params& e = c->evp;
     const double f0 = e.has_coriolis ? e.coriolis_f : 0.0;
     if (!c->cor_dirty && f0 == c->cor_synced) return CSI_OK;
+    if (c->metric_kind == CSI_METRIC_FULL) { c->cor_dirty = false; c->cor_synced = f0; return CSI_OK; }   // no FAST table
     const bool rows = e.has_coriolis && !c->fcor_rows[0].empty();
     const bool metrics_uniform = c->metric_kind == CSI_METRIC_UNIFORM;
     c->coef.uni[FC_FU] = f0; c->coef.uni[FC_FV] = f0;
@@ -662,7 +663,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     }
     EvpDev P = evp_dev(c, dt);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
-    const bool fast = c->mode == CSI_MODE_FAST;
+    const bool fast = c->mode == CSI_MODE_FAST && c->metric_kind != CSI_METRIC_FULL;   // general metrics: reference-order kernels
     FastCoef fc = c->coef;
     {
         const double ie = 1.0 / P.ecc;
@@ -949,7 +950,8 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
     if (topo_x < CSI_PERIODIC || topo_x > CSI_RIGHT_CONNECTED || topo_y < CSI_PERIODIC || topo_y > CSI_RIGHT_CONNECTED)
         return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown topology");
     if (!m) return fail(c, CSI_ERR_INVALID_ARGUMENT, "metrics == NULL");
-    if (metric_kind != CSI_METRIC_UNIFORM && metric_kind != CSI_METRIC_PER_J) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown metric kind");
+    if (metric_kind != CSI_METRIC_UNIFORM && metric_kind != CSI_METRIC_PER_J && metric_kind != CSI_METRIC_FULL)
+        return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown metric kind");
     HIP_TRY(c, hipSetDevice(c->device));
     c->Nx = Nx; c->Ny = Ny; c->Hx = Hx; c->Hy = Hy; c->topo_x = topo_x; c->topo_y = topo_y; c->metric_kind = metric_kind;
     GridDev& g = c->g;
@@ -975,6 +977,21 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
         g.dxc = base; g.dxf = base + n; g.azc = base + 2 * n; g.azf = base + 3 * n;
         g.rdxc = base + 4 * n; g.rdxf = base + 5 * n; g.razc = base + 6 * n; g.razf = base + 7 * n;
     }
+    if (metric_kind == CSI_METRIC_FULL) {
+        const int64_t ni = (int64_t)Nx + 2 * Hx + 1, nj = (int64_t)Ny + 2 * Hy + 1;
+        if (m->full_ld < ni) return fail(c, CSI_ERR_INVALID_ARGUMENT, "FULL metrics: full_ld < Nx + 2Hx + 1");
+        std::vector<double> host((size_t)(12 * ni * nj));
+        for (int k = 0; k < 12; ++k) {
+            if (!m->full[k]) return fail(c, CSI_ERR_INVALID_ARGUMENT, "FULL metrics need all twelve arrays");
+            for (int64_t r = 0; r < nj; ++r)
+                for (int64_t q = 0; q < ni; ++q) host[(size_t)((k * nj + r) * ni + q)] = m->full[k][r * m->full_ld + q];
+        }
+        HIP_TRY(c, hipMalloc((void**)&c->dev_metrics, sizeof(double) * host.size()));
+        HIP_TRY(c, hipMemcpy(c->dev_metrics, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+        g.m2 = c->dev_metrics + (Hx - 1) + (int64_t)(Hy - 1) * ni;      // so that m2[k * plane + i + j * ld] is (i, j)
+        g.m2_plane = (long)(ni * nj);
+        g.m2_ld = (int)ni;
+    }
     // FAST-mode stencil coefficients
     if (c->dev_coef) { hipFree(c->dev_coef); c->dev_coef = nullptr; }
     if (c->dev_fcor) { hipFree(c->dev_fcor); c->dev_fcor = nullptr; }
@@ -984,7 +1001,7 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
     c->coef.uniform = metric_kind == CSI_METRIC_UNIFORM;
     if (metric_kind == CSI_METRIC_UNIFORM) {
         build_fast_coef_uniform(m->dx, m->dy, c->coef.uni);
-    } else {
+    } else if (metric_kind == CSI_METRIC_PER_J) {
         const int n = Ny + 2 * Hy + 1;
         std::vector<double> host;
         build_fast_coef_per_j(n, m->dy, m->dxc, m->dxf, m->azc, m->azf, host);
@@ -1313,7 +1330,7 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = P.ca * dt; fc.rdt = 1.0 / dt;
       fc.Dmin2 = P.Dmin * P.Dmin; fc.rDmin = 1.0 / P.Dmin;
       fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax; }
-    const bool fast = c->mode == CSI_MODE_FAST, tiled = is_tiled(c);
+    const bool fast = c->mode == CSI_MODE_FAST && c->metric_kind != CSI_METRIC_FULL, tiled = is_tiled(c);
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};

@@ -21,7 +21,7 @@ struct FRef {
 struct GridDev {
     int Nx, Ny, Hx, Hy;
     int xlo, xhi, ylo, yhi;   // SIDE_* of each edge of this tile
-    int metric_kind;          // 0 uniform, 1 per-j
+    int metric_kind;          // 0 uniform, 1 per-j, 2 full 2-D arrays (orthogonal curvilinear grids; STRICT kernels)
     int has_mask;
     double dx, dy;
     // per-j vectors, indexable directly with the reference j (pointer pre-offset): j in [1-Hy, Ny+Hy+1]
@@ -29,7 +29,31 @@ struct GridDev {
     const double *rdxc, *rdxf, *razc, *razf;   // reciprocals (FAST mode)
     const uint8_t* mask;      // element (0,0)-offset like FRef
     int mask_ld;
+    // metric_kind 2: twelve planes dx, dy, Az at (c,c), (f,c), (c,f), (f,f) -- plane 4 * {dx 0, dy 1, Az 2} + (x Face) +
+    // 2 * (y Face) -- element (i, j) of plane k at m2[k * m2_plane + i + j * m2_ld] (pointer pre-offset)
+    const double* m2;
+    long m2_plane;
+    int m2_ld;
 };
+
+// ---- metrics at a location (Oceananigans.Operators dx / dy / Az at (lx, ly)) --------------------
+__device__ __forceinline__ double metric2(const GridDev& g, int which, int lx, int ly, int i, int j) {
+    return g.m2[(4 * which + (lx == LOC_F ? 1 : 0) + (ly == LOC_F ? 2 : 0)) * g.m2_plane + i + (long)j * g.m2_ld];
+}
+__device__ __forceinline__ double dxm(const GridDev& g, int lx, int ly, int i, int j) {
+    if (g.metric_kind == 0) return g.dx;
+    if (g.metric_kind == 1) return ly == LOC_C ? g.dxc[j] : g.dxf[j];
+    return metric2(g, 0, lx, ly, i, j);
+}
+__device__ __forceinline__ double dym(const GridDev& g, int lx, int ly, int i, int j) {
+    if (g.metric_kind != 2) return g.dy;
+    return metric2(g, 1, lx, ly, i, j);
+}
+__device__ __forceinline__ double azm(const GridDev& g, int lx, int ly, int i, int j) {
+    if (g.metric_kind == 0) return g.dx * g.dy;
+    if (g.metric_kind == 1) return ly == LOC_C ? g.azc[j] : g.azf[j];
+    return metric2(g, 2, lx, ly, i, j);
+}
 
 struct StressDev {
     int kind, ue_kind, ve_kind, pad;

@@ -19,15 +19,10 @@
 namespace csi {
 namespace strict {
 
-// ---- metrics (Oceananigans.Operators) -------------------------------------
-__device__ __forceinline__ double dxm(const GridDev& g, int ly, int j) {
-    if (g.metric_kind == 0) return g.dx;
-    return ly == LOC_C ? g.dxc[j] : g.dxf[j];
-}
-__device__ __forceinline__ double azm(const GridDev& g, int ly, int j) {
-    if (g.metric_kind == 0) return g.dx * g.dy;
-    return ly == LOC_C ? g.azc[j] : g.azf[j];
-}
+// metrics: dxm / dym / azm(g, lx, ly, i, j) in csi_dev.h, called with the location and indices the reference's
+// operators use (same calls as oracle/csi_oracle.c)
+#define F_ LOC_F
+#define C_ LOC_C
 
 // Julia's max(a, b) for floats: NaN if either is NaN (fmax would drop the NaN)
 __device__ __forceinline__ double jmax(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? b : a); }
@@ -39,23 +34,23 @@ __device__ __forceinline__ double ice_mass(const EvpDev& P, int i, int j) {   //
 // ---- strain rates, evp:360-375 ----------------------------------------------------------------
 __device__ __forceinline__ double eps_D(const EvpDev& P, int i, int j) {
     const GridDev& g = P.g;
-    double a = g.dy * P.u(i + 1, j) - g.dy * P.u(i, j);
-    double b = dxm(g, LOC_F, j + 1) * P.v(i, j + 1) - dxm(g, LOC_F, j) * P.v(i, j);
-    return (a + b) / azm(g, LOC_C, j);
+    double a = dym(g, F_, C_, i + 1, j) * P.u(i + 1, j) - dym(g, F_, C_, i, j) * P.u(i, j);
+    double b = dxm(g, C_, F_, i, j + 1) * P.v(i, j + 1) - dxm(g, C_, F_, i, j) * P.v(i, j);
+    return (a + b) / azm(g, C_, C_, i, j);
 }
 __device__ __forceinline__ double eps_T(const EvpDev& P, int i, int j) {
     const GridDev& g = P.g;
-    double dycc = g.dy, dxcc = dxm(g, LOC_C, j);
-    double a = P.u(i + 1, j) / g.dy - P.u(i, j) / g.dy;
-    double b = P.v(i, j + 1) / dxm(g, LOC_F, j + 1) - P.v(i, j) / dxm(g, LOC_F, j);
-    return ((dycc * dycc) * a - (dxcc * dxcc) * b) / azm(g, LOC_C, j);
+    double dycc = dym(g, C_, C_, i, j), dxcc = dxm(g, C_, C_, i, j);
+    double a = P.u(i + 1, j) / dym(g, F_, C_, i + 1, j) - P.u(i, j) / dym(g, F_, C_, i, j);
+    double b = P.v(i, j + 1) / dxm(g, C_, F_, i, j + 1) - P.v(i, j) / dxm(g, C_, F_, i, j);
+    return ((dycc * dycc) * a - (dxcc * dxcc) * b) / azm(g, C_, C_, i, j);
 }
 __device__ __forceinline__ double eps_S(const EvpDev& P, int i, int j) {
     const GridDev& g = P.g;
-    double dxff = dxm(g, LOC_F, j), dyff = g.dy;
-    double a = P.u(i, j) / dxm(g, LOC_C, j) - P.u(i, j - 1) / dxm(g, LOC_C, j - 1);
-    double b = P.v(i, j) / g.dy - P.v(i - 1, j) / g.dy;
-    return ((dxff * dxff) * a + (dyff * dyff) * b) / azm(g, LOC_F, j);
+    double dxff = dxm(g, F_, F_, i, j), dyff = dym(g, F_, F_, i, j);
+    double a = P.u(i, j) / dxm(g, F_, C_, i, j) - P.u(i, j - 1) / dxm(g, F_, C_, i, j - 1);
+    double b = P.v(i, j) / dym(g, C_, F_, i, j) - P.v(i - 1, j) / dym(g, C_, F_, i - 1, j);
+    return ((dxff * dxff) * a + (dyff * dyff) * b) / azm(g, F_, F_, i, j);
 }
 __device__ __forceinline__ double e_xx(const EvpDev& P, int i, int j) { return (eps_D(P, i, j) + eps_T(P, i, j)) / 2; }
 __device__ __forceinline__ double e_yy(const EvpDev& P, int i, int j) { return (eps_D(P, i, j) - eps_T(P, i, j)) / 2; }
@@ -128,10 +123,10 @@ __global__ void k_stress(EvpDev P, Range r) {
     double s12n = 2 * etaf * e12;
     double mc = ice_mass(P, i, j);
     double mf = AVG4_FF(ice_mass, P, i, j);
-    double g2c = zc * ca * dt / mc / azm(g, LOC_C, j);
+    double g2c = zc * ca * dt / mc / azm(g, C_, C_, i, j);
     g2c = isnan(g2c) ? ap * ap : g2c;
     double gc = clampd(sqrt(g2c), am, ap);
-    double g2f = zf * ca * dt / mf / azm(g, LOC_F, j);
+    double g2f = zf * ca * dt / mf / azm(g, F_, F_, i, j);
     g2f = isnan(g2f) ? ap * ap : g2f;
     double gf = clampd(sqrt(g2f), am, ap);
     double s11s = (s11n - P.s11(i, j)) / gc;
@@ -152,23 +147,23 @@ __device__ __forceinline__ double sigT(const EvpDev& P, int i, int j) { return s
 
 __device__ __forceinline__ double div_sigma_1(const EvpDev& P, int i, int j) {   // :39-44
     const GridDev& g = P.g;
-    double dyfc = g.dy;
+    double dyfc = dym(g, F_, C_, i, j);
     double d = dyfc * (sigD(P, i, j) - sigD(P, i - 1, j)) / 2;
-    double dyc = g.dy, dycm = g.dy;
+    double dyc = dym(g, C_, C_, i, j), dycm = dym(g, C_, C_, i - 1, j);
     double T = ((dyc * dyc) * sigT(P, i, j) - (dycm * dycm) * sigT(P, i - 1, j)) / dyfc / 2;
-    double dxfn = dxm(g, LOC_F, j + 1), dxf = dxm(g, LOC_F, j);
-    double S = ((dxfn * dxfn) * sig12(P, i, j + 1) - (dxf * dxf) * sig12(P, i, j)) / dxm(g, LOC_C, j);
-    return (d + T + S) / azm(g, LOC_C, j);
+    double dxfn = dxm(g, F_, F_, i, j + 1), dxf = dxm(g, F_, F_, i, j);
+    double S = ((dxfn * dxfn) * sig12(P, i, j + 1) - (dxf * dxf) * sig12(P, i, j)) / dxm(g, F_, C_, i, j);
+    return (d + T + S) / azm(g, F_, C_, i, j);
 }
 __device__ __forceinline__ double div_sigma_2(const EvpDev& P, int i, int j) {   // :46-51
     const GridDev& g = P.g;
-    double dxcf = dxm(g, LOC_F, j);
+    double dxcf = dxm(g, C_, F_, i, j);
     double d = dxcf * (sigD(P, i, j) - sigD(P, i, j - 1)) / 2;
-    double dxc = dxm(g, LOC_C, j), dxcm = dxm(g, LOC_C, j - 1);
+    double dxc = dxm(g, C_, C_, i, j), dxcm = dxm(g, C_, C_, i, j - 1);
     double T = -((dxc * dxc) * sigT(P, i, j) - (dxcm * dxcm) * sigT(P, i, j - 1)) / dxcf / 2;
-    double dyfn = g.dy, dyf = g.dy;
-    double S = ((dyfn * dyfn) * sig12(P, i + 1, j) - (dyf * dyf) * sig12(P, i, j)) / g.dy;
-    return (d + T + S) / azm(g, LOC_F, j);
+    double dyfn = dym(g, F_, F_, i + 1, j), dyf = dym(g, F_, F_, i, j);
+    double S = ((dyfn * dyfn) * sig12(P, i + 1, j) - (dyf * dyf) * sig12(P, i, j)) / dym(g, C_, F_, i, j);
+    return (d + T + S) / azm(g, C_, F_, i, j);
 }
 
 // ---- external stresses, sea_ice_external_stress.jl:8-27,176-202 ------------------------------

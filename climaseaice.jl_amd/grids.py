@@ -171,6 +171,73 @@ class LatitudeLongitudeGrid(_Grid2D):
         return dict(kind="per_j", dy=self.dy, dxc=self.dxc, dxf=self.dxf, azc=self.azc, azf=self.azf)
 
 
+# order of the twelve 2-D metric arrays of an orthogonal curvilinear grid (include/csi.h, CSI_METRIC_FULL)
+METRIC_NAMES = [w + l for w in ("dx", "dy", "az") for l in ("cc", "fc", "cf", "ff")]
+
+
+class OrthogonalCurvilinearGrid(_Grid2D):
+    """A grid given by its twelve 2-D metric arrays (dx, dy, Az at (c,c), (f,c), (c,f), (f,f)), the form an
+    OrthogonalSphericalShellGrid hands to the operators.  Arrays have (Ny + 2Hy + 1, Nx + 2Hx + 1) entries, element
+    (i, j) at [j + Hy - 1, i + Hx - 1]; halo entries of a Periodic direction must repeat the interior.
+
+    `from_grid(g)` spreads the metrics of a RectilinearGrid / LatitudeLongitudeGrid over 2-D arrays (same numbers, so
+    the same results bit for bit in STRICT mode); `distort` perturbs them smoothly for tests of the general operators."""
+
+    metric_kind = "full"
+
+    def __init__(self, size, metrics, topology=(Periodic, Periodic), halo=(4, 4), nodes=None):
+        self.Nx, self.Ny = int(size[0]), int(size[1])
+        self.Hx, self.Hy = int(halo[0]), int(halo[1])
+        self.topology = _topo2(topology)
+        shape = (self.Ny + 2 * self.Hy + 1, self.Nx + 2 * self.Hx + 1)
+        self._m = {}
+        for name in METRIC_NAMES:
+            a = np.ascontiguousarray(metrics[name], dtype=np.float64)
+            if a.shape != shape:
+                raise ValueError(f"metric {name}: shape {a.shape}, expected {shape}")
+            self._m[name] = a
+        self._nodes = nodes          # optional (xnodes(LX), ynodes(LY)) callables of the grid it was built from
+
+    @classmethod
+    def from_grid(cls, g, distort=0.0, seed=0):
+        n, ni = g.Ny + 2 * g.Hy + 1, g.Nx + 2 * g.Hx + 1
+        m = g.metrics()
+        ones = np.ones((n, ni))
+        if m["kind"] == "uniform":
+            row = {k: np.full(n, m["dx"]) for k in ("dxc", "dxf")}
+            row.update(azc=np.full(n, m["dx"] * m["dy"]), azf=np.full(n, m["dx"] * m["dy"]))
+            dy = m["dy"]
+        else:
+            row, dy = m, m["dy"]
+        out = {}
+        for l in ("cc", "fc", "cf", "ff"):
+            fy = l[1] == "f"
+            out["dx" + l] = (row["dxf"] if fy else row["dxc"])[:, None] * ones
+            out["az" + l] = (row["azf"] if fy else row["azc"])[:, None] * ones
+            out["dy" + l] = dy * ones
+        if distort:
+            # smooth, location-dependent stretching (periodic in both directions so that Periodic halos stay images)
+            ii = (np.arange(ni) - (g.Hx - 1))[None, :] / g.Nx
+            jj = (np.arange(n) - (g.Hy - 1))[:, None] / g.Ny
+            rng = np.random.default_rng(seed)
+            for k, name in enumerate(METRIC_NAMES):
+                ph = rng.random(2) * 2 * np.pi
+                out[name] = out[name] * (1.0 + distort * np.sin(2 * np.pi * ii + ph[0]) * np.cos(2 * np.pi * jj + ph[1]))
+        return cls((g.Nx, g.Ny), out, topology=g.topology, halo=(g.Hx, g.Hy), nodes=(g.xnodes, g.ynodes, g._ynode))
+
+    def xnodes(self, LX):
+        return self._nodes[0](LX)
+
+    def ynodes(self, LY):
+        return self._nodes[1](LY)
+
+    def _ynode(self, j, LY):
+        return self._nodes[2](j, LY)
+
+    def metrics(self):
+        return dict(kind="full", **self._m)
+
+
 class TileGrid(_Grid2D):
     """One tile of an Rx x Ry decomposition of a global grid (the analogue of an Oceananigans grid built on
     Distributed(arch; partition = Partition(Rx, Ry)), test/distributed_tests_utils.jl:60-62).
@@ -220,6 +287,10 @@ class TileGrid(_Grid2D):
             n = self.Ny + 2 * self.Hy + 1
             for k in ("dxc", "dxf", "azc", "azf"):
                 m[k] = np.ascontiguousarray(m[k][self.j_off:self.j_off + n])
+        elif m["kind"] == "full":
+            n, ni = self.Ny + 2 * self.Hy + 1, self.Nx + 2 * self.Hx + 1
+            for k in METRIC_NAMES:
+                m[k] = np.ascontiguousarray(m[k][self.j_off:self.j_off + n, self.i_off:self.i_off + ni])
         return m
 
     def local_interior(self, global_interior, LX, LY):

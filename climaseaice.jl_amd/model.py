@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .dynamics import (ElastoViscoPlasticRheology, FPlane, IceStrength, SeaIceMomentumEquation, SemiImplicitStress)
 from .fields import CenterField, Field, XFaceField, YFaceField
-from .grids import Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
+from .grids import METRIC_NAMES, Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
 
 
 class PrescribedTemperature:
@@ -169,6 +169,14 @@ class SeaIceModel:
         if m["kind"] == "uniform":
             kind = _lib.METRIC_UNIFORM
             met.dx, met.dy = m["dx"], m["dy"]
+        elif m["kind"] == "full":
+            kind = _lib.METRIC_FULL
+            met.full_ld = g.Nx + 2 * g.Hx + 1
+            for k, name in enumerate(METRIC_NAMES):
+                a = np.ascontiguousarray(m[name], dtype=np.float64)
+                assert a.shape == (g.Ny + 2 * g.Hy + 1, g.Nx + 2 * g.Hx + 1), (name, a.shape)
+                self._keep.append(a)
+                met.full[k] = _dptr(a)
         else:
             kind = _lib.METRIC_PER_J
             met.dy = m["dy"]

@@ -56,17 +56,26 @@ typedef enum {
 
 typedef enum {
     CSI_METRIC_UNIFORM = 0,   /* RectilinearGrid, regular spacing */
-    CSI_METRIC_PER_J = 1      /* LatitudeLongitudeGrid, regular: metrics vary with j only */
+    CSI_METRIC_PER_J = 1,     /* LatitudeLongitudeGrid, regular: metrics vary with j only */
+    CSI_METRIC_FULL = 2       /* orthogonal curvilinear grid (OrthogonalSphericalShellGrid and the like): 2-D metric arrays.
+                               * Every operator takes them (same calls as the reference's Oceananigans.Operators); the
+                               * kernels are the reference-order (STRICT) ones in both modes: the FAST kernels fold the
+                               * metrics into per-row coefficients, which a general grid does not have. */
 } csi_metric_kind;
 
 /* Host-side description of the grid metrics (copied by csi_grid_set).  PER_J vectors have
  * length Ny + 2Hy + 1; the entry for row j (1-based) sits at [j + Hy - 1]:
  *   dxc = dx at Center rows (dx^cc = dx^fc)   dxf = dx at Face rows (dx^cf = dx^ff)
  *   azc = Az at Center rows (Az^cc = Az^fc)   azf = Az at Face rows (Az^cf = Az^ff)
- * dy is constant for both kinds. */
+ * dy is constant for these two kinds. */
 typedef struct {
     double dx, dy;
     const double *dxc, *dxf, *azc, *azf;
+    /* CSI_METRIC_FULL: the twelve HOST arrays dx, dy, Az at (c,c), (f,c), (c,f), (f,f) -- index 4 * {dx 0, dy 1, Az 2}
+     * + (x at Face) + 2 * (y at Face), i.e. dx^ccc, dx^fcc, dx^cfc, dx^ffc, dy^ccc, ... -- each with Ny + 2Hy + 1 rows
+     * of leading dimension full_ld >= Nx + 2Hx + 1; element (i, j) at [(i + Hx - 1) + (j + Hy - 1) * full_ld]. */
+    const double* full[12];
+    int64_t full_ld;
 } csi_metrics;
 
 /* Field slots (csi_field_bind).  Locations: (x, y) with c = Center, f = Face. */

@@ -21,7 +21,9 @@ const libcsi = get(ENV, "LIBCSI_HIP", "libcsi_hip.so")
 struct CsiMetrics
     dx::Cdouble; dy::Cdouble
     dxc::Ptr{Cdouble}; dxf::Ptr{Cdouble}; azc::Ptr{Cdouble}; azf::Ptr{Cdouble}
+    full::NTuple{12, Ptr{Cdouble}}; full_ld::Int64          # CSI_METRIC_FULL: twelve host arrays (include/csi.h)
 end
+CsiMetrics(dx, dy, dxc, dxf, azc, azf) = CsiMetrics(dx, dy, dxc, dxf, azc, azf, ntuple(_ -> Ptr{Cdouble}(C_NULL), 12), 0)
 struct CsiEvpParams
     ice_compressive_strength::Cdouble; ice_compaction_hardening::Cdouble; yield_curve_eccentricity::Cdouble
     minimum_plastic_stress::Cdouble; min_relaxation_parameter::Cdouble; max_relaxation_parameter::Cdouble
@@ -87,6 +89,24 @@ function set_grid!(ctx, grid::LatitudeLongitudeGrid)
         m = Ref(CsiMetrics(0.0, grid.Δyᶜᶠᵃ, pointer(dxc), pointer(dxf), pointer(azc), pointer(azf)))
         check(ctx, ccall((:csi_grid_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Ref{CsiMetrics}),
                          ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), topo_code(TY), 1, m))
+    end
+end
+
+# Orthogonal curvilinear grids (OrthogonalSphericalShellGrid: 2-D metric arrays): the twelve metrics at the four
+# horizontal locations, evaluated with the public operators over the halo-extended index range and copied to the host once.
+function set_grid!(ctx, grid::Oceananigans.Grids.OrthogonalSphericalShellGrid)
+    Nx, Ny, _ = size(grid); Hx, Hy, _ = halo_size(grid); TX, TY, _ = topology(grid)
+    is, js = (1 - Hx):(Nx + Hx + 1), (1 - Hy):(Ny + Hy + 1)
+    ops = (Oceananigans.Operators.Δxᶜᶜᶜ, Oceananigans.Operators.Δxᶠᶜᶜ, Oceananigans.Operators.Δxᶜᶠᶜ, Oceananigans.Operators.Δxᶠᶠᶜ,
+           Oceananigans.Operators.Δyᶜᶜᶜ, Oceananigans.Operators.Δyᶠᶜᶜ, Oceananigans.Operators.Δyᶜᶠᶜ, Oceananigans.Operators.Δyᶠᶠᶜ,
+           Oceananigans.Operators.Azᶜᶜᶜ, Oceananigans.Operators.Azᶠᶜᶜ, Oceananigans.Operators.Azᶜᶠᶜ, Oceananigans.Operators.Azᶠᶠᶜ)
+    cpu_grid = Oceananigans.on_architecture(CPU(), grid)
+    inside(i, j) = i <= Nx + Hx && j <= Ny + Hy                       # the +1 column / row exists for Face points on a wall only
+    arrays = [Float64[inside(i, j) ? op(i, j, 1, cpu_grid) : 1.0 for i in is, j in js] for op in ops]
+    GC.@preserve arrays begin
+        m = Ref(CsiMetrics(0.0, 0.0, C_NULL, C_NULL, C_NULL, C_NULL, ntuple(k -> pointer(arrays[k]), 12), length(is)))
+        check(ctx, ccall((:csi_grid_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Ref{CsiMetrics}),
+                         ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), topo_code(TY), 2, m))
     end
 end
 

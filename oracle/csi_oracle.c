@@ -33,17 +33,20 @@ static inline double jmax(double a, double b);
 /* Grid metrics (Oceananigans.Operators)                  */
 /* Rectilinear regular: constants, Az = dx*dy.  Lat-lon regular: per-j rows */
 /* ------------------------------------------------------------------------ */
+static inline double metric2d(const ora_problem* g, int which, int lx, int ly, int i, int j) {
+    return g->m2d[4 * which + (lx == F_ ? 1 : 0) + (ly == F_ ? 2 : 0)][((int64_t)i + g->Hx - 1) + ((int64_t)j + g->Hy - 1) * g->m2d_ld];
+}
 double ora_dx(const ora_problem* g, int lx, int ly, int i, int j) {
-    (void)lx; (void)i;
+    if (g->metric_kind == ORA_METRIC_FULL) return metric2d(g, 0, lx, ly, i, j);
     if (g->metric_kind == ORA_METRIC_UNIFORM) return g->dx;
     return (ly == C_) ? g->dxc[j + g->Hy - 1] : g->dxf[j + g->Hy - 1];
 }
 double ora_dy(const ora_problem* g, int lx, int ly, int i, int j) {
-    (void)lx; (void)ly; (void)i; (void)j;
+    if (g->metric_kind == ORA_METRIC_FULL) return metric2d(g, 1, lx, ly, i, j);
     return g->dy;
 }
 double ora_az(const ora_problem* g, int lx, int ly, int i, int j) {
-    (void)lx; (void)i;
+    if (g->metric_kind == ORA_METRIC_FULL) return metric2d(g, 2, lx, ly, i, j);
     if (g->metric_kind == ORA_METRIC_UNIFORM) return g->dx * g->dy;
     return (ly == C_) ? g->azc[j + g->Hy - 1] : g->azf[j + g->Hy - 1];
 }

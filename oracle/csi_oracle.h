@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 enum { ORA_PERIODIC = 0, ORA_BOUNDED = 1, ORA_FULLY_CONNECTED = 2, ORA_LEFT_CONNECTED = 3, ORA_RIGHT_CONNECTED = 4 };
-enum { ORA_METRIC_UNIFORM = 0, ORA_METRIC_PER_J = 1 };
+enum { ORA_METRIC_UNIFORM = 0, ORA_METRIC_PER_J = 1, ORA_METRIC_FULL = 2 };
 enum { ORA_STRESS_NONE = 0, ORA_STRESS_CONST = 1, ORA_STRESS_FIELD = 2, ORA_STRESS_SEMI_IMPLICIT = 3 };
 enum { ORA_VEL_ZERO = 0, ORA_VEL_CONST = 1, ORA_VEL_FIELD = 2 };
 enum { ORA_PRESSURE_REPLACEMENT = 0, ORA_PRESSURE_ICE_STRENGTH = 1 };
@@ -88,6 +88,11 @@ typedef struct {
      * for y_f_cross_U.  The caller evaluates it per row: fu_rows / fv_rows, element for row j at [j + Hy - 1],
      * length Ny + 2Hy + 1; NULL = FPlane (f_coriolis). */
     const double *fu_rows, *fv_rows;
+    /* ORA_METRIC_FULL (orthogonal curvilinear grids: OrthogonalSphericalShellGrid and the like): the twelve metric
+     * arrays dx, dy, Az at (c,c), (f,c), (c,f), (f,f) -- index = 4 * {dx: 0, dy: 1, Az: 2} + (x at Face) + 2 * (y at
+     * Face) -- each laid out like a parent array with leading dimension m2d_ld >= Nx + 2Hx + 1 and Ny + 2Hy + 1 rows. */
+    const double* m2d[12];
+    int64_t m2d_ld;
     ora_stress top, bottom;
 
     /* ---- fields ---- */

@@ -21,7 +21,8 @@ PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3
 
 def hi_wall(t):
     return t in (BOUNDED, LEFT_CONNECTED)
-METRIC_UNIFORM, METRIC_PER_J = 0, 1
+METRIC_UNIFORM, METRIC_PER_J, METRIC_FULL = 0, 1, 2
+METRIC_NAMES = [w + l for w in ("dx", "dy", "az") for l in ("cc", "fc", "cf", "ff")]   # order of the twelve 2-D arrays
 STRESS_NONE, STRESS_CONST, STRESS_FIELD, STRESS_SEMI_IMPLICIT = 0, 1, 2, 3
 VEL_ZERO, VEL_CONST, VEL_FIELD = 0, 1, 2
 PRESSURE_REPLACEMENT, PRESSURE_ICE_STRENGTH = 0, 1
@@ -66,6 +67,7 @@ class ProblemStruct(C.Structure):
                  ("min_mass", C.c_double), ("min_conc", C.c_double), ("rho_ice", C.c_double),
                  ("f_coriolis", C.c_double), ("has_coriolis", C.c_int32), ("free_drift_kind", C.c_int32),
                  ("fu_rows", C.POINTER(C.c_double)), ("fv_rows", C.POINTER(C.c_double)),
+                 ("m2d", C.POINTER(C.c_double) * 12), ("m2d_ld", C.c_int64),
                  ("top", Stress), ("bottom", Stress)] +
                 [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("pad_snow", C.c_int32)])
 
@@ -165,7 +167,8 @@ class Problem:
     """
 
     def __init__(self, Nx, Ny, Hx=4, Hy=4, topo=(PERIODIC, PERIODIC), dx=1.0, dy=1.0,
-                 per_j=None, substeps=120, omp=False):
+                 per_j=None, substeps=120, omp=False, full=None):
+        """full: dict of the twelve (Ny + 2Hy + 1, Nx + 2Hx + 1) metric arrays named METRIC_NAMES (ORA_METRIC_FULL)."""
         self.L = lib(omp)
         self.s = ProblemStruct()
         s = self.s
@@ -181,6 +184,14 @@ class Problem:
                 self._keep.append(a)
                 setattr(s, k, _dptr(a))
             s.dy = per_j["dy"]
+        elif full is not None:
+            s.metric_kind = METRIC_FULL
+            s.m2d_ld = Nx + 2 * Hx + 1
+            for k, name in enumerate(METRIC_NAMES):
+                a = np.ascontiguousarray(full[name], dtype=np.float64)
+                assert a.shape == (Ny + 2 * Hy + 1, Nx + 2 * Hx + 1), (name, a.shape)
+                self._keep.append(a)
+                s.m2d[k] = _dptr(a)
         else:
             s.metric_kind = METRIC_UNIFORM
         # EVP defaults: elasto_visco_plastic_rheology.jl:119-127

@@ -14,7 +14,7 @@ import climaseaice_jl_amd as csi
 def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
-              field_forcing=False, land=0.0, free_drift=False, beta=None):
+              field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
@@ -25,6 +25,9 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
         g = csi.RectilinearGrid((Nx, Ny), x=(0.0, Nx * spacing), y=(0.0, Ny * spacing), topology=tt, halo=(H, H))
     else:
         g = csi.LatitudeLongitudeGrid((Nx, Ny), longitude=(0, 60), latitude=(20, 70), topology=tt, halo=(H, H))
+    if curvilinear is not None:
+        # the same grid described by twelve 2-D metric arrays (CSI_METRIC_FULL), optionally distorted by `curvilinear`
+        g = csi.OrthogonalCurvilinearGrid.from_grid(g, distort=curvilinear, seed=seed)
     c["g"] = g
     xc = (np.arange(Nx) + 0.5) / Nx
     yc = (np.arange(Ny) + 0.5) / Ny
@@ -106,6 +109,8 @@ def oracle_problem(case, omp=False):
     m = g.metrics()
     if m["kind"] == "uniform":
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"], omp=omp)
+    elif m["kind"] == "full":
+        p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, full=m, substeps=case["substeps"], omp=omp)
     else:
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, per_j=m, substeps=case["substeps"], omp=omp)
     p.set_coriolis(case["coriolis"], rows=coriolis_rows(case, g))

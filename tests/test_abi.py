@@ -48,6 +48,6 @@ def test_struct_sizes_match_header_layout():
     import ctypes as C
     assert C.sizeof(csi._lib.EvpParams) == 7 * 8 + 2 * 4 + 4 * 8
     assert C.sizeof(csi._lib.Stress) == 4 * 4 + 6 * 8
-    assert C.sizeof(csi._lib.Metrics) == 2 * 8 + 4 * 8
+    assert C.sizeof(csi._lib.Metrics) == 2 * 8 + 4 * 8 + 12 * 8 + 8
     assert C.sizeof(csi._lib.SlabParams) == 13 * 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8
     assert C.sizeof(csi._lib.SnowParams) == 4 * 8 + 2 * 4

@@ -69,6 +69,10 @@ CASES = {
     "beta_channel": dict(Nx=130, Ny=64, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=-1.5e-10),
     "beta_latlon": dict(Nx=48, Ny=56, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, beta=1e-6),
     "beta_periodic": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05, beta=2e-10),
+    # orthogonal curvilinear grids (twelve 2-D metric arrays, CSI_METRIC_FULL): reference-order kernels in both modes
+    "curvilinear_periodic": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05, curvilinear=0.05),
+    "curvilinear_bounded": dict(Nx=40, Ny=56, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.05, curvilinear=0.04),
+    "curvilinear_masked": dict(Nx=72, Ny=60, topo=("periodic", "bounded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.25),
     "beta_masked": dict(Nx=96, Ny=80, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=2e-10, land=0.25),
 }
 MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",

@@ -389,3 +389,24 @@ def test_snow_layer_mass_fluxes_close_and_bare_limit(bc, oracle_lib):
     O.lib().ora_slab_thermo_step(C.byref(slab), n, O._dptr(hb), O._dptr(ab), O._dptr(mf), dt)
     assert np.all(r["hs"] == 0)
     assert np.abs(r["h"] - hb).max() <= 1e-13 and np.abs(r["aice"] - ab).max() <= 1e-13
+
+
+# ---- orthogonal curvilinear grids: twelve 2-D metric arrays (CSI_METRIC_FULL) ---------------------------------------------
+@pytest.mark.parametrize("grid,topo", [("rectilinear", ("periodic", "periodic")), ("latlon", ("bounded", "bounded")),
+                                       ("latlon", ("periodic", "bounded"))])
+def test_full_2d_metrics_reduce_to_the_regular_grids(grid, topo, oracle_lib):
+    """The operators read dx, dy, Az at the location and indices the reference's Oceananigans.Operators calls name
+    (oracle: ora_dx / ora_dy / ora_az(g, lx, ly, i, j)).  Fed with the regular grid's own numbers spread over 2-D
+    arrays, a whole RK3 step (WENO7 + EVP sub-cycle) is bit-identical to the regular-grid path; a smooth distortion of
+    the arrays changes the answer (every array is actually read)."""
+    out = {}
+    for curv in (None, 0.0, 0.05):
+        c = cases.make_case(Nx=28, Ny=24, substeps=8, topo=topo, grid=grid, random_uv=0.03, curvilinear=curv)
+        p = cases.oracle_problem(c)
+        p.time_step_rk3(c["dt"], 7)
+        out[curv] = {k: p.f[k].copy() for k in ("u", "v", "h", "aice", "s11", "s12")}
+    for k in out[None]:
+        assert np.array_equal(out[None][k], out[0.0][k]), k
+        assert np.all(np.isfinite(out[0.05][k]))
+    assert np.abs(out[0.05]["u"] - out[None]["u"]).max() > 1e-6 * np.abs(out[None]["u"]).max()
+    assert np.abs(out[0.05]["h"] - out[None]["h"]).max() > 1e-9

@@ -23,6 +23,8 @@ def tile_problem(case, Rx, Ry, rank, force_connected=False):
     m = tg.metrics()
     if m["kind"] == "uniform":
         p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"])
+    elif m["kind"] == "full":
+        p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, full=m, substeps=case["substeps"])
     else:
         p = O.Problem(tg.Nx, tg.Ny, tg.Hx, tg.Hy, topo, per_j=m, substeps=case["substeps"])
     from cases import coriolis_rows
