@@ -7,8 +7,8 @@ inputs resident in HBM.  value = cell-updates/s = owned cells * substeps * steps
 
 N = 1: the 2048 x 2048 periodic f-plane grid the metric is quoted on.
 N > 1 (torch.distributed.run, one rank per GPU): the grid is an Rx x Ry arrangement of 2048 x 2048 tiles
-(weak scaling: per-GPU work fixed) advanced by the SAME kernels with the RCCL halo exchange of u, v
-(width 2) once per sub-step; `--scaling strong` instead splits ONE 2048 x 2048 grid over the ranks.
+(weak scaling: per-GPU work fixed) advanced by the SAME kernels with the RCCL halo exchange of u, v, sigma
+(width 2k every k sub-steps; halo 16 -> k = 8); `--scaling strong` instead splits ONE 2048 x 2048 grid over the ranks.
 Prints ONE JSON line on rank 0.
 """
 import argparse
