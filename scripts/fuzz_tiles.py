@@ -12,7 +12,11 @@ for seed in range(80):
     topo = ("periodic" if fc[0] or rng.integers(2) else "bounded", "periodic" if fc[1] or rng.integers(2) else "bounded")
     Nx = int(rng.integers(2 * H + 2, 160)); Ny = int(rng.integers(2 * H + 2, 80))
     kw = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, patches=bool(rng.integers(2)), random_uv=0.04,
-              field_forcing=bool(rng.integers(2)), land=(0.0, 0.25)[rng.integers(2)])
+              field_forcing=bool(rng.integers(2)), land=(0.0, 0.25)[rng.integers(2)], free_drift=bool(rng.integers(4) == 0))
+    if kw["free_drift"] and not kw["field_forcing"]:
+        kw.update(ue=0.05, ve=-0.02, top=(0.03, -0.02))
+    if topo[1] == "bounded" and rng.integers(3) == 0:
+        kw["beta"] = 2e-10
     nsub = int(rng.integers(2, 14))
     try:
         c = cases.make_case(substeps=nsub, **kw)

@@ -153,7 +153,7 @@ def oracle_problem(case, omp=False):
     return p
 
 
-def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0", tile=None):
+def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0", tile=None, **model_kw):
     """tile = (Rx, Ry, rank[, force_connected]): build the model of one tile of the global case."""
     g = case["g"]
     if tile is not None:
@@ -181,7 +181,7 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
                                      rheology=rheo, top_momentum_stress=top, bottom_momentum_stress=bottom,
                                      free_drift=csi.StressBalanceFreeDrift() if case.get("free_drift") else None,
                                      solver=csi.SplitExplicitSolver(substeps=case["substeps"]), device=device)
-    model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode)
+    model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode, **model_kw)
     if case.get("field_forcing"):
         for slot in ("TOP", "BOT"):
             for comp in ("U", "V"):
