@@ -785,21 +785,21 @@ AdvDev adv_dev(const csi_context* c, int scheme, double dt, int from_cache) {
 int32_t do_update_state(csi_context* c) {
     int32_t rc;
     if ((rc = need(c, {CSI_F_H, CSI_F_A}))) return rc;
+    // mask_immersed_field_xy! of every prognostic field, then their local halo fills in one batch (two launches)
+    const bool snow = c->f[CSI_F_HS].p != nullptr, vel = c->f[CSI_F_U].p && c->f[CSI_F_V].p;
     launch_mask_center(ref_of(c, CSI_F_H), c->g, c->stream);
     launch_mask_center(ref_of(c, CSI_F_A), c->g, c->stream);
-    if ((rc = fill_halo(c, CSI_F_H))) return rc;
-    if ((rc = fill_halo(c, CSI_F_A))) return rc;
-    const bool snow = c->f[CSI_F_HS].p != nullptr;
-    if (snow) {
-        launch_mask_center(ref_of(c, CSI_F_HS), c->g, c->stream);
-        if ((rc = fill_halo(c, CSI_F_HS))) return rc;
-    }
-    if (c->f[CSI_F_U].p && c->f[CSI_F_V].p) {
+    if (snow) launch_mask_center(ref_of(c, CSI_F_HS), c->g, c->stream);
+    if (vel) {
         launch_mask_u(ref_of(c, CSI_F_U), c->g, c->stream);
         launch_mask_v(ref_of(c, CSI_F_V), c->g, c->stream);
-        if ((rc = fill_halo(c, CSI_F_U))) return rc;
-        if ((rc = fill_halo(c, CSI_F_V))) return rc;
     }
+    HaloBatch B{};
+    auto add = [&](int fid) { B.f[B.n] = ref_of(c, fid); B.im[B.n] = image_spec(c, fid); ++B.n; };
+    add(CSI_F_H); add(CSI_F_A);
+    if (snow) add(CSI_F_HS);
+    if (vel) { add(CSI_F_U); add(CSI_F_V); }
+    launch_fill_halo_batch(B, c->g, c->stream);
     HIP_TRY(c, hipGetLastError());
     if (is_tiled(c)) {                                      // the MPI part of fill_halo_regions!, sea_ice_model.jl:383
         int ff[5] = {CSI_F_H, CSI_F_A, CSI_F_U, CSI_F_V, CSI_F_HS};
@@ -1147,11 +1147,14 @@ int32_t csi_fill_halo_local(csi_context* c, int32_t fid) {
 
 int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t scheme, int32_t first_iteration) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
-    int32_t rc = need_evp(c);
+    // dynamics = nothing (csi_evp_params_set never called): prescribed velocities, time_step_momentum! is a no-op
+    // (SeaIceDynamics.jl:40) -- the advection-only models of examples/ice_advected_by_anticyclone.jl's family
+    const bool dynamics = c->evp_set;
+    int32_t rc = dynamics ? need_evp(c) : need(c, {CSI_F_H, CSI_F_A});
     if (rc) return rc;
     if (first_iteration && (rc = do_update_state(c))) return rc;          // sea_ice_fe_step.jl:16
     if (scheme && (rc = do_tendencies(c, scheme))) return rc;             // :19
-    if ((rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
+    if (dynamics && (rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
     if (scheme && (rc = do_tracer_step(c, dt, 0))) return rc;             // :25
     if ((rc = do_thermo(c, dt))) return rc;                               // :28 thermodynamic_time_step!
     return do_update_state(c);                                            // :31
@@ -1159,14 +1162,15 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
 
 int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t scheme) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
-    int32_t rc = need_evp(c);
+    const bool dynamics = c->evp_set;                                     // see csi_time_step_fe
+    int32_t rc = dynamics ? need_evp(c) : need(c, {CSI_F_H, CSI_F_A});
     if (rc) return rc;
-    if ((rc = need(c, {CSI_F_HM, CSI_F_AM, CSI_F_UM, CSI_F_VM}))) return rc;
+    if ((rc = dynamics ? need(c, {CSI_F_HM, CSI_F_AM, CSI_F_UM, CSI_F_VM}) : need(c, {CSI_F_HM, CSI_F_AM}))) return rc;
     if ((rc = csi_cache_current_fields(c))) return rc;                    // sea_ice_rk_substep.jl:29-42
     for (int beta = 3; beta >= 1; --beta) {                               // upstream stage loop
         const double dtau = dt / beta;
         if (scheme && (rc = do_tendencies(c, scheme))) return rc;         // :84
-        if ((rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
+        if (dynamics && (rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
         if (scheme && (rc = do_tracer_step(c, dtau, 1))) return rc;       // :89
         if ((rc = do_thermo(c, dtau))) return rc;                         // :91 thermodynamic_time_step!
         if ((rc = do_update_state(c))) return rc;

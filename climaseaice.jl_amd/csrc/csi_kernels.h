@@ -68,6 +68,8 @@ void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u,
 void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipStream_t s);
 void launch_mask_center(const FRef& f, const GridDev& g, hipStream_t s);
 void launch_mask_u(const FRef& f, const GridDev& g, hipStream_t s);
+struct HaloBatch { FRef f[6]; ImageSpec im[6]; int n; };
+void launch_fill_halo_batch(const HaloBatch& B, const GridDev& g, hipStream_t s);
 void launch_mask_v(const FRef& f, const GridDev& g, hipStream_t s);
 
 // advection + tracer update (advect.hip)

@@ -44,6 +44,40 @@ void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipS
     }
 }
 
+// Several fields in one pair of launches (update_state! fills h, aice, [hs,] u, v back to back: at 512^2 the eight
+// 5-us launches cost more than the advection kernel); blockIdx.z selects the field.
+__global__ void k_fill_halo_batch(HaloBatch B, GridDev g, int strip) {
+    const FRef f = B.f[blockIdx.z];
+    const ImageSpec im = B.im[blockIdx.z];
+    const int Nx = g.Nx, Ny = g.Ny, Hx = g.Hx, Hy = g.Hy;
+    int i, j;
+    if (strip == 0) {
+        i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+        int jj = blockIdx.y * blockDim.y + threadIdx.y;
+        if (i > Nx + im.ex || jj >= 2 * Hy + im.ey) return;
+        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 + jj;
+        if (j < 1 || j > Ny + im.ey || (jj >= Hy && j <= Hy)) return;
+    } else {
+        int ii = blockIdx.x * blockDim.x + threadIdx.x;
+        j = 1 + Hy + blockIdx.y * blockDim.y + threadIdx.y;
+        if (ii >= 2 * Hx || j > Ny - Hy) return;
+        i = ii < Hx ? 1 + ii : Nx - 2 * Hx + 1 + ii;
+        if (i < 1 || i > Nx || (ii >= Hx && i <= Hx)) return;
+    }
+    store_with_images(f, g, im, i, j, f(i, j));
+}
+void launch_fill_halo_batch(const HaloBatch& B, const GridDev& g, hipStream_t s) {
+    if (B.n <= 0) return;
+    dim3 b(64, 4);
+    unsigned gx0 = (unsigned)((g.Nx + 1 + 63) / 64), gy0 = (unsigned)((2 * g.Hy + 1 + 3) / 4);
+    hipLaunchKernelGGL(k_fill_halo_batch, dim3(gx0, gy0, (unsigned)B.n), b, 0, s, B, g, 0);
+    int mid = g.Ny - 2 * g.Hy;
+    if (mid > 0) {
+        unsigned gx1 = (unsigned)((2 * g.Hx + 63) / 64), gy1 = (unsigned)((mid + 3) / 4);
+        hipLaunchKernelGGL(k_fill_halo_batch, dim3(gx1, gy1, (unsigned)B.n), b, 0, s, B, g, 1);
+    }
+}
+
 // mask_immersed_field_xy!(field, k = Nz), sea_ice_model.jl:381-389: zero at peripheral nodes of an
 // immersed grid (no-op without a mask).
 __global__ void k_mask(FRef f, GridDev g, int kind) {

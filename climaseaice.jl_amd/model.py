@@ -350,7 +350,7 @@ class SeaIceModel:
     # ---- convenience ----------------------------------------------------------------------------
     @property
     def substeps(self):
-        return self.dynamics.solver.substeps
+        return 0 if self.dynamics is None else self.dynamics.solver.substeps
 
     @property
     def scheme(self):
@@ -393,11 +393,11 @@ def time_step_momentum(model, dt, rk_reset=False):
 
 def time_step(model, dt):
     """time_step!(model, dt)."""
-    if model.dynamics is None:
+    if model.dynamics is None and model.scheme in (0, None):
         # dynamics = nothing, advection = nothing: the step is the thermodynamic update alone
         # (sea_ice_fe_step.jl:13-34 with time_step_momentum!, compute_tendencies! and dynamic_time_step! no-ops)
-        if model.ice_thermodynamics is None or model.scheme not in (0, None):
-            raise NotImplementedError("without dynamics only the slab thermodynamics step is on the accelerated path")
+        if model.ice_thermodynamics is None:
+            raise NotImplementedError("a model without dynamics, advection and thermodynamics has nothing to step")
         snow = model.snow_thermodynamics
         sp = model.ice_thermodynamics.params(model.sea_ice_density, snow=snow is not None)
         if snow is None:

@@ -222,8 +222,9 @@ int32_t csi_cache_current_fields(csi_context* ctx);
 int32_t csi_update_state(csi_context* ctx);
 /* fill_halo_regions!(field; only_local_halos = true) for one bound field */
 int32_t csi_fill_halo_local(csi_context* ctx, int32_t field_id);
-/* Whole model steps without thermodynamics: FE (sea_ice_fe_step.jl:13-34) and the
- * SplitRungeKutta3 stage loop around rk_substep! (sea_ice_rk_substep.jl:81-94). */
+/* Whole model steps: FE (sea_ice_fe_step.jl:13-34) and the SplitRungeKutta3 stage loop around rk_substep!
+ * (sea_ice_rk_substep.jl:81-94).  Without csi_evp_params_set (dynamics = nothing) the velocities are prescribed and
+ * the momentum step is skipped: advection-only models.  Thermodynamics: csi_slab_params_set / csi_snow_params_set. */
 int32_t csi_time_step_fe(csi_context* ctx, double dt, int32_t substeps, int32_t scheme, int32_t first_iteration);
 int32_t csi_time_step_rk3(csi_context* ctx, double dt, int32_t substeps, int32_t scheme);
 

@@ -173,6 +173,37 @@ def test_curvilinear_grid_full_step_bitwise(stepper, name, oracle_lib):
         assert np.array_equal(out["strict"][k], out["fast"][k]), k
 
 
+@pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
+def test_advection_only_time_step_bitwise(stepper, oracle_lib):
+    """BASELINE config 2: dynamics = nothing, prescribed velocities, time_step! = tendencies + tracer update +
+    update_state! (time_step_momentum!(model, ::Nothing, dt) is a no-op, SeaIceDynamics.jl:40); FE and the RK3 stage
+    loop with the Psi^- cache.  Five steps, h and aice bit for bit."""
+    c = anticyclone_case(96)
+    p = cases.oracle_problem(c)
+    g = c["g"]
+    m = csi.SeaIceModel(g, dynamics=None, advection=csi.WENO(order=7), timestepper=stepper)
+    csi.set_(m, h=c["h"], aice=c["a"], u=c["u"], v=c["v"])
+    dt = 120.0
+    for n in range(5):
+        if stepper == "ForwardEuler":
+            if n == 0:
+                p.update_state()
+            p.compute_tracer_tendencies(7)
+            p.dynamic_step_tracers(dt, False)
+            p.update_state()
+        else:
+            p.f["hm"][...] = p.f["h"]; p.f["am"][...] = p.f["aice"]
+            for beta in (3, 2, 1):
+                p.compute_tracer_tendencies(7)
+                p.dynamic_step_tracers(dt / beta, True)
+                p.update_state()
+        csi.time_step(m, dt)
+    m.synchronize()
+    assert np.array_equal(m.ice_thickness.numpy(), p.f["h"])
+    assert np.array_equal(m.ice_concentration.numpy(), p.f["aice"])
+    assert np.abs(p.interior("h") - c["h"]).max() > 1e-4
+
+
 def test_advection_conserves_volume_at_full_size():
     """Config 2 at 512^2: flux-form divergence on a periodic grid conserves sum(h) and sum(aice) to rounding
     (a size-independent property, checked without the oracle)."""
