@@ -92,6 +92,8 @@ struct csi_context {
     size_t alt_elems[5] = {0, 0, 0, 0, 0};
     bool slab_set = false;   // thermodynamic step inside csi_time_step_fe / _rk3
     SlabDev slab{};
+    int vel_bc_on[2][2] = {{0, 0}, {0, 0}};          // csi_velocity_bc_set: [u | v][low | high] ValueBoundaryCondition
+    double vel_bc_value[2][2] = {{0, 0}, {0, 0}};
     bool snow_set = false;   // layered (snow + ice) step instead of the bare-ice one
     SnowDev snow{};
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
@@ -145,6 +147,15 @@ ImageSpec image_spec(const csi_context* c, int fid) {
     im.yhi = img_of(c->g.yhi, kLoc[fid][1]);
     im.ex = (kLoc[fid][0] == LOC_F && c->g.xhi == SIDE_WALL) ? 1 : 0;
     im.ey = (kLoc[fid][1] == LOC_F && c->g.yhi == SIDE_WALL) ? 1 : 0;
+    im.vxlo = im.vxhi = im.vylo = im.vyhi = 0.0;
+    // ValueBoundaryCondition on the tangential velocity at a wall replaces the no-flux mirror (one halo cell)
+    if (fid == CSI_F_U) {
+        if (im.ylo == IMG_MIRROR && c->vel_bc_on[0][0]) { im.ylo = IMG_VALUE; im.vylo = c->vel_bc_value[0][0]; }
+        if (im.yhi == IMG_MIRROR && c->vel_bc_on[0][1]) { im.yhi = IMG_VALUE; im.vyhi = c->vel_bc_value[0][1]; }
+    } else if (fid == CSI_F_V) {
+        if (im.xlo == IMG_MIRROR && c->vel_bc_on[1][0]) { im.xlo = IMG_VALUE; im.vxlo = c->vel_bc_value[1][0]; }
+        if (im.xhi == IMG_MIRROR && c->vel_bc_on[1][1]) { im.xhi = IMG_VALUE; im.vxhi = c->vel_bc_value[1][1]; }
+    }
     return im;
 }
 // a Face-located field has one extra point where the HIGH side of that direction is a wall
@@ -678,7 +689,8 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // three kernels inside run_fused)
     const int pfk = pair_forcing_kind(P);
     const bool pair_only = P.g.has_mask || pfk == 1;      // configurations only the two-sub-steps kernel takes
-    const bool fuse = fast && c->fusion && substeps > 0 &&
+    const bool value_bc = c->vel_bc_on[0][0] | c->vel_bc_on[0][1] | c->vel_bc_on[1][0] | c->vel_bc_on[1][1];   // three-kernel paths
+    const bool fuse = fast && c->fusion && substeps > 0 && !value_bc &&
                       (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                  : fused_supported(P));
     if (fuse) {
@@ -1070,6 +1082,17 @@ int32_t csi_coriolis_rows_set(csi_context* c, const double* f_u, const double* f
     return CSI_OK;
 }
 
+int32_t csi_velocity_bc_set(csi_context* c, int32_t field_id, int32_t side, int32_t kind, double value) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (field_id != CSI_F_U && field_id != CSI_F_V) return fail(c, CSI_ERR_INVALID_ARGUMENT, "velocity boundary conditions: CSI_F_U or CSI_F_V");
+    if (side != 0 && side != 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "side: 0 (south / west) or 1 (north / east)");
+    if (kind != 0 && kind != 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "kind: 0 (default no-flux) or 1 (ValueBoundaryCondition)");
+    const int q = field_id == CSI_F_U ? 0 : 1;
+    c->vel_bc_on[q][side] = kind;
+    c->vel_bc_value[q][side] = kind ? value : 0.0;
+    return CSI_OK;
+}
+
 int32_t csi_stress_set(csi_context* c, int32_t side, const csi_stress* s) {
     if (!c || !s) return CSI_ERR_INVALID_ARGUMENT;
     if (side != CSI_STRESS_TOP && side != CSI_STRESS_BOTTOM) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown stress side");
@@ -1338,7 +1361,7 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};
-    if (fast && c->fusion && fused_supported(P)) {
+    if (fast && c->fusion && fused_supported(P) && !(c->vel_bc_on[0][0] | c->vel_bc_on[0][1] | c->vel_bc_on[1][0] | c->vel_bc_on[1][1])) {
         // the fused path: one launch per sub-step or per pair (csi_last_launches); bracket the whole run with two events
         if (substeps & 1) ++substeps;                      // even count: the state ends in the caller's arrays
         if ((rc = run_fused(c, P, fc, substeps, 1))) return rc;

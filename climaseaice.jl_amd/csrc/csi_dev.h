@@ -9,7 +9,7 @@ namespace csi {
 
 enum : int { SIDE_PERIODIC = 0, SIDE_WALL = 1, SIDE_CONNECTED = 2 };
 enum : int { LOC_C = 0, LOC_F = 1 };
-enum : int { IMG_NONE = 0, IMG_WRAP = 1, IMG_MIRROR = 2 };
+enum : int { IMG_NONE = 0, IMG_WRAP = 1, IMG_MIRROR = 2, IMG_VALUE = 3 };
 
 struct FRef {
     double* p;   // element (0, 0) in reference indexing
@@ -119,16 +119,20 @@ struct ImageSpec {
     int xlo, xhi, ylo, yhi;   // IMG_* per side
     int ex, ey;               // 1: the field has an extra column / row of points on a high wall (Face location): the
                               // wall faces have images in the OTHER direction like any interior point
+    double vxlo, vxhi, vylo, vyhi;   // IMG_VALUE sides (ValueBoundaryCondition on a tangential velocity): the first halo
+                                     // cell holds 2 * value - c[first interior cell]; deeper halo cells are left alone
 };
 __device__ __forceinline__ int image_lo(int mode, int i, int N, int H, bool& has) {
     // halo index on the LOW side that copies from interior index i
     if (mode == IMG_WRAP) { has = (i > N - H); return i - N; }
     if (mode == IMG_MIRROR) { has = (i <= H); return 1 - i; }
+    if (mode == IMG_VALUE) { has = (i == 1); return 0; }
     has = false; return 0;
 }
 __device__ __forceinline__ int image_hi(int mode, int i, int N, int H, bool& has) {
     if (mode == IMG_WRAP) { has = (i <= H); return i + N; }
     if (mode == IMG_MIRROR) { has = (i > N - H); return 2 * N + 1 - i; }
+    if (mode == IMG_VALUE) { has = (i == N); return N + 1; }
     has = false; return 0;
 }
 __device__ __forceinline__ void store_with_images(const FRef& f, const GridDev& g, const ImageSpec& im, int i, int j, double val) {
@@ -141,22 +145,29 @@ __device__ __forceinline__ void store_with_images(const FRef& f, const GridDev& 
     const bool near_y = in_y & ((j <= g.Hy) | (j > g.Ny - g.Hy));
     if (!(near_x | near_y)) return;
     int xi[3], yj[3];
+    double cx[3], cy[3];          // image value = c - val (c = 2 * bc value on an IMG_VALUE side), or val itself (c = NaN marker unused)
+    bool fx[3], fy[3];            // the image is a ValueBoundaryCondition reflection
     int nx = 0, ny = 0;
-    xi[nx++] = i;
-    yj[ny++] = j;
+    xi[nx] = i; fx[nx] = false; cx[nx++] = 0.0;
+    yj[ny] = j; fy[ny] = false; cy[ny++] = 0.0;
     bool has;
     int t;
     if (in_x) {
-        t = image_lo(im.xlo, i, g.Nx, g.Hx, has); if (has) xi[nx++] = t;
-        t = image_hi(im.xhi, i, g.Nx, g.Hx, has); if (has) xi[nx++] = t;
+        t = image_lo(im.xlo, i, g.Nx, g.Hx, has); if (has) { xi[nx] = t; fx[nx] = im.xlo == IMG_VALUE; cx[nx++] = 2 * im.vxlo; }
+        t = image_hi(im.xhi, i, g.Nx, g.Hx, has); if (has) { xi[nx] = t; fx[nx] = im.xhi == IMG_VALUE; cx[nx++] = 2 * im.vxhi; }
     }
     if (in_y) {
-        t = image_lo(im.ylo, j, g.Ny, g.Hy, has); if (has) yj[ny++] = t;
-        t = image_hi(im.yhi, j, g.Ny, g.Hy, has); if (has) yj[ny++] = t;
+        t = image_lo(im.ylo, j, g.Ny, g.Hy, has); if (has) { yj[ny] = t; fy[ny] = im.ylo == IMG_VALUE; cy[ny++] = 2 * im.vylo; }
+        t = image_hi(im.yhi, j, g.Ny, g.Hy, has); if (has) { yj[ny] = t; fy[ny] = im.yhi == IMG_VALUE; cy[ny++] = 2 * im.vyhi; }
     }
     for (int b = 0; b < ny; ++b)
         for (int a = 0; a < nx; ++a)
-            if (a | b) f(xi[a], yj[b]) = val;
+            if (a | b) {
+                double w = val;
+                if (fx[a]) w = cx[a] - w;
+                if (fy[b]) w = cy[b] - w;
+                f(xi[a], yj[b]) = w;
+            }
 }
 
 }  // namespace csi

@@ -19,6 +19,21 @@ from .fields import CenterField, Field, XFaceField, YFaceField
 from .grids import METRIC_NAMES, Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
 
 
+class ValueBoundaryCondition:
+    """Oceananigans ValueBoundaryCondition(value): on a tangential velocity at a wall, value 0 is no-slip."""
+
+    def __init__(self, value=0.0):
+        self.value = float(value)
+
+
+class FieldBoundaryConditions:
+    """FieldBoundaryConditions(north =, south =, west =, east =): sides left out keep the default (no-flux for the
+    tangential velocity, impenetrable for the normal one).  Used as SeaIceModel(boundary_conditions = dict(u =, v =))."""
+
+    def __init__(self, north=None, south=None, west=None, east=None):
+        self.north, self.south, self.west, self.east = north, south, west, east
+
+
 class PrescribedTemperature:
     """HeatBoundaryConditions.PrescribedTemperature(T)."""
 
@@ -110,11 +125,12 @@ def _dptr(a):
 class SeaIceModel:
     def __init__(self, grid, dynamics=None, advection=None, timestepper="SplitRungeKutta3", sea_ice_density=900.0,
                  ice_thermodynamics=None, snow_thermodynamics=None, snow_density=330.0, snowfall=0.0,
-                 device="cuda:0", mode="fast", stream=None):
+                 boundary_conditions=None, device="cuda:0", mode="fast", stream=None):
         self.grid = grid
         self.dynamics = dynamics
         self.advection = advection
         self.ice_thermodynamics = ice_thermodynamics
+        self.boundary_conditions = boundary_conditions or {}
         self.snow_thermodynamics = snow_thermodynamics
         self.snow_density, self.snowfall = float(snow_density), float(snowfall)
         if snow_thermodynamics is not None and ice_thermodynamics is None:
@@ -211,6 +227,14 @@ class SeaIceModel:
             self._bind("TUS", self.snow_top_temperature)
             wp = self.snow_thermodynamics.params(self.snow_density, self.snowfall)
             self.ctx.call("csi_snow_params_set", C.byref(wp))
+        # boundary_conditions = (u = FieldBoundaryConditions(north = ValueBoundaryCondition(0), ...), v = ...)
+        for name, sides in (("U", ("south", "north")), ("V", ("west", "east"))):
+            bcs = self.boundary_conditions.get(name.lower())
+            for k, side in enumerate(sides):
+                bc = getattr(bcs, side, None) if bcs is not None else None
+                if bc is not None and not isinstance(bc, ValueBoundaryCondition):
+                    raise NotImplementedError("velocity boundary conditions: ValueBoundaryCondition or the default")
+                self.ctx.call("csi_velocity_bc_set", _lib.F[name], k, 0 if bc is None else 1, 0.0 if bc is None else bc.value)
         d = self.dynamics
         if d is None:
             return
@@ -380,6 +404,7 @@ def set_(model, **kw):
         names[k].set(val)
     torch.cuda.synchronize(model.device)   # torch wrote on its stream; the library uses its own
     update_state(model)
+    model.synchronize()                    # ... and whoever reads the fields next (torch / numpy) sees the filled halos
 
 
 def update_state(model):

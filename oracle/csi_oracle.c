@@ -479,7 +479,13 @@ void ora_v_velocity_step(ora_problem* g, double dt, int i0, int i1, int j0, int 
 /*   c[1-m] = c[m], c[N+m] = c[N+1-m].  NONE: nothing (Face location in a     */
 /*   Bounded direction: impenetrable / auxiliary default).                    */
 /* ------------------------------------------------------------------------ */
+static void fill_halo4v(const ora_problem* g, ora_field f, int bxlo, int bxhi, int bylo, int byhi, const double* vx, const double* vy);
 void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int bylo, int byhi) {
+    static const double zero[2] = {0.0, 0.0};
+    fill_halo4v(g, f, bxlo, bxhi, bylo, byhi, zero, zero);
+}
+/* vx / vy: values of ORA_BC_VALUE sides ([0] low, [1] high) */
+static void fill_halo4v(const ora_problem* g, ora_field f, int bxlo, int bxhi, int bylo, int byhi, const double* vx, const double* vy) {
     int Nx = g->Nx, Ny = g->Ny, Hx = g->Hx, Hy = g->Hy;
     /* x sides over the interior rows (upstream order: x first, then y over the whole x extent); on a tile
      * whose y side is connected (no local y pass there) the rows beyond it are included, because the ring
@@ -494,6 +500,8 @@ void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int b
             else if (bxlo == ORA_BC_MIRROR) AT(g, f, 1 - m, j) = AT(g, f, m, j);
             if (bxhi == ORA_BC_PERIODIC) AT(g, f, Nx + m, j) = AT(g, f, m, j);
             else if (bxhi == ORA_BC_MIRROR) AT(g, f, Nx + m, j) = AT(g, f, Nx + 1 - m, j);
+            if (m == 1 && bxlo == ORA_BC_VALUE) AT(g, f, 0, j) = 2 * vx[0] - AT(g, f, 1, j);          /* one halo cell */
+            if (m == 1 && bxhi == ORA_BC_VALUE) AT(g, f, Nx + 1, j) = 2 * vx[1] - AT(g, f, Nx, j);
         }
     /* y sides cover the full stored x extent (including the extra Face column, if any) */
     int64_t nxs = f.ld;
@@ -504,6 +512,8 @@ void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int b
             else if (bylo == ORA_BC_MIRROR) AT(g, f, i, 1 - m) = AT(g, f, i, m);
             if (byhi == ORA_BC_PERIODIC) AT(g, f, i, Ny + m) = AT(g, f, i, m);
             else if (byhi == ORA_BC_MIRROR) AT(g, f, i, Ny + m) = AT(g, f, i, Ny + 1 - m);
+            if (m == 1 && bylo == ORA_BC_VALUE) AT(g, f, i, 0) = 2 * vy[0] - AT(g, f, i, 1);
+            if (m == 1 && byhi == ORA_BC_VALUE) AT(g, f, i, Ny + 1) = 2 * vy[1] - AT(g, f, i, Ny);
         }
 }
 void ora_fill_halo(const ora_problem* g, ora_field f, int lx, int ly, int bcx, int bcy) {
@@ -519,8 +529,21 @@ static int bc_side(int topo, int loc, int high) {
 static void fill_loc(const ora_problem* g, ora_field f, int lx, int ly) {
     ora_fill_halo4(g, f, bc_side(g->topo_x, lx, 0), bc_side(g->topo_x, lx, 1), bc_side(g->topo_y, ly, 0), bc_side(g->topo_y, ly, 1));
 }
-void ora_fill_halo_u(ora_problem* g) { fill_loc(g, g->u, F_, C_); }
-void ora_fill_halo_v(ora_problem* g) { fill_loc(g, g->v, C_, F_); }
+/* u, v: a ValueBoundaryCondition replaces the no-flux mirror of the tangential component on a wall */
+void ora_fill_halo_u(ora_problem* g) {
+    int bylo = bc_side(g->topo_y, C_, 0), byhi = bc_side(g->topo_y, C_, 1);
+    if (bylo == ORA_BC_MIRROR && g->u_value_on[0]) bylo = ORA_BC_VALUE;
+    if (byhi == ORA_BC_MIRROR && g->u_value_on[1]) byhi = ORA_BC_VALUE;
+    static const double zero[2] = {0.0, 0.0};
+    fill_halo4v(g, g->u, bc_side(g->topo_x, F_, 0), bc_side(g->topo_x, F_, 1), bylo, byhi, zero, g->u_value);
+}
+void ora_fill_halo_v(ora_problem* g) {
+    int bxlo = bc_side(g->topo_x, C_, 0), bxhi = bc_side(g->topo_x, C_, 1);
+    if (bxlo == ORA_BC_MIRROR && g->v_value_on[0]) bxlo = ORA_BC_VALUE;
+    if (bxhi == ORA_BC_MIRROR && g->v_value_on[1]) bxhi = ORA_BC_VALUE;
+    static const double zero[2] = {0.0, 0.0};
+    fill_halo4v(g, g->v, bxlo, bxhi, bc_side(g->topo_y, F_, 0), bc_side(g->topo_y, F_, 1), g->v_value, zero);
+}
 void ora_fill_halo_center(ora_problem* g, ora_field f) { fill_loc(g, f, C_, C_); }
 
 /* finalize_rheology!, evp:275-280: halo fill of sigma11, sigma12, sigma22 */

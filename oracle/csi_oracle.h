@@ -41,7 +41,7 @@ enum { ORA_STRESS_NONE = 0, ORA_STRESS_CONST = 1, ORA_STRESS_FIELD = 2, ORA_STRE
 enum { ORA_VEL_ZERO = 0, ORA_VEL_CONST = 1, ORA_VEL_FIELD = 2 };
 enum { ORA_PRESSURE_REPLACEMENT = 0, ORA_PRESSURE_ICE_STRENGTH = 1 };
 enum { ORA_LOC_CENTER = 0, ORA_LOC_FACE = 1 };
-enum { ORA_BC_PERIODIC = 0, ORA_BC_MIRROR = 1, ORA_BC_NONE = 2 };
+enum { ORA_BC_PERIODIC = 0, ORA_BC_MIRROR = 1, ORA_BC_NONE = 2, ORA_BC_VALUE = 3 };
 
 typedef struct {
     double* p;     /* parent array start (element (1-Hx, 1-Hy)) */
@@ -105,6 +105,11 @@ typedef struct {
     ora_field hm, am, um, vm;    /* Psi^- cache for RK3: h, aice, u, v */
     ora_field hs, Ghs, hsm;      /* snow thickness, its tendency and Psi^- copy (used when has_snow) */
     int32_t has_snow, pad_snow;
+    /* ValueBoundaryCondition on the tangential velocity at a wall (no-slip: examples/ice_advected_on_coastline.jl:96-99):
+     * u on the south / north walls, v on the west / east walls; [0] low side, [1] high side.  Upstream fills ONE halo
+     * cell, c[0] = 2 val - c[1]; deeper halo cells are left alone.  Default (on = 0): no-flux mirror. */
+    int32_t u_value_on[2], v_value_on[2];
+    double u_value[2], v_value[2];
 } ora_problem;
 
 /* ---- grid metric accessors (Oceananigans operators) ---- */

@@ -69,7 +69,9 @@ class ProblemStruct(C.Structure):
                  ("fu_rows", C.POINTER(C.c_double)), ("fv_rows", C.POINTER(C.c_double)),
                  ("m2d", C.POINTER(C.c_double) * 12), ("m2d_ld", C.c_int64),
                  ("top", Stress), ("bottom", Stress)] +
-                [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("pad_snow", C.c_int32)])
+                [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("pad_snow", C.c_int32),
+                                                      ("u_value_on", C.c_int32 * 2), ("v_value_on", C.c_int32 * 2),
+                                                      ("u_value", C.c_double * 2), ("v_value", C.c_double * 2)])
 
 
 class Slab(C.Structure):
@@ -267,6 +269,13 @@ class Problem:
                 fld = getattr(st, "f" + comp)
                 fld.p = _dptr(a)
                 fld.ld = a.shape[1]
+
+    def set_value_bc(self, field, side, value):
+        """ValueBoundaryCondition(value) on the tangential velocity at a wall: field "u" (side 0 south / 1 north) or
+        "v" (0 west / 1 east); value None restores the no-flux default."""
+        on, val = getattr(self.s, field + "_value_on"), getattr(self.s, field + "_value")
+        on[side] = 0 if value is None else 1
+        val[side] = 0.0 if value is None else float(value)
 
     def set_coriolis(self, f, rows=None):
         """f: None | FPlane f.  rows = (fu, fv): BetaPlane values per row (entry for row j at [j + Hy - 1],

@@ -14,11 +14,12 @@ import climaseaice_jl_amd as csi
 def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
-              field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None):
+              field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None, noslip=False):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
-             free_drift=free_drift, beta=beta)     # beta: BetaPlane(f0 = coriolis, beta)
+             free_drift=free_drift, beta=beta,     # beta: BetaPlane(f0 = coriolis, beta)
+             noslip=noslip)                        # ValueBoundaryCondition(0) on the tangential velocity at every wall
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded}
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
@@ -114,6 +115,10 @@ def oracle_problem(case, omp=False):
     else:
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, per_j=m, substeps=case["substeps"], omp=omp)
     p.set_coriolis(case["coriolis"], rows=coriolis_rows(case, g))
+    if case.get("noslip"):
+        for side in (0, 1):
+            p.set_value_bc("u", side, 0.0)
+            p.set_value_bc("v", side, 0.0)
     if case["pressure"] != "replacement":
         p.s.pressure_kind = O.PRESSURE_ICE_STRENGTH
     if case.get("field_forcing"):
@@ -181,6 +186,10 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
                                      rheology=rheo, top_momentum_stress=top, bottom_momentum_stress=bottom,
                                      free_drift=csi.StressBalanceFreeDrift() if case.get("free_drift") else None,
                                      solver=csi.SplitExplicitSolver(substeps=case["substeps"]), device=device)
+    if case.get("noslip"):
+        vbc = csi.ValueBoundaryCondition(0.0)
+        model_kw = dict(model_kw, boundary_conditions=dict(u=csi.FieldBoundaryConditions(north=vbc, south=vbc),
+                                                           v=csi.FieldBoundaryConditions(west=vbc, east=vbc)))
     model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode, **model_kw)
     if case.get("field_forcing"):
         for slot in ("TOP", "BOT"):

@@ -73,11 +73,16 @@ CASES = {
     "curvilinear_periodic": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.05, curvilinear=0.05),
     "curvilinear_bounded": dict(Nx=40, Ny=56, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.05, curvilinear=0.04),
     "curvilinear_masked": dict(Nx=72, Ny=60, topo=("periodic", "bounded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.25),
+    # no-slip walls: ValueBoundaryCondition(0) on the tangential velocity (examples/ice_advected_on_coastline.jl:96-99)
+    "noslip_channel": dict(Nx=64, Ny=40, topo=("periodic", "bounded"), patches=True, random_uv=0.05, noslip=True),
+    "noslip_bounded": dict(Nx=40, Ny=48, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.05, noslip=True),
+    "noslip_coastline": dict(Nx=72, Ny=48, topo=("periodic", "bounded"), patches=False, random_uv=0.03, noslip=True, land=0.2,
+                             field_forcing=True),
     "beta_masked": dict(Nx=96, Ny=80, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=2e-10, land=0.25),
 }
 MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = set()
+THREE_KERNEL_ONLY = {"noslip_channel", "noslip_bounded", "noslip_coastline"}     # value BCs: three-kernel paths
 
 
 def ulp_diff(a, b):
@@ -373,7 +378,8 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
 
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
-               "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic"] + sorted(MASKED)
+               "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
+               "noslip_coastline"] + sorted(MASKED)
 PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6",
               "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams",
               "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic"} | MASKED

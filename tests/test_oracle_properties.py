@@ -410,3 +410,25 @@ def test_full_2d_metrics_reduce_to_the_regular_grids(grid, topo, oracle_lib):
         assert np.all(np.isfinite(out[0.05][k]))
     assert np.abs(out[0.05]["u"] - out[None]["u"]).max() > 1e-6 * np.abs(out[None]["u"]).max()
     assert np.abs(out[0.05]["h"] - out[None]["h"]).max() > 1e-9
+
+
+def test_no_slip_value_boundary_condition(oracle_lib):
+    """ValueBoundaryCondition(0) on the tangential velocity (a13 of the scope table; examples/ice_advected_on_coastline.jl
+    :96-99): the halo fill writes ONE halo cell, c[0] = 2 val - c[1]; deeper cells keep what they had; the wall corners
+    then see the shear 2 u / dy instead of the free-slip zero, so sigma12 on the wall differs and the flow next to the
+    wall is slowed down."""
+    out = {}
+    for noslip in (False, True):
+        c = cases.make_case(Nx=24, Ny=16, substeps=30, topo=("periodic", "bounded"), patches=False, noise=0.0, u0=0.2, noslip=noslip)
+        p = cases.oracle_problem(c)
+        H = c["H"]
+        u = p.f["u"]
+        if noslip:
+            assert np.array_equal(u[H - 1, H:-H], -u[H, H:-H]) and np.array_equal(u[H + 16, H:-H], -u[H + 15, H:-H])
+            assert np.all(u[:H - 1, :] == 0.0) and np.all(u[H + 17:, :] == 0.0)          # deeper halo rows untouched
+        else:
+            assert np.array_equal(u[H - 1, H:-H], u[H, H:-H]) and np.array_equal(u[H - 2, H:-H], u[H + 1, H:-H])
+        p.time_step_momentum(c["dt"])
+        out[noslip] = {k: p.interior(k).copy() for k in ("u", "s12")}
+    assert np.abs(out[True]["s12"][0, :]).max() > 10 * np.abs(out[False]["s12"][0, :]).max()     # wall corners, j = 1
+    assert np.abs(out[True]["u"][0, :]).mean() < np.abs(out[False]["u"][0, :]).mean()            # first row slowed down
