@@ -689,8 +689,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // three kernels inside run_fused)
     const int pfk = pair_forcing_kind(P);
     const bool pair_only = P.g.has_mask || pfk == 1;      // configurations only the two-sub-steps kernel takes
-    const bool value_bc = c->vel_bc_on[0][0] | c->vel_bc_on[0][1] | c->vel_bc_on[1][0] | c->vel_bc_on[1][1];   // three-kernel paths
-    const bool fuse = fast && c->fusion && substeps > 0 && !value_bc &&
+    const bool fuse = fast && c->fusion && substeps > 0 &&
                       (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                  : fused_supported(P));
     if (fuse) {
@@ -1361,7 +1360,7 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};
-    if (fast && c->fusion && fused_supported(P) && !(c->vel_bc_on[0][0] | c->vel_bc_on[0][1] | c->vel_bc_on[1][0] | c->vel_bc_on[1][1])) {
+    if (fast && c->fusion && fused_supported(P)) {
         // the fused path: one launch per sub-step or per pair (csi_last_launches); bracket the whole run with two events
         if (substeps & 1) ++substeps;                      // even count: the state ends in the caller's arrays
         if ((rc = run_fused(c, P, fc, substeps, 1))) return rc;

@@ -371,6 +371,7 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     for (int k = 0; k < 4; ++k) { I[base[k]] = rr[k]->i0; I[base[k] + 1] = rr[k]->i1; I[base[k] + 2] = rr[k]->j0; I[base[k] + 3] = rr[k]->j1; }
     I[FI_IMU] = imu.xlo; I[FI_IMU + 1] = imu.xhi; I[FI_IMU + 2] = imu.ylo; I[FI_IMU + 3] = imu.yhi;
     I[FI_IMV] = imv.xlo; I[FI_IMV + 1] = imv.xhi; I[FI_IMV + 2] = imv.ylo; I[FI_IMV + 3] = imv.yhi;
+    K[FK_BCU] = imu.vylo; K[FK_BCU + 1] = imu.vyhi; K[FK_BCV] = imv.vxlo; K[FK_BCV + 1] = imv.vxhi;    // IMG_VALUE sides
     I[FI_PRESSURE_KIND] = P.pressure_kind; I[FI_HAS_COR] = P.has_cor; I[FI_TOP_KIND] = P.top.kind; I[FI_BOT_KIND] = P.bot.kind;
     I[FI_COEF_STRIDE] = c.stride; I[FI_COEF_JMIN] = c.jmin; I[FI_COEF_JMAX] = c.jmax;
     if (g.has_mask) {

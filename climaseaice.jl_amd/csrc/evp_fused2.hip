@@ -53,6 +53,8 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     unsigned flags;
     int dx;                  // byte offset of this column's halo image on a periodic side (0: none): every field
     int dxv;                 // the same for v, which also has mirror images across x walls (Center in x)
+    double cvx = 0.0;        // WALLS: this lane's x image of v is a ValueBoundaryCondition reflection, image = cvx - v (xval)
+    bool xval = false;
     bool wave_has_dx;        // any lane of the wave has one
     bool lanes_uniform;      // fast store path allowed (see flush)
     enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64 };
@@ -86,8 +88,12 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             if ((xlo_wall & (i < 1)) | (xhi_wall & (i > Nx))) flags |= L_WALL_V;
             if (xlo_wall & (i == 0)) flags |= L_MIR_LO;
             if (xhi_wall & (i == Nx + 1)) flags |= L_MIR_HI;
-            if (xlo_wall & (i >= 1) & (i <= Hx)) dxv = (1 - 2 * i) * 8;
-            if (xhi_wall & (i > Nx - Hx) & (i <= Nx)) dxv = (2 * Nx + 1 - 2 * i) * 8;
+            // v at an x wall: no-flux mirror of H columns, or ValueBoundaryCondition (IMG_VALUE): ONE halo cell, 2 val - v
+            const bool vval_lo = T->I[FI_IMV + 0] == IMG_VALUE, vval_hi = T->I[FI_IMV + 1] == IMG_VALUE;
+            if (xlo_wall & (i >= 1) & (i <= Hx)) dxv = vval_lo ? ((i == 1) ? -8 : 0) : (1 - 2 * i) * 8;
+            if (xhi_wall & (i > Nx - Hx) & (i <= Nx)) dxv = vval_hi ? ((i == Nx) ? 8 : 0) : (2 * Nx + 1 - 2 * i) * 8;
+            if (xlo_wall & vval_lo & ((i == 1) | (i == 0))) { xval = true; cvx = 2 * T->K[FK_BCV]; }
+            if (xhi_wall & vval_hi & ((i == Nx) | (i == Nx + 1))) { xval = true; cvx = 2 * T->K[FK_BCV + 1]; }
         }
         wave_has_dx = __builtin_amdgcn_ballot_w64((dx != 0) | (dxv != 0)) != 0;
         // every lane stores all three kinds or none, and no lane has an image: the common store path
@@ -168,24 +174,43 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     };
     // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
     const bool ylo_wall = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall = WALLS && T->I[FI_YHI] == SIDE_WALL;
+    // ... unless that wall carries a ValueBoundaryCondition (IMG_VALUE): then ONE halo row, 2 val - u
+    const bool uval_lo = WALLS && T->I[FI_IMU + 2] == IMG_VALUE, uval_hi = WALLS && T->I[FI_IMU + 3] == IMG_VALUE;
     auto yimg_u = [&](int j) __attribute__((always_inline)) {
         int d = yimg(j);
         if (WALLS) {
-            if (ylo_wall & (j >= 1) & (j <= HyW)) d = 1 - 2 * j;
-            if (yhi_wall & (j > NyW - HyW) & (j <= NyW)) d = 2 * NyW + 1 - 2 * j;
+            if (ylo_wall & (j >= 1) & (j <= HyW)) d = uval_lo ? ((j == 1) ? -1 : 0) : 1 - 2 * j;
+            if (yhi_wall & (j > NyW - HyW) & (j <= NyW)) d = uval_hi ? ((j == NyW) ? 1 : 0) : 2 * NyW + 1 - 2 * j;
         }
         return d;
     };
-    // one value -> its cell and the halo images of that cell (same semantics as store_with_images for wrap sides)
-    auto put = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val) __attribute__((always_inline)) {
+    // one value -> its cell and the halo images of that cell (same semantics as store_with_images); valy / valx: the
+    // value of the y / x image (a ValueBoundaryCondition reflection differs from the cell's own value)
+    auto put4 = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val, double valy, double valx, double valxy) __attribute__((always_inline)) {
         stg(base, off, val);
-        if (dy != 0u) stg(base, off + dy, val);
+        if (dy != 0u) stg(base, off + dy, valy);
         if (wave_has_dx) {
             if (dxl != 0) {
-                stg(base, off + (unsigned)dxl, val);
-                if (dy != 0u) stg(base, off + (unsigned)dxl + dy, val);
+                stg(base, off + (unsigned)dxl, valx);
+                if (dy != 0u) stg(base, off + (unsigned)dxl + dy, valxy);
             }
         }
+    };
+    auto put = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val) __attribute__((always_inline)) {
+        put4(base, off, dy, dxl, val, val, val, val);
+    };
+    // u of row j: its y image is a reflection about 2 val on a ValueBoundaryCondition wall
+    auto put_u = [&](unsigned long base, unsigned off, int j, unsigned dy, double val) __attribute__((always_inline)) {
+        double vy = val;
+        if (WALLS) {
+            if (uval_lo & ylo_wall & (j == 1)) vy = 2 * T->K[FK_BCU] - val;
+            if (uval_hi & yhi_wall & (j == NyW)) vy = 2 * T->K[FK_BCU + 1] - val;
+        }
+        put4(base, off, dy, dx, val, vy, val, vy);
+    };
+    auto put_v = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
+        const double vx = (WALLS && xval) ? cvx - val : val;
+        put4(base, off, dy, dxv, val, val, vx, vx);
     };
     // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
     // store path (two scalar compares per row instead of the full bookkeeping)
@@ -225,8 +250,12 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             put(P.s22, ocq, (unsigned)yq * sc, dx, B.S22_m);
             put(P.s12, ofq, (unsigned)yq * sf, dx, B.S12_m);
         }
-        if (do_1 & ((flags & L_R1) != 0)) put(AUF ? P.v : P.u, o1, (unsigned)y1 * (AUF ? sc : sf), AUF ? dxv : dx, B.Wprev);
-        if (do_2 & ((flags & L_R2) != 0)) put(AUF ? P.u : P.v, o2, (unsigned)y2 * (AUF ? sf : sc), AUF ? dx : dxv, pend_second);
+        if (do_1 & ((flags & L_R1) != 0)) {
+            if (AUF) put_v(P.v, o1, (unsigned)y1 * sc, B.Wprev); else put_u(P.u, o1, j1, (unsigned)y1 * sf, B.Wprev);
+        }
+        if (do_2 & ((flags & L_R2) != 0)) {
+            if (AUF) put_u(P.u, o2, j2, (unsigned)y2 * sf, pend_second); else put_v(P.v, o2, (unsigned)y2 * sc, pend_second);
+        }
     };
 #ifdef CSI_PAIR_PROBE
     const unsigned long long wall0 = wall_clock64();
@@ -345,9 +374,11 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             // beyond an x wall is its neighbour's; u of the first row beyond a y wall is the wall row's (row 0 is
             // patched when row 1 arrives, row N + 1 copies row N).  Deeper halo cells only feed halo results.
             const double vl = from_left(bv_p), vr = from_right(bv_p);
-            bv_p = (flags & L_MIR_LO) ? vr : ((flags & L_MIR_HI) ? vl : bv_p);
-            if (ylo_wall & (q == 0)) B.u_0 = bu_p;
-            if (yhi_wall & (q == NyW)) bu_p = B.u_0;
+            // (a ValueBoundaryCondition wall reflects about 2 val instead: cvx - v, 2 val - u)
+            const double ml = xval ? cvx - vr : vr, mh = xval ? cvx - vl : vl;
+            bv_p = (flags & L_MIR_LO) ? ml : ((flags & L_MIR_HI) ? mh : bv_p);
+            if (ylo_wall & (q == 0)) B.u_0 = uval_lo ? 2 * T->K[FK_BCU] - bu_p : bu_p;
+            if (yhi_wall & (q == NyW)) bu_p = uval_hi ? 2 * T->K[FK_BCU + 1] - B.u_0 : B.u_0;
         }
         const double bm_0 = A.m_mm, ba_0 = A.a_mm;             // row r-2
         asm volatile("" : "+s"(T));      // re-read the forcing numbers for stage B instead of holding 24 SGPRs across stage A

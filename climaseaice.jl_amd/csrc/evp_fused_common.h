@@ -64,6 +64,10 @@ __device__ __forceinline__ void store_vel(tptr_t T, int which_ptr, int which_ld,
         ImageSpec im;
         im.xlo = T->I[img0]; im.xhi = T->I[img0 + 1]; im.ylo = T->I[img0 + 2]; im.yhi = T->I[img0 + 3];
         im.ex = 0; im.ey = 0;        // velocities are never stored on the wall faces
+        // ValueBoundaryCondition sides (IMG_VALUE): u on the y walls, v on the x walls
+        im.vxlo = im.vxhi = im.vylo = im.vyhi = 0.0;
+        if (img0 == FI_IMU) { im.vylo = T->K[FK_BCU]; im.vyhi = T->K[FK_BCU + 1]; }
+        else { im.vxlo = T->K[FK_BCV]; im.vxhi = T->K[FK_BCV + 1]; }
         store_with_images(f, g, im, i, j, val);
     } else {
         f(i, j) = val;

@@ -194,8 +194,8 @@ int32_t csi_stress_set(csi_context* ctx, int32_t side, const csi_stress* s);
  * side 0 (west) / 1 (east).  kind 0: the default no-flux condition (halo = mirror image, free slip); kind 1:
  * ValueBoundaryCondition(value) -- no-slip for value 0, as in examples/ice_advected_on_coastline.jl:96-99 -- whose
  * halo fill sets the first halo cell to 2 * value - c[first interior cell] (upstream fill_halo_regions!, SURVEY.md
- * App. B; a13 of the scope table).  Sides that are not walls ignore it.  Such configurations run the three-kernel
- * paths (the fused kernels build the mirror into their register pipelines). */
+ * App. B; a13 of the scope table).  Sides that are not walls ignore it.  Every path takes it (the fused kernels
+ * reflect about 2 * value where they otherwise mirror). */
 int32_t csi_velocity_bc_set(csi_context* ctx, int32_t field_id, int32_t side, int32_t kind, double value);
 /* Row-dependent Coriolis parameter: BetaPlane, f = f0 + beta * ynode (upstream x_f_cross_U / y_f_cross_U called at
  * momentum_tendencies_kernel_functions.jl:31,64; in the reference's test matrix, test/test_time_stepping.jl:35).

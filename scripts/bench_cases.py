@@ -20,6 +20,7 @@ CONFIGS = {
     "OMIP style (arrays, 30 % land, StressBalanceFreeDrift; test/distributed_tests_utils.jl:190-212)":
         dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True),
     "beta-plane channel (per-row f on uniform metrics)": dict(topo=("periodic", "bounded"), beta=1.6e-11),
+    "no-slip channel with 30 % land (coastline-example style)": dict(topo=("periodic", "bounded"), land=0.3, noslip=True),
 }
 if len(sys.argv) > 2:
     CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}

@@ -16,6 +16,8 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
         kw["beta"] = 2e-10 if kw["grid"] == "rectilinear" else 1e-6
     if rng.integers(4) == 0:
         kw["curvilinear"] = 0.04
+    if "bounded" in topo and rng.integers(3) == 0:
+        kw["noslip"] = True
     snow = bool(rng.integers(3) == 0)
     scheme = [7, 5, -5, 3, -3, 1][rng.integers(6)]
     stepper = ["ForwardEuler", "SplitRungeKutta3"][rng.integers(2)]

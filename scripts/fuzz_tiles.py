@@ -17,6 +17,8 @@ for seed in range(80):
         kw.update(ue=0.05, ve=-0.02, top=(0.03, -0.02))
     if topo[1] == "bounded" and rng.integers(3) == 0:
         kw["beta"] = 2e-10
+    if "bounded" in topo and rng.integers(3) == 0:
+        kw["noslip"] = True
     nsub = int(rng.integers(2, 14))
     try:
         c = cases.make_case(substeps=nsub, **kw)

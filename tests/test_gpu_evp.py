@@ -80,9 +80,9 @@ CASES = {
                              field_forcing=True),
     "beta_masked": dict(Nx=96, Ny=80, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=2e-10, land=0.25),
 }
-MASKED = {"masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
+MASKED = {"noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = {"noslip_channel", "noslip_bounded", "noslip_coastline"}     # value BCs: three-kernel paths
+THREE_KERNEL_ONLY = set()
 
 
 def ulp_diff(a, b):
@@ -379,10 +379,10 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
-               "noslip_coastline"] + sorted(MASKED)
+               ] + sorted(MASKED)
 PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6",
               "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams",
-              "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic"} | MASKED
+              "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded"} | MASKED
 
 
 @pytest.mark.parametrize("nsub", [1, 2, 7, 120])
@@ -456,6 +456,8 @@ def test_fused_paths_fuzz_bitwise(seed):
               grid=("rectilinear", "latlon")[rng.integers(2)] if topo[1] == "bounded" else "rectilinear",
               field_forcing=bool(rng.integers(2)), land=(0.0, 0.25)[rng.integers(2)],
               coriolis=(1e-4, None)[rng.integers(2)], pressure=("replacement", "ice_strength")[rng.integers(2)])
+    if "bounded" in topo and rng.integers(3) == 0:
+        kw["noslip"] = True
     if rng.integers(4) == 0:
         kw["free_drift"] = True
         if not kw["field_forcing"]:
