@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsi_hip.so")
+LIB_PATH = os.environ.get("CSI_HIP_LIBRARY", os.path.join(_HERE, "libcsi_hip.so"))   # override: A/B runs of two builds
 
 # ---- enums (include/csi.h) ---------------------------------------------------------------------
 OK = 0

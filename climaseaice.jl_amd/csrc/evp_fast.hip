@@ -245,9 +245,9 @@ void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u
 }
 
 bool fast_supported(const EvpDev& P) {
-    // free-drift closed forms and field-valued forcing besides the bound stress slots are "next"
-    (void)P;
-    return true;
+    // minimum_mass > 0: evp_fast_math.h drops the reference's mi <= 0 guards, which the active / marginal selection
+    // makes redundant in that case (the reference's default is 1 kg m^-2)
+    return P.min_mass > 0;
 }
 
 void launch_fast_init(const EvpDev& P, const Range& r, hipStream_t s) {

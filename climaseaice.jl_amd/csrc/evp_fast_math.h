@@ -26,9 +26,12 @@ __device__ __forceinline__ double fma_(double a, double b, double c) { return __
 __device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 __device__ __forceinline__ double avg2(double a, double b) { return 0.5 * (a + b); }
-__device__ __forceinline__ double avg4(double a, double b, double c, double d) {   // y-average of x-averages
-    return 0.5 * (avg2(a, b) + avg2(c, d));
-}
+// y-average of x-averages, 0.5 * (0.5 * (a + b) + 0.5 * (c + d)): the halvings are exact, so one scaling at the end
+// gives the same bits with two multiplications fewer (barring subnormal intermediates)
+__device__ __forceinline__ double avg4(double a, double b, double c, double d) { return 0.25 * ((a + b) + (c + d)); }
+__device__ __forceinline__ double sum2(double a, double b) { return a + b; }
+// the same from two x-sums kept from row to row (the row pipelines of the fused kernels)
+__device__ __forceinline__ double quarter(double s_a, double s_b) { return 0.25 * (s_a + s_b); }
 
 // Reciprocal and square root without the IEEE special-case scaffolding of the library versions
 // (v_div_scale / v_div_fixup, denormal rescaling): hardware seed (v_rcp_f64 / v_rsq_f64) + Newton /
@@ -148,8 +151,10 @@ __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, d
     if (kind == 3) {
         const double d1 = we - w, d2 = webar - wbar;
         const double n2 = fma_(d1, d1, d2 * d2);
-        const double n = sqrt_pos(n2);
-        im = rhoCd * ((n2 > 0) ? n : 0.0);
+        // sqrt(0) through the rsq seed is NaN: the argument is floored at the smallest normal number instead of
+        // selecting afterwards (a drag coefficient of 1e-154 rho C_D where the ice moves exactly with the ocean)
+        const double n = sqrt_pos(fmax_(n2, 2.2250738585072014e-308));
+        im = rhoCd * n;
         ex = im * we;
     } else {            // kind 1 / 2: tau; kind 0 (no stress): the caller passes tau = 0
         ex = tau; im = 0.0;
@@ -166,10 +171,11 @@ __device__ __forceinline__ double vel_update_avg(const VelConst& k, double w, do
                                                  double div, double cor, double ext, double imt, double exb, double imb, bool peripheral) {
     const double rm = rcp(mi);
     const double rai = rm * ai;
-    double G = fma_(wn - w, k.rdt, fma_(div, rm, fma_(exb - ext, rai, cor)));
-    double tau_i = (imb - imt) * rai;
-    G = (mi <= 0) ? 0.0 : G;
-    tau_i = (mi <= 0) ? 0.0 : tau_i;
+    const double G = fma_(wn - w, k.rdt, fma_(div, rm, fma_(exb - ext, rai, cor)));
+    const double tau_i = (imb - imt) * rai;
+    // The reference zeroes G and tau_i where mi <= 0 (momentum_tendencies_kernel_functions.jl:38).  With
+    // minimum_mass > 0 (required in FAST mode: fast_supported) such a point is neither active nor marginal, so its
+    // result is the final select's 0 (or the free-drift velocity's guard) whatever G was: the two selects are dropped.
     // (w + dtau G) / (1 + dtau tau_i) with dtau = dt / abar, as one quotient: (abar w + dt G) / (abar + dt tau_i)
     const double wD = fma_(k.dt, G, abar * w) * rcp(fma_(k.dt, tau_i, abar));
     const bool active_ice = (mi >= k.min_mass) & (ai >= k.min_conc);

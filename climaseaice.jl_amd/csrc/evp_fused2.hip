@@ -125,19 +125,19 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         A.a_mm = 0.0; A.a_m = ldg(T->P[FP_A], oc - sc);
         A.m_mm = 0.0; A.m_m = ldg(T->P[FP_H], oc - sc) * rho0 * A.a_m;
         P_d1 = ldg(T->P[FP_P], oc - sc);
-        A.XP_m = fm::avg2(from_left(P_d1), P_d1);
+        A.XP_m = fm::sum2(from_left(P_d1), P_d1);
         A.Xm_m = fm::avg2(from_left(A.m_m), A.m_m);
         A.Xa_m = fm::avg2(from_left(A.a_m), A.a_m);
-        A.Xv_m = fm::avg2(from_left(A.v_m), A.v_m);
-        A.Xv_0 = fm::avg2(from_left(A.v_0), A.v_0);
+        A.Xv_m = fm::sum2(from_left(A.v_m), A.v_m);
+        A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
         double e11_m, e22_m;
         const int jm = r - 1;
         fm::strain_cell(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                         coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
         A.e12_0 = fm::strain_corner(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
-        A.Xe11_m = fm::avg2(from_left(e11_m), e11_m);
-        A.Xe22_m = fm::avg2(from_left(e22_m), e22_m);
-        A.Ye12_0 = fm::avg2(A.e12_0, from_right(A.e12_0));
+        A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);
+        A.Xe22_m = fm::sum2(from_left(e22_m), e22_m);
+        A.Ye12_0 = fm::sum2(A.e12_0, from_right(A.e12_0));
         A.XAL_m = 0; A.XS11L_m = 0; A.XW = 0; A.Wprev = 0;
         A.S11_mm = 0; A.S22_mm = 0; A.S12_mm = 0; A.AL_mm = 0; A.S11_m = 0; A.S22_m = 0; A.S12_m = 0; A.AL_m = 0;
     }

@@ -48,21 +48,21 @@ struct Stage {
                                          bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
                                          const Forcing& F) {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
-        Xv_p = fm::avg2(from_left(v_p), v_p);
+        Xv_p = fm::sum2(from_left(v_p), v_p);               // x-SUMS (Xv, Xe11, Xe22, Ye12, XP, XW): scaled once, in quarter()
         double e11_0, e22_0;
         fm::strain_cell(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
                         coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
         e12_p = fm::strain_corner(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
                                   u_p, u_0, v_p, from_left(v_p));
         {
-            const double Xe11_0 = fm::avg2(from_left(e11_0), e11_0), Xe22_0 = fm::avg2(from_left(e22_0), e22_0);
-            const double Ye12_p = fm::avg2(e12_p, from_right(e12_p));
-            const double XP_0 = fm::avg2(from_left(P_0), P_0);
+            const double Xe11_0 = fm::sum2(from_left(e11_0), e11_0), Xe22_0 = fm::sum2(from_left(e22_0), e22_0);
+            const double Ye12_p = fm::sum2(e12_p, from_right(e12_p));
+            const double XP_0 = fm::sum2(from_left(P_0), P_0);
             Xm_0 = fm::avg2(from_left(m_0), m_0);
-            const double e11f = 0.5 * (Xe11_m + Xe11_0);
-            const double e22f = 0.5 * (Xe22_m + Xe22_0);
-            const double e12c = 0.5 * (Ye12_0 + Ye12_p);
-            const double Pf = 0.5 * (XP_m + XP_0);
+            const double e11f = fm::quarter(Xe11_m, Xe11_0);
+            const double e22f = fm::quarter(Xe22_m, Xe22_0);
+            const double e12c = fm::quarter(Ye12_0, Ye12_p);
+            const double Pf = fm::quarter(XP_m, XP_0);
             const double mf = 0.5 * (Xm_m + Xm_0);
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
             if (do_stress) {
@@ -97,7 +97,7 @@ struct Stage {
             const int j = r - 1;
             double W_0;
             {
-                const double vbar = 0.5 * (Xv_m + Xv_0);
+                const double vbar = fm::quarter(Xv_m, Xv_0);
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
@@ -107,9 +107,9 @@ struct Stage {
                 W_0 = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
                            : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
-            const double XW_0 = fm::avg2(W_0, from_right(W_0));
+            const double XW_0 = fm::sum2(W_0, from_right(W_0));
             {
-                const double ubar = 0.5 * (XW + XW_0);
+                const double ubar = fm::quarter(XW, XW_0);
                 const double div = fm::div2(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
@@ -136,10 +136,10 @@ struct Stage {
                 W_0 = F.fd ? fm::vel_update_fd(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
                            : fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
-            const double XW_0 = fm::avg2(from_left(W_0), W_0);
+            const double XW_0 = fm::sum2(from_left(W_0), W_0);
             {
                 const int j = r - 1;
-                const double vbar = 0.5 * (XW + XW_0);
+                const double vbar = fm::quarter(XW, XW_0);
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
