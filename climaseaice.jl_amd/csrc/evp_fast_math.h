@@ -24,6 +24,8 @@ namespace fm {
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // v_max_f64; only used where neither operand can be NaN unless the inputs already are
 __device__ __forceinline__ double fmax_(double a, double b) { return __builtin_fmax(a, b); }
+// v_min_f64, IEEE minNum (kernels run in IEEE mode): a NaN operand yields the other one
+__device__ __forceinline__ double fmin_(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 __device__ __forceinline__ double avg2(double a, double b) { return 0.5 * (a + b); }
 // y-average of x-averages, 0.5 * (0.5 * (a + b) + 0.5 * (c + d)): the halvings are exact, so one scaling at the end
@@ -122,11 +124,11 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     const double s12n = 2.0 * etaf * e12f;
     // gamma = clamp(sqrt(gamma^2), alpha-, alpha+) with NaN -> alpha+ (evp:334-340): gamma^2 is clamped to
     // [alpha-^2, alpha+^2], so the refinement only ever sees finite positive arguments and gamma, 1 / gamma need
-    // no select.  The upper side is an explicit select, !(x < a): NaN (0 * inf where there is no ice) and +inf
-    // go to alpha+^2 whatever the min / max NaN convention of the hardware mode.
+    // no select.  The upper side is v_min_f64 (minNum): NaN (0 * inf where there is no ice) and +inf go to alpha+^2,
+    // as the reference's isnan(gamma^2) ? alpha+^2 branch does.
     const double g2c_raw = zc * kc * rcp(mc), g2f_raw = zf * kf * rcp(mf);
-    const double g2c = fmax_((g2c_raw < k.amax2) ? g2c_raw : k.amax2, k.amin2);
-    const double g2f = fmax_((g2f_raw < k.amax2) ? g2f_raw : k.amax2, k.amin2);
+    const double g2c = fmax_(fmin_(g2c_raw, k.amax2), k.amin2);
+    const double g2f = fmax_(fmin_(g2f_raw, k.amax2), k.amin2);
     double gc, rgc, gf, rgf;
     sqrt_rsqrt(g2c, gc, rgc);
     sqrt_rsqrt(g2f, gf, rgf);
