@@ -132,9 +132,12 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     double gc, rgc, gf, rgf;
     sqrt_rsqrt(g2c, gc, rgc);
     sqrt_rsqrt(g2f, gf, rgf);
-    o.s11 = s11 + ((mc > 0) ? (s11n - s11) * rgc : 0.0);
-    o.s22 = s22 + ((mc > 0) ? (s22n - s22) * rgc : 0.0);
-    o.s12 = s12 + ((mf > 0) ? (s12n - s12) * rgf : 0.0);
+    // sigma += (mass > 0) ? (sigma' - sigma) / gamma : 0 (evp:343-347): the mask goes onto 1 / gamma (sigma' is finite
+    // where there is no ice: zeta = 0 or the ice strength is finite), and the update is one fused multiply-add
+    const double wc = (mc > 0) ? rgc : 0.0, wf = (mf > 0) ? rgf : 0.0;
+    o.s11 = fma_(s11n - s11, wc, s11);
+    o.s22 = fma_(s22n - s22, wc, s22);
+    o.s12 = fma_(s12n - s12, wf, s12);
     o.alpha = gc;
     o.zc = zc; o.zf = zf; o.Dc = Dc;
     return o;
