@@ -104,14 +104,14 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
 
     // strain rates at the four cells (i-1..i, j-1..j) and the four corners (i..i+1, j..j+1)
     double e11_00, e22_00, e11_m0, e22_m0, e11_0m, e22_0m, e11_mm, e22_mm;
-    fm::strain_cell(A0, Bn0, Bs0, Cn0, Cs0, u_p0, u_00, v_0p, v_00, e11_00, e22_00);
-    fm::strain_cell(A0, Bn0, Bs0, Cn0, Cs0, u_00, u_m0, v_mp, v_m0, e11_m0, e22_m0);
-    fm::strain_cell(Am, Bnm, Bsm, Cnm, Csm, u_pm, u_0m, v_00, v_0m, e11_0m, e22_0m);
-    fm::strain_cell(Am, Bnm, Bsm, Cnm, Csm, u_0m, u_mm, v_m0, v_mm, e11_mm, e22_mm);
-    const double e12_00 = fm::strain_corner(Sn0, Ss0, Sv0, u_00, u_0m, v_00, v_m0);
-    const double e12_p0 = fm::strain_corner(Sn0, Ss0, Sv0, u_p0, u_pm, v_p0, v_00);
-    const double e12_0p = fm::strain_corner(Snp, Ssp, Svp, u_0p, u_00, v_0p, v_mp);
-    const double e12_pp = fm::strain_corner(Snp, Ssp, Svp, u_pp, u_p0, v_pp, v_0p);
+    fm::strain_cell<UNI>(A0, Bn0, Bs0, Cn0, Cs0, u_p0, u_00, v_0p, v_00, e11_00, e22_00);
+    fm::strain_cell<UNI>(A0, Bn0, Bs0, Cn0, Cs0, u_00, u_m0, v_mp, v_m0, e11_m0, e22_m0);
+    fm::strain_cell<UNI>(Am, Bnm, Bsm, Cnm, Csm, u_pm, u_0m, v_00, v_0m, e11_0m, e22_0m);
+    fm::strain_cell<UNI>(Am, Bnm, Bsm, Cnm, Csm, u_0m, u_mm, v_m0, v_mm, e11_mm, e22_mm);
+    const double e12_00 = fm::strain_corner<UNI>(Sn0, Ss0, Sv0, u_00, u_0m, v_00, v_m0);
+    const double e12_p0 = fm::strain_corner<UNI>(Sn0, Ss0, Sv0, u_p0, u_pm, v_p0, v_00);
+    const double e12_0p = fm::strain_corner<UNI>(Snp, Ssp, Svp, u_0p, u_00, v_0p, v_mp);
+    const double e12_pp = fm::strain_corner<UNI>(Snp, Ssp, Svp, u_pp, u_p0, v_pp, v_0p);
 
     // 4-point averages (y-average of x-averages), evp:250-252, :268, :330
     const double e11f = fm::avg4(e11_mm, e11_0m, e11_m0, e11_00);
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
         if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
     }
     const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
-    const double div = fm::div2(coef<UNI>(c, FC_Q1N, j), coef<UNI>(c, FC_Q2N, j), coef<UNI>(c, FC_Q1S, j), coef<UNI>(c, FC_Q2S, j),
+    const double div = fm::div2<UNI>(coef<UNI>(c, FC_Q1N, j), coef<UNI>(c, FC_Q2N, j), coef<UNI>(c, FC_Q1S, j), coef<UNI>(c, FC_Q2S, j),
                                 coef<UNI>(c, FC_K, j), s11_0, s22_0, s11_m, s22_m, s12_p, s12_0);
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);

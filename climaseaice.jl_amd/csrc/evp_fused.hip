@@ -96,10 +96,10 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
     double e11_m, e22_m;
     {
         const int jm = r - 1;
-        fm::strain_cell(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
+        fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                         coef<UNI>(T, FC_CS, jm), from_right(u_m), u_m, v_0, v_m, e11_m, e22_m);
     }
-    double e12_0 = fm::strain_corner(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), u_0, u_m, v_0, from_left(v_0));
+    double e12_0 = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), u_0, u_m, v_0, from_left(v_0));
     Xe11_m = fm::avg2(from_left(e11_m), e11_m);
     Xe22_m = fm::avg2(from_left(e22_m), e22_m);
     Ye12_0 = fm::avg2(e12_0, from_right(e12_0));
@@ -140,9 +140,9 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
         const double Xv_p = fm::avg2(from_left(v_p), v_p);
         double S11_0, S22_0, S12_0, AL_0;
         double e11_0, e22_0;
-        fm::strain_cell(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
+        fm::strain_cell<UNI>(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
                         coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
-        const double e12_p = fm::strain_corner(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
+        const double e12_p = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
                                                u_p, u_0, v_p, from_left(v_p));
         {
             const double Xe11_0 = fm::avg2(from_left(e11_0), e11_0), Xe22_0 = fm::avg2(from_left(e22_0), e22_0);
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
             if ((j >= T->I[FI_R2 + 2]) & (j <= T->I[FI_R2 + 3]) & (j >= ja) & (j <= jb)) {
                 const bool wall_vrow = (ylo_wall & (j <= 1)) | (yhi_wall & (j > Ny));
                 const double ubar = 0.5 * (XW_mm + XW_0);           // == fm::avg4(W_mm, R(W_mm), W_0, R(W_0))
-                const double div = fm::div2(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
+                const double div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             S11_m, S22_m, S11_mm, S22_mm, from_right(S12_m), S12_m);
                 double ext, imt, exb, imb;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
             if ((r >= T->I[FI_R1C + 2]) & (r <= T->I[FI_R1C + 3]) & (r >= ja)) {
                 const bool wall_vrow = (ylo_wall & (r <= 1)) | (yhi_wall & (r > Ny));
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
-                const double div = fm::div2(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
+                const double div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
                                             S11_0, S22_0, S11_m, S22_m, from_right(S12_0), S12_0);
                 double ext, imt, exb, imb;

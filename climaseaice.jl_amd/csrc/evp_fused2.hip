@@ -132,9 +132,9 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
         double e11_m, e22_m;
         const int jm = r - 1;
-        fm::strain_cell(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
+        fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                         coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
-        A.e12_0 = fm::strain_corner(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
+        A.e12_0 = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
         A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);
         A.Xe22_m = fm::sum2(from_left(e22_m), e22_m);
         A.Ye12_0 = fm::sum2(A.e12_0, from_right(A.e12_0));

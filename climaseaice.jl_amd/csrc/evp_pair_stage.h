@@ -50,9 +50,9 @@ struct Stage {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
         Xv_p = fm::sum2(from_left(v_p), v_p);               // x-SUMS (Xv, Xe11, Xe22, Ye12, XP, XW): scaled once, in quarter()
         double e11_0, e22_0;
-        fm::strain_cell(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
+        fm::strain_cell<UNI>(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
                         coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
-        e12_p = fm::strain_corner(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
+        e12_p = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
                                   u_p, u_0, v_p, from_left(v_p));
         {
             const double Xe11_0 = fm::sum2(from_left(e11_0), e11_0), Xe22_0 = fm::sum2(from_left(e22_0), e22_0);
@@ -110,7 +110,7 @@ struct Stage {
             const double XW_0 = fm::sum2(W_0, from_right(W_0));
             {
                 const double ubar = fm::quarter(XW, XW_0);
-                const double div = fm::div2(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
+                const double div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
@@ -126,7 +126,7 @@ struct Stage {
             double W_0;
             {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
-                const double div = fm::div2(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
+                const double div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
