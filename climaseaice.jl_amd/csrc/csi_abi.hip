@@ -679,7 +679,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     {
         const double ie = 1.0 / P.ecc;
         fc.em2 = ie * ie;
-        fc.ca_dt = P.ca * dt;
+        fc.ca_dt = 0.5 * (P.ca * dt); fc.hkc = fc.ca_dt * fc.uni[FC_RAZC]; fc.hkf = fc.ca_dt * fc.uni[FC_RAZF]; fc.hk1 = 0.5 * (1.0 - ie * ie);
         fc.rdt = 1.0 / dt;
         fc.Dmin2 = P.Dmin * P.Dmin; fc.rDmin = 1.0 / P.Dmin;
         fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax;
@@ -1353,7 +1353,7 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     if (substeps < 2 || substeps > 64) return fail(c, CSI_ERR_INVALID_ARGUMENT, "2 <= substeps <= 64");
     EvpDev P = evp_dev(c, dt);
     FastCoef fc = c->coef;
-    { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = P.ca * dt; fc.rdt = 1.0 / dt;
+    { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = 0.5 * (P.ca * dt); fc.hkc = fc.ca_dt * fc.uni[FC_RAZC]; fc.hkf = fc.ca_dt * fc.uni[FC_RAZF]; fc.hk1 = 0.5 * (1.0 - ie * ie); fc.rdt = 1.0 / dt;
       fc.Dmin2 = P.Dmin * P.Dmin; fc.rDmin = 1.0 / P.Dmin;
       fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax; }
     const bool fast = c->mode == CSI_MODE_FAST && c->metric_kind != CSI_METRIC_FULL, tiled = is_tiled(c);

@@ -46,7 +46,9 @@ struct FastCoef {
     int uniform;
     int jmin, jmax;         // valid row range of `vec`
     double em2;             // e^-2
-    double ca_dt;           // c_alpha * dt (stage step)
+    double ca_dt;           // HALF of c_alpha * dt (stage step): see fm::stress_update
+    double hkc, hkf;        // uniform grid: ca_dt / Az at cells / corners
+    double hk1;             // (1 - e^-2) / 2
     double rdt;             // 1 / dt
     double Dmin2, rDmin, amin2, amax2, ramin, ramax;   // Delta_min^2, 1/Delta_min, alpha-^2, alpha+^2, 1/alpha-, 1/alpha+
 };

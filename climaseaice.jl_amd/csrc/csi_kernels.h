@@ -25,7 +25,7 @@ bool fast_supported(const EvpDev& P);
 // fused sub-step (evp_fused.hip): stress + both velocities in one launch, double-buffered u, v, sigma.
 // All uniform inputs live in a device table read through the constant address space.
 enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_RDMIN, FK_AMIN, FK_AMAX, FK_AMIN2, FK_AMAX2, FK_RAMIN, FK_RAMAX,
-             FK_DT, FK_RDT, FK_FCOR, FK_MIN_MASS, FK_MIN_CONC, FK_RHO, FK_CA_DT,
+             FK_DT, FK_RDT, FK_FCOR, FK_MIN_MASS, FK_MIN_CONC, FK_RHO, FK_CA_DT, FK_HKC, FK_HKF, FK_HK1,
              FK_TOP_TAU_U, FK_TOP_TAU_V, FK_TOP_RHOCD, FK_TOP_UE, FK_TOP_VE,
              FK_BOT_TAU_U, FK_BOT_TAU_V, FK_BOT_RHOCD, FK_BOT_UE, FK_BOT_VE,
              FK_BCU, FK_BCV = FK_BCU + 2,      // ValueBoundaryCondition values: u at the y walls (low, high), v at the x walls

@@ -69,7 +69,7 @@ __device__ __forceinline__ fm::StressConst stress_const(const EvpDev& P, const F
     fm::StressConst k;
     k.em2 = c.em2; k.Dmin = P.Dmin; k.Dmin2 = c.Dmin2; k.rDmin = c.rDmin;
     k.amin = P.amin; k.amax = P.amax; k.amin2 = c.amin2; k.amax2 = c.amax2;
-    k.ramin = c.ramin; k.ramax = c.ramax;
+    k.ramin = c.ramin; k.ramax = c.ramax; k.hk1 = c.hk1;
     k.pressure_kind = P.pressure_kind;
     return k;
 }
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
     const double Pf = fm::avg4(P_mm, P_0m, P_m0, P_00);
     const double m_00 = h_00 * P.rho * a_00, m_m0 = h_m0 * P.rho * a_m0, m_0m = h_0m * P.rho * a_0m, m_mm = h_mm * P.rho * a_mm;
     const double mf = fm::avg4(m_mm, m_0m, m_m0, m_00);
-    const double kc = c.ca_dt * coef<UNI>(c, FC_RAZC, j), kf = c.ca_dt * coef<UNI>(c, FC_RAZF, j);
+    const double kc = UNI ? c.hkc : c.ca_dt * coef<UNI>(c, FC_RAZC, j), kf = UNI ? c.hkf : c.ca_dt * coef<UNI>(c, FC_RAZF, j);
 
     const fm::StressOut o = fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
                                               m_00, mf, kc, kf, s11, s22, s12);
@@ -129,8 +129,8 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
     P.s12(i, j) = o.s12;
     P.al(i, j) = o.alpha;
     if (P.write_diag) {   // leave zeta, Delta as the reference's viscosity kernel would (evp:270-272)
-        P.zf(i, j) = o.zf;
-        P.zc(i, j) = o.zc;
+        P.zf(i, j) = 0.5 * o.zf2;
+        P.zc(i, j) = 0.5 * o.zc2;
         P.Dl(i, j) = o.Dc;
     }
 }

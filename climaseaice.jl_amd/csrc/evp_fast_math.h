@@ -97,21 +97,22 @@ __device__ __forceinline__ double strain_corner(double Sn, double Ss, double Sv,
 
 struct StressConst {
     double em2, Dmin, Dmin2, rDmin, amin, amax, amin2, amax2, ramin, ramax;
+    double hk1;      // (1 - e^-2) / 2
     int pressure_kind;
 };
 
 struct StressOut {
-    double s11, s22, s12, alpha, zc, zf, Dc;
+    double s11, s22, s12, alpha, zc2, zf2, Dc;      // zc2, zf2: TWICE the bulk viscosities (halved where they are stored)
 };
 
 // One stress index (cell (i,j) + corner (i,j)): viscosities and sigma relaxation.
 //   e11c, e22c : cell strain rates; e12f : corner strain rate
 //   e11f, e22f : 4-point averages of the cell strain rates at the corner; e12c : of the corner rate at the cell
 //   Pc, Pf : ice strength at the cell / averaged to the corner; mc, mf : ice mass likewise
-//   kc, kf : c_alpha * dt / Az at the cell / corner
+//   hkc, hkf : HALF of c_alpha * dt / Az at the cell / corner (the stress phase works with 2 zeta = P / Delta)
 __device__ __forceinline__ StressOut stress_update(const StressConst& k, double e11c, double e22c, double e12f,
                                                    double e11f, double e22f, double e12c, double Pc, double Pf,
-                                                   double mc, double mf, double kc, double kf,
+                                                   double mc, double mf, double hkc, double hkf,
                                                    double s11, double s22, double s12) {
     StressOut o;
     const double dc = e11c + e22c, df = e11f + e22f;
@@ -124,19 +125,20 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     double Dc, rDc, Df, rDf;
     sqrt_rsqrt(xc, Dc, rDc);
     sqrt_rsqrt(xf, Df, rDf);
-    const double zc = Pc * (0.5 * rDc);
-    const double zf = Pf * (0.5 * rDf);
+    // zeta = P / (2 Delta), eta = zeta e^-2 (evp:267-272): carried as 2 zeta, 2 eta -- the factors of two cancel
+    // against sigma' = 2 eta eps + ((zeta - eta) div - P_r / 2) and fold into the constants hk1, hkc, hkf
+    const double zc2 = Pc * rDc, zf2 = Pf * rDf;
     const double Pr = (k.pressure_kind == 0) ? Pc * Dc * rcp(Dc + k.Dmin) : Pc;
-    const double etac = zc * k.em2, etaf = zf * k.em2;
-    const double bulk = fma_(zc - etac, dc, -0.5 * Pr);
-    const double s11n = fma_(2.0 * etac, e11c, bulk);
-    const double s22n = fma_(2.0 * etac, e22c, bulk);
-    const double s12n = 2.0 * etaf * e12f;
+    const double ec2 = zc2 * k.em2, ef2 = zf2 * k.em2;
+    const double bulk = fma_(zc2 * k.hk1, dc, -0.5 * Pr);
+    const double s11n = fma_(ec2, e11c, bulk);
+    const double s22n = fma_(ec2, e22c, bulk);
+    const double s12n = ef2 * e12f;
     // gamma = clamp(sqrt(gamma^2), alpha-, alpha+) with NaN -> alpha+ (evp:334-340): gamma^2 is clamped to
     // [alpha-^2, alpha+^2], so the refinement only ever sees finite positive arguments and gamma, 1 / gamma need
     // no select.  The upper side is v_min_f64 (minNum): NaN (0 * inf where there is no ice) and +inf go to alpha+^2,
     // as the reference's isnan(gamma^2) ? alpha+^2 branch does.
-    const double g2c_raw = zc * kc * rcp(mc), g2f_raw = zf * kf * rcp(mf);
+    const double g2c_raw = zc2 * hkc * rcp(mc), g2f_raw = zf2 * hkf * rcp(mf);
     const double g2c = fmax_(fmin_(g2c_raw, k.amax2), k.amin2);
     const double g2f = fmax_(fmin_(g2f_raw, k.amax2), k.amin2);
     double gc, rgc, gf, rgf;
@@ -149,7 +151,7 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     o.s22 = fma_(s22n - s22, wc, s22);
     o.s12 = fma_(s12n - s12, wf, s12);
     o.alpha = gc;
-    o.zc = zc; o.zf = zf; o.Dc = Dc;
+    o.zc2 = zc2; o.zf2 = zf2; o.Dc = Dc;
     return o;
 }
 

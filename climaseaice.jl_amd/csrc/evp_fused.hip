@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
         fm::StressConst ks;
         ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
         ks.amin = T->K[FK_AMIN]; ks.amax = T->K[FK_AMAX]; ks.amin2 = T->K[FK_AMIN2]; ks.amax2 = T->K[FK_AMAX2];
-        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
         // ---- this iteration's inputs (loaded one iteration ago) ---------------------------------------------------
         const double u_p = C.u_p, v_p = C.v_p, P_0 = C.P_0, h_0 = C.h_0, a_0 = C.a_0;
         const double s11 = C.s11, s22 = C.s22, s12 = C.s12, un_m = C.un_m, vn_x = C.vn_x;
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
             const double mf = 0.5 * (Xm_m + Xm_0);
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
             Xm_next = Xm_0;
-            const double kc = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
+            const double kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
             const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
             S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha;
             if (((flags & L_RS) != 0) & (r >= ja) & (r <= jb)) {
@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                 stg(T->P[FP_S12_OUT], of_cur, o.s12);
                 if (write_diag) {
                     stg(T->P[FP_AL], oc_cur, o.alpha);
-                    stg(T->P[FP_ZF], of_cur, o.zf);
-                    stg(T->P[FP_ZC], oc_cur, o.zc);
+                    stg(T->P[FP_ZF], of_cur, 0.5 * o.zf2);
+                    stg(T->P[FP_ZC], oc_cur, 0.5 * o.zc2);
                     stg(T->P[FP_DL], oc_cur, o.Dc);
                 }
             }
@@ -344,7 +344,7 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     K[FK_EM2] = c.em2; K[FK_DMIN] = P.Dmin; K[FK_DMIN2] = c.Dmin2; K[FK_RDMIN] = c.rDmin;
     K[FK_AMIN] = P.amin; K[FK_AMAX] = P.amax; K[FK_AMIN2] = c.amin2; K[FK_AMAX2] = c.amax2; K[FK_RAMIN] = c.ramin; K[FK_RAMAX] = c.ramax;
     K[FK_DT] = P.dt; K[FK_RDT] = c.rdt; K[FK_FCOR] = P.fcor; K[FK_MIN_MASS] = P.min_mass; K[FK_MIN_CONC] = P.min_conc;
-    K[FK_RHO] = P.rho; K[FK_CA_DT] = c.ca_dt;
+    K[FK_RHO] = P.rho; K[FK_CA_DT] = c.ca_dt; K[FK_HKC] = c.hkc; K[FK_HKF] = c.hkf; K[FK_HK1] = c.hk1;
     // (ext_stress treats every kind but 3 as an explicit stress: no stress = 0)
     K[FK_TOP_TAU_U] = P.top.kind == 1 ? P.top.tau_u : 0.0; K[FK_TOP_TAU_V] = P.top.kind == 1 ? P.top.tau_v : 0.0; K[FK_TOP_RHOCD] = P.top.rho_e * P.top.Cd;
     K[FK_TOP_UE] = eff(P.top.ue_kind, P.top.ue); K[FK_TOP_VE] = eff(P.top.ve_kind, P.top.ve);

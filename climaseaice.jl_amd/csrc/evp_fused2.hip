@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         fm::StressConst ks;
         ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
         ks.amin = T->K[FK_AMIN]; ks.amax = T->K[FK_AMAX]; ks.amin2 = T->K[FK_AMIN2]; ks.amax2 = T->K[FK_AMAX2];
-        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
         fm::VelConst kv;
         kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.fcor = T->K[FK_FCOR]; kv.min_mass = T->K[FK_MIN_MASS];
         kv.min_conc = T->K[FK_MIN_CONC]; kv.has_cor = T->I[FI_HAS_COR];
@@ -403,8 +403,8 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
                 const unsigned ocq = oc_cur - 2u * sc, ofq = of_cur - 2u * sf;
                 const int yq = yimg(q);
                 put(T->P[FP_AL], ocq, (unsigned)yq * sc, dx, B.AL_0);
-                put(T->P[FP_ZF], ofq, (unsigned)yq * sf, dx, B.zf);
-                put(T->P[FP_ZC], ocq, (unsigned)yq * sc, dx, B.zc);
+                put(T->P[FP_ZF], ofq, (unsigned)yq * sf, dx, 0.5 * B.zf);       // the stage carries 2 zeta
+                put(T->P[FP_ZC], ocq, (unsigned)yq * sc, dx, 0.5 * B.zc);
                 put(T->P[FP_DL], ocq, (unsigned)yq * sc, dx, B.Dc);
             }
         }

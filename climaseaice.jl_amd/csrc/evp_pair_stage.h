@@ -66,9 +66,9 @@ struct Stage {
             const double mf = 0.5 * (Xm_m + Xm_0);
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
             if (do_stress) {
-                const double kc = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
+                const double kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
                 const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
-                S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc; zf = o.zf; Dc = o.Dc;
+                S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.Dc;      // zc, zf: 2 zeta
             }
         }
         // stresses as the divergence sees them, peripheral flags
