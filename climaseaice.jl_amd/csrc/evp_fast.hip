@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
     if (P.write_diag) {   // leave zeta, Delta as the reference's viscosity kernel would (evp:270-272)
         P.zf(i, j) = 0.5 * o.zf2;
         P.zc(i, j) = 0.5 * o.zc2;
-        P.Dl(i, j) = o.Dc;
+        P.Dl(i, j) = o.xc * o.rDc;
     }
 }
 

@@ -102,7 +102,8 @@ struct StressConst {
 };
 
 struct StressOut {
-    double s11, s22, s12, alpha, zc2, zf2, Dc;      // zc2, zf2: TWICE the bulk viscosities (halved where they are stored)
+    double s11, s22, s12, alpha, zc2, zf2;          // zc2, zf2: TWICE the bulk viscosities (halved where they are stored)
+    double xc, rDc;                                 // Delta^2 (floored) and 1 / Delta at the cell: Delta = xc * rDc where it is stored
 };
 
 // One stress index (cell (i,j) + corner (i,j)): viscosities and sigma relaxation.
@@ -128,7 +129,8 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     // zeta = P / (2 Delta), eta = zeta e^-2 (evp:267-272): carried as 2 zeta, 2 eta -- the factors of two cancel
     // against sigma' = 2 eta eps + ((zeta - eta) div - P_r / 2) and fold into the constants hk1, hkc, hkf
     const double zc2 = Pc * rDc, zf2 = Pf * rDf;
-    const double Pr = (k.pressure_kind == 0) ? Pc * Dc * rcp(Dc + k.Dmin) : Pc;
+    // replacement pressure P Delta / (Delta + Delta_min) (evp:282-289) = P / (1 + Delta_min / Delta): only 1 / Delta is needed
+    const double Pr = (k.pressure_kind == 0) ? Pc * rcp(fma_(k.Dmin, rDc, 1.0)) : Pc;
     const double ec2 = zc2 * k.em2, ef2 = zf2 * k.em2;
     const double bulk = fma_(zc2 * k.hk1, dc, -0.5 * Pr);
     const double s11n = fma_(ec2, e11c, bulk);
@@ -151,7 +153,7 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     o.s22 = fma_(s22n - s22, wc, s22);
     o.s12 = fma_(s12n - s12, wf, s12);
     o.alpha = gc;
-    o.zc2 = zc2; o.zf2 = zf2; o.Dc = Dc;
+    o.zc2 = zc2; o.zf2 = zf2; o.xc = xc; o.rDc = rDc;
     return o;
 }
 

@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_substep(const FusedTable* __restrict__ 
                     stg(T->P[FP_AL], oc_cur, o.alpha);
                     stg(T->P[FP_ZF], of_cur, 0.5 * o.zf2);
                     stg(T->P[FP_ZC], oc_cur, 0.5 * o.zc2);
-                    stg(T->P[FP_DL], oc_cur, o.Dc);
+                    stg(T->P[FP_DL], oc_cur, o.xc * o.rDc);
                 }
             }
         }

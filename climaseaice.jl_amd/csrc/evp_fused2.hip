@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
                 put(T->P[FP_AL], ocq, (unsigned)yq * sc, dx, B.AL_0);
                 put(T->P[FP_ZF], ofq, (unsigned)yq * sf, dx, 0.5 * B.zf);       // the stage carries 2 zeta
                 put(T->P[FP_ZC], ocq, (unsigned)yq * sc, dx, 0.5 * B.zc);
-                put(T->P[FP_DL], ocq, (unsigned)yq * sc, dx, B.Dc);
+                put(T->P[FP_DL], ocq, (unsigned)yq * sc, dx, B.Dc * B.rDc);         // ... and Delta^2, 1 / Delta
             }
         }
 

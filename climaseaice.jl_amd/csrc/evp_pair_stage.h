@@ -36,7 +36,7 @@ struct Stage {
     double XAL_m, XS11L_m, XW, Wprev;
     double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
     // results of the last step()
-    double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, first, second;
+    double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, rDc, first, second;
     // pending window updates
     double Xv_p, Xa_0, Xm_0, e12_p, XW_next;
 
@@ -68,7 +68,7 @@ struct Stage {
             if (do_stress) {
                 const double kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
                 const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
-                S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.Dc;      // zc, zf: 2 zeta
+                S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
             }
         }
         // stresses as the divergence sees them, peripheral flags
