@@ -53,11 +53,10 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     unsigned flags;
     int dx;                  // byte offset of this column's halo image on a periodic side (0: none): every field
     int dxv;                 // the same for v, which also has mirror images across x walls (Center in x)
-    double cvx = 0.0;        // WALLS: this lane's x image of v is a ValueBoundaryCondition reflection, image = cvx - v (xval)
-    bool xval = false;
-    bool wave_has_dx;        // any lane of the wave has one
+    bool wave_valx_b = false;  // WALLS: some lane of the wave reflects v about a ValueBoundaryCondition value (L_VAL_LO / L_VAL_HI)
+    bool wave_has_dx_b;      // any lane of the wave has one
     bool lanes_uniform;      // fast store path allowed (see flush)
-    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64 };
+    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64, L_VAL_LO = 128, L_VAL_HI = 256 };
     {
         const int Nx = T->I[FI_NX], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
         const int i0s = T->I[FI_DEC + 0] - P_LO + strip * P_W;
@@ -92,13 +91,14 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             const bool vval_lo = T->I[FI_IMV + 0] == IMG_VALUE, vval_hi = T->I[FI_IMV + 1] == IMG_VALUE;
             if (xlo_wall & (i >= 1) & (i <= Hx)) dxv = vval_lo ? ((i == 1) ? -8 : 0) : (1 - 2 * i) * 8;
             if (xhi_wall & (i > Nx - Hx) & (i <= Nx)) dxv = vval_hi ? ((i == Nx) ? 8 : 0) : (2 * Nx + 1 - 2 * i) * 8;
-            if (xlo_wall & vval_lo & ((i == 1) | (i == 0))) { xval = true; cvx = 2 * T->K[FK_BCV]; }
-            if (xhi_wall & vval_hi & ((i == Nx) | (i == Nx + 1))) { xval = true; cvx = 2 * T->K[FK_BCV + 1]; }
+            if (xlo_wall & vval_lo & ((i == 1) | (i == 0))) flags |= L_VAL_LO;      // columns 0 / 1: reflection about 2 * K[FK_BCV]
+            if (xhi_wall & vval_hi & ((i == Nx) | (i == Nx + 1))) flags |= L_VAL_HI;
+            wave_valx_b = __builtin_amdgcn_ballot_w64((flags & (L_VAL_LO | L_VAL_HI)) != 0) != 0;
         }
-        wave_has_dx = __builtin_amdgcn_ballot_w64((dx != 0) | (dxv != 0)) != 0;
+        wave_has_dx_b = __builtin_amdgcn_ballot_w64((dx != 0) | (dxv != 0)) != 0;
         // every lane stores all three kinds or none, and no lane has an image: the common store path
         const bool same = ((flags & L_RS) != 0) == ((flags & L_R1) != 0) && ((flags & L_RS) != 0) == ((flags & L_R2) != 0);
-        lanes_uniform = !wave_has_dx && (__builtin_amdgcn_ballot_w64(!same) == 0);
+        lanes_uniform = !wave_has_dx_b && (__builtin_amdgcn_ballot_w64(!same) == 0);
         rstart = max(ja - 3, T->I[FI_AJ0]);
         rend = min(jb + 3, T->I[FI_AJ1]);
         sc = (unsigned)T->I[FI_LD_C] * 8u;
@@ -166,16 +166,29 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
     const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
     struct OutPtrs { unsigned long s11, s22, s12, u, v; };
-    const bool wrap_y = T->I[FI_YLO] == SIDE_PERIODIC;
+    const bool wrap_y_b = T->I[FI_YLO] == SIDE_PERIODIC;
     const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
+    // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
+    const bool ylo_wall_b = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall_b = WALLS && T->I[FI_YHI] == SIDE_WALL;
+    // ... unless that wall carries a ValueBoundaryCondition (IMG_VALUE): then ONE halo row, 2 val - u
+    const bool uval_lo_b = WALLS && T->I[FI_IMU + 2] == IMG_VALUE, uval_hi_b = WALLS && T->I[FI_IMU + 3] == IMG_VALUE;
+    // the wave-uniform switches of the row loop, packed into one scalar register (as separate bools each is a 64-bit
+    // lane mask: the WALLS / FORCE variants run out of scalar registers)
+    enum : unsigned { U_WRAPY = 1, U_YLO = 2, U_YHI = 4, U_UVLO = 8, U_UVHI = 16, U_HASDX = 32, U_VALX = 64 };
+    const unsigned UF = (unsigned)__builtin_amdgcn_readfirstlane((int)((wrap_y_b ? U_WRAPY : 0u) | (ylo_wall_b ? U_YLO : 0u) | (yhi_wall_b ? U_YHI : 0u) |
+                                                                         (uval_lo_b ? U_UVLO : 0u) | (uval_hi_b ? U_UVHI : 0u) |
+                                                                         (wave_has_dx_b ? U_HASDX : 0u) | (wave_valx_b ? U_VALX : 0u)));
+#define wrap_y ((UF & U_WRAPY) != 0)
+#define ylo_wall (WALLS && (UF & U_YLO) != 0)
+#define yhi_wall (WALLS && (UF & U_YHI) != 0)
+#define uval_lo (WALLS && (UF & U_UVLO) != 0)
+#define uval_hi (WALLS && (UF & U_UVHI) != 0)
+#define wave_has_dx ((UF & U_HASDX) != 0)
+#define wave_valx (WALLS && (UF & U_VALX) != 0)
     // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
     auto yimg = [&](int j) __attribute__((always_inline)) {
         return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
     };
-    // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
-    const bool ylo_wall = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall = WALLS && T->I[FI_YHI] == SIDE_WALL;
-    // ... unless that wall carries a ValueBoundaryCondition (IMG_VALUE): then ONE halo row, 2 val - u
-    const bool uval_lo = WALLS && T->I[FI_IMU + 2] == IMG_VALUE, uval_hi = WALLS && T->I[FI_IMU + 3] == IMG_VALUE;
     auto yimg_u = [&](int j) __attribute__((always_inline)) {
         int d = yimg(j);
         if (WALLS) {
@@ -209,7 +222,11 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         put4(base, off, dy, dx, val, vy, val, vy);
     };
     auto put_v = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
-        const double vx = (WALLS && xval) ? cvx - val : val;
+        double vx = val;
+        if (WALLS && wave_valx) {
+            if (flags & L_VAL_LO) vx = 2 * T->K[FK_BCV] - val;
+            if (flags & L_VAL_HI) vx = 2 * T->K[FK_BCV + 1] - val;
+        }
         put4(base, off, dy, dxv, val, val, vx, vx);
     };
     // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
@@ -375,7 +392,11 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             // patched when row 1 arrives, row N + 1 copies row N).  Deeper halo cells only feed halo results.
             const double vl = from_left(bv_p), vr = from_right(bv_p);
             // (a ValueBoundaryCondition wall reflects about 2 val instead: cvx - v, 2 val - u)
-            const double ml = xval ? cvx - vr : vr, mh = xval ? cvx - vl : vl;
+            double ml = vr, mh = vl;
+            if (wave_valx) {
+                if (flags & L_VAL_LO) ml = 2 * T->K[FK_BCV] - vr;
+                if (flags & L_VAL_HI) mh = 2 * T->K[FK_BCV + 1] - vl;
+            }
             bv_p = (flags & L_MIR_LO) ? ml : ((flags & L_MIR_HI) ? mh : bv_p);
             if (ylo_wall & (q == 0)) B.u_0 = uval_lo ? 2 * T->K[FK_BCU] - bu_p : bu_p;
             if (yhi_wall & (q == NyW)) bu_p = uval_hi ? 2 * T->K[FK_BCU + 1] - B.u_0 : B.u_0;
