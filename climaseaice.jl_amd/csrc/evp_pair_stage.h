@@ -28,7 +28,10 @@ struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsign
 // (ice_stress_divergence.jl:57-123), faces next to an inactive cell are peripheral nodes.
 __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x138, 0xf, 0xf, true); }
 
-template <bool UNI, bool UFIRST, bool MASK>
+// TIGHT: the constants of each phase (strain / stress / velocities) are (re)loaded from the table right before that phase
+// (an empty asm ties the loads to that point): the variants with walls, masks and array forcing otherwise hold more
+// scalars than there are scalar registers and spill them to vector lanes.
+template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
     double a_mm, a_m, m_mm, m_m;
@@ -42,7 +45,7 @@ struct Stage {
 
     // do_stress / do_vel (wave-uniform): the rows at the start of a tile only fill the window (strain rates and
     // x-averages); their stresses / velocities would never be used
-    __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks, const fm::VelConst& kv, int r,
+    __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks_in, const fm::VelConst& kv_in, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
                                          bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
@@ -66,6 +69,12 @@ struct Stage {
             const double mf = 0.5 * (Xm_m + Xm_0);
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
             if (do_stress) {
+                fm::StressConst ks = ks_in;
+                if (TIGHT) {
+                    asm volatile("" : "+s"(T));
+                    ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.amin2 = T->K[FK_AMIN2];
+                    ks.amax2 = T->K[FK_AMAX2]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+                }
                 const double kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
                 const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
@@ -90,6 +99,11 @@ struct Stage {
             const bool per_u = ia_m | ia_mL;                                          // u(i, r-1): cells (i, r-1), (i-1, r-1)
             per_first = UFIRST ? per_u : (ia_0 | ia_m);                               // v(i, r): cells (i, r), (i, r-1)
             per_second = UFIRST ? (ia_m | ia_mm) : per_u;                             // v(i, r-1): cells (i, r-1), (i, r-2)
+        }
+        fm::VelConst kv = kv_in;
+        if (TIGHT) {
+            asm volatile("" : "+s"(T));
+            kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.min_mass = T->K[FK_MIN_MASS]; kv.min_conc = T->K[FK_MIN_CONC];
         }
         if (!do_vel) {
             XW_next = XW;
