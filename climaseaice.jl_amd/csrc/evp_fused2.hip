@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         };
         Forcing FA, FB;
         numbers(FA);
-        double fb[6] = {0, 0, 0, 0, 0, 0};          // FORCE: B's array values, loaded early, merged after stage A
-        unsigned fd_ub = 0, fd_vb = 0;
+        unsigned f_ub = 0, f_vb = 0;                // FORCE: offsets of B's array values, loaded after stage A (they are
+                                                    // not needed before B's velocity update; holding them across A spills)
         if (FORCE) {
             // (B's first rows of a tile only fill its window: clamp their row to the array instead of running off it)
             const unsigned below = (unsigned)(r - (1 - HyW));                                     // rows between r and the array's first row
@@ -364,20 +364,17 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             const unsigned va = AUF ? oc_cur - sc : oc_cur, vb = AUF ? oc_cur - k2 * sc : oc_cur - k3 * sc;   // v points
             if (T->I[FI_TOP_KIND] == 2) {
                 FA.t_tau_u = ldg(T->P[FP_FT_U], ua); FA.t_tau_v = ldg(T->P[FP_FT_V], va);
-                fb[0] = ldg(T->P[FP_FT_U], ub); fb[1] = ldg(T->P[FP_FT_V], vb);
             }
             if (T->I[FI_BOT_UEK] == 2) {       // u_e array: own component at u points, averaged to v points
                 FA.b_we_u = ldg(T->P[FP_FB_U], ua); FA.b_wb_v = ldg(T->P[FP_FB_UBAR], va);
-                fb[2] = ldg(T->P[FP_FB_U], ub); fb[3] = ldg(T->P[FP_FB_UBAR], vb);
             }
             if (T->I[FI_BOT_VEK] == 2) {       // v_e array: own component at v points, averaged to u points
                 FA.b_we_v = ldg(T->P[FP_FB_V], va); FA.b_wb_u = ldg(T->P[FP_FB_VBAR], ua);
-                fb[4] = ldg(T->P[FP_FB_V], vb); fb[5] = ldg(T->P[FP_FB_VBAR], ub);
             }
             if (FD) {                          // StressBalanceFreeDrift: free-drift velocities (once per sub-cycle, csi_abi.hip)
                 FA.fd_u = ldg(T->P[FP_FD_U], ua); FA.fd_v = ldg(T->P[FP_FD_V], va);
-                fd_ub = ub; fd_vb = vb;            // B's values are loaded after stage A: they are not needed before B's velocity update
             }
+            f_ub = ub; f_vb = vb;
         }
         A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
 
@@ -405,10 +402,10 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         asm volatile("" : "+s"(T));      // re-read the forcing numbers for stage B instead of holding 24 SGPRs across stage A
         numbers(FB);
         if (FORCE) {
-            if (T->I[FI_TOP_KIND] == 2) { FB.t_tau_u = fb[0]; FB.t_tau_v = fb[1]; }
-            if (T->I[FI_BOT_UEK] == 2) { FB.b_we_u = fb[2]; FB.b_wb_v = fb[3]; }
-            if (T->I[FI_BOT_VEK] == 2) { FB.b_we_v = fb[4]; FB.b_wb_u = fb[5]; }
-            if (FD) { FB.fd_u = ldg(T->P[FP_FD_U], fd_ub); FB.fd_v = ldg(T->P[FP_FD_V], fd_vb); }
+            if (T->I[FI_TOP_KIND] == 2) { FB.t_tau_u = ldg(T->P[FP_FT_U], f_ub); FB.t_tau_v = ldg(T->P[FP_FT_V], f_vb); }
+            if (T->I[FI_BOT_UEK] == 2) { FB.b_we_u = ldg(T->P[FP_FB_U], f_ub); FB.b_wb_v = ldg(T->P[FP_FB_UBAR], f_vb); }
+            if (T->I[FI_BOT_VEK] == 2) { FB.b_we_v = ldg(T->P[FP_FB_V], f_vb); FB.b_wb_u = ldg(T->P[FP_FB_VBAR], f_ub); }
+            if (FD) { FB.fd_u = ldg(T->P[FP_FD_U], f_ub); FB.fd_v = ldg(T->P[FP_FD_V], f_vb); }
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
