@@ -41,7 +41,7 @@ enum : int {
 
 struct FastCoef {
     double uni[FC_COUNT];   // uniform grid: the (row-independent) values
-    const double* vec;      // per-j: device array [FC_COUNT][stride], pre-offset so vec[w*stride + j] is row j
+    const double* vec;      // per-j: device array [rows][FC_COUNT] (row-major), pre-offset so vec[j*stride + w] is row j
     int stride;
     int uniform;
     int jmin, jmax;         // valid row range of `vec`

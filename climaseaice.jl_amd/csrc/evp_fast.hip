@@ -29,7 +29,7 @@ namespace fast {
 template <bool UNI>
 __device__ __forceinline__ double coef(const FastCoef& c, int which, int j) {
     if (UNI) return c.uni[which];
-    return c.vec[(long)which * c.stride + j];
+    return c.vec[(long)j * c.stride + which];
 }
 
 // Block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an

@@ -35,7 +35,7 @@ __device__ __forceinline__ double coef(tptr_t T, int which, int j) {
     if (UNI) return T->K[FK_COEF0 + which];
     typedef const __attribute__((address_space(4))) double* vptr_t;
     vptr_t vec = (vptr_t)T->P[FP_COEF_VEC];
-    return vec[(long)which * T->I[FI_COEF_STRIDE] + min(max(j, T->I[FI_COEF_JMIN]), T->I[FI_COEF_JMAX])];   // ring rows may fall off the table
+    return vec[(long)min(max(j, T->I[FI_COEF_JMIN]), T->I[FI_COEF_JMAX]) * FC_COUNT + which];   // row-major; ring rows may fall off the table
 }
 
 // Addressing: uniform base = parent array start, per-lane unsigned byte offset in a VGPR ->
