@@ -13,29 +13,28 @@
 namespace csi {
 
 enum : int {
-    // centre rows j
-    FC_A = 0,   // e11: A (u[i+1] - u[i])               = dy / Az^cc
-    FC_BN,      // e11: + BN v[j+1]                      = (dxf[j+1]/Az - dxc^2/(dxf[j+1] Az)) / 2
-    FC_BS,      // e11: - BS v[j]
-    FC_CN,      // e22: + CN v[j+1]
-    FC_CS,      // e22: - CS v[j]
-    FC_E,       // div1: E (s11[i] - s11[i-1])           = dy / Az^fc
-    FC_FN,      // div1: + FN s12[j+1]                   = dxf[j+1]^2 / (dxc[j] Az^fc)
-    FC_FS,      // div1: - FS s12[j]
-    FC_RAZC,    // 1 / Az^cc
-    // face rows j
-    FC_SN,      // e12: + SN u[j]                        = dxf[j]^2 / (2 dxc[j] Az^ff)
-    FC_SS,      // e12: - SS u[j-1]
-    FC_SV,      // e12: + SV (v[i] - v[i-1])             = dy / (2 Az^ff)
-    FC_Q1N,     // div2: + Q1N s11[j] + Q2N s22[j] - Q1S s11[j-1] - Q2S s22[j-1] + K (s12[i+1] - s12[i])
-    FC_Q2N,
+    // Order = order of use, so that the constants of one phase sit next to each other (the scalar loads of adjacent
+    // table entries merge into wide ones).  Centre-row (j) and face-row coefficients are marked (c) / (f).
+    FC_A = 0,   // (c) e11: A (u[i+1] - u[i])               = dy / Az^cc
+    FC_CN,      // (c) e22: + CN v[j+1]
+    FC_BN,      // (c) e11: + BN v[j+1]                      = (dxf[j+1]/Az - dxc^2/(dxf[j+1] Az)) / 2
+    FC_BS,      // (c) e11: - BS v[j]
+    FC_CS,      // (c) e22: - CS v[j]
+    FC_RAZC,    // (c) 1 / Az^cc
+    FC_RAZF,    // (f) 1 / Az^ff
+    FC_SN,      // (f) e12: + SN u[j]                        = dxf[j]^2 / (2 dxc[j] Az^ff)
+    FC_SV,      // (f) e12: + SV (v[i] - v[i-1])             = dy / (2 Az^ff)
+    FC_SS,      // (f) e12: - SS u[j-1]
+    FC_E,       // (c) div1: E (s11[i] - s11[i-1])           = dy / Az^fc
+    FC_FN,      // (c) div1: + FN s12[j+1]                   = dxf[j+1]^2 / (dxc[j] Az^fc)
+    FC_FS,      // (c) div1: - FS s12[j]
+    FC_FU,      // (c) Coriolis parameter at the u points of the row (FPlane: the same in every row; BetaPlane: csi_coriolis_rows_set)
+    FC_Q2N,     // (f) div2: + Q1N s11[j] + Q2N s22[j] - Q1S s11[j-1] - Q2S s22[j-1] + K (s12[i+1] - s12[i])
+    FC_K,
+    FC_FV,      // (f) Coriolis parameter at the v points of the row
+    FC_Q1N,
     FC_Q1S,
     FC_Q2S,
-    FC_K,
-    FC_RAZF,    // 1 / Az^ff
-    // Coriolis parameter of the row (FPlane: the same value in every row; BetaPlane: csi_coriolis_rows_set)
-    FC_FU,      // at the u points of centre row j
-    FC_FV,      // at the v points of face row j
     FC_COUNT
 };
 

@@ -24,12 +24,14 @@ bool fast_supported(const EvpDev& P);
 
 // fused sub-step (evp_fused.hip): stress + both velocities in one launch, double-buffered u, v, sigma.
 // All uniform inputs live in a device table read through the constant address space.
-enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_RDMIN, FK_AMIN, FK_AMAX, FK_AMIN2, FK_AMAX2, FK_RAMIN, FK_RAMAX,
-             FK_DT, FK_RDT, FK_FCOR, FK_MIN_MASS, FK_MIN_CONC, FK_RHO, FK_CA_DT, FK_HKC, FK_HKF, FK_HK1,
+// (order of use: adjacent entries are read by merged wide scalar loads)
+enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_AMIN2, FK_AMAX2, FK_HK1, FK_HKC, FK_HKF,      // stress phase
+             FK_DT, FK_RDT, FK_MIN_MASS, FK_MIN_CONC, FK_RHO,                                     // velocity phases
              FK_TOP_TAU_U, FK_TOP_TAU_V, FK_TOP_RHOCD, FK_TOP_UE, FK_TOP_VE,
              FK_BOT_TAU_U, FK_BOT_TAU_V, FK_BOT_RHOCD, FK_BOT_UE, FK_BOT_VE,
              FK_BCU, FK_BCV = FK_BCU + 2,      // ValueBoundaryCondition values: u at the y walls (low, high), v at the x walls
-             FK_COEF0 = FK_BCV + 2, FK_COUNT = FK_COEF0 + FC_COUNT };
+             FK_CA_DT = FK_BCV + 2, FK_RDMIN, FK_AMIN, FK_AMAX, FK_RAMIN, FK_RAMAX, FK_FCOR,
+             FK_COEF0, FK_COUNT = FK_COEF0 + FC_COUNT };
 enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, FP_A, FP_UN, FP_VN,     // 10 inputs, contiguous
              FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUTP, FP_V_OUTP,                                // 5 outputs (parent addresses), contiguous
              FP_U_OUT, FP_V_OUT, FP_S11_OUT0, FP_S22_OUT0, FP_S12_OUT0,                               // (0,0)-offset addresses for stores with halo images
