@@ -138,6 +138,10 @@ def main():
     for _ in range(args.warmup):
         csi.time_step_momentum(model, dt)
     barrier()
+    # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
+    # below is the last thing this process writes
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         csi.time_step_momentum(model, dt)
@@ -220,12 +224,17 @@ def main():
                      "all_phases_ms": phases,
                      "substep_frac": cells_launch * 256.0 / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    model = None                                   # contexts (and their RCCL communicators) go before the line is printed
+    import gc
+    gc.collect()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
