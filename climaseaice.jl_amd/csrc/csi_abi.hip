@@ -521,6 +521,10 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const bool masked = P.g.has_mask != 0;
     const bool force = pair_forcing_kind(P) == 1;           // array-valued forcing: two-sub-steps kernel only
     const bool pairs = pair_supported(c) && (!tiled || k % 2 == 0);
+    // number-valued top stress (or none) and a bottom SemiImplicitStress with number-valued ocean velocities: the kernels'
+    // compile-time forcing kinds
+    const bool common_forcing = !force && P.top.kind <= 1 && P.bot.kind == 3 && P.bot.ue_kind != 2 && P.bot.ve_kind != 2 &&
+                                P.pressure_kind == 0;     // ... and the default ReplacementPressure
     FRef ubar_v{nullptr, 0}, vbar_u{nullptr, 0};
     if (force && P.bot.kind == 3 && (P.bot.ue_kind == 2 || P.bot.ve_kind == 2)) {
         // cross components of the ocean velocity averaged to the velocity points, once per sub-cycle
@@ -597,7 +601,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
-                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
             m += 2; s += 2;
         } else if (masked || force) {
             // the one-sub-step kernel takes neither masks nor array-valued forcing: a trailing single sub-step runs the

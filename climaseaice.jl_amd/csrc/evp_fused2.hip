@@ -34,7 +34,7 @@ namespace fused {
 __device__ unsigned long long g_probe[4096 * 16];
 #endif
 
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, bool CF>
 __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                int blocks_per_xcd, int write_diag) {
     const int b = (int)blockIdx.x;
@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     }
     int r = rstart;
 
-    Stage<UNI, AUF, MASK, FORCE> A;          // TIGHT scalar live ranges in the array-forcing variants (measured: +6 .. +27 %;
-    Stage<UNI, !AUF, MASK, FORCE> B;         // neutral for walls / masks alone)
+    Stage<UNI, AUF, MASK, FORCE, CF> A;          // TIGHT scalar live ranges in the array-forcing variants (measured: +6 .. +27 %;
+    Stage<UNI, !AUF, MASK, FORCE, CF> B;         // neutral for walls / masks alone)
     // ---- stage A prologue: rows r-1, r (as evp_fused.hip) ------------------------------------------------------
     double P_d1, P_d2 = 0.0;                       // P of rows r-1, r-2
     double un_d1 = 0.0, un_d2 = 0.0;               // u^n of rows r-2, r-3
@@ -513,34 +513,42 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 #define CSI_PAIR_NAME launch_fused_pair_mask_force_fd
 #define CSI_PAIR_FLAGS true, true, true, true
 #endif
-void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, int nstrips, int nchunks, int rows,
+// common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF); the
+// array-forcing variants have one instantiation (kinds read from the table)
+void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool common, int nstrips, int nchunks, int rows,
                    int write_diag, hipStream_t s) {
     const int nw = nstrips * nchunks;
     const int nblocks = (nw + 3) / 4;
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
-#define CSI_LAUNCH_PAIR(U, A) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
+#define CSI_LAUNCH_PAIR_(U, A, C) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
+#if CSI_PAIR_VARIANT <= 2
+#define CSI_LAUNCH_PAIR(U, A) do { if (common) CSI_LAUNCH_PAIR_(U, A, true); else CSI_LAUNCH_PAIR_(U, A, false); } while (0)
+#else
+#define CSI_LAUNCH_PAIR(U, A) do { (void)common; CSI_LAUNCH_PAIR_(U, A, false); } while (0)
+#endif
     if (uniform) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
     else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true); else CSI_LAUNCH_PAIR(false, false); }
 #undef CSI_LAUNCH_PAIR
+#undef CSI_LAUNCH_PAIR_
 }
 
 #if CSI_PAIR_VARIANT == 0
-void launch_fused_pair_walls(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_force(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_force_fd(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force_fd(const FusedTable*, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_walls(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_force(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_force_fd(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force_fd(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
 void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
-                       int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
-    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
-    else if (free_drift) launch_fused_pair_force_fd(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
-    else if (force && mask) launch_fused_pair_mask_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
-    else if (force) launch_fused_pair_force(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
-    else if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
-    else if (walls) launch_fused_pair_walls(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
-    else launch_fused_pair_plain(dev_table, uniform, a_ufirst, nstrips, nchunks, rows, write_diag, s);
+                       bool common, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
+    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (free_drift) launch_fused_pair_force_fd(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (force && mask) launch_fused_pair_mask_force(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (force) launch_fused_pair_force(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (walls) launch_fused_pair_walls(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else launch_fused_pair_plain(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
 }
 #endif
 

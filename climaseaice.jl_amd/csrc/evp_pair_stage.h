@@ -31,7 +31,10 @@ __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__b
 // TIGHT: the constants of each phase (strain / stress / velocities) are (re)loaded from the table right before that phase
 // (an empty asm ties the loads to that point): the variants with walls, masks and array forcing otherwise hold more
 // scalars than there are scalar registers and spill them to vector lanes.
-template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false>
+// CF ("common forcing"): the external stresses are known at compile time to be a number-valued top stress (kind 0 / 1) and
+// a bottom SemiImplicitStress with number-valued ocean velocities (kind 3) -- the bench and most stand-alone runs --, so
+// the four wave-uniform kind branches per stage-row disappear.
+template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, bool CF = false>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
     double a_mm, a_m, m_mm, m_m;
@@ -70,6 +73,7 @@ struct Stage {
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
             if (do_stress) {
                 fm::StressConst ks = ks_in;
+                if (CF) ks.pressure_kind = 0;          // ReplacementPressure is part of the common configuration
                 if (TIGHT) {
                     asm volatile("" : "+s"(T));
                     ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.amin2 = T->K[FK_AMIN2];
@@ -115,8 +119,8 @@ struct Stage {
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
+                if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
+                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 W_0 = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
                            : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
@@ -128,8 +132,8 @@ struct Stage {
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
+                if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
+                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
                 const double cor = -coef<UNI>(T, FC_FV, j) * ubar;
                 second = F.fd ? fm::vel_update_fd(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
                               : fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
@@ -144,8 +148,8 @@ struct Stage {
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
+                if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
+                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
                 const double cor = -coef<UNI>(T, FC_FV, r) * ubar;
                 W_0 = F.fd ? fm::vel_update_fd(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
                            : fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
@@ -157,8 +161,8 @@ struct Stage {
                 const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
-                fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                fm::ext_stress(T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
+                if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
+                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 second = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
                               : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
