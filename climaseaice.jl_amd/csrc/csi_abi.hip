@@ -83,6 +83,13 @@ struct csi_context {
     int last_exchanges = 0, last_k = 1;
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
     FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
+    // pinned staging ring for their upload: the host never waits for the stream (a slot is reused after its own copy
+    // has completed, four sub-cycles later)
+    static constexpr int kRing = 4;
+    FusedTable* host_ring = nullptr;
+    hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool ring_used[kRing] = {false, false, false, false};
+    unsigned ring_pos = 0;
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
     double* fd[2] = {nullptr, nullptr};     // free-drift velocities at u / v points (StressBalanceFreeDrift)
@@ -563,7 +570,13 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
     FusedGeom G[KMAX], GP[KMAX / 2];
     {
-        static thread_local FusedTable host[NSINGLE + NPAIR];
+        if (!c->host_ring) {
+            HIP_TRY(c, hipHostMalloc((void**)&c->host_ring, sizeof(FusedTable) * (NSINGLE + NPAIR) * csi_context::kRing, hipHostMallocDefault));
+            for (int q = 0; q < csi_context::kRing; ++q) HIP_TRY(c, hipEventCreateWithFlags(&c->ring_ev[q], hipEventDisableTiming));
+        }
+        const int slot = (int)(c->ring_pos++ % csi_context::kRing);
+        if (c->ring_used[slot]) HIP_TRY(c, hipEventSynchronize(c->ring_ev[slot]));
+        FusedTable* host = c->host_ring + (size_t)slot * (NSINGLE + NPAIR);
         for (int m = 0; m < kb; ++m) {
             const int V = tiled ? W - 2 * m : 2;
             G[m] = fused_geom(c, V);
@@ -594,7 +607,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             }
         }
         HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(FusedTable) * (NSINGLE + NPAIR), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));   // `host` is reused by the next call; tiny, once per stage
+        HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
+        c->ring_used[slot] = true;
     }
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
@@ -752,10 +766,10 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
 }
 
 int32_t do_finalize(csi_context* c) {
-    int32_t rc;
-    if ((rc = fill_halo(c, CSI_F_S11))) return rc;
-    if ((rc = fill_halo(c, CSI_F_S12))) return rc;
-    if ((rc = fill_halo(c, CSI_F_S22))) return rc;
+    HaloBatch B{};
+    for (int fid : {CSI_F_S11, CSI_F_S12, CSI_F_S22}) { B.f[B.n] = ref_of(c, fid); B.im[B.n] = image_spec(c, fid); ++B.n; }
+    launch_fill_halo_batch(B, c->g, c->stream);
+    HIP_TRY(c, hipGetLastError());
     const int sg[3] = {CSI_F_S11, CSI_F_S12, CSI_F_S22};
     return exchange(c, sg, 3, c->Hx < c->Hy ? c->Hx : c->Hy);
 }
@@ -941,6 +955,8 @@ int32_t csi_context_destroy(csi_context* c) {
     hipStreamSynchronize(c->stream);
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_fcor) hipFree(c->dev_fcor);
+    if (c->host_ring) hipHostFree(c->host_ring);
+    for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
     for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
