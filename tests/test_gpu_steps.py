@@ -406,6 +406,40 @@ def test_full_time_step_with_snow_vs_oracle(stepper, oracle_lib):
         assert np.abs(p.interior("hs") - hs0).max() > 1e-4            # the snow did something
 
 
+@pytest.mark.parametrize("snow", [False, True])
+@pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
+def test_full_time_step_on_a_tile_equals_untiled(stepper, snow):
+    """Whole time_step! on a tile whose periodic sides go through the RCCL exchange (to itself): the halo refresh of
+    update_state! (h, aice, [hs,] u, v exchanged with the full halo width), WENO7 advection reading those halos, the
+    batched sub-cycle exchange and the thermodynamic step give the untiled run bit for bit on the owned cells."""
+    c = cases.make_case(Nx=72, Ny=56, H=8, substeps=12, topo=("periodic", "periodic"), patches=True, random_uv=0.03)
+    rng = np.random.default_rng(51)
+    hs0 = np.where(c["a"] > 0, 0.2 * rng.random(c["a"].shape), 0.0)
+    out = {}
+    for tile in (None, (1, 1, 0, True)):
+        kw = {}
+        if snow:
+            kw = dict(ice_thermodynamics=csi.SlabThermodynamics(top_heat_flux=-60.0, bottom_heat_flux=5.0, bottom_salinity=30.0,
+                                                                top_heat_boundary_condition=csi.MeltingConstrainedFluxBalance()),
+                      snow_thermodynamics=csi.snow_slab_thermodynamics(), snowfall=2e-5)
+        m = cases.csi_model(c, mode="fast", timestepper=stepper, advection=csi.WENO(order=7), tile=tile, **kw)
+        if snow:
+            csi.set_(m, hs=hs0)
+        for n in range(3):
+            csi.time_step(m, c["dt"])
+        m.synchronize()
+        out[tile is None] = {k: f.interior_numpy().copy() for k, f in (("u", m.velocities.u), ("v", m.velocities.v), ("h", m.ice_thickness),
+                                                                      ("aice", m.ice_concentration))}
+        if snow:
+            out[tile is None]["hs"] = m.snow_thickness.interior_numpy().copy()
+        if tile is not None:
+            assert m.ctx.last_path()["exchanges"] > 0
+    for k in out[True]:
+        assert np.all(np.isfinite(out[False][k])), k
+        assert np.array_equal(out[True][k], out[False][k]), (k, np.abs(out[True][k] - out[False][k]).max())
+    assert np.abs(out[True]["h"] - c["h"]).max() > 1e-5
+
+
 def test_config4_style_latlon_evp_plus_slab_thermodynamics(oracle_lib):
     """BASELINE config 4 in miniature: lat-lon (lon 0..60, lat 20..70) channel, EVP + WENO7 (order reduced next to
     the walls) + bare-ice slab thermodynamics (top 100 W m^-2, bottom 10 W m^-2, test/test_thermodynamic_mass_fluxes.jl:56), RK3, 2 steps."""
