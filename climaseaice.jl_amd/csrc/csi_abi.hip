@@ -60,7 +60,8 @@ struct csi_context {
     int Nx = 0, Ny = 0, Hx = 0, Hy = 0, topo_x = 0, topo_y = 0, metric_kind = 0;
     GridDev g{};
     double* dev_metrics = nullptr;   // 8 vectors of length Ny + 2Hy + 1 (PER_J) or 12 planes (FULL)
-    double* dev_coef = nullptr;      // FAST per-row stencil coefficients [FC_COUNT][Ny + 2Hy + 1]
+    double* dev_coef = nullptr;      // FAST per-row stencil coefficients [Ny + 2Hy + 1][FC_COUNT]
+    double* dev_coef2 = nullptr;     // FAST per-point stencil coefficients of a CSI_METRIC_FULL grid, C2_COUNT planes
     FastCoef coef{};
     std::vector<double> coef_host;       // host copy of the per-row table built from PER_J metrics (empty: uniform metrics)
     std::vector<double> fcor_rows[2];    // csi_coriolis_rows_set: f per row at u / v points (empty: FPlane scalar)
@@ -489,6 +490,7 @@ bool has_walls(const csi_context* c) {
 }
 bool pair_supported(const csi_context* c) {
     if (!c->pairing) return false;
+    if (c->metric_kind == CSI_METRIC_FULL) return false;        // per-point coefficients: three-kernel path
     const GridDev& g = c->g;
     auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED || s == SIDE_WALL; };
     // per-row metrics with a periodic y side: the ring rows recomputed beyond the seam would use other metrics than
@@ -703,7 +705,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     }
     EvpDev P = evp_dev(c, dt);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
-    const bool fast = c->mode == CSI_MODE_FAST && c->metric_kind != CSI_METRIC_FULL;   // general metrics: reference-order kernels
+    const bool fast = c->mode == CSI_MODE_FAST;
     FastCoef fc = c->coef;
     {
         const double ie = 1.0 / P.ecc;
@@ -955,6 +957,7 @@ int32_t csi_context_destroy(csi_context* c) {
     hipStreamSynchronize(c->stream);
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_fcor) hipFree(c->dev_fcor);
+    if (c->dev_coef2) hipFree(c->dev_coef2);
     if (c->host_ring) hipHostFree(c->host_ring);
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
     if (c->dev_coef) hipFree(c->dev_coef);
@@ -1033,6 +1036,14 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
         g.m2 = c->dev_metrics + (Hx - 1) + (int64_t)(Hy - 1) * ni;      // so that m2[k * plane + i + j * ld] is (i, j)
         g.m2_plane = (long)(ni * nj);
         g.m2_ld = (int)ni;
+        // FAST mode: per-point stencil coefficients (three-kernel path)
+        std::vector<double> coef2;
+        const double* planes[12];
+        for (int k = 0; k < 12; ++k) planes[k] = host.data() + (size_t)k * ni * nj;
+        build_fast_coef_full((int)ni, (int)nj, planes, coef2);
+        if (c->dev_coef2) { hipFree(c->dev_coef2); c->dev_coef2 = nullptr; }
+        HIP_TRY(c, hipMalloc((void**)&c->dev_coef2, sizeof(double) * coef2.size()));
+        HIP_TRY(c, hipMemcpy(c->dev_coef2, coef2.data(), sizeof(double) * coef2.size(), hipMemcpyHostToDevice));
     }
     // FAST-mode stencil coefficients
     if (c->dev_coef) { hipFree(c->dev_coef); c->dev_coef = nullptr; }
@@ -1041,6 +1052,13 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
     c->cor_dirty = true;
     c->coef = FastCoef{};
     c->coef.uniform = metric_kind == CSI_METRIC_UNIFORM;
+    if (metric_kind == CSI_METRIC_FULL) {
+        const int64_t ni = (int64_t)Nx + 2 * Hx + 1, nj = (int64_t)Ny + 2 * Hy + 1;
+        c->coef.full = 1;
+        c->coef.c2 = c->dev_coef2 + (Hx - 1) + (int64_t)(Hy - 1) * ni;
+        c->coef.c2_plane = (long)(ni * nj);
+        c->coef.c2_ld = (int)ni;
+    }
     if (metric_kind == CSI_METRIC_UNIFORM) {
         build_fast_coef_uniform(m->dx, m->dy, c->coef.uni);
     } else if (metric_kind == CSI_METRIC_PER_J) {
@@ -1387,7 +1405,7 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     { const double ie = 1.0 / P.ecc; fc.em2 = ie * ie; fc.ca_dt = 0.5 * (P.ca * dt); fc.hkc = fc.ca_dt * fc.uni[FC_RAZC]; fc.hkf = fc.ca_dt * fc.uni[FC_RAZF]; fc.hk1 = 0.5 * (1.0 - ie * ie); fc.rdt = 1.0 / dt;
       fc.Dmin2 = P.Dmin * P.Dmin; fc.rDmin = 1.0 / P.Dmin;
       fc.amin2 = P.amin * P.amin; fc.amax2 = P.amax * P.amax; fc.ramin = 1.0 / P.amin; fc.ramax = 1.0 / P.amax; }
-    const bool fast = c->mode == CSI_MODE_FAST && c->metric_kind != CSI_METRIC_FULL, tiled = is_tiled(c);
+    const bool fast = c->mode == CSI_MODE_FAST, tiled = is_tiled(c);
     const Range rs = stress_range(c), rv = interior_range(c), ru1 = first_u_range(c), rv1 = first_v_range(c);
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     const int uv[2] = {CSI_F_U, CSI_F_V};

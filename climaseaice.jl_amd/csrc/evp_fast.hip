@@ -220,6 +220,122 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
     store_with_images(P.v, P.g, img, i, j, res);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Orthogonal curvilinear grids (CSI_METRIC_FULL): the same three phases with per-POINT stencil coefficients
+// (csi_fast_coef.h, C2_*: the reference's operators with the metric of every location and index folded on the host).
+// The arithmetic after the strain rates / divergences is that of the regular-grid kernels (evp_fast_math.h).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double c2(const FastCoef& c, int w, int i, int j) { return c.c2[(long)w * c.c2_plane + i + (long)j * c.c2_ld]; }
+
+__device__ __forceinline__ void strain_cell2(const FastCoef& c, int i, int j, double u_e, double u_w, double v_n, double v_s, double& e11, double& e22) {
+    e11 = fm::fma_(c2(c, C2_E11E, i, j), u_e, fm::fma_(c2(c, C2_E11N, i, j), v_n, -fm::fma_(c2(c, C2_E11W, i, j), u_w, c2(c, C2_E11S, i, j) * v_s)));
+    e22 = fm::fma_(c2(c, C2_E22E, i, j), u_e, fm::fma_(c2(c, C2_E22N, i, j), v_n, -fm::fma_(c2(c, C2_E22W, i, j), u_w, c2(c, C2_E22S, i, j) * v_s)));
+}
+__device__ __forceinline__ double strain_corner2(const FastCoef& c, int i, int j, double u_n, double u_s, double v_e, double v_w) {
+    return fm::fma_(c2(c, C2_SUN, i, j), u_n, fm::fma_(c2(c, C2_SVE, i, j), v_e, -fm::fma_(c2(c, C2_SUS, i, j), u_s, c2(c, C2_SVW, i, j) * v_w)));
+}
+
+__global__ void __launch_bounds__(256) k_stress2(EvpDev P, Range r, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
+    const double u_mm = P.u(i - 1, j - 1), u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1);
+    const double u_m0 = P.u(i - 1, j),     u_00 = P.u(i, j),     u_p0 = P.u(i + 1, j);
+    const double                           u_0p = P.u(i, j + 1), u_pp = P.u(i + 1, j + 1);
+    const double v_mm = P.v(i - 1, j - 1), v_0m = P.v(i, j - 1);
+    const double v_m0 = P.v(i - 1, j),     v_00 = P.v(i, j),     v_p0 = P.v(i + 1, j);
+    const double v_mp = P.v(i - 1, j + 1), v_0p = P.v(i, j + 1), v_pp = P.v(i + 1, j + 1);
+    const double P_mm = P.P(i - 1, j - 1), P_0m = P.P(i, j - 1), P_m0 = P.P(i - 1, j), P_00 = P.P(i, j);
+    const double h_mm = P.h(i - 1, j - 1), h_0m = P.h(i, j - 1), h_m0 = P.h(i - 1, j), h_00 = P.h(i, j);
+    const double a_mm = P.a(i - 1, j - 1), a_0m = P.a(i, j - 1), a_m0 = P.a(i - 1, j), a_00 = P.a(i, j);
+    const double s11 = P.s11(i, j), s22 = P.s22(i, j), s12 = P.s12(i, j);
+    double e11_00, e22_00, e11_m0, e22_m0, e11_0m, e22_0m, e11_mm, e22_mm;
+    strain_cell2(c, i, j, u_p0, u_00, v_0p, v_00, e11_00, e22_00);
+    strain_cell2(c, i - 1, j, u_00, u_m0, v_mp, v_m0, e11_m0, e22_m0);
+    strain_cell2(c, i, j - 1, u_pm, u_0m, v_00, v_0m, e11_0m, e22_0m);
+    strain_cell2(c, i - 1, j - 1, u_0m, u_mm, v_m0, v_mm, e11_mm, e22_mm);
+    const double e12_00 = strain_corner2(c, i, j, u_00, u_0m, v_00, v_m0);
+    const double e12_p0 = strain_corner2(c, i + 1, j, u_p0, u_pm, v_p0, v_00);
+    const double e12_0p = strain_corner2(c, i, j + 1, u_0p, u_00, v_0p, v_mp);
+    const double e12_pp = strain_corner2(c, i + 1, j + 1, u_pp, u_p0, v_pp, v_0p);
+    const double e11f = fm::avg4(e11_mm, e11_0m, e11_m0, e11_00);
+    const double e22f = fm::avg4(e22_mm, e22_0m, e22_m0, e22_00);
+    const double e12c = fm::avg4(e12_00, e12_p0, e12_0p, e12_pp);
+    const double Pf = fm::avg4(P_mm, P_0m, P_m0, P_00);
+    const double m_00 = h_00 * P.rho * a_00, m_m0 = h_m0 * P.rho * a_m0, m_0m = h_0m * P.rho * a_0m, m_mm = h_mm * P.rho * a_mm;
+    const double mf = fm::avg4(m_mm, m_0m, m_m0, m_00);
+    const double kc = c.ca_dt * c2(c, C2_RAZC, i, j), kf = c.ca_dt * c2(c, C2_RAZF, i, j);
+    const fm::StressOut o = fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
+                                              m_00, mf, kc, kf, s11, s22, s12);
+    P.s11(i, j) = o.s11;
+    P.s22(i, j) = o.s22;
+    P.s12(i, j) = o.s12;
+    P.al(i, j) = o.alpha;
+    if (P.write_diag) {
+        P.zf(i, j) = 0.5 * o.zf2;
+        P.zc(i, j) = 0.5 * o.zc2;
+        P.Dl(i, j) = o.xc * o.rDc;
+    }
+}
+
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
+    const double h0 = P.h(i, j), hm = P.h(i - 1, j), a0 = P.a(i, j), am = P.a(i - 1, j);
+    const double al0 = P.al(i, j), alm = P.al(i - 1, j);
+    const double u = P.u(i, j), un = P.un(i, j);
+    const double v_m0 = P.v(i - 1, j), v_00 = P.v(i, j), v_mp = P.v(i - 1, j + 1), v_0p = P.v(i, j + 1);
+    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s22_0 = P.s22(i, j), s22_m = P.s22(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
+    if (MASK) {
+        if (immersed_peripheral_cc(P.g, i, j)) { s11_0 = 0.0; s22_0 = 0.0; }
+        if (immersed_peripheral_cc(P.g, i - 1, j)) { s11_m = 0.0; s22_m = 0.0; }
+        if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
+        if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
+    }
+    const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
+    const double east = fm::fma_(c2(c, C2_A11E, i, j), s11_0, fm::fma_(c2(c, C2_A22E, i, j), s22_0, c2(c, C2_A12N, i, j) * s12_p));
+    const double west = fm::fma_(c2(c, C2_A11W, i, j), s11_m, fm::fma_(c2(c, C2_A22W, i, j), s22_m, c2(c, C2_A12S, i, j) * s12_0));
+    const double div = east - west;
+    double ext, imt, exb, imb;
+    stress_x(P.top, i, j, u, vbar, ext, imt);
+    stress_x(P.bot, i, j, u, vbar, exb, imb);
+    const double cor = (P.fcor_u ? P.fcor_u[j] : P.fcor) * vbar;
+    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
+    const double res = P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
+        : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j));
+    store_with_images(P.u, P.g, img, i, j, res);
+}
+
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
+    const double h0 = P.h(i, j), hm = P.h(i, j - 1), a0 = P.a(i, j), am = P.a(i, j - 1);
+    const double al0 = P.al(i, j), alm = P.al(i, j - 1);
+    const double v = P.v(i, j), vn = P.vn(i, j);
+    const double u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1), u_00 = P.u(i, j), u_p0 = P.u(i + 1, j);
+    double s11_0 = P.s11(i, j), s11_m = P.s11(i, j - 1), s22_0 = P.s22(i, j), s22_m = P.s22(i, j - 1);
+    double s12_0 = P.s12(i, j), s12_p = P.s12(i + 1, j);
+    if (MASK) {
+        if (immersed_peripheral_cc(P.g, i, j)) { s11_0 = 0.0; s22_0 = 0.0; }
+        if (immersed_peripheral_cc(P.g, i, j - 1)) { s11_m = 0.0; s22_m = 0.0; }
+        if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
+        if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
+    }
+    const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
+    const double north = fm::fma_(c2(c, C2_B11N, i, j), s11_0, fm::fma_(c2(c, C2_B22N, i, j), s22_0, c2(c, C2_B12E, i, j) * s12_p));
+    const double south = fm::fma_(c2(c, C2_B11S, i, j), s11_m, fm::fma_(c2(c, C2_B22S, i, j), s22_m, c2(c, C2_B12W, i, j) * s12_0));
+    const double div = north - south;
+    double ext, imt, exb, imb;
+    stress_y(P.top, i, j, v, ubar, ext, imt);
+    stress_y(P.bot, i, j, v, ubar, exb, imb);
+    const double cor = -(P.fcor_v ? P.fcor_v[j] : P.fcor) * ubar;
+    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
+    const double res = P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))
+        : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j));
+    store_with_images(P.v, P.g, img, i, j, res);
+}
+
 }  // namespace fast
 
 static inline dim3 grid_for(const Range& r, dim3 b) {
@@ -270,6 +386,7 @@ static fast::TileMap tile_map(const EvpDev& P, const Range& r, dim3& grid) {
 void launch_fast_stress(const EvpDev& P, const Range& r, const FastCoef& c, hipStream_t s) {
     dim3 b(fast::TILE_X, fast::TILE_Y), g;
     const fast::TileMap tm = tile_map(P, r, g);
+    if (c.full) { hipLaunchKernelGGL(fast::k_stress2, g, b, 0, s, P, r, c, tm); return; }
     if (c.uniform) hipLaunchKernelGGL(fast::k_stress<true>, g, b, 0, s, P, r, c, tm);
     else hipLaunchKernelGGL(fast::k_stress<false>, g, b, 0, s, P, r, c, tm);
 }
@@ -277,6 +394,11 @@ void launch_fast_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, con
     dim3 b(fast::TILE_X, fast::TILE_Y), g;
     const fast::TileMap tm = tile_map(P, r, g);
     const bool m = P.g.has_mask != 0;
+    if (c.full) {
+        if (m) hipLaunchKernelGGL((fast::k_ustep2<true>), g, b, 0, s, P, r, im, c, tm);
+        else hipLaunchKernelGGL((fast::k_ustep2<false>), g, b, 0, s, P, r, im, c, tm);
+        return;
+    }
     if (c.uniform) {
         if (m) hipLaunchKernelGGL((fast::k_ustep<true, true>), g, b, 0, s, P, r, im, c, tm);
         else hipLaunchKernelGGL((fast::k_ustep<true, false>), g, b, 0, s, P, r, im, c, tm);
@@ -289,6 +411,11 @@ void launch_fast_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, con
     dim3 b(fast::TILE_X, fast::TILE_Y), g;
     const fast::TileMap tm = tile_map(P, r, g);
     const bool m = P.g.has_mask != 0;
+    if (c.full) {
+        if (m) hipLaunchKernelGGL((fast::k_vstep2<true>), g, b, 0, s, P, r, im, c, tm);
+        else hipLaunchKernelGGL((fast::k_vstep2<false>), g, b, 0, s, P, r, im, c, tm);
+        return;
+    }
     if (c.uniform) {
         if (m) hipLaunchKernelGGL((fast::k_vstep<true, true>), g, b, 0, s, P, r, im, c, tm);
         else hipLaunchKernelGGL((fast::k_vstep<true, false>), g, b, 0, s, P, r, im, c, tm);

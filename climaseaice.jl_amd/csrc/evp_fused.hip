@@ -289,6 +289,7 @@ static unsigned long parent_addr(const FRef& f, const GridDev& g) {
 // Array-valued forcing the two-sub-steps-per-launch kernel takes (FORCE variant): top stress given as arrays
 // (kind 2) and / or a bottom SemiImplicitStress whose ocean velocities are arrays -- the coupled-model case.
 int pair_forcing_kind(const EvpDev& P) {
+    if (P.g.metric_kind == 2) return -1;
     const int lc = P.h.ld, lf = P.u.ld;
     if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return -1;
     if (P.un.ld != lf || P.s12.ld != lf) return -1;
@@ -321,7 +322,7 @@ bool fused_supported(const EvpDev& P) {
     if (P.un.ld != lf || P.s12.ld != lf) return false;
     // first version: no immersed mask, forcing given by numbers (the benchmark configuration); everything else
     // runs the three-kernel FAST path
-    if (P.g.has_mask || P.free_drift) return false;
+    if (P.g.has_mask || P.free_drift || P.g.metric_kind == 2) return false;   // (full 2-D metrics: three-kernel path)
     // per-row metrics with a periodic y side: ring rows beyond the seam would not reproduce their owners
     if (P.g.metric_kind != 0 && (P.g.ylo == SIDE_PERIODIC || P.g.yhi == SIDE_PERIODIC)) return false;
     auto ok = [](const StressDev& s) {

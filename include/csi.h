@@ -58,9 +58,9 @@ typedef enum {
     CSI_METRIC_UNIFORM = 0,   /* RectilinearGrid, regular spacing */
     CSI_METRIC_PER_J = 1,     /* LatitudeLongitudeGrid, regular: metrics vary with j only */
     CSI_METRIC_FULL = 2       /* orthogonal curvilinear grid (OrthogonalSphericalShellGrid and the like): 2-D metric arrays.
-                               * Every operator takes them (same calls as the reference's Oceananigans.Operators); the
-                               * kernels are the reference-order (STRICT) ones in both modes: the FAST kernels fold the
-                               * metrics into per-row coefficients, which a general grid does not have. */
+                               * Every operator takes them (same calls as the reference's Oceananigans.Operators).  FAST
+                               * mode folds them into per-POINT stencil coefficients and runs the three-kernel path (the
+                               * fused kernels rely on coefficients that depend on the row alone). */
 } csi_metric_kind;
 
 /* Host-side description of the grid metrics (copied by csi_grid_set).  PER_J vectors have

@@ -139,7 +139,8 @@ def test_tracer_tendencies_next_to_immersed_cells_bitwise(topo, scheme, oracle_l
 def test_curvilinear_grid_full_step_bitwise(stepper, name, oracle_lib):
     """Orthogonal curvilinear grid (twelve distorted 2-D metric arrays, CSI_METRIC_FULL): tracer tendencies and whole
     time steps (WENO7 + EVP sub-cycle + tracer update) equal the oracle -- tendencies bit for bit, the step to the
-    rounding of exp() in the ice strength; FAST mode runs the same reference-order kernels (three-kernel path)."""
+    rounding of exp() in the ice strength (STRICT) / to the FAST tolerance (per-point stencil coefficients,
+    three-kernel path)."""
     kw = dict(periodic=dict(Nx=80, Ny=36, topo=("periodic", "periodic"), patches=True, random_uv=0.03, curvilinear=0.05),
               latlon_channel_masked=dict(Nx=70, Ny=40, topo=("periodic", "bounded"), grid="latlon", patches=True, random_uv=0.03,
                                          curvilinear=0.04, land=0.2))[name]
@@ -164,13 +165,13 @@ def test_curvilinear_grid_full_step_bitwise(stepper, name, oracle_lib):
         m.synchronize()
         assert m.ctx.last_path()["level"] == 0
         vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+        tol = 1e-12 if mode == "strict" else 1e-11
         for k, f in (("u", m.velocities.u), ("v", m.velocities.v)):
-            assert np.abs(f.numpy() - p.f[k]).max() <= 1e-12 * vmax, (mode, k)
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * vmax, (mode, k, np.abs(f.numpy() - p.f[k]).max() / vmax)
         for k, f in (("h", m.ice_thickness), ("aice", m.ice_concentration)):
-            assert np.abs(f.numpy() - p.f[k]).max() <= 1e-12 * np.abs(p.f[k]).max(), (mode, k)
+            assert np.abs(f.numpy() - p.f[k]).max() <= tol * np.abs(p.f[k]).max(), (mode, k)
         out[mode] = {k: f.numpy().copy() for k, f in (("u", m.velocities.u), ("h", m.ice_thickness))}
-    for k in out["strict"]:
-        assert np.array_equal(out["strict"][k], out["fast"][k]), k
+    assert not np.array_equal(out["strict"]["u"], out["fast"]["u"])       # FAST really ran its own kernels
 
 
 @pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
