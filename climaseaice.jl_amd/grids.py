@@ -217,8 +217,12 @@ class OrthogonalCurvilinearGrid(_Grid2D):
             out["dy" + l] = dy * ones
         if distort:
             # smooth, location-dependent stretching (periodic in both directions so that Periodic halos stay images)
-            ii = (np.arange(ni) - (g.Hx - 1))[None, :] / g.Nx
-            jj = (np.arange(n) - (g.Hy - 1))[:, None] / g.Ny
+            ia, ja = np.arange(ni) - (g.Hx - 1), np.arange(n) - (g.Hy - 1)          # the index i, j of every entry
+            if g.topology[0] is Periodic:
+                ia = (ia - 1) % g.Nx + 1                                            # halo entries are exact images
+            if g.topology[1] is Periodic:
+                ja = (ja - 1) % g.Ny + 1
+            ii, jj = ia[None, :] / g.Nx, ja[:, None] / g.Ny
             rng = np.random.default_rng(seed)
             for k, name in enumerate(METRIC_NAMES):
                 ph = rng.random(2) * 2 * np.pi

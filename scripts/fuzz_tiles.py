@@ -19,6 +19,8 @@ for seed in range(80):
         kw["beta"] = 2e-10
     if "bounded" in topo and rng.integers(3) == 0:
         kw["noslip"] = True
+    if rng.integers(5) == 0:
+        kw["curvilinear"] = 0.04
     nsub = int(rng.integers(2, 14))
     try:
         c = cases.make_case(substeps=nsub, **kw)
