@@ -80,6 +80,8 @@ PARTITIONS = [
     # BetaPlane: each tile evaluates f = f0 + beta * y on its own rows (halo rows: the neighbour's / the wrapped row's)
     ("y2_beta_bounded", 1, 2, dict(Nx=40, Ny=48, topo=("bounded", "bounded"), beta=2e-10)),
     ("y2_beta_periodic", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"), beta=2e-10)),
+    # orthogonal curvilinear grid: each tile gets its slice of the twelve 2-D metric arrays
+    ("x2_curvilinear", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "bounded"), curvilinear=0.04)),
 ]
 
 
