@@ -864,6 +864,20 @@ int32_t do_tendencies(csi_context* c, int scheme) {
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
+// advection = nothing: zero tendencies (horizontal_div_Uc(..., ::Nothing, ...) = zero(grid), sea_ice_advection.jl:50); the
+// tracer update still runs -- dynamic_time_step! launches unconditionally -- and resets h, aice [, hs] to Psi^- at every
+// RK stage (what makes the stage-wise thermodynamic steps of an RK3 step non-cumulative)
+int32_t do_tendencies_or_zero(csi_context* c, int scheme) {
+    if (scheme) return do_tendencies(c, scheme);
+    int32_t rc;
+    if ((rc = need(c, {CSI_F_GH, CSI_F_GA}))) return rc;
+    for (int id : {CSI_F_GH, CSI_F_GA, CSI_F_GHS}) {
+        const Bound& b = c->f[id];
+        if (b.p) HIP_TRY(c, hipMemsetAsync(b.p, 0, (size_t)b.ld * (size_t)b.nj * sizeof(double), c->stream));
+    }
+    return CSI_OK;
+}
+int32_t do_tracer_step(csi_context* c, double dt, int from_cache);
 int32_t do_tracer_step(csi_context* c, double dt, int from_cache) {
     int32_t rc;
     if ((rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA}))) return rc;
@@ -1224,9 +1238,9 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
     int32_t rc = dynamics ? need_evp(c) : need(c, {CSI_F_H, CSI_F_A});
     if (rc) return rc;
     if (first_iteration && (rc = do_update_state(c))) return rc;          // sea_ice_fe_step.jl:16
-    if (scheme && (rc = do_tendencies(c, scheme))) return rc;             // :19
+    if ((rc = do_tendencies_or_zero(c, scheme))) return rc;               // :19
     if (dynamics && (rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
-    if (scheme && (rc = do_tracer_step(c, dt, 0))) return rc;             // :25
+    if ((rc = do_tracer_step(c, dt, 0))) return rc;                       // :25
     if ((rc = do_thermo(c, dt))) return rc;                               // :28 thermodynamic_time_step!
     return do_update_state(c);                                            // :31
 }
@@ -1240,9 +1254,9 @@ int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t s
     if ((rc = csi_cache_current_fields(c))) return rc;                    // sea_ice_rk_substep.jl:29-42
     for (int beta = 3; beta >= 1; --beta) {                               // upstream stage loop
         const double dtau = dt / beta;
-        if (scheme && (rc = do_tendencies(c, scheme))) return rc;         // :84
+        if ((rc = do_tendencies_or_zero(c, scheme))) return rc;           // :84
         if (dynamics && (rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
-        if (scheme && (rc = do_tracer_step(c, dtau, 1))) return rc;       // :89
+        if ((rc = do_tracer_step(c, dtau, 1))) return rc;                 // :89
         if ((rc = do_thermo(c, dtau))) return rc;                         // :91 thermodynamic_time_step!
         if ((rc = do_update_state(c))) return rc;
     }

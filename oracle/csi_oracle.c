@@ -743,6 +743,18 @@ static double tendency_of(const ora_problem* g, int scheme, ora_field c, int i, 
     double fy = ora_weno_flux_y(g, scheme, c, i, j + 1) - ora_weno_flux_y(g, scheme, c, i, j);
     return -(1 / V * (fx + fy));
 }
+static void zero_field(const ora_problem* g, ora_field f) {
+    if (!f.p) return;
+    for (int j = 1; j <= g->Ny; ++j) for (int i = 1; i <= g->Nx; ++i) AT(g, f, i, j) = 0.0;
+}
+/* advection = nothing: horizontal_div_Uc(..., ::Nothing, ...) = zero(grid) (sea_ice_advection.jl:50), so the tendencies
+ * are zero -- and the tracer update still runs (dynamic_time_step! launches unconditionally): it resets h, aice [, hs]
+ * to Psi^- at every RK stage and applies the clipping / ridging rules */
+static void tendencies_or_zero(ora_problem* g, int scheme) {
+    if (scheme) { ora_compute_tracer_tendencies(g, scheme); return; }
+    zero_field(g, g->Gh); zero_field(g, g->Ga);
+    if (g->has_snow) zero_field(g, g->Ghs);
+}
 void ora_compute_tracer_tendencies(ora_problem* g, int scheme) {
     OMP_ROWS
     for (int j = 1; j <= g->Ny; ++j)
@@ -799,9 +811,9 @@ void ora_update_state(ora_problem* g) {
 /* time_step!(::FESeaIceModel), sea_ice_fe_step.jl:13-34 (no thermodynamics) */
 void ora_time_step_fe(ora_problem* g, double dt, int scheme, int first_iteration) {
     if (first_iteration) ora_update_state(g);          /* :16 */
-    if (scheme) ora_compute_tracer_tendencies(g, scheme);  /* :19 */
+    tendencies_or_zero(g, scheme);  /* :19 */
     ora_time_step_momentum(g, dt, 0);                  /* :22 */
-    if (scheme) ora_dynamic_step_tracers(g, dt, 0);    /* :25 */
+    ora_dynamic_step_tracers(g, dt, 0);    /* :25 */
     ora_update_state(g);                               /* :31 */
 }
 /* SplitRungeKutta3: cache_current_fields! (sea_ice_rk_substep.jl:29-42), then for beta in (3,2,1):
@@ -813,9 +825,9 @@ void ora_time_step_rk3(ora_problem* g, double dt, int scheme) {
     copy_parent(g, g->vm, g->v);
     for (int beta = 3; beta >= 1; --beta) {
         double dtau = dt / beta;
-        if (scheme) ora_compute_tracer_tendencies(g, scheme);   /* :84 */
+        tendencies_or_zero(g, scheme);   /* :84 */
         ora_time_step_momentum(g, dtau, 1);                     /* :87 */
-        if (scheme) ora_dynamic_step_tracers(g, dtau, 1);       /* :89 */
+        ora_dynamic_step_tracers(g, dtau, 1);       /* :89 */
         ora_update_state(g);
     }
 }
@@ -992,18 +1004,18 @@ void ora_slab_step_fields(ora_problem* g, const ora_slab* s, double dt) {
 /* whole steps with the thermodynamic step in its place (sea_ice_fe_step.jl:28, sea_ice_rk_substep.jl:91) */
 void ora_time_step_fe_thermo(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s) {
     if (first_iteration) ora_update_state(g);
-    if (scheme) ora_compute_tracer_tendencies(g, scheme);
+    tendencies_or_zero(g, scheme);
     ora_time_step_momentum(g, dt, 0);
-    if (scheme) ora_dynamic_step_tracers(g, dt, 0);
+    ora_dynamic_step_tracers(g, dt, 0);
     if (s) ora_slab_step_fields(g, s, dt);
     ora_update_state(g);
 }
 /* the same with a snow layer: hs is a third advected tracer and joins the Psi^- cache (sea_ice_rk_substep.jl:29-42) */
 void ora_time_step_fe_snow(ora_problem* g, double dt, int scheme, int first_iteration, const ora_slab* s, const ora_snow* w) {
     if (first_iteration) ora_update_state(g);
-    if (scheme) ora_compute_tracer_tendencies(g, scheme);
+    tendencies_or_zero(g, scheme);
     ora_time_step_momentum(g, dt, 0);
-    if (scheme) ora_dynamic_step_tracers(g, dt, 0);
+    ora_dynamic_step_tracers(g, dt, 0);
     ora_layered_step_fields(g, s, w, dt);
     ora_update_state(g);
 }
@@ -1015,9 +1027,9 @@ void ora_time_step_rk3_snow(ora_problem* g, double dt, int scheme, const ora_sla
     copy_parent(g, g->vm, g->v);
     for (int beta = 3; beta >= 1; --beta) {
         double dtau = dt / beta;
-        if (scheme) ora_compute_tracer_tendencies(g, scheme);
+        tendencies_or_zero(g, scheme);
         ora_time_step_momentum(g, dtau, 1);
-        if (scheme) ora_dynamic_step_tracers(g, dtau, 1);
+        ora_dynamic_step_tracers(g, dtau, 1);
         ora_layered_step_fields(g, s, w, dtau);
         ora_update_state(g);
     }
@@ -1029,9 +1041,9 @@ void ora_time_step_rk3_thermo(ora_problem* g, double dt, int scheme, const ora_s
     copy_parent(g, g->vm, g->v);
     for (int beta = 3; beta >= 1; --beta) {
         double dtau = dt / beta;
-        if (scheme) ora_compute_tracer_tendencies(g, scheme);
+        tendencies_or_zero(g, scheme);
         ora_time_step_momentum(g, dtau, 1);
-        if (scheme) ora_dynamic_step_tracers(g, dtau, 1);
+        ora_dynamic_step_tracers(g, dtau, 1);
         if (s) ora_slab_step_fields(g, s, dtau);
         ora_update_state(g);
     }

@@ -441,6 +441,27 @@ def test_full_time_step_on_a_tile_equals_untiled(stepper, snow):
     assert np.abs(out[True]["h"] - c["h"]).max() > 1e-5
 
 
+@pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
+def test_dynamics_and_thermodynamics_without_advection(stepper, oracle_lib):
+    """advection = nothing (the default of SeaIceModel) with dynamics and slab thermodynamics: zero tendencies, the
+    tracer update still resets h, aice to Psi^- at every RK stage (so the stage-wise thermodynamic steps do not add up)."""
+    c = cases.make_case(Nx=40, Ny=32, substeps=8, topo=("periodic", "bounded"), patches=True, random_uv=0.02)
+    slab_o = O.make_slab(Tu=-5.0, top_flux_kind=0, Qu=100.0, Qb=10.0)
+    p = cases.oracle_problem(c)
+    m = cases.csi_model(c, mode="strict", timestepper=stepper, advection=None,
+                        ice_thermodynamics=csi.SlabThermodynamics(top_temperature=-5.0, top_heat_flux=100.0, bottom_heat_flux=10.0))
+    h0 = p.interior("h").copy()
+    for n in range(2):
+        if stepper == "ForwardEuler":
+            p.time_step_fe(c["dt"], 0, n == 0, slab=slab_o)
+        else:
+            p.time_step_rk3(c["dt"], 0, slab=slab_o)
+        csi.time_step(m, c["dt"])
+    m.synchronize()
+    assert np.array_equal(m.ice_thickness.numpy(), p.f["h"]) and np.array_equal(m.ice_concentration.numpy(), p.f["aice"])
+    assert np.abs(p.interior("h") - h0).max() > 1e-6
+
+
 def test_config4_style_latlon_evp_plus_slab_thermodynamics(oracle_lib):
     """BASELINE config 4 in miniature: lat-lon (lon 0..60, lat 20..70) channel, EVP + WENO7 (order reduced next to
     the walls) + bare-ice slab thermodynamics (top 100 W m^-2, bottom 10 W m^-2, test/test_thermodynamic_mass_fluxes.jl:56), RK3, 2 steps."""

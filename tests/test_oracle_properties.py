@@ -432,3 +432,18 @@ def test_no_slip_value_boundary_condition(oracle_lib):
         out[noslip] = {k: p.interior(k).copy() for k in ("u", "s12")}
     assert np.abs(out[True]["s12"][0, :]).max() > 10 * np.abs(out[False]["s12"][0, :]).max()     # wall corners, j = 1
     assert np.abs(out[True]["u"][0, :]).mean() < np.abs(out[False]["u"][0, :]).mean()            # first row slowed down
+
+
+def test_rk3_stages_without_advection_reset_the_tracers(oracle_lib):
+    """advection = nothing with SplitRungeKutta3: the tendencies are zero (sea_ice_advection.jl:50) but the tracer update
+    still runs at every stage (dynamic_time_step!, sea_ice_rk_substep.jl:134-152) and resets h, aice to Psi^-; the
+    stage-wise thermodynamic steps (dt / 3, dt / 2, dt) are therefore not cumulative: after the step h, aice are the
+    ONE slab step of length dt applied to the state at the start of the step."""
+    c = cases.make_case(Nx=20, Ny=16, substeps=4, topo=("periodic", "periodic"), patches=True, random_uv=0.02)
+    slab = O.make_slab(Tu=-5.0, top_flux_kind=0, Qu=100.0, Qb=10.0)
+    p = cases.oracle_problem(c)
+    h0, a0 = p.interior("h").copy(), p.interior("aice").copy()
+    p.time_step_rk3(c["dt"], 0, slab=slab)
+    h1, a1, _ = O.slab_step(h0.ravel(), a0.ravel(), c["dt"], Tu=-5.0, top_flux_kind=0, Qu=100.0, Qb=10.0)
+    assert np.array_equal(p.interior("h").ravel(), h1) and np.array_equal(p.interior("aice").ravel(), a1)
+    assert np.abs(h1 - h0.ravel()).max() > 1e-6
