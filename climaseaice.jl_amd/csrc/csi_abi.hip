@@ -832,6 +832,8 @@ int32_t do_update_state(csi_context* c) {
     launch_mask_center(ref_of(c, CSI_F_H), c->g, c->stream);
     launch_mask_center(ref_of(c, CSI_F_A), c->g, c->stream);
     if (snow) launch_mask_center(ref_of(c, CSI_F_HS), c->g, c->stream);
+    for (int id : {CSI_F_MASS_FLUX, CSI_F_MASS_FLUX_SNOW, CSI_F_SNOWFALL_INTERCEPTED})       // sea_ice_model.jl:387-390
+        if (c->f[id].p) launch_mask_center(ref_of(c, id), c->g, c->stream);
     if (vel) {
         launch_mask_u(ref_of(c, CSI_F_U), c->g, c->stream);
         launch_mask_v(ref_of(c, CSI_F_V), c->g, c->stream);

@@ -405,6 +405,10 @@ def test_full_time_step_with_snow_vs_oracle(stepper, oracle_lib):
             assert np.abs(f.numpy() - p.f[k]).max() <= tol * np.abs(p.f[k]).max(), (mode, k, np.abs(f.numpy() - p.f[k]).max())
             assert np.array_equal(f.numpy() == 0.0, p.f[k] == 0.0), (mode, k, "zero set")
         assert np.abs(p.interior("hs") - hs0).max() > 1e-4            # the snow did something
+        # update_state! masks the mass-flux diagnostics on land too (sea_ice_model.jl:387-390)
+        land = ~c["mask"].astype(bool)
+        for f in (m.mass_fluxes.thermodynamics.ice, m.mass_fluxes.thermodynamics.snow, m.mass_fluxes.intercepted_snowfall):
+            assert np.all(f.interior_numpy()[land] == 0.0) and np.abs(f.interior_numpy()[~land]).max() > 0
 
 
 @pytest.mark.parametrize("snow", [False, True])
