@@ -158,7 +158,11 @@ typedef struct {
  * STRICT: the reference's operation order, no FMA contraction, IEEE division -- bit-for-bit
  *         equal to the CPU oracle (used to anchor parity).
  * FAST:   hoisted reciprocals / FMA contraction, shared strain rates; differs from STRICT
- *         by rounding only (tolerance stated in DESIGN.md and enforced in tests/). */
+ *         by rounding only (tolerance stated in DESIGN.md and enforced in tests/).  Requires
+ *         minimum_mass > 0 (the reference's default is 1 kg m^-2): the mi <= 0 guards of the velocity
+ *         tendencies are then implied by the active / marginal ice selection and are not evaluated
+ *         (CSI_ERR_UNSUPPORTED otherwise).  Advection, the tracer update and the thermodynamic steps are
+ *         computed in the reference's order in both modes. */
 typedef enum { CSI_MODE_STRICT = 0, CSI_MODE_FAST = 1 } csi_mode;
 
 typedef enum { CSI_ADVECT_NONE = 0, CSI_ADVECT_UPWIND1 = 1, CSI_ADVECT_WENO3 = 3, CSI_ADVECT_WENO5 = 5, CSI_ADVECT_WENO7 = 7,
