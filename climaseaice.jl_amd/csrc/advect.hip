@@ -209,14 +209,20 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
     ap = (hp == 0) ? 0.0 : ap;
     hp = (ap == 0) ? 0.0 : hp;
     const double Vp = hp * ap;
-    const double a1 = (ap > 1) ? 1.0 : ap;
-    A.a(i, j) = a1;
-    A.h(i, j) = (ap > 1) ? Vp : hp;
+    const double a1 = (ap > 1) ? 1.0 : ap, h1 = (ap > 1) ? Vp : hp;
+    if (A.fill_images) {             // update_state!'s halo fill of h, aice fused into the stores (csi_abi.hip)
+        store_with_images(A.a, A.g, A.im, i, j, a1);
+        store_with_images(A.h, A.g, A.im, i, j, h1);
+    } else {
+        A.a(i, j) = a1;
+        A.h(i, j) = h1;
+    }
     if (A.has_snow) {                // dynamic_step_snow!, sea_ice_fe_step.jl:86-94
         const double sn = A.from_cache ? A.hsm(i, j) : A.hs(i, j);
         double sp = sn + A.dt * A.Ghs(i, j);
         sp = jmax(0.0, sp);
-        A.hs(i, j) = (a1 <= 0) ? 0.0 : sp;
+        const double s1 = (a1 <= 0) ? 0.0 : sp;
+        if (A.fill_images) store_with_images(A.hs, A.g, A.im, i, j, s1); else A.hs(i, j) = s1;
     }
 }
 

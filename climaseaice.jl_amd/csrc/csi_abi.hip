@@ -821,14 +821,19 @@ AdvDev adv_dev(const csi_context* c, int scheme, double dt, int from_cache) {
     A.has_snow = c->f[CSI_F_HS].p != nullptr && c->f[CSI_F_GHS].p != nullptr;     // snow thickness: the third tracer
     if (A.has_snow) { A.hs = ref_of(c, CSI_F_HS); A.Ghs = ref_of(c, CSI_F_GHS); A.hsm = ref_of(c, CSI_F_HSM); }
     A.scheme = scheme; A.dt = dt; A.from_cache = from_cache;
+    A.fill_images = 0; A.im = image_spec(c, CSI_F_H);
     return A;
 }
 
-int32_t do_update_state(csi_context* c) {
+// in_step: called from csi_time_step_*.  tracers_filled: the tracer update of this stage already wrote the halo images of
+// h, aice [, hs] with its stores (no mask, no thermodynamic step after it).  Inside a step the velocities are prognostic
+// fields only with dynamics (sea_ice_model.jl:230,373-377): prescribed velocities keep the halos set! gave them.
+int32_t do_update_state(csi_context* c, bool in_step = false, bool tracers_filled = false) {
     int32_t rc;
     if ((rc = need(c, {CSI_F_H, CSI_F_A}))) return rc;
     // mask_immersed_field_xy! of every prognostic field, then their local halo fills in one batch (two launches)
-    const bool snow = c->f[CSI_F_HS].p != nullptr, vel = c->f[CSI_F_U].p && c->f[CSI_F_V].p;
+    const bool snow = c->f[CSI_F_HS].p != nullptr;
+    const bool vel = c->f[CSI_F_U].p && c->f[CSI_F_V].p && (!in_step || c->evp_set);
     launch_mask_center(ref_of(c, CSI_F_H), c->g, c->stream);
     launch_mask_center(ref_of(c, CSI_F_A), c->g, c->stream);
     if (snow) launch_mask_center(ref_of(c, CSI_F_HS), c->g, c->stream);
@@ -840,14 +845,16 @@ int32_t do_update_state(csi_context* c) {
     }
     HaloBatch B{};
     auto add = [&](int fid) { B.f[B.n] = ref_of(c, fid); B.im[B.n] = image_spec(c, fid); ++B.n; };
-    add(CSI_F_H); add(CSI_F_A);
-    if (snow) add(CSI_F_HS);
+    if (!tracers_filled) {
+        add(CSI_F_H); add(CSI_F_A);
+        if (snow) add(CSI_F_HS);
+    }
     if (vel) { add(CSI_F_U); add(CSI_F_V); }
     launch_fill_halo_batch(B, c->g, c->stream);
     HIP_TRY(c, hipGetLastError());
     if (is_tiled(c)) {                                      // the MPI part of fill_halo_regions!, sea_ice_model.jl:383
         int ff[5] = {CSI_F_H, CSI_F_A, CSI_F_U, CSI_F_V, CSI_F_HS};
-        int n = (c->f[CSI_F_U].p && c->f[CSI_F_V].p) ? 4 : 2;
+        int n = vel ? 4 : 2;
         if (snow) ff[n++] = CSI_F_HS;
         if ((rc = exchange(c, ff, n, c->Hx < c->Hy ? c->Hx : c->Hy))) return rc;
     }
@@ -879,13 +886,15 @@ int32_t do_tendencies_or_zero(csi_context* c, int scheme) {
     }
     return CSI_OK;
 }
-int32_t do_tracer_step(csi_context* c, double dt, int from_cache);
-int32_t do_tracer_step(csi_context* c, double dt, int from_cache) {
+// fill_images: the stores also write the local halo images (periodic wrap / no-flux mirror) of h, aice [, hs]
+int32_t do_tracer_step(csi_context* c, double dt, int from_cache, bool fill_images = false) {
     int32_t rc;
     if ((rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA}))) return rc;
     if (from_cache && (rc = need(c, {CSI_F_HM, CSI_F_AM}))) return rc;
     if (from_cache && c->f[CSI_F_HS].p && c->f[CSI_F_GHS].p && (rc = need(c, {CSI_F_HSM}))) return rc;
-    launch_tracer_step(adv_dev(c, 0, dt, from_cache), c->stream);
+    AdvDev A = adv_dev(c, 0, dt, from_cache);
+    A.fill_images = fill_images ? 1 : 0;
+    launch_tracer_step(A, c->stream);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
@@ -1242,9 +1251,11 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
     if (first_iteration && (rc = do_update_state(c))) return rc;          // sea_ice_fe_step.jl:16
     if ((rc = do_tendencies_or_zero(c, scheme))) return rc;               // :19
     if (dynamics && (rc = do_time_step_momentum(c, dt, substeps, 0))) return rc;      // :22
-    if ((rc = do_tracer_step(c, dt, 0))) return rc;                       // :25
+    // without a mask and without a thermodynamic step the tracer update's stores write the halo images themselves
+    const bool fused_fill = !c->g.has_mask && !c->slab_set;
+    if ((rc = do_tracer_step(c, dt, 0, fused_fill))) return rc;           // :25
     if ((rc = do_thermo(c, dt))) return rc;                               // :28 thermodynamic_time_step!
-    return do_update_state(c);                                            // :31
+    return do_update_state(c, true, fused_fill);                          // :31
 }
 
 int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t scheme) {
@@ -1258,9 +1269,10 @@ int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t s
         const double dtau = dt / beta;
         if ((rc = do_tendencies_or_zero(c, scheme))) return rc;           // :84
         if (dynamics && (rc = do_time_step_momentum(c, dtau, substeps, 1))) return rc;   // :87
-        if ((rc = do_tracer_step(c, dtau, 1))) return rc;                 // :89
+        const bool fused_fill = !c->g.has_mask && !c->slab_set;
+        if ((rc = do_tracer_step(c, dtau, 1, fused_fill))) return rc;     // :89
         if ((rc = do_thermo(c, dtau))) return rc;                         // :91 thermodynamic_time_step!
-        if ((rc = do_update_state(c))) return rc;
+        if ((rc = do_update_state(c, true, fused_fill))) return rc;
     }
     return CSI_OK;
 }

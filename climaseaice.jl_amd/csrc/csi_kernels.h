@@ -82,6 +82,8 @@ struct AdvDev {
     FRef u, v, h, a, Gh, Ga, hm, am;
     FRef hs, Ghs, hsm;      // snow thickness as a third tracer (has_snow)
     int has_snow;
+    int fill_images;        // tracer update: also store the local halo images (im) of h, aice [, hs]
+    ImageSpec im;
     int scheme;
     double dt;
     int from_cache;
