@@ -3,7 +3,8 @@ import sys, numpy as np, traceback
 sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
 import test_gpu_evp as T
 bad = 0
-for seed in range(24, 200):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 200)
+for seed in range(lo, hi):
     try:
         T.test_fused_paths_fuzz_bitwise(seed)
     except AssertionError as e:

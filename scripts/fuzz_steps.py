@@ -4,7 +4,8 @@ import sys, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
 import climaseaice_jl_amd as csi, cases
 bad = 0
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, int(sys.argv[1]) if len(sys.argv) > 1 else 40)
+for seed in range(lo, hi):
     rng = np.random.default_rng(9000 + seed)
     topo = (("periodic", "bounded")[rng.integers(2)], ("periodic", "bounded")[rng.integers(2)])
     H = int(rng.integers(4, 7))

@@ -4,7 +4,8 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle
 import climaseaice_jl_amd as csi, cases
 from test_gpu_evp import EVP_FIELDS
 bad = 0
-for seed in range(80):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 80)
+for seed in range(lo, hi):
     rng = np.random.default_rng(5000 + seed)
     H = int(rng.integers(4, 11))
     k = int(rng.integers(1, H // 2 + 1))
