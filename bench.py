@@ -8,7 +8,7 @@ inputs resident in HBM.  value = cell-updates/s = owned cells * substeps * steps
 N = 1: the 2048 x 2048 periodic f-plane grid the metric is quoted on.
 N > 1 (torch.distributed.run, one rank per GPU): the grid is an Rx x Ry arrangement of 2048 x 2048 tiles
 (weak scaling: per-GPU work fixed) advanced by the SAME kernels with the RCCL halo exchange of u, v, sigma
-(width 2k every k sub-steps; halo 16 -> k = 8); `--scaling strong` instead splits ONE 2048 x 2048 grid over the ranks.
+(width 2k every k sub-steps; halo 32 -> k = 16); `--scaling strong` instead splits ONE 2048 x 2048 grid over the ranks.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
-    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 16 on tiles so that k = 8)")
+    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 32 on tiles so that k = 16)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
     ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
                     help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
@@ -117,7 +117,7 @@ def main():
             raise SystemExit("--size must be divisible by the partition")
         nx_l, ny_l = args.size // Rx, args.size // Ry
     if args.halo == 0:
-        args.halo = 16 if (world > 1 or args.force_connected) else 4
+        args.halo = 32 if (world > 1 or args.force_connected) else 4
     device = f"cuda:{local_rank}"
     tg, f = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=args.halo)
     dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
@@ -206,7 +206,7 @@ def main():
                    "substeps": args.substeps, "mode": args.mode,
                    "halo": args.halo,
                    "halo_exchange": "none (one tile)" if (world == 1 and not args.force_connected)
-                   else f"RCCL send/recv, exchange interval k={args.exchange_interval or 'auto(min(halo/2,8))'}: width 2k every k sub-steps"},
+                   else f"RCCL send/recv, exchange interval k={args.exchange_interval or 'auto(min(halo/2,16))'}: width 2k every k sub-steps"},
         "model_days_per_hr": model_days_per_hr,
         "model_days_per_hr_config": "full RK3 time_step! (3 stages x [WENO7 advection of h, aice + sub-cycle + tracer update]), dt = 120 s",
         "subcycle_ms_hip_events": subcycle_ms,

@@ -448,7 +448,7 @@ int32_t ensure_alt(csi_context* c) {
 int exchange_interval(const csi_context* c) {
     if (!is_tiled(c)) return 1;
     const int hmin = c->Hx < c->Hy ? c->Hx : c->Hy, nmin = c->Nx < c->Ny ? c->Nx : c->Ny;
-    int k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 8 ? hmin / 2 : 8);   // automatic: as rare as the halo allows (<= 8)
+    int k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 16 ? hmin / 2 : 16);   // automatic: as rare as the halo allows (<= 16)
     while (k > 1 && (2 * k > hmin || 2 * k > nmin)) --k;
     return k < 1 ? 1 : k;
 }
@@ -567,7 +567,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     // tables: singles (position in the exchange batch) x (which buffer is current) x (u first / v first), then
     // pairs (pair position) x (buffer) x (first sub-step u first / v first)
-    constexpr int KMAX = 8, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4;
+    constexpr int KMAX = 16, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4;
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
     FusedGeom G[KMAX], GP[KMAX / 2];

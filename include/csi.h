@@ -318,7 +318,7 @@ int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
 /* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
- * k <= 8 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
+ * k <= 16 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
  * k = substeps extreme (halo 2*substeps+3, split_explicit_momentum_equations.jl:51-64). */
 int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 

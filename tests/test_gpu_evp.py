@@ -376,6 +376,25 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("periodic", "bounded")])
+def test_pair_kernel_on_tiles_halo32_interval16(topo):
+    """The widest batch: halo 32, automatic exchange interval 16 (eight pairs per batch, valid widths 32 .. 2);
+    40 sub-steps = 2 full batches + half a batch; with walls in y and an immersed mask too."""
+    c = cases.make_case(Nx=150, Ny=128, H=32, substeps=40, topo=topo, patches=True, random_uv=0.05,
+                        land=0.2 if topo[1] == "bounded" else 0.0)
+    ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
+    csi.time_step_momentum(ref, c["dt"])
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, topo[1] == "periodic")))
+    csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    path = til.ctx.last_path()
+    assert path["exchange_interval"] == 16 and path["level"] == 2 and path["exchanges"] == 3, path
+    for f in ("u", "v", "s11", "s22", "s12", "alpha"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+
+
 FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
