@@ -6,13 +6,17 @@ finalize_rheology!, SeaIceDynamics/split_explicit_momentum_equations.jl:103-195)
 inputs resident in HBM.  value = cell-updates/s = owned cells * substeps * steps / wall time, whole job.
 
 N = 1: the 2048 x 2048 periodic f-plane grid the metric is quoted on.
-N > 1 (torch.distributed.run, one rank per GPU): the grid is an Rx x Ry arrangement of 2048 x 2048 tiles
-(weak scaling: per-GPU work fixed) advanced by the SAME kernels with the RCCL halo exchange of u, v, sigma
-(width 2k every k sub-steps; halo 32 -> k = 16); `--scaling strong` instead splits ONE 2048 x 2048 grid over the ranks.
+N > 1 (torch.distributed.run, one rank per GPU): STRONG scaling by default -- the SAME 2048 x 2048 grid split into
+Rx x Ry tiles (2x1, 2x2, 2x4: 1024 x 512 per GPU at N = 8, BASELINE config 4's decomposition), advanced by the same
+kernels with the RCCL halo exchange of u, v, sigma (width 2k every k sub-steps; halo 16 -> k = 8; `--exchange-interval 1`
+is the north star's one exchange per sub-step and is timed as well, outside the headline region).  `--scaling weak`
+gives every GPU its own 2048 x 2048 tile instead.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -24,31 +28,55 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 ALGO_BYTES = {"stress": 96.0, "ustep": 80.0, "vstep": 80.0}   # SURVEY.md 8(d); 256 B per cell-update
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# Compulsory HBM bytes per cell PER LAUNCH of each kernel: what `roofline.frac` is priced on.
+#   k_pair / k_substep: read u, v, P, h, aice, sigma x 3, u^n, v^n + write sigma x 3, u, v = 15 x 8 B (k_pair does two
+#   sub-steps on them); three-kernel path: the per-phase figures of SURVEY.md 8(d).
+KERNEL_BYTES = {"pair": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
 PARTITION = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}
+KERNEL_NAMES = {"substep": "csi::fused::k_substep (stress + u + v in one launch)",
+                "pair": "csi::fused::k_pair (two sub-steps: 2 x [stress + u + v] in one launch)",
+                "stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The oracle (strict-order C restatement, OpenMP over rows) timed on the host cores of this box:
-    a reported baseline on a bounded sample of the same workload, never the target."""
+def cpu_baseline(seconds_budget=12.0):
+    """The oracle (strict-order C restatement of the reference's kernel split, oracle/csi_oracle.c, OpenMP over rows)
+    timed on this box's host cores: the EVP sub-step loop alone (ora_subcycle: viscosities, stresses, u / v steps, halo
+    fills -- no initialize_rheology!, no Python in the loop), one thread and all threads this process may use.  A
+    reported baseline on a bounded sample of the same workload; never the target, and no speed-up is derived from it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cases
-    n, sub = 2048, 2
-    c = cases.make_case(Nx=n, Ny=n, substeps=sub, topo=("periodic", "periodic"), patches=True, random_uv=0.02)
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    p = cases.oracle_problem(c, omp=True)
-    p.time_step_momentum(c["dt"])                       # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        p.time_step_momentum(c["dt"])
-        reps += 1
-        if time.perf_counter() - t0 > seconds_budget or reps >= 64:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n * n * sub * reps / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x time_step_momentum! of {n}x{n} periodic f-plane with {sub} sub-steps; "
-                      f"oracle/csi_oracle.c (reference kernel split, strict order) with OpenMP over rows, {cores} threads"}
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except OSError:
+        gomp = None
+
+    def run(n, sub, nt):
+        if gomp is not None:
+            gomp.omp_set_num_threads(nt)
+        c = cases.make_case(Nx=n, Ny=n, substeps=sub, topo=("periodic", "periodic"), patches=True, random_uv=0.02)
+        p = cases.oracle_problem(c, omp=True)
+        p.initialize_rheology()
+        p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
+        p.subcycle(c["dt"], 1, 2)                      # warm-up: thread team, page faults
+        t0 = time.perf_counter()
+        p.subcycle(c["dt"], 1, sub)
+        return n * n * sub / (time.perf_counter() - t0)
+
+    # one thread: ~1.3 M cell-updates/s on a 2 GHz core -> 512^2 x 12 sub-steps is ~2.5 s
+    v1 = run(512, 12, 1)
+    # all threads: size the sample from the one-thread rate, assuming it may scale perfectly
+    budget_updates = v1 * threads * seconds_budget
+    n = 2048
+    sub = int(max(2, min(120, budget_updates / (n * n))))
+    vall = run(n, sub, threads) if (gomp is not None and threads > 1) else v1
+    return {"value": vall, "unit": "cell-updates/s", "cores": threads if gomp is not None else 1, "kind": "port",
+            "one_thread_value": v1, "thread_scaling": vall / v1,
+            "sample": f"EVP sub-step loop only (ora_subcycle): {sub} sub-steps of the 2048x2048 periodic f-plane workload on "
+                      f"{threads} OpenMP threads (= os.sched_getaffinity); one-thread figure from 12 sub-steps of a 512x512 "
+                      f"grid of the same workload; oracle/csi_oracle.c: the reference's four-kernel split in strict IEEE "
+                      f"order (gcc -O2 -ffp-contract=off), strain rates recomputed per stencil point as the reference does -- "
+                      f"a lower bound on what a tuned CPU code would reach"}
 
 
 def local_case(csi, np, nx, ny, Rx, Ry, rank, force_connected=False, halo=4):
@@ -63,16 +91,32 @@ def local_case(csi, np, nx, ny, Rx, Ry, rank, force_connected=False, halo=4):
     xc = ((np.arange(nx) + rx * nx) + 0.5) / Nx
     yc = ((np.arange(ny) + ry * ny) + 0.5) / Ny
     X, Y = xc[None, :], yc[:, None]
-    h = (0.3 + 0.005 * (np.sin(2 * np.pi * 3 * Rx * X) + np.sin(2 * np.pi * 2 * Ry * Y))) * (1.0 + 0.05 * (rng.random((ny, nx)) - 0.5))
-    a = np.clip(0.6 + 0.6 * np.sin(2 * np.pi * Rx * X) * np.cos(2 * np.pi * Ry * Y) + 0.2 * rng.random((ny, nx)), 0.0, 1.0)
-    i0, i1, j0, j1 = nx // 8, nx // 4, ny // 6, ny // 3
-    a[j0:j1, i0:i1] = 0.0
-    h[j0:j1, i0:i1] = 0.0
-    a[j1:j1 + 2, i0:i1] = 5e-4
-    h[j1:j1 + 2, i0:i1] = 1e-3
+    h = (0.3 + 0.005 * (np.sin(2 * np.pi * 3 * X) + np.sin(2 * np.pi * 2 * Y))) * (1.0 + 0.05 * (rng.random((ny, nx)) - 0.5))
+    a = np.clip(0.6 + 0.6 * np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) + 0.2 * rng.random((ny, nx)), 0.0, 1.0)
+    # open water and marginal ice patches at fixed GLOBAL positions (every branch of the velocity kernels is exercised)
+    gi0, gi1, gj0, gj1 = Nx // 8, Nx // 4, Ny // 6, Ny // 3
+    I = (np.arange(nx) + rx * nx)[None, :] + 0 * np.arange(ny)[:, None]
+    J = (np.arange(ny) + ry * ny)[:, None] + 0 * np.arange(nx)[None, :]
+    water = (I >= gi0) & (I < gi1) & (J >= gj0) & (J < gj1)
+    thin = (I >= gi0) & (I < gi1) & (J >= gj1) & (J < gj1 + 2)
+    a[water] = 0.0; h[water] = 0.0
+    a[thin] = 5e-4; h[thin] = 1e-3
     u = 0.1 + 0.02 * rng.standard_normal((ny, nx))
     v = 0.02 * rng.standard_normal((ny, nx))
     return tg, dict(h=h, a=a, u=u, v=v)
+
+
+def counters():
+    """PMC evidence of the dominant kernel from the newest committed rocprofv3 counter passes (profiles/counters_latest.json,
+    written by scripts/pmc.sh + scripts/summarize_db.py): HBM bytes per launch, VALU instruction counts.  Static data of
+    an EARLIER run of the same kernel build -- labelled as such in the output, never mixed into `achieved`."""
+    f = os.path.join(ROOT, "profiles", "counters_latest.json")
+    if not os.path.exists(f):
+        return None
+    try:
+        return json.load(open(f))
+    except Exception:
+        return None
 
 
 def main():
@@ -80,14 +124,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=2048, help="tile edge (weak) or global edge (strong)")
+    ap.add_argument("--size", type=int, default=2048, help="global edge (strong) or tile edge (weak)")
+    ap.add_argument("--tile", type=str, default="", help="debug, one GPU: NXxNY tile instead of --size (e.g. 1024x512)")
     ap.add_argument("--substeps", type=int, default=120)
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
-    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 32 on tiles so that k = 16)")
+    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 16 on tiles so that k = 8)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
     ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
                     help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
@@ -110,14 +155,17 @@ def main():
     if world not in PARTITION:
         raise SystemExit(f"--gpus must be one of {sorted(PARTITION)}")
     Rx, Ry = PARTITION[world]
-    if args.scaling == "weak":
+    if args.tile:
+        nx_l, ny_l = (int(s) for s in args.tile.lower().split("x"))
+    elif args.scaling == "weak":
         nx_l = ny_l = args.size
     else:
         if args.size % Rx or args.size % Ry:
             raise SystemExit("--size must be divisible by the partition")
         nx_l, ny_l = args.size // Rx, args.size // Ry
+    tiled = world > 1 or args.force_connected
     if args.halo == 0:
-        args.halo = 32 if (world > 1 or args.force_connected) else 4
+        args.halo = 16 if tiled else 4
     device = f"cuda:{local_rank}"
     tg, f = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=args.halo)
     dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
@@ -135,51 +183,94 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(nsteps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            csi.time_step_momentum(model, dt)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
     for _ in range(args.warmup):
         csi.time_step_momentum(model, dt)
     barrier()
     # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
     # below is the last thing this process writes
-    import ctypes
     ctypes.CDLL(None).fflush(None)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        csi.time_step_momentum(model, dt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps)
 
     owned = nx_l * ny_l * world
     value = owned * args.substeps * args.steps / elapsed
     subcycle_ms = model.ctx.last_subcycle_ms()            # HIP events on the launch stream, last step
-
-    # ---- outside the timed region: per-kernel HIP-event times (roofline) and whole model steps ----
     path = model.ctx.last_path()
+
+    # ---- result check (outside the timed region): the state the timed steps produced is finite and non-trivial -------
+    model.synchronize()
+    chk = {}
+    for name, fld in (("u", model.velocities.u), ("v", model.velocities.v), ("s11", model.dynamics.auxiliaries.fields.s11)):
+        t = fld.data
+        chk[name] = {"finite": bool(torch.isfinite(t).all().item()), "max_abs": float(t.abs().max().item()),
+                     "nonzero_frac": float((t != 0).double().mean().item())}
+    ok = all(c["finite"] for c in chk.values()) and 0 < chk["u"]["max_abs"] < 10.0 and chk["u"]["nonzero_frac"] > 0.5 \
+        and chk["s11"]["max_abs"] > 0
+    if dist is not None:
+        t = torch.tensor([1.0 if ok else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() > 0.5)
+    if not ok:
+        raise SystemExit(f"bench.py: the timed steps left a non-finite or trivial state: {chk}")
+
+    # ---- outside the timed region: per-kernel HIP-event times (roofline) and whole model steps ------------------------
     phases = model.ctx.profile_substeps(dt, 32)
     cells_launch = nx_l * ny_l
     spl = 1.0                                             # sub-steps per launch of the dominant kernel
     if path["fused"]:
-        # one launch performs one whole sub-step (level 1) or two (level 2): its algorithmic bytes are the 256 B per
-        # cell-update of SURVEY.md 8(d) times the sub-steps it performs
         launches, nsub = model.ctx.last_launches()
         spl = nsub / max(launches, 1)
         dom = "pair" if path["level"] == 2 else "substep"
-        algo = 256.0 * spl
         phases = {dom: phases["stress"], "exchange": phases["exchange"]}
         sub_ms = phases[dom] / spl
     else:
         dom = max(("stress", "ustep", "vstep"), key=lambda k: phases[k])
-        algo = ALGO_BYTES[dom]
         sub_ms = phases["stress"] + phases["ustep"] + phases["vstep"]
-    achieved = cells_launch * algo / (phases[dom] * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tfile) and world == 1 and args.size == 2048 and args.mode == "fast":
-        tj = json.load(open(tfile))
-        traffic = tj.get("bytes_per_launch", {}).get(dom)   # PMC passes of profiles/ (FETCH_SIZE doubled, gfx950 rule)
+    launch_s = phases[dom] * 1e-3
+    # roofline.achieved: the kernel's compulsory HBM bytes per launch (owned cells; ring re-reads and the extra cells of a
+    # tile's valid-halo ring are overhead, not counted) / its average launch duration from HIP events on the launch stream
+    kernel_bytes = cells_launch * KERNEL_BYTES[dom]
+    achieved = kernel_bytes / launch_s / 1e9
+    # the SURVEY.md 8(d) figure: 256 B per cell-update of the unfused three-phase split, for comparison only (a fused kernel
+    # does not move these bytes, so this can exceed 1: it measures the traffic fusion removed, not a roofline)
+    algorithmic_rate = cells_launch * 256.0 * spl / launch_s / 1e9 if path["fused"] else cells_launch * ALGO_BYTES[dom] / launch_s / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": None,
+            "kernel": KERNEL_NAMES[dom] if args.mode == "fast" else dom,
+            "kernel_bytes_per_launch": kernel_bytes, "kernel_bytes_per_cell": KERNEL_BYTES[dom],
+            "avg_launch_ms": phases[dom], "substeps_per_launch": spl, "all_phases_ms": phases,
+            "algorithmic_bytes_per_launch": cells_launch * (256.0 * spl if path["fused"] else ALGO_BYTES[dom]),
+            "algorithmic_frac": algorithmic_rate / HBM_PEAK_GBS,
+            "algorithmic_note": "SURVEY.md 8(d): 256 B per cell-update of the unfused stress / u / v split; above 1 = traffic removed by fusion",
+            "substep_ms": sub_ms}
+    ctr = counters()
+    if ctr and world == 1 and not tiled and (nx_l, ny_l) == (2048, 2048) and args.mode == "fast" and ctr.get("kernel") == dom:
+        roof["traffic"] = ctr.get("hbm_bytes_per_launch")
+        roof["traffic_source"] = ctr.get("source", "profiles/counters_latest.json") + " (rocprofv3 --pmc passes of an earlier run of this kernel; not re-measured by bench.py)"
+        if ctr.get("hbm_bytes_per_launch"):
+            roof["traffic_frac"] = ctr["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBS
+        # second roof: FP64 vector issue.  valu_frac = share of the SIMDs' VALU issue time the launch used, from the
+        # same committed counter passes: SQ_ACTIVE_INST_VALU (quad-cycles, summed over SIMDs) x 4 / (1024 SIMDs x
+        # GRBM_GUI_ACTIVE / 8 XCDs); every wave64 VALU instruction, FP64 arithmetic or move, occupies its SIMD 4 cycles
+        if ctr.get("valu_busy_frac") is not None:
+            roof["valu_frac"] = ctr["valu_busy_frac"]
+            roof["valu_insts_per_launch"] = ctr.get("valu_insts_per_launch")
+            roof["valu_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed PMC pass; the kernel is "
+                                 "co-limited by VALU issue (DESIGN.md section 3)")
     model_days_per_hr = None
     if not args.no_full_step:
         nfull = 2
@@ -189,12 +280,19 @@ def main():
         for _ in range(nfull):
             csi.time_step(model, dt)                       # RK3: 3 x [WENO7 tendencies + sub-cycle + tracer update + halos]
         barrier()
-        full = (time.perf_counter() - t1) / nfull
-        if dist is not None:
-            t = torch.tensor([full], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            full = float(t.item())
+        full = max_over_ranks((time.perf_counter() - t1) / nfull)
         model_days_per_hr = 3600.0 / (full * 86400.0 / dt)
+
+    # ---- tiles: the north star's "exchange once per sub-step" (k = 1), timed outside the headline region ---------------
+    k1 = None
+    if tiled and path["exchange_interval"] != 1:
+        model.set_exchange_interval(1)
+        csi.time_step_momentum(model, dt)
+        e1 = timed(args.steps)
+        p1 = model.ctx.last_path()
+        k1 = {"value": owned * args.substeps * args.steps / e1, "ms_per_step": 1e3 * e1 / args.steps,
+              "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
+        model.set_exchange_interval(args.exchange_interval)
 
     out = {
         "metric": "EVP sub-cycle cell-updates/s", "value": value, "unit": "cell-updates/s",
@@ -205,25 +303,18 @@ def main():
                    "global_grid": [nx_l * Rx, ny_l * Ry], "tile": [nx_l, ny_l], "partition": [Rx, Ry],
                    "substeps": args.substeps, "mode": args.mode,
                    "halo": args.halo,
-                   "halo_exchange": "none (one tile)" if (world == 1 and not args.force_connected)
-                   else f"RCCL send/recv, exchange interval k={args.exchange_interval or 'auto(min(halo/2,16))'}: width 2k every k sub-steps"},
+                   "halo_exchange": "none (one tile)" if not tiled
+                   else f"RCCL send/recv of u, v, sigma: width {2 * path['exchange_interval']} every {path['exchange_interval']} sub-steps "
+                        f"({path['exchanges']} exchanges per step)"},
         "model_days_per_hr": model_days_per_hr,
         "model_days_per_hr_config": "full RK3 time_step! (3 stages x [WENO7 advection of h, aice + sub-cycle + tracer update]), dt = 120 s",
         "subcycle_ms_hip_events": subcycle_ms,
         "path": path,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": {"substep": "csi::fused::k_substep (stress + u + v in one launch)",
-                                "pair": "csi::fused::k_pair (two sub-steps: 2 x [stress + u + v] in one launch)", "stress": "csi::fast::k_stress",
-                                "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}[dom] if args.mode == "fast" else dom,
-                     "algorithmic_bytes_per_launch": cells_launch * algo,
-                     "kernel_minimum_bytes_per_launch": cells_launch * (120.0 if path["fused"] else algo),
-                     "frac_of_kernel_minimum": cells_launch * (120.0 if path["fused"] else algo) / (phases[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "avg_launch_ms": phases[dom], "substeps_per_launch": spl,
-                     "note": "fused kernels are co-limited by FP64 VALU issue (DESIGN.md section 3); frac is the HBM figure the contract asks for",
-                     "all_phases_ms": phases,
-                     "substep_frac": cells_launch * 256.0 / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "result_check": chk,
+        "roofline": roof,
     }
+    if k1 is not None:
+        out["exchange_every_substep"] = k1
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     model = None                                   # contexts (and their RCCL communicators) go before the line is printed

@@ -1,0 +1,238 @@
+"""BASELINE.json's configurations at their STATED sizes.  The oracle does not finish
+these in seconds, so parity is carried by the chain  oracle == STRICT (bit for bit, small sizes, test_gpu_evp.py)
+-> STRICT vs FAST at full size (stated tolerance) -> FAST three-kernel == fused kernels (bit for bit, full size)
+-> untiled == tiled (bit for bit, full size), plus size-independent properties (finite, land exactly zero, zero
+sets identical).  Reference set-ups: test/distributed_tests_utils.jl:104-137 (config 3), :183-259 (configs 4 / 5
+geometry), examples/arctic_basin_seasonal_cycle.jl (config 4 physics).
+
+  config 3: 1024^2 (and the metric's 2048^2) periodic f-plane, EVP, 120 sub-steps
+  config 4: 2048^2 lat-lon (lon 0..60, lat 20..70, per-row metrics), EVP + slab thermodynamics, one RK3 time_step!
+            with WENO7; also on a self-connected tile with bench.py's halo 32 / k = 16 and with k = 1
+  config 5: 4096^2 channel, 30 % land discs + solid caps, 500 sub-steps
+
+Tolerances (fp64): FAST vs STRICT after a 120-sub-step cycle <= 1e-12 max|u| on u, v and <= 1e-11 max|sigma| on
+sigma, or 10 x STRICT's own sensitivity to a 1e-15 relative input perturbation where the mEVP iteration is
+ill-conditioned (which branch was taken is recorded in gpurun_out/fullsize_tolerance.json and printed).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import climaseaice_jl_amd as csi
+from test_gpu_evp import EVP_FIELDS, FAST_TOL_SIG, FAST_TOL_VEL
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_REPORT = {}
+
+
+def _record(name, entry):
+    _REPORT[name] = entry
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fullsize_tolerance.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+    print(f"[fullsize] {name}: {entry}")
+
+
+def run_cycle(c, mode, fusion=None, tile=None, k=None):
+    m = cases.csi_model(c, mode=mode, tile=tile)
+    if fusion is not None:
+        m.set_fusion(fusion)
+    if k is not None:
+        m.set_exchange_interval(k)
+    csi.time_step_momentum(m, c["dt"])
+    m.synchronize()
+    out = {f: EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+    path = m.ctx.last_path()
+    del m
+    return out, path
+
+
+def perturbed(c, seed=11):
+    rng = np.random.default_rng(seed)
+    c2 = dict(c)
+    for k in ("u", "v", "h"):
+        c2[k] = c[k] * (1 + 1e-15 * rng.standard_normal(c[k].shape))
+    return c2
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_config3_fplane_120_substeps(N):
+    """Config 3 (1024^2) and the metric's grid (2048^2): periodic f-plane, EVP defaults, 120 sub-steps, constant wind
+    stress, semi-implicit ocean drag (test/distributed_tests_utils.jl:104-137 physics)."""
+    c = cases.make_case(Nx=N, Ny=N, topo=("periodic", "periodic"), patches=True, random_uv=0.02, substeps=120)
+    strict, p0 = run_cycle(c, "strict")
+    three, p1 = run_cycle(c, "fast", fusion=0)
+    pair, p2 = run_cycle(c, "fast", fusion=2)
+    assert p0["level"] == 0 and p1["level"] == 0 and p2["level"] == 2
+    # the benchmarked kernel (two sub-steps per launch) == the three-kernel FAST path, bit for bit, every field
+    for f in three:
+        assert np.all(np.isfinite(pair[f])), f
+        assert np.array_equal(three[f], pair[f]), (f, np.abs(three[f] - pair[f]).max())
+    # FAST vs STRICT: stated tolerance, or 10 x STRICT's own sensitivity where the iteration is ill-conditioned
+    sens_run, _ = run_cycle(perturbed(c), "strict")
+    vmax = max(np.abs(strict["u"]).max(), np.abs(strict["v"]).max())
+    smax = max(np.abs(strict[f]).max() for f in ("s11", "s22", "s12"))
+    entry = {"vmax": vmax, "smax": smax}
+    for f in ("u", "v", "s11", "s22", "s12"):
+        tol = (FAST_TOL_VEL * vmax) if f in ("u", "v") else (FAST_TOL_SIG * smax)
+        sens = float(np.abs(sens_run[f] - strict[f]).max())
+        d = float(np.abs(pair[f] - strict[f]).max())
+        entry[f] = {"diff": d, "stated_tol": tol, "strict_self_sensitivity": sens, "branch": "stated" if d <= tol else "10x sensitivity"}
+        assert d <= max(tol, 10 * sens), (f, d, tol, sens)
+    _record(f"config3_{N}", entry)
+    # threshold decisions: open water / marginal ice cells are the same set in every path
+    for f in ("u", "v"):
+        assert np.array_equal(strict[f] == 0.0, pair[f] == 0.0), f
+    assert 0 < (strict["u"] == 0.0).sum() < strict["u"].size
+    assert vmax < 10.0
+
+
+def latlon_case(N, H, topo, substeps=120):
+    c = cases.make_case(Nx=N, Ny=N, H=H, topo=topo, grid="latlon", patches=True, random_uv=0.02, substeps=substeps)
+    return c
+
+
+def slab():
+    # test/test_thermodynamic_mass_fluxes.jl:56 (numeric top / bottom fluxes), prescribed top temperature
+    return csi.SlabThermodynamics(top_temperature=-10.0, top_heat_flux=100.0, bottom_heat_flux=10.0)
+
+
+def full_model(c, mode, tile=None, k=None, fusion=None):
+    m = cases.csi_model(c, mode=mode, timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=tile,
+                        ice_thermodynamics=slab())
+    if k is not None:
+        m.set_exchange_interval(k)
+    if fusion is not None:
+        m.set_fusion(fusion)
+    return m
+
+
+def model_state(m):
+    m.synchronize()
+    out = {"h": m.ice_thickness.interior_numpy().copy(), "a": m.ice_concentration.interior_numpy().copy()}
+    out.update({f: EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")})
+    return out
+
+
+def test_config4_latlon_rk3_step_fast_vs_strict():
+    """Config 4 physics at 2048^2: lat-lon grid with per-row metrics, bounded, one SplitRungeKutta3 time_step! =
+    3 x [WENO7 advection of h, aice; 120 EVP sub-steps; tracer update; slab thermodynamics]."""
+    N = 2048
+    c = latlon_case(N, 4, ("bounded", "bounded"))
+    res = {}
+    for mode in ("strict", "fast"):
+        m = full_model(c, mode)
+        csi.time_step(m, c["dt"])
+        res[mode] = model_state(m)
+        if mode == "fast":
+            assert m.ctx.last_path()["level"] == 2
+        del m
+    ms = full_model(perturbed(c), "strict")
+    csi.time_step(ms, c["dt"])
+    sens = model_state(ms)
+    del ms
+    entry = {}
+    # tracers: advection, update and slab step are computed in the reference's order in both modes; they see the
+    # velocities of the sub-cycle, so they inherit its rounding-level differences only
+    for f, tol in (("h", 1e-11), ("a", 1e-11)):
+        scale = np.abs(res["strict"][f]).max()
+        d = float(np.abs(res["fast"][f] - res["strict"][f]).max())
+        s = float(np.abs(sens[f] - res["strict"][f]).max())
+        entry[f] = {"diff": d, "stated_tol": tol * scale, "strict_self_sensitivity": s}
+        assert np.all(np.isfinite(res["fast"][f]))
+        assert d <= max(tol * scale, 10 * s), (f, d, scale, s)
+    vmax = max(np.abs(res["strict"]["u"]).max(), np.abs(res["strict"]["v"]).max())
+    smax = max(np.abs(res["strict"][f]).max() for f in ("s11", "s22", "s12"))
+    for f in ("u", "v", "s11", "s22", "s12"):
+        tol = (FAST_TOL_VEL * vmax) if f in ("u", "v") else (FAST_TOL_SIG * smax)
+        d = float(np.abs(res["fast"][f] - res["strict"][f]).max())
+        s = float(np.abs(sens[f] - res["strict"][f]).max())
+        entry[f] = {"diff": d, "stated_tol": tol, "strict_self_sensitivity": s, "branch": "stated" if d <= tol else "10x sensitivity"}
+        assert np.all(np.isfinite(res["fast"][f]))
+        assert d <= max(tol, 10 * s), (f, d, tol, s)
+    _record("config4_latlon_rk3", entry)
+    a = res["fast"]["a"]
+    assert a.min() >= 0.0 and a.max() <= 1.0 and res["fast"]["h"].min() >= 0.0
+    # the slab step changed the thickness (top flux 100 W m^-2 melts, bottom growth): not a no-op
+    m0 = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7))
+    csi.time_step(m0, c["dt"])
+    assert not np.array_equal(model_state(m0)["h"], res["fast"]["h"])
+
+
+@pytest.mark.parametrize("k", [16, 1])
+def test_config4_latlon_tile_bitwise(k):
+    """Config 4 on a tile: 2048^2 lat-lon channel (periodic x, walls in y) with bench.py's tile halo 32; the same RK3
+    step on a tile whose x edges are CONNECTED (RCCL exchange with itself: width 2k every k sub-steps, k = 16 as
+    bench.py runs it and k = 1 as BASELINE.json's north star states) equals the untiled run bit for bit."""
+    N = 2048
+    c = latlon_case(N, 32, ("periodic", "bounded"))
+    ref = full_model(c, "fast")
+    csi.time_step(ref, c["dt"])
+    want = model_state(ref)
+    assert ref.ctx.last_path()["level"] == 2
+    del ref
+    til = full_model(c, "fast", tile=(1, 1, 0, (True, False)), k=k)
+    csi.time_step(til, c["dt"])
+    got = model_state(til)
+    path = til.ctx.last_path()
+    assert path["exchange_interval"] == k and path["level"] == (2 if k % 2 == 0 else 1), path
+    assert path["exchanges"] == (120 // k + (1 if 120 % k else 0)), path
+    for f in want:
+        assert np.all(np.isfinite(got[f])), f
+        assert np.array_equal(want[f], got[f]), (f, np.abs(want[f] - got[f]).max(), np.argwhere(want[f] != got[f])[:4])
+
+
+def config5_case(N, substeps):
+    """4096^2 uniform 2 km channel (periodic x, walls in y), land = seeded discs covering 30 % + solid caps of N / 32
+    rows at both walls, h = aice = 0 on land."""
+    c = cases.make_case(Nx=N, Ny=N, topo=("periodic", "bounded"), patches=True, random_uv=0.02, substeps=substeps, land=0.3)
+    cap = N // 32
+    wet = c["mask"].copy()
+    wet[:cap, :] = False
+    wet[-cap:, :] = False
+    c["mask"] = wet
+    c["h"] = np.where(wet, c["h"], 0.0)
+    c["a"] = np.where(wet, c["a"], 0.0)
+    return c
+
+
+def test_config5_masked_4096_500_substeps():
+    """Config 5: 4096^2 masked channel, 500 sub-steps.  The two-sub-steps-per-launch kernel with the immersed mask ==
+    the three-kernel FAST path bit for bit; everything finite; land faces exactly zero."""
+    N = 4096
+    c = config5_case(N, 500)
+    three, p1 = run_cycle(c, "fast", fusion=0)
+    pair, p2 = run_cycle(c, "fast", fusion=2)
+    assert p1["level"] == 0 and p2["level"] == 2
+    for f in three:
+        assert np.all(np.isfinite(pair[f])), f
+        assert np.array_equal(three[f], pair[f]), (f, np.abs(three[f] - pair[f]).max(), np.argwhere(three[f] != pair[f])[:4])
+    wet = c["mask"]
+    # peripheral nodes: faces with an inactive cell on either side carry exactly zero velocity
+    u_land = ~(wet & np.roll(wet, 1, axis=1))                     # u(i, j) between cells i-1 and i (periodic x)
+    assert np.all(pair["u"][u_land] == 0.0)
+    v = pair["v"]                                                  # (Ny + 1, Nx): faces 1 .. Ny + 1, walls at both ends
+    v_land = np.ones(v.shape, dtype=bool)
+    v_land[1:N, :] = ~(wet[1:, :] & wet[:-1, :])
+    assert np.all(v[v_land] == 0.0)
+    assert np.abs(pair["u"]).max() < 10.0 and np.abs(pair["u"][~u_land]).max() > 0.0
+    frac = 1.0 - wet.mean()
+    assert 0.3 <= frac <= 0.45, frac
+    _record("config5_4096", {"land_fraction": float(frac), "vmax": float(max(np.abs(pair['u']).max(), np.abs(pair['v']).max()))})
+
+
+def test_config5_tile_2048x1024_bitwise():
+    """Config 5's tile shape (4096^2 over 2 x 4 GPUs = 2048 x 1024 per tile) as a self-connected masked tile with the
+    batched exchange, 120 sub-steps: owned cells equal the untiled run bit for bit."""
+    c = cases.make_case(Nx=2048, Ny=1024, H=16, topo=("periodic", "bounded"), patches=True, random_uv=0.02, substeps=120, land=0.3)
+    want, p1 = run_cycle(c, "fast", fusion=2)
+    got, p2 = run_cycle(c, "fast", tile=(1, 1, 0, (True, False)))
+    assert p1["level"] == 2 and p2["level"] == 2 and p2["exchange_interval"] == 8, (p1, p2)
+    for f in want:
+        assert np.array_equal(want[f], got[f]), (f, np.abs(want[f] - got[f]).max())
