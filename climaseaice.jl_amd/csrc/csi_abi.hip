@@ -445,10 +445,12 @@ int32_t ensure_alt(csi_context* c) {
     return CSI_OK;
 }
 
+constexpr int kMaxExchangeInterval = 16;
 int exchange_interval(const csi_context* c) {
     if (!is_tiled(c)) return 1;
     const int hmin = c->Hx < c->Hy ? c->Hx : c->Hy, nmin = c->Nx < c->Ny ? c->Nx : c->Ny;
     int k = c->exch_k > 0 ? c->exch_k : (hmin / 2 < 16 ? hmin / 2 : 16);   // automatic: as rare as the halo allows (<= 16)
+    if (k > kMaxExchangeInterval) k = kMaxExchangeInterval;                 // the fused path's table has that many batch positions
     while (k > 1 && (2 * k > hmin || 2 * k > nmin)) --k;
     return k < 1 ? 1 : k;
 }
@@ -488,8 +490,22 @@ bool has_walls(const csi_context* c) {
     const GridDev& g = c->g;
     return g.xlo == SIDE_WALL || g.xhi == SIDE_WALL || g.ylo == SIDE_WALL || g.yhi == SIDE_WALL;
 }
+// The fused kernels address every field with 32-bit unsigned BYTE offsets from the parent's first element (one SGPR
+// base + one VGPR offset per access): a parent of 4 GiB or more (about 23k x 23k cells; it fits the 288 GB of HBM) would
+// wrap silently, so such grids run the three-kernel path, whose FRef indexes with 64-bit integers.
+bool offsets_fit_32bit(int Nx, int Ny, int Hx, int Hy, int64_t max_ld) {
+    const int64_t ld = max_ld > 0 ? max_ld : (int64_t)Nx + 2 * Hx + 1, nj = (int64_t)Ny + 2 * Hy + 1;
+    return ld * nj * 8 < ((int64_t)1 << 32);
+}
+int64_t max_bound_ld(const csi_context* c) {
+    int64_t m = 0;
+    for (int k = 0; k < CSI_F_COUNT; ++k) if (c->f[k].p && c->f[k].ld > m) m = c->f[k].ld;
+    if (c->g.has_mask && c->g.mask_ld > m) m = c->g.mask_ld;
+    return m;
+}
 bool pair_supported(const csi_context* c) {
     if (!c->pairing) return false;
+    if (!offsets_fit_32bit(c->Nx, c->Ny, c->Hx, c->Hy, max_bound_ld(c))) return false;
     if (c->metric_kind == CSI_METRIC_FULL) return false;        // per-point coefficients: three-kernel path
     const GridDev& g = c->g;
     auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED || s == SIDE_WALL; };
@@ -567,7 +583,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     // tables: singles (position in the exchange batch) x (which buffer is current) x (u first / v first), then
     // pairs (pair position) x (buffer) x (first sub-step u first / v first)
-    constexpr int KMAX = 16, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4;
+    constexpr int KMAX = kMaxExchangeInterval, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4;
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
     FusedGeom G[KMAX], GP[KMAX / 2];
@@ -1030,6 +1046,7 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
     g.xlo = side_lo(topo_x); g.xhi = side_hi(topo_x); g.ylo = side_lo(topo_y); g.yhi = side_hi(topo_y);
     g.metric_kind = metric_kind;
     g.dx = m->dx; g.dy = m->dy;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // kernels still in flight may read the tables freed below
     if (c->dev_metrics) { hipFree(c->dev_metrics); c->dev_metrics = nullptr; }
     if (metric_kind == CSI_METRIC_PER_J) {
         if (!m->dxc || !m->dxf || !m->azc || !m->azf) return fail(c, CSI_ERR_INVALID_ARGUMENT, "PER_J metrics need dxc, dxf, azc, azf");

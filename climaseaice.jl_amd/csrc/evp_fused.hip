@@ -288,11 +288,21 @@ static unsigned long parent_addr(const FRef& f, const GridDev& g) {
 
 // Array-valued forcing the two-sub-steps-per-launch kernel takes (FORCE variant): top stress given as arrays
 // (kind 2) and / or a bottom SemiImplicitStress whose ocean velocities are arrays -- the coupled-model case.
+// 32-bit byte offsets (evp_fused_common.h: ldg / stg): every parent the fused kernels touch must be smaller than 4 GiB
+static bool fused_offsets_fit(const EvpDev& P) {
+    const long nj = (long)P.g.Ny + 2 * P.g.Hy + 1;
+    long ld = P.h.ld > P.u.ld ? P.h.ld : P.u.ld;
+    if (P.g.has_mask && P.g.mask_ld > ld) ld = P.g.mask_ld;
+    return ld * nj * 8 < (1L << 32);
+}
 int pair_forcing_kind(const EvpDev& P) {
     if (P.g.metric_kind == 2) return -1;
     const int lc = P.h.ld, lf = P.u.ld;
     if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return -1;
     if (P.un.ld != lf || P.s12.ld != lf) return -1;
+    if (P.al.ld != lc || P.zc.ld != lc || P.Dl.ld != lc || P.zf.ld != lf) return -1;      // diagnostics stored with the same two strides
+    if (P.g.has_mask && P.g.mask_ld <= 0) return -1;
+    if (!fused_offsets_fit(P)) return -1;
     const StressDev &t = P.top, &b = P.bot;
     const bool t_arr = t.kind == 2, b_arr = b.kind == 3 && (b.ue_kind == 2 || b.ve_kind == 2);
     if (t.kind == 3 && (t.ue_kind == 2 || t.ve_kind == 2)) return -1;      // array-valued wind drag: three kernels
@@ -320,6 +330,8 @@ bool fused_supported(const EvpDev& P) {
     const int lc = P.h.ld, lf = P.u.ld;
     if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return false;
     if (P.un.ld != lf || P.s12.ld != lf) return false;
+    if (P.al.ld != lc || P.zc.ld != lc || P.Dl.ld != lc || P.zf.ld != lf) return false;   // diagnostics stored with the same two strides
+    if (!fused_offsets_fit(P)) return false;
     // first version: no immersed mask, forcing given by numbers (the benchmark configuration); everything else
     // runs the three-kernel FAST path
     if (P.g.has_mask || P.free_drift || P.g.metric_kind == 2) return false;   // (full 2-D metrics: three-kernel path)

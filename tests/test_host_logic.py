@@ -72,3 +72,14 @@ def test_pair_plan_geometry_and_ranges():
     assert _lib.plan_pair(64, 64, 3, 3, P, P) is None
     assert _lib.plan_pair(7, 64, 4, 4, P, P) is None
     assert _lib.plan_pair(256, 256, 8, 8, FC, FC, 3, 0) is None
+
+
+def test_fused_paths_refuse_parents_beyond_32bit_offsets():
+    """The fused kernels address fields with 32-bit byte offsets: a parent array of 4 GiB or more (about 23k x 23k cells)
+    must fall back to the three-kernel path (64-bit indexing) instead of wrapping (csi_abi.hip: offsets_fit_32bit)."""
+    from climaseaice_jl_amd import _lib
+    P = _lib.PERIODIC
+    assert _lib.plan_pair(16384, 16384, 4, 4, P, P) is not None           # 2.1 GiB per parent
+    assert _lib.plan_pair(23160, 23160, 4, 4, P, P) is not None           # just below 4 GiB
+    assert _lib.plan_pair(23170, 23170, 4, 4, P, P) is None               # (23179 x 23179 x 8 B >= 2^32)
+    assert _lib.plan_pair(40000, 16384, 4, 4, P, P) is None
