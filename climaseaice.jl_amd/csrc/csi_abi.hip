@@ -517,18 +517,20 @@ bool pair_supported(const csi_context* c) {
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     FusedGeom G;
     G.rs = dec;
-    // (56-column strip) x (rows) wave tiles.  The kernel runs 2 waves per SIMD (256 CUs x 2 workgroups x 4 waves
-    // = 2048 resident) and is bound by FP64 VALU issue.  Exactly one round of tiles, as tall as possible: every
-    // SIMD keeps its two waves from start to end (they trade issue priority every row, evp_fused2.hip) and each
-    // tile pays its 6 ring rows once.  Measured at 2048^2: rows 38 -> 1998 waves, 48.5 G cell-updates/s;
-    // rows 36 -> 2109 waves (a second round of 61), 36.5 G; rows 25 -> 3034 waves, 45.7 G.
+    // (56-column strip) x (rows) tiles, one workgroup of two waves (producer: first sub-step, consumer: second) per tile.
+    // The kernel is compiled for 3 waves per SIMD (<= 168 VGPRs): 256 CUs x 6 workgroups = 1536 resident tiles.  Exactly
+    // one round of tiles, as tall as possible: every SIMD keeps its waves from start to end and each tile pays its 6 ring
+    // rows once.
     const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
     G.nstrips = (width + 55) / 56;
-    int max_chunks = 2048 / G.nstrips;
+    int target = 1536;
+    if (const char* e = getenv("CSI_PAIR_TILES")) target = atoi(e);   // tuning aid
+    int max_chunks = target / G.nstrips;
     if (max_chunks < 1) max_chunks = 1;
     int rows = (height + max_chunks - 1) / max_chunks;
-    if (rows < 6) rows = 6;            // small grids (measured 512^2: rows 6 -> 18.5 G, 16 -> 10.4 G cell-updates/s;
-                                       // 1024^2: rows 10 -> 37.5 G, 16 -> 29.3 G): parallelism beats the 6 ring rows
+    int min_rows = 6;                  // small grids: parallelism beats the 6 ring rows
+    if (const char* e = getenv("CSI_PAIR_MINROWS")) min_rows = atoi(e);
+    if (rows < min_rows) rows = min_rows;
     if (const char* e = getenv("CSI_PAIR_ROWS")) rows = atoi(e);   // tuning aid
     if (rows > height) rows = height;
     if (rows < 1) rows = 1;

@@ -2,21 +2,23 @@
 // evp_fused.hip applied twice).
 //
 // The one-sub-step kernel (evp_fused.hip) moves 120 B per cell-update and runs at the bandwidth this access
-// pattern can reach (profiles/r01e: a copy kernel with the same 10-read / 5-write row march gets 4.5 TB/s; the
-// kernel gets 4.4).  The only way further down is fewer bytes: this kernel carries the state of sub-step s in
-// registers into sub-step s + 1 (temporal blocking), so u, v, sigma cross HBM once per PAIR of sub-steps
+// pattern can reach.  The only way further down is fewer bytes: this kernel carries the state of sub-step s into
+// sub-step s + 1 without a trip through HBM (temporal blocking), so u, v, sigma cross HBM once per PAIR of sub-steps
 // (60 B per cell-update).  The dependency ring doubles (radius 2 per sub-step):
 //
-//   * a 64-lane wave owns 56 columns (lanes 4..59) x `rows` rows; lanes 0..3 / 60..63 and 3 + 3 rows above and
+//   * a wave tile owns 56 columns (lanes 4..59) x `rows` rows; lanes 0..3 / 60..63 and 3 + 3 rows above and
 //     below are recomputed redundantly (bit-identical to their owner's results: same code, same inputs);
-//   * stage A (sub-step s) runs row r, stage B (sub-step s + 1) runs row r - 2 in the same loop iteration, fed
-//     from A's registers (new u, v of row r - 1, new sigma / P / mass of row r - 2 from short delay lines);
-//     nothing A computes is stored;
+//   * PRODUCER / CONSUMER waves: a workgroup is two 64-lane waves working on the same tile.  Wave 0 runs stage A
+//     (sub-step s) down the rows; wave 1 runs stage B (sub-step s + 1) two rows behind it.  A's new u, v, sigma rows
+//     travel through a four-row ring in LDS (10 KB per workgroup, one s_barrier per row); P, h, aice, u^n, v^n are
+//     read by both waves (B's reads hit L2: A fetched those rows two iterations earlier).  Each wave holds ONE stage's
+//     row window, constants and delay lines, so the kernel needs ~1/2 of the registers of a single wave running both
+//     stages (round 1: 212-234 VGPRs -> 2 waves per SIMD, VALU busy 62-68 %): three or more waves per SIMD, half the
+//     instructions per wave-row (a wave issues at most one instruction per 4 cycles), and a tile is finished by two
+//     waves at once -- small tiles (multi-GPU decompositions) are twice as tall for the same number of waves;
 //   * the halo cells B's neighbours need next are refreshed by the owner's store (periodic sides: halo images
 //     of u, v AND sigma -- sigma is history dependent, so its halo copies must follow the owner) or by the tile
-//     exchange (connected sides, every k sub-steps, k even);
-//   * sides must be periodic or connected and the halo >= 4; walls (mirror images inside the ring) stay with
-//     the one-sub-step kernel.
+//     exchange (connected sides, every k sub-steps, k even); walls: see below.
 //
 // Ranges follow csi_abi.hip (stress [2-V, N+V-1], ...) with V = 4 for A and V = 2 for B on periodic sides and
 // the batch position's V on connected sides; every in-range value depends on in-range values only, so the
@@ -27,28 +29,66 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef CSI_PAIR_WAVES
+#define CSI_PAIR_WAVES 3        // waves per SIMD the register allocation aims at (512 / 3 -> 168 VGPRs)
+#endif
+#ifndef CSI_PAIR_PRIO
+#define CSI_PAIR_PRIO 1         // rotate the user priority of the resident workgroups of a CU every row (see k_pair)
+#endif
+#ifndef CSI_PAIR_FLIP
+#define CSI_PAIR_FLIP 1         // which workgroups swap the roles of their two waves (0: none, 1: odd age rank, 2: rank / 2 odd)
+#endif
+#ifndef CSI_PAIR_PD
+#define CSI_PAIR_PD 1           // rows the producer prefetches ahead (1 or 2; 2 costs 20 more VGPRs)
+#endif
+
 namespace csi {
 namespace fused {
 
 #ifdef CSI_PAIR_PROBE
-__device__ unsigned long long g_probe[4096 * 16];
+__device__ unsigned long long g_probe[8192 * 16];
+#define PROBE_DECL unsigned long long pacc0 = 0, pacc1 = 0, pacc2 = 0, ptprev = 0, pit = 0; const unsigned long long pwall0 = wall_clock64()
+#define PROBE_START do { __builtin_amdgcn_sched_barrier(0); ptprev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); ++pit; } while (0)
+#define PROBE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                        __builtin_amdgcn_sched_barrier(0); acc += t_ - ptprev; ptprev = t_; } while (0)
+#define PROBE_END(slot) do { if (lane == 0 && (slot) < 8192) { unsigned long long* dbg = g_probe + (size_t)(slot) * 16; \
+                        dbg[0] = pacc0; dbg[1] = pacc1; dbg[2] = pacc2; dbg[6] = pit; dbg[8] = pwall0; dbg[9] = wall_clock64(); } } while (0)
+#else
+#define PROBE_DECL do { } while (0)
+#define PROBE_START do { } while (0)
+#define PROBE(acc) do { } while (0)
+#define PROBE_END(slot) do { } while (0)
 #endif
 
+template <int V> struct Idx { static constexpr int value = V; };
+
+// hand-off ring: rows x {sigma11, sigma22, sigma12, u, v of sub-step s; P, ice mass, aice, u^n, v^n} x 64 lanes (+ the 2-bit mask
+// code of each row): everything stage B consumes, so that the consumer wave issues no global loads at all -- its vmcnt
+// queue holds stores only and is never waited for inside the row loop
+constexpr int RING_ROWS = 4, RING_FIELDS = 10;
+enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF_VN };
+
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, bool CF>
-__global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
-                                               int blocks_per_xcd, int write_diag) {
+__global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+                                                              int blocks_per_xcd, int write_diag) {
+    __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
+    __shared__ unsigned ringm[RING_ROWS * 64];
     const int b = (int)blockIdx.x;
-    const int blk = (b & 7) * blocks_per_xcd + (b >> 3);
-    if ((b >> 3) >= blocks_per_xcd) return;
-    const int w = __builtin_amdgcn_readfirstlane(blk * 4 + (int)(threadIdx.x >> 6));
-    if (w >= nstrips * nchunks) return;
+    const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
+    if (w >= nstrips * nchunks) return;                      // (uniform over the workgroup: both waves leave)
+    // Roles: wave 0 produces, wave 1 consumes -- swapped in every other workgroup of a CU (by age rank), so that the SIMDs,
+    // which receive the waves of a workgroup in order, each get a mix of producers and consumers (the consumer has ~10 %
+    // more instructions per row: stores and their bookkeeping).
+    const int age_rank = (int)(((unsigned)b >> 3) >> 5);
+    const int flip = CSI_PAIR_FLIP == 1 ? (age_rank & 1) : (CSI_PAIR_FLIP == 2 ? ((age_rank >> 1) & 1) : 0);
+    const bool consumer = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) ^ flip) != 0;
     const int chunk = w / nstrips, strip = w - chunk * nstrips;
     const int lane = (int)(threadIdx.x & 63);
     tptr_t T = (tptr_t)table;
 
     int ja, jb, rstart, rend;
-    unsigned loff, oc, of, sc, sf;
-    unsigned om = 0, sm = 0;  // MASK: byte offset / row stride into the uint8 activity mask
+    unsigned loff, sc, sf;
+    unsigned lm = 0, sm = 0;   // MASK: column offset / row stride into the uint8 activity mask
     int i;
     unsigned flags;
     int dx;                  // byte offset of this column's halo image on a periodic side (0: none): every field
@@ -56,6 +96,8 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
     bool wave_valx_b = false;  // WALLS: some lane of the wave reflects v about a ValueBoundaryCondition value (L_VAL_LO / L_VAL_HI)
     bool wave_has_dx_b;      // any lane of the wave has one
     bool lanes_uniform;      // fast store path allowed (see flush)
+    bool lanes_same;         // every lane stores all three kinds of results or none (x images allowed)
+    int row0;                // first row of the parent arrays (1 - Hy)
     enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64, L_VAL_LO = 128, L_VAL_HI = 256 };
     {
         const int Nx = T->I[FI_NX], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
@@ -65,12 +107,13 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         jb = min(ja + rows - 1, T->I[FI_DEC + 3]);
         const int ic = min(max(i, 1 - Hx), Nx + Hx);
         loff = (unsigned)(ic - (1 - Hx)) * 8u;
+        row0 = 1 - Hy;
         const bool own = (lane >= P_LO) & (lane <= P_HI) & (i <= T->I[FI_DEC + 1]);
         flags = 0;
         if (own & (i >= T->I[FI_RS + 0]) & (i <= T->I[FI_RS + 1])) flags |= L_RS;
         if (own & (i >= T->I[FI_R1 + 0]) & (i <= T->I[FI_R1 + 1])) flags |= L_R1;
         if (own & (i >= T->I[FI_R2 + 0]) & (i <= T->I[FI_R2 + 1])) flags |= L_R2;
-        // halo images of a periodic side (the pair kernel only runs on periodic / connected sides, N >= 2H):
+        // halo images of a periodic side (the pair kernel only runs on periodic / connected / wall sides, N >= 2H):
         // column i in [1, H] is also stored at i + N, column in (N - H, N] at i - N; rows likewise
         dx = 0;
         if (T->I[FI_XLO] == SIDE_PERIODIC) {
@@ -98,82 +141,28 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         wave_has_dx_b = __builtin_amdgcn_ballot_w64((dx != 0) | (dxv != 0)) != 0;
         // every lane stores all three kinds or none, and no lane has an image: the common store path
         const bool same = ((flags & L_RS) != 0) == ((flags & L_R1) != 0) && ((flags & L_RS) != 0) == ((flags & L_R2) != 0);
-        lanes_uniform = !wave_has_dx_b && (__builtin_amdgcn_ballot_w64(!same) == 0);
+        lanes_same = __builtin_amdgcn_ballot_w64(!same) == 0;
+        lanes_uniform = !wave_has_dx_b && lanes_same;
         rstart = max(ja - 3, T->I[FI_AJ0]);
         rend = min(jb + 3, T->I[FI_AJ1]);
         sc = (unsigned)T->I[FI_LD_C] * 8u;
         sf = (unsigned)T->I[FI_LD_F] * 8u;
-        oc = loff + (unsigned)(rstart - (1 - Hy)) * sc;
-        of = loff + (unsigned)(rstart - (1 - Hy)) * sf;
         if (MASK) {
             sm = (unsigned)T->I[FI_MASK_LD];
-            om = (unsigned)(ic - (1 - Hx)) + (unsigned)(rstart - (1 - Hy)) * sm;
+            lm = (unsigned)(ic - (1 - Hx));
         }
     }
-    int r = rstart;
-
-    Stage<UNI, AUF, MASK, FORCE, CF> A;          // TIGHT scalar live ranges in the array-forcing variants (measured: +6 .. +27 %;
-    Stage<UNI, !AUF, MASK, FORCE, CF> B;         // neutral for walls / masks alone)
-    // ---- stage A prologue: rows r-1, r (as evp_fused.hip) ------------------------------------------------------
-    double P_d1, P_d2 = 0.0;                       // P of rows r-1, r-2
-    double un_d1 = 0.0, un_d2 = 0.0;               // u^n of rows r-2, r-3
-    double vn_d1 = 0.0, vn_d2 = 0.0, vn_d3 = 0.0;  // A u-first: v^n of row r-2 ; A v-first: rows r-1, r-2, r-3
-    {
-        const double rho0 = T->K[FK_RHO];
-        A.u_m = ldg(T->P[FP_U_IN], of - sf); A.v_m = ldg(T->P[FP_V_IN], oc - sc);
-        A.u_0 = ldg(T->P[FP_U_IN], of); A.v_0 = ldg(T->P[FP_V_IN], oc);
-        A.a_mm = 0.0; A.a_m = ldg(T->P[FP_A], oc - sc);
-        A.m_mm = 0.0; A.m_m = ldg(T->P[FP_H], oc - sc) * rho0 * A.a_m;
-        P_d1 = ldg(T->P[FP_P], oc - sc);
-        A.XP_m = fm::sum2(from_left(P_d1), P_d1);
-        A.Xm_m = fm::avg2(from_left(A.m_m), A.m_m);
-        A.Xa_m = fm::avg2(from_left(A.a_m), A.a_m);
-        A.Xv_m = fm::sum2(from_left(A.v_m), A.v_m);
-        A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
-        double e11_m, e22_m;
-        const int jm = r - 1;
-        fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
-                        coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
-        A.e12_0 = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r), coef<UNI>(T, FC_SS, r), coef<UNI>(T, FC_SV, r), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
-        A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);
-        A.Xe22_m = fm::sum2(from_left(e22_m), e22_m);
-        A.Ye12_0 = fm::sum2(A.e12_0, from_right(A.e12_0));
-        A.XAL_m = 0; A.XS11L_m = 0; A.XW = 0; A.Wprev = 0;
-        A.S11_mm = 0; A.S22_mm = 0; A.S12_mm = 0; A.AL_mm = 0; A.S11_m = 0; A.S22_m = 0; A.S12_m = 0; A.AL_m = 0;
-    }
-    // ---- stage B starts empty: its window fills from A's output during the first iterations ---------------------
-    B.u_m = 0; B.u_0 = 0; B.v_m = 0; B.v_0 = 0; B.Xv_m = 0; B.Xv_0 = 0;
-    B.a_mm = 0; B.a_m = 0; B.m_mm = 0; B.m_m = 0;
-    B.XP_m = 0; B.Xm_m = 0; B.Xa_m = 0; B.Xe11_m = 0; B.Xe22_m = 0; B.Ye12_0 = 0; B.e12_0 = 0;
-    B.XAL_m = 0; B.XS11L_m = 0; B.XW = 0; B.Wprev = 0;
-    B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
-
-    auto load_row = [&](RowIn& R) __attribute__((always_inline)) {
-        R.u_p = ldg(T->P[FP_U_IN], of + sf); R.v_p = ldg(T->P[FP_V_IN], oc + sc);
-        R.P_0 = ldg(T->P[FP_P], oc); R.h_0 = ldg(T->P[FP_H], oc); R.a_0 = ldg(T->P[FP_A], oc);
-        R.s11 = ldg(T->P[FP_S11_IN], oc); R.s22 = ldg(T->P[FP_S22_IN], oc); R.s12 = ldg(T->P[FP_S12_IN], of);
-        R.un_m = ldg(T->P[FP_UN], of - sf); R.vn_x = ldg(T->P[FP_VN], AUF ? oc - sc : oc);
-        R.mk = MASK ? ldub(T->P[FP_MASK], om) : 1u;
-    };
-    // B's results of the iteration that ran row rr (q = rr - 2) are stored at the top of the NEXT iteration:
-    // vmcnt counts loads and stores in one in-order queue, and the number of stores is data dependent, so a wait
-    // for prefetched loads placed after fresh stores degenerates to "wait for those stores" -- a full write round
-    // trip per row.  Order per iteration: wait for everything issued one iteration ago -> stores -> prefetch ->
-    // arithmetic.  sigma / first velocity are still in B's window after shift() (S11_m.., Wprev).
-    double pend_second = 0.0;
-    // rows of this tile each kind of store covers (wave-uniform, fixed for the whole march)
-    const int rs_lo = max(ja, T->I[FI_RS + 2]), rs_hi = min(jb, T->I[FI_RS + 3]);
-    const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
-    const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
-    struct OutPtrs { unsigned long s11, s22, s12, u, v; };
-    const bool wrap_y_b = T->I[FI_YLO] == SIDE_PERIODIC;
+    // byte offset of (this lane's column, row j) in a Center-x / Face-x parent, and into the mask
+    auto offc = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * sc; };
+    auto offf = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * sf; };
+    auto offm = [&](int j) __attribute__((always_inline)) { return lm + (unsigned)(j - row0) * sm; };
     const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
     // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
+    const bool wrap_y_b = T->I[FI_YLO] == SIDE_PERIODIC;
     const bool ylo_wall_b = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall_b = WALLS && T->I[FI_YHI] == SIDE_WALL;
     // ... unless that wall carries a ValueBoundaryCondition (IMG_VALUE): then ONE halo row, 2 val - u
     const bool uval_lo_b = WALLS && T->I[FI_IMU + 2] == IMG_VALUE, uval_hi_b = WALLS && T->I[FI_IMU + 3] == IMG_VALUE;
-    // the wave-uniform switches of the row loop, packed into one scalar register (as separate bools each is a 64-bit
-    // lane mask: the WALLS / FORCE variants run out of scalar registers)
+    // the wave-uniform switches of the row loop, packed into one scalar register (as separate bools each is a 64-bit lane mask)
     enum : unsigned { U_WRAPY = 1, U_YLO = 2, U_YHI = 4, U_UVLO = 8, U_UVHI = 16, U_HASDX = 32, U_VALX = 64 };
     const unsigned UF = (unsigned)__builtin_amdgcn_readfirstlane((int)((wrap_y_b ? U_WRAPY : 0u) | (ylo_wall_b ? U_YLO : 0u) | (yhi_wall_b ? U_YHI : 0u) |
                                                                          (uval_lo_b ? U_UVLO : 0u) | (uval_hi_b ? U_UVHI : 0u) |
@@ -185,6 +174,198 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
 #define uval_hi (WALLS && (UF & U_UVHI) != 0)
 #define wave_has_dx ((UF & U_HASDX) != 0)
 #define wave_valx (WALLS && (UF & U_VALX) != 0)
+    // peripheral nodes of a row (walls only): u faces of rows beyond a y wall, v faces on / beyond it
+    auto wall_row = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j < 1)) | (yhi_wall & (j > NyW)); };
+    auto wall_vrow = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j <= 1)) | (yhi_wall & (j > NyW)); };
+    const bool lane_wu = WALLS && (flags & L_WALL_U) != 0, lane_wv = WALLS && (flags & L_WALL_V) != 0;
+    // External stresses.  Numbers come from the table; FORCE: an array-valued top stress (tau at the u / v points)
+    // and / or a bottom SemiImplicitStress whose ocean velocities are arrays (own component at the point, cross
+    // component pre-averaged to the point once per sub-cycle: csi_abi.hip) are loaded one value per lane for the rows a
+    // stage updates.
+    auto numbers = [&](Forcing& F) __attribute__((always_inline)) {
+        F.t_tau_u = T->K[FK_TOP_TAU_U]; F.t_we_u = T->K[FK_TOP_UE]; F.t_wb_u = T->K[FK_TOP_VE];
+        F.b_tau_u = T->K[FK_BOT_TAU_U]; F.b_we_u = T->K[FK_BOT_UE]; F.b_wb_u = T->K[FK_BOT_VE];
+        F.t_tau_v = T->K[FK_TOP_TAU_V]; F.t_we_v = T->K[FK_TOP_VE]; F.t_wb_v = T->K[FK_TOP_UE];
+        F.b_tau_v = T->K[FK_BOT_TAU_V]; F.b_we_v = T->K[FK_BOT_VE]; F.b_wb_v = T->K[FK_BOT_UE];
+        F.fd_u = 0.0; F.fd_v = 0.0; F.fd = FD;
+    };
+    auto arrays = [&](Forcing& F, unsigned ou, unsigned ov) __attribute__((always_inline)) {
+        if (T->I[FI_TOP_KIND] == 2) { F.t_tau_u = ldg(T->P[FP_FT_U], ou); F.t_tau_v = ldg(T->P[FP_FT_V], ov); }
+        if (T->I[FI_BOT_UEK] == 2) { F.b_we_u = ldg(T->P[FP_FB_U], ou); F.b_wb_v = ldg(T->P[FP_FB_UBAR], ov); }   // u_e: own component at u points, averaged to v points
+        if (T->I[FI_BOT_VEK] == 2) { F.b_we_v = ldg(T->P[FP_FB_V], ov); F.b_wb_u = ldg(T->P[FP_FB_VBAR], ou); }   // v_e: own component at v points, averaged to u points
+        if (FD) { F.fd_u = ldg(T->P[FP_FD_U], ou); F.fd_v = ldg(T->P[FP_FD_V], ov); }                             // StressBalanceFreeDrift (once per sub-cycle, csi_abi.hip)
+    };
+    auto stress_consts = [&](fm::StressConst& ks) __attribute__((always_inline)) {
+        ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
+        ks.amin = T->K[FK_AMIN]; ks.amax = T->K[FK_AMAX]; ks.amin2 = T->K[FK_AMIN2]; ks.amax2 = T->K[FK_AMAX2];
+        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+    };
+    auto vel_consts = [&](fm::VelConst& kv) __attribute__((always_inline)) {
+        kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.fcor = T->K[FK_FCOR]; kv.min_mass = T->K[FK_MIN_MASS];
+        kv.min_conc = T->K[FK_MIN_CONC]; kv.has_cor = T->I[FI_HAS_COR];
+    };
+    // Issue arbitration favours the OLDEST wave of a SIMD: without help the workgroups dispatched first finish after ~2/3 of
+    // the launch and the youngest run on alone (measured: tile lifetimes 100 .. 180 us in one launch).  The workgroups
+    // therefore rotate the user priority every row: dispatch fills the 32 CUs of an XCD before it doubles up, so
+    // (local workgroup index / 32) is the age rank of a workgroup on its CU; rank + row (mod 3) gives every resident wave of
+    // a SIMD the top priority one row in three.
+    const int prio_rank = (int)(((unsigned)b >> 3) >> 5) % 3;
+    auto set_prio = [&](int k) __attribute__((always_inline)) {
+        if (CSI_PAIR_PRIO) {
+            int p = prio_rank + k;
+            p = p >= 3 ? p - 3 : p;
+            if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+        }
+    };
+    // ring slot of row j (lane-private column): element f of row j sits at ring[((j - rstart) & 3) * 5 + f][lane]
+    auto rslot = [&](int j) __attribute__((always_inline)) { return (unsigned)((j - rstart) & (RING_ROWS - 1)) * (RING_FIELDS * 64) + (unsigned)lane; };
+
+#ifndef CSI_PAIR_UNROLL
+#define CSI_PAIR_UNROLL 3
+#endif
+
+    if (!consumer) {
+        // ===== PRODUCER: stage A = sub-step s, rows rstart .. rend ===================================================
+        PROBE_DECL;
+        Stage<UNI, AUF, MASK, FORCE, CF> A;          // (TIGHT scalar live ranges in the array-forcing variants)
+        unsigned oc = offc(rstart), of = offf(rstart), om = MASK ? offm(rstart) : 0u;
+        {
+            const double rho0 = T->K[FK_RHO];
+            A.u_m = ldg(T->P[FP_U_IN], of - sf); A.v_m = ldg(T->P[FP_V_IN], oc - sc);
+            A.u_0 = ldg(T->P[FP_U_IN], of); A.v_0 = ldg(T->P[FP_V_IN], oc);
+            A.a_mm = 0.0; A.a_m = ldg(T->P[FP_A], oc - sc);
+            A.m_mm = 0.0; A.m_m = ldg(T->P[FP_H], oc - sc) * rho0 * A.a_m;
+            const double P_m = ldg(T->P[FP_P], oc - sc);
+            A.XP_m = fm::sum2(from_left(P_m), P_m);
+            A.Xm_m = fm::avg2(from_left(A.m_m), A.m_m);
+            A.Xa_m = fm::avg2(from_left(A.a_m), A.a_m);
+            A.Xv_m = fm::sum2(from_left(A.v_m), A.v_m);
+            A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
+            double e11_m, e22_m;
+            const int jm = rstart - 1;
+            fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
+                            coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
+            A.e12_0 = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, rstart), coef<UNI>(T, FC_SS, rstart), coef<UNI>(T, FC_SV, rstart), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
+            A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);
+            A.Xe22_m = fm::sum2(from_left(e22_m), e22_m);
+            A.Ye12_0 = fm::sum2(A.e12_0, from_right(A.e12_0));
+            A.XAL_m = 0; A.XS11L_m = 0; A.XW = 0; A.Wprev = 0;
+            A.S11_mm = 0; A.S22_mm = 0; A.S12_mm = 0; A.AL_mm = 0; A.S11_m = 0; A.S22_m = 0; A.S12_m = 0; A.AL_m = 0;
+            A.S11_0 = 0; A.S22_0 = 0; A.S12_0 = 0; A.AL_0 = 0; A.first = 0; A.second = 0;
+        }
+        // the ring starts clean: the consumer's first iterations read rows the producer never wrote (their results only
+        // fill B's window and are never used -- but they must not be NaN patterns left in LDS by an earlier workgroup)
+#pragma unroll
+        for (int q = 0; q < RING_ROWS * RING_FIELDS; ++q) ring[q * 64 + lane] = 0.0;
+        // MASK: two bits per row (bit 0 inactive, bit 1 beyond a wall), newest row in bits 1:0; row rstart-1 from memory,
+        // older rows count as beyond the domain (their results are never used)
+        unsigned mhist = 0xffffffffu;
+        if (MASK) {
+            const bool wi = lane_wv | wall_row(rstart - 1);
+            const unsigned act = ldub(T->P[FP_MASK], om - sm);
+            mhist = (mhist << 2) | (wi ? 3u : (act ? 0u : 1u));
+            ringm[(unsigned)((-1) & (RING_ROWS - 1)) * 64 + (unsigned)lane] = mhist & 3u;      // row rstart - 1, for the consumer
+        }
+        // Prefetch CSI_PAIR_PD rows ahead (three rotating register sets; the loop is unrolled by three, so the set of every
+        // iteration is fixed at compile time).  The producer issues no stores and loads return in order, so the wait at the
+        // top of an iteration leaves exactly the younger rows in flight.  (Measured: one row ahead already hides the
+        // memory latency -- 9 cycles of 2500 per iteration are spent in that wait.)
+        RowIn R[3];
+        auto load_row = [&](RowIn& Q) __attribute__((always_inline)) {
+            Q.u_p = ldg(T->P[FP_U_IN], of + sf); Q.v_p = ldg(T->P[FP_V_IN], oc + sc);
+            Q.P_0 = ldg(T->P[FP_P], oc); Q.h_0 = ldg(T->P[FP_H], oc); Q.a_0 = ldg(T->P[FP_A], oc);
+            Q.s11 = ldg(T->P[FP_S11_IN], oc); Q.s22 = ldg(T->P[FP_S22_IN], oc); Q.s12 = ldg(T->P[FP_S12_IN], of);
+            Q.un_m = ldg(T->P[FP_UN], of - sf); Q.vn_x = ldg(T->P[FP_VN], AUF ? oc - sc : oc);
+            Q.mk = MASK ? ldub(T->P[FP_MASK], om) : 1u;
+        };
+        // oc / of / om: offsets of the row the NEXT load_row fetches; advance by one row, stopping at rend (the last
+        // iterations re-read row rend: an unconditional prefetch keeps the number of loads in flight static)
+        int rnext = rstart;
+        auto advance = [&]() __attribute__((always_inline)) {
+            const bool more = rnext < rend;
+            oc += more ? sc : 0u; of += more ? sf : 0u;
+            if (MASK) om += more ? sm : 0u;
+            rnext += more ? 1 : 0;
+        };
+        int r = rstart;
+        auto body = [&](auto KK) __attribute__((always_inline)) {
+            constexpr int k = decltype(KK)::value;
+            asm volatile("" : "+s"(T));
+            set_prio(k);
+            PROBE_START;
+            // rows r and r + 1 are in flight (loads return in order; FORCE: the array loads of the previous iteration were
+            // consumed there): wait until only row r + 1's remain
+            if (CSI_PAIR_PD == 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else if (MASK) __builtin_amdgcn_s_waitcnt(0x0F70 | 11);
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
+            PROBE(pacc0);
+            const RowIn& C = R[k];
+            advance();
+            load_row(R[(k + CSI_PAIR_PD) % 3]);           // row r + CSI_PAIR_PD (clamped to rend)
+            fm::StressConst ks; stress_consts(ks);
+            fm::VelConst kv; vel_consts(kv);
+            const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
+            // first / second velocity of a stage that ran row rr: u-first: u(rr-1), v(rr-1); v-first: v(rr), u(rr-1)
+            const bool pa1 = WALLS && (AUF ? (lane_wu | wall_row(r - 1)) : (lane_wv | wall_vrow(r)));
+            const bool pa2 = WALLS && (AUF ? (lane_wv | wall_vrow(r - 1)) : (lane_wu | wall_row(r - 1)));
+            if (MASK) {
+                const bool wi = lane_wv | wall_row(r);
+                mhist = (mhist << 2) | (wi ? 3u : (C.mk ? 0u : 1u));
+            }
+            Forcing FA;
+            numbers(FA);
+            if (FORCE) arrays(FA, offf(r - 1), AUF ? offc(r - 1) : offc(r));      // u points of row r-1, v points of row r-1 / r
+            A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
+            // ---- hand-off to the consumer: sigma(r); u(r-1); v(r-1) [u first] or v(r) [v first] --------------------------
+            {
+                const unsigned s0 = rslot(r), s1 = rslot(r - 1);
+                ring[s0 + RF_S11 * 64] = A.S11_0; ring[s0 + RF_S22 * 64] = A.S22_0; ring[s0 + RF_S12 * 64] = A.S12_0;
+                if (AUF) { ring[s1 + RF_U * 64] = A.first; ring[s1 + RF_V * 64] = A.second; }
+                else { ring[s0 + RF_V * 64] = A.first; ring[s1 + RF_U * 64] = A.second; }
+                // the static fields of the rows B reaches two iterations from now: P, m, aice of row r; u^n of row r-1;
+                // v^n of row r-1 (A u-first: B v-first reads it as row q) / row r (B u-first reads it as row q-1 one iteration later)
+                ring[s0 + RF_P * 64] = C.P_0; ring[s0 + RF_M * 64] = m_0; ring[s0 + RF_A * 64] = C.a_0;
+                ring[s1 + RF_UN * 64] = C.un_m; ring[(AUF ? s1 : s0) + RF_VN * 64] = C.vn_x;
+                if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] = mhist & 3u;
+            }
+            A.shift(C.u_p, C.v_p, m_0, C.a_0);
+            PROBE(pacc1);
+            __syncthreads();                              // row r is complete: the consumer may run its iteration r
+            PROBE(pacc2);
+        };
+        load_row(R[0]);                                   // row rstart
+        if (CSI_PAIR_PD == 2) {
+            advance();
+            load_row(R[1]);                               // row rstart + 1 (clamped)
+        }
+        for (;;) {
+            body(Idx<0>{});
+            if (++r > rend) break;
+            body(Idx<1>{});
+            if (++r > rend) break;
+            body(Idx<2>{});
+            if (++r > rend) break;
+        }
+        PROBE_END(w * 2);
+        return;
+    }
+
+    // ===== CONSUMER: stage B = sub-step s + 1, rows q = r - 2, one iteration behind the producer ====================
+    PROBE_DECL;
+    Stage<UNI, !AUF, MASK, FORCE, CF> B;
+    B.u_m = 0; B.u_0 = 0; B.v_m = 0; B.v_0 = 0; B.Xv_m = 0; B.Xv_0 = 0;
+    B.a_mm = 0; B.a_m = 0; B.m_mm = 0; B.m_m = 0;
+    B.XP_m = 0; B.Xm_m = 0; B.Xa_m = 0; B.Xe11_m = 0; B.Xe22_m = 0; B.Ye12_0 = 0; B.e12_0 = 0;
+    B.XAL_m = 0; B.XS11L_m = 0; B.XW = 0; B.Wprev = 0;
+    B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
+    B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
+    B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0;
+    double pend_second = 0.0;
+    // rows of this tile each kind of store covers (wave-uniform, fixed for the whole march)
+    const int rs_lo = max(ja, T->I[FI_RS + 2]), rs_hi = min(jb, T->I[FI_RS + 3]);
+    const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
+    const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
+    struct OutPtrs { unsigned long s11, s22, s12, u, v; };
     // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
     auto yimg = [&](int j) __attribute__((always_inline)) {
         return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
@@ -238,24 +419,35 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
         fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
         if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
         if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
-        if (!lanes_uniform) fast_hi = fast_lo - 1;
+        if (!lanes_same) fast_hi = fast_lo - 1;
     }
-    auto flush = [&](int rr, unsigned oc_rr, unsigned of_rr) __attribute__((always_inline)) {
-        const int q = rr - 2;
+    const bool fast_plain = lanes_uniform;                // no lane of the wave has an x image either
+    // B's results of the iteration that ran row q are stored at the top of the NEXT iteration (sigma / first velocity are
+    // still in B's window after shift(): S11_m.., Wprev).  The consumer never waits for these stores.
+    auto flush = [&](int q) __attribute__((always_inline)) {
         if ((q >= fast_lo) & (q <= fast_hi)) {
-            // interior tile, interior rows (nearly every call): the owned lanes store five values, no images
+            // interior rows (nearly every call): every kind of store is due, no row has a y image
             if (flags & L_RS) {
-                const unsigned ocq = oc_rr - 2u * sc, ofq = of_rr - 2u * sf;
-                stg(T->P[FP_S11_OUT], ocq, B.S11_m); stg(T->P[FP_S22_OUT], ocq, B.S22_m); stg(T->P[FP_S12_OUT], ofq, B.S12_m);
-                stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, B.Wprev);
-                stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, pend_second);
+                const unsigned ocq = offc(q), ofq = offf(q);
+                if (fast_plain) {
+                    // interior tile: the owned lanes store five values, no images
+                    stg(T->P[FP_S11_OUT], ocq, B.S11_m); stg(T->P[FP_S22_OUT], ocq, B.S22_m); stg(T->P[FP_S12_OUT], ofq, B.S12_m);
+                    stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, B.Wprev);
+                    stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, pend_second);
+                } else {
+                    // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap; v
+                    // mirrors / reflects across an x wall), none of the row bookkeeping of the general path
+                    put(T->P[FP_S11_OUT], ocq, 0u, dx, B.S11_m); put(T->P[FP_S22_OUT], ocq, 0u, dx, B.S22_m); put(T->P[FP_S12_OUT], ofq, 0u, dx, B.S12_m);
+                    if (AUF) { put_v(T->P[FP_V_OUTP], ocq, 0u, B.Wprev); put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, pend_second, pend_second, pend_second, pend_second); }
+                    else { put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, B.Wprev, B.Wprev, B.Wprev, B.Wprev); put_v(T->P[FP_V_OUTP], ocq - sc, 0u, pend_second); }
+                }
             }
             return;
         }
         const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
         const bool do_s = (q >= rs_lo) & (q <= rs_hi), do_1 = (j1 >= r1_lo) & (j1 <= r1_hi), do_2 = (j2 >= r2_lo) & (j2 <= r2_hi);
         if (!(do_s | do_1 | do_2)) return;
-        const unsigned ocq = oc_rr - 2u * sc, ofq = of_rr - 2u * sf;
+        const unsigned ocq = offc(q), ofq = offf(q);
         const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
         const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
         OutPtrs P;                                                // adjacent table slots: one wide scalar load
@@ -274,121 +466,38 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             if (AUF) put_u(P.u, o2, j2, (unsigned)y2 * sf, pend_second); else put_v(P.v, o2, (unsigned)y2 * sc, pend_second);
         }
     };
-#ifdef CSI_PAIR_PROBE
-    const unsigned long long wall0 = wall_clock64();
-    unsigned long long acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, tprev = 0;
-#define PROBE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
-                        __builtin_amdgcn_sched_barrier(0); acc += t_ - tprev; tprev = t_; } while (0)
-#else
-#define PROBE(acc) do { } while (0)
-#endif
-    // Issue arbitration favours the older wave of a SIMD; with two resident waves the older one then finishes early
-    // and the younger runs alone (a single wave cannot fill the FP64 pipe).  The two workgroups of a CU therefore
-    // trade the user priority every row: dispatch fills the 32 CUs of an XCD once before it doubles up, so the
-    // parity of (local workgroup index / 32) tells the first from the second resident workgroup.
-    const int prio_phase = (((b >> 3) >> 5) & 1);
-    // MASK: two bits per row (bit 0 inactive, bit 1 beyond a wall), newest row in bits 1:0; row rstart-1 from memory,
-    // older rows count as beyond the domain (their results are never used)
-    unsigned mhist = 0xffffffffu;
-    if (MASK) {
-        const bool wi = ((flags & L_WALL_V) != 0) | (ylo_wall & (rstart - 1 < 1)) | (yhi_wall & (rstart - 1 > NyW));
-        const unsigned act = ldub(T->P[FP_MASK], om - sm);
-        mhist = (mhist << 2) | (wi ? 3u : (act ? 0u : 1u));
-    }
-    RowIn C, N;
-    auto body = [&]() __attribute__((always_inline)) {
+    // Stage B's row inputs all come from the ring (the producer read them from memory two or three iterations earlier):
+    // the consumer issues no global loads (FORCE: except its forcing arrays), so it never waits for its own stores.
+    const int rlo = rstart - 1;
+    unsigned mhistB = 0xffffffffu;
+    double vn_delay = 0.0;                                // B u-first: v^n of row q - 1 (read one iteration earlier as row q)
+    int r = rstart;
+    auto bodyB = [&](auto KK) __attribute__((always_inline)) {
         asm volatile("" : "+s"(T));
-#ifdef CSI_PAIR_PRIO_PER_ROW
-        if ((r + prio_phase) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef CSI_PAIR_PROBE
-        { __builtin_amdgcn_sched_barrier(0); tprev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#endif
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): row r's inputs and every older store
-        PROBE(acc0);
-        C = N;
-        flush(r - 1, oc - sc, of - sf);
-        PROBE(acc1);
-        const unsigned oc_cur = oc, of_cur = of;
-        // Unconditional prefetch of the next row (the last iteration re-reads its own row): a conditional one
-        // would hide the number of loads in flight from the compiler's wait-count bookkeeping.
-        {
-            const bool more = r < rend;
-            oc += more ? sc : 0u; of += more ? sf : 0u;
-            if (MASK) om += more ? sm : 0u;
-            load_row(N);
-        }
-        PROBE(acc2);
-        fm::StressConst ks;
-        ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
-        ks.amin = T->K[FK_AMIN]; ks.amax = T->K[FK_AMAX]; ks.amin2 = T->K[FK_AMIN2]; ks.amax2 = T->K[FK_AMAX2];
-        ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
-        fm::VelConst kv;
-        kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.fcor = T->K[FK_FCOR]; kv.min_mass = T->K[FK_MIN_MASS];
-        kv.min_conc = T->K[FK_MIN_CONC]; kv.has_cor = T->I[FI_HAS_COR];
-
-        // ---- stage A: sub-step s, row r ------------------------------------------------------------------------
-        const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
-        // peripheral nodes of a row (walls only): u faces of rows beyond a y wall, v faces on / beyond it
-        auto wall_row = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j < 1)) | (yhi_wall & (j > NyW)); };
-        auto wall_vrow = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j <= 1)) | (yhi_wall & (j > NyW)); };
-        const bool lane_wu = WALLS && (flags & L_WALL_U) != 0, lane_wv = WALLS && (flags & L_WALL_V) != 0;
-        // first / second velocity of a stage that ran row rr: u-first: u(rr-1), v(rr-1); v-first: v(rr), u(rr-1)
-        const bool pa1 = WALLS && (AUF ? (lane_wu | wall_row(r - 1)) : (lane_wv | wall_vrow(r)));
-        const bool pa2 = WALLS && (AUF ? (lane_wv | wall_vrow(r - 1)) : (lane_wu | wall_row(r - 1)));
-        if (MASK) {
-            const bool wi = lane_wv | wall_row(r);
-            mhist = (mhist << 2) | (wi ? 3u : (C.mk ? 0u : 1u));
-        }
-        // External stresses.  Numbers come from the table; FORCE: an array-valued top stress (tau at the u / v points)
-        // and / or a bottom SemiImplicitStress whose ocean velocities are arrays (own component at the point, cross
-        // component pre-averaged to the point once per sub-cycle: csi_abi.hip) are loaded here, one value per lane,
-        // for the rows the two stages update: u points of rows r-1 (A) and r-3 (B), v points of rows
-        // r-1 / r (A, u first / v first) and r-2 / r-3 (B, v first / u first).
-        auto numbers = [&](Forcing& F) __attribute__((always_inline)) {
-            F.t_tau_u = T->K[FK_TOP_TAU_U]; F.t_we_u = T->K[FK_TOP_UE]; F.t_wb_u = T->K[FK_TOP_VE];
-            F.b_tau_u = T->K[FK_BOT_TAU_U]; F.b_we_u = T->K[FK_BOT_UE]; F.b_wb_u = T->K[FK_BOT_VE];
-            F.t_tau_v = T->K[FK_TOP_TAU_V]; F.t_we_v = T->K[FK_TOP_VE]; F.t_wb_v = T->K[FK_TOP_UE];
-            F.b_tau_v = T->K[FK_BOT_TAU_V]; F.b_we_v = T->K[FK_BOT_VE]; F.b_wb_v = T->K[FK_BOT_UE];
-            F.fd_u = 0.0; F.fd_v = 0.0; F.fd = FD;
-        };
-        Forcing FA, FB;
-        numbers(FA);
-        unsigned f_ub = 0, f_vb = 0;                // FORCE: offsets of B's array values, loaded after stage A (they are
-                                                    // not needed before B's velocity update; holding them across A spills)
-        if (FORCE) {
-            // (B's first rows of a tile only fill its window: clamp their row to the array instead of running off it)
-            const unsigned below = (unsigned)(r - (1 - HyW));                                     // rows between r and the array's first row
-            const unsigned k3 = min(3u, below), k2 = min(2u, below);
-            const unsigned ua = of_cur - sf, ub = of_cur - k3 * sf;                               // u points: rows r-1, r-3
-            const unsigned va = AUF ? oc_cur - sc : oc_cur, vb = AUF ? oc_cur - k2 * sc : oc_cur - k3 * sc;   // v points
-            if (T->I[FI_TOP_KIND] == 2) {
-                FA.t_tau_u = ldg(T->P[FP_FT_U], ua); FA.t_tau_v = ldg(T->P[FP_FT_V], va);
-            }
-            if (T->I[FI_BOT_UEK] == 2) {       // u_e array: own component at u points, averaged to v points
-                FA.b_we_u = ldg(T->P[FP_FB_U], ua); FA.b_wb_v = ldg(T->P[FP_FB_UBAR], va);
-            }
-            if (T->I[FI_BOT_VEK] == 2) {       // v_e array: own component at v points, averaged to u points
-                FA.b_we_v = ldg(T->P[FP_FB_V], va); FA.b_wb_u = ldg(T->P[FP_FB_VBAR], ua);
-            }
-            if (FD) {                          // StressBalanceFreeDrift: free-drift velocities (once per sub-cycle, csi_abi.hip)
-                FA.fd_u = ldg(T->P[FP_FD_U], ua); FA.fd_v = ldg(T->P[FP_FD_V], va);
-            }
-            f_ub = ub; f_vb = vb;
-        }
-        A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
-
-        PROBE(acc3);
-        // ---- stage B: sub-step s + 1, row q = r - 2, fed from A ---------------------------------------------------
+        set_prio(decltype(KK)::value);
         const int q = r - 2;
-        double bu_p = AUF ? A.first : A.second;                // new u of row r-1
-        double bv_p = AUF ? A.second : A.Wprev;                // new v of row r-1
+        PROBE_START;
+        __syncthreads();                                  // the producer has finished row r
+        PROBE(pacc0);
+        // ---- stage A's results from the ring: u, v of row q + 1, sigma of row q; P, m, aice of row q, u^n of row q - 1, v^n
+        const unsigned s1 = rslot(r - 1), s2 = rslot(r - 2), s3 = rslot(r - 3);
+        double bu_p = ring[s1 + RF_U * 64], bv_p = ring[s1 + RF_V * 64];
+        const double s11 = ring[s2 + RF_S11 * 64], s22 = ring[s2 + RF_S22 * 64], s12 = ring[s2 + RF_S12 * 64];
+        const double bP_0 = ring[s2 + RF_P * 64], bm_0 = ring[s2 + RF_M * 64], ba_0 = ring[s2 + RF_A * 64];
+        const double bun = ring[s3 + RF_UN * 64], vn_new = ring[s2 + RF_VN * 64];
+        const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
+        vn_delay = vn_new;
+        const unsigned bmk = MASK ? ringm[(unsigned)((r - 2 - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] : 0u;
+        flush(q - 1);                                     // (the stores cover the latency of the ring reads above)
+        PROBE(pacc1);
+        fm::StressConst ks; stress_consts(ks);
+        fm::VelConst kv; vel_consts(kv);
         if (WALLS) {
-            // What the reference reads from mirror halos, stage B reads from A's registers: v of the first cell
+            // What the reference reads from mirror halos, stage B reads from A's results: v of the first cell
             // beyond an x wall is its neighbour's; u of the first row beyond a y wall is the wall row's (row 0 is
             // patched when row 1 arrives, row N + 1 copies row N).  Deeper halo cells only feed halo results.
             const double vl = from_left(bv_p), vr = from_right(bv_p);
-            // (a ValueBoundaryCondition wall reflects about 2 val instead: cvx - v, 2 val - u)
+            // (a ValueBoundaryCondition wall reflects about 2 val instead: 2 val - v, 2 val - u)
             double ml = vr, mh = vl;
             if (wave_valx) {
                 if (flags & L_VAL_LO) ml = 2 * T->K[FK_BCV] - vr;
@@ -398,27 +507,24 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
             if (ylo_wall & (q == 0)) B.u_0 = uval_lo ? 2 * T->K[FK_BCU] - bu_p : bu_p;
             if (yhi_wall & (q == NyW)) bu_p = uval_hi ? 2 * T->K[FK_BCU + 1] - B.u_0 : B.u_0;
         }
-        const double bm_0 = A.m_mm, ba_0 = A.a_mm;             // row r-2
-        asm volatile("" : "+s"(T));      // re-read the forcing numbers for stage B instead of holding 24 SGPRs across stage A
+        if (MASK) mhistB = (mhistB << 2) | ((q >= rlo) ? bmk : 3u);           // the producer's 2-bit code of row q
+        Forcing FB;
         numbers(FB);
         if (FORCE) {
-            if (T->I[FI_TOP_KIND] == 2) { FB.t_tau_u = ldg(T->P[FP_FT_U], f_ub); FB.t_tau_v = ldg(T->P[FP_FT_V], f_vb); }
-            if (T->I[FI_BOT_UEK] == 2) { FB.b_we_u = ldg(T->P[FP_FB_U], f_ub); FB.b_wb_v = ldg(T->P[FP_FB_UBAR], f_vb); }
-            if (T->I[FI_BOT_VEK] == 2) { FB.b_we_v = ldg(T->P[FP_FB_V], f_vb); FB.b_wb_u = ldg(T->P[FP_FB_VBAR], f_ub); }
-            if (FD) { FB.fd_u = ldg(T->P[FP_FD_U], f_ub); FB.fd_v = ldg(T->P[FP_FD_V], f_vb); }
+            // u points of row q-1, v points of row q (B v-first) / q-1 (B u-first); B's first rows of a tile only fill its
+            // window: clamp their row to the array instead of running off it
+            const int qm = max(q - 1, row0), qa = max(q, row0);
+            arrays(FB, offf(qm), AUF ? offc(qa) : offc(qm));
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
-        B.step(T, ks, kv, q, bu_p, bv_p, P_d2, bm_0, ba_0, A.S11_mm, A.S22_mm, A.S12_mm, un_d2, AUF ? vn_d1 : vn_d3,
-               q >= ja - 1, q >= ja, pb1, pb2, mhist >> 4, FB);
+        B.step(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB);
         pend_second = B.second;
-        PROBE(acc4);
-
         // diagnostics: last launch of the sub-cycle only, stored at once (with their halo images on periodic sides,
         // where the reference computes them from halo data: same values)
         if (write_diag) {
             if (((flags & L_RS) != 0) & (q >= rs_lo) & (q <= rs_hi)) {
-                const unsigned ocq = oc_cur - 2u * sc, ofq = of_cur - 2u * sf;
+                const unsigned ocq = offc(q), ofq = offf(q);
                 const int yq = yimg(q);
                 put(T->P[FP_AL], ocq, (unsigned)yq * sc, dx, B.AL_0);
                 put(T->P[FP_ZF], ofq, (unsigned)yq * sf, dx, 0.5 * B.zf);       // the stage carries 2 zeta
@@ -426,62 +532,26 @@ __global__ void __launch_bounds__(256, 2) k_pair(const FusedTable* __restrict__ 
                 put(T->P[FP_DL], ocq, (unsigned)yq * sc, dx, B.Dc * B.rDc);         // ... and Delta^2, 1 / Delta
             }
         }
-
-        // ---- slide both windows and the delay lines ---------------------------------------------------------------
         B.shift(bu_p, bv_p, bm_0, ba_0);
-        A.shift(C.u_p, C.v_p, m_0, C.a_0);
-        P_d2 = P_d1; P_d1 = C.P_0;
-        un_d2 = un_d1; un_d1 = C.un_m;
-        if (AUF) { vn_d1 = C.vn_x; }
-        else { vn_d3 = vn_d2; vn_d2 = vn_d1; vn_d1 = C.vn_x; }
-        PROBE(acc5);
+        PROBE(pacc2);
     };
-    load_row(N);
-    // unrolled by hand (runtime trip count): the row windows are 2 and 3 deep, so after 3 copies of the body most
-    // loop-carried values are back in their registers and the window shifts cost no moves
-#ifndef CSI_PAIR_UNROLL
-#define CSI_PAIR_UNROLL 3
-#endif
-    for (int trip = prio_phase;; ++trip) {
-#ifndef CSI_PAIR_PRIO_PER_ROW
-        if (trip & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);     // trade once per trip (3 rows)
-#endif
-        body();
+    for (;;) {
+        bodyB(Idx<0>{});
         if (++r > rend) break;
-#if CSI_PAIR_UNROLL >= 2
-        body();
+        bodyB(Idx<1>{});
         if (++r > rend) break;
-#endif
-#if CSI_PAIR_UNROLL >= 3
-        body();
+        bodyB(Idx<2>{});
         if (++r > rend) break;
-#endif
-#if CSI_PAIR_UNROLL >= 6
-        body();
-        if (++r > rend) break;
-        body();
-        if (++r > rend) break;
-        body();
-        if (++r > rend) break;
-#endif
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    flush(rend, oc, of);
-#ifdef CSI_PAIR_PROBE
-    if (lane == 0 && w < 4096) {
-        unsigned long long* dbg = g_probe + (size_t)w * 16;
-        dbg[8] = wall0; dbg[9] = wall_clock64();
-        dbg[0] = acc0; dbg[1] = acc1; dbg[2] = acc2; dbg[3] = acc3; dbg[4] = acc4; dbg[5] = acc5; dbg[6] = (unsigned long long)(rend - rstart + 1);
-        dbg[7] = __builtin_readcyclecounter();
-    }
-#endif
+    flush(rend - 2);
+    PROBE_END(w * 2 + 1);
 }
 
 }  // namespace fused
 
 #if defined(CSI_PAIR_PROBE) && (!defined(CSI_PAIR_VARIANT) || CSI_PAIR_VARIANT == 0)
 extern "C" int csi_debug_probe(unsigned long long* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_probe), sizeof(unsigned long long) * 4096 * 16);
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_probe), sizeof(unsigned long long) * 8192 * 16);
 }
 #endif
 
@@ -517,10 +587,9 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 // array-forcing variants have one instantiation (kinds read from the table)
 void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool common, int nstrips, int nchunks, int rows,
                    int write_diag, hipStream_t s) {
-    const int nw = nstrips * nchunks;
-    const int nblocks = (nw + 3) / 4;
+    const int nblocks = nstrips * nchunks;              // one workgroup (producer wave + consumer wave) per tile
     const int per_xcd = (nblocks + 7) / 8;
-    dim3 grid((unsigned)(per_xcd * 8)), block(256);
+    dim3 grid((unsigned)(per_xcd * 8)), block(128);
 #define CSI_LAUNCH_PAIR_(U, A, C) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
 #if CSI_PAIR_VARIANT <= 2
 #define CSI_LAUNCH_PAIR(U, A) do { if (common) CSI_LAUNCH_PAIR_(U, A, true); else CSI_LAUNCH_PAIR_(U, A, false); } while (0)

@@ -1,10 +1,18 @@
-"""Debug aid: per-phase cycle counts of csi::fused::k_pair (library built with -DCSI_PAIR_PROBE)."""
-import sys, numpy as np, torch
+"""Debug aid: where the producer and consumer waves of csi::fused::k_pair spend their time
+(library built with -DCSI_PAIR_PROBE: scripts/build_variant.sh probe "-DCSI_PAIR_PROBE"; run with
+CSI_HIP_LIBRARY=.../libcsi_hip_probe.so python scripts/pair_probe.py [NX NY])."""
+import ctypes as C
+import sys
+
+import numpy as np
+
 sys.path.insert(0, ".")
 import bench  # noqa
 import climaseaice_jl_amd as csi
-g = csi.RectilinearGrid((2048, 2048), x=(0, 2048 * 2000.0), y=(0, 2048 * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
-tg, f = bench.local_case(csi, np, 2048, 2048, 1, 1, 0, force_connected=False, halo=4)
+
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+ny = int(sys.argv[2]) if len(sys.argv) > 2 else nx
+tg, f = bench.local_case(csi, np, nx, ny, 1, 1, 0, force_connected=False, halo=4)
 dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
                                  top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
                                  solver=csi.SplitExplicitSolver(substeps=4), device="cuda:0")
@@ -12,33 +20,35 @@ model = csi.SeaIceModel(tg, dynamics=dyn, advection=None, timestepper="ForwardEu
 csi.set_(model, h=f["h"], aice=f["a"], u=f["u"], v=f["v"])
 csi.time_step_momentum(model, 120.0)
 model.synchronize()
-import ctypes as C
 L = C.CDLL(csi._lib.LIB_PATH)
-buf = np.zeros(4096 * 16, dtype=np.uint64)
+buf = np.zeros(8192 * 16, dtype=np.uint64)
 rc = L.csi_debug_probe(buf.ctypes.data_as(C.c_void_p))
-p = buf.reshape(4096, 16)
-p = p[p[:, 6] > 0]
-it = p[:, 6].astype(float)
-names = ["wait vmcnt", "flush", "prefetch issue", "consts + stage A", "stage B", "diag + shifts"]
-print("waves", len(p), "iterations/wave", it.mean())
-tot = 0
-for k, n in enumerate(names):
-    per = (p[:, k] / it)
-    tot += per.mean()
-    print(f"{n:20s} {per.mean():9.0f} ticks/iteration  (min {per.min():.0f} max {per.max():.0f})")
-print("sum", tot, "ticks per iteration; s_memtime ticks: 100 MHz => x10 ns")
-life = p[:, :6].sum(axis=1).astype(float)
-w0, w1 = p[:, 8].astype(float), p[:, 9].astype(float)
-t0 = w0.min()
-print("wall clock (100 MHz): kernel span %.1f us; wave lifetime mean %.1f us (min %.1f max %.1f); cycle-counter lifetime mean %.0f ticks => %.2f GHz"
-      % ((w1.max() - t0) / 100, (w1 - w0).mean() / 100, (w1 - w0).min() / 100, (w1 - w0).max() / 100, life.mean(), life.mean() / ((w1 - w0).mean() * 10) ))
-print("start deciles (us):", (np.percentile(w0 - t0, [0, 10, 25, 50, 75, 90, 100]) / 100).round(1))
-print("end   deciles (us):", (np.percentile(w1 - t0, [0, 10, 25, 50, 75, 90, 100]) / 100).round(1))
-nstr = 37
-lifeus = (w1 - w0) / 100
-nw = len(lifeus)
-chunk = np.arange(nw) // nstr; strip = np.arange(nw) % nstr
-print("mean lifetime by strip:", np.array([lifeus[strip == s_].mean() for s_ in range(nstr)]).round(0))
-print("mean lifetime by chunk:", np.array([lifeus[chunk == c_].mean() for c_ in range(chunk.max() + 1)]).round(0))
-fl = p[:, 1] / it
-print("flush ticks/iter by strip:", np.array([fl[strip == s_].mean() for s_ in range(nstr)]).round(0))
+p = buf.reshape(8192, 16)
+names = {0: ["wait for rows (vmcnt)", "loads issue + stage A + LDS writes", "barrier (wait for consumer)"],
+         1: ["barrier (wait for producer)", "wait vmcnt(0) (inputs + stores)", "stores + prefetch + LDS reads + stage B"]}
+for role in (0, 1):
+    q = p[role::2]
+    q = q[q[:, 6] > 0]
+    it = q[:, 6].astype(float)
+    print(("PRODUCER" if role == 0 else "CONSUMER"), "waves", len(q), "iterations/wave %.1f" % it.mean())
+    tot = 0.0
+    for k, n in enumerate(names[role]):
+        per = q[:, k] / it
+        tot += per.mean()
+        print(f"   {n:45s} {per.mean() * 10:8.0f} ns/iteration  (min {per.min() * 10:.0f} max {per.max() * 10:.0f})")
+    w0, w1 = q[:, 8].astype(float), q[:, 9].astype(float)
+    print("   sum %.0f ns per iteration; wave lifetime mean %.1f us (min %.1f max %.1f); kernel span %.1f us"
+          % (tot * 10, (w1 - w0).mean() / 100, (w1 - w0).min() / 100, (w1 - w0).max() / 100, (w1.max() - w0.min()) / 100))
+    t0 = w0.min()
+    print("   start deciles (us):", (np.percentile(w0 - t0, [0, 10, 50, 90, 100]) / 100).round(1),
+          " end deciles (us):", (np.percentile(w1 - t0, [0, 10, 50, 90, 100]) / 100).round(1))
+    nstr = -(-(nx + 2) // 56)
+    life = (w1 - w0) / 100
+    n = len(life)
+    chunk, strip = np.arange(n) // nstr, np.arange(n) % nstr
+    print("   lifetime percentiles (us):", np.percentile(life, [0, 5, 25, 50, 75, 90, 95, 99, 100]).round(1))
+    print("   mean lifetime by strip:", np.array([life[strip == s_].mean() for s_ in range(nstr)]).round(0))
+    print("   mean lifetime by chunk:", np.array([life[chunk == c_].mean() for c_ in range(chunk.max() + 1)]).round(0))
+    work = q[:, 2 if role else 1] / it
+    print("   work ticks/iteration by strip:", np.array([work[strip == s_].mean() for s_ in range(nstr)]).round(0))
+    print("   work ticks/iteration by chunk:", np.array([work[chunk == c_].mean() for c_ in range(chunk.max() + 1)]).round(0))
