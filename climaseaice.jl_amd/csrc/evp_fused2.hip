@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
                                                               int blocks_per_xcd, int write_diag) {
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[RING_ROWS * 64];
+    __shared__ double outr[2 * 5 * 64];                    // stage B's results on their way to the producer's stores
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
     if (w >= nstrips * nchunks) return;                      // (uniform over the workgroup: both waves leave)
@@ -217,6 +218,113 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
             if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
         }
     };
+    // rows of this tile each kind of store covers (wave-uniform, fixed for the whole march)
+    const int rs_lo = max(ja, T->I[FI_RS + 2]), rs_hi = min(jb, T->I[FI_RS + 3]);
+    const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
+    const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
+    struct OutPtrs { unsigned long s11, s22, s12, u, v; };
+    // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
+    auto yimg = [&](int j) __attribute__((always_inline)) {
+        return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
+    };
+    auto yimg_u = [&](int j) __attribute__((always_inline)) {
+        int d = yimg(j);
+        if (WALLS) {
+            if (ylo_wall & (j >= 1) & (j <= HyW)) d = uval_lo ? ((j == 1) ? -1 : 0) : 1 - 2 * j;
+            if (yhi_wall & (j > NyW - HyW) & (j <= NyW)) d = uval_hi ? ((j == NyW) ? 1 : 0) : 2 * NyW + 1 - 2 * j;
+        }
+        return d;
+    };
+    // one value -> its cell and the halo images of that cell (same semantics as store_with_images); valy / valx: the
+    // value of the y / x image (a ValueBoundaryCondition reflection differs from the cell's own value)
+    auto put4 = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val, double valy, double valx, double valxy) __attribute__((always_inline)) {
+        stg(base, off, val);
+        if (dy != 0u) stg(base, off + dy, valy);
+        if (wave_has_dx) {
+            if (dxl != 0) {
+                stg(base, off + (unsigned)dxl, valx);
+                if (dy != 0u) stg(base, off + (unsigned)dxl + dy, valxy);
+            }
+        }
+    };
+    auto put = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val) __attribute__((always_inline)) {
+        put4(base, off, dy, dxl, val, val, val, val);
+    };
+    // u of row j: its y image is a reflection about 2 val on a ValueBoundaryCondition wall
+    auto put_u = [&](unsigned long base, unsigned off, int j, unsigned dy, double val) __attribute__((always_inline)) {
+        double vy = val;
+        if (WALLS) {
+            if (uval_lo & ylo_wall & (j == 1)) vy = 2 * T->K[FK_BCU] - val;
+            if (uval_hi & yhi_wall & (j == NyW)) vy = 2 * T->K[FK_BCU + 1] - val;
+        }
+        put4(base, off, dy, dx, val, vy, val, vy);
+    };
+    auto put_v = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
+        double vx = val;
+        if (WALLS && wave_valx) {
+            if (flags & L_VAL_LO) vx = 2 * T->K[FK_BCV] - val;
+            if (flags & L_VAL_HI) vx = 2 * T->K[FK_BCV + 1] - val;
+        }
+        put4(base, off, dy, dxv, val, val, vx, vx);
+    };
+    // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
+    // store path (two scalar compares per row instead of the full bookkeeping)
+    int fast_lo, fast_hi;
+    {
+        const int d1 = AUF ? 0 : 1;                                            // first velocity row = q - d1, second = q - 1
+        fast_lo = max(rs_lo, max(r1_lo + d1, r2_lo + 1));
+        fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
+        if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
+        if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
+        if (!lanes_same) fast_hi = fast_lo - 1;
+    }
+    const bool fast_plain = lanes_uniform;                // no lane of the wave has an x image either
+    // Stage B's results of row q (sigma(q); first velocity v(q) / u(q-1); second velocity u(q-1) / v(q-1)) reach memory through
+    // the PRODUCER wave: the consumer hands them over in a two-row LDS ring and the producer stores them two iterations
+    // later.  The consumer has ~10 % more arithmetic-side work per row than the producer and sits on the critical path of
+    // the pair; the stores and their bookkeeping (~50 instructions per row) fill the producer's idle time at the barrier.
+    auto flush = [&](int q, double v11, double v22, double v12, double vfirst, double vsecond) __attribute__((always_inline)) {
+        if ((q >= fast_lo) & (q <= fast_hi)) {
+            // interior rows (nearly every call): every kind of store is due, no row has a y image
+            if (flags & L_RS) {
+                const unsigned ocq = offc(q), ofq = offf(q);
+                if (fast_plain) {
+                    // interior tile: the owned lanes store five values, no images
+                    stg(T->P[FP_S11_OUT], ocq, v11); stg(T->P[FP_S22_OUT], ocq, v22); stg(T->P[FP_S12_OUT], ofq, v12);
+                    stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, vfirst);
+                    stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, vsecond);
+                } else {
+                    // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap; v
+                    // mirrors / reflects across an x wall), none of the row bookkeeping of the general path
+                    put(T->P[FP_S11_OUT], ocq, 0u, dx, v11); put(T->P[FP_S22_OUT], ocq, 0u, dx, v22); put(T->P[FP_S12_OUT], ofq, 0u, dx, v12);
+                    if (AUF) { put_v(T->P[FP_V_OUTP], ocq, 0u, vfirst); put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vsecond, vsecond, vsecond, vsecond); }
+                    else { put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vfirst, vfirst, vfirst, vfirst); put_v(T->P[FP_V_OUTP], ocq - sc, 0u, vsecond); }
+                }
+            }
+            return;
+        }
+        const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
+        const bool do_s = (q >= rs_lo) & (q <= rs_hi), do_1 = (j1 >= r1_lo) & (j1 <= r1_hi), do_2 = (j2 >= r2_lo) & (j2 <= r2_hi);
+        if (!(do_s | do_1 | do_2)) return;
+        const unsigned ocq = offc(q), ofq = offf(q);
+        const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
+        const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
+        OutPtrs P;                                                // adjacent table slots: one wide scalar load
+        P.s11 = T->P[FP_S11_OUT]; P.s22 = T->P[FP_S22_OUT]; P.s12 = T->P[FP_S12_OUT]; P.u = T->P[FP_U_OUTP]; P.v = T->P[FP_V_OUTP];
+        // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
+        const int yq = yimg(q), y1 = AUF ? yimg(j1) : yimg_u(j1), y2 = AUF ? yimg_u(j2) : yimg(j2);
+        if (do_s & ((flags & L_RS) != 0)) {
+            put(P.s11, ocq, (unsigned)yq * sc, dx, v11);
+            put(P.s22, ocq, (unsigned)yq * sc, dx, v22);
+            put(P.s12, ofq, (unsigned)yq * sf, dx, v12);
+        }
+        if (do_1 & ((flags & L_R1) != 0)) {
+            if (AUF) put_v(P.v, o1, (unsigned)y1 * sc, vfirst); else put_u(P.u, o1, j1, (unsigned)y1 * sf, vfirst);
+        }
+        if (do_2 & ((flags & L_R2) != 0)) {
+            if (AUF) put_u(P.u, o2, j2, (unsigned)y2 * sf, vsecond); else put_v(P.v, o2, (unsigned)y2 * sc, vsecond);
+        }
+    };
     // ring slot of row j (lane-private column): element f of row j sits at ring[((j - rstart) & 3) * 5 + f][lane]
     auto rslot = [&](int j) __attribute__((always_inline)) { return (unsigned)((j - rstart) & (RING_ROWS - 1)) * (RING_FIELDS * 64) + (unsigned)lane; };
 
@@ -300,8 +408,12 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
             else __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
             PROBE(pacc0);
             const RowIn& C = R[k];
+            // stage B's results of two iterations ago (rows r - 4 / r - 5): read them now, store them after the prefetch
+            const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
+            const double o11 = outr[so], o22 = outr[so + 64], o12 = outr[so + 128], ofirst = outr[so + 192], osecond = outr[so + 256];
             advance();
             load_row(R[(k + CSI_PAIR_PD) % 3]);           // row r + CSI_PAIR_PD (clamped to rend)
+            flush(r - 4, o11, o22, o12, ofirst, osecond);
             fm::StressConst ks; stress_consts(ks);
             fm::VelConst kv; vel_consts(kv);
             const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
@@ -346,6 +458,13 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
             body(Idx<2>{});
             if (++r > rend) break;
         }
+        // drain: the consumer's last two rows (r = rend + 1: its iteration rend - 1 is complete; one more barrier for rend)
+        for (int d = 0; d < 2; ++d) {
+            const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
+            flush(r - 4, outr[so], outr[so + 64], outr[so + 128], outr[so + 192], outr[so + 256]);
+            if (d == 0) __syncthreads();
+            ++r;
+        }
         PROBE_END(w * 2);
         return;
     }
@@ -360,112 +479,6 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
     B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0;
-    double pend_second = 0.0;
-    // rows of this tile each kind of store covers (wave-uniform, fixed for the whole march)
-    const int rs_lo = max(ja, T->I[FI_RS + 2]), rs_hi = min(jb, T->I[FI_RS + 3]);
-    const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
-    const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
-    struct OutPtrs { unsigned long s11, s22, s12, u, v; };
-    // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
-    auto yimg = [&](int j) __attribute__((always_inline)) {
-        return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
-    };
-    auto yimg_u = [&](int j) __attribute__((always_inline)) {
-        int d = yimg(j);
-        if (WALLS) {
-            if (ylo_wall & (j >= 1) & (j <= HyW)) d = uval_lo ? ((j == 1) ? -1 : 0) : 1 - 2 * j;
-            if (yhi_wall & (j > NyW - HyW) & (j <= NyW)) d = uval_hi ? ((j == NyW) ? 1 : 0) : 2 * NyW + 1 - 2 * j;
-        }
-        return d;
-    };
-    // one value -> its cell and the halo images of that cell (same semantics as store_with_images); valy / valx: the
-    // value of the y / x image (a ValueBoundaryCondition reflection differs from the cell's own value)
-    auto put4 = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val, double valy, double valx, double valxy) __attribute__((always_inline)) {
-        stg(base, off, val);
-        if (dy != 0u) stg(base, off + dy, valy);
-        if (wave_has_dx) {
-            if (dxl != 0) {
-                stg(base, off + (unsigned)dxl, valx);
-                if (dy != 0u) stg(base, off + (unsigned)dxl + dy, valxy);
-            }
-        }
-    };
-    auto put = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val) __attribute__((always_inline)) {
-        put4(base, off, dy, dxl, val, val, val, val);
-    };
-    // u of row j: its y image is a reflection about 2 val on a ValueBoundaryCondition wall
-    auto put_u = [&](unsigned long base, unsigned off, int j, unsigned dy, double val) __attribute__((always_inline)) {
-        double vy = val;
-        if (WALLS) {
-            if (uval_lo & ylo_wall & (j == 1)) vy = 2 * T->K[FK_BCU] - val;
-            if (uval_hi & yhi_wall & (j == NyW)) vy = 2 * T->K[FK_BCU + 1] - val;
-        }
-        put4(base, off, dy, dx, val, vy, val, vy);
-    };
-    auto put_v = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
-        double vx = val;
-        if (WALLS && wave_valx) {
-            if (flags & L_VAL_LO) vx = 2 * T->K[FK_BCV] - val;
-            if (flags & L_VAL_HI) vx = 2 * T->K[FK_BCV + 1] - val;
-        }
-        put4(base, off, dy, dxv, val, val, vx, vx);
-    };
-    // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
-    // store path (two scalar compares per row instead of the full bookkeeping)
-    int fast_lo, fast_hi;
-    {
-        const int d1 = AUF ? 0 : 1;                                            // first velocity row = q - d1, second = q - 1
-        fast_lo = max(rs_lo, max(r1_lo + d1, r2_lo + 1));
-        fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
-        if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
-        if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
-        if (!lanes_same) fast_hi = fast_lo - 1;
-    }
-    const bool fast_plain = lanes_uniform;                // no lane of the wave has an x image either
-    // B's results of the iteration that ran row q are stored at the top of the NEXT iteration (sigma / first velocity are
-    // still in B's window after shift(): S11_m.., Wprev).  The consumer never waits for these stores.
-    auto flush = [&](int q) __attribute__((always_inline)) {
-        if ((q >= fast_lo) & (q <= fast_hi)) {
-            // interior rows (nearly every call): every kind of store is due, no row has a y image
-            if (flags & L_RS) {
-                const unsigned ocq = offc(q), ofq = offf(q);
-                if (fast_plain) {
-                    // interior tile: the owned lanes store five values, no images
-                    stg(T->P[FP_S11_OUT], ocq, B.S11_m); stg(T->P[FP_S22_OUT], ocq, B.S22_m); stg(T->P[FP_S12_OUT], ofq, B.S12_m);
-                    stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, B.Wprev);
-                    stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, pend_second);
-                } else {
-                    // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap; v
-                    // mirrors / reflects across an x wall), none of the row bookkeeping of the general path
-                    put(T->P[FP_S11_OUT], ocq, 0u, dx, B.S11_m); put(T->P[FP_S22_OUT], ocq, 0u, dx, B.S22_m); put(T->P[FP_S12_OUT], ofq, 0u, dx, B.S12_m);
-                    if (AUF) { put_v(T->P[FP_V_OUTP], ocq, 0u, B.Wprev); put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, pend_second, pend_second, pend_second, pend_second); }
-                    else { put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, B.Wprev, B.Wprev, B.Wprev, B.Wprev); put_v(T->P[FP_V_OUTP], ocq - sc, 0u, pend_second); }
-                }
-            }
-            return;
-        }
-        const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
-        const bool do_s = (q >= rs_lo) & (q <= rs_hi), do_1 = (j1 >= r1_lo) & (j1 <= r1_hi), do_2 = (j2 >= r2_lo) & (j2 <= r2_hi);
-        if (!(do_s | do_1 | do_2)) return;
-        const unsigned ocq = offc(q), ofq = offf(q);
-        const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
-        const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
-        OutPtrs P;                                                // adjacent table slots: one wide scalar load
-        P.s11 = T->P[FP_S11_OUT]; P.s22 = T->P[FP_S22_OUT]; P.s12 = T->P[FP_S12_OUT]; P.u = T->P[FP_U_OUTP]; P.v = T->P[FP_V_OUTP];
-        // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
-        const int yq = yimg(q), y1 = AUF ? yimg(j1) : yimg_u(j1), y2 = AUF ? yimg_u(j2) : yimg(j2);
-        if (do_s & ((flags & L_RS) != 0)) {
-            put(P.s11, ocq, (unsigned)yq * sc, dx, B.S11_m);
-            put(P.s22, ocq, (unsigned)yq * sc, dx, B.S22_m);
-            put(P.s12, ofq, (unsigned)yq * sf, dx, B.S12_m);
-        }
-        if (do_1 & ((flags & L_R1) != 0)) {
-            if (AUF) put_v(P.v, o1, (unsigned)y1 * sc, B.Wprev); else put_u(P.u, o1, j1, (unsigned)y1 * sf, B.Wprev);
-        }
-        if (do_2 & ((flags & L_R2) != 0)) {
-            if (AUF) put_u(P.u, o2, j2, (unsigned)y2 * sf, pend_second); else put_v(P.v, o2, (unsigned)y2 * sc, pend_second);
-        }
-    };
     // Stage B's row inputs all come from the ring (the producer read them from memory two or three iterations earlier):
     // the consumer issues no global loads (FORCE: except its forcing arrays), so it never waits for its own stores.
     const int rlo = rstart - 1;
@@ -488,7 +501,6 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
         const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
         vn_delay = vn_new;
         const unsigned bmk = MASK ? ringm[(unsigned)((r - 2 - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] : 0u;
-        flush(q - 1);                                     // (the stores cover the latency of the ring reads above)
         PROBE(pacc1);
         fm::StressConst ks; stress_consts(ks);
         fm::VelConst kv; vel_consts(kv);
@@ -519,7 +531,10 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.step(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB);
-        pend_second = B.second;
+        {
+            const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
+            outr[so] = B.S11_0; outr[so + 64] = B.S22_0; outr[so + 128] = B.S12_0; outr[so + 192] = B.first; outr[so + 256] = B.second;
+        }
         // diagnostics: last launch of the sub-cycle only, stored at once (with their halo images on periodic sides,
         // where the reference computes them from halo data: same values)
         if (write_diag) {
@@ -543,7 +558,7 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
         bodyB(Idx<2>{});
         if (++r > rend) break;
     }
-    flush(rend - 2);
+    __syncthreads();                                      // the last row's results are in the out ring: the producer drains them
     PROBE_END(w * 2 + 1);
 }
 

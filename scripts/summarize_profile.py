@@ -1,4 +1,5 @@
-"""Summarise gpurun_out/prof_<tag> (scripts/profile_bench.sh) into profiles/<name>.md + profiles/traffic_latest.json.
+"""Summarise gpurun_out/prof_<tag> (scripts/profile_bench.sh) into profiles/<name>.md + profiles/counters_latest.json
+(the static PMC evidence bench.py quotes, labelled with its source, in roofline.traffic / roofline.valu_frac).
 
 usage: python scripts/summarize_profile.py <tag> <name> ["note"]
 """
@@ -55,6 +56,15 @@ for k, v in agg.items():
         if c not in ("FETCH_SIZE", "WRITE_SIZE"):
             out.append(f"| {k} | {c} | {x:.4g} |\n")
 open(f"profiles/{name}.md", "w").write("".join(out))
-json.dump({"source": f"profiles/{name}.md", "workload": "2048x2048 periodic f-plane, FAST", "bytes_per_launch": traffic},
-          open("profiles/traffic_latest.json", "w"), indent=1)
+dom = max(traffic, key=lambda k: avg.get(k, 0.0) * 1.0) if traffic else None
+if dom:
+    v = agg[dom]
+    ctr = {"source": f"profiles/{name}.md", "workload": "2048x2048 periodic f-plane, FAST", "kernel": dom,
+           "hbm_bytes_per_launch": traffic[dom], "avg_launch_us": avg[dom]}
+    if "SQ_INSTS_VALU" in v:
+        ctr["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
+    if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
+        # SQ_ACTIVE_INST_VALU: quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs
+        ctr["valu_busy_frac"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0)
+    json.dump(ctr, open("profiles/counters_latest.json", "w"), indent=1)
 print("".join(out))
