@@ -35,9 +35,6 @@
 #ifndef CSI_PAIR_PRIO
 #define CSI_PAIR_PRIO 1         // rotate the user priority of the resident workgroups of a CU every row (see k_pair)
 #endif
-#ifndef CSI_PAIR_FLIP
-#define CSI_PAIR_FLIP 1         // which workgroups swap the roles of their two waves (0: none, 1: odd age rank, 2: rank / 2 odd)
-#endif
 #ifndef CSI_PAIR_PD
 #define CSI_PAIR_PD 1           // rows the producer prefetches ahead (1 or 2; 2 costs 20 more VGPRs)
 #endif
@@ -52,7 +49,8 @@ __device__ unsigned long long g_probe[8192 * 16];
 #define PROBE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
                         __builtin_amdgcn_sched_barrier(0); acc += t_ - ptprev; ptprev = t_; } while (0)
 #define PROBE_END(slot) do { if (lane == 0 && (slot) < 8192) { unsigned long long* dbg = g_probe + (size_t)(slot) * 16; \
-                        dbg[0] = pacc0; dbg[1] = pacc1; dbg[2] = pacc2; dbg[6] = pit; dbg[8] = pwall0; dbg[9] = wall_clock64(); } } while (0)
+                        dbg[0] = pacc0; dbg[1] = pacc1; dbg[2] = pacc2; dbg[6] = pit; dbg[8] = pwall0; dbg[9] = wall_clock64(); \
+                        dbg[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); dbg[11] = (unsigned long long)blockIdx.x; } } while (0)
 #else
 #define PROBE_DECL do { } while (0)
 #define PROBE_START do { } while (0)
@@ -77,12 +75,10 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
     if (w >= nstrips * nchunks) return;                      // (uniform over the workgroup: both waves leave)
-    // Roles: wave 0 produces, wave 1 consumes -- swapped in every other workgroup of a CU (by age rank), so that the SIMDs,
-    // which receive the waves of a workgroup in order, each get a mix of producers and consumers (the consumer has ~10 %
-    // more instructions per row: stores and their bookkeeping).
-    const int age_rank = (int)(((unsigned)b >> 3) >> 5);
-    const int flip = CSI_PAIR_FLIP == 1 ? (age_rank & 1) : (CSI_PAIR_FLIP == 2 ? ((age_rank >> 1) & 1) : 0);
-    const bool consumer = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) ^ flip) != 0;
+    // Roles: wave 0 produces, wave 1 consumes.  (Measured placement of the 12 waves of a CU's six workgroups, in dispatch
+    // order, on its SIMDs a..d: a b | b c | c d | d a | a b | c d -- every SIMD gets producers and consumers, the two waves
+    // of a workgroup never share a SIMD; swapping the roles in some workgroups changed nothing measurable.)
+    const bool consumer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
     const int chunk = w / nstrips, strip = w - chunk * nstrips;
     const int lane = (int)(threadIdx.x & 63);
     tptr_t T = (tptr_t)table;
@@ -206,11 +202,15 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
         kv.min_conc = T->K[FK_MIN_CONC]; kv.has_cor = T->I[FI_HAS_COR];
     };
     // Issue arbitration favours the OLDEST wave of a SIMD: without help the workgroups dispatched first finish after ~2/3 of
-    // the launch and the youngest run on alone (measured: tile lifetimes 100 .. 180 us in one launch).  The workgroups
-    // therefore rotate the user priority every row: dispatch fills the 32 CUs of an XCD before it doubles up, so
-    // (local workgroup index / 32) is the age rank of a workgroup on its CU; rank + row (mod 3) gives every resident wave of
-    // a SIMD the top priority one row in three.
-    const int prio_rank = (int)(((unsigned)b >> 3) >> 5) % 3;
+    // the launch and the youngest run on alone (measured: tile lifetimes 100 .. 180 us in one launch; by age rank on the CU
+    // 115 .. 136 us even with a rotation keyed on the dispatch order, because the allocator does not place ranks r, r + 3 on
+    // different SIMDs).  The waves therefore rotate the user priority every row, keyed on their own slot in the SIMD
+    // (HW_ID.wave_id: the three resident waves of a SIMD hold slots 0, 1, 2): slot + row (mod 3) gives each of them the
+    // top priority one row in three.
+    // (Measured with static priorities: the two youngest workgroups of a CU at a higher priority finish after 77 us, the others
+    // after 108 .. 138 us, the launch still takes 150 us -- the SIMDs are work-conserving, the launch time is set by the
+    // work per SIMD and by how often its three waves stall at the same time, not by the order they finish in.)
+    const int prio_rank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) % 3u);      // HW_REG_HW_ID bits [3:0]
     auto set_prio = [&](int k) __attribute__((always_inline)) {
         if (CSI_PAIR_PRIO) {
             int p = prio_rank + k;

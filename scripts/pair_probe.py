@@ -52,3 +52,33 @@ for role in (0, 1):
     work = q[:, 2 if role else 1] / it
     print("   work ticks/iteration by strip:", np.array([work[strip == s_].mean() for s_ in range(nstr)]).round(0))
     print("   work ticks/iteration by chunk:", np.array([work[chunk == c_].mean() for c_ in range(chunk.max() + 1)]).round(0))
+
+# ---- where the hardware placed the waves (HW_REG_HW_ID: wave_id [3:0], simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]) ----
+hw = p[:, 10].astype(np.int64)
+valid = p[:, 6] > 0
+role = np.arange(8192) % 2
+blk = p[:, 11].astype(np.int64)
+simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+xcd = blk & 7
+rank = (blk >> 3) >> 5
+life = (p[:, 9].astype(float) - p[:, 8].astype(float)) / 100
+key = (((xcd * 8 + se) * 2 + sh) * 16 + cu)
+print("distinct (xcd, se, sh, cu):", len(set(key[valid])))
+import collections
+per_simd = collections.defaultdict(list)
+for idx in np.nonzero(valid)[0]:
+    per_simd[(key[idx], simd[idx])].append((int(rank[idx]), int(role[idx]), float(life[idx])))
+hist = collections.Counter()
+for k, v in per_simd.items():
+    hist[tuple(sorted((r, ro) for r, ro, _ in v))] += 1
+print("most common SIMD populations ((age rank, role) ...):")
+for comp, n in hist.most_common(8):
+    print("   ", n, comp)
+same = sum(1 for idx in range(0, 8192, 2) if valid[idx] and valid[idx + 1] and key[idx] == key[idx + 1] and simd[idx] == simd[idx + 1])
+print("workgroups whose two waves share a SIMD:", same, "of", int(valid.sum() // 2))
+for rk in range(8):
+    sel = valid & (rank == rk)
+    if sel.any():
+        print(f"   age rank {rk}: {sel.sum()} waves, mean lifetime {life[sel].mean():.1f} us")
+wid = hw & 15
+print("HW wave_id histogram:", collections.Counter(wid[valid].tolist()).most_common())
