@@ -13,7 +13,7 @@ from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
 from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected,
                     OrthogonalCurvilinearGrid, Periodic,
                     RectilinearGrid, RightConnected, TileGrid)
-from .model import (FieldBoundaryConditions, MeltingConstrainedFluxBalance, ValueBoundaryCondition, PrescribedTemperature, SeaIceModel, SlabThermodynamics, SnowSlabThermodynamics,
+from .model import (FieldBoundaryConditions, FluxBoundaryCondition, ImmersedBoundaryCondition, MeltingConstrainedFluxBalance, ValueBoundaryCondition, PrescribedTemperature, SeaIceModel, SlabThermodynamics, SnowSlabThermodynamics,
                     snow_slab_thermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -41,11 +41,12 @@ const int kLoc[CSI_F_COUNT][2] = {
     {LOC_F, LOC_C}, {LOC_C, LOC_F}, {LOC_F, LOC_C}, {LOC_C, LOC_F},   // TOP_U TOP_V BOT_U BOT_V
     {LOC_C, LOC_C},                                                   // MASS_FLUX
     {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C},                   // HS GHS HSM
-    {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}};  // MASS_FLUX_SNOW SNOWFALL_INTERCEPTED TU TUS
+    {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C}, {LOC_C, LOC_C},   // MASS_FLUX_SNOW SNOWFALL_INTERCEPTED TU TUS
+    {LOC_F, LOC_C}, {LOC_C, LOC_F}};                                  // FORCING_U FORCING_V
 const char* kName[CSI_F_COUNT] = {"u", "v", "h", "aice", "sigma11", "sigma22", "sigma12", "un", "vn", "P", "alpha",
                                   "Delta", "zeta_f", "zeta_c", "Gh", "Gaice", "h-", "aice-", "u-", "v-",
                                   "top_u", "top_v", "bottom_u", "bottom_v", "mass_flux",
-                                  "hs", "Ghs", "hs-", "mass_flux_snow", "intercepted_snowfall", "Tu", "Tu_snow"};
+                                  "hs", "Ghs", "hs-", "mass_flux_snow", "intercepted_snowfall", "Tu", "Tu_snow", "forcing_u", "forcing_v"};
 
 std::string g_create_error;
 
@@ -108,6 +109,7 @@ struct csi_context {
     int pairing = 1;      // 1: two sub-steps per launch where supported (csi_set_fusion level 2)
     int last_launches = 0, last_substeps = 0, last_used_pairs = 0;   // kernel launches / sub-steps of the last fused sub-cycle
     int last_fused = 0;
+    double ibc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // csi_immersed_flux_bc_set: [u | v][west, east, south, north]
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
 };
 
@@ -261,6 +263,11 @@ EvpDev evp_dev(const csi_context* c, double dt) {
     P.pressure_kind = e.pressure_formulation;
     P.dt = dt;
     P.write_diag = 0;
+    P.has_forcing = (c->f[CSI_F_FORCING_U].p && c->f[CSI_F_FORCING_V].p) ? 1 : 0;
+    if (P.has_forcing) { P.forcing_u = ref_of(c, CSI_F_FORCING_U); P.forcing_v = ref_of(c, CSI_F_FORCING_V); }
+    bool any_ibc = false;
+    for (int k = 0; k < 4; ++k) { P.ibc_u[k] = c->ibc[0][k]; P.ibc_v[k] = c->ibc[1][k]; any_ibc |= (c->ibc[0][k] != 0.0) | (c->ibc[1][k] != 0.0); }
+    P.extra = (P.has_forcing || (any_ibc && c->g.has_mask)) ? 1 : 0;
     P.free_drift = c->free_drift;
     if (c->free_drift && c->fd[0] && c->fd[1]) {
         P.ufd.p = c->fd[0] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * c->f[CSI_F_U].ld; P.ufd.ld = (int)c->f[CSI_F_U].ld;
@@ -524,10 +531,18 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
     G.nstrips = (width + 55) / 56;
     int target = 1536;
-    if (const char* e = getenv("CSI_PAIR_TILES")) target = atoi(e);   // tuning aid
+    bool forced = false;
+    if (const char* e = getenv("CSI_PAIR_TILES")) { target = atoi(e); forced = true; }   // tuning aid
     int max_chunks = target / G.nstrips;
     if (max_chunks < 1) max_chunks = 1;
     int rows = (height + max_chunks - 1) / max_chunks;
+    if (!forced && rows < 16) {
+        // small grids (tiles of a multi-GPU decomposition): the 6 ring rows dominate short tiles; two waves per SIMD
+        // (1024 tiles) with taller tiles beat three (measured: 1024 x 512 tile 35.3 vs 32.4, 1024 x 1024 47.0 vs 45.6 G cell-updates/s)
+        max_chunks = 1024 / G.nstrips;
+        if (max_chunks < 1) max_chunks = 1;
+        rows = (height + max_chunks - 1) / max_chunks;
+    }
     int min_rows = 6;                  // small grids: parallelism beats the 6 ring rows
     if (const char* e = getenv("CSI_PAIR_MINROWS")) min_rows = atoi(e);
     if (rows < min_rows) rows = min_rows;
@@ -822,6 +837,8 @@ int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_re
     // update_external_stress! :133-134: halos of the forcing fields (local boundary conditions, then tiles)
     for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V})
         if (c->f[id].p && (rc = fill_halo(c, id))) return rc;
+    if ((c->f[CSI_F_FORCING_U].p != nullptr) != (c->f[CSI_F_FORCING_V].p != nullptr))
+        return fail(c, CSI_ERR_NOT_BOUND, "model.forcing arrays: bind both CSI_F_FORCING_U and CSI_F_FORCING_V or neither");
     if (is_tiled(c)) {
         int ff[4], n = 0;
         for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V}) if (c->f[id].p) ff[n++] = id;
@@ -1142,6 +1159,14 @@ int32_t csi_field_bind(csi_context* c, int32_t fid, void* dev_ptr, int64_t ld, i
     if (ld > 0x7fffffff) return fail(c, CSI_ERR_INVALID_ARGUMENT, "ld too large");
     if (((uintptr_t)dev_ptr) & 7) return fail(c, CSI_ERR_INVALID_ARGUMENT, "field pointer must be 8-byte aligned");
     c->f[fid].p = (double*)dev_ptr; c->f[fid].ld = ld; c->f[fid].ni = ni; c->f[fid].nj = nj;
+    return CSI_OK;
+}
+
+int32_t csi_immersed_flux_bc_set(csi_context* c, int32_t fid, double west, double east, double south, double north) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (fid != CSI_F_U && fid != CSI_F_V) return fail(c, CSI_ERR_INVALID_ARGUMENT, "immersed flux boundary conditions: CSI_F_U or CSI_F_V");
+    double* q = c->ibc[fid == CSI_F_U ? 0 : 1];
+    q[0] = west; q[1] = east; q[2] = south; q[3] = north;
     return CSI_OK;
 }
 

@@ -73,6 +73,11 @@ struct EvpDev {
     FRef ufd, vfd;            // free-drift velocities at u / v points (library scratch, once per sub-cycle)
     double dt;
     int write_diag;   // FAST: also store zeta_c, zeta_f, Delta (last sub-step only)
+    // rarely used terms of the velocity tendencies (three-kernel paths only; `extra` = any of them present):
+    int extra;
+    int has_forcing;          // model.forcing.u / .v as arrays (user_forcing of sum_of_forcing_u / _v, evp:391-401)
+    FRef forcing_u, forcing_v;
+    double ibc_u[4], ibc_v[4];   // immersed FluxBoundaryCondition numbers of u / v: west, east, south, north (isd:65-123)
 };
 
 struct Range { int i0, i1, j0, j1; };
@@ -108,6 +113,33 @@ __device__ __forceinline__ bool immersed_peripheral_ff(const GridDev& g, int i, 
     bool pu = inactive_cell_underlying(g, i, j) | inactive_cell_underlying(g, i - 1, j) |
               inactive_cell_underlying(g, i, j - 1) | inactive_cell_underlying(g, i - 1, j - 1);
     return p && !pu;
+}
+
+// ---- immersed_dj_sigma_1j / _2j with FluxBoundaryCondition numbers (ice_stress_divergence.jl:65-123): the stress on an
+// immersed face is -flux (west, south) / +flux (east, north); conditional_flux_* picks it where the node is an immersed
+// peripheral node; index_left / index_right: Face -> (i - 1, i), Center -> (i, i + 1).  Single-layer grid, dz = 1:
+// Ax = dy, Ay = dx, V = Az.  Reference operation order (used by STRICT and FAST alike: the term is rare).
+__device__ __forceinline__ double immersed_div_sigma_1(const EvpDev& P, int i, int j) {
+    const GridDev& g = P.g;
+    if (!g.has_mask) return 0.0;
+    const double qtW = -P.ibc_u[0], qtE = P.ibc_u[1], qtS = -P.ibc_u[2], qtN = P.ibc_u[3];
+    const int iW = i - 1, iE = i, jS = j, jN = j + 1;
+    const double qW = (immersed_peripheral_cc(g, iW, j) ? qtW : 0.0) * dym(g, LOC_C, LOC_C, iW, j);
+    const double qE = (immersed_peripheral_cc(g, iE, j) ? qtE : 0.0) * dym(g, LOC_C, LOC_C, iE, j);
+    const double qS = (immersed_peripheral_ff(g, i, jS) ? qtS : 0.0) * dxm(g, LOC_F, LOC_F, i, jS);
+    const double qN = (immersed_peripheral_ff(g, i, jN) ? qtN : 0.0) * dxm(g, LOC_F, LOC_F, i, jN);
+    return (qE - qW + qN - qS) / azm(g, LOC_F, LOC_C, i, j);
+}
+__device__ __forceinline__ double immersed_div_sigma_2(const EvpDev& P, int i, int j) {
+    const GridDev& g = P.g;
+    if (!g.has_mask) return 0.0;
+    const double qtW = -P.ibc_v[0], qtE = P.ibc_v[1], qtS = -P.ibc_v[2], qtN = P.ibc_v[3];
+    const int iW = i, iE = i + 1, jS = j - 1, jN = j;
+    const double qW = (immersed_peripheral_ff(g, iW, j) ? qtW : 0.0) * dym(g, LOC_F, LOC_F, iW, j);
+    const double qE = (immersed_peripheral_ff(g, iE, j) ? qtE : 0.0) * dym(g, LOC_F, LOC_F, iE, j);
+    const double qS = (immersed_peripheral_cc(g, i, jS) ? qtS : 0.0) * dxm(g, LOC_C, LOC_C, i, jS);
+    const double qN = (immersed_peripheral_cc(g, i, jN) ? qtN : 0.0) * dxm(g, LOC_C, LOC_C, i, jN);
+    return (qE - qW + qN - qS) / azm(g, LOC_C, LOC_F, i, j);
 }
 
 // ---- fused local halo fill: the thread that owns interior element (i, j) also writes the halo

@@ -179,11 +179,12 @@ __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img,
         if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
     }
     const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
-    const double div = fm::div1(coef<UNI>(c, FC_E, j), coef<UNI>(c, FC_FN, j), coef<UNI>(c, FC_FS, j), s11_0, s11_m, s12_p, s12_0);
+    double div = fm::div1(coef<UNI>(c, FC_E, j), coef<UNI>(c, FC_FN, j), coef<UNI>(c, FC_FS, j), s11_0, s11_m, s12_p, s12_0);
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
-    const double cor = coef<UNI>(c, FC_FU, j) * vbar;         // -x_f_cross_U = +f vbar (f = 0 without Coriolis)
+    double cor = coef<UNI>(c, FC_FU, j) * vbar;               // -x_f_cross_U = +f vbar (f = 0 without Coriolis)
+    if (P.extra) { if (P.has_forcing) cor += P.forcing_u(i, j); div += immersed_div_sigma_1(P, i, j); }   // model.forcing.u; immersed flux BCs
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
         ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
@@ -207,12 +208,13 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
         if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
     }
     const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
-    const double div = fm::div2<UNI>(coef<UNI>(c, FC_Q1N, j), coef<UNI>(c, FC_Q2N, j), coef<UNI>(c, FC_Q1S, j), coef<UNI>(c, FC_Q2S, j),
+    double div = fm::div2<UNI>(coef<UNI>(c, FC_Q1N, j), coef<UNI>(c, FC_Q2N, j), coef<UNI>(c, FC_Q1S, j), coef<UNI>(c, FC_Q2S, j),
                                 coef<UNI>(c, FC_K, j), s11_0, s22_0, s11_m, s22_m, s12_p, s12_0);
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
-    const double cor = -coef<UNI>(c, FC_FV, j) * ubar;       // -y_f_cross_U = -f ubar
+    double cor = -coef<UNI>(c, FC_FV, j) * ubar;             // -y_f_cross_U = -f ubar
+    if (P.extra) { if (P.has_forcing) cor += P.forcing_v(i, j); div += immersed_div_sigma_2(P, i, j); }
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
         ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))
@@ -294,11 +296,12 @@ __global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img
     const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
     const double east = fm::fma_(c2(c, C2_A11E, i, j), s11_0, fm::fma_(c2(c, C2_A22E, i, j), s22_0, c2(c, C2_A12N, i, j) * s12_p));
     const double west = fm::fma_(c2(c, C2_A11W, i, j), s11_m, fm::fma_(c2(c, C2_A22W, i, j), s22_m, c2(c, C2_A12S, i, j) * s12_0));
-    const double div = east - west;
+    double div = east - west;
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
-    const double cor = (P.fcor_u ? P.fcor_u[j] : P.fcor) * vbar;
+    double cor = (P.fcor_u ? P.fcor_u[j] : P.fcor) * vbar;
+    if (P.extra) { if (P.has_forcing) cor += P.forcing_u(i, j); div += immersed_div_sigma_1(P, i, j); }
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
         ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
@@ -324,11 +327,12 @@ __global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img
     const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
     const double north = fm::fma_(c2(c, C2_B11N, i, j), s11_0, fm::fma_(c2(c, C2_B22N, i, j), s22_0, c2(c, C2_B12E, i, j) * s12_p));
     const double south = fm::fma_(c2(c, C2_B11S, i, j), s11_m, fm::fma_(c2(c, C2_B22S, i, j), s22_m, c2(c, C2_B12W, i, j) * s12_0));
-    const double div = north - south;
+    double div = north - south;
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
-    const double cor = -(P.fcor_v ? P.fcor_v[j] : P.fcor) * ubar;
+    double cor = -(P.fcor_v ? P.fcor_v[j] : P.fcor) * ubar;
+    if (P.extra) { if (P.has_forcing) cor += P.forcing_v(i, j); div += immersed_div_sigma_2(P, i, j); }
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
         ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))

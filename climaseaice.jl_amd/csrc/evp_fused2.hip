@@ -35,6 +35,9 @@
 #ifndef CSI_PAIR_PRIO
 #define CSI_PAIR_PRIO 1         // rotate the user priority of the resident workgroups of a CU every row (see k_pair)
 #endif
+#ifndef CSI_PAIR_HOIST
+#define CSI_PAIR_HOIST 0        // 1: let the compiler keep the table constants in SGPRs across rows (no per-row reload fence)
+#endif
 #ifndef CSI_PAIR_PD
 #define CSI_PAIR_PD 1           // rows the producer prefetches ahead (1 or 2; 2 costs 20 more VGPRs)
 #endif
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
         int r = rstart;
         auto body = [&](auto KK) __attribute__((always_inline)) {
             constexpr int k = decltype(KK)::value;
-            asm volatile("" : "+s"(T));
+            if (!CSI_PAIR_HOIST || FORCE) asm volatile("" : "+s"(T));
             set_prio(k);
             PROBE_START;
             // rows r and r + 1 are in flight (loads return in order; FORCE: the array loads of the previous iteration were
@@ -486,7 +489,7 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
     double vn_delay = 0.0;                                // B u-first: v^n of row q - 1 (read one iteration earlier as row q)
     int r = rstart;
     auto bodyB = [&](auto KK) __attribute__((always_inline)) {
-        asm volatile("" : "+s"(T));
+        if (!CSI_PAIR_HOIST || FORCE) asm volatile("" : "+s"(T));
         set_prio(decltype(KK)::value);
         const int q = r - 2;
         PROBE_START;

@@ -259,8 +259,9 @@ __global__ void k_ustep(EvpDev P, Range r, ImageSpec im) {
         cor = -(P.fcor_u ? P.fcor_u[j] : P.fcor) * AVG4_FC(V_);     // FPlane / BetaPlane (f at this row's u points)
 #undef V_
     }
-    double forcing = 0.0 + (P.un(i, j) - P.u(i, j)) / dtau / abar;   // sum_of_forcing_u, evp:391-395
-    double imm = 0.0 / mi;
+    const double user = P.has_forcing ? P.forcing_u(i, j) : 0.0;    // model.forcing.u as an array
+    double forcing = user + (P.un(i, j) - P.u(i, j)) / dtau / abar;  // sum_of_forcing_u, evp:391-395
+    double imm = immersed_div_sigma_1(P, i, j) / mi;                  // zero(grid) / FluxBoundaryCondition numbers, isd:57-85
     double G = (-cor
                 - explicit_tau_x(P, P.top, i, j) / mi * ai
                 + explicit_tau_x(P, P.bot, i, j) / mi * ai
@@ -293,8 +294,9 @@ __global__ void k_vstep(EvpDev P, Range r, ImageSpec im) {
         cor = (P.fcor_v ? P.fcor_v[j] : P.fcor) * AVG4_CF(U_);
 #undef U_
     }
-    double forcing = 0.0 + (P.vn(i, j) - P.v(i, j)) / dtau / abar;
-    double imm = 0.0 / mi;
+    const double user = P.has_forcing ? P.forcing_v(i, j) : 0.0;
+    double forcing = user + (P.vn(i, j) - P.v(i, j)) / dtau / abar;
+    double imm = immersed_div_sigma_2(P, i, j) / mi;
     double G = (-cor
                 - explicit_tau_y(P, P.top, i, j) / mi * ai
                 + explicit_tau_y(P, P.bot, i, j) / mi * ai

@@ -30,8 +30,35 @@ class FieldBoundaryConditions:
     """FieldBoundaryConditions(north =, south =, west =, east =): sides left out keep the default (no-flux for the
     tangential velocity, impenetrable for the normal one).  Used as SeaIceModel(boundary_conditions = dict(u =, v =))."""
 
-    def __init__(self, north=None, south=None, west=None, east=None):
-        self.north, self.south, self.west, self.east = north, south, west, east
+    def __init__(self, north=None, south=None, west=None, east=None, immersed=None):
+        self.north, self.south, self.west, self.east, self.immersed = north, south, west, east, immersed
+
+
+class FluxBoundaryCondition:
+    """Oceananigans FluxBoundaryCondition(number)."""
+
+    def __init__(self, value=0.0):
+        self.value = float(value)
+
+
+class ImmersedBoundaryCondition:
+    """ImmersedBoundaryCondition(west =, east =, south =, north =) of FluxBoundaryConditions with number values: the
+    stresses the ice feels on immersed faces (ice_stress_divergence.jl:65-123).  Passed as
+    SeaIceModel(boundary_conditions = dict(u = FieldBoundaryConditions(immersed = ImmersedBoundaryCondition(...)), ...))."""
+
+    def __init__(self, west=None, east=None, south=None, north=None):
+        self.west, self.east, self.south, self.north = west, east, south, north
+
+    def values(self):
+        out = []
+        for bc in (self.west, self.east, self.south, self.north):
+            if bc is None:
+                out.append(0.0)
+            elif isinstance(bc, FluxBoundaryCondition):
+                out.append(bc.value)
+            else:
+                raise NotImplementedError("immersed boundary conditions: FluxBoundaryCondition(number) or None")
+        return out
 
 
 class PrescribedTemperature:
@@ -125,12 +152,13 @@ def _dptr(a):
 class SeaIceModel:
     def __init__(self, grid, dynamics=None, advection=None, timestepper="SplitRungeKutta3", sea_ice_density=900.0,
                  ice_thermodynamics=None, snow_thermodynamics=None, snow_density=330.0, snowfall=0.0,
-                 boundary_conditions=None, device="cuda:0", mode="fast", stream=None):
+                 boundary_conditions=None, forcing=None, device="cuda:0", mode="fast", stream=None):
         self.grid = grid
         self.dynamics = dynamics
         self.advection = advection
         self.ice_thermodynamics = ice_thermodynamics
         self.boundary_conditions = boundary_conditions or {}
+        self.forcing = forcing          # dict(u = array-like, v = array-like): model.forcing given as arrays (m s^-2)
         self.snow_thermodynamics = snow_thermodynamics
         self.snow_density, self.snowfall = float(snow_density), float(snowfall)
         if snow_thermodynamics is not None and ice_thermodynamics is None:
@@ -235,6 +263,18 @@ class SeaIceModel:
                 if bc is not None and not isinstance(bc, ValueBoundaryCondition):
                     raise NotImplementedError("velocity boundary conditions: ValueBoundaryCondition or the default")
                 self.ctx.call("csi_velocity_bc_set", _lib.F[name], k, 0 if bc is None else 1, 0.0 if bc is None else bc.value)
+            imm = getattr(bcs, "immersed", None) if bcs is not None else None
+            self.ctx.call("csi_immersed_flux_bc_set", _lib.F[name], *(imm.values() if imm is not None else (0.0, 0.0, 0.0, 0.0)))
+        # model.forcing = (u = array, v = array): user forcing of the velocity tendencies (sum_of_forcing_u / _v)
+        if self.forcing is not None:
+            fu, fv = self.forcing["u"], self.forcing["v"]
+            self.forcing_fields = SimpleNamespace(u=XFaceField(g, self.device, "forcing_u"), v=YFaceField(g, self.device, "forcing_v"))
+            self.forcing_fields.u.set(fu); self.forcing_fields.v.set(fv)
+            self._bind("FORCING_U", self.forcing_fields.u)
+            self._bind("FORCING_V", self.forcing_fields.v)
+            torch.cuda.synchronize(self.device)
+            self.ctx.call("csi_fill_halo_local", _lib.F["FORCING_U"])
+            self.ctx.call("csi_fill_halo_local", _lib.F["FORCING_V"])
         d = self.dynamics
         if d is None:
             return

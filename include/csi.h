@@ -112,6 +112,9 @@ typedef enum {
     CSI_F_SNOWFALL_INTERCEPTED, /* (c,c) mass_fluxes.intercepted_snowfall (optional) */
     CSI_F_TU,         /* (c,c) ice_thermodynamics.top_surface_temperature (optional output) */
     CSI_F_TUS,        /* (c,c) snow_thermodynamics.top_surface_temperature (optional output) */
+    CSI_F_FORCING_U,  /* (f,c) model.forcing.u given as an array: the `user_forcing` of sum_of_forcing_u
+                       * (elasto_visco_plastic_rheology.jl:391-395), an acceleration in m s^-2; optional, both or neither */
+    CSI_F_FORCING_V,  /* (c,f) model.forcing.v (:397-401) */
     CSI_F_COUNT
 } csi_field_id;
 
@@ -201,6 +204,12 @@ int32_t csi_stress_set(csi_context* ctx, int32_t side, const csi_stress* s);
  * App. B; a13 of the scope table).  Sides that are not walls ignore it.  Every path takes it (the fused kernels
  * reflect about 2 * value where they otherwise mirror). */
 int32_t csi_velocity_bc_set(csi_context* ctx, int32_t field_id, int32_t side, int32_t kind, double value);
+/* Immersed boundary conditions of u / v: ImmersedBoundaryCondition(west = FluxBoundaryCondition(number), ...) entering
+ * immersed_dj_sigma_1j / immersed_dj_sigma_2j (ice_stress_divergence.jl:65-123; the stress is minus the flux on west / south
+ * faces and plus the flux on east / north faces, :115-123).  field_id CSI_F_U or CSI_F_V; all zeros (the default) is the
+ * reference's default `nothing`.  Non-zero values need a mask (csi_mask_set) to have any effect and run the three-kernel
+ * paths (the fused kernels take the default only). */
+int32_t csi_immersed_flux_bc_set(csi_context* ctx, int32_t field_id, double west, double east, double south, double north);
 /* Row-dependent Coriolis parameter: BetaPlane, f = f0 + beta * ynode (upstream x_f_cross_U / y_f_cross_U called at
  * momentum_tendencies_kernel_functions.jl:31,64; in the reference's test matrix, test/test_time_stepping.jl:35).
  * f_u: f at the (Face, Center) nodes of each row (u points), f_v: at the (Center, Face) nodes (v points); HOST

@@ -378,6 +378,37 @@ double ora_free_drift_u(const ora_problem* g, int i, int j) { return free_drift_
 double ora_free_drift_v(const ora_problem* g, int i, int j) { return free_drift_v(g, i, j); }
 
 /* ------------------------------------------------------------------------ */
+/* immersed_dj_sigma_1j / _2j, ice_stress_divergence.jl:65-107, with            */
+/* FluxBoundaryCondition NUMBERS on the immersed boundary (:115-123: the stress */
+/* is minus the flux on west / south faces, plus the flux on east / north).     */
+/* conditional_flux_*(i, j, k, ibg, ib_flux, intrinsic): the immersed flux      */
+/* where the node is an immersed peripheral node, else `intrinsic` (zero here). */
+/* index_left / index_right (upstream): Face -> (i - 1, i), Center -> (i, i + 1).*/
+/* Areas and volumes of a single-layer grid with dz = 1: Ax = dy, Ay = dx,      */
+/* V = Az (dz cancels between the areas and the volume).                         */
+/* ------------------------------------------------------------------------ */
+double ora_immersed_div_sigma_1(const ora_problem* g, int i, int j) {
+    if (!g->has_mask) return 0.0;                                            /* isd:57: zero(grid) on a non-immersed grid */
+    double qtW = -g->ibc_u[0], qtE = g->ibc_u[1], qtS = -g->ibc_u[2], qtN = g->ibc_u[3];   /* :115-123 */
+    int iW = i - 1, iE = i, jS = j, jN = j + 1;                             /* index_left / _right of (f, c) :72-73 */
+    double qW = (immersed_peripheral_cc(g, iW, j) ? qtW : 0.0) * ora_dy(g, C_, C_, iW, j);     /* :76 Ax^{ccc} */
+    double qE = (immersed_peripheral_cc(g, iE, j) ? qtE : 0.0) * ora_dy(g, C_, C_, iE, j);
+    double qS = (immersed_peripheral_ff(g, i, jS) ? qtS : 0.0) * ora_dx(g, F_, F_, i, jS);     /* :78 Ay^{ffc} */
+    double qN = (immersed_peripheral_ff(g, i, jN) ? qtN : 0.0) * ora_dx(g, F_, F_, i, jN);
+    return (qE - qW + qN - qS) / ora_az(g, F_, C_, i, j);                    /* :81 / V^{fcc} */
+}
+double ora_immersed_div_sigma_2(const ora_problem* g, int i, int j) {
+    if (!g->has_mask) return 0.0;
+    double qtW = -g->ibc_v[0], qtE = g->ibc_v[1], qtS = -g->ibc_v[2], qtN = g->ibc_v[3];
+    int iW = i, iE = i + 1, jS = j - 1, jN = j;                             /* (c, f) :94-95 */
+    double qW = (immersed_peripheral_ff(g, iW, j) ? qtW : 0.0) * ora_dy(g, F_, F_, iW, j);     /* :98 Ax^{ffc} */
+    double qE = (immersed_peripheral_ff(g, iE, j) ? qtE : 0.0) * ora_dy(g, F_, F_, iE, j);
+    double qS = (immersed_peripheral_cc(g, i, jS) ? qtS : 0.0) * ora_dx(g, C_, C_, i, jS);     /* :100 Ay^{ccc} */
+    double qN = (immersed_peripheral_cc(g, i, jN) ? qtN : 0.0) * ora_dx(g, C_, C_, i, jN);
+    return (qE - qW + qN - qS) / ora_az(g, C_, F_, i, j);                    /* :106 / V^{cfc} */
+}
+
+/* ------------------------------------------------------------------------ */
 /* u_velocity_tendency, momentum_tendencies_kernel_functions.jl:11-41         */
 /* ------------------------------------------------------------------------ */
 static double u_tendency(const ora_problem* g, int i, int j, double dtau) {
@@ -391,9 +422,10 @@ static double u_tendency(const ora_problem* g, int i, int j, double dtau) {
 #undef V_
     }
     double abar = (AT(g, g->alpha, i - 1, j) + AT(g, g->alpha, i, j)) / 2;  /* Ix^f(alpha), evp:393 */
-    /* sum_of_forcing_u, evp:391-395: user forcing (zero) + (un - u) / dt / Ix(alpha), with dt := dtau */
-    double forcing = 0.0 + (AT(g, g->un, i, j) - AT(g, g->u, i, j)) / dtau / abar;
-    double imm = 0.0 / mi;                                                   /* immersed_dj_sigma_1j == zero(grid), isd:57 (bcs TODO upstream :103-112) */
+    /* sum_of_forcing_u, evp:391-395: user forcing (zero, or an array value) + (un - u) / dt / Ix(alpha), with dt := dtau */
+    double user = g->has_forcing ? AT(g, g->forcing_u, i, j) : 0.0;
+    double forcing = user + (AT(g, g->un, i, j) - AT(g, g->u, i, j)) / dtau / abar;
+    double imm = ora_immersed_div_sigma_1(g, i, j) / mi;                     /* isd:57 (zero) / :65-85 with FluxBoundaryCondition numbers */
     double G = (-cor
                 - explicit_tau_x(g, &g->top, i, j) / mi * ai
                 + explicit_tau_x(g, &g->bottom, i, j) / mi * ai
@@ -413,8 +445,9 @@ static double v_tendency(const ora_problem* g, int i, int j, double dtau) {  /* 
 #undef U_
     }
     double abar = (AT(g, g->alpha, i, j - 1) + AT(g, g->alpha, i, j)) / 2;  /* evp:399 */
-    double forcing = 0.0 + (AT(g, g->vn, i, j) - AT(g, g->v, i, j)) / dtau / abar;
-    double imm = 0.0 / mi;
+    double user = g->has_forcing ? AT(g, g->forcing_v, i, j) : 0.0;
+    double forcing = user + (AT(g, g->vn, i, j) - AT(g, g->v, i, j)) / dtau / abar;
+    double imm = ora_immersed_div_sigma_2(g, i, j) / mi;
     double G = (-cor
                 - explicit_tau_y(g, &g->top, i, j) / mi * ai
                 + explicit_tau_y(g, &g->bottom, i, j) / mi * ai

@@ -110,6 +110,13 @@ typedef struct {
      * cell, c[0] = 2 val - c[1]; deeper halo cells are left alone.  Default (on = 0): no-flux mirror. */
     int32_t u_value_on[2], v_value_on[2];
     double u_value[2], v_value[2];
+    /* model.forcing.u / .v given as arrays (the `user_forcing` of sum_of_forcing_u / _v, evp:391-401): values at the
+     * (f,c) / (c,f) points, parent-shaped like u / v; has_forcing = 0: the reference's default (zero forcing). */
+    int32_t has_forcing, pad_forcing;
+    ora_field forcing_u, forcing_v;
+    /* Immersed FluxBoundaryConditions of u and v with NUMBER values, [0..3] = west, east, south, north
+     * (immersed_dj_sigma_1j / _2j, ice_stress_divergence.jl:65-123): all zero = the reference's default. */
+    double ibc_u[4], ibc_v[4];
 } ora_problem;
 
 /* ---- grid metric accessors (Oceananigans operators) ---- */
@@ -123,6 +130,8 @@ double ora_strain_yy(const ora_problem* g, int i, int j);   /* :374 */
 double ora_strain_xy(const ora_problem* g, int i, int j);   /* :375 */
 double ora_div_sigma_1(const ora_problem* g, int i, int j); /* ice_stress_divergence.jl:39-44 */
 double ora_div_sigma_2(const ora_problem* g, int i, int j); /* ice_stress_divergence.jl:46-51 */
+double ora_immersed_div_sigma_1(const ora_problem* g, int i, int j); /* :65-85, FluxBoundaryCondition numbers :115-123 */
+double ora_immersed_div_sigma_2(const ora_problem* g, int i, int j); /* :87-107 */
 /* pre-v0.5.8 flux-form divergence kept by the reference's own test for contrast
  * (test/test_rheology_energy_budget.jl:22-32) */
 double ora_old_div_sigma_1(const ora_problem* g, int i, int j);

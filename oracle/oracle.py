@@ -71,7 +71,10 @@ class ProblemStruct(C.Structure):
                  ("top", Stress), ("bottom", Stress)] +
                 [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("pad_snow", C.c_int32),
                                                       ("u_value_on", C.c_int32 * 2), ("v_value_on", C.c_int32 * 2),
-                                                      ("u_value", C.c_double * 2), ("v_value", C.c_double * 2)])
+                                                      ("u_value", C.c_double * 2), ("v_value", C.c_double * 2),
+                                                      ("has_forcing", C.c_int32), ("pad_forcing", C.c_int32),
+                                                      ("forcing_u", Field), ("forcing_v", Field),
+                                                      ("ibc_u", C.c_double * 4), ("ibc_v", C.c_double * 4)])
 
 
 class Slab(C.Structure):
@@ -276,6 +279,26 @@ class Problem:
         on, val = getattr(self.s, field + "_value_on"), getattr(self.s, field + "_value")
         on[side] = 0 if value is None else 1
         val[side] = 0.0 if value is None else float(value)
+
+    def set_forcing(self, fu, fv):
+        """model.forcing = (u = array, v = array): parent-shaped arrays at the u / v points (None, None: no forcing)."""
+        if fu is None:
+            self.s.has_forcing = 0
+            return
+        for name, val, like in (("forcing_u", fu, "u"), ("forcing_v", fv, "v")):
+            a = np.ascontiguousarray(val, dtype=np.float64)
+            assert a.shape == self.f[like].shape, (name, a.shape)
+            self._keep.append(a)
+            fld = getattr(self.s, name)
+            fld.p = _dptr(a)
+            fld.ld = a.shape[1]
+        self.s.has_forcing = 1
+
+    def set_immersed_flux_bc(self, field, west=0.0, east=0.0, south=0.0, north=0.0):
+        """ImmersedBoundaryCondition(west = FluxBoundaryCondition(number), ...) of "u" or "v"."""
+        arr = getattr(self.s, "ibc_" + field)
+        for k, val in enumerate((west, east, south, north)):
+            arr[k] = float(val)
 
     def set_coriolis(self, f, rows=None):
         """f: None | FPlane f.  rows = (fu, fv): BetaPlane values per row (entry for row j at [j + Hy - 1],

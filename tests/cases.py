@@ -14,12 +14,15 @@ import climaseaice_jl_amd as csi
 def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinear", spacing=2000.0,
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
-              field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None, noslip=False):
+              field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None, noslip=False,
+              user_forcing=False, immersed_bc=None):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
              free_drift=free_drift, beta=beta,     # beta: BetaPlane(f0 = coriolis, beta)
-             noslip=noslip)                        # ValueBoundaryCondition(0) on the tangential velocity at every wall
+             noslip=noslip,                        # ValueBoundaryCondition(0) on the tangential velocity at every wall
+             user_forcing=user_forcing,            # model.forcing.u / .v as arrays
+             immersed_bc=immersed_bc)              # ((uW, uE, uS, uN), (vW, vE, vS, vN)): immersed FluxBoundaryCondition numbers
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded}
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
@@ -69,6 +72,10 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
         h = np.where(wet, h, 0.0)
         a = np.where(wet, a, 0.0)
     c.update(h=h, a=a, u=u, v=v)
+    if user_forcing:
+        # an acceleration of a few 1e-6 m s^-2 (comparable to the Coriolis term), smooth + seeded noise
+        c["force_u"] = 3e-6 * np.sin(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 1e-6 * rng.standard_normal((nyu, nxu))
+        c["force_v"] = -2e-6 * np.cos(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1)) + 1e-6 * rng.standard_normal((nyv, nxv))
     if field_forcing:
         c["top_u"] = 0.01 * (1 + 0.5 * np.sin(2 * np.pi * X)) * np.ones((nyu, 1))[:, :1] * np.ones((1, 1))
         c["top_u"] = np.broadcast_to(0.01 * (1 + 0.5 * np.sin(2 * np.pi * np.linspace(0, 1, nxu)))[None, :], (nyu, nxu)).copy()
@@ -139,6 +146,13 @@ def oracle_problem(case, omp=False):
             p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
     if case.get("free_drift"):
         p.s.free_drift_kind = 1                     # StressBalanceFreeDrift on the model's own stresses
+    if case.get("user_forcing"):
+        fu = _fill_parent_like(p, "u", case["force_u"]); fv = _fill_parent_like(p, "v", case["force_v"])
+        p.set_forcing(fu, fv)
+    if case.get("immersed_bc"):
+        (uw, ue_, us, un_), (vw, ve_, vs, vn_) = case["immersed_bc"]
+        p.set_immersed_flux_bc("u", uw, ue_, us, un_)
+        p.set_immersed_flux_bc("v", vw, ve_, vs, vn_)
     if case.get("mask") is not None:
         s_ = p.s
         full = np.zeros(p.f["h"].shape, dtype=np.uint8)
@@ -186,10 +200,22 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
                                      rheology=rheo, top_momentum_stress=top, bottom_momentum_stress=bottom,
                                      free_drift=csi.StressBalanceFreeDrift() if case.get("free_drift") else None,
                                      solver=csi.SplitExplicitSolver(substeps=case["substeps"]), device=device)
+    ubc, vbc_ = {}, {}
     if case.get("noslip"):
         vbc = csi.ValueBoundaryCondition(0.0)
-        model_kw = dict(model_kw, boundary_conditions=dict(u=csi.FieldBoundaryConditions(north=vbc, south=vbc),
-                                                           v=csi.FieldBoundaryConditions(west=vbc, east=vbc)))
+        ubc.update(north=vbc, south=vbc); vbc_.update(west=vbc, east=vbc)
+    if case.get("immersed_bc"):
+        F = csi.FluxBoundaryCondition
+        (uw, ue_, us, un_), (vw, ve_, vs, vn_) = case["immersed_bc"]
+        ubc["immersed"] = csi.ImmersedBoundaryCondition(west=F(uw), east=F(ue_), south=F(us), north=F(un_))
+        vbc_["immersed"] = csi.ImmersedBoundaryCondition(west=F(vw), east=F(ve_), south=F(vs), north=F(vn_))
+    if ubc or vbc_:
+        model_kw = dict(model_kw, boundary_conditions=dict(u=csi.FieldBoundaryConditions(**ubc), v=csi.FieldBoundaryConditions(**vbc_)))
+    if case.get("user_forcing"):
+        fu, fv = case["force_u"], case["force_v"]
+        if tile is not None:
+            fu, fv = g.local_interior(fu, csi.Face, csi.Center), g.local_interior(fv, csi.Center, csi.Face)
+        model_kw = dict(model_kw, forcing=dict(u=fu, v=fv))
     model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode, **model_kw)
     if case.get("field_forcing"):
         for slot in ("TOP", "BOT"):

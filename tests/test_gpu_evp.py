@@ -79,10 +79,18 @@ CASES = {
     "noslip_coastline": dict(Nx=72, Ny=48, topo=("periodic", "bounded"), patches=False, random_uv=0.03, noslip=True, land=0.2,
                              field_forcing=True),
     "beta_masked": dict(Nx=96, Ny=80, topo=("periodic", "bounded"), patches=True, random_uv=0.03, beta=2e-10, land=0.25),
+    # model.forcing.u / .v given as arrays (user_forcing of sum_of_forcing_u / _v, elasto_visco_plastic_rheology.jl:391-401)
+    "user_forcing": dict(Nx=72, Ny=56, topo=("periodic", "periodic"), patches=True, random_uv=0.05, user_forcing=True),
+    "user_forcing_latlon": dict(Nx=56, Ny=48, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, user_forcing=True, land=0.2),
+    # immersed FluxBoundaryCondition numbers on u and v (ice_stress_divergence.jl:65-123)
+    "immersed_flux_bc": dict(Nx=80, Ny=64, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.3,
+                             immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))),
+    "immersed_flux_bc_curvilinear": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.03, land=0.25, curvilinear=0.05,
+                                         immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)), user_forcing=True),
 }
 MASKED = {"noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = set()
+THREE_KERNEL_ONLY = {"user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}   # rare tendency terms: never fused
 
 
 def ulp_diff(a, b):
@@ -395,7 +403,8 @@ def test_pair_kernel_on_tiles_halo32_interval16(topo):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
-FUSED_CASES = ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
+EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear"})
+FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
                ] + sorted(MASKED)

@@ -447,3 +447,58 @@ def test_rk3_stages_without_advection_reset_the_tracers(oracle_lib):
     h1, a1, _ = O.slab_step(h0.ravel(), a0.ravel(), c["dt"], Tu=-5.0, top_flux_kind=0, Qu=100.0, Qb=10.0)
     assert np.array_equal(p.interior("h").ravel(), h1) and np.array_equal(p.interior("aice").ravel(), a1)
     assert np.abs(h1 - h0.ravel()).max() > 1e-6
+
+
+def test_immersed_flux_bc_and_user_forcing_terms(oracle_lib):
+    """Rare terms of the velocity tendencies (momentum_tendencies_kernel_functions.jl:31-36): the immersed-boundary stress
+    divergence with FluxBoundaryCondition numbers (ice_stress_divergence.jl:65-123) and array-valued model.forcing
+    (elasto_visco_plastic_rheology.jl:391-401).  Closed forms on a uniform grid: next to ONE immersed cell the u point
+    west of it sees (q_E * dy) / (dx dy) with q_E = +east flux, the u point east of it -(−west flux) ... ; zeros reproduce
+    the default bit for bit; a user forcing F moves u by dtau * F / (1 + dtau * tau_i) in one sub-step."""
+    import cases
+    import oracle as O
+    c = cases.make_case(Nx=24, Ny=20, substeps=1, topo=("periodic", "periodic"), patches=False, random_uv=0.02)
+    wet = np.ones((20, 24), dtype=bool)
+    wet[10, 12] = False                          # one immersed cell: (i, j) = (13, 11) in 1-based indices
+    c["mask"] = wet
+    c["h"] = np.where(wet, c["h"], 0.0); c["a"] = np.where(wet, c["a"], 0.0)
+    p = cases.oracle_problem(c)
+    L = p.L
+    L.ora_immersed_div_sigma_1.restype = O.C.c_double; L.ora_immersed_div_sigma_1.argtypes = [O.C.POINTER(O.ProblemStruct), O.C.c_int, O.C.c_int]
+    L.ora_immersed_div_sigma_2.restype = O.C.c_double; L.ora_immersed_div_sigma_2.argtypes = [O.C.POINTER(O.ProblemStruct), O.C.c_int, O.C.c_int]
+    dx = dy = 2000.0
+    assert L.ora_immersed_div_sigma_1(p.ptr, 13, 11) == 0.0          # default: zero everywhere
+    p.set_immersed_flux_bc("u", west=0.3, east=0.5, south=0.0, north=0.0)
+    p.set_immersed_flux_bc("v", west=0.0, east=0.0, south=0.7, north=1.1)
+    # u point i = 13 has the immersed cell on its EAST side (cell iE = 13): +east flux * Ax / V
+    assert np.isclose(L.ora_immersed_div_sigma_1(p.ptr, 13, 11), 0.5 * dy / (dx * dy), rtol=1e-15)
+    # u point i = 14 has it on its WEST side (cell iW = 13): -(−west flux) * Ax / V
+    assert np.isclose(L.ora_immersed_div_sigma_1(p.ptr, 14, 11), 0.3 * dy / (dx * dy), rtol=1e-15)
+    assert L.ora_immersed_div_sigma_1(p.ptr, 10, 5) == 0.0
+    # v point j = 11 has the cell on its NORTH side (jN = 11), j = 12 on its SOUTH side (jS = 11)
+    assert np.isclose(L.ora_immersed_div_sigma_2(p.ptr, 13, 11), 1.1 * dx / (dx * dy), rtol=1e-15)
+    assert np.isclose(L.ora_immersed_div_sigma_2(p.ptr, 13, 12), 0.7 * dx / (dx * dy), rtol=1e-15)
+    # zeros == default, bit for bit, through a whole sub-cycle
+    c10 = dict(c, substeps=10)
+    a = cases.oracle_problem(c10); a.time_step_momentum(c["dt"])
+    b = cases.oracle_problem(dict(c10, immersed_bc=((0, 0, 0, 0), (0, 0, 0, 0)))); b.time_step_momentum(c["dt"])
+    for k in ("u", "v", "s11", "s12"):
+        assert np.array_equal(a.f[k], b.f[k])
+    d = cases.oracle_problem(dict(c10, immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)))); d.time_step_momentum(c["dt"])
+    assert not np.array_equal(a.f["u"], d.f["u"]) and np.all(np.isfinite(d.f["u"]))
+    # locality: after 2 sub-steps (dependency radius 2 cells each, SURVEY.md A.5) the difference stays within 5 cells
+    c2 = dict(c, substeps=2)
+    a2 = cases.oracle_problem(c2); a2.time_step_momentum(c["dt"])
+    d2 = cases.oracle_problem(dict(c2, immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)))); d2.time_step_momentum(c["dt"])
+    far = np.ones_like(wet); far[4:17, 6:20] = False
+    assert np.array_equal(a2.interior("u")[far], d2.interior("u")[far]) and not np.array_equal(a2.interior("u"), d2.interior("u"))
+    # user forcing: one sub-step, u' - u'_0 = dtau F / (1 + dtau tau_i) with the same dtau, tau_i (they depend on the old state)
+    c1 = cases.make_case(Nx=24, Ny=20, substeps=1, topo=("periodic", "periodic"), patches=False, random_uv=0.02)
+    q0 = cases.oracle_problem(c1); q0.time_step_momentum(c1["dt"])
+    c1f = cases.make_case(Nx=24, Ny=20, substeps=1, topo=("periodic", "periodic"), patches=False, random_uv=0.02, user_forcing=True)
+    q1 = cases.oracle_problem(c1f); q1.time_step_momentum(c1f["dt"])
+    du = q1.interior("u") - q0.interior("u")
+    F = c1f["force_u"]
+    ratio = du / F                                                      # = dtau / (1 + dtau tau_i) > 0, about dt / alpha
+    assert np.all(ratio > 0) and np.all(ratio < c1["dt"] / 50.0 * 1.05)     # (u sees the forced v through the Coriolis term: a few 1e-4 relative)
+    assert np.all(np.isfinite(q1.f["v"]))
