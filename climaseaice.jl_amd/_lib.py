@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("CSI_HIP_LIBRARY", os.path.join(_HERE, "libcsi_hip.so"
 
 # ---- enums (include/csi.h) ---------------------------------------------------------------------
 OK = 0
-PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3, 4
+PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED, RIGHT_FOLDED, LEFT_CONNECTED_RIGHT_FOLDED = 0, 1, 2, 3, 4, 5, 6
 METRIC_UNIFORM, METRIC_PER_J, METRIC_FULL = 0, 1, 2
 FIELD_IDS = ["U", "V", "H", "A", "S11", "S22", "S12", "UN", "VN", "P", "ALPHA", "DELTA", "ZETA_F", "ZETA_C",
              "GH", "GA", "HM", "AM", "UM", "VM", "TOP_U", "TOP_V", "BOT_U", "BOT_V", "MASS_FLUX",

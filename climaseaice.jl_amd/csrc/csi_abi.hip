@@ -132,7 +132,8 @@ int side_lo(int topo) {
         case CSI_BOUNDED: return SIDE_WALL;
         case CSI_FULLY_CONNECTED: return SIDE_CONNECTED;
         case CSI_LEFT_CONNECTED: return SIDE_CONNECTED;
-        default: return SIDE_WALL;   // RIGHT_CONNECTED: low side is the wall
+        case CSI_LEFT_CONNECTED_RIGHT_FOLDED: return SIDE_CONNECTED;
+        default: return SIDE_WALL;   // RIGHT_CONNECTED, RIGHT_FOLDED: low side is the wall
     }
 }
 int side_hi(int topo) {
@@ -141,12 +142,15 @@ int side_hi(int topo) {
         case CSI_BOUNDED: return SIDE_WALL;
         case CSI_FULLY_CONNECTED: return SIDE_CONNECTED;
         case CSI_LEFT_CONNECTED: return SIDE_WALL;
+        case CSI_RIGHT_FOLDED: return SIDE_FOLD;
+        case CSI_LEFT_CONNECTED_RIGHT_FOLDED: return SIDE_FOLD;
         default: return SIDE_CONNECTED;
     }
 }
 int img_of(int side, int loc) {
     if (side == SIDE_PERIODIC) return IMG_WRAP;
     if (side == SIDE_WALL) return loc == LOC_C ? IMG_MIRROR : IMG_NONE;
+    if (side == SIDE_FOLD) return IMG_FOLD;
     return IMG_NONE;
 }
 ImageSpec image_spec(const csi_context* c, int fid) {
@@ -158,6 +162,10 @@ ImageSpec image_spec(const csi_context* c, int fid) {
     im.ex = (kLoc[fid][0] == LOC_F && c->g.xhi == SIDE_WALL) ? 1 : 0;
     im.ey = (kLoc[fid][1] == LOC_F && c->g.yhi == SIDE_WALL) ? 1 : 0;
     im.vxlo = im.vxhi = im.vylo = im.vyhi = 0.0;
+    // Zipper (north fold): vector components change sign (sea_ice_model.jl:57-64 for u, v; the stress / ocean-velocity /
+    // forcing arrays at the velocity points are built with the same boundary conditions, test/distributed_tests_utils.jl:196-197)
+    im.fold_fx = kLoc[fid][0] == LOC_F; im.fold_fy = kLoc[fid][1] == LOC_F;
+    im.fold_sign = (kLoc[fid][0] != kLoc[fid][1]) ? -1 : 1;       // (f,c) and (c,f) fields are all velocity-like here
     // ValueBoundaryCondition on the tangential velocity at a wall replaces the no-flux mirror (one halo cell)
     if (fid == CSI_F_U) {
         if (im.ylo == IMG_MIRROR && c->vel_bc_on[0][0]) { im.ylo = IMG_VALUE; im.vylo = c->vel_bc_value[0][0]; }
@@ -1052,7 +1060,9 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
                      int32_t metric_kind, const csi_metrics* m) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     if (Nx < 1 || Ny < 1 || Hx < 1 || Hy < 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "grid sizes must be >= 1");
-    if (topo_x < CSI_PERIODIC || topo_x > CSI_RIGHT_CONNECTED || topo_y < CSI_PERIODIC || topo_y > CSI_RIGHT_CONNECTED)
+    if ((topo_y == CSI_RIGHT_FOLDED || topo_y == CSI_LEFT_CONNECTED_RIGHT_FOLDED) && topo_x != CSI_PERIODIC)
+        return fail(c, CSI_ERR_UNSUPPORTED, "a north fold needs a Periodic, unpartitioned x direction (Partition(1, Ry))");
+    if (topo_x < CSI_PERIODIC || topo_x > CSI_RIGHT_CONNECTED || topo_y < CSI_PERIODIC || topo_y > CSI_LEFT_CONNECTED_RIGHT_FOLDED)
         return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown topology");
     if (!m) return fail(c, CSI_ERR_INVALID_ARGUMENT, "metrics == NULL");
     if (metric_kind != CSI_METRIC_UNIFORM && metric_kind != CSI_METRIC_PER_J && metric_kind != CSI_METRIC_FULL)

@@ -7,9 +7,9 @@
 
 namespace csi {
 
-enum : int { SIDE_PERIODIC = 0, SIDE_WALL = 1, SIDE_CONNECTED = 2 };
+enum : int { SIDE_PERIODIC = 0, SIDE_WALL = 1, SIDE_CONNECTED = 2, SIDE_FOLD = 3 };   // SIDE_FOLD: north fold of a TripolarGrid (yhi only)
 enum : int { LOC_C = 0, LOC_F = 1 };
-enum : int { IMG_NONE = 0, IMG_WRAP = 1, IMG_MIRROR = 2, IMG_VALUE = 3 };
+enum : int { IMG_NONE = 0, IMG_WRAP = 1, IMG_MIRROR = 2, IMG_VALUE = 3, IMG_FOLD = 4 };
 
 struct FRef {
     double* p;   // element (0, 0) in reference indexing
@@ -151,6 +151,8 @@ struct ImageSpec {
     int xlo, xhi, ylo, yhi;   // IMG_* per side
     int ex, ey;               // 1: the field has an extra column / row of points on a high wall (Face location): the
                               // wall faces have images in the OTHER direction like any interior point
+    int fold_sign;            // yhi == IMG_FOLD (Zipper): +1 / -1 (velocity components)
+    int fold_fx, fold_fy;     // ... and the field's location (1 = Face) in x / y
     double vxlo, vxhi, vylo, vyhi;   // IMG_VALUE sides (ValueBoundaryCondition on a tangential velocity): the first halo
                                      // cell holds 2 * value - c[first interior cell]; deeper halo cells are left alone
 };
@@ -174,8 +176,24 @@ __device__ __forceinline__ void store_with_images(const FRef& f, const GridDev& 
     // its neighbours), y-images for interior rows; corners are the product of the two.
     const bool in_x = (i >= 1) & (i <= g.Nx), in_y = (j >= 1) & (j <= g.Ny);
     const bool near_x = in_x & ((i <= g.Hx) | (i > g.Nx - g.Hx));
-    const bool near_y = in_y & ((j <= g.Hy) | (j > g.Ny - g.Hy));
+    const bool fold = im.yhi == IMG_FOLD;
+    const bool near_y = in_y & ((j <= g.Hy) | (j > g.Ny - g.Hy - (fold ? 1 : 0)));
     if (!(near_x | near_y)) return;
+    if (fold & in_x & in_y) {
+        // North fold (Zipper; recalled upstream semantics, oracle/csi_oracle.c fold_north): the owner of (i, j) writes
+        //   c[it, 2 Ny - j] (Center in y, rows Ny-Hy .. Ny-1) / c[it, 2 Ny + 1 - j] (Face in y, rows Ny-Hy+1 .. Ny)
+        // with it = Nx - i + 1 (Center in x) / Nx - i + 2 (Face in x; column 1 folds onto itself without the sign change),
+        // and the periodic x images of that target column.
+        const int jt = im.fold_fy ? 2 * g.Ny + 1 - j : 2 * g.Ny - j;
+        if ((jt > g.Ny) & (jt <= g.Ny + g.Hy)) {
+            int it = im.fold_fx ? g.Nx - i + 2 : g.Nx - i + 1;
+            double w = (double)im.fold_sign * val;
+            if (it > g.Nx) { it -= g.Nx; w = fabs((double)im.fold_sign) * val; }
+            f(it, jt) = w;
+            if (it <= g.Hx) f(it + g.Nx, jt) = w;
+            if (it > g.Nx - g.Hx) f(it - g.Nx, jt) = w;
+        }
+    }
     int xi[3], yj[3];
     double cx[3], cy[3];          // image value = c - val (c = 2 * bc value on an IMG_VALUE side), or val itself (c = NaN marker unused)
     bool fx[3], fy[3];            // the image is a ValueBoundaryCondition reflection

@@ -297,7 +297,7 @@ static bool fused_offsets_fit(const EvpDev& P) {
 }
 int pair_forcing_kind(const EvpDev& P) {
     if (P.g.metric_kind == 2) return -1;
-    if (P.extra) return -1;                                   // model.forcing arrays / immersed flux BCs: three kernels
+    if (P.extra || P.g.yhi == SIDE_FOLD) return -1;           // model.forcing arrays / immersed flux BCs / north fold: three kernels
     const int lc = P.h.ld, lf = P.u.ld;
     if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return -1;
     if (P.un.ld != lf || P.s12.ld != lf) return -1;
@@ -335,7 +335,7 @@ bool fused_supported(const EvpDev& P) {
     if (!fused_offsets_fit(P)) return false;
     // first version: no immersed mask, forcing given by numbers (the benchmark configuration); everything else
     // runs the three-kernel FAST path
-    if (P.g.has_mask || P.free_drift || P.g.metric_kind == 2 || P.extra) return false;   // (full 2-D metrics: three-kernel path)
+    if (P.g.has_mask || P.free_drift || P.g.metric_kind == 2 || P.extra || P.g.yhi == SIDE_FOLD) return false;   // (north fold: three kernels)   // (full 2-D metrics: three-kernel path)
     // per-row metrics with a periodic y side: ring rows beyond the seam would not reproduce their owners
     if (P.g.metric_kind != 0 && (P.g.ylo == SIDE_PERIODIC || P.g.yhi == SIDE_PERIODIC)) return false;
     auto ok = [](const StressDev& s) {

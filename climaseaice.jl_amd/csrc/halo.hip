@@ -20,8 +20,9 @@ __global__ void k_fill_halo(FRef f, GridDev g, ImageSpec im, int strip) {
     if (strip == 0) {
         i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
         int jj = blockIdx.y * blockDim.y + threadIdx.y;      // 0 .. 2Hy-1 (+1: the wall-face row Ny+1 of a Face-y field)
-        if (i > Nx + im.ex || jj >= 2 * Hy + im.ey) return;
-        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 + jj;          // rows 1..Hy and Ny-Hy+1..Ny(+1)
+        const int fo = im.yhi == IMG_FOLD ? 1 : 0;            // a fold also images row Ny - Hy (Center in y)
+        if (i > Nx + im.ex || jj >= 2 * Hy + im.ey + fo) return;
+        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 - fo + jj;      // rows 1..Hy and Ny-Hy+1(-1)..Ny(+1)
         if (j < 1 || j > Ny + im.ey || (jj >= Hy && j <= Hy)) return; // overlap when Ny < 2Hy
     } else {
         int ii = blockIdx.x * blockDim.x + threadIdx.x;      // 0 .. 2Hx-1
@@ -35,7 +36,7 @@ __global__ void k_fill_halo(FRef f, GridDev g, ImageSpec im, int strip) {
 
 void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipStream_t s) {
     dim3 b(64, 4);
-    unsigned gx0 = (unsigned)((g.Nx + im.ex + 63) / 64), gy0 = (unsigned)((2 * g.Hy + im.ey + 3) / 4);
+    unsigned gx0 = (unsigned)((g.Nx + im.ex + 63) / 64), gy0 = (unsigned)((2 * g.Hy + im.ey + 1 + 3) / 4);
     hipLaunchKernelGGL(k_fill_halo, dim3(gx0, gy0, 1), b, 0, s, f, g, im, 0);
     int mid = g.Ny - 2 * g.Hy;
     if (mid > 0) {
@@ -54,8 +55,9 @@ __global__ void k_fill_halo_batch(HaloBatch B, GridDev g, int strip) {
     if (strip == 0) {
         i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
         int jj = blockIdx.y * blockDim.y + threadIdx.y;
-        if (i > Nx + im.ex || jj >= 2 * Hy + im.ey) return;
-        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 + jj;
+        const int fo = im.yhi == IMG_FOLD ? 1 : 0;
+        if (i > Nx + im.ex || jj >= 2 * Hy + im.ey + fo) return;
+        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 - fo + jj;
         if (j < 1 || j > Ny + im.ey || (jj >= Hy && j <= Hy)) return;
     } else {
         int ii = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,7 +71,7 @@ __global__ void k_fill_halo_batch(HaloBatch B, GridDev g, int strip) {
 void launch_fill_halo_batch(const HaloBatch& B, const GridDev& g, hipStream_t s) {
     if (B.n <= 0) return;
     dim3 b(64, 4);
-    unsigned gx0 = (unsigned)((g.Nx + 1 + 63) / 64), gy0 = (unsigned)((2 * g.Hy + 1 + 3) / 4);
+    unsigned gx0 = (unsigned)((g.Nx + 1 + 63) / 64), gy0 = (unsigned)((2 * g.Hy + 2 + 3) / 4);
     hipLaunchKernelGGL(k_fill_halo_batch, dim3(gx0, gy0, (unsigned)B.n), b, 0, s, B, g, 0);
     int mid = g.Ny - 2 * g.Hy;
     if (mid > 0) {

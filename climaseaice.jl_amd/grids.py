@@ -31,6 +31,15 @@ class RightConnected:
     """Low side is a wall (the first tile of a Bounded direction), high side exchanged."""
 
 
+class RightFolded:
+    """y topology of a TripolarGrid: the low side is a wall (southernmost latitude), the high side is the north fold,
+    filled by the Zipper boundary condition (sea_ice_model.jl:57-64)."""
+
+
+class LeftConnectedRightFolded:
+    """The northernmost tile of a y partition of a RightFolded direction: low side exchanged, high side folded."""
+
+
 class Center:
     pass
 
@@ -41,9 +50,11 @@ class Face:
 
 def _topo2(topology):
     t = tuple(topology)[:2]
-    for x in t:
-        if x not in (Periodic, Bounded):
-            raise ValueError("horizontal topology must be Periodic or Bounded")
+    for k, x in enumerate(t):
+        if x not in (Periodic, Bounded) and not (k == 1 and x is RightFolded):
+            raise ValueError("horizontal topology must be Periodic or Bounded (y may also be RightFolded)")
+    if t[1] is RightFolded and t[0] is not Periodic:
+        raise ValueError("a RightFolded y direction needs a Periodic x direction")
     return t
 
 
@@ -61,7 +72,7 @@ def local_topology(T, r, R):
     if r == 0:
         return RightConnected
     if r == R - 1:
-        return LeftConnected
+        return LeftConnectedRightFolded if T is RightFolded else LeftConnected
     return FullyConnected
 
 
@@ -171,6 +182,27 @@ class LatitudeLongitudeGrid(_Grid2D):
         return dict(kind="per_j", dy=self.dy, dxc=self.dxc, dxf=self.dxf, azc=self.azc, azf=self.azf)
 
 
+def fold_north(a, Nx, Ny, Hx, Hy, face_x, face_y, sign=1):
+    """The Zipper (north fold) halo fill of one parent-shaped array, in numpy (upstream semantics as recalled in
+    oracle/csi_oracle.c fold_north: c[i, Ny + j] = s c[i', Ny - j (+1 if Face in y)], i' = Nx - i + 1 (+1 if Face in x,
+    column 1 onto itself without the sign change); x halos of the folded rows periodic).  a[j + Hy - 1, i + Hx - 1] is
+    element (i, j).  Used for fold-consistent metric arrays and as an independent check of the C / HIP fills."""
+    a = np.array(a, dtype=np.float64, copy=True)
+    i = np.arange(1, Nx + 1)
+    ip = Nx - i + (2 if face_x else 1)
+    s = np.full(Nx, float(sign))
+    s[ip > Nx] = abs(float(sign))
+    ip = np.where(ip > Nx, ip - Nx, ip)
+    for m in range(1, Hy + 1):
+        js = Ny - m + (1 if face_y else 0)
+        row = s * a[js + Hy - 1, ip + Hx - 1]
+        a[Ny + m + Hy - 1, i + Hx - 1] = row
+        for k in range(1, Hx + 1):
+            a[Ny + m + Hy - 1, (1 - k) + Hx - 1] = a[Ny + m + Hy - 1, (Nx + 1 - k) + Hx - 1]
+            a[Ny + m + Hy - 1, (Nx + k) + Hx - 1] = a[Ny + m + Hy - 1, k + Hx - 1]
+    return a
+
+
 # order of the twelve 2-D metric arrays of an orthogonal curvilinear grid (include/csi.h, CSI_METRIC_FULL)
 METRIC_NAMES = [w + l for w in ("dx", "dy", "az") for l in ("cc", "fc", "cf", "ff")]
 
@@ -227,6 +259,10 @@ class OrthogonalCurvilinearGrid(_Grid2D):
             for k, name in enumerate(METRIC_NAMES):
                 ph = rng.random(2) * 2 * np.pi
                 out[name] = out[name] * (1.0 + distort * np.sin(2 * np.pi * ii + ph[0]) * np.cos(2 * np.pi * jj + ph[1]))
+        if g.topology[1] is RightFolded:
+            # metric halos beyond the fold are the fold images of the interior metrics (a grid folded onto itself)
+            for name in METRIC_NAMES:
+                out[name] = fold_north(out[name], g.Nx, g.Ny, g.Hx, g.Hy, name[2] == "f", name[3] == "f", 1)
         return cls((g.Nx, g.Ny), out, topology=g.topology, halo=(g.Hx, g.Hy), nodes=(g.xnodes, g.ynodes, g._ynode))
 
     def xnodes(self, LX):

@@ -16,7 +16,8 @@ import torch
 from . import _lib
 from .dynamics import (ElastoViscoPlasticRheology, FPlane, IceStrength, SeaIceMomentumEquation, SemiImplicitStress)
 from .fields import CenterField, Field, XFaceField, YFaceField
-from .grids import METRIC_NAMES, Bounded, FullyConnected, LeftConnected, Periodic, RightConnected, TileGrid
+from .grids import (METRIC_NAMES, Bounded, FullyConnected, LeftConnected, LeftConnectedRightFolded, Periodic, RightConnected,
+                    RightFolded, TileGrid)
 
 
 class ValueBoundaryCondition:
@@ -142,7 +143,8 @@ class UpwindBiased:
 
 
 _TOPO = {Periodic: _lib.PERIODIC, Bounded: _lib.BOUNDED, FullyConnected: _lib.FULLY_CONNECTED,
-         LeftConnected: _lib.LEFT_CONNECTED, RightConnected: _lib.RIGHT_CONNECTED}
+         LeftConnected: _lib.LEFT_CONNECTED, RightConnected: _lib.RIGHT_CONNECTED,
+         RightFolded: _lib.RIGHT_FOLDED, LeftConnectedRightFolded: _lib.LEFT_CONNECTED_RIGHT_FOLDED}
 
 
 def _dptr(a):
@@ -406,6 +408,9 @@ class SeaIceModel:
         if G.topology[1] is Periodic:
             full[:G.Hy, :] = full[G.Ny:G.Ny + G.Hy, :]
             full[G.Ny + G.Hy:, :] = full[G.Hy:2 * G.Hy, :]
+        if G.topology[1] is RightFolded:              # cells beyond the north fold are images of real cells
+            from .grids import fold_north
+            full = fold_north(full, G.Nx, G.Ny, G.Hx, G.Hy, False, False, 1).astype(np.uint8)
         if isinstance(g, TileGrid):
             full = np.ascontiguousarray(full[g.j_off:g.j_off + g.Ny + 2 * g.Hy, g.i_off:g.i_off + g.Nx + 2 * g.Hx])
         self.mask = torch.from_numpy(full).to(self.device)

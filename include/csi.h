@@ -51,7 +51,14 @@ typedef enum {
     CSI_BOUNDED = 1,
     CSI_FULLY_CONNECTED = 2,
     CSI_LEFT_CONNECTED = 3,   /* low side exchanged, high side Bounded */
-    CSI_RIGHT_CONNECTED = 4   /* low side Bounded, high side exchanged */
+    CSI_RIGHT_CONNECTED = 4,  /* low side Bounded, high side exchanged */
+    /* y direction of a TripolarGrid: low side Bounded (the southernmost latitude), high side the north FOLD filled by the
+     * Zipper boundary condition (sea_ice_model.jl:57-64: u, v change sign across the fold, every other field does not;
+     * upstream fold semantics recalled in SURVEY.md App. B / oracle/csi_oracle.c fold_north).  x must be Periodic (or, on
+     * tiles, not partitioned: the reference's own distributed tripolar test uses Partition(1, 4),
+     * test/distributed_tests_utils.jl:239).  The fused kernels do not take folds: three-kernel paths. */
+    CSI_RIGHT_FOLDED = 5,
+    CSI_LEFT_CONNECTED_RIGHT_FOLDED = 6   /* the northernmost tile of a y partition of such a grid */
 } csi_topology;
 
 typedef enum {

@@ -54,7 +54,8 @@ double ora_az(const ora_problem* g, int lx, int ly, int i, int j) {
 /* walls of a (tile of a) domain: Bounded has both; a tile at the end of a Bounded direction has one
  * (ORA_RIGHT_CONNECTED: low side wall, ORA_LEFT_CONNECTED: high side wall; connected sides are filled by the
  * halo exchange of the multi-process tests, never by a local boundary condition) */
-static int wall_lo(int topo) { return topo == ORA_BOUNDED || topo == ORA_RIGHT_CONNECTED; }
+static int wall_lo(int topo) { return topo == ORA_BOUNDED || topo == ORA_RIGHT_CONNECTED || topo == ORA_RIGHT_FOLDED; }
+static int fold_hi(int topo) { return topo == ORA_RIGHT_FOLDED || topo == ORA_LEFT_CONNECTED_RIGHT_FOLDED; }
 static int wall_hi(int topo) { return topo == ORA_BOUNDED || topo == ORA_LEFT_CONNECTED; }
 static int outside_walls(const ora_problem* g, int i, int j) {
     if ((wall_lo(g->topo_x) && i < 1) || (wall_hi(g->topo_x) && i > g->Nx)) return 1;
@@ -517,13 +518,36 @@ void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int b
     static const double zero[2] = {0.0, 0.0};
     fill_halo4v(g, f, bxlo, bxhi, bylo, byhi, zero, zero);
 }
+/* North fold of a TripolarGrid (upstream Zipper boundary condition; RECALLED semantics, SURVEY.md App. B -- Oceananigans is
+ * not under /root/reference): the fold runs through the cell CENTRES of row Ny ("the Ny line is duplicated"), so for
+ * j = 1 .. Hy and i = 1 .. Nx
+ *     c[i, Ny + j] = s * c[i', Ny - j]      Center in y          c[i, Ny + j] = s * c[i', Ny - j + 1]      Face in y
+ *     i' = Nx - i + 1  (Center in x)        i' = Nx - i + 2  (Face in x; i' = Nx + 1 is column 1 again: there s := |s|)
+ * with s = -1 for the velocity components (sea_ice_model.jl:57-64 flips the default) and +1 otherwise; x is Periodic, and
+ * the x halos of the folded rows are filled from the folded rows (x pass over rows 1..Ny, fold, x pass over the fold rows). */
+static void fold_north(const ora_problem* g, ora_field f, int lx, int ly, int sign) {
+    int Nx = g->Nx, Ny = g->Ny, Hx = g->Hx, Hy = g->Hy;
+    for (int m = 1; m <= Hy; ++m) {
+        int js = (ly == C_) ? Ny - m : Ny - m + 1;
+        for (int i = 1; i <= Nx; ++i) {
+            int ip = (lx == C_) ? Nx - i + 1 : Nx - i + 2;
+            double s = (double)sign;
+            if (ip > Nx) { ip -= Nx; s = fabs(s); }
+            AT(g, f, i, Ny + m) = s * AT(g, f, ip, js);
+        }
+        for (int k = 1; k <= Hx; ++k) {                    /* periodic x images of the folded row */
+            AT(g, f, 1 - k, Ny + m) = AT(g, f, Nx + 1 - k, Ny + m);
+            AT(g, f, Nx + k, Ny + m) = AT(g, f, k, Ny + m);
+        }
+    }
+}
 /* vx / vy: values of ORA_BC_VALUE sides ([0] low, [1] high) */
 static void fill_halo4v(const ora_problem* g, ora_field f, int bxlo, int bxhi, int bylo, int byhi, const double* vx, const double* vy) {
     int Nx = g->Nx, Ny = g->Ny, Hx = g->Hx, Hy = g->Hy;
     /* x sides over the interior rows (upstream order: x first, then y over the whole x extent); on a tile
      * whose y side is connected (no local y pass there) the rows beyond it are included, because the ring
      * rows recomputed for the neighbours need their x images too. */
-    int jlo = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_LEFT_CONNECTED) ? 1 - Hy : 1;
+    int jlo = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_LEFT_CONNECTED || g->topo_y == ORA_LEFT_CONNECTED_RIGHT_FOLDED) ? 1 - Hy : 1;
     int jhi = (g->topo_y == ORA_FULLY_CONNECTED || g->topo_y == ORA_RIGHT_CONNECTED) ? Ny + Hy : Ny;
     /* a Face-in-y field on a high y wall has one more row of points (the wall faces, row Ny + 1): its x images too */
     if (wall_hi(g->topo_y) && byhi == ORA_BC_NONE && bylo == ORA_BC_NONE) jhi = Ny + 1;
@@ -555,27 +579,35 @@ void ora_fill_halo(const ora_problem* g, ora_field f, int lx, int ly, int bcx, i
 }
 static int bc_side(int topo, int loc, int high) {
     if (topo == ORA_PERIODIC) return ORA_BC_PERIODIC;
+    if (high && fold_hi(topo)) return ORA_BC_FOLD;
     int wall = high ? wall_hi(topo) : wall_lo(topo);
     if (!wall) return ORA_BC_NONE;              /* connected: left to the exchange */
     return loc == C_ ? ORA_BC_MIRROR : ORA_BC_NONE;
 }
-static void fill_loc(const ora_problem* g, ora_field f, int lx, int ly) {
-    ora_fill_halo4(g, f, bc_side(g->topo_x, lx, 0), bc_side(g->topo_x, lx, 1), bc_side(g->topo_y, ly, 0), bc_side(g->topo_y, ly, 1));
+static void fill_loc_sign(const ora_problem* g, ora_field f, int lx, int ly, int sign) {
+    int byhi = bc_side(g->topo_y, ly, 1);
+    ora_fill_halo4(g, f, bc_side(g->topo_x, lx, 0), bc_side(g->topo_x, lx, 1), bc_side(g->topo_y, ly, 0), byhi == ORA_BC_FOLD ? ORA_BC_NONE : byhi);
+    if (byhi == ORA_BC_FOLD) fold_north(g, f, lx, ly, sign);
 }
+static void fill_loc(const ora_problem* g, ora_field f, int lx, int ly) { fill_loc_sign(g, f, lx, ly, 1); }
+void ora_fill_halo_loc(const ora_problem* g, ora_field f, int lx, int ly, int fold_sign) { fill_loc_sign(g, f, lx, ly, fold_sign); }
 /* u, v: a ValueBoundaryCondition replaces the no-flux mirror of the tangential component on a wall */
 void ora_fill_halo_u(ora_problem* g) {
     int bylo = bc_side(g->topo_y, C_, 0), byhi = bc_side(g->topo_y, C_, 1);
     if (bylo == ORA_BC_MIRROR && g->u_value_on[0]) bylo = ORA_BC_VALUE;
     if (byhi == ORA_BC_MIRROR && g->u_value_on[1]) byhi = ORA_BC_VALUE;
     static const double zero[2] = {0.0, 0.0};
-    fill_halo4v(g, g->u, bc_side(g->topo_x, F_, 0), bc_side(g->topo_x, F_, 1), bylo, byhi, zero, g->u_value);
+    fill_halo4v(g, g->u, bc_side(g->topo_x, F_, 0), bc_side(g->topo_x, F_, 1), bylo, byhi == ORA_BC_FOLD ? ORA_BC_NONE : byhi, zero, g->u_value);
+    if (byhi == ORA_BC_FOLD) fold_north(g, g->u, F_, C_, -1);      /* sea_ice_model.jl:57-64: the velocities flip sign across the fold */
 }
 void ora_fill_halo_v(ora_problem* g) {
     int bxlo = bc_side(g->topo_x, C_, 0), bxhi = bc_side(g->topo_x, C_, 1);
     if (bxlo == ORA_BC_MIRROR && g->v_value_on[0]) bxlo = ORA_BC_VALUE;
     if (bxhi == ORA_BC_MIRROR && g->v_value_on[1]) bxhi = ORA_BC_VALUE;
     static const double zero[2] = {0.0, 0.0};
-    fill_halo4v(g, g->v, bxlo, bxhi, bc_side(g->topo_y, F_, 0), bc_side(g->topo_y, F_, 1), g->v_value, zero);
+    int byhi = bc_side(g->topo_y, F_, 1);
+    fill_halo4v(g, g->v, bxlo, bxhi, bc_side(g->topo_y, F_, 0), byhi == ORA_BC_FOLD ? ORA_BC_NONE : byhi, g->v_value, zero);
+    if (byhi == ORA_BC_FOLD) fold_north(g, g->v, C_, F_, -1);
 }
 void ora_fill_halo_center(ora_problem* g, ora_field f) { fill_loc(g, f, C_, C_); }
 

@@ -35,13 +35,16 @@
 extern "C" {
 #endif
 
-enum { ORA_PERIODIC = 0, ORA_BOUNDED = 1, ORA_FULLY_CONNECTED = 2, ORA_LEFT_CONNECTED = 3, ORA_RIGHT_CONNECTED = 4 };
+enum { ORA_PERIODIC = 0, ORA_BOUNDED = 1, ORA_FULLY_CONNECTED = 2, ORA_LEFT_CONNECTED = 3, ORA_RIGHT_CONNECTED = 4,
+       /* y direction of a TripolarGrid: low side a wall (southernmost latitude), high side the north FOLD (Zipper boundary
+        * condition, sea_ice_model.jl:57-64); _CONNECTED_FOLDED: the northernmost tile of a y partition */
+       ORA_RIGHT_FOLDED = 5, ORA_LEFT_CONNECTED_RIGHT_FOLDED = 6 };
 enum { ORA_METRIC_UNIFORM = 0, ORA_METRIC_PER_J = 1, ORA_METRIC_FULL = 2 };
 enum { ORA_STRESS_NONE = 0, ORA_STRESS_CONST = 1, ORA_STRESS_FIELD = 2, ORA_STRESS_SEMI_IMPLICIT = 3 };
 enum { ORA_VEL_ZERO = 0, ORA_VEL_CONST = 1, ORA_VEL_FIELD = 2 };
 enum { ORA_PRESSURE_REPLACEMENT = 0, ORA_PRESSURE_ICE_STRENGTH = 1 };
 enum { ORA_LOC_CENTER = 0, ORA_LOC_FACE = 1 };
-enum { ORA_BC_PERIODIC = 0, ORA_BC_MIRROR = 1, ORA_BC_NONE = 2, ORA_BC_VALUE = 3 };
+enum { ORA_BC_PERIODIC = 0, ORA_BC_MIRROR = 1, ORA_BC_NONE = 2, ORA_BC_VALUE = 3, ORA_BC_FOLD = 4 };
 
 typedef struct {
     double* p;     /* parent array start (element (1-Hx, 1-Hy)) */
@@ -151,6 +154,9 @@ void ora_fill_halo4(const ora_problem* g, ora_field f, int bxlo, int bxhi, int b
 void ora_fill_halo_u(ora_problem* g);
 void ora_fill_halo_v(ora_problem* g);
 void ora_fill_halo_center(ora_problem* g, ora_field f);
+/* local halo fill of a field at (lx, ly) with the boundary conditions its location implies on this grid; sign: the Zipper
+ * sign of a north fold (+1 scalars and tensor components, -1 vector components) */
+void ora_fill_halo_loc(const ora_problem* g, ora_field f, int lx, int ly, int fold_sign);
 void ora_finalize_rheology(ora_problem* g);                                     /* evp:275-280 */
 
 /* time_step_momentum!(model, ::SplitExplicitMomentumEquation, dt), split_explicit:103-195.

@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED = 0, 1, 2, 3, 4
+PERIODIC, BOUNDED, FULLY_CONNECTED, LEFT_CONNECTED, RIGHT_CONNECTED, RIGHT_FOLDED, LEFT_CONNECTED_RIGHT_FOLDED = 0, 1, 2, 3, 4, 5, 6
 
 
 def hi_wall(t):
@@ -130,6 +130,7 @@ def lib(omp=False):
         L.ora_fill_halo_u.argtypes = [P]
         L.ora_fill_halo_v.argtypes = [P]
         L.ora_fill_halo_center.argtypes = [P, Field]
+        L.ora_fill_halo_loc.argtypes = [P, Field, i32, i32, i32]
         L.ora_finalize_rheology.argtypes = [P]
         L.ora_time_step_momentum.argtypes = [P, dbl, i32]
         L.ora_subcycle.argtypes = [P, dbl, i32, i32]

@@ -23,7 +23,7 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
              noslip=noslip,                        # ValueBoundaryCondition(0) on the tangential velocity at every wall
              user_forcing=user_forcing,            # model.forcing.u / .v as arrays
              immersed_bc=immersed_bc)              # ((uW, uE, uS, uN), (vW, vE, vS, vN)): immersed FluxBoundaryCondition numbers
-    T = {"periodic": csi.Periodic, "bounded": csi.Bounded}
+    T = {"periodic": csi.Periodic, "bounded": csi.Bounded, "folded": csi.RightFolded}     # "folded": y of a TripolarGrid
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
         g = csi.RectilinearGrid((Nx, Ny), x=(0.0, Nx * spacing), y=(0.0, Ny * spacing), topology=tt, halo=(H, H))
@@ -57,6 +57,8 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
     if topo[1] == "bounded":
         v[0, :] = 0.0
         v[-1, :] = 0.0
+    if topo[1] == "folded":
+        v[0, :] = 0.0                               # the south wall; the north side is the fold (no wall face row)
     c["mask"] = None
     if land:
         # immersed "land": union of seeded discs covering about `land` of the domain
@@ -68,6 +70,9 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
             ddx = np.minimum(np.abs(II - cx), Nx - np.abs(II - cx)) if topo[0] == "periodic" else np.abs(II - cx)
             ddy = np.minimum(np.abs(JJ - cy), Ny - np.abs(JJ - cy)) if topo[1] == "periodic" else np.abs(JJ - cy)
             wet &= (ddx ** 2 + ddy ** 2) > rad ** 2
+        if topo[1] == "folded":
+            # the fold runs through the centres of row Ny: that row must be its own mirror image (cell i <-> Nx - i + 1)
+            wet[-1, :] &= wet[-1, ::-1]
         c["mask"] = wet
         h = np.where(wet, h, 0.0)
         a = np.where(wet, a, 0.0)
@@ -113,7 +118,7 @@ def coriolis_of(case):
 def oracle_problem(case, omp=False):
     import oracle as O
     g = case["g"]
-    topo = tuple(O.PERIODIC if t == "periodic" else O.BOUNDED for t in case["topo"])
+    topo = tuple({"periodic": O.PERIODIC, "bounded": O.BOUNDED, "folded": O.RIGHT_FOLDED}[t] for t in case["topo"])
     m = g.metrics()
     if m["kind"] == "uniform":
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, dx=m["dx"], dy=m["dy"], substeps=case["substeps"], omp=omp)
@@ -136,9 +141,7 @@ def oracle_problem(case, omp=False):
         # halos of the forcing fields: update_external_stress! (sea_ice_external_stress.jl:72-78,148-152)
         for arr, (lx, ly) in ((tu, (O.FACE, O.CENTER)), (tv, (O.CENTER, O.FACE)), (ue, (O.FACE, O.CENTER)), (ve, (O.CENTER, O.FACE))):
             fld = O.Field(arr.ctypes.data_as(O.C.POINTER(O.C.c_double)), arr.shape[1])
-            bcx = 0 if topo[0] == O.PERIODIC else (1 if lx == O.CENTER else 2)
-            bcy = 0 if topo[1] == O.PERIODIC else (1 if ly == O.CENTER else 2)
-            p.L.ora_fill_halo(p.ptr, fld, lx, ly, bcx, bcy)
+            p.L.ora_fill_halo_loc(p.ptr, fld, lx, ly, -1)      # vector components: they change sign across a north fold
     else:
         if case["top"] is not None:
             p.set_stress("top", O.STRESS_CONST, tau=case["top"])
@@ -148,6 +151,8 @@ def oracle_problem(case, omp=False):
         p.s.free_drift_kind = 1                     # StressBalanceFreeDrift on the model's own stresses
     if case.get("user_forcing"):
         fu = _fill_parent_like(p, "u", case["force_u"]); fv = _fill_parent_like(p, "v", case["force_v"])
+        for arr, (lx, ly) in ((fu, (O.FACE, O.CENTER)), (fv, (O.CENTER, O.FACE))):
+            p.L.ora_fill_halo_loc(p.ptr, O.Field(arr.ctypes.data_as(O.C.POINTER(O.C.c_double)), arr.shape[1]), lx, ly, -1)
         p.set_forcing(fu, fv)
     if case.get("immersed_bc"):
         (uw, ue_, us, un_), (vw, ve_, vs, vn_) = case["immersed_bc"]
@@ -163,6 +168,8 @@ def oracle_problem(case, omp=False):
         if topo[1] == O.PERIODIC:
             full[:s_.Hy, :] = full[s_.Ny:s_.Ny + s_.Hy, :]
             full[s_.Ny + s_.Hy:, :] = full[s_.Hy:2 * s_.Hy, :]
+        if topo[1] == O.RIGHT_FOLDED:                # cells beyond the fold are images of real cells
+            full = csi.fold_north(full, s_.Nx, s_.Ny, s_.Hx, s_.Hy, False, False, 1).astype(np.uint8)
         p.set_mask(full)
     p.interior("h")[...] = case["h"]
     p.interior("aice")[...] = case["a"]

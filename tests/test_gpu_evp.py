@@ -85,12 +85,18 @@ CASES = {
     # immersed FluxBoundaryCondition numbers on u and v (ice_stress_divergence.jl:65-123)
     "immersed_flux_bc": dict(Nx=80, Ny=64, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.3,
                              immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))),
+    # TripolarGrid-like grids: north fold filled by the Zipper boundary condition (u, v change sign; sea_ice_model.jl:57-64)
+    "folded_uniform": dict(Nx=64, Ny=48, topo=("periodic", "folded"), patches=True, random_uv=0.05),
+    # ... and the reference's own tripolar test configuration (test/distributed_tests_utils.jl:190-212): curvilinear metrics,
+    # immersed land, wind-stress / ocean-velocity arrays, StressBalanceFreeDrift
+    "folded_tripolar": dict(Nx=60, Ny=44, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.04, land=0.2,
+                            field_forcing=True, free_drift=True),
     "immersed_flux_bc_curvilinear": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.03, land=0.25, curvilinear=0.05,
                                          immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)), user_forcing=True),
 }
 MASKED = {"noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = {"user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}   # rare tendency terms: never fused
+THREE_KERNEL_ONLY = {"folded_uniform", "folded_tripolar", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}   # rare tendency terms: never fused
 
 
 def ulp_diff(a, b):
@@ -111,10 +117,10 @@ def cmp_region(c, k, a):
       -H+2 : N+H-1; the two-sub-steps-per-launch kernel writes the interior plus all H periodic images and nothing
       beyond walls -> periodic directions without the outermost layer, bounded directions interior only."""
     H = c["H"]
-    if k == "s12" and "bounded" in c["topo"]:
+    if k == "s12" and ("bounded" in c["topo"] or "folded" in c["topo"]):
         return a[H:a.shape[0] - H, H:a.shape[1] - H]
     if k in DIAG:
-        cut = [H if t == "bounded" else 1 for t in c["topo"]]          # (x, y)
+        cut = [H if t in ("bounded", "folded") else 1 for t in c["topo"]]          # (x, y)
         return a[cut[1]:a.shape[0] - cut[1], cut[0]:a.shape[1] - cut[0]]
     return a
 
@@ -403,7 +409,7 @@ def test_pair_kernel_on_tiles_halo32_interval16(topo):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
-EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear"})
+EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear", "folded_tripolar"})
 FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",

@@ -35,6 +35,8 @@ def _run(world, Rx, Ry, kw, k, tmp_path):
 @pytest.mark.parametrize("Rx,Ry", [(2, 1), (1, 2)] + ([(2, 2)] if NGPU >= 4 else []) + ([(2, 4)] if NGPU >= 8 else []))
 def test_multirank_rccl_tiles_bitwise(Rx, Ry, k, tmp_path):
     kw = dict(Nx=256, Ny=192, H=8, substeps=14, topo=("periodic", "bounded"), patches=True, random_uv=0.05)
+    if Rx == 1:      # pure y partitions also run the TripolarGrid-like case: the north fold lives on the last rank
+        kw = dict(kw, topo=("periodic", "folded"))
     c = cases.make_case(**kw)
     ref = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7))
     csi.time_step_momentum(ref, c["dt"])

@@ -135,7 +135,7 @@ def test_tracer_tendencies_next_to_immersed_cells_bitwise(topo, scheme, oracle_l
 
 
 @pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
-@pytest.mark.parametrize("name", ["periodic", "latlon_channel_masked"])
+@pytest.mark.parametrize("name", ["periodic", "latlon_channel_masked", "folded_masked"])
 def test_curvilinear_grid_full_step_bitwise(stepper, name, oracle_lib):
     """Orthogonal curvilinear grid (twelve distorted 2-D metric arrays, CSI_METRIC_FULL): tracer tendencies and whole
     time steps (WENO7 + EVP sub-cycle + tracer update) equal the oracle -- tendencies bit for bit, the step to the
@@ -143,7 +143,9 @@ def test_curvilinear_grid_full_step_bitwise(stepper, name, oracle_lib):
     three-kernel path)."""
     kw = dict(periodic=dict(Nx=80, Ny=36, topo=("periodic", "periodic"), patches=True, random_uv=0.03, curvilinear=0.05),
               latlon_channel_masked=dict(Nx=70, Ny=40, topo=("periodic", "bounded"), grid="latlon", patches=True, random_uv=0.03,
-                                         curvilinear=0.04, land=0.2))[name]
+                                         curvilinear=0.04, land=0.2),
+              # TripolarGrid-like: north fold (Zipper) -- WENO stencils, stresses and velocities read across the fold
+              folded_masked=dict(Nx=64, Ny=44, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.04, land=0.2))[name]
     c = cases.make_case(substeps=10, **kw)
     p = cases.oracle_problem(c)
     m = cases.csi_model(c, mode="strict", timestepper=stepper, advection=csi.WENO(order=7))

@@ -502,3 +502,41 @@ def test_immersed_flux_bc_and_user_forcing_terms(oracle_lib):
     ratio = du / F                                                      # = dtau / (1 + dtau tau_i) > 0, about dt / alpha
     assert np.all(ratio > 0) and np.all(ratio < c1["dt"] / 50.0 * 1.05)     # (u sees the forced v through the Coriolis term: a few 1e-4 relative)
     assert np.all(np.isfinite(q1.f["v"]))
+
+
+@pytest.mark.parametrize("loc", [("c", "c"), ("f", "c"), ("c", "f"), ("f", "f")])
+@pytest.mark.parametrize("sign", [1, -1])
+def test_north_fold_fill_matches_numpy_restatement(loc, sign, oracle_lib):
+    """Zipper boundary condition of a TripolarGrid (sea_ice_model.jl:57-64; upstream fold semantics as recalled in
+    oracle/csi_oracle.c fold_north): the C oracle's fill equals the independent numpy restatement (grids.fold_north) bit for
+    bit at all four locations and both signs; the folded rows are periodic in x; a field that is symmetric under the fold
+    map keeps a continuous image (row Ny + 1 of a Center-y field equals its row Ny - 1 partner)."""
+    import oracle as O
+    Nx, Ny, H = 24, 18, 4
+    p = O.Problem(Nx, Ny, H, H, (O.PERIODIC, O.RIGHT_FOLDED), dx=1.0, dy=1.0)
+    rng = np.random.default_rng(5)
+    name = {("c", "c"): "h", ("f", "c"): "u", ("c", "f"): "v", ("f", "f"): "s12"}[loc]
+    a = p.f[name]
+    assert a.shape == (Ny + 2 * H, Nx + 2 * H)                 # no extra row: the fold side is not a wall
+    a[...] = rng.standard_normal(a.shape)
+    before = a.copy()
+    lx, ly = (O.FACE if loc[0] == "f" else O.CENTER), (O.FACE if loc[1] == "f" else O.CENTER)
+    p.L.ora_fill_halo_loc(p.ptr, p.field_struct(name), lx, ly, sign)
+    # numpy: x periodic pass over the interior rows, south wall mirror for Center-y fields, then the fold
+    want = before.copy()
+    want[H:H + Ny, :H] = want[H:H + Ny, Nx:Nx + H]
+    want[H:H + Ny, Nx + H:] = want[H:H + Ny, H:2 * H]
+    if ly == O.CENTER:
+        for m in range(1, H + 1):
+            want[H - m, :] = want[H + m - 1, :]
+    want = csi.fold_north(want, Nx, Ny, H, H, loc[0] == "f", loc[1] == "f", sign)
+    assert np.array_equal(a, want)
+    top = a[H + Ny:, :]
+    assert np.array_equal(top[:, :H], top[:, Nx:Nx + H]) and np.array_equal(top[:, Nx + H:], top[:, H:2 * H])
+    # spot values straight from the definition
+    i, m = 5, 2
+    ip = Nx - i + (2 if loc[0] == "f" else 1)
+    js = Ny - m + (1 if loc[1] == "f" else 0)
+    assert a[Ny + m + H - 1, i + H - 1] == sign * before[js + H - 1, ip + H - 1]
+    if loc[0] == "f":                                         # column 1 folds onto itself without the sign change
+        assert a[Ny + m + H - 1, 1 + H - 1] == abs(sign) * before[js + H - 1, 1 + H - 1]

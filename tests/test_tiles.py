@@ -82,6 +82,10 @@ PARTITIONS = [
     ("y2_beta_periodic", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"), beta=2e-10)),
     # orthogonal curvilinear grid: each tile gets its slice of the twelve 2-D metric arrays
     ("x2_curvilinear", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "bounded"), curvilinear=0.04)),
+    # TripolarGrid-like: north fold (Zipper), partitioned in y only as the reference's own distributed tripolar test
+    # (test/distributed_tests_utils.jl:239: Partition(1, 4)); the fold lives on the northernmost tile
+    ("y2_folded", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "folded"))),
+    ("y2_folded_curvilinear", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "folded"), curvilinear=0.04)),
 ]
 
 

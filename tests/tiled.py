@@ -9,7 +9,8 @@ import climaseaice_jl_amd as csi
 import oracle as O
 
 _TOPO_CODE = {csi.Periodic: O.PERIODIC, csi.Bounded: O.BOUNDED, csi.FullyConnected: O.FULLY_CONNECTED,
-              csi.LeftConnected: O.LEFT_CONNECTED, csi.RightConnected: O.RIGHT_CONNECTED}
+              csi.LeftConnected: O.LEFT_CONNECTED, csi.RightConnected: O.RIGHT_CONNECTED,
+              csi.RightFolded: O.RIGHT_FOLDED, csi.LeftConnectedRightFolded: O.LEFT_CONNECTED_RIGHT_FOLDED}
 _LOC = {"u": (csi.Face, csi.Center), "v": (csi.Center, csi.Face), "h": (csi.Center, csi.Center),
         "aice": (csi.Center, csi.Center), "s11": (csi.Center, csi.Center), "s22": (csi.Center, csi.Center),
         "s12": (csi.Face, csi.Face)}
@@ -44,10 +45,10 @@ class Exchanger:
     def __init__(self, tg, dist=None):
         self.tg, self.dist = tg, dist
         L = csi._lib
-        self.topo = ({csi.Periodic: L.PERIODIC, csi.Bounded: L.BOUNDED, csi.FullyConnected: L.FULLY_CONNECTED,
-                      csi.LeftConnected: L.LEFT_CONNECTED, csi.RightConnected: L.RIGHT_CONNECTED}[tg.topology[0]],
-                     {csi.Periodic: L.PERIODIC, csi.Bounded: L.BOUNDED, csi.FullyConnected: L.FULLY_CONNECTED,
-                      csi.LeftConnected: L.LEFT_CONNECTED, csi.RightConnected: L.RIGHT_CONNECTED}[tg.topology[1]])
+        code = {csi.Periodic: L.PERIODIC, csi.Bounded: L.BOUNDED, csi.FullyConnected: L.FULLY_CONNECTED,
+                csi.LeftConnected: L.LEFT_CONNECTED, csi.RightConnected: L.RIGHT_CONNECTED,
+                csi.RightFolded: L.RIGHT_FOLDED, csi.LeftConnectedRightFolded: L.LEFT_CONNECTED_RIGHT_FOLDED}
+        self.topo = (code[tg.topology[0]], code[tg.topology[1]])
 
     def plan(self, W, halo):
         t = self.tg
