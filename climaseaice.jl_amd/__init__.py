@@ -7,7 +7,7 @@ contains a dot, so import it through the repo-root shim: `import climaseaice_jl_
 """
 from . import _lib
 from ._lib import Context, CsiError, plan_exchange, plan_ranges
-from .dynamics import (Auxiliaries, BetaPlane, ElastoViscoPlasticRheology, FPlane, IceStrength, ReplacementPressure,
+from .dynamics import (Auxiliaries, BetaPlane, PointwiseCoriolis, ElastoViscoPlasticRheology, FPlane, IceStrength, ReplacementPressure,
                        SeaIceMomentumEquation, SemiImplicitStress, SplitExplicitSolver, StressBalanceFreeDrift)
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
 from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected,

@@ -32,7 +32,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
-           "csi_immersed_flux_bc_set"]
+           "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
 
 
 class Metrics(C.Structure):
@@ -122,6 +122,7 @@ def load():
         "csi_set_fusion": [vp, i32], "csi_free_drift_set": [vp, i32],
         "csi_coriolis_rows_set": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32],
         "csi_velocity_bc_set": [vp, i32, i32, i32, dbl],
+        "csi_coriolis_points_set": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i64],
         "csi_immersed_flux_bc_set": [vp, i32, dbl, dbl, dbl, dbl],
         "csi_plan_exchange": [i32] * 14 + [C.POINTER(i32)],
         "csi_profile_substeps": [vp, dbl, i32, C.POINTER(dbl)],

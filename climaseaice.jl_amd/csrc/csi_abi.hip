@@ -67,6 +67,8 @@ struct csi_context {
     std::vector<double> coef_host;       // host copy of the per-row table built from PER_J metrics (empty: uniform metrics)
     std::vector<double> fcor_rows[2];    // csi_coriolis_rows_set: f per row at u / v points (empty: FPlane scalar)
     double* dev_fcor = nullptr;          // the same on the device (STRICT kernels), 2 x (Ny + 2Hy + 1)
+    double* dev_fcor2 = nullptr;         // csi_coriolis_points_set: two planes (u points, v points) of ni x nj
+    long fcor2_ld = 0, fcor2_plane = 0;
     bool cor_dirty = true;               // Coriolis columns of the FAST table need (re)building
     double cor_synced = 0.0;             // FPlane value they were built with
     Bound f[CSI_F_COUNT];
@@ -267,6 +269,10 @@ EvpDev evp_dev(const csi_context* c, double dt) {
     if (c->dev_fcor && e.has_coriolis) {
         const size_t n = (size_t)c->Ny + 2 * (size_t)c->Hy + 1;
         P.fcor_u = c->dev_fcor + (c->Hy - 1); P.fcor_v = c->dev_fcor + n + (c->Hy - 1);   // ptr[j] is row j
+    }
+    if (c->dev_fcor2 && e.has_coriolis) {
+        const long off = (c->Hx - 1) + (long)(c->Hy - 1) * c->fcor2_ld;
+        P.fcor2_u = c->dev_fcor2 + off; P.fcor2_v = c->dev_fcor2 + c->fcor2_plane + off; P.fcor2_ld = c->fcor2_ld;
     }
     P.pressure_kind = e.pressure_formulation;
     P.dt = dt;
@@ -1025,6 +1031,7 @@ int32_t csi_context_destroy(csi_context* c) {
     hipStreamSynchronize(c->stream);
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_fcor) hipFree(c->dev_fcor);
+    if (c->dev_fcor2) hipFree(c->dev_fcor2);
     if (c->dev_coef2) hipFree(c->dev_coef2);
     if (c->host_ring) hipHostFree(c->host_ring);
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
@@ -1119,6 +1126,7 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
     // FAST-mode stencil coefficients
     if (c->dev_coef) { hipFree(c->dev_coef); c->dev_coef = nullptr; }
     if (c->dev_fcor) { hipFree(c->dev_fcor); c->dev_fcor = nullptr; }
+    if (c->dev_fcor2) { hipFree(c->dev_fcor2); c->dev_fcor2 = nullptr; }
     c->coef_host.clear(); c->fcor_rows[0].clear(); c->fcor_rows[1].clear();
     c->cor_dirty = true;
     c->coef = FastCoef{};
@@ -1206,6 +1214,27 @@ int32_t csi_coriolis_rows_set(csi_context* c, const double* f_u, const double* f
     for (int t = 0; t < n; ++t) { host[t] = f_u[t]; host[(size_t)n + t] = f_v[t]; }
     HIP_TRY(c, hipMalloc((void**)&c->dev_fcor, sizeof(double) * host.size()));
     HIP_TRY(c, hipMemcpy(c->dev_fcor, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+    return CSI_OK;
+}
+
+int32_t csi_coriolis_points_set(csi_context* c, const double* f_u, const double* f_v, int64_t ld) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");
+    if ((f_u == nullptr) != (f_v == nullptr)) return fail(c, CSI_ERR_INVALID_ARGUMENT, "f_u and f_v: both or neither");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dev_fcor2) { hipFree(c->dev_fcor2); c->dev_fcor2 = nullptr; }
+    if (!f_u) return CSI_OK;
+    if (c->metric_kind != CSI_METRIC_FULL)
+        return fail(c, CSI_ERR_UNSUPPORTED, "per-point Coriolis parameter: CSI_METRIC_FULL grids only (use csi_coriolis_rows_set on per-row grids)");
+    const long ni = c->Nx + 2 * c->Hx + 1, nj = c->Ny + 2 * c->Hy + 1;
+    if (ld < ni) return fail(c, CSI_ERR_INVALID_ARGUMENT, "coriolis points: ld must be >= Nx + 2Hx + 1");
+    std::vector<double> host(2 * (size_t)ni * nj);
+    for (long b = 0; b < nj; ++b)
+        for (long a = 0; a < ni; ++a) { host[a + b * ni] = f_u[a + b * ld]; host[(size_t)ni * nj + a + b * ni] = f_v[a + b * ld]; }
+    HIP_TRY(c, hipMalloc((void**)&c->dev_fcor2, sizeof(double) * host.size()));
+    HIP_TRY(c, hipMemcpy(c->dev_fcor2, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+    c->fcor2_ld = ni; c->fcor2_plane = ni * nj;
     return CSI_OK;
 }
 

@@ -68,6 +68,8 @@ struct EvpDev {
     double P_star, C_star, ecc, Dmin, amin, amax, ca;
     double min_mass, min_conc, rho, fcor;
     const double *fcor_u, *fcor_v;   // BetaPlane: f per row at the u / v points (ptr[j] = row j); NULL: fcor
+    const double *fcor2_u, *fcor2_v; // per-point f on CSI_METRIC_FULL grids (ptr[i + j * fcor2_ld]); NULL: rows / fcor
+    long fcor2_ld;
     int pressure_kind, has_cor;
     int free_drift;           // 1: StressBalanceFreeDrift, velocities of marginal ice from ufd / vfd
     FRef ufd, vfd;            // free-drift velocities at u / v points (library scratch, once per sub-cycle)
@@ -81,6 +83,14 @@ struct EvpDev {
 };
 
 struct Range { int i0, i1, j0, j1; };
+
+// Coriolis parameter at the u / v point (i, j): per point, per row or a number
+__device__ __forceinline__ double fcor_at_u(const EvpDev& P, int i, int j) {
+    return P.fcor2_u ? P.fcor2_u[i + (long)j * P.fcor2_ld] : (P.fcor_u ? P.fcor_u[j] : P.fcor);
+}
+__device__ __forceinline__ double fcor_at_v(const EvpDev& P, int i, int j) {
+    return P.fcor2_v ? P.fcor2_v[i + (long)j * P.fcor2_ld] : (P.fcor_v ? P.fcor_v[j] : P.fcor);
+}
 
 // ---- activity / peripheral nodes (upstream Grids.inactive_cell / peripheral_node) ------------
 __device__ __forceinline__ bool inactive_cell(const GridDev& g, int i, int j) {

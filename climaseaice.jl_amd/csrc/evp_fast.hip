@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
-    double cor = (P.fcor_u ? P.fcor_u[j] : P.fcor) * vbar;
+    double cor = fcor_at_u(P, i, j) * vbar;
     if (P.extra) { if (P.has_forcing) cor += P.forcing_u(i, j); div += immersed_div_sigma_1(P, i, j); }
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);
-    double cor = -(P.fcor_v ? P.fcor_v[j] : P.fcor) * ubar;
+    double cor = -fcor_at_v(P, i, j) * ubar;
     if (P.extra) { if (P.has_forcing) cor += P.forcing_v(i, j); div += immersed_div_sigma_2(P, i, j); }
     const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
     const double res = P.free_drift

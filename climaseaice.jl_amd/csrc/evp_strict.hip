@@ -256,7 +256,7 @@ __global__ void k_ustep(EvpDev P, Range r, ImageSpec im) {
     double cor = 0.0;
     if (P.has_cor) {
 #define V_(ii, jj) P.v(ii, jj)
-        cor = -(P.fcor_u ? P.fcor_u[j] : P.fcor) * AVG4_FC(V_);     // FPlane / BetaPlane (f at this row's u points)
+        cor = -fcor_at_u(P, i, j) * AVG4_FC(V_);     // FPlane / BetaPlane (f at this row's u points) / per-point f
 #undef V_
     }
     const double user = P.has_forcing ? P.forcing_u(i, j) : 0.0;    // model.forcing.u as an array
@@ -291,7 +291,7 @@ __global__ void k_vstep(EvpDev P, Range r, ImageSpec im) {
     double cor = 0.0;
     if (P.has_cor) {
 #define U_(ii, jj) P.u(ii, jj)
-        cor = (P.fcor_v ? P.fcor_v[j] : P.fcor) * AVG4_CF(U_);
+        cor = fcor_at_v(P, i, j) * AVG4_CF(U_);
 #undef U_
     }
     const double user = P.has_forcing ? P.forcing_v(i, j) : 0.0;

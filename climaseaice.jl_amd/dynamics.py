@@ -78,6 +78,23 @@ class BetaPlane:
         return (self.f0 + self.beta * grid.ynodes_with_halo(Center), self.f0 + self.beta * grid.ynodes_with_halo(Face))
 
 
+class PointwiseCoriolis:
+    """f given at every (Face, Center) and (Center, Face) node of an orthogonal curvilinear grid (e.g. 2 Omega sin(latitude)
+    of a TripolarGrid, whose latitude varies along both indices): arrays of shape (Ny + 2Hy + 1, Nx + 2Hx + 1) laid out
+    like the grid's metric arrays, halo entries holding the value of the point they image.  Applied with the FPlane /
+    BetaPlane stencil (include/csi.h csi_coriolis_points_set).  On a tile: slices of the global arrays."""
+
+    def __init__(self, f_u, f_v):
+        self.f_u, self.f_v = np.asarray(f_u, dtype=np.float64), np.asarray(f_v, dtype=np.float64)
+
+    def points(self, grid):
+        n, ni = grid.Ny + 2 * grid.Hy + 1, grid.Nx + 2 * grid.Hx + 1
+        j0, i0 = getattr(grid, "j_off", 0), getattr(grid, "i_off", 0)
+        out = tuple(np.ascontiguousarray(a[j0:j0 + n, i0:i0 + ni]) for a in (self.f_u, self.f_v))
+        assert out[0].shape == (n, ni), (out[0].shape, (n, ni))
+        return out
+
+
 @dataclass
 class SemiImplicitStress:
     """tau = rho_e Cd |u_e - u| (u_e - u); u_e, v_e: None (ZeroField), a number (ConstantField) or a Field."""

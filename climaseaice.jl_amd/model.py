@@ -297,7 +297,12 @@ class SeaIceModel:
                            0 if d.coriolis is None else 1, float(getattr(d.coriolis, "f", 0.0)),
                            d.minimum_concentration, d.minimum_mass, self.sea_ice_density)
         self.ctx.call("csi_evp_params_set", C.byref(p))
-        if hasattr(d.coriolis, "rows"):            # BetaPlane: f per row, evaluated here like the metric vectors
+        if hasattr(d.coriolis, "points"):          # per-point f (curvilinear grids)
+            fu, fv = d.coriolis.points(g)
+            self._keep += [fu, fv]
+            self.ctx.call("csi_coriolis_rows_set", None, None, 0)
+            self.ctx.call("csi_coriolis_points_set", _dptr(fu), _dptr(fv), fu.shape[1])
+        elif hasattr(d.coriolis, "rows"):          # BetaPlane: f per row, evaluated here like the metric vectors
             fu, fv = (np.ascontiguousarray(a, dtype=np.float64) for a in d.coriolis.rows(g))
             self.ctx.call("csi_coriolis_rows_set", _dptr(fu), _dptr(fv), fu.size)
         else:

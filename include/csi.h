@@ -225,6 +225,14 @@ int32_t csi_immersed_flux_bc_set(csi_context* ctx, int32_t field_id, double west
  * kernels recompute ring rows there and must see their owner's f).  They replace csi_evp_params.coriolis_f while set (has_coriolis must be 1);
  * NULL, NULL returns to the FPlane value.  Call after csi_grid_set (a new grid drops them). */
 int32_t csi_coriolis_rows_set(csi_context* ctx, const double* f_u, const double* f_v, int32_t n);
+/* Point-dependent Coriolis parameter on CSI_METRIC_FULL grids (f = 2 Omega sin(latitude) of a curvilinear grid whose
+ * latitude varies along both indices, e.g. a TripolarGrid): f at the (Face, Center) and (Center, Face) nodes, HOST arrays laid
+ * out like the metric planes (Ny + 2Hy + 1 rows of leading dimension ld >= Nx + 2Hx + 1, element (i, j) at
+ * [(i + Hx - 1) + (j + Hy - 1) * ld]; halo entries hold the value of the point they image).  Applied with the stencil the
+ * reference's hot path exercises, -f * Ixy(v) / +f * Ixy(u) (FPlane / BetaPlane: test/test_time_stepping.jl:35,
+ * examples and distributed tests); upstream's HydrostaticSphericalCoriolis enstrophy-conserving stencil appears nowhere in
+ * the reference and is not implemented.  Replaces csi_evp_params.coriolis_f / the rows while set; NULL, NULL removes it. */
+int32_t csi_coriolis_points_set(csi_context* ctx, const double* f_u, const double* f_v, int64_t ld);
 
 /* ---- the reference's verbs ----------------------------------------------------------------- */
 /* initialize_rheology!(model, ::ElastoViscoPlasticRheology), elasto_visco_plastic_rheology.jl:192-219 */

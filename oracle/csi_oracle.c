@@ -418,7 +418,8 @@ static double u_tendency(const ora_problem* g, int i, int j, double dtau) {
     double cor = 0.0;                                                        /* x_f_cross_U, `nothing` -> zero */
     if (g->has_coriolis) {
 #define V_(ii, jj) AT(g, g->v, ii, jj)
-        double f = g->fu_rows ? g->fu_rows[j + g->Hy - 1] : g->f_coriolis;   /* BetaPlane: f0 + beta * y^{fc}(j) */
+        double f = g->fu_points ? g->fu_points[((int64_t)i + g->Hx - 1) + ((int64_t)j + g->Hy - 1) * g->f_points_ld]
+                                : (g->fu_rows ? g->fu_rows[j + g->Hy - 1] : g->f_coriolis);   /* BetaPlane: f0 + beta * y^{fc}(j) */
         cor = -f * AVG4_FC(V_);                                              /* FPlane: -f * Ixy^{fc}(v) */
 #undef V_
     }
@@ -441,7 +442,8 @@ static double v_tendency(const ora_problem* g, int i, int j, double dtau) {  /* 
     double cor = 0.0;
     if (g->has_coriolis) {
 #define U_(ii, jj) AT(g, g->u, ii, jj)
-        double f = g->fv_rows ? g->fv_rows[j + g->Hy - 1] : g->f_coriolis;   /* BetaPlane: f0 + beta * y^{cf}(j) */
+        double f = g->fv_points ? g->fv_points[((int64_t)i + g->Hx - 1) + ((int64_t)j + g->Hy - 1) * g->f_points_ld]
+                                : (g->fv_rows ? g->fv_rows[j + g->Hy - 1] : g->f_coriolis);   /* BetaPlane: f0 + beta * y^{cf}(j) */
         cor = f * AVG4_CF(U_);                                               /* FPlane: +f * Ixy^{cf}(u) */
 #undef U_
     }

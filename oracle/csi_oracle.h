@@ -120,6 +120,10 @@ typedef struct {
     /* Immersed FluxBoundaryConditions of u and v with NUMBER values, [0..3] = west, east, south, north
      * (immersed_dj_sigma_1j / _2j, ice_stress_divergence.jl:65-123): all zero = the reference's default. */
     double ibc_u[4], ibc_v[4];
+    /* per-point Coriolis parameter at the u / v points (metric-plane layout: element (i, j) at [(i + Hx - 1) + (j + Hy - 1) * ld]);
+     * NULL: rows / f_coriolis.  Same FPlane / BetaPlane stencil (see include/csi.h csi_coriolis_points_set). */
+    const double *fu_points, *fv_points;
+    int64_t f_points_ld;
 } ora_problem;
 
 /* ---- grid metric accessors (Oceananigans operators) ---- */

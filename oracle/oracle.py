@@ -74,7 +74,9 @@ class ProblemStruct(C.Structure):
                                                       ("u_value", C.c_double * 2), ("v_value", C.c_double * 2),
                                                       ("has_forcing", C.c_int32), ("pad_forcing", C.c_int32),
                                                       ("forcing_u", Field), ("forcing_v", Field),
-                                                      ("ibc_u", C.c_double * 4), ("ibc_v", C.c_double * 4)])
+                                                      ("ibc_u", C.c_double * 4), ("ibc_v", C.c_double * 4),
+                                                      ("fu_points", C.POINTER(C.c_double)), ("fv_points", C.POINTER(C.c_double)),
+                                                      ("f_points_ld", C.c_int64)])
 
 
 class Slab(C.Structure):
@@ -300,6 +302,18 @@ class Problem:
         arr = getattr(self.s, "ibc_" + field)
         for k, val in enumerate((west, east, south, north)):
             arr[k] = float(val)
+
+    def set_coriolis_points(self, fu, fv):
+        """Per-point Coriolis parameter (arrays of shape (Ny + 2Hy + 1, Nx + 2Hx + 1) like the metric planes)."""
+        s = self.s
+        shape = (s.Ny + 2 * s.Hy + 1, s.Nx + 2 * s.Hx + 1)
+        for name, val in (("fu_points", fu), ("fv_points", fv)):
+            a = np.ascontiguousarray(val, dtype=np.float64)
+            assert a.shape == shape, (name, a.shape, shape)
+            self._keep.append(a)
+            setattr(s, name, _dptr(a))
+        s.f_points_ld = shape[1]
+        s.has_coriolis = 1
 
     def set_coriolis(self, f, rows=None):
         """f: None | FPlane f.  rows = (fu, fv): BetaPlane values per row (entry for row j at [j + Hy - 1],

@@ -15,14 +15,15 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
               field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None, noslip=False,
-              user_forcing=False, immersed_bc=None):
+              user_forcing=False, immersed_bc=None, coriolis_points=False):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
              free_drift=free_drift, beta=beta,     # beta: BetaPlane(f0 = coriolis, beta)
              noslip=noslip,                        # ValueBoundaryCondition(0) on the tangential velocity at every wall
              user_forcing=user_forcing,            # model.forcing.u / .v as arrays
-             immersed_bc=immersed_bc)              # ((uW, uE, uS, uN), (vW, vE, vS, vN)): immersed FluxBoundaryCondition numbers
+             immersed_bc=immersed_bc,              # ((uW, uE, uS, uN), (vW, vE, vS, vN)): immersed FluxBoundaryCondition numbers
+             coriolis_points=coriolis_points)      # per-point f planes on a curvilinear grid (PointwiseCoriolis)
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded, "folded": csi.RightFolded}     # "folded": y of a TripolarGrid
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
@@ -77,6 +78,22 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
         h = np.where(wet, h, 0.0)
         a = np.where(wet, a, 0.0)
     c.update(h=h, a=a, u=u, v=v)
+    if coriolis_points:
+        # f(i, j) = f0 (1 + 0.3 sin cos) at the u / v nodes, metric-plane layout; halo entries image their points
+        n, ni = Ny + 2 * H + 1, Nx + 2 * H + 1
+        ia, ja = np.arange(ni) - (H - 1), np.arange(n) - (H - 1)
+        if topo[0] == "periodic":
+            ia = (ia - 1) % Nx + 1
+        if topo[1] == "periodic":
+            ja = (ja - 1) % Ny + 1
+        planes = []
+        for (ox, oy) in ((0.0, 0.5), (0.5, 0.0)):          # u nodes (Face, Center), v nodes (Center, Face)
+            X2, Y2 = (ia[None, :] - 1 + ox) / Nx, (ja[:, None] - 1 + oy) / Ny
+            fpl = (coriolis or 1e-4) * (1.0 + 0.3 * np.sin(2 * np.pi * X2) * np.cos(np.pi * Y2))
+            if topo[1] == "folded":
+                fpl = csi.fold_north(fpl, Nx, Ny, H, H, ox == 0.0, oy == 0.0, 1)     # f is a scalar: no sign change
+            planes.append(np.ascontiguousarray(fpl))
+        c["f_points"] = tuple(planes)
     if user_forcing:
         # an acceleration of a few 1e-6 m s^-2 (comparable to the Coriolis term), smooth + seeded noise
         c["force_u"] = 3e-6 * np.sin(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 1e-6 * rng.standard_normal((nyu, nxu))
@@ -108,6 +125,8 @@ def coriolis_rows(case, grid):
 
 
 def coriolis_of(case):
+    if case.get("coriolis_points"):
+        return csi.PointwiseCoriolis(*case["f_points"])
     if case["coriolis"] is None:
         return None
     if case.get("beta") is not None:
@@ -127,6 +146,8 @@ def oracle_problem(case, omp=False):
     else:
         p = O.Problem(g.Nx, g.Ny, g.Hx, g.Hy, topo, per_j=m, substeps=case["substeps"], omp=omp)
     p.set_coriolis(case["coriolis"], rows=coriolis_rows(case, g))
+    if case.get("coriolis_points"):
+        p.set_coriolis_points(*case["f_points"])
     if case.get("noslip"):
         for side in (0, 1):
             p.set_value_bc("u", side, 0.0)
