@@ -527,12 +527,15 @@ int64_t max_bound_ld(const csi_context* c) {
 bool pair_supported(const csi_context* c) {
     if (!c->pairing) return false;
     if (!offsets_fit_32bit(c->Nx, c->Ny, c->Hx, c->Hy, max_bound_ld(c))) return false;
-    if (c->metric_kind == CSI_METRIC_FULL) return false;        // per-point coefficients: three-kernel path
     const GridDev& g = c->g;
+    // per-point coefficients (CSI_METRIC_FULL): the pair kernel streams the 26 coefficient planes; a periodic y side
+    // would need the ring rows beyond the seam to see their owners' coefficients -- the planes' halo entries are images
+    // of the interior (csi.h), so that holds; a north fold does not pair
+    if (c->metric_kind == CSI_METRIC_FULL && !c->dev_coef2) return false;
     auto ok = [](int s) { return s == SIDE_PERIODIC || s == SIDE_CONNECTED || s == SIDE_WALL; };
     // per-row metrics with a periodic y side: the ring rows recomputed beyond the seam would use other metrics than
     // their owners (an unphysical grid anyway) -- three kernels
-    if (c->metric_kind != CSI_METRIC_UNIFORM && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;   // (BetaPlane rows wrap: csi.h)
+    if (c->metric_kind == CSI_METRIC_PER_J && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;   // (BetaPlane rows wrap: csi.h)
     return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
 }
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
@@ -659,6 +662,12 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
         c->ring_used[slot] = true;
     }
+    if (getenv("CSI_DEBUG_TABLE")) {
+        const FusedTable* t = c->host_ring + (size_t)((c->ring_pos - 1) % csi_context::kRing) * (NSINGLE + NPAIR) + NSINGLE;
+        fprintf(stderr, "[csi] pair table: metric %d c2_ld %d fkind %d dev_coef2 %p plane %ld bytes; P[C2_0] %lx P[C2_25] %lx; U_IN %lx P %lx; dec %d..%d x %d..%d AJ %d..%d\n",
+                c->metric_kind, t->I[FI_C2_LD], t->I[FI_FKIND], (void*)c->dev_coef2, (long)c->coef.c2_plane * 8, t->P[FP_C2_0], t->P[FP_C2_0 + 25],
+                t->P[FP_U_IN], t->P[FP_P], t->I[FI_DEC], t->I[FI_DEC + 1], t->I[FI_DEC + 2], t->I[FI_DEC + 3], t->I[FI_AJ0], t->I[FI_AJ1]);
+    }
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
     const int end = first + substeps;
@@ -667,12 +676,13 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
-            launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)), c->coef.uniform != 0, ufirst,
+            launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
+                              c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
             m += 2; s += 2;
-        } else if (masked || force) {
-            // the one-sub-step kernel takes neither masks nor array-valued forcing: a trailing single sub-step runs the
-            // three kernels in place on whichever buffer is current
+        } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
+            // the one-sub-step kernel takes neither masks nor array-valued forcing nor per-point metrics: a trailing
+            // single sub-step runs the three kernels in place on whichever buffer is current
             EvpDev Q = P;
             const FRef* b = cur == 0 ? orig : alt;
             Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
@@ -766,7 +776,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // immersed masks: only the two-sub-steps-per-launch kernel takes them (a trailing odd sub-step falls back to the
     // three kernels inside run_fused)
     const int pfk = pair_forcing_kind(P);
-    const bool pair_only = P.g.has_mask || pfk == 1;      // configurations only the two-sub-steps kernel takes
+    const bool pair_only = P.g.has_mask || pfk == 1 || c->metric_kind == CSI_METRIC_FULL;      // configurations only the two-sub-steps kernel takes
     const bool fuse = fast && c->fusion && substeps > 0 &&
                       (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                  : fused_supported(P));

@@ -36,11 +36,16 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
              FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUTP, FP_V_OUTP,                                // 5 outputs (parent addresses), contiguous
              FP_U_OUT, FP_V_OUT, FP_S11_OUT0, FP_S22_OUT0, FP_S12_OUT0,                               // (0,0)-offset addresses for stores with halo images
              FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_MASK,
-             FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_FD_U, FP_FD_V, FP_COUNT };   // forcing arrays (parent addresses)                            // FP_MASK: parent address of the uint8 mask
+             FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_FD_U, FP_FD_V,
+             FP_FROW_U, FP_FROW_V,      // CSI_METRIC_FULL: per-row Coriolis parameter (device pointers, ptr[j] = row j)
+             FP_F2U, FP_F2V,            // ... per-point Coriolis planes (parent addresses)
+             FP_C2_0, FP_COUNT = FP_C2_0 + C2_COUNT };   // ... the C2_COUNT per-point stencil coefficient planes (parent addresses)   // forcing arrays (parent addresses)                            // FP_MASK: parent address of the uint8 mask
 enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_LD_C, FI_LD_F,
              FI_RS, FI_R1 = FI_RS + 4, FI_R1C = FI_R1 + 4, FI_R2 = FI_R1C + 4, FI_IMU = FI_R2 + 4, FI_IMV = FI_IMU + 4,
              FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX,
-             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_FREE_DRIFT, FI_COUNT };
+             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_FREE_DRIFT,
+             FI_C2_LD, FI_FKIND,        // CSI_METRIC_FULL: leading dimension of the coefficient / Coriolis planes; f kind 0 number, 1 rows, 2 points
+             FI_COUNT };
 struct FusedTable {
     double K[FK_COUNT];
     unsigned long P[FP_COUNT];
@@ -53,12 +58,13 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
                       const ImageSpec& imu, const ImageSpec& imv, FusedTable* host_table);
 void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst, int nstrips, int nchunks, int rows,
                           int write_diag, hipStream_t s);
-// two sub-steps per launch (evp_fused2.hip).  The table is one filled by fused_fill_table for the SECOND
+// two sub-steps per launch (evp_fused2.hip); metric: 0 uniform coefficients, 1 per-row table, 2 per-point planes (CSI_METRIC_FULL).
+// The table is one filled by fused_fill_table for the SECOND
 // sub-step's store ranges (rs, r1, r2; r1c unused) plus: dec = the second sub-step's compute (stress) range that
 // the wave tiles decompose, a_j0 / a_j1 = the first sub-step's stress rows, sigma image specs.
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
                            const ImageSpec& ims12, FusedTable* host_table);
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
+void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
                        bool common_forcing, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s);
 // array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported;
 // StressBalanceFreeDrift (P.free_drift: free-drift velocity arrays P.ufd / P.vfd) also selects the FORCE variant

@@ -296,7 +296,6 @@ static bool fused_offsets_fit(const EvpDev& P) {
     return ld * nj * 8 < (1L << 32);
 }
 int pair_forcing_kind(const EvpDev& P) {
-    if (P.g.metric_kind == 2) return -1;
     if (P.extra || P.g.yhi == SIDE_FOLD) return -1;           // model.forcing arrays / immersed flux BCs / north fold: three kernels
     const int lc = P.h.ld, lf = P.u.ld;
     if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return -1;
@@ -391,6 +390,21 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     if (g.has_mask) {
         Q[FP_MASK] = (unsigned long)(g.mask - ((g.Hx - 1) + (long)(g.Hy - 1) * g.mask_ld));
         I[FI_MASK_LD] = g.mask_ld;
+    }
+    if (g.metric_kind == 2 && c.c2) {
+        // per-point stencil coefficients: parent address (element (1 - Hx, 1 - Hy)) of every plane
+        const long org = (1 - g.Hx) + (long)(1 - g.Hy) * c.c2_ld;
+        for (int k = 0; k < C2_COUNT; ++k) Q[FP_C2_0 + k] = (unsigned long)(c.c2 + (long)k * c.c2_plane + org);
+        I[FI_C2_LD] = c.c2_ld;
+        I[FI_FKIND] = 0;
+        if (P.has_cor && P.fcor2_u) {
+            I[FI_FKIND] = 2;
+            Q[FP_F2U] = (unsigned long)(P.fcor2_u + (1 - g.Hx) + (long)(1 - g.Hy) * P.fcor2_ld);
+            Q[FP_F2V] = (unsigned long)(P.fcor2_v + (1 - g.Hx) + (long)(1 - g.Hy) * P.fcor2_ld);
+        } else if (P.has_cor && P.fcor_u) {
+            I[FI_FKIND] = 1;
+            Q[FP_FROW_U] = (unsigned long)P.fcor_u; Q[FP_FROW_V] = (unsigned long)P.fcor_v;
+        }
     }
 }
 

@@ -69,8 +69,10 @@ template <int V> struct Idx { static constexpr int value = V; };
 constexpr int RING_ROWS = 4, RING_FIELDS = 10;
 enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF_VN };
 
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, bool CF>
-__global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+// FULL (orthogonal curvilinear grids, per-point stencil coefficients streamed from 26 planes): 26 more loads per stage-row
+// in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the coefficient traffic there.
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, bool CF, bool FULL = false>
+__global__ void __launch_bounds__(128, FULL ? 2 : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag) {
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[RING_ROWS * 64];
@@ -156,6 +158,8 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
     auto offc = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * sc; };
     auto offf = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * sf; };
     auto offm = [&](int j) __attribute__((always_inline)) { return lm + (unsigned)(j - row0) * sm; };
+    const unsigned c2s = FULL ? (unsigned)T->I[FI_C2_LD] * 8u : 0u;         // row stride of the per-point coefficient planes
+    auto off2 = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * c2s; };
     const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
     // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
     const bool wrap_y_b = T->I[FI_YLO] == SIDE_PERIODIC;
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
     if (!consumer) {
         // ===== PRODUCER: stage A = sub-step s, rows rstart .. rend ===================================================
         PROBE_DECL;
-        Stage<UNI, AUF, MASK, FORCE, CF> A;          // (TIGHT scalar live ranges in the array-forcing variants)
+        Stage<UNI, AUF, MASK, FORCE, CF, FULL> A;    // (TIGHT scalar live ranges in the array-forcing variants)
         unsigned oc = offc(rstart), of = offf(rstart), om = MASK ? offm(rstart) : 0u;
         {
             const double rho0 = T->K[FK_RHO];
@@ -354,13 +358,21 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
             A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
             double e11_m, e22_m;
             const int jm = rstart - 1;
+            if constexpr (FULL) {
+                const unsigned om2 = off2(jm), o02 = off2(rstart);
+                const double u_e = from_right(A.u_m), v_w = from_left(A.v_0);
+                e11_m = fm::fma_(c2at(T, C2_E11E, om2), u_e, fm::fma_(c2at(T, C2_E11N, om2), A.v_0, -fm::fma_(c2at(T, C2_E11W, om2), A.u_m, c2at(T, C2_E11S, om2) * A.v_m)));
+                e22_m = fm::fma_(c2at(T, C2_E22E, om2), u_e, fm::fma_(c2at(T, C2_E22N, om2), A.v_0, -fm::fma_(c2at(T, C2_E22W, om2), A.u_m, c2at(T, C2_E22S, om2) * A.v_m)));
+                A.e12_0 = fm::fma_(c2at(T, C2_SUN, o02), A.u_0, fm::fma_(c2at(T, C2_SVE, o02), A.v_0, -fm::fma_(c2at(T, C2_SUS, o02), A.u_m, c2at(T, C2_SVW, o02) * v_w)));
+            } else {
             fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                             coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
             A.e12_0 = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, rstart), coef<UNI>(T, FC_SS, rstart), coef<UNI>(T, FC_SV, rstart), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
+            }
             A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);
             A.Xe22_m = fm::sum2(from_left(e22_m), e22_m);
             A.Ye12_0 = fm::sum2(A.e12_0, from_right(A.e12_0));
-            A.XAL_m = 0; A.XS11L_m = 0; A.XW = 0; A.Wprev = 0;
+            A.XAL_m = 0; A.XS11L_m = 0; A.XS22L_m = 0; A.XW = 0; A.Wprev = 0;
             A.S11_mm = 0; A.S22_mm = 0; A.S12_mm = 0; A.AL_mm = 0; A.S11_m = 0; A.S22_m = 0; A.S12_m = 0; A.AL_m = 0;
             A.S11_0 = 0; A.S22_0 = 0; A.S12_0 = 0; A.AL_0 = 0; A.first = 0; A.second = 0;
         }
@@ -430,7 +442,8 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
             Forcing FA;
             numbers(FA);
             if (FORCE) arrays(FA, offf(r - 1), AUF ? offc(r - 1) : offc(r));      // u points of row r-1, v points of row r-1 / r
-            A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
+            A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA,
+                   FULL ? off2(r) : 0u, c2s);
             // ---- hand-off to the consumer: sigma(r); u(r-1); v(r-1) [u first] or v(r) [v first] --------------------------
             {
                 const unsigned s0 = rslot(r), s1 = rslot(r - 1);
@@ -474,11 +487,11 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
 
     // ===== CONSUMER: stage B = sub-step s + 1, rows q = r - 2, one iteration behind the producer ====================
     PROBE_DECL;
-    Stage<UNI, !AUF, MASK, FORCE, CF> B;
+    Stage<UNI, !AUF, MASK, FORCE, CF, FULL> B;
     B.u_m = 0; B.u_0 = 0; B.v_m = 0; B.v_0 = 0; B.Xv_m = 0; B.Xv_0 = 0;
     B.a_mm = 0; B.a_m = 0; B.m_mm = 0; B.m_m = 0;
     B.XP_m = 0; B.Xm_m = 0; B.Xa_m = 0; B.Xe11_m = 0; B.Xe22_m = 0; B.Ye12_0 = 0; B.e12_0 = 0;
-    B.XAL_m = 0; B.XS11L_m = 0; B.XW = 0; B.Wprev = 0;
+    B.XAL_m = 0; B.XS11L_m = 0; B.XS22L_m = 0; B.XW = 0; B.Wprev = 0;
     B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0;
@@ -533,7 +546,8 @@ __global__ void __launch_bounds__(128, CSI_PAIR_WAVES) k_pair(const FusedTable* 
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
-        B.step(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB);
+        B.step(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
+               FULL ? off2(max(q, row0)) : 0u, c2s);      // (rows below the planes only fill the window: clamped)
         {
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
             outr[so] = B.S11_0; outr[so + 64] = B.S22_0; outr[so + 128] = B.S12_0; outr[so + 192] = B.first; outr[so + 256] = B.second;
@@ -573,6 +587,10 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 }
 #endif
 
+#if defined(CSI_PAIR_DEBUG_C2) && CSI_PAIR_VARIANT == 1
+extern "C" int csi_debug_c2(unsigned* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_c2_bad), sizeof(unsigned) * 8); }
+#endif
+
 // One translation unit per variant so that the instantiations compile in parallel.  CSI_PAIR_VARIANT:
 // 0 plain, 1 walls, 2 walls + immersed mask, 3 walls + array-valued forcing, 4 walls + mask + array-valued forcing,
 // 5 / 6: 3 / 4 with StressBalanceFreeDrift (free-drift velocity arrays).
@@ -603,39 +621,44 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 #endif
 // common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF); the
 // array-forcing variants have one instantiation (kinds read from the table)
-void CSI_PAIR_NAME(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool common, int nstrips, int nchunks, int rows,
+void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, bool common, int nstrips, int nchunks, int rows,
                    int write_diag, hipStream_t s) {
     const int nblocks = nstrips * nchunks;              // one workgroup (producer wave + consumer wave) per tile
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(128);
-#define CSI_LAUNCH_PAIR_(U, A, C) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
+#define CSI_LAUNCH_PAIR_(U, A, C, F) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
 #if CSI_PAIR_VARIANT <= 2
-#define CSI_LAUNCH_PAIR(U, A) do { if (common) CSI_LAUNCH_PAIR_(U, A, true); else CSI_LAUNCH_PAIR_(U, A, false); } while (0)
+#define CSI_LAUNCH_PAIR(U, A) do { if (common) CSI_LAUNCH_PAIR_(U, A, true, false); else CSI_LAUNCH_PAIR_(U, A, false, false); } while (0)
 #else
-#define CSI_LAUNCH_PAIR(U, A) do { (void)common; CSI_LAUNCH_PAIR_(U, A, false); } while (0)
+#define CSI_LAUNCH_PAIR(U, A) do { (void)common; CSI_LAUNCH_PAIR_(U, A, false, false); } while (0)
 #endif
-    if (uniform) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
+    if (metric == 2) {
+#if CSI_PAIR_VARIANT >= 1
+        if (a_ufirst) CSI_LAUNCH_PAIR_(false, true, false, true); else CSI_LAUNCH_PAIR_(false, false, false, true);
+#endif
+    } else if (metric == 0) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
     else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true); else CSI_LAUNCH_PAIR(false, false); }
 #undef CSI_LAUNCH_PAIR
 #undef CSI_LAUNCH_PAIR_
 }
 
 #if CSI_PAIR_VARIANT == 0
-void launch_fused_pair_walls(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_force(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_force_fd(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force_fd(const FusedTable*, bool, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair(const FusedTable* dev_table, bool uniform, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
+void launch_fused_pair_walls(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_force(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_force_fd(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
                        bool common, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
-    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (free_drift) launch_fused_pair_force_fd(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (force && mask) launch_fused_pair_mask_force(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (force) launch_fused_pair_force(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (mask) launch_fused_pair_mask(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (walls) launch_fused_pair_walls(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else launch_fused_pair_plain(dev_table, uniform, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    if (metric == 2) walls = true;      // per-point coefficients: the general variants only (none built without walls)
+    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (force && mask) launch_fused_pair_mask_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (force) launch_fused_pair_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (mask) launch_fused_pair_mask(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else if (walls) launch_fused_pair_walls(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    else launch_fused_pair_plain(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
 }
 #endif
 

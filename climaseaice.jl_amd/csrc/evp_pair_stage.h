@@ -34,12 +34,16 @@ __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__b
 // CF ("common forcing"): the external stresses are known at compile time to be a number-valued top stress (kind 0 / 1) and
 // a bottom SemiImplicitStress with number-valued ocean velocities (kind 3) -- the bench and most stand-alone runs --, so
 // the four wave-uniform kind branches per stage-row disappear.
-template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, bool CF = false>
+// FULL: orthogonal curvilinear grid (CSI_METRIC_FULL): the strain rates and stress divergences are the per-POINT stencils
+// of evp_fast.hip's k_*2 kernels (same operations, same order: bit-identical), their coefficients loaded per lane from
+// the C2_* planes at byte offset o2 (row r; o2 - s2 / o2 + s2: rows r - 1 / r + 1); UNI must be false.
+template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, bool CF = false, bool FULL = false>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
     double a_mm, a_m, m_mm, m_m;
     double XP_m, Xm_m, Xa_m, Xe11_m, Xe22_m, Ye12_0, e12_0;
     double XAL_m, XS11L_m, XW, Wprev;
+    double XS22L_m;      // FULL: sigma22 of row r-1 from the left neighbour (the u equation sees sigma22 on such grids)
     double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
     // results of the last step()
     double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, rDc, first, second;
@@ -52,14 +56,22 @@ struct Stage {
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
                                          bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
-                                         const Forcing& F) {
+                                         const Forcing& F, unsigned o2 = 0u, unsigned s2 = 0u) {
         Xa_0 = fm::avg2(from_left(a_0), a_0);
         Xv_p = fm::sum2(from_left(v_p), v_p);               // x-SUMS (Xv, Xe11, Xe22, Ye12, XP, XW): scaled once, in quarter()
         double e11_0, e22_0;
+        if constexpr (FULL) {
+            // strain_cell2 / strain_corner2 of evp_fast.hip: cell (i, r), corner (i, r + 1)
+            const double u_e = from_right(u_0), v_w = from_left(v_p);
+            e11_0 = fm::fma_(c2at(T, C2_E11E, o2), u_e, fm::fma_(c2at(T, C2_E11N, o2), v_p, -fm::fma_(c2at(T, C2_E11W, o2), u_0, c2at(T, C2_E11S, o2) * v_0)));
+            e22_0 = fm::fma_(c2at(T, C2_E22E, o2), u_e, fm::fma_(c2at(T, C2_E22N, o2), v_p, -fm::fma_(c2at(T, C2_E22W, o2), u_0, c2at(T, C2_E22S, o2) * v_0)));
+            e12_p = fm::fma_(c2at(T, C2_SUN, o2 + s2), u_p, fm::fma_(c2at(T, C2_SVE, o2 + s2), v_p, -fm::fma_(c2at(T, C2_SUS, o2 + s2), u_0, c2at(T, C2_SVW, o2 + s2) * v_w)));
+        } else {
         fm::strain_cell<UNI>(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
                         coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
         e12_p = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
                                   u_p, u_0, v_p, from_left(v_p));
+        }
         {
             const double Xe11_0 = fm::sum2(from_left(e11_0), e11_0), Xe22_0 = fm::sum2(from_left(e22_0), e22_0);
             const double Ye12_p = fm::sum2(e12_p, from_right(e12_p));
@@ -79,14 +91,16 @@ struct Stage {
                     ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.amin2 = T->K[FK_AMIN2];
                     ks.amax2 = T->K[FK_AMAX2]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
                 }
-                const double kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r), kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r);
+                double kc, kf;
+                if constexpr (FULL) { kc = T->K[FK_CA_DT] * c2at(T, C2_RAZC, o2); kf = T->K[FK_CA_DT] * c2at(T, C2_RAZF, o2); }
+                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r); }
                 const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
             }
         }
         // stresses as the divergence sees them, peripheral flags
         double d11_0 = S11_0, d22_0 = S22_0, d12_0 = S12_0, d11_m = S11_m, d22_m = S22_m, d12_m = S12_m, d11_mm = S11_mm, d22_mm = S22_mm;
-        double d11_mL = XS11L_m;
+        double d11_mL = XS11L_m, d22_mL = XS22L_m;
         if (MASK) {
             const unsigned m0 = mh & 3u, m1 = (mh >> 2) & 3u, m2 = (mh >> 4) & 3u;
             const bool pcc_0 = m0 == 1u, pcc_m = m1 == 1u, pcc_mm = m2 == 1u;        // immersed, not beyond a wall
@@ -98,12 +112,31 @@ struct Stage {
             d11_mm = pcc_mm ? 0.0 : S11_mm; d22_mm = pcc_mm ? 0.0 : S22_mm;
             d12_0 = pff_0 ? 0.0 : S12_0; d12_m = pff_m ? 0.0 : S12_m;
             d11_mL = from_left(d11_m);
+            if constexpr (FULL) d22_mL = from_left(d22_m);
             const bool ia_0 = (m0 & 1u) != 0, ia_m = (m1 & 1u) != 0, ia_mm = (m2 & 1u) != 0;
             const bool ia_mL = (left_bits(m1) & 1u) != 0;
             const bool per_u = ia_m | ia_mL;                                          // u(i, r-1): cells (i, r-1), (i-1, r-1)
             per_first = UFIRST ? per_u : (ia_0 | ia_m);                               // v(i, r): cells (i, r), (i, r-1)
             per_second = UFIRST ? (ia_m | ia_mm) : per_u;                             // v(i, r-1): cells (i, r-1), (i, r-2)
         }
+        // FULL: d_j sigma_1j at the u point of row ju (k_ustep2) / d_j sigma_2j at the v point of row jv (k_vstep2); o = the
+        // coefficient offset of that row; f at the point: a number, a per-row value or a per-point plane
+        auto div1_full = [&](unsigned o, double s11_0, double s11_w, double s22_0, double s22_w, double s12_n, double s12_s) __attribute__((always_inline)) {
+            const double east = fm::fma_(c2at(T, C2_A11E, o), s11_0, fm::fma_(c2at(T, C2_A22E, o), s22_0, c2at(T, C2_A12N, o) * s12_n));
+            const double west = fm::fma_(c2at(T, C2_A11W, o), s11_w, fm::fma_(c2at(T, C2_A22W, o), s22_w, c2at(T, C2_A12S, o) * s12_s));
+            return east - west;
+        };
+        auto div2_full = [&](unsigned o, double s11_0, double s11_s, double s22_0, double s22_s, double s12_e, double s12_0) __attribute__((always_inline)) {
+            const double north = fm::fma_(c2at(T, C2_B11N, o), s11_0, fm::fma_(c2at(T, C2_B22N, o), s22_0, c2at(T, C2_B12E, o) * s12_e));
+            const double south = fm::fma_(c2at(T, C2_B11S, o), s11_s, fm::fma_(c2at(T, C2_B22S, o), s22_s, c2at(T, C2_B12W, o) * s12_0));
+            return north - south;
+        };
+        auto f_full = [&](int which_row, int which_plane, unsigned o, int j) __attribute__((always_inline)) {
+            const int kind = T->I[FI_FKIND];
+            if (kind == 2) return ldg(T->P[which_plane], o);
+            if (kind == 1) { typedef const __attribute__((address_space(4))) double* vptr_t; return ((vptr_t)T->P[which_row])[j]; }
+            return T->K[FK_FCOR];
+        };
         fm::VelConst kv = kv_in;
         if (TIGHT) {
             asm volatile("" : "+s"(T));
@@ -116,25 +149,33 @@ struct Stage {
             double W_0;
             {
                 const double vbar = fm::quarter(Xv_m, Xv_0);
-                const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
+                double div;
+                if constexpr (FULL) div = div1_full(o2 - s2, d11_m, d11_mL, d22_m, d22_mL, d12_0, d12_m);
+                else div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
                 fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
-                const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                double cor;
+                if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
+                else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 W_0 = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
                            : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::sum2(W_0, from_right(W_0));
             {
                 const double ubar = fm::quarter(XW, XW_0);
-                const double div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
+                double div;
+                if constexpr (FULL) div = div2_full(o2 - s2, d11_m, d11_mm, d22_m, d22_mm, from_right(d12_m), d12_m);
+                else div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
                 fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
-                const double cor = -coef<UNI>(T, FC_FV, j) * ubar;
+                double cor;
+                if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2 - s2, j) * ubar;
+                else cor = -coef<UNI>(T, FC_FV, j) * ubar;
                 second = F.fd ? fm::vel_update_fd(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
                               : fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
@@ -144,13 +185,17 @@ struct Stage {
             double W_0;
             {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
-                const double div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
+                double div;
+                if constexpr (FULL) div = div2_full(o2, d11_0, d11_m, d22_0, d22_m, from_right(d12_0), d12_0);
+                else div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
                 fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
-                const double cor = -coef<UNI>(T, FC_FV, r) * ubar;
+                double cor;
+                if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2, r) * ubar;
+                else cor = -coef<UNI>(T, FC_FV, r) * ubar;
                 W_0 = F.fd ? fm::vel_update_fd(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
                            : fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -158,12 +203,16 @@ struct Stage {
             {
                 const int j = r - 1;
                 const double vbar = fm::quarter(XW, XW_0);
-                const double div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
+                double div;
+                if constexpr (FULL) div = div1_full(o2 - s2, d11_m, d11_mL, d22_m, d22_mL, d12_0, d12_m);
+                else div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
                 fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
-                const double cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                double cor;
+                if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
+                else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 second = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
                               : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
@@ -182,6 +231,7 @@ struct Stage {
         S11_mm = S11_m; S22_mm = S22_m; S12_mm = S12_m; AL_mm = AL_m;
         S11_m = S11_0; S22_m = S22_0; S12_m = S12_0; AL_m = AL_0;
         XAL_m = fm::avg2(from_left(AL_0), AL_0); XS11L_m = from_left(S11_0);
+        if constexpr (FULL) XS22L_m = from_left(S22_0);
         XW = XW_next;
         Wprev = first;
     }

@@ -21,6 +21,9 @@ CONFIGS = {
         dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True),
     "beta-plane channel (per-row f on uniform metrics)": dict(topo=("periodic", "bounded"), beta=1.6e-11),
     "no-slip channel with 30 % land (coastline-example style)": dict(topo=("periodic", "bounded"), land=0.3, noslip=True),
+    "curvilinear channel (twelve 2-D metric arrays, CSI_METRIC_FULL)": dict(topo=("periodic", "bounded"), curvilinear=0.05),
+    "curvilinear channel with 30 % land": dict(topo=("periodic", "bounded"), curvilinear=0.05, land=0.3),
+    "tripolar-like (north fold, curvilinear, 30 % land, arrays, free drift): three kernels": dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True),
 }
 if len(sys.argv) > 2:
     CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}

@@ -1,0 +1,28 @@
+import sys
+sys.path[:0] = [".", "tests", "oracle"]
+import faulthandler
+import numpy as np
+import cases
+import climaseaice_jl_amd as csi
+from test_gpu_evp import CASES, EVP_FIELDS
+name = sys.argv[1] if len(sys.argv) > 1 else "curvilinear_bounded"
+nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+c = cases.make_case(substeps=nsub, **CASES[name])
+out = {}
+for fusion in (0, 2):
+    m = cases.csi_model(c, mode="fast")
+    m.set_fusion(fusion)
+    print("running fusion", fusion, flush=True)
+    csi.time_step_momentum(m, c["dt"])
+    m.synchronize()
+    print("level", m.ctx.last_path(), flush=True)
+    out[fusion] = {k: EVP_FIELDS[k](m).interior_numpy().copy() for k in ("u", "v", "s11", "s22", "s12")}
+for k in out[0]:
+    d = np.abs(out[0][k] - out[2][k])
+    print(k, "max diff", d.max(), "n diff", (d > 0).sum(), np.argwhere(d > 0)[:5].tolist())
+import ctypes as C
+L = C.CDLL(csi._lib.LIB_PATH)
+if hasattr(L, "csi_debug_c2"):
+    buf = (C.c_uint * 8)()
+    L.csi_debug_c2(buf)
+    print("c2 debug: count", buf[0], "which", buf[1], "off", buf[2], "= %d" % (buf[2] - (1 << 32)), "thread", buf[3], "block", buf[4])

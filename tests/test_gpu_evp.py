@@ -98,9 +98,9 @@ CASES = {
     "immersed_flux_bc_curvilinear": dict(Nx=64, Ny=48, topo=("periodic", "periodic"), patches=True, random_uv=0.03, land=0.25, curvilinear=0.05,
                                          immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)), user_forcing=True),
 }
-MASKED = {"noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
+MASKED = {"curvilinear_periodic", "curvilinear_bounded", "curvilinear_masked", "coriolis_points_curvilinear", "noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = {"coriolis_points_curvilinear", "coriolis_points_tripolar", "folded_uniform", "folded_tripolar", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}   # rare tendency terms: never fused
+THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}   # rare tendency terms: never fused
 
 
 def ulp_diff(a, b):
@@ -413,7 +413,7 @@ def test_pair_kernel_on_tiles_halo32_interval16(topo):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
-EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear", "folded_tripolar", "coriolis_points_curvilinear", "coriolis_points_tripolar"})
+EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear", "folded_tripolar", "coriolis_points_tripolar"})
 FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",

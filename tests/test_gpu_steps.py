@@ -165,7 +165,8 @@ def test_curvilinear_grid_full_step_bitwise(stepper, name, oracle_lib):
                 p.time_step_rk3(c["dt"], 7)
             csi.time_step(m, c["dt"])
         m.synchronize()
-        assert m.ctx.last_path()["level"] == 0
+        # FAST: the two-sub-steps kernel streams the per-point coefficient planes (a north fold runs the three kernels)
+        assert m.ctx.last_path()["level"] == (2 if (mode == "fast" and name != "folded_masked") else 0)
         vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
         tol = 1e-12 if mode == "strict" else 1e-11
         for k, f in (("u", m.velocities.u), ("v", m.velocities.v)):
