@@ -32,6 +32,9 @@
 #ifndef CSI_PAIR_WAVES
 #define CSI_PAIR_WAVES 3        // waves per SIMD the register allocation aims at (512 / 3 -> 168 VGPRs)
 #endif
+#ifndef CSI_PAIR_FULL_WAVES
+#define CSI_PAIR_FULL_WAVES 2   // ... of the per-point-coefficient (CSI_METRIC_FULL) instantiations
+#endif
 #ifndef CSI_PAIR_PRIO
 #define CSI_PAIR_PRIO 1         // rotate the user priority of the resident workgroups of a CU every row (see k_pair)
 #endif
@@ -72,7 +75,7 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 // FULL (orthogonal curvilinear grids, per-point stencil coefficients streamed from 26 planes): 26 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the coefficient traffic there.
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, bool CF, bool FULL = false>
-__global__ void __launch_bounds__(128, FULL ? 2 : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+__global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag) {
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[RING_ROWS * 64];
