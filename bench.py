@@ -38,6 +38,25 @@ KERNEL_NAMES = {"substep": "csi::fused::k_substep (stress + u + v in one launch)
                 "stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU boxes
+    show 256 hardware threads but grant 16 CPUs: cpu.max = 1600000 100000; more OpenMP threads than that only spin)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, int(math.ceil(q / per))))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The oracle (strict-order C restatement of the reference's kernel split, oracle/csi_oracle.c, OpenMP over rows)
     timed on this box's host cores: the EVP sub-step loop alone (ora_subcycle: viscosities, stresses, u / v steps, halo
@@ -45,7 +64,7 @@ def cpu_baseline(seconds_budget=12.0):
     reported baseline on a bounded sample of the same workload; never the target, and no speed-up is derived from it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cases
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = usable_cores()
     try:
         gomp = ctypes.CDLL("libgomp.so.1")
     except OSError:
@@ -73,7 +92,7 @@ def cpu_baseline(seconds_budget=12.0):
     return {"value": vall, "unit": "cell-updates/s", "cores": threads if gomp is not None else 1, "kind": "port",
             "one_thread_value": v1, "thread_scaling": vall / v1,
             "sample": f"EVP sub-step loop only (ora_subcycle): {sub} sub-steps of the 2048x2048 periodic f-plane workload on "
-                      f"{threads} OpenMP threads (= os.sched_getaffinity); one-thread figure from 12 sub-steps of a 512x512 "
+                      f"{threads} OpenMP threads (= scheduler affinity capped by the cgroup CPU quota); one-thread figure from 12 sub-steps of a 512x512 "
                       f"grid of the same workload; oracle/csi_oracle.c: the reference's four-kernel split in strict IEEE "
                       f"order (gcc -O2 -ffp-contract=off), strain rates recomputed per stencil point as the reference does -- "
                       f"a lower bound on what a tuned CPU code would reach"}
