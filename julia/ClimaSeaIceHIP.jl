@@ -8,12 +8,22 @@ module ClimaSeaIceHIP
 
 using ClimaSeaIce
 using ClimaSeaIce: SeaIceModel
-using ClimaSeaIce.SeaIceDynamics: SeaIceMomentumEquation, SplitExplicitSolver, SemiImplicitStress
+using ClimaSeaIce.SeaIceDynamics: SeaIceMomentumEquation, SplitExplicitSolver, SemiImplicitStress, StressBalanceFreeDrift
 using ClimaSeaIce.Rheologies: ElastoViscoPlasticRheology, ReplacementPressure
 using Oceananigans
-using Oceananigans.Grids: topology, halo_size, Periodic, Bounded, RectilinearGrid, LatitudeLongitudeGrid
+using Oceananigans: CPU
+using Oceananigans.Architectures: architecture
+using Oceananigans.BoundaryConditions: FluxBoundaryCondition, getbc
+using Oceananigans.Coriolis: FPlane, BetaPlane
+using Oceananigans.DistributedComputations: Distributed
+using Oceananigans.Fields: Field, ZeroField, ConstantField
+using Oceananigans.Grids: topology, halo_size, Periodic, Bounded, Center, Face, RectilinearGrid, LatitudeLongitudeGrid,
+                          OrthogonalSphericalShellGrid, ynode, inactive_cell
+using Oceananigans.ImmersedBoundaries: ImmersedBoundaryGrid, ImmersedBoundaryCondition
+using Oceananigans.OrthogonalSphericalShellGrids: TripolarGrid
 using Oceananigans.TimeSteppers: SplitRungeKuttaTimeStepper
 using AMDGPU
+using MPI
 
 const libcsi = get(ENV, "LIBCSI_HIP", "libcsi_hip.so")
 
@@ -38,7 +48,7 @@ end
 # field slots, in the order of csi_field_id
 const F = (U=0, V=1, H=2, A=3, S11=4, S22=5, S12=6, UN=7, VN=8, P=9, ALPHA=10, DELTA=11, ZETA_F=12, ZETA_C=13,
            GH=14, GA=15, HM=16, AM=17, UM=18, VM=19, TOP_U=20, TOP_V=21, BOT_U=22, BOT_V=23, MASS_FLUX=24,
-           HS=25, GHS=26, HSM=27, MASS_FLUX_SNOW=28, SNOWFALL_INTERCEPTED=29, TU=30, TUS=31)
+           HS=25, GHS=26, HSM=27, MASS_FLUX_SNOW=28, SNOWFALL_INTERCEPTED=29, TU=30, TUS=31, FORCING_U=32, FORCING_V=33)
 
 mutable struct Context
     handle::Ptr{Cvoid}
@@ -62,8 +72,17 @@ function Context(device_id = AMDGPU.device_id(AMDGPU.device()) - 1; stream = AMD
     return ctx
 end
 
+# csi_topology: 0 Periodic, 1 Bounded, 2 FullyConnected, 3 LeftConnected, 4 RightConnected, 5 RightFolded (the y direction
+# of a TripolarGrid: south wall + north fold / Zipper), 6 LeftConnected + RightFolded (northernmost rank of a y partition)
 topo_code(::Type{Periodic}) = Int32(0)
 topo_code(::Type{Bounded}) = Int32(1)
+topo_code(::Type{Oceananigans.Grids.FullyConnected}) = Int32(2)
+topo_code(::Type{Oceananigans.Grids.LeftConnected}) = Int32(3)
+topo_code(::Type{Oceananigans.Grids.RightConnected}) = Int32(4)
+# a TripolarGrid reports (Periodic, RightConnected, ...) on one rank; its north side is the fold, not an exchange
+y_topo_code(grid, TY) = topo_code(TY)
+y_topo_code(grid::TripolarGrid, TY) = TY === Oceananigans.Grids.FullyConnected || TY === Oceananigans.Grids.LeftConnected ? Int32(6) : Int32(5)
+y_topo_code(grid::ImmersedBoundaryGrid, TY) = y_topo_code(grid.underlying_grid, TY)
 
 # Oceananigans parent array: column-major (ni, nj, 1); ld = ni
 function bind!(ctx, slot, field)
@@ -94,7 +113,9 @@ end
 
 # Orthogonal curvilinear grids (OrthogonalSphericalShellGrid: 2-D metric arrays): the twelve metrics at the four
 # horizontal locations, evaluated with the public operators over the halo-extended index range and copied to the host once.
-function set_grid!(ctx, grid::Oceananigans.Grids.OrthogonalSphericalShellGrid)
+set_grid!(ctx, grid::ImmersedBoundaryGrid) = set_grid!(ctx, grid.underlying_grid)       # the mask goes through csi_mask_set
+
+function set_grid!(ctx, grid::OrthogonalSphericalShellGrid)
     Nx, Ny, _ = size(grid); Hx, Hy, _ = halo_size(grid); TX, TY, _ = topology(grid)
     is, js = (1 - Hx):(Nx + Hx + 1), (1 - Hy):(Ny + Hy + 1)
     ops = (Oceananigans.Operators.Δxᶜᶜᶜ, Oceananigans.Operators.Δxᶠᶜᶜ, Oceananigans.Operators.Δxᶜᶠᶜ, Oceananigans.Operators.Δxᶠᶠᶜ,
@@ -106,12 +127,23 @@ function set_grid!(ctx, grid::Oceananigans.Grids.OrthogonalSphericalShellGrid)
     GC.@preserve arrays begin
         m = Ref(CsiMetrics(0.0, 0.0, C_NULL, C_NULL, C_NULL, C_NULL, ntuple(k -> pointer(arrays[k]), 12), length(is)))
         check(ctx, ccall((:csi_grid_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Ref{CsiMetrics}),
-                         ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), topo_code(TY), 2, m))
+                         ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), y_topo_code(grid, TY), 2, m))
     end
+end
+
+# activity mask of an immersed grid: 1 = active cell, parent shape of a (Center, Center) field, halos included
+function active_cells_mask(grid::ImmersedBoundaryGrid)
+    Nx, Ny, Nz = size(grid); Hx, Hy, _ = halo_size(grid)
+    cpu_grid = Oceananigans.on_architecture(CPU(), grid)
+    mask = UInt8[inactive_cell(i, j, Nz, cpu_grid) ? 0x00 : 0x01 for i in (1 - Hx):(Nx + Hx), j in (1 - Hy):(Ny + Hy)]
+    return ROCArray(mask)
 end
 
 stress_struct(::Nothing) = CsiStress(0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 stress_struct(τ::NamedTuple{(:u, :v), <:Tuple{Number, Number}}) = CsiStress(1, 0, 0, 0, τ.u, τ.v, 0, 0, 0, 0)
+# stress given as Fields at the (Face, Center) / (Center, Face) points (the coupled-model case, sea_ice_external_stress.jl:19-20):
+# CSI_STRESS_FIELD; the arrays are bound to CSI_F_TOP_U / _V or CSI_F_BOT_U / _V in attach!
+stress_struct(τ::NamedTuple{(:u, :v), <:Tuple{Field, Field}}) = CsiStress(2, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 function stress_struct(τ::SemiImplicitStress)
     kind(x) = x isa Oceananigans.Fields.ZeroField ? Int32(0) : x isa Oceananigans.Fields.ConstantField ? Int32(1) : Int32(2)
     val(x) = x isa Oceananigans.Fields.ConstantField ? Float64(x.constant) : 0.0
@@ -171,12 +203,32 @@ function attach!(model::SeaIceModel)
         if τ isa SemiImplicitStress    # field-valued external velocities
             τ.uₑ isa Field && bind!(ctx, side == 0 ? F.TOP_U : F.BOT_U, τ.uₑ)
             τ.vₑ isa Field && bind!(ctx, side == 0 ? F.TOP_V : F.BOT_V, τ.vₑ)
+        elseif τ isa NamedTuple && τ.u isa Field      # stress arrays
+            bind!(ctx, side == 0 ? F.TOP_U : F.BOT_U, τ.u)
+            bind!(ctx, side == 0 ? F.TOP_V : F.BOT_V, τ.v)
         end
     end
     # free_drift = StressBalanceFreeDrift(...): the library rebuilds the balance on the model's own stresses, like
     # materialize_free_drift (stress_balance_free_drift.jl:44-46)
     check(ctx, ccall((:csi_free_drift_set, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle,
                      dyn.free_drift isa StressBalanceFreeDrift ? 1 : 0))
+    # model.forcing.u / .v given as Fields (arrays): the user forcing of sum_of_forcing_u / _v (elasto_visco_plastic_rheology.jl:391-401);
+    # closures cannot cross a C ABI and keep the model on the Julia kernels
+    if model.forcing.u isa Field && model.forcing.v isa Field
+        bind!(ctx, F.FORCING_U, model.forcing.u); bind!(ctx, F.FORCING_V, model.forcing.v)
+    end
+    # immersed FluxBoundaryConditions of u and v with number values (ice_stress_divergence.jl:65-123)
+    for (slot, f) in ((F.U, model.velocities.u), (F.V, model.velocities.v))
+        ibc = f.boundary_conditions.immersed
+        if ibc isa ImmersedBoundaryCondition
+            val(bc) = bc isa FluxBoundaryCondition && bc.condition isa Number ? Float64(bc.condition) : 0.0
+            check(ctx, ccall((:csi_immersed_flux_bc_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Cdouble, Cdouble, Cdouble, Cdouble),
+                             ctx.handle, slot, val(ibc.west), val(ibc.east), val(ibc.south), val(ibc.north)))
+        end
+    end
+    # tiles of a Distributed grid: one rank per GPU, RCCL point-to-point halos (csi_halo_exchange)
+    arch = architecture(grid)
+    arch isa Distributed && attach_tiles!(ctx, arch, grid)
     # immersed boundary: the activity mask (1 = active) as a UInt8 ROCArray with the parent shape of a Center field
     if grid isa ImmersedBoundaryGrid
         ctx.mask = active_cells_mask(grid)                       # kept alive by the context
@@ -185,6 +237,23 @@ function attach!(model::SeaIceModel)
     check(ctx, ccall((:csi_set_mode, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, 1))   # CSI_MODE_FAST
     check(ctx, ccall((:csi_set_fusion, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, 2)) # two sub-steps per launch (default)
     return ctx
+end
+
+# Distributed(arch; partition = Partition(Rx, Ry)): this rank's tile, the RCCL communicator (unique id made on rank 0 and
+# broadcast over MPI) -- after which csi_time_step_momentum exchanges u, v (, sigma) itself and the 2 * substeps + 3 halo of
+# split_explicit_momentum_equations.jl:51-64 is not needed (halo >= 2 k with csi_set_exchange_interval(k))
+function attach_tiles!(ctx, arch::Distributed, grid)
+    Rx, Ry, _ = arch.ranks
+    rx, ry, _ = arch.local_index .- 1
+    TX, TY, _ = topology(grid isa ImmersedBoundaryGrid ? grid.underlying_grid : grid)
+    px = TX === Periodic || TX === Oceananigans.Grids.FullyConnected && arch.connectivity.west !== nothing
+    py = TY === Periodic
+    check(ctx, ccall((:csi_tile_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32),
+                     ctx.handle, rx, ry, Rx, Ry, px ? 1 : 0, py ? 1 : 0))
+    id = zeros(UInt8, 128)
+    arch.local_rank == 0 && check(ctx, ccall((:csi_comm_unique_id, libcsi), Int32, (Ptr{UInt8},), id))
+    MPI.Bcast!(id, 0, arch.communicator)
+    check(ctx, ccall((:csi_comm_init, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), ctx.handle, Rx * Ry, arch.local_rank, id))
 end
 
 # row whose value a halo row images: the wrapped row of a Periodic y direction, the row itself otherwise
@@ -233,5 +302,27 @@ function ClimaSeaIce.dynamic_time_step!(model::SeaIceModel{<:Any, <:Any, <:Any, 
     GC.@preserve model check(ctx, ccall((:csi_dynamic_step_tracers, libcsi), Int32, (Ptr{Cvoid}, Cdouble, Int32), ctx.handle, Δt, from_cache))
     return nothing
 end
+
+# update_state!, sea_ice_model.jl:379-394: mask_immersed_field_xy! + fill_halo_regions! of the prognostic fields.  On one
+# rank csi_update_state does both (masks, local boundary conditions, the Zipper fold); on a Distributed grid the halos of
+# h, aice, u, v then travel over RCCL with the full halo width -- the hand-off Oceananigans' MPI halo pass would do.
+function ClimaSeaIce.update_state!(model::SeaIceModel{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPMomentumEquation}, callbacks = [])
+    ctx = context(model)
+    grid = model.velocities.u.grid
+    GC.@preserve model begin
+        check(ctx, ccall((:csi_update_state, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
+        if architecture(grid) isa Distributed
+            Hx, Hy, _ = halo_size(grid)
+            ids = Int32[F.H, F.A, F.U, F.V]
+            check(ctx, ccall((:csi_halo_exchange, libcsi), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32, Int32), ctx.handle, ids, length(ids), min(Hx, Hy)))
+        end
+    end
+    return nothing
+end
+
+# Checkpointing (sea_ice_model.jl:414-445: prognostic_state / restore_prognostic_state!) needs nothing from the library: the
+# state lives in the Oceananigans Fields, restore writes into the same parents, and the library holds pointers only.  If a
+# restore REPLACES parents (new arrays), drop the context so that the next step re-attaches:
+detach!(model) = (delete!(CONTEXTS, model); nothing)
 
 end # module
