@@ -8,7 +8,7 @@ inputs resident in HBM.  value = cell-updates/s = owned cells * substeps * steps
 N = 1: the 2048 x 2048 periodic f-plane grid the metric is quoted on.
 N > 1 (torch.distributed.run, one rank per GPU): STRONG scaling by default -- the SAME 2048 x 2048 grid split into
 Rx x Ry tiles (2x1, 2x2, 2x4: 1024 x 512 per GPU at N = 8, BASELINE config 4's decomposition), advanced by the same
-kernels with the RCCL halo exchange of u, v, sigma (width 2k every k sub-steps; halo 16 -> k = 8; `--exchange-interval 1`
+kernels with the RCCL halo exchange of u, v, sigma (width 2k every k sub-steps; halo 32 -> k = 16; `--exchange-interval 1`
 is the north star's one exchange per sub-step and is timed as well, outside the headline region).  `--scaling weak`
 gives every GPU its own 2048 x 2048 tile instead.
 Prints ONE JSON line on rank 0.
@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
-    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 16 on tiles so that k = 8)")
+    ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 32 on tiles so that k = 16)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
     ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
                     help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
@@ -184,7 +184,7 @@ def main():
         nx_l, ny_l = args.size // Rx, args.size // Ry
     tiled = world > 1 or args.force_connected
     if args.halo == 0:
-        args.halo = 16 if tiled else 4
+        args.halo = 32 if tiled else 4
     device = f"cuda:{local_rank}"
     tg, f = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=args.halo)
     dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
