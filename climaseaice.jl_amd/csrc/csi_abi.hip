@@ -421,14 +421,15 @@ struct FusedGeom { Range rs; int nstrips, nchunks, rows; };
 FusedGeom fused_geom(const csi_context* c, int V) {
     FusedGeom G;
     G.rs = stress_range(c, V);
-    // decomposition of the stress range into (60-column strip) x (rows) wave tiles: enough waves to fill the
-    // chip (>= ~10 per CU), rows long enough to amortise the 3 ring rows
+    // decomposition of the stress range into (60-column strip) x (rows) wave tiles.  Measured (round 2, MI355X): 2048^2
+    // rows 12 -> 32.2, 24 -> 28.8, 48 -> 20.7 G cell-updates/s; 1024 x 512: rows 2 -> 21.0, 4 -> 19.0, 12 -> 12.1: many short
+    // tiles beat few tall ones (the kernel is bandwidth-bound, its 3 ring rows are re-read from L2)
     const int width = G.rs.i1 - G.rs.i0 + 1, height = G.rs.j1 - G.rs.j0 + 1;
     G.nstrips = (width + 59) / 60;
     long strip_rows = (long)G.nstrips * height;
-    int rows = (int)(strip_rows / 2816);
-    if (rows < 12) rows = 12;
-    if (rows > 48) rows = 48;
+    int rows = (int)(strip_rows / 6000);
+    if (rows < 3) rows = 3;
+    if (rows > 12) rows = 12;
     if (const char* e = getenv("CSI_FUSED_ROWS")) rows = atoi(e);   // tuning aid
     if (rows > height) rows = height;
     if (rows < 1) rows = 1;

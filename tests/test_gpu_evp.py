@@ -164,6 +164,7 @@ def test_strict_bitwise_vs_oracle(name, oracle_lib):
 
 
 FAST_TOL_VEL, FAST_TOL_SIG = 1e-12, 1e-11
+_TOL_BRANCH = {}        # case -> {field: "stated" | "10x sensitivity"}: which bound each full-cycle comparison needed
 
 
 def oracle_self_sensitivity(c, fields=("u", "v", "s11", "s22", "s12")):
@@ -190,13 +191,17 @@ def test_fast_vs_oracle_full_cycle(name, oracle_lib):
     vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
     smax = max(np.abs(p.f["s11"]).max(), np.abs(p.f["s22"]).max(), np.abs(p.f["s12"]).max())
     well_conditioned = max(sens["u"], sens["v"]) <= 1e-13 * vmax
+    branch = {}
     for k in ("u", "v"):
         assert np.all(np.isfinite(g[k]))
         d = np.abs(g[k] - p.f[k]).max()
         assert d <= max(FAST_TOL_VEL * vmax, 10 * sens[k]), (k, d, vmax, sens[k])
+        branch[k] = "stated" if d <= FAST_TOL_VEL * vmax else "10x sensitivity"
     for k in ("s11", "s22", "s12"):
         d = np.abs(cmp_region(c, k, g[k]) - cmp_region(c, k, p.f[k])).max()
         assert d <= max(FAST_TOL_SIG * smax, 10 * sens[k]), (k, d, smax, sens[k])
+        branch[k] = "stated" if d <= FAST_TOL_SIG * smax else "10x sensitivity"
+    _TOL_BRANCH[name] = branch
     # masks / threshold decisions: zero velocity cells (no ice, peripheral nodes) are bit-identical sets
     assert np.array_equal(g["u"] == 0.0, p.f["u"] == 0.0)
     assert np.array_equal(g["v"] == 0.0, p.f["v"] == 0.0)
@@ -210,6 +215,25 @@ def test_fast_vs_oracle_full_cycle(name, oracle_lib):
         for k in ("zeta_c", "zeta_f", "Delta"):
             scale = np.abs(p.f[k]).max()
             assert np.abs(cmp_region(c, k, g[k]) - cmp_region(c, k, p.f[k])).max() <= 1e-10 * scale, k
+
+
+def test_fast_vs_oracle_tolerance_branch_report():
+    """How many of the full-cycle comparisons above needed the loose bound (10 x the oracle's own sensitivity) instead of
+    the stated tolerance: printed and written to gpurun_out/fast_tolerance_branches.json.  The rigid-pack cases (a fully
+    compact, uniformly moving pack: Delta = Delta_min, gamma > alpha+) are the ones expected there; they are checked tight
+    after 1-2 sub-steps below."""
+    import json, os
+    if not _TOL_BRANCH:
+        pytest.skip("the full-cycle tests did not run in this session")
+    loose = {n: [k for k, b in br.items() if b != "stated"] for n, br in _TOL_BRANCH.items()}
+    loose = {n: v for n, v in loose.items() if v}
+    report = {"cases": len(_TOL_BRANCH), "cases_with_a_loose_field": len(loose), "loose": loose}
+    print("[fast-vs-oracle]", json.dumps(report))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(report, open(os.path.join(out, "fast_tolerance_branches.json"), "w"), indent=1)
+    # the seeded inputs of most cases are well conditioned: at least half of them must pass on the stated tolerance alone
+    assert len(loose) <= len(_TOL_BRANCH) // 2, report
 
 
 @pytest.mark.parametrize("name", ["periodic_full_ice", "ice_strength_nocoriolis", "periodic_patches", "latlon_bounded"])
