@@ -665,12 +665,6 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
         c->ring_used[slot] = true;
     }
-    if (getenv("CSI_DEBUG_TABLE")) {
-        const FusedTable* t = c->host_ring + (size_t)((c->ring_pos - 1) % csi_context::kRing) * (NSINGLE + NPAIR) + NSINGLE;
-        fprintf(stderr, "[csi] pair table: metric %d c2_ld %d fkind %d dev_coef2 %p plane %ld bytes; P[C2_0] %lx P[C2_25] %lx; U_IN %lx P %lx; dec %d..%d x %d..%d AJ %d..%d\n",
-                c->metric_kind, t->I[FI_C2_LD], t->I[FI_FKIND], (void*)c->dev_coef2, (long)c->coef.c2_plane * 8, t->P[FP_C2_0], t->P[FP_C2_0 + 25],
-                t->P[FP_U_IN], t->P[FP_P], t->I[FI_DEC], t->I[FI_DEC + 1], t->I[FI_DEC + 2], t->I[FI_DEC + 3], t->I[FI_AJ0], t->I[FI_AJ1]);
-    }
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
     const int end = first + substeps;

@@ -590,10 +590,6 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 }
 #endif
 
-#if defined(CSI_PAIR_DEBUG_C2) && CSI_PAIR_VARIANT == 1
-extern "C" int csi_debug_c2(unsigned* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_c2_bad), sizeof(unsigned) * 8); }
-#endif
-
 // One translation unit per variant so that the instantiations compile in parallel.  CSI_PAIR_VARIANT:
 // 0 plain, 1 walls, 2 walls + immersed mask, 3 walls + array-valued forcing, 4 walls + mask + array-valued forcing,
 // 5 / 6: 3 / 4 with StressBalanceFreeDrift (free-drift velocity arrays).

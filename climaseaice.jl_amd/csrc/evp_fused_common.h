@@ -55,15 +55,7 @@ __device__ __forceinline__ void stg(unsigned long base, unsigned off, double v) 
 
 // CSI_METRIC_FULL: stencil coefficient `which` (C2_*, csi_fast_coef.h) of this lane's column at the row whose byte offset in
 // a coefficient plane is `off` (planes have their own leading dimension: FI_C2_LD)
-#ifdef CSI_PAIR_DEBUG_C2
-__device__ unsigned g_c2_bad[8];
-__device__ __forceinline__ double c2at(tptr_t T, int which, unsigned off) {
-    if (off > 0x7fffffffu) { if (atomicAdd(&g_c2_bad[0], 1u) == 0u) { g_c2_bad[1] = (unsigned)which; g_c2_bad[2] = off; g_c2_bad[3] = threadIdx.x; g_c2_bad[4] = blockIdx.x; } return 0.0; }
-    return ldg(T->P[FP_C2_0 + which], off);
-}
-#else
 __device__ __forceinline__ double c2at(tptr_t T, int which, unsigned off) { return ldg(T->P[FP_C2_0 + which], off); }
-#endif
 
 // Velocity store: plain, or with halo images when this wave's tile touches an edge band (wave-uniform test).
 __device__ __forceinline__ void store_vel(tptr_t T, int which_ptr, int which_ld, int img0, bool near_edge, int i, int j, double val) {

@@ -1,3 +1,5 @@
+"""Debug aid: run one named case of tests/test_gpu_evp.py::CASES with the three-kernel path and with the fused paths and
+print where they differ (they must not): python scripts/compare_paths.py <case> [substeps]"""
 import sys
 sys.path[:0] = [".", "tests", "oracle"]
 import faulthandler
@@ -20,9 +22,3 @@ for fusion in (0, 2):
 for k in out[0]:
     d = np.abs(out[0][k] - out[2][k])
     print(k, "max diff", d.max(), "n diff", (d > 0).sum(), np.argwhere(d > 0)[:5].tolist())
-import ctypes as C
-L = C.CDLL(csi._lib.LIB_PATH)
-if hasattr(L, "csi_debug_c2"):
-    buf = (C.c_uint * 8)()
-    L.csi_debug_c2(buf)
-    print("c2 debug: count", buf[0], "which", buf[1], "off", buf[2], "= %d" % (buf[2] - (1 << 32)), "thread", buf[3], "block", buf[4])
