@@ -36,19 +36,30 @@ __device__ __forceinline__ double sum2(double a, double b) { return a + b; }
 __device__ __forceinline__ double quarter(double s_a, double s_b) { return 0.25 * (s_a + s_b); }
 
 // Reciprocal and square root without the IEEE special-case scaffolding of the library versions
-// (v_div_scale / v_div_fixup, denormal rescaling): hardware seed (v_rcp_f64 / v_rsq_f64) + Newton /
-// Goldschmidt refinement, about 1 ulp.  Arguments are positive finite where the result is used; zero,
-// infinite and NaN arguments may yield NaN, which every caller absorbs with the same selects the
-// reference uses (m <= 0 ? 0 : ..., isnan(gamma^2) ? alpha+^2 : ...) or an explicit guard.
+// (v_div_scale / v_div_fixup, denormal rescaling): hardware seed (v_rcp_f64 / v_rsq_f64, 2^-25 relative error, measured)
+// + ONE Newton / Goldschmidt step.  Measured on gfx950 over 120 binades (scripts/microbench/seed_acc.hip,
+// profiles/r01_microbenchmarks.md): rcp max 11 ulp / mean 0.7 ulp; 1 / sqrt max 19.5 / mean 1.0 ulp; sqrt max 35.7 / mean
+// 1.2 ulp -- i.e. <= 8e-15 relative, against a stated FAST tolerance of 1e-12 on u, v (measured whole-cycle differences to
+// STRICT at 2048^2: 2.8e-15 max|u| with these, 1.9e-15 with 0.5-ulp versions).  Round 2 dropped the second refinement
+// steps: 34 of 282 VALU instructions per stage-row, +11 % cell-updates/s.  The one place that keeps its residual correction
+// is the square root that becomes alpha (sqrt_rsqrt's `s`: 0.5 ulp max), so that the clamp plateaus alpha- / alpha+ are the
+// exact numbers the reference stores (sqrt(alpha+^2) == alpha+).
+// Arguments are positive finite where the result is used; zero, infinite and NaN arguments may yield NaN, which every
+// caller absorbs with the same selects the reference uses (m <= 0 ? 0 : ..., isnan(gamma^2) ? alpha+^2 : ...) or an
+// explicit guard.
 __device__ __forceinline__ double rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma_(fma_(-x, r, 1.0), r, r);
-    r = fma_(fma_(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma_(fma_(-x, r, 1.0), r, r);
 }
-// s = sqrt(x), rs = 1 / sqrt(x) for x > 0.  Measured on gfx950 over 120 binades (scripts/microbench/seed_acc.hip):
-// the seed has 2^-25 relative error; coupled Goldschmidt step + one residual correction gives sqrt to 0.5 ulp
-// (a second correction changes nothing), the reciprocal to 0.6 ulp mean / 10 ulp max.
+// 1 / sqrt(x) for x > 0: coupled Goldschmidt step on (g ~ sqrt x, h ~ 1 / (2 sqrt x)), h only
+__device__ __forceinline__ double rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma_(-h, g, 0.5);
+    return 2.0 * fma_(h, r, h);
+}
+// s = sqrt(x) to 0.5 ulp (coupled step + one residual correction; a second correction changes nothing), rs = 1 / sqrt(x)
+// from the coupled step alone
 __device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
@@ -56,22 +67,15 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs) {
     g = fma_(g, r, g);
     h = fma_(h, r, h);
     const double d = fma_(-g, g, x);
-    g = fma_(d, h, g);
-    // one more step for the reciprocal: h ~ 1 / (2 sqrt(x))
-    const double e = fma_(-h, g, 0.5);
-    h = fma_(h, e, h);
-    s = g;
+    s = fma_(d, h, g);
     rs = 2.0 * h;
 }
-// sqrt(x) alone (same operations as sqrt_rsqrt up to s)
-__device__ __forceinline__ double sqrt_pos(double x) {
+// sqrt(x) from the coupled step alone (the drag norm)
+__device__ __forceinline__ double sqrt_fast(double x) {
     const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
+    const double g = x * y, h = 0.5 * y;
     const double r = fma_(-h, g, 0.5);
-    g = fma_(g, r, g);
-    h = fma_(h, r, h);
-    const double d = fma_(-g, g, x);
-    return fma_(d, h, g);
+    return fma_(g, r, g);
 }
 
 // e11 = A (u_e - u_w) + Bn v_n - Bs v_s ; e22 = Cn v_n - Cs v_s        (cell)
@@ -123,9 +127,7 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     // Delta = max(sqrt(x), Dmin) and 1 / Delta (evp:265-266, 270-271): sqrt is monotone, so the argument is
     // clamped instead of the result and no select follows
     const double xc = fmax_(fma_(dc, dc, sc2 * k.em2), k.Dmin2), xf = fmax_(fma_(df, df, sf2 * k.em2), k.Dmin2);
-    double Dc, rDc, Df, rDf;
-    sqrt_rsqrt(xc, Dc, rDc);
-    sqrt_rsqrt(xf, Df, rDf);
+    const double rDc = rsqrt(xc), rDf = rsqrt(xf);     // Delta itself is only stored as a diagnostic: xc * rDc
     // zeta = P / (2 Delta), eta = zeta e^-2 (evp:267-272): carried as 2 zeta, 2 eta -- the factors of two cancel
     // against sigma' = 2 eta eps + ((zeta - eta) div - P_r / 2) and fold into the constants hk1, hkc, hkf
     const double zc2 = Pc * rDc, zf2 = Pf * rDf;
@@ -172,7 +174,7 @@ __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, d
         const double n2 = fma_(d1, d1, d2 * d2);
         // sqrt(0) through the rsq seed is NaN: the argument is floored at the smallest normal number instead of
         // selecting afterwards (a drag coefficient of 1e-154 rho C_D where the ice moves exactly with the ocean)
-        const double n = sqrt_pos(fmax_(n2, 2.2250738585072014e-308));
+        const double n = sqrt_fast(fmax_(n2, 2.2250738585072014e-308));
         im = rhoCd * n;
         ex = im * we;
     } else {            // kind 1 / 2: tau; kind 0 (no stress): the caller passes tau = 0
