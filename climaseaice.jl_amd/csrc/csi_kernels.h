@@ -27,6 +27,7 @@ bool fast_supported(const EvpDev& P);
 // (order of use: adjacent entries are read by merged wide scalar loads)
 enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_AMIN2, FK_AMAX2, FK_HK1, FK_HKC, FK_HKF,      // stress phase
              FK_DT, FK_RDT, FK_MIN_MASS, FK_MIN_CONC, FK_RHO,                                     // velocity phases
+             FK_DT2, FK_MIN_MASS2, FK_MIN_CONC2,      // 2 dt, 2 minimum_mass, 2 minimum_concentration (fm::vel_update_sum)
              FK_TOP_TAU_U, FK_TOP_TAU_V, FK_TOP_RHOCD, FK_TOP_UE, FK_TOP_VE,
              FK_BOT_TAU_U, FK_BOT_TAU_V, FK_BOT_RHOCD, FK_BOT_UE, FK_BOT_VE,
              FK_BCU, FK_BCV = FK_BCU + 2,      // ValueBoundaryCondition values: u at the y walls (low, high), v at the x walls
@@ -65,7 +66,7 @@ void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
                            const ImageSpec& ims12, FusedTable* host_table);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
-                       bool common_forcing, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s);
+                       int common_forcing, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s);
 // array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported;
 // StressBalanceFreeDrift (P.free_drift: free-drift velocity arrays P.ufd / P.vfd) also selects the FORCE variant
 int pair_forcing_kind(const EvpDev& P);

@@ -182,6 +182,15 @@ __device__ __forceinline__ void ext_stress(int kind, double tau, double rhoCd, d
     }
 }
 
+// SemiImplicitStress against an ocean at rest (the reference's default ZeroField ocean velocities): the same bits as
+// ext_stress(3, ...) with we = webar = 0 -- (0 - w)^2 = w^2 exactly, ex = im * 0 = +0 -- without the subtractions and
+// the explicit part.
+__device__ __forceinline__ void ext_stress_rest(double rhoCd, double w, double wbar, double& ex, double& im) {
+    const double n2 = fma_(w, w, wbar * wbar);
+    im = rhoCd * sqrt_fast(fmax_(n2, 2.2250738585072014e-308));
+    ex = 0.0;
+}
+
 // Semi-implicit velocity update of one component.
 //   w, wn   : this component now and at the start of the stage (u, u^n)
 //   mi, ai, abar : ice mass, concentration, alpha averaged to the velocity point
@@ -223,6 +232,31 @@ __device__ __forceinline__ double vel_update_fd(const VelConst& k, double w, dou
                                                 double al_a, double al_b, double div, double cor,
                                                 double ext, double imt, double exb, double imb, bool peripheral, double wf) {
     return vel_update_avg_fd(k, w, wn, avg2(m_a, m_b), avg2(a_a, a_b), avg2(al_a, al_b), div, cor, ext, imt, exb, imb, peripheral, wf);
+}
+
+// The same from SUMS over the two cells the face separates (m2 = 2 mi, a2 = 2 ai, al2 = 2 abar) and a VelConst whose dt,
+// min_mass, min_conc are DOUBLED (rdt is not): every intermediate is vel_update_avg's scaled by an exact power of two
+// (also through rcp: seed and Newton step scale exactly), so the result has the same bits -- the three halvings of the
+// averages become one doubling of 1 / m.  The row pipelines of the pair kernel (evp_pair_stage.h) use these.
+__device__ __forceinline__ double vel_update_sum(const VelConst& k2, double w, double wn, double m2, double a2, double al2,
+                                                 double div, double cor, double ext, double imt, double exb, double imb, bool peripheral) {
+    const double rm2 = rcp(m2);                             // 1 / (2 mi)
+    const double rai = rm2 * a2;                            // ai / mi
+    const double G = fma_(wn - w, k2.rdt, fma_(div, rm2 + rm2, fma_(exb - ext, rai, cor)));
+    const double tau_i = (imb - imt) * rai;
+    const double wD = fma_(k2.dt, G, al2 * w) * rcp(fma_(k2.dt, tau_i, al2));
+    const bool active_ice = (m2 >= k2.min_mass) & (a2 >= k2.min_conc);
+    double res = active_ice ? wD : 0.0;
+    return peripheral ? 0.0 : res;
+}
+__device__ __forceinline__ double vel_update_sum_fd(const VelConst& k2, double w, double wn, double m2, double a2, double al2,
+                                                    double div, double cor, double ext, double imt, double exb, double imb,
+                                                    bool peripheral, double wf) {
+    const double wD = vel_update_sum(k2, w, wn, m2, a2, al2, div, cor, ext, imt, exb, imb, false);
+    const bool active_ice = (m2 >= k2.min_mass) & (a2 >= k2.min_conc);
+    const bool marginal = (m2 > 2.0 * CSI_EPS64) & (a2 > 2.0 * CSI_EPS64);
+    const double res = active_ice ? wD : (marginal ? wf : 0.0);
+    return peripheral ? 0.0 : res;
 }
 
 // d_j sigma_1j = E (s11_i - s11_{i-1}) + Fn s12(j+1) - Fs s12(j)          (constant dy)

@@ -357,6 +357,7 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     K[FK_EM2] = c.em2; K[FK_DMIN] = P.Dmin; K[FK_DMIN2] = c.Dmin2; K[FK_RDMIN] = c.rDmin;
     K[FK_AMIN] = P.amin; K[FK_AMAX] = P.amax; K[FK_AMIN2] = c.amin2; K[FK_AMAX2] = c.amax2; K[FK_RAMIN] = c.ramin; K[FK_RAMAX] = c.ramax;
     K[FK_DT] = P.dt; K[FK_RDT] = c.rdt; K[FK_FCOR] = P.fcor; K[FK_MIN_MASS] = P.min_mass; K[FK_MIN_CONC] = P.min_conc;
+    K[FK_DT2] = 2.0 * P.dt; K[FK_MIN_MASS2] = 2.0 * P.min_mass; K[FK_MIN_CONC2] = 2.0 * P.min_conc;
     K[FK_RHO] = P.rho; K[FK_CA_DT] = c.ca_dt; K[FK_HKC] = c.hkc; K[FK_HKF] = c.hkf; K[FK_HK1] = c.hk1;
     // (ext_stress treats every kind but 3 as an explicit stress: no stress = 0)
     K[FK_TOP_TAU_U] = P.top.kind == 1 ? P.top.tau_u : 0.0; K[FK_TOP_TAU_V] = P.top.kind == 1 ? P.top.tau_v : 0.0; K[FK_TOP_RHOCD] = P.top.rho_e * P.top.Cd;

@@ -74,7 +74,7 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 
 // FULL (orthogonal curvilinear grids, per-point stencil coefficients streamed from 26 planes): 26 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the coefficient traffic there.
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, bool CF, bool FULL = false>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag) {
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
@@ -208,8 +208,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
     };
     auto vel_consts = [&](fm::VelConst& kv) __attribute__((always_inline)) {
-        kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.fcor = T->K[FK_FCOR]; kv.min_mass = T->K[FK_MIN_MASS];
-        kv.min_conc = T->K[FK_MIN_CONC]; kv.has_cor = T->I[FI_HAS_COR];
+        // doubled dt and thresholds: Stage updates the velocities from sums over the two cells of a face (fm::vel_update_sum)
+        kv.dt = T->K[FK_DT2]; kv.rdt = T->K[FK_RDT]; kv.fcor = T->K[FK_FCOR]; kv.min_mass = T->K[FK_MIN_MASS2];
+        kv.min_conc = T->K[FK_MIN_CONC2]; kv.has_cor = T->I[FI_HAS_COR];
     };
     // Issue arbitration favours the OLDEST wave of a SIMD: without help the workgroups dispatched first finish after ~2/3 of
     // the launch and the youngest run on alone (measured: tile lifetimes 100 .. 180 us in one launch; by age rank on the CU
@@ -355,8 +356,8 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             A.m_mm = 0.0; A.m_m = ldg(T->P[FP_H], oc - sc) * rho0 * A.a_m;
             const double P_m = ldg(T->P[FP_P], oc - sc);
             A.XP_m = fm::sum2(from_left(P_m), P_m);
-            A.Xm_m = fm::avg2(from_left(A.m_m), A.m_m);
-            A.Xa_m = fm::avg2(from_left(A.a_m), A.a_m);
+            A.Xm_m = fm::sum2(from_left(A.m_m), A.m_m);
+            A.Xa_m = fm::sum2(from_left(A.a_m), A.a_m);
             A.Xv_m = fm::sum2(from_left(A.v_m), A.v_m);
             A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
             double e11_m, e22_m;
@@ -618,22 +619,22 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 #define CSI_PAIR_NAME launch_fused_pair_mask_force_fd
 #define CSI_PAIR_FLAGS true, true, true, true
 #endif
-// common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF); the
+// common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF; 2: zero ocean velocities); the
 // array-forcing variants have one instantiation (kinds read from the table)
-void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, bool common, int nstrips, int nchunks, int rows,
+void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int common, int nstrips, int nchunks, int rows,
                    int write_diag, hipStream_t s) {
     const int nblocks = nstrips * nchunks;              // one workgroup (producer wave + consumer wave) per tile
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(128);
 #define CSI_LAUNCH_PAIR_(U, A, C, F) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
 #if CSI_PAIR_VARIANT <= 2
-#define CSI_LAUNCH_PAIR(U, A) do { if (common) CSI_LAUNCH_PAIR_(U, A, true, false); else CSI_LAUNCH_PAIR_(U, A, false, false); } while (0)
+#define CSI_LAUNCH_PAIR(U, A) do { if (common == 2) CSI_LAUNCH_PAIR_(U, A, 2, false); else if (common) CSI_LAUNCH_PAIR_(U, A, 1, false); else CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #else
-#define CSI_LAUNCH_PAIR(U, A) do { (void)common; CSI_LAUNCH_PAIR_(U, A, false, false); } while (0)
+#define CSI_LAUNCH_PAIR(U, A) do { (void)common; CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #endif
     if (metric == 2) {
 #if CSI_PAIR_VARIANT >= 1
-        if (a_ufirst) CSI_LAUNCH_PAIR_(false, true, false, true); else CSI_LAUNCH_PAIR_(false, false, false, true);
+        if (a_ufirst) CSI_LAUNCH_PAIR_(false, true, 0, true); else CSI_LAUNCH_PAIR_(false, false, 0, true);
 #endif
     } else if (metric == 0) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
     else { if (a_ufirst) CSI_LAUNCH_PAIR(false, true); else CSI_LAUNCH_PAIR(false, false); }
@@ -642,14 +643,14 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, bool 
 }
 
 #if CSI_PAIR_VARIANT == 0
-void launch_fused_pair_walls(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_force(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_force_fd(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, bool, int, int, int, int, hipStream_t);
+void launch_fused_pair_walls(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_force(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
-                       bool common, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
+                       int common, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
     if (metric == 2) walls = true;      // per-point coefficients: the general variants only (none built without walls)
     if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
     else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);

@@ -33,11 +33,12 @@ __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__b
 // scalars than there are scalar registers and spill them to vector lanes.
 // CF ("common forcing"): the external stresses are known at compile time to be a number-valued top stress (kind 0 / 1) and
 // a bottom SemiImplicitStress with number-valued ocean velocities (kind 3) -- the bench and most stand-alone runs --, so
-// the four wave-uniform kind branches per stage-row disappear.
+// the four wave-uniform kind branches per stage-row disappear.  CF == 2: those ocean velocities are zero (the reference's
+// default: ZeroField), fm::ext_stress_rest.
 // FULL: orthogonal curvilinear grid (CSI_METRIC_FULL): the strain rates and stress divergences are the per-POINT stencils
 // of evp_fast.hip's k_*2 kernels (same operations, same order: bit-identical), their coefficients loaded per lane from
 // the C2_* planes at byte offset o2 (row r; o2 - s2 / o2 + s2: rows r - 1 / r + 1); UNI must be false.
-template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, bool CF = false, bool FULL = false>
+template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, int CF = 0, bool FULL = false>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
     double a_mm, a_m, m_mm, m_m;
@@ -57,7 +58,7 @@ struct Stage {
                                          double s11, double s22, double s12, double un_m, double vn_x,
                                          bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
                                          const Forcing& F, unsigned o2 = 0u, unsigned s2 = 0u) {
-        Xa_0 = fm::avg2(from_left(a_0), a_0);
+        Xa_0 = fm::sum2(from_left(a_0), a_0);               // SUMS too (Xa, Xm, XAL): fm::vel_update_sum
         Xv_p = fm::sum2(from_left(v_p), v_p);               // x-SUMS (Xv, Xe11, Xe22, Ye12, XP, XW): scaled once, in quarter()
         double e11_0, e22_0;
         if constexpr (FULL) {
@@ -76,12 +77,12 @@ struct Stage {
             const double Xe11_0 = fm::sum2(from_left(e11_0), e11_0), Xe22_0 = fm::sum2(from_left(e22_0), e22_0);
             const double Ye12_p = fm::sum2(e12_p, from_right(e12_p));
             const double XP_0 = fm::sum2(from_left(P_0), P_0);
-            Xm_0 = fm::avg2(from_left(m_0), m_0);
+            Xm_0 = fm::sum2(from_left(m_0), m_0);
             const double e11f = fm::quarter(Xe11_m, Xe11_0);
             const double e22f = fm::quarter(Xe22_m, Xe22_0);
             const double e12c = fm::quarter(Ye12_0, Ye12_p);
             const double Pf = fm::quarter(XP_m, XP_0);
-            const double mf = 0.5 * (Xm_m + Xm_0);
+            const double mf = fm::quarter(Xm_m, Xm_0);
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
             if (do_stress) {
                 fm::StressConst ks = ks_in;
@@ -140,7 +141,7 @@ struct Stage {
         fm::VelConst kv = kv_in;
         if (TIGHT) {
             asm volatile("" : "+s"(T));
-            kv.dt = T->K[FK_DT]; kv.rdt = T->K[FK_RDT]; kv.min_mass = T->K[FK_MIN_MASS]; kv.min_conc = T->K[FK_MIN_CONC];
+            kv.dt = T->K[FK_DT2]; kv.rdt = T->K[FK_RDT]; kv.min_mass = T->K[FK_MIN_MASS2]; kv.min_conc = T->K[FK_MIN_CONC2];
         }
         if (!do_vel) {
             XW_next = XW;
@@ -155,12 +156,13 @@ struct Stage {
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], u_m, vbar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
                 else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
-                W_0 = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
-                           : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
+                W_0 = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
+                           : fm::vel_update_sum(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::sum2(W_0, from_right(W_0));
             {
@@ -172,12 +174,13 @@ struct Stage {
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
-                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], v_m, ubar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2 - s2, j) * ubar;
                 else cor = -coef<UNI>(T, FC_FV, j) * ubar;
-                second = F.fd ? fm::vel_update_fd(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
-                              : fm::vel_update(kv, v_m, vn_x, m_mm, m_m, a_mm, a_m, AL_mm, AL_m, div, cor, ext, imt, exb, imb, per_second);
+                second = F.fd ? fm::vel_update_sum_fd(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
+                              : fm::vel_update_sum(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
             XW_next = XW_0;
@@ -192,12 +195,13 @@ struct Stage {
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
-                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], v_0, ubar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2, r) * ubar;
                 else cor = -coef<UNI>(T, FC_FV, r) * ubar;
-                W_0 = F.fd ? fm::vel_update_fd(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
-                           : fm::vel_update(kv, v_0, vn_x, m_m, m_0, a_m, a_0, AL_m, AL_0, div, cor, ext, imt, exb, imb, per_first);
+                W_0 = F.fd ? fm::vel_update_sum_fd(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
+                           : fm::vel_update_sum(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
             const double XW_0 = fm::sum2(from_left(W_0), W_0);
             {
@@ -209,12 +213,13 @@ struct Stage {
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], u_m, vbar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
                 else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
-                second = F.fd ? fm::vel_update_avg_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
-                              : fm::vel_update_avg(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
+                second = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
+                              : fm::vel_update_sum(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
             first = W_0;
             XW_next = XW_0;
@@ -230,7 +235,7 @@ struct Stage {
         e12_0 = e12_p;
         S11_mm = S11_m; S22_mm = S22_m; S12_mm = S12_m; AL_mm = AL_m;
         S11_m = S11_0; S22_m = S22_0; S12_m = S12_0; AL_m = AL_0;
-        XAL_m = fm::avg2(from_left(AL_0), AL_0); XS11L_m = from_left(S11_0);
+        XAL_m = fm::sum2(from_left(AL_0), AL_0); XS11L_m = from_left(S11_0);
         if constexpr (FULL) XS22L_m = from_left(S22_0);
         XW = XW_next;
         Wprev = first;
