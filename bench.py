@@ -288,8 +288,8 @@ def main():
         if ctr.get("valu_busy_frac") is not None:
             roof["valu_frac"] = ctr["valu_busy_frac"]
             roof["valu_insts_per_launch"] = ctr.get("valu_insts_per_launch")
-            roof["valu_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed PMC pass; the kernel is "
-                                 "co-limited by VALU issue (DESIGN.md section 3)")
+            roof["valu_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed PMC pass; the launch time is the "
+                                 "kernel's HBM traffic at the bandwidth of its marching access pattern (DESIGN.md section 3)")
     model_days_per_hr = None
     if not args.no_full_step:
         nfull = 2
