@@ -43,19 +43,46 @@ __device__ __forceinline__ double coef(tptr_t T, int which, int j) {
 // dimension and all Face-in-x fields another (dense Oceananigans parents; checked on the host), so two running
 // offsets (oc, of) address every field.
 typedef __attribute__((address_space(1))) char* gptr_t;     // global address space: global_load / global_store, not flat
-__device__ __forceinline__ double ldg(unsigned long base, unsigned off) {
+// Cache policy of the streaming loads -- an experiment knob, plain loads are the default.  Non-temporal loads
+// (`global_load ... nt`) gain 3-5 % at exactly 2048^2 (62.4 -> 65.4 G on one box) and LOSE everywhere else measured:
+// 1024 x 512 -4.7 %, 1024^2 -6 %, 1536^2 -5 %, 3072^2 -7 %, 4096^2 -13 % (the ring lanes a strip shares with its neighbour
+// are evicted before the neighbour reads them); non-temporal stores lose 5.5 %, agent- / system-scope loads change
+// nothing (profiles/r02d_experiments.md).  ldg_keep: loads that are re-read soon whatever the policy (the per-point
+// coefficient planes: stage B reads what stage A read three rows earlier).
+#ifndef CSI_NT_LOAD
+#define CSI_NT_LOAD 0           // 0 plain, 1 non-temporal, 2 / 3: agent- / system-scope relaxed atomic loads (sc1 / sc0 sc1; experiments)
+#endif
+#ifndef CSI_NT_STORE
+#define CSI_NT_STORE 0
+#endif
+__device__ __forceinline__ double ldg_keep(unsigned long base, unsigned off) {
     return *(const __attribute__((address_space(1))) double*)((gptr_t)base + off);
+}
+__device__ __forceinline__ double ldg(unsigned long base, unsigned off) {
+#if CSI_NT_LOAD == 1
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) double*)((gptr_t)base + off));
+#elif CSI_NT_LOAD == 2
+    return __builtin_bit_cast(double, __scoped_atomic_load_n((const __attribute__((address_space(1))) long*)((gptr_t)base + off), __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE));
+#elif CSI_NT_LOAD == 3
+    return __builtin_bit_cast(double, __scoped_atomic_load_n((const __attribute__((address_space(1))) long*)((gptr_t)base + off), __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM));
+#else
+    return ldg_keep(base, off);
+#endif
 }
 __device__ __forceinline__ unsigned ldub(unsigned long base, unsigned off) {
     return *(const __attribute__((address_space(1))) unsigned char*)((gptr_t)base + off);
 }
 __device__ __forceinline__ void stg(unsigned long base, unsigned off, double v) {
+#if CSI_NT_STORE
+    __builtin_nontemporal_store(v, (__attribute__((address_space(1))) double*)((gptr_t)base + off));
+#else
     *(__attribute__((address_space(1))) double*)((gptr_t)base + off) = v;
+#endif
 }
 
 // CSI_METRIC_FULL: stencil coefficient `which` (C2_*, csi_fast_coef.h) of this lane's column at the row whose byte offset in
 // a coefficient plane is `off` (planes have their own leading dimension: FI_C2_LD)
-__device__ __forceinline__ double c2at(tptr_t T, int which, unsigned off) { return ldg(T->P[FP_C2_0 + which], off); }
+__device__ __forceinline__ double c2at(tptr_t T, int which, unsigned off) { return ldg_keep(T->P[FP_C2_0 + which], off); }
 
 // Velocity store: plain, or with halo images when this wave's tile touches an edge band (wave-uniform test).
 __device__ __forceinline__ void store_vel(tptr_t T, int which_ptr, int which_ld, int img0, bool near_edge, int i, int j, double val) {
