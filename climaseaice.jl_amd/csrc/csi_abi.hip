@@ -529,7 +529,7 @@ bool pair_supported(const csi_context* c) {
     if (!c->pairing) return false;
     if (!offsets_fit_32bit(c->Nx, c->Ny, c->Hx, c->Hy, max_bound_ld(c))) return false;
     const GridDev& g = c->g;
-    // per-point coefficients (CSI_METRIC_FULL): the pair kernel streams the 26 coefficient planes; a periodic y side
+    // per-point coefficients (CSI_METRIC_FULL): the pair kernel streams the 14 metric planes; a periodic y side
     // would need the ring rows beyond the seam to see their owners' coefficients -- the planes' halo entries are images
     // of the interior (csi.h), so that holds; a north fold does not pair
     if (c->metric_kind == CSI_METRIC_FULL && !c->dev_coef2) return false;

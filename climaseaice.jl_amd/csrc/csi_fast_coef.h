@@ -38,18 +38,17 @@ enum : int {
     FC_COUNT
 };
 
-// Per-point coefficients for grids whose metrics vary in both directions: the reference's operators with the metric
-// at the location and index each one names (elasto_visco_plastic_rheology.jl:360-375, ice_stress_divergence.jl:39-51)
-// written as linear stencils.
+// Per-point metric planes for grids whose metrics vary in both directions (CSI_METRIC_FULL): the reference's operators with
+// the metric at the location and index each one names (elasto_visco_plastic_rheology.jl:360-375,
+// ice_stress_divergence.jl:39-51), written in terms of FOURTEEN planes -- four at the u points, four at the v points,
+// three at the cells, three at the corners -- instead of one folded coefficient per stencil entry (26 planes, round 2 a):
+// the kernels on such grids are bound by the planes' traffic and load count, not by arithmetic (fm::full_* in
+// evp_fast_math.h spell the stencils out).
 enum : int {
-    // cell (i, j):  e11 = E11E u[i+1] - E11W u[i] + E11N v[j+1] - E11S v[j] ;  e22 likewise
-    C2_E11E = 0, C2_E11W, C2_E11N, C2_E11S, C2_E22E, C2_E22W, C2_E22N, C2_E22S, C2_RAZC,
-    // corner (i, j): e12 = SUN u[j] - SUS u[j-1] + SVE v[i] - SVW v[i-1]
-    C2_SUN, C2_SUS, C2_SVE, C2_SVW, C2_RAZF,
-    // u point (i, j): d_j sigma_1j = A11E s11[i] - A11W s11[i-1] + A22E s22[i] - A22W s22[i-1] + A12N s12[j+1] - A12S s12[j]
-    C2_A11E, C2_A11W, C2_A22E, C2_A22W, C2_A12N, C2_A12S,
-    // v point (i, j): d_j sigma_2j = B11N s11[j] - B11S s11[j-1] + B22N s22[j] - B22S s22[j-1] + B12E s12[i+1] - B12W s12[i]
-    C2_B11N, C2_B11S, C2_B22N, C2_B22S, C2_B12E, C2_B12W,
+    C2_DYU = 0, C2_RDYU, C2_RDXU, C2_RAZU,      // u points (Face, Center): dy, 1 / dy, 1 / dx, 1 / Az
+    C2_DXV, C2_RDXV, C2_RDYV, C2_RAZV,          // v points (Center, Face): dx, 1 / dx, 1 / dy, 1 / Az
+    C2_DYC2, C2_DXC2, C2_RAZC,                  // cells: dy^2, dx^2, 1 / Az
+    C2_DXF2, C2_DYF2, C2_RAZF,                  // corners (Face, Face): dx^2, dy^2, 1 / Az
     C2_COUNT
 };
 
@@ -119,48 +118,18 @@ inline void build_fast_coef_per_j(int n, double dy, const double* dxc, const dou
 }
 
 // m[k]: the twelve metric planes of csi_metrics.full (dx, dy, Az at (c,c), (f,c), (c,f), (f,f)), each nj rows of ni
-// (dense); out: C2_COUNT planes of the same shape.  Neighbours beyond the arrays are clamped (those entries are never
-// used: the kernels' ranges stay one cell inside the parents).
+// (dense); out: C2_COUNT planes of the same shape.
 inline void build_fast_coef_full(int ni, int nj, const double* const* m, std::vector<double>& out) {
     out.assign((size_t)C2_COUNT * ni * nj, 0.0);
-    auto M = [&](int which, int loc, int a, int b) -> double {          // which: 0 dx, 1 dy, 2 Az; loc: 0 cc, 1 fc, 2 cf, 3 ff
-        a = a < 0 ? 0 : (a >= ni ? ni - 1 : a); b = b < 0 ? 0 : (b >= nj ? nj - 1 : b);
-        return m[4 * which + loc][(size_t)b * ni + a];
-    };
-    auto O = [&](int w, int a, int b) -> double& { return out[((size_t)w * nj + b) * ni + a]; };
     enum { CC = 0, FC = 1, CF = 2, FF = 3 };
-    for (int b = 0; b < nj; ++b)
-        for (int a = 0; a < ni; ++a) {
-            {   // cell
-                const double az = M(2, CC, a, b), dyfe = M(1, FC, a + 1, b), dyfw = M(1, FC, a, b), dxfn = M(0, CF, a, b + 1), dxfs = M(0, CF, a, b);
-                const double dycc = M(1, CC, a, b), dxcc = M(0, CC, a, b), h = 0.5 / az;
-                O(C2_E11E, a, b) = (dyfe + dycc * dycc / dyfe) * h; O(C2_E11W, a, b) = (dyfw + dycc * dycc / dyfw) * h;
-                O(C2_E11N, a, b) = (dxfn - dxcc * dxcc / dxfn) * h; O(C2_E11S, a, b) = (dxfs - dxcc * dxcc / dxfs) * h;
-                O(C2_E22E, a, b) = (dyfe - dycc * dycc / dyfe) * h; O(C2_E22W, a, b) = (dyfw - dycc * dycc / dyfw) * h;
-                O(C2_E22N, a, b) = (dxfn + dxcc * dxcc / dxfn) * h; O(C2_E22S, a, b) = (dxfs + dxcc * dxcc / dxfs) * h;
-                O(C2_RAZC, a, b) = 1.0 / az;
-            }
-            {   // corner
-                const double az = M(2, FF, a, b), dxff = M(0, FF, a, b), dyff = M(1, FF, a, b), h = 0.5 / az;
-                O(C2_SUN, a, b) = dxff * dxff / M(0, FC, a, b) * h; O(C2_SUS, a, b) = dxff * dxff / M(0, FC, a, b - 1) * h;
-                O(C2_SVE, a, b) = dyff * dyff / M(1, CF, a, b) * h; O(C2_SVW, a, b) = dyff * dyff / M(1, CF, a - 1, b) * h;
-                O(C2_RAZF, a, b) = 1.0 / az;
-            }
-            {   // u point
-                const double raz = 1.0 / M(2, FC, a, b), dyfc = M(1, FC, a, b), dyc = M(1, CC, a, b), dycm = M(1, CC, a - 1, b);
-                const double dxfn = M(0, FF, a, b + 1), dxf = M(0, FF, a, b), dxfc = M(0, FC, a, b);
-                O(C2_A11E, a, b) = (0.5 * dyfc + 0.5 * dyc * dyc / dyfc) * raz; O(C2_A22E, a, b) = (0.5 * dyfc - 0.5 * dyc * dyc / dyfc) * raz;
-                O(C2_A11W, a, b) = (0.5 * dyfc + 0.5 * dycm * dycm / dyfc) * raz; O(C2_A22W, a, b) = (0.5 * dyfc - 0.5 * dycm * dycm / dyfc) * raz;
-                O(C2_A12N, a, b) = dxfn * dxfn / dxfc * raz; O(C2_A12S, a, b) = dxf * dxf / dxfc * raz;
-            }
-            {   // v point
-                const double raz = 1.0 / M(2, CF, a, b), dxcf = M(0, CF, a, b), dxc = M(0, CC, a, b), dxcm = M(0, CC, a, b - 1);
-                const double dyfn = M(1, FF, a + 1, b), dyf = M(1, FF, a, b), dycf = M(1, CF, a, b);
-                O(C2_B11N, a, b) = (0.5 * dxcf - 0.5 * dxc * dxc / dxcf) * raz; O(C2_B22N, a, b) = (0.5 * dxcf + 0.5 * dxc * dxc / dxcf) * raz;
-                O(C2_B11S, a, b) = (0.5 * dxcf - 0.5 * dxcm * dxcm / dxcf) * raz; O(C2_B22S, a, b) = (0.5 * dxcf + 0.5 * dxcm * dxcm / dxcf) * raz;
-                O(C2_B12E, a, b) = dyfn * dyfn / dycf * raz; O(C2_B12W, a, b) = dyf * dyf / dycf * raz;
-            }
-        }
+    auto M = [&](int which, int loc, size_t t) -> double { return m[4 * which + loc][t]; };     // which: 0 dx, 1 dy, 2 Az
+    auto O = [&](int w, size_t t) -> double& { return out[(size_t)w * nj * ni + t]; };
+    for (size_t t = 0; t < (size_t)ni * nj; ++t) {
+        O(C2_DYU, t) = M(1, FC, t); O(C2_RDYU, t) = 1.0 / M(1, FC, t); O(C2_RDXU, t) = 1.0 / M(0, FC, t); O(C2_RAZU, t) = 1.0 / M(2, FC, t);
+        O(C2_DXV, t) = M(0, CF, t); O(C2_RDXV, t) = 1.0 / M(0, CF, t); O(C2_RDYV, t) = 1.0 / M(1, CF, t); O(C2_RAZV, t) = 1.0 / M(2, CF, t);
+        O(C2_DYC2, t) = M(1, CC, t) * M(1, CC, t); O(C2_DXC2, t) = M(0, CC, t) * M(0, CC, t); O(C2_RAZC, t) = 1.0 / M(2, CC, t);
+        O(C2_DXF2, t) = M(0, FF, t) * M(0, FF, t); O(C2_DYF2, t) = M(1, FF, t) * M(1, FF, t); O(C2_RAZF, t) = 1.0 / M(2, FF, t);
+    }
 }
 
 }  // namespace csi

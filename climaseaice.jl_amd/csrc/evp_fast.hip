@@ -225,17 +225,19 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
 
 // ------------------------------------------------------------------------------------------------
 // Orthogonal curvilinear grids (CSI_METRIC_FULL): the same three phases with per-POINT stencil coefficients
-// (csi_fast_coef.h, C2_*: the reference's operators with the metric of every location and index folded on the host).
+// (csi_fast_coef.h, C2_*: fourteen metric planes; fm::full_* are the reference's operators in terms of them).
 // The arithmetic after the strain rates / divergences is that of the regular-grid kernels (evp_fast_math.h).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double c2(const FastCoef& c, int w, int i, int j) { return c.c2[(long)w * c.c2_plane + i + (long)j * c.c2_ld]; }
 
 __device__ __forceinline__ void strain_cell2(const FastCoef& c, int i, int j, double u_e, double u_w, double v_n, double v_s, double& e11, double& e22) {
-    e11 = fm::fma_(c2(c, C2_E11E, i, j), u_e, fm::fma_(c2(c, C2_E11N, i, j), v_n, -fm::fma_(c2(c, C2_E11W, i, j), u_w, c2(c, C2_E11S, i, j) * v_s)));
-    e22 = fm::fma_(c2(c, C2_E22E, i, j), u_e, fm::fma_(c2(c, C2_E22N, i, j), v_n, -fm::fma_(c2(c, C2_E22W, i, j), u_w, c2(c, C2_E22S, i, j) * v_s)));
+    fm::full_strain_cell(c2(c, C2_DYU, i + 1, j) * u_e, c2(c, C2_DYU, i, j) * u_w, c2(c, C2_DXV, i, j + 1) * v_n, c2(c, C2_DXV, i, j) * v_s,
+                         c2(c, C2_RDYU, i + 1, j) * u_e, c2(c, C2_RDYU, i, j) * u_w, c2(c, C2_RDXV, i, j + 1) * v_n, c2(c, C2_RDXV, i, j) * v_s,
+                         c2(c, C2_DYC2, i, j), c2(c, C2_DXC2, i, j), c2(c, C2_RAZC, i, j), e11, e22);
 }
 __device__ __forceinline__ double strain_corner2(const FastCoef& c, int i, int j, double u_n, double u_s, double v_e, double v_w) {
-    return fm::fma_(c2(c, C2_SUN, i, j), u_n, fm::fma_(c2(c, C2_SVE, i, j), v_e, -fm::fma_(c2(c, C2_SUS, i, j), u_s, c2(c, C2_SVW, i, j) * v_w)));
+    return fm::full_strain_corner(c2(c, C2_RDXU, i, j) * u_n, c2(c, C2_RDXU, i, j - 1) * u_s, c2(c, C2_RDYV, i, j) * v_e, c2(c, C2_RDYV, i - 1, j) * v_w,
+                                  c2(c, C2_DXF2, i, j), c2(c, C2_DYF2, i, j), c2(c, C2_RAZF, i, j));
 }
 
 __global__ void __launch_bounds__(256) k_stress2(EvpDev P, Range r, FastCoef c, TileMap tm) {
@@ -294,9 +296,9 @@ __global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img
         if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
     }
     const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
-    const double east = fm::fma_(c2(c, C2_A11E, i, j), s11_0, fm::fma_(c2(c, C2_A22E, i, j), s22_0, c2(c, C2_A12N, i, j) * s12_p));
-    const double west = fm::fma_(c2(c, C2_A11W, i, j), s11_m, fm::fma_(c2(c, C2_A22W, i, j), s22_m, c2(c, C2_A12S, i, j) * s12_0));
-    double div = east - west;
+    double div = fm::full_div1(c2(c, C2_DYU, i, j), c2(c, C2_RDYU, i, j), c2(c, C2_RDXU, i, j), c2(c, C2_RAZU, i, j),
+                               s11_0 + s22_0, s11_m + s22_m, c2(c, C2_DYC2, i, j) * (s11_0 - s22_0), c2(c, C2_DYC2, i - 1, j) * (s11_m - s22_m),
+                               c2(c, C2_DXF2, i, j + 1) * s12_p, c2(c, C2_DXF2, i, j) * s12_0);
     double ext, imt, exb, imb;
     stress_x(P.top, i, j, u, vbar, ext, imt);
     stress_x(P.bot, i, j, u, vbar, exb, imb);
@@ -325,9 +327,9 @@ __global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img
         if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
     }
     const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
-    const double north = fm::fma_(c2(c, C2_B11N, i, j), s11_0, fm::fma_(c2(c, C2_B22N, i, j), s22_0, c2(c, C2_B12E, i, j) * s12_p));
-    const double south = fm::fma_(c2(c, C2_B11S, i, j), s11_m, fm::fma_(c2(c, C2_B22S, i, j), s22_m, c2(c, C2_B12W, i, j) * s12_0));
-    double div = north - south;
+    double div = fm::full_div2(c2(c, C2_DXV, i, j), c2(c, C2_RDXV, i, j), c2(c, C2_RDYV, i, j), c2(c, C2_RAZV, i, j),
+                               s11_0 + s22_0, s11_m + s22_m, c2(c, C2_DXC2, i, j) * (s11_0 - s22_0), c2(c, C2_DXC2, i, j - 1) * (s11_m - s22_m),
+                               c2(c, C2_DYF2, i + 1, j) * s12_p, c2(c, C2_DYF2, i, j) * s12_0);
     double ext, imt, exb, imb;
     stress_y(P.top, i, j, v, ubar, ext, imt);
     stress_y(P.bot, i, j, v, ubar, exb, imb);

@@ -274,5 +274,34 @@ __device__ __forceinline__ double div2(double Q1n, double Q2n, double Q1s, doubl
     return fma_(K, s12_p - s12_0, n - s);
 }
 
+// ---- orthogonal curvilinear grids (CSI_METRIC_FULL): the operators in terms of the per-point metric planes of
+// csi_fast_coef.h (C2_*).  Callers form the products of a velocity or stress with ONE plane value -- Uy = dy_fc u, Ur = u / dy_fc,
+// Ux = u / dx_fc at the u points; Vx = dx_cf v, Vr = v / dx_cf, Vy = v / dy_cf at the v points; S = s11 + s22, T = dy_cc^2 (s11 - s22),
+// T' = dx_cc^2 (s11 - s22) at the cells; Z = dx_ff^2 s12, Z' = dy_ff^2 s12 at the corners -- each a single operation, so every
+// kernel that forms them gets the same bits; these functions fix the order of the rest.
+//   e11, e22 = [ d_x(dy u) + d_y(dx v)  +/-  (dy_cc^2 d_x(u / dy) - dx_cc^2 d_y(v / dx)) ] / (2 Az)        (cell)
+__device__ __forceinline__ void full_strain_cell(double Uy_e, double Uy_w, double Vx_n, double Vx_s, double Ur_e, double Ur_w,
+                                                 double Vr_n, double Vr_s, double dyc2, double dxc2, double razc, double& e11, double& e22) {
+    const double D1 = (Uy_e - Uy_w) + (Vx_n - Vx_s);
+    const double D2 = fma_(dyc2, Ur_e - Ur_w, -(dxc2 * (Vr_n - Vr_s)));
+    const double hr = 0.5 * razc;
+    e11 = hr * (D1 + D2);
+    e22 = hr * (D1 - D2);
+}
+//   e12 = [ dx_ff^2 d_y(u / dx) + dy_ff^2 d_x(v / dy) ] / (2 Az)                                              (corner)
+__device__ __forceinline__ double full_strain_corner(double Ux_n, double Ux_s, double Vy_e, double Vy_w, double dxf2, double dyf2, double razf) {
+    return (0.5 * razf) * fma_(dxf2, Ux_n - Ux_s, dyf2 * (Vy_e - Vy_w));
+}
+//   d_j sigma_1j = [ dy/2 d_x(s11 + s22) + 1/(2 dy) d_x(dy_cc^2 (s11 - s22)) + 1/dx d_y(dx_ff^2 s12) ] / Az   (u point)
+__device__ __forceinline__ double full_div1(double dyu, double rdyu, double rdxu, double razu, double S_e, double S_w, double T_e, double T_w,
+                                            double Z_n, double Z_s) {
+    return razu * fma_(0.5 * dyu, S_e - S_w, fma_(0.5 * rdyu, T_e - T_w, rdxu * (Z_n - Z_s)));
+}
+//   d_j sigma_2j = [ dx/2 d_y(s11 + s22) - 1/(2 dx) d_y(dx_cc^2 (s11 - s22)) + 1/dy d_x(dy_ff^2 s12) ] / Az   (v point)
+__device__ __forceinline__ double full_div2(double dxv, double rdxv, double rdyv, double razv, double S_n, double S_s, double T_n, double T_s,
+                                            double Z_e, double Z_w) {
+    return razv * fma_(0.5 * dxv, S_n - S_s, fma_(-0.5 * rdxv, T_n - T_s, rdyv * (Z_e - Z_w)));
+}
+
 }  // namespace fm
 }  // namespace csi

@@ -72,8 +72,8 @@ template <int V> struct Idx { static constexpr int value = V; };
 constexpr int RING_ROWS = 4, RING_FIELDS = 10;
 enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF_VN };
 
-// FULL (orthogonal curvilinear grids, per-point stencil coefficients streamed from 26 planes): 26 more loads per stage-row
-// in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the coefficient traffic there.
+// FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
+// in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag) {
@@ -364,10 +364,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             const int jm = rstart - 1;
             if constexpr (FULL) {
                 const unsigned om2 = off2(jm), o02 = off2(rstart);
-                const double u_e = from_right(A.u_m), v_w = from_left(A.v_0);
-                e11_m = fm::fma_(c2at(T, C2_E11E, om2), u_e, fm::fma_(c2at(T, C2_E11N, om2), A.v_0, -fm::fma_(c2at(T, C2_E11W, om2), A.u_m, c2at(T, C2_E11S, om2) * A.v_m)));
-                e22_m = fm::fma_(c2at(T, C2_E22E, om2), u_e, fm::fma_(c2at(T, C2_E22N, om2), A.v_0, -fm::fma_(c2at(T, C2_E22W, om2), A.u_m, c2at(T, C2_E22S, om2) * A.v_m)));
-                A.e12_0 = fm::fma_(c2at(T, C2_SUN, o02), A.u_0, fm::fma_(c2at(T, C2_SVE, o02), A.v_0, -fm::fma_(c2at(T, C2_SUS, o02), A.u_m, c2at(T, C2_SVW, o02) * v_w)));
+                full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m);
+                A.e12_0 = full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0);
+                A.full_init(T, o02);
             } else {
             fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                             coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
@@ -499,6 +498,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0;
+    if constexpr (FULL) B.full_init(T, off2(max(rstart - 2, row0)));
     // Stage B's row inputs all come from the ring (the producer read them from memory two or three iterations earlier):
     // the consumer issues no global loads (FORCE: except its forcing arrays), so it never waits for its own stores.
     const int rlo = rstart - 1;

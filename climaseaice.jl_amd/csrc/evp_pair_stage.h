@@ -38,6 +38,22 @@ __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__b
 // FULL: orthogonal curvilinear grid (CSI_METRIC_FULL): the strain rates and stress divergences are the per-POINT stencils
 // of evp_fast.hip's k_*2 kernels (same operations, same order: bit-identical), their coefficients loaded per lane from
 // the C2_* planes at byte offset o2 (row r; o2 - s2 / o2 + s2: rows r - 1 / r + 1); UNI must be false.
+// CSI_METRIC_FULL: strain rates of cell (i, row of `o`) from u(i, row), v(i, row), v(i, row + 1) / of corner (i, row of `o`) from
+// u(i, row), u(i, row - 1), v(i, row): the operations of evp_fast.hip's strain_cell2 / strain_corner2 (the neighbouring
+// column's products come over the lane shift); s2: row pitch of the planes in bytes
+__device__ __forceinline__ void full_cell(tptr_t T, unsigned o, unsigned s2, double u_0, double v_0, double v_p, double& e11, double& e22) {
+    const double Uy_w = c2at(T, C2_DYU, o) * u_0, Ur_w = c2at(T, C2_RDYU, o) * u_0;
+    const double Vx_s = c2at(T, C2_DXV, o) * v_0, Vr_s = c2at(T, C2_RDXV, o) * v_0;
+    const double Vx_n = c2at(T, C2_DXV, o + s2) * v_p, Vr_n = c2at(T, C2_RDXV, o + s2) * v_p;
+    fm::full_strain_cell(from_right(Uy_w), Uy_w, Vx_n, Vx_s, from_right(Ur_w), Ur_w, Vr_n, Vr_s,
+                         c2at(T, C2_DYC2, o), c2at(T, C2_DXC2, o), c2at(T, C2_RAZC, o), e11, e22);
+}
+__device__ __forceinline__ double full_corner(tptr_t T, unsigned o, unsigned s2, double u_n, double u_s, double v_e) {
+    const double Ux_n = c2at(T, C2_RDXU, o) * u_n, Ux_s = c2at(T, C2_RDXU, o - s2) * u_s;
+    const double Vy_e = c2at(T, C2_RDYV, o) * v_e;
+    return fm::full_strain_corner(Ux_n, Ux_s, Vy_e, from_left(Vy_e), c2at(T, C2_DXF2, o), c2at(T, C2_DYF2, o), c2at(T, C2_RAZF, o));
+}
+
 template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, int CF = 0, bool FULL = false>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
@@ -45,6 +61,22 @@ struct Stage {
     double XP_m, Xm_m, Xa_m, Xe11_m, Xe22_m, Ye12_0, e12_0;
     double XAL_m, XS11L_m, XW, Wprev;
     double XS22L_m;      // FULL: sigma22 of row r-1 from the left neighbour (the u equation sees sigma22 on such grids)
+    // FULL: the metric planes of the rows in the window -- every plane value is loaded ONCE, when its row enters (the v-point
+    // and corner planes as row r + 1, the u-point and cell planes as row r), and kept until the velocity phase has used it
+    // as row r - 1 / r - 2 (the kernel on such grids is bound by the number of loads).  (The products
+    // with u, v of row r are formed again each row: stage B patches u_0 at walls between two steps.)
+    double DXV_0, RDXV_0, RDYV_0, RDXU_0, DXF2_0, DYF2_0, RAZF_0;
+    double DXV_m, RDXV_m, RDYV_m, RDXU_m, DXF2_m, DYF2_m, DYU_m, RDYU_m, DYC2_m, DXC2_m, DXC2_mm;
+    double DXV_p, RDXV_p, RDYV_p, RDXU_p, DXF2_p, DYF2_p, RAZF_p, DYU_0, RDYU_0, DYC2_0, DXC2_0;      // pending (shift)
+
+    // FULL: before the first step(r): o = plane offset of row r, u_0 / v_0 = u, v of row r
+    __device__ __forceinline__ void full_init(tptr_t T, unsigned o) {
+        DXV_0 = c2at(T, C2_DXV, o); RDXV_0 = c2at(T, C2_RDXV, o); RDYV_0 = c2at(T, C2_RDYV, o); RDXU_0 = c2at(T, C2_RDXU, o);
+        DXF2_0 = c2at(T, C2_DXF2, o); DYF2_0 = c2at(T, C2_DYF2, o); RAZF_0 = c2at(T, C2_RAZF, o);
+        // rows r - 1, r - 2: multiplied by zero stresses until their real values have been shifted in (any finite number)
+        DXV_m = DXV_0; RDXV_m = RDXV_0; RDYV_m = RDYV_0; RDXU_m = RDXU_0; DXF2_m = DXF2_0; DYF2_m = DYF2_0;
+        DYU_m = c2at(T, C2_DYU, o); RDYU_m = c2at(T, C2_RDYU, o); DYC2_m = c2at(T, C2_DYC2, o); DXC2_m = c2at(T, C2_DXC2, o); DXC2_mm = DXC2_m;
+    }
     double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
     // results of the last step()
     double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, rDc, first, second;
@@ -63,10 +95,15 @@ struct Stage {
         double e11_0, e22_0;
         if constexpr (FULL) {
             // strain_cell2 / strain_corner2 of evp_fast.hip: cell (i, r), corner (i, r + 1)
-            const double u_e = from_right(u_0), v_w = from_left(v_p);
-            e11_0 = fm::fma_(c2at(T, C2_E11E, o2), u_e, fm::fma_(c2at(T, C2_E11N, o2), v_p, -fm::fma_(c2at(T, C2_E11W, o2), u_0, c2at(T, C2_E11S, o2) * v_0)));
-            e22_0 = fm::fma_(c2at(T, C2_E22E, o2), u_e, fm::fma_(c2at(T, C2_E22N, o2), v_p, -fm::fma_(c2at(T, C2_E22W, o2), u_0, c2at(T, C2_E22S, o2) * v_0)));
-            e12_p = fm::fma_(c2at(T, C2_SUN, o2 + s2), u_p, fm::fma_(c2at(T, C2_SVE, o2 + s2), v_p, -fm::fma_(c2at(T, C2_SUS, o2 + s2), u_0, c2at(T, C2_SVW, o2 + s2) * v_w)));
+            // (full_cell / full_corner above with the plane values of rows already in the window taken from registers)
+            DXV_p = c2at(T, C2_DXV, o2 + s2); RDXV_p = c2at(T, C2_RDXV, o2 + s2); RDYV_p = c2at(T, C2_RDYV, o2 + s2); RDXU_p = c2at(T, C2_RDXU, o2 + s2);
+            DXF2_p = c2at(T, C2_DXF2, o2 + s2); DYF2_p = c2at(T, C2_DYF2, o2 + s2); RAZF_p = c2at(T, C2_RAZF, o2 + s2);
+            DYU_0 = c2at(T, C2_DYU, o2); RDYU_0 = c2at(T, C2_RDYU, o2); DYC2_0 = c2at(T, C2_DYC2, o2); DXC2_0 = c2at(T, C2_DXC2, o2);
+            const double Uy_w = DYU_0 * u_0, Ur_w = RDYU_0 * u_0;
+            fm::full_strain_cell(from_right(Uy_w), Uy_w, DXV_p * v_p, DXV_0 * v_0, from_right(Ur_w), Ur_w, RDXV_p * v_p, RDXV_0 * v_0,
+                                 DYC2_0, DXC2_0, c2at(T, C2_RAZC, o2), e11_0, e22_0);
+            const double Vy_e = RDYV_p * v_p;
+            e12_p = fm::full_strain_corner(RDXU_p * u_p, RDXU_0 * u_0, Vy_e, from_left(Vy_e), DXF2_p, DYF2_p, RAZF_p);
         } else {
         fm::strain_cell<UNI>(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
                         coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
@@ -93,7 +130,7 @@ struct Stage {
                     ks.amax2 = T->K[FK_AMAX2]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
                 }
                 double kc, kf;
-                if constexpr (FULL) { kc = T->K[FK_CA_DT] * c2at(T, C2_RAZC, o2); kf = T->K[FK_CA_DT] * c2at(T, C2_RAZF, o2); }
+                if constexpr (FULL) { kc = T->K[FK_CA_DT] * c2at(T, C2_RAZC, o2); kf = T->K[FK_CA_DT] * RAZF_0; }
                 else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r); }
                 const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
@@ -122,15 +159,23 @@ struct Stage {
         }
         // FULL: d_j sigma_1j at the u point of row ju (k_ustep2) / d_j sigma_2j at the v point of row jv (k_vstep2); o = the
         // coefficient offset of that row; f at the point: a number, a per-row value or a per-point plane
-        auto div1_full = [&](unsigned o, double s11_0, double s11_w, double s22_0, double s22_w, double s12_n, double s12_s) __attribute__((always_inline)) {
-            const double east = fm::fma_(c2at(T, C2_A11E, o), s11_0, fm::fma_(c2at(T, C2_A22E, o), s22_0, c2at(T, C2_A12N, o) * s12_n));
-            const double west = fm::fma_(c2at(T, C2_A11W, o), s11_w, fm::fma_(c2at(T, C2_A22W, o), s22_w, c2at(T, C2_A12S, o) * s12_s));
-            return east - west;
+        // d_j sigma_1j at the u point of row r - 1; d_j sigma_2j at the v point of row r - 1 (`low`) or r: k_ustep2 / k_vstep2 of
+        // evp_fast.hip (a neighbouring column's S, T, Z' is the neighbour's own product: one lane shift each)
+        auto div1_full = [&]() __attribute__((always_inline)) {
+            const double S_e = d11_m + d22_m, T_e = DYC2_m * (d11_m - d22_m);
+            const double S_w = MASK ? from_left(S_e) : d11_mL + d22_mL;
+            const double T_w = MASK ? from_left(T_e) : from_left(DYC2_m) * (d11_mL - d22_mL);
+            return fm::full_div1(DYU_m, RDYU_m, RDXU_m, c2at(T, C2_RAZU, o2 - s2), S_e, S_w, T_e, T_w, DXF2_0 * d12_0, DXF2_m * d12_m);
         };
-        auto div2_full = [&](unsigned o, double s11_0, double s11_s, double s22_0, double s22_s, double s12_e, double s12_0) __attribute__((always_inline)) {
-            const double north = fm::fma_(c2at(T, C2_B11N, o), s11_0, fm::fma_(c2at(T, C2_B22N, o), s22_0, c2at(T, C2_B12E, o) * s12_e));
-            const double south = fm::fma_(c2at(T, C2_B11S, o), s11_s, fm::fma_(c2at(T, C2_B22S, o), s22_s, c2at(T, C2_B12W, o) * s12_0));
-            return north - south;
+        auto div2_full = [&](bool low) __attribute__((always_inline)) {
+            if (low) {
+                const double Zw = DYF2_m * d12_m;
+                return fm::full_div2(DXV_m, RDXV_m, RDYV_m, c2at(T, C2_RAZV, o2 - s2), d11_m + d22_m, d11_mm + d22_mm,
+                                     DXC2_m * (d11_m - d22_m), DXC2_mm * (d11_mm - d22_mm), from_right(Zw), Zw);
+            }
+            const double Zw = DYF2_0 * d12_0;
+            return fm::full_div2(DXV_0, RDXV_0, RDYV_0, c2at(T, C2_RAZV, o2), d11_0 + d22_0, d11_m + d22_m,
+                                 DXC2_0 * (d11_0 - d22_0), DXC2_m * (d11_m - d22_m), from_right(Zw), Zw);
         };
         auto f_full = [&](int which_row, int which_plane, unsigned o, int j) __attribute__((always_inline)) {
             const int kind = T->I[FI_FKIND];
@@ -151,7 +196,7 @@ struct Stage {
             {
                 const double vbar = fm::quarter(Xv_m, Xv_0);
                 double div;
-                if constexpr (FULL) div = div1_full(o2 - s2, d11_m, d11_mL, d22_m, d22_mL, d12_0, d12_m);
+                if constexpr (FULL) div = div1_full();
                 else div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
@@ -168,7 +213,7 @@ struct Stage {
             {
                 const double ubar = fm::quarter(XW, XW_0);
                 double div;
-                if constexpr (FULL) div = div2_full(o2 - s2, d11_m, d11_mm, d22_m, d22_mm, from_right(d12_m), d12_m);
+                if constexpr (FULL) div = div2_full(true);
                 else div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
                                             coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
@@ -189,7 +234,7 @@ struct Stage {
             {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
                 double div;
-                if constexpr (FULL) div = div2_full(o2, d11_0, d11_m, d22_0, d22_m, from_right(d12_0), d12_0);
+                if constexpr (FULL) div = div2_full(false);
                 else div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
                                             coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
@@ -208,7 +253,7 @@ struct Stage {
                 const int j = r - 1;
                 const double vbar = fm::quarter(XW, XW_0);
                 double div;
-                if constexpr (FULL) div = div1_full(o2 - s2, d11_m, d11_mL, d22_m, d22_mL, d12_0, d12_m);
+                if constexpr (FULL) div = div1_full();
                 else div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
@@ -236,7 +281,12 @@ struct Stage {
         S11_mm = S11_m; S22_mm = S22_m; S12_mm = S12_m; AL_mm = AL_m;
         S11_m = S11_0; S22_m = S22_0; S12_m = S12_0; AL_m = AL_0;
         XAL_m = fm::sum2(from_left(AL_0), AL_0); XS11L_m = from_left(S11_0);
-        if constexpr (FULL) XS22L_m = from_left(S22_0);
+        if constexpr (FULL) {
+            XS22L_m = from_left(S22_0);
+            DXV_m = DXV_0; RDXV_m = RDXV_0; RDYV_m = RDYV_0; RDXU_m = RDXU_0; DXF2_m = DXF2_0; DYF2_m = DYF2_0;
+            DXV_0 = DXV_p; RDXV_0 = RDXV_p; RDYV_0 = RDYV_p; RDXU_0 = RDXU_p; DXF2_0 = DXF2_p; DYF2_0 = DYF2_p; RAZF_0 = RAZF_p;
+            DYU_m = DYU_0; RDYU_m = RDYU_0; DYC2_m = DYC2_0; DXC2_mm = DXC2_m; DXC2_m = DXC2_0;
+        }
         XW = XW_next;
         Wprev = first;
     }
