@@ -40,13 +40,13 @@ enum : int {
 
 // Per-point metric planes for grids whose metrics vary in both directions (CSI_METRIC_FULL): the reference's operators with
 // the metric at the location and index each one names (elasto_visco_plastic_rheology.jl:360-375,
-// ice_stress_divergence.jl:39-51), written in terms of FOURTEEN planes -- four at the u points, four at the v points,
+// ice_stress_divergence.jl:39-51), written in terms of TWELVE planes -- three at the u points, three at the v points,
 // three at the cells, three at the corners -- instead of one folded coefficient per stencil entry (26 planes, round 2 a):
 // the kernels on such grids are bound by the planes' traffic and load count, not by arithmetic (fm::full_* in
 // evp_fast_math.h spell the stencils out).
 enum : int {
-    C2_DYU = 0, C2_RDYU, C2_RDXU, C2_RAZU,      // u points (Face, Center): dy, 1 / dy, 1 / dx, 1 / Az
-    C2_DXV, C2_RDXV, C2_RDYV, C2_RAZV,          // v points (Center, Face): dx, 1 / dx, 1 / dy, 1 / Az
+    C2_DYU = 0, C2_RDXU, C2_RAZU,               // u points (Face, Center): dy, 1 / dx, 1 / Az     (1 / dy: fm::rcp in the kernels,
+    C2_DXV, C2_RDYV, C2_RAZV,                   // v points (Center, Face): dx, 1 / dy, 1 / Az      1 / dx likewise: two loads fewer)
     C2_DYC2, C2_DXC2, C2_RAZC,                  // cells: dy^2, dx^2, 1 / Az
     C2_DXF2, C2_DYF2, C2_RAZF,                  // corners (Face, Face): dx^2, dy^2, 1 / Az
     C2_COUNT
@@ -125,8 +125,8 @@ inline void build_fast_coef_full(int ni, int nj, const double* const* m, std::ve
     auto M = [&](int which, int loc, size_t t) -> double { return m[4 * which + loc][t]; };     // which: 0 dx, 1 dy, 2 Az
     auto O = [&](int w, size_t t) -> double& { return out[(size_t)w * nj * ni + t]; };
     for (size_t t = 0; t < (size_t)ni * nj; ++t) {
-        O(C2_DYU, t) = M(1, FC, t); O(C2_RDYU, t) = 1.0 / M(1, FC, t); O(C2_RDXU, t) = 1.0 / M(0, FC, t); O(C2_RAZU, t) = 1.0 / M(2, FC, t);
-        O(C2_DXV, t) = M(0, CF, t); O(C2_RDXV, t) = 1.0 / M(0, CF, t); O(C2_RDYV, t) = 1.0 / M(1, CF, t); O(C2_RAZV, t) = 1.0 / M(2, CF, t);
+        O(C2_DYU, t) = M(1, FC, t); O(C2_RDXU, t) = 1.0 / M(0, FC, t); O(C2_RAZU, t) = 1.0 / M(2, FC, t);
+        O(C2_DXV, t) = M(0, CF, t); O(C2_RDYV, t) = 1.0 / M(1, CF, t); O(C2_RAZV, t) = 1.0 / M(2, CF, t);
         O(C2_DYC2, t) = M(1, CC, t) * M(1, CC, t); O(C2_DXC2, t) = M(0, CC, t) * M(0, CC, t); O(C2_RAZC, t) = 1.0 / M(2, CC, t);
         O(C2_DXF2, t) = M(0, FF, t) * M(0, FF, t); O(C2_DYF2, t) = M(1, FF, t) * M(1, FF, t); O(C2_RAZF, t) = 1.0 / M(2, FF, t);
     }

@@ -232,7 +232,7 @@ __device__ __forceinline__ double c2(const FastCoef& c, int w, int i, int j) { r
 
 __device__ __forceinline__ void strain_cell2(const FastCoef& c, int i, int j, double u_e, double u_w, double v_n, double v_s, double& e11, double& e22) {
     fm::full_strain_cell(c2(c, C2_DYU, i + 1, j) * u_e, c2(c, C2_DYU, i, j) * u_w, c2(c, C2_DXV, i, j + 1) * v_n, c2(c, C2_DXV, i, j) * v_s,
-                         c2(c, C2_RDYU, i + 1, j) * u_e, c2(c, C2_RDYU, i, j) * u_w, c2(c, C2_RDXV, i, j + 1) * v_n, c2(c, C2_RDXV, i, j) * v_s,
+                         fm::rcp(c2(c, C2_DYU, i + 1, j)) * u_e, fm::rcp(c2(c, C2_DYU, i, j)) * u_w, fm::rcp(c2(c, C2_DXV, i, j + 1)) * v_n, fm::rcp(c2(c, C2_DXV, i, j)) * v_s,
                          c2(c, C2_DYC2, i, j), c2(c, C2_DXC2, i, j), c2(c, C2_RAZC, i, j), e11, e22);
 }
 __device__ __forceinline__ double strain_corner2(const FastCoef& c, int i, int j, double u_n, double u_s, double v_e, double v_w) {
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img
         if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
     }
     const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
-    double div = fm::full_div1(c2(c, C2_DYU, i, j), c2(c, C2_RDYU, i, j), c2(c, C2_RDXU, i, j), c2(c, C2_RAZU, i, j),
+    double div = fm::full_div1(c2(c, C2_DYU, i, j), fm::rcp(c2(c, C2_DYU, i, j)), c2(c, C2_RDXU, i, j), c2(c, C2_RAZU, i, j),
                                s11_0 + s22_0, s11_m + s22_m, c2(c, C2_DYC2, i, j) * (s11_0 - s22_0), c2(c, C2_DYC2, i - 1, j) * (s11_m - s22_m),
                                c2(c, C2_DXF2, i, j + 1) * s12_p, c2(c, C2_DXF2, i, j) * s12_0);
     double ext, imt, exb, imb;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img
         if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
     }
     const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
-    double div = fm::full_div2(c2(c, C2_DXV, i, j), c2(c, C2_RDXV, i, j), c2(c, C2_RDYV, i, j), c2(c, C2_RAZV, i, j),
+    double div = fm::full_div2(c2(c, C2_DXV, i, j), fm::rcp(c2(c, C2_DXV, i, j)), c2(c, C2_RDYV, i, j), c2(c, C2_RAZV, i, j),
                                s11_0 + s22_0, s11_m + s22_m, c2(c, C2_DXC2, i, j) * (s11_0 - s22_0), c2(c, C2_DXC2, i, j - 1) * (s11_m - s22_m),
                                c2(c, C2_DYF2, i + 1, j) * s12_p, c2(c, C2_DYF2, i, j) * s12_0);
     double ext, imt, exb, imb;

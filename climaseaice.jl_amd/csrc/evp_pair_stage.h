@@ -42,9 +42,10 @@ __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__b
 // u(i, row), u(i, row - 1), v(i, row): the operations of evp_fast.hip's strain_cell2 / strain_corner2 (the neighbouring
 // column's products come over the lane shift); s2: row pitch of the planes in bytes
 __device__ __forceinline__ void full_cell(tptr_t T, unsigned o, unsigned s2, double u_0, double v_0, double v_p, double& e11, double& e22) {
-    const double Uy_w = c2at(T, C2_DYU, o) * u_0, Ur_w = c2at(T, C2_RDYU, o) * u_0;
-    const double Vx_s = c2at(T, C2_DXV, o) * v_0, Vr_s = c2at(T, C2_RDXV, o) * v_0;
-    const double Vx_n = c2at(T, C2_DXV, o + s2) * v_p, Vr_n = c2at(T, C2_RDXV, o + s2) * v_p;
+    const double dyu = c2at(T, C2_DYU, o), dxv_s = c2at(T, C2_DXV, o), dxv_n = c2at(T, C2_DXV, o + s2);
+    const double Uy_w = dyu * u_0, Ur_w = fm::rcp(dyu) * u_0;
+    const double Vx_s = dxv_s * v_0, Vr_s = fm::rcp(dxv_s) * v_0;
+    const double Vx_n = dxv_n * v_p, Vr_n = fm::rcp(dxv_n) * v_p;
     fm::full_strain_cell(from_right(Uy_w), Uy_w, Vx_n, Vx_s, from_right(Ur_w), Ur_w, Vr_n, Vr_s,
                          c2at(T, C2_DYC2, o), c2at(T, C2_DXC2, o), c2at(T, C2_RAZC, o), e11, e22);
 }
@@ -71,11 +72,11 @@ struct Stage {
 
     // FULL: before the first step(r): o = plane offset of row r, u_0 / v_0 = u, v of row r
     __device__ __forceinline__ void full_init(tptr_t T, unsigned o) {
-        DXV_0 = c2at(T, C2_DXV, o); RDXV_0 = c2at(T, C2_RDXV, o); RDYV_0 = c2at(T, C2_RDYV, o); RDXU_0 = c2at(T, C2_RDXU, o);
+        DXV_0 = c2at(T, C2_DXV, o); RDXV_0 = fm::rcp(DXV_0); RDYV_0 = c2at(T, C2_RDYV, o); RDXU_0 = c2at(T, C2_RDXU, o);
         DXF2_0 = c2at(T, C2_DXF2, o); DYF2_0 = c2at(T, C2_DYF2, o); RAZF_0 = c2at(T, C2_RAZF, o);
         // rows r - 1, r - 2: multiplied by zero stresses until their real values have been shifted in (any finite number)
         DXV_m = DXV_0; RDXV_m = RDXV_0; RDYV_m = RDYV_0; RDXU_m = RDXU_0; DXF2_m = DXF2_0; DYF2_m = DYF2_0;
-        DYU_m = c2at(T, C2_DYU, o); RDYU_m = c2at(T, C2_RDYU, o); DYC2_m = c2at(T, C2_DYC2, o); DXC2_m = c2at(T, C2_DXC2, o); DXC2_mm = DXC2_m;
+        DYU_m = c2at(T, C2_DYU, o); RDYU_m = fm::rcp(DYU_m); DYC2_m = c2at(T, C2_DYC2, o); DXC2_m = c2at(T, C2_DXC2, o); DXC2_mm = DXC2_m;
     }
     double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
     // results of the last step()
@@ -96,9 +97,9 @@ struct Stage {
         if constexpr (FULL) {
             // strain_cell2 / strain_corner2 of evp_fast.hip: cell (i, r), corner (i, r + 1)
             // (full_cell / full_corner above with the plane values of rows already in the window taken from registers)
-            DXV_p = c2at(T, C2_DXV, o2 + s2); RDXV_p = c2at(T, C2_RDXV, o2 + s2); RDYV_p = c2at(T, C2_RDYV, o2 + s2); RDXU_p = c2at(T, C2_RDXU, o2 + s2);
+            DXV_p = c2at(T, C2_DXV, o2 + s2); RDXV_p = fm::rcp(DXV_p); RDYV_p = c2at(T, C2_RDYV, o2 + s2); RDXU_p = c2at(T, C2_RDXU, o2 + s2);
             DXF2_p = c2at(T, C2_DXF2, o2 + s2); DYF2_p = c2at(T, C2_DYF2, o2 + s2); RAZF_p = c2at(T, C2_RAZF, o2 + s2);
-            DYU_0 = c2at(T, C2_DYU, o2); RDYU_0 = c2at(T, C2_RDYU, o2); DYC2_0 = c2at(T, C2_DYC2, o2); DXC2_0 = c2at(T, C2_DXC2, o2);
+            DYU_0 = c2at(T, C2_DYU, o2); RDYU_0 = fm::rcp(DYU_0); DYC2_0 = c2at(T, C2_DYC2, o2); DXC2_0 = c2at(T, C2_DXC2, o2);
             const double Uy_w = DYU_0 * u_0, Ur_w = RDYU_0 * u_0;
             fm::full_strain_cell(from_right(Uy_w), Uy_w, DXV_p * v_p, DXV_0 * v_0, from_right(Ur_w), Ur_w, RDXV_p * v_p, RDXV_0 * v_0,
                                  DYC2_0, DXC2_0, c2at(T, C2_RAZC, o2), e11_0, e22_0);
