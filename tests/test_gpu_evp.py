@@ -542,3 +542,32 @@ def test_fused_paths_fuzz_bitwise(seed):
         a, b = out[0][k], out[2][k]
         assert np.all(np.isfinite(b)), (k, kw)
         assert np.array_equal(a, b), (seed, kw, nsub, k, np.abs(a - b).max(), np.argwhere(a != b)[:4])
+
+
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("bounded", "bounded"), ("periodic", "bounded")])
+@pytest.mark.parametrize("Nx,Ny,H", [(8, 8, 4), (9, 7, 3), (5, 5, 4), (4, 9, 4), (3, 3, 2), (64, 8, 4), (8, 64, 4), (57, 9, 4), (113, 10, 5)])
+def test_degenerate_grid_sizes_every_path(Nx, Ny, H, topo, oracle_lib):
+    """Grids of a few cells, N = H, N = 2H, one strip / one chunk, ragged widths: STRICT bit for bit and FAST (three kernels,
+    one sub-step per launch, two sub-steps per launch -- each falls back where its geometry needs more cells) against the
+    oracle.  (scripts/tiny_grids.py also checks that halo < 2 and N < H fail loudly.)"""
+    c = cases.make_case(Nx=Nx, Ny=Ny, H=H, topo=topo, substeps=6, patches=False, random_uv=0.02)
+    p = cases.oracle_problem(c)
+    p.time_step_momentum(c["dt"])
+    vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+    for mode, fusion in (("strict", 0), ("fast", 0), ("fast", 1), ("fast", 2)):
+        m = cases.csi_model(c, mode=mode)
+        m.set_fusion(fusion)
+        csi.time_step_momentum(m, c["dt"])
+        g = gpu_fields(m)
+        for k in ("u", "v"):
+            assert np.all(np.isfinite(g[k]))
+            d = np.abs(g[k] - p.f[k]).max()
+            assert (d == 0.0) if mode == "strict" else (d <= 1e-11 * vmax), (mode, fusion, k, d, vmax)
+
+
+def test_invalid_grids_fail_loudly():
+    for (Nx, Ny, H, topo) in [(2, 2, 1, ("periodic", "periodic")), (1, 6, 2, ("bounded", "bounded")), (6, 1, 2, ("periodic", "bounded"))]:
+        c = cases.make_case(Nx=Nx, Ny=Ny, H=H, topo=topo, substeps=2, patches=False)
+        with pytest.raises(csi.CsiError):
+            m = cases.csi_model(c, mode="fast")
+            csi.time_step_momentum(m, c["dt"])
