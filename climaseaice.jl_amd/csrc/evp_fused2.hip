@@ -41,6 +41,10 @@
 #ifndef CSI_PAIR_HOIST
 #define CSI_PAIR_HOIST 0        // 1: let the compiler keep the table constants in SGPRs across rows (no per-row reload fence)
 #endif
+#ifndef CSI_PAIR_STORES
+#define CSI_PAIR_STORES 7       // which of stage B's results the CONSUMER stores itself (bit 0: the stresses, bit 1: the first velocity, bit 2: the
+                                // second); the producer stores the rest, handed over through the out ring, two iterations later
+#endif
 #ifndef CSI_PAIR_PD
 #define CSI_PAIR_PD 1           // rows the producer prefetches ahead (1 or 2; 2 costs 20 more VGPRs)
 #endif
@@ -290,32 +294,39 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         if (!lanes_same) fast_hi = fast_lo - 1;
     }
     const bool fast_plain = lanes_uniform;                // no lane of the wave has an x image either
-    // Stage B's results of row q (sigma(q); first velocity v(q) / u(q-1); second velocity u(q-1) / v(q-1)) reach memory through
-    // the PRODUCER wave: the consumer hands them over in a two-row LDS ring and the producer stores them two iterations
-    // later.  The consumer has ~10 % more arithmetic-side work per row than the producer and sits on the critical path of
-    // the pair; the stores and their bookkeeping (~50 instructions per row) fill the producer's idle time at the barrier.
-    auto flush = [&](int q, double v11, double v22, double v12, double vfirst, double vsecond) __attribute__((always_inline)) {
+    // Stage B's results of row q (sigma(q); first velocity v(q) / u(q-1); second velocity u(q-1) / v(q-1)) go to memory from
+    // whichever wave CSI_PAIR_STORES names: the consumer itself, straight from its registers (the default), or the producer,
+    // which gets them through a two-row LDS ring and stores them two iterations later.  The stores and their bookkeeping
+    // are ~20 % of a wave's row time, so they decide which wave of the pair waits for the other at the barrier: while the
+    // arithmetic was 282 instructions per stage-row the consumer was the longer wave and the producer stored (+3 %); at 234
+    // the producer -- loads, address arithmetic, eleven LDS writes -- became the longer one (probe: 36 + 4 waiting against
+    // 30 + 12 waiting) and the stores went back to the consumer: +5 % at 2048^2, +7 % on a 1024 x 512 tile (28 + 13 against
+    // 39 + 5 now; splitting the five stores between the waves balances them better and measures the same within noise).
+    auto flush = [&](int q, double v11, double v22, double v12, double vfirst, double vsecond, auto WH) __attribute__((always_inline)) {
+        constexpr int which = decltype(WH)::value;           // bit 0: stresses, bit 1: first velocity, bit 2: second velocity
+        if (which == 0) return;
         if ((q >= fast_lo) & (q <= fast_hi)) {
             // interior rows (nearly every call): every kind of store is due, no row has a y image
             if (flags & L_RS) {
                 const unsigned ocq = offc(q), ofq = offf(q);
                 if (fast_plain) {
                     // interior tile: the owned lanes store five values, no images
-                    stg(T->P[FP_S11_OUT], ocq, v11); stg(T->P[FP_S22_OUT], ocq, v22); stg(T->P[FP_S12_OUT], ofq, v12);
-                    stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, vfirst);
-                    stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, vsecond);
+                    if (which & 1) { stg(T->P[FP_S11_OUT], ocq, v11); stg(T->P[FP_S22_OUT], ocq, v22); stg(T->P[FP_S12_OUT], ofq, v12); }
+                    if (which & 2) stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, vfirst);
+                    if (which & 4) stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, vsecond);
                 } else {
                     // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap; v
                     // mirrors / reflects across an x wall), none of the row bookkeeping of the general path
-                    put(T->P[FP_S11_OUT], ocq, 0u, dx, v11); put(T->P[FP_S22_OUT], ocq, 0u, dx, v22); put(T->P[FP_S12_OUT], ofq, 0u, dx, v12);
-                    if (AUF) { put_v(T->P[FP_V_OUTP], ocq, 0u, vfirst); put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vsecond, vsecond, vsecond, vsecond); }
-                    else { put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vfirst, vfirst, vfirst, vfirst); put_v(T->P[FP_V_OUTP], ocq - sc, 0u, vsecond); }
+                    if (which & 1) { put(T->P[FP_S11_OUT], ocq, 0u, dx, v11); put(T->P[FP_S22_OUT], ocq, 0u, dx, v22); put(T->P[FP_S12_OUT], ofq, 0u, dx, v12); }
+                    if (AUF) { if (which & 2) put_v(T->P[FP_V_OUTP], ocq, 0u, vfirst); if (which & 4) put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vsecond, vsecond, vsecond, vsecond); }
+                    else { if (which & 2) put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vfirst, vfirst, vfirst, vfirst); if (which & 4) put_v(T->P[FP_V_OUTP], ocq - sc, 0u, vsecond); }
                 }
             }
             return;
         }
         const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
-        const bool do_s = (q >= rs_lo) & (q <= rs_hi), do_1 = (j1 >= r1_lo) & (j1 <= r1_hi), do_2 = (j2 >= r2_lo) & (j2 <= r2_hi);
+        const bool do_s = ((which & 1) != 0) & (q >= rs_lo) & (q <= rs_hi), do_1 = ((which & 2) != 0) & (j1 >= r1_lo) & (j1 <= r1_hi),
+                   do_2 = ((which & 4) != 0) & (j2 >= r2_lo) & (j2 <= r2_hi);
         if (!(do_s | do_1 | do_2)) return;
         const unsigned ocq = offc(q), ofq = offf(q);
         const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
@@ -428,10 +439,14 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             const RowIn& C = R[k];
             // stage B's results of two iterations ago (rows r - 4 / r - 5): read them now, store them after the prefetch
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
-            const double o11 = outr[so], o22 = outr[so + 64], o12 = outr[so + 128], ofirst = outr[so + 192], osecond = outr[so + 256];
+            constexpr int PW = 7 & ~CSI_PAIR_STORES;          // what the producer stores
+            double o11 = 0, o22 = 0, o12 = 0, ofirst = 0, osecond = 0;
+            if (PW & 1) { o11 = outr[so]; o22 = outr[so + 64]; o12 = outr[so + 128]; }
+            if (PW & 2) ofirst = outr[so + 192];
+            if (PW & 4) osecond = outr[so + 256];
             advance();
             load_row(R[(k + CSI_PAIR_PD) % 3]);           // row r + CSI_PAIR_PD (clamped to rend)
-            flush(r - 4, o11, o22, o12, ofirst, osecond);
+            flush(r - 4, o11, o22, o12, ofirst, osecond, Idx<PW>{});
             fm::StressConst ks; stress_consts(ks);
             fm::VelConst kv; vel_consts(kv);
             const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
@@ -480,7 +495,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         // drain: the consumer's last two rows (r = rend + 1: its iteration rend - 1 is complete; one more barrier for rend)
         for (int d = 0; d < 2; ++d) {
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
-            flush(r - 4, outr[so], outr[so + 64], outr[so + 128], outr[so + 192], outr[so + 256]);
+            flush(r - 4, outr[so], outr[so + 64], outr[so + 128], outr[so + 192], outr[so + 256], Idx<(7 & ~CSI_PAIR_STORES)>{});
             if (d == 0) __syncthreads();
             ++r;
         }
@@ -552,9 +567,12 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.step(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
                FULL ? off2(max(q, row0)) : 0u, c2s);      // (rows below the planes only fill the window: clamped)
-        {
+        flush(q, B.S11_0, B.S22_0, B.S12_0, B.first, B.second, Idx<(CSI_PAIR_STORES & 7)>{});
+        if ((CSI_PAIR_STORES & 7) != 7) {
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
-            outr[so] = B.S11_0; outr[so + 64] = B.S22_0; outr[so + 128] = B.S12_0; outr[so + 192] = B.first; outr[so + 256] = B.second;
+            if (!(CSI_PAIR_STORES & 1)) { outr[so] = B.S11_0; outr[so + 64] = B.S22_0; outr[so + 128] = B.S12_0; }
+            if (!(CSI_PAIR_STORES & 2)) outr[so + 192] = B.first;
+            if (!(CSI_PAIR_STORES & 4)) outr[so + 256] = B.second;
         }
         // diagnostics: last launch of the sub-cycle only, stored at once (with their halo images on periodic sides,
         // where the reference computes them from halo data: same values)
