@@ -36,7 +36,8 @@
 #define CSI_PAIR_FULL_WAVES 2   // ... of the per-point-coefficient (CSI_METRIC_FULL) instantiations
 #endif
 #ifndef CSI_PAIR_PRIO
-#define CSI_PAIR_PRIO 1         // rotate the user priority of the resident workgroups of a CU every row (see k_pair)
+#define CSI_PAIR_PRIO 2         // 2: the consumer wave of every pair above the producers (see k_pair); 1: rotate the priority of the
+                                // resident workgroups of a CU every row; 0: none
 #endif
 #ifndef CSI_PAIR_HOIST
 #define CSI_PAIR_HOIST 0        // 1: let the compiler keep the table constants in SGPRs across rows (no per-row reload fence)
@@ -227,7 +228,13 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     // work per SIMD and by how often its three waves stall at the same time, not by the order they finish in.)
     const int prio_rank = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) % 3u);      // HW_REG_HW_ID bits [3:0]
     auto set_prio = [&](int k) __attribute__((always_inline)) {
-        if (CSI_PAIR_PRIO) {
+        if (CSI_PAIR_PRIO == 2) {                    // the longer wave of the pair (since the stores moved: the consumer) first
+            if (consumer) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        } else if (CSI_PAIR_PRIO == 3) {             // (the other way round: measured worse)
+            if (consumer) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+        } else if (CSI_PAIR_PRIO == 4) {
+            if (consumer) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        } else if (CSI_PAIR_PRIO) {
             int p = prio_rank + k;
             p = p >= 3 ? p - 3 : p;
             if (p == 0) __builtin_amdgcn_s_setprio(0); else if (p == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
