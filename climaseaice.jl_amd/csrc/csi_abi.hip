@@ -585,7 +585,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const bool pairs = pair_supported(c) && (!tiled || k % 2 == 0);
     // number-valued top stress (or none) and a bottom SemiImplicitStress with number-valued ocean velocities: the kernels'
     // compile-time forcing kinds
-    auto ocean_at_rest = [](int kind, double value) { return kind == 0 || (kind == 1 && value == 0.0); };
+    auto ocean_at_rest = [](int kind, double value) { return kind == 0 || (kind == 1 && value == 0.0 && !std::signbit(value)); };   // (-0.0 would flip signed zeros)
     int common_forcing = !force && P.top.kind <= 1 && P.bot.kind == 3 && P.bot.ue_kind != 2 && P.bot.ve_kind != 2 &&
                          P.pressure_kind == 0;            // ... and the default ReplacementPressure
     if (common_forcing && ocean_at_rest(P.bot.ue_kind, P.bot.ue) && ocean_at_rest(P.bot.ve_kind, P.bot.ve))
