@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
     ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 32 on tiles so that k = 16)")
+    ap.add_argument("--overlap", action="store_true", help="tiles: halo exchange on a second stream beside the interior tiles of the next launch (slower: DESIGN.md section 5)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
     ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
                     help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
@@ -192,6 +193,7 @@ def main():
                                      solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
     model = csi.SeaIceModel(tg, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
     model.set_exchange_interval(args.exchange_interval)
+    model.set_overlap(args.overlap)
     model.set_fusion(0 if args.no_fusion else args.fusion_level)
     csi.set_(model, h=f["h"], aice=f["a"], u=f["u"], v=f["v"])
     dt = 120.0
@@ -229,6 +231,7 @@ def main():
     value = owned * args.substeps * args.steps / elapsed
     subcycle_ms = model.ctx.last_subcycle_ms()            # HIP events on the launch stream, last step
     path = model.ctx.last_path()
+    path["overlapped_exchanges"] = model.ctx.last_overlapped()
 
     # ---- result check (outside the timed region): the state the timed steps produced is finite and non-trivial -------
     model.synchronize()

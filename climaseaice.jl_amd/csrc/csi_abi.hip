@@ -85,6 +85,13 @@ struct csi_context {
     double *sendbuf = nullptr, *recvbuf = nullptr;
     size_t buf_cap = 0;   // elements per buffer
     int last_exchanges = 0, last_k = 1;
+    // exchange / compute overlap (csi_set_overlap; off by default: measured slower): the grouped send /
+    // receive runs on a second stream beside the tiles of the next launch that read no received cell
+    int overlap = 0;
+    int last_overlapped = 0;             // exchanges of the last sub-cycle that ran beside an interior launch
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_received = nullptr;
+    ExPlan pending_rp;                   // the receive plan of an exchange that has been begun
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
     FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
     // pinned staging ring for their upload: the host never waits for the stream (a slot is reused after its own copy
@@ -349,21 +356,24 @@ int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     return exchange_refs(c, fr, nf, W);
 }
 
-// the same on explicit array references (the fused path exchanges whichever ping-pong buffer is current)
-int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
-    if (!is_tiled(c)) return CSI_OK;
+// the same on explicit array references (the fused path exchanges whichever ping-pong buffer is current).
+// exchange_begin: pack on the context stream, the grouped send / receive on `on` (the context stream itself, or the
+// communication stream ordered after the pack by an event); exchange_end: unpack on the context stream (ordered after
+// the receive by an event when it ran on the communication stream).
+int32_t exchange_begin(csi_context* c, const FRef* fr, int nf, int W, bool second_stream) {
     if (!c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
     if (!c->comm) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
     if (nf > MAX_EX_FIELDS) return fail(c, CSI_ERR_INVALID_ARGUMENT, "too many fields in one exchange");
     if (W < 1 || W > c->Hx || W > c->Hy || W > c->Nx || W > c->Ny) return fail(c, CSI_ERR_INVALID_ARGUMENT, "exchange width out of range");
-    ExPlan sp, rp;
+    ExPlan sp;
     long soff[8], scnt[8], roff[8], rcnt[8];
     int speer[8], rpeer[8];
     build_plan(c->g, c->tile, fr, nf, W, 0, sp, soff, scnt, speer);
-    build_plan(c->g, c->tile, fr, nf, W, 1, rp, roff, rcnt, rpeer);
-    const size_t need_elems = (size_t)(sp.total > rp.total ? sp.total : rp.total);
+    build_plan(c->g, c->tile, fr, nf, W, 1, c->pending_rp, roff, rcnt, rpeer);
+    const size_t need_elems = (size_t)(sp.total > c->pending_rp.total ? sp.total : c->pending_rp.total);
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->comm_stream) HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
         if (c->sendbuf) hipFree(c->sendbuf);
         if (c->recvbuf) hipFree(c->recvbuf);
         c->sendbuf = c->recvbuf = nullptr;
@@ -373,15 +383,39 @@ int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
         c->buf_cap = cap;
     }
     launch_pack(sp, c->sendbuf, 0, c->stream);
+    hipStream_t on = c->stream;
+    if (second_stream) {
+        if (!c->comm_stream) {
+            int lo = 0, hi = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));                  // (hi: the numerically lowest = highest priority)
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_received, hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+        on = c->comm_stream;
+    }
     NCCL_TRY(c, ncclGroupStart());
     for (int k = 0; k < 8; ++k)
-        if (speer[k] >= 0 && scnt[k] > 0) NCCL_TRY(c, ncclSend(c->sendbuf + soff[k], (size_t)scnt[k], ncclDouble, speer[k], c->comm, c->stream));
+        if (speer[k] >= 0 && scnt[k] > 0) NCCL_TRY(c, ncclSend(c->sendbuf + soff[k], (size_t)scnt[k], ncclDouble, speer[k], c->comm, on));
     for (int k = 0; k < 8; ++k)
-        if (rpeer[k] >= 0 && rcnt[k] > 0) NCCL_TRY(c, ncclRecv(c->recvbuf + roff[k], (size_t)rcnt[k], ncclDouble, rpeer[k], c->comm, c->stream));
+        if (rpeer[k] >= 0 && rcnt[k] > 0) NCCL_TRY(c, ncclRecv(c->recvbuf + roff[k], (size_t)rcnt[k], ncclDouble, rpeer[k], c->comm, on));
     NCCL_TRY(c, ncclGroupEnd());
-    launch_pack(rp, c->recvbuf, 1, c->stream);
+    if (second_stream) HIP_TRY(c, hipEventRecord(c->ev_received, c->comm_stream));
+    return CSI_OK;
+}
+int32_t exchange_end(csi_context* c, bool second_stream) {
+    if (second_stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_received, 0));
+    launch_pack(c->pending_rp, c->recvbuf, 1, c->stream);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
+}
+int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
+    if (!is_tiled(c)) return CSI_OK;
+    int32_t rc;
+    if ((rc = exchange_begin(c, fr, nf, W, false))) return rc;
+    return exchange_end(c, false);
 }
 
 int32_t fill_halo(csi_context* c, int fid) {
@@ -671,6 +705,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     }
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
+    c->last_overlapped = 0;
     const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int s = first; s < end;) {
@@ -679,7 +714,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, c->stream);
+                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, 0, c->stream);
             m += 2; s += 2;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
             // the one-sub-step kernel takes neither masks nor array-valued forcing nor per-point metrics: a trailing
@@ -703,8 +738,33 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         cur ^= 1;
         ++nlaunch;
         if (tiled && (m == kb || s == end)) {
-            if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
-            m = 0;
+            // Overlap: when a pair launch follows, the grouped send / receive runs on the communication stream while the
+            // context stream launches the tiles that read no received cell; the others follow the unpack (k_pair's `sel`).
+            // Same tiles, same inputs, same results as the unsplit launch.
+            const bool overlap = c->overlap && pairs && kb >= 2 && end - s >= 2;
+            const FRef* bufs = cur == 0 ? orig : alt;
+            if (!overlap) {
+                if ((rc = exchange_refs(c, bufs, nxf, W))) return rc;
+                m = 0;
+            } else {
+                if ((rc = exchange_begin(c, bufs, nxf, W, true))) return rc;
+                const bool uf2 = (s % 2) == 0;
+                for (int sel = 1; sel <= 2; ++sel) {
+                    if (sel == 2 && (rc = exchange_end(c, true))) return rc;
+                    launch_fused_pair(c->dev_tables + NSINGLE + ((0 * 2 + cur) * 2 + (uf2 ? 1 : 0)),
+                                      c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), uf2,
+                                      has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[0].nstrips, GP[0].nchunks, GP[0].rows, s + 2 == end, sel, c->stream);
+                }
+                m = 2; s += 2; cur ^= 1; ++nlaunch;
+                ++c->last_overlapped;
+                if (m >= kb && s < end) {            // k = 2: the next exchange follows at once (not overlapped: one launch per batch)
+                    if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
+                    m = 0; ++nex;
+                } else if (s == end) {
+                    if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
+                    m = 0; ++nex;
+                }
+            }
             ++nex;
         } else if (m >= kb) {
             m = 0;
@@ -1043,6 +1103,9 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_fcor) hipFree(c->dev_fcor);
     if (c->dev_fcor2) hipFree(c->dev_fcor2);
+    if (c->ev_packed) hipEventDestroy(c->ev_packed);
+    if (c->ev_received) hipEventDestroy(c->ev_received);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     if (c->dev_coef2) hipFree(c->dev_coef2);
     if (c->host_ring) hipHostFree(c->host_ring);
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
@@ -1483,6 +1546,13 @@ int32_t csi_set_exchange_interval(csi_context* c, int32_t k) {
     c->exch_k = k;
     return CSI_OK;
 }
+
+int32_t csi_set_overlap(csi_context* c, int32_t on) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    c->overlap = on != 0;
+    return CSI_OK;
+}
+int32_t csi_last_overlapped(csi_context* c) { return c ? c->last_overlapped : 0; }
 
 int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t V, int32_t* out16) {
     if (!out16 || Nx < 1 || Ny < 1 || V < 2) return CSI_ERR_INVALID_ARGUMENT;

@@ -66,7 +66,7 @@ void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
                            const ImageSpec& ims12, FusedTable* host_table);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
-                       int common_forcing, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s);
+                       int common_forcing, int nstrips, int nchunks, int rows, int write_diag, int sel, hipStream_t s);
 // array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported;
 // StressBalanceFreeDrift (P.free_drift: free-drift velocity arrays P.ufd / P.vfd) also selects the FORCE variant
 int pair_forcing_kind(const EvpDev& P);

@@ -81,7 +81,7 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
-                                                              int blocks_per_xcd, int write_diag) {
+                                                              int blocks_per_xcd, int write_diag, int sel) {
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[RING_ROWS * 64];
     __shared__ double outr[2 * 5 * 64];                    // stage B's results on their way to the producer's stores
@@ -155,6 +155,16 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         lanes_uniform = !wave_has_dx_b && lanes_same;
         rstart = max(ja - 3, T->I[FI_AJ0]);
         rend = min(jb + 3, T->I[FI_AJ1]);
+        if (sel) {
+            // Exchange / compute overlap (csi_abi.hip run_fused): the first launch after a halo exchange runs twice -- beside the
+            // exchange (sel = 1) only the tiles that read no cell the exchange delivers, after it (sel = 2) the others.  A tile
+            // reads columns i0s .. i0s + 63 and rows ja - 4 .. jb + 4 of its inputs (one more row of margin here); the received
+            // cells lie beyond the connected sides.
+            const int NyS = T->I[FI_NY];
+            const bool inside = !(T->I[FI_XLO] == SIDE_CONNECTED && i0s < 1) && !(T->I[FI_XHI] == SIDE_CONNECTED && i0s + 63 > Nx) &&
+                                !(T->I[FI_YLO] == SIDE_CONNECTED && ja - 5 < 1) && !(T->I[FI_YHI] == SIDE_CONNECTED && jb + 5 > NyS);
+            if ((sel == 1) != inside) return;                // (uniform over the workgroup)
+        }
         sc = (unsigned)T->I[FI_LD_C] * 8u;
         sf = (unsigned)T->I[FI_LD_F] * 8u;
         if (MASK) {
@@ -647,11 +657,11 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 // common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF; 2: zero ocean velocities); the
 // array-forcing variants have one instantiation (kinds read from the table)
 void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int common, int nstrips, int nchunks, int rows,
-                   int write_diag, hipStream_t s) {
+                   int write_diag, int sel, hipStream_t s) {
     const int nblocks = nstrips * nchunks;              // one workgroup (producer wave + consumer wave) per tile
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(128);
-#define CSI_LAUNCH_PAIR_(U, A, C, F) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag)
+#define CSI_LAUNCH_PAIR_(U, A, C, F) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, sel)
 #if CSI_PAIR_VARIANT <= 2
 #define CSI_LAUNCH_PAIR(U, A) do { if (common == 2) CSI_LAUNCH_PAIR_(U, A, 2, false); else if (common) CSI_LAUNCH_PAIR_(U, A, 1, false); else CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #else
@@ -668,22 +678,22 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int c
 }
 
 #if CSI_PAIR_VARIANT == 0
-void launch_fused_pair_walls(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_force(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_walls(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_force(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
-                       int common, int nstrips, int nchunks, int rows, int write_diag, hipStream_t s) {
+                       int common, int nstrips, int nchunks, int rows, int write_diag, int sel, hipStream_t s) {
     if (metric == 2) walls = true;      // per-point coefficients: the general variants only (none built without walls)
-    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (force && mask) launch_fused_pair_mask_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (force) launch_fused_pair_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (mask) launch_fused_pair_mask(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else if (walls) launch_fused_pair_walls(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
-    else launch_fused_pair_plain(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, s);
+    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    else if (force && mask) launch_fused_pair_mask_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    else if (force) launch_fused_pair_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    else if (mask) launch_fused_pair_mask(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    else if (walls) launch_fused_pair_walls(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    else launch_fused_pair_plain(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
 }
 #endif
 

@@ -346,6 +346,17 @@ int32_t csi_set_fusion(csi_context* ctx, int32_t level);
  * k = substeps extreme (halo 2*substeps+3, split_explicit_momentum_equations.jl:51-64). */
 int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 
+/* Exchange / compute overlap on tiles (default OFF: measured slower on MI355X, DESIGN.md section 5 -- the two-sub-steps kernel
+ * fills every CU's register files, so the communication kernel does not run beside it, and the split launch pays its row
+ * pipeline twice).  The halo exchange that is followed by a two-sub-steps launch runs its
+ * grouped send / receive on a second, high-priority stream while the context stream launches the tiles that read no
+ * received cell; the tiles that do are launched after the unpack.  Same tiles, same inputs: results are bit-identical with
+ * the setting off.  (The reference needs no overlap: it never communicates inside the sub-cycle, at the price of a
+ * 2 * substeps + 3 halo, split_explicit_momentum_equations.jl:51-64.)  csi_last_overlapped: how many exchanges of the last
+ * sub-cycle ran that way. */
+int32_t csi_set_overlap(csi_context* ctx, int32_t on);
+int32_t csi_last_overlapped(csi_context* ctx);
+
 /* Index ranges (1-based, inclusive: i0, i1, j0, j1) the launch loop uses for a grid of this shape and
  * topology when `valid_width` (V >= 2) layers of u, v beyond the owned cells are valid on connected sides:
  * [0..3] stress kernel (Auxiliaries kernel parameters -H+2:N+H-1, elasto_visco_plastic_rheology.jl:145, on

@@ -437,6 +437,32 @@ def test_pair_kernel_on_tiles_halo32_interval16(topo):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
+@pytest.mark.parametrize("topo,land", [(("periodic", "periodic"), 0.0), (("periodic", "bounded"), 0.2)])
+def test_exchange_compute_overlap_bitwise(topo, land):
+    """csi_set_overlap: the exchange that precedes a two-sub-steps launch runs on the communication stream beside the tiles
+    that read no received cell, the others follow the unpack.  Same tiles, same inputs: bit-identical with the setting off and
+    with the untiled three-kernel path; the overlapped exchanges are counted."""
+    c = cases.make_case(Nx=300, Ny=200, H=16, substeps=36, topo=topo, patches=True, random_uv=0.05, land=land)
+    ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
+    csi.time_step_momentum(ref, c["dt"])
+    out = {}
+    for on in (False, True):
+        til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, topo[1] == "periodic")))
+        til.set_overlap(on)
+        csi.time_step_momentum(til, c["dt"])
+        til.synchronize()
+        path = til.ctx.last_path()
+        assert path["exchange_interval"] == 8 and path["level"] == 2 and path["exchanges"] == 5, path
+        assert til.ctx.last_overlapped() == (4 if on else 0)
+        out[on] = {f: EVP_FIELDS[f](til).numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+        for f in ("u", "v", "s11", "s22", "s12", "alpha"):
+            a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+            assert np.array_equal(a, b), (on, f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+    for f in out[True]:
+        assert np.array_equal(out[False][f], out[True][f]), f      # halos included
+
+
 EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear", "folded_tripolar", "coriolis_points_tripolar"})
 FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
