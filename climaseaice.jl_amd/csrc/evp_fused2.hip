@@ -40,7 +40,8 @@
                                 // resident workgroups of a CU every row; 0: none
 #endif
 #ifndef CSI_PAIR_HOIST
-#define CSI_PAIR_HOIST 0        // 1: let the compiler keep the table constants in SGPRs across rows (no per-row reload fence)
+#define CSI_PAIR_HOIST 1        // 1: let the compiler keep the table constants in SGPRs across rows (no per-row reload fence); not in the
+                                // array-forcing and per-point-metric instantiations (scalar spills: curvilinear 30.3 -> 27.1 G with it)
 #endif
 #ifndef CSI_PAIR_STORES
 #define CSI_PAIR_STORES 7       // which of stage B's results the CONSUMER stores itself (bit 0: the stresses, bit 1: the first velocity, bit 2: the
@@ -444,7 +445,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         int r = rstart;
         auto body = [&](auto KK) __attribute__((always_inline)) {
             constexpr int k = decltype(KK)::value;
-            if (!CSI_PAIR_HOIST || FORCE) asm volatile("" : "+s"(T));
+            if (!CSI_PAIR_HOIST || FORCE || FULL) asm volatile("" : "+s"(T));
             set_prio(k);
             PROBE_START;
             // rows r and r + 1 are in flight (loads return in order; FORCE: the array loads of the previous iteration were
@@ -538,7 +539,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     double vn_delay = 0.0;                                // B u-first: v^n of row q - 1 (read one iteration earlier as row q)
     int r = rstart;
     auto bodyB = [&](auto KK) __attribute__((always_inline)) {
-        if (!CSI_PAIR_HOIST || FORCE) asm volatile("" : "+s"(T));
+        if (!CSI_PAIR_HOIST || FORCE || FULL) asm volatile("" : "+s"(T));
         set_prio(decltype(KK)::value);
         const int q = r - 2;
         PROBE_START;
