@@ -115,10 +115,12 @@ struct StressOut {
 //   e11f, e22f : 4-point averages of the cell strain rates at the corner; e12c : of the corner rate at the cell
 //   Pc, Pf : ice strength at the cell / averaged to the corner; mc, mf : ice mass likewise
 //   hkc, hkf : HALF of c_alpha * dt / Az at the cell / corner (the stress phase works with 2 zeta = P / Delta)
-__device__ __forceinline__ StressOut stress_update(const StressConst& k, double e11c, double e22c, double e12f,
-                                                   double e11f, double e22f, double e12c, double Pc, double Pf,
-                                                   double mc, double mf, double hkc, double hkf,
-                                                   double s11, double s22, double s12) {
+//   rmc, rmf : fm::rcp(mc), fm::rcp(mf) -- depend on the ice mass only, which does not change inside a sub-cycle: the pair
+//              kernel's consumer wave takes them from its producer (evp_pair_stage.h) instead of forming them again
+__device__ __forceinline__ StressOut stress_update_r(const StressConst& k, double e11c, double e22c, double e12f,
+                                                     double e11f, double e22f, double e12c, double Pc, double Pf,
+                                                     double mc, double mf, double rmc, double rmf, double hkc, double hkf,
+                                                     double s11, double s22, double s12) {
     StressOut o;
     const double dc = e11c + e22c, df = e11f + e22f;
     const double tc = e11c - e22c, tf = e11f - e22f;
@@ -142,7 +144,7 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     // [alpha-^2, alpha+^2], so the refinement only ever sees finite positive arguments and gamma, 1 / gamma need
     // no select.  The upper side is v_min_f64 (minNum): NaN (0 * inf where there is no ice) and +inf go to alpha+^2,
     // as the reference's isnan(gamma^2) ? alpha+^2 branch does.
-    const double g2c_raw = zc2 * hkc * rcp(mc), g2f_raw = zf2 * hkf * rcp(mf);
+    const double g2c_raw = zc2 * hkc * rmc, g2f_raw = zf2 * hkf * rmf;
     const double g2c = fmax_(fmin_(g2c_raw, k.amax2), k.amin2);
     const double g2f = fmax_(fmin_(g2f_raw, k.amax2), k.amin2);
     double gc, rgc, gf, rgf;
@@ -157,6 +159,13 @@ __device__ __forceinline__ StressOut stress_update(const StressConst& k, double 
     o.alpha = gc;
     o.zc2 = zc2; o.zf2 = zf2; o.xc = xc; o.rDc = rDc;
     return o;
+}
+
+__device__ __forceinline__ StressOut stress_update(const StressConst& k, double e11c, double e22c, double e12f,
+                                                   double e11f, double e22f, double e12c, double Pc, double Pf,
+                                                   double mc, double mf, double hkc, double hkf,
+                                                   double s11, double s22, double s12) {
+    return stress_update_r(k, e11c, e22c, e12f, e11f, e22f, e12c, Pc, Pf, mc, mf, rcp(mc), rcp(mf), hkc, hkf, s11, s22, s12);
 }
 
 struct VelConst {

@@ -75,14 +75,23 @@ template <int V> struct Idx { static constexpr int value = V; };
 // hand-off ring: rows x {sigma11, sigma22, sigma12, u, v of sub-step s; P, ice mass, aice, u^n, v^n} x 64 lanes (+ the 2-bit mask
 // code of each row): everything stage B consumes, so that the consumer wave issues no global loads at all -- its vmcnt
 // queue holds stores only and is never waited for inside the row loop
-constexpr int RING_ROWS = 4, RING_FIELDS = 10;
-enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF_VN };
+constexpr int RING_ROWS = 4;
+enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF_VN, RF_PF, RF_RMC, RF_RMF };
+// The last three -- ice strength at the corner, 1 / m at the cell and the corner, of the producer's row -- spare the consumer
+// two reciprocals, a lane shift and four more operations per row (it is the longer wave of the pair); 26 KB of LDS per
+// workgroup instead of 20: six workgroups per CU still fit, except with the mask rows of the immersed-boundary
+// instantiations, which therefore keep the ten-field ring (CSI_PAIR_PRE).
+#ifndef CSI_PAIR_PRE
+#define CSI_PAIR_PRE 1
+#endif
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, int sel) {
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK;
+    constexpr int RING_FIELDS = PRE ? 13 : 10;
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[RING_ROWS * 64];
     __shared__ double outr[2 * 5 * 64];                    // stage B's results on their way to the producer's stores
@@ -489,6 +498,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 // the static fields of the rows B reaches two iterations from now: P, m, aice of row r; u^n of row r-1;
                 // v^n of row r-1 (A u-first: B v-first reads it as row q) / row r (B u-first reads it as row q-1 one iteration later)
                 ring[s0 + RF_P * 64] = C.P_0; ring[s0 + RF_M * 64] = m_0; ring[s0 + RF_A * 64] = C.a_0;
+                if (PRE) { ring[s0 + RF_PF * 64] = A.Pf_0; ring[s0 + RF_RMC * 64] = A.rmc_0; ring[s0 + RF_RMF * 64] = A.rmf_0; }
                 ring[s1 + RF_UN * 64] = C.un_m; ring[(AUF ? s1 : s0) + RF_VN * 64] = C.vn_x;
                 if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] = mhist & 3u;
             }
@@ -530,7 +540,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     B.XAL_m = 0; B.XS11L_m = 0; B.XS22L_m = 0; B.XW = 0; B.Wprev = 0;
     B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
-    B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0;
+    B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0; B.Pf_0 = 0; B.rmc_0 = 0; B.rmf_0 = 0;
     if constexpr (FULL) B.full_init(T, off2(max(rstart - 2, row0)));
     // Stage B's row inputs all come from the ring (the producer read them from memory two or three iterations earlier):
     // the consumer issues no global loads (FORCE: except its forcing arrays), so it never waits for its own stores.
@@ -550,6 +560,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         double bu_p = ring[s1 + RF_U * 64], bv_p = ring[s1 + RF_V * 64];
         const double s11 = ring[s2 + RF_S11 * 64], s22 = ring[s2 + RF_S22 * 64], s12 = ring[s2 + RF_S12 * 64];
         const double bP_0 = ring[s2 + RF_P * 64], bm_0 = ring[s2 + RF_M * 64], ba_0 = ring[s2 + RF_A * 64];
+        if (PRE) { B.Pf_0 = ring[s2 + RF_PF * 64]; B.rmc_0 = ring[s2 + RF_RMC * 64]; B.rmf_0 = ring[s2 + RF_RMF * 64]; }
         const double bun = ring[s3 + RF_UN * 64], vn_new = ring[s2 + RF_VN * 64];
         const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
         vn_delay = vn_new;
@@ -583,7 +594,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
-        B.step(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
+        B.template step<PRE>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
                FULL ? off2(max(q, row0)) : 0u, c2s);      // (rows below the planes only fill the window: clamped)
         flush(q, B.S11_0, B.S22_0, B.S12_0, B.first, B.second, Idx<(CSI_PAIR_STORES & 7)>{});
         if ((CSI_PAIR_STORES & 7) != 7) {

@@ -83,9 +83,15 @@ struct Stage {
     double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, rDc, first, second;
     // pending window updates
     double Xv_p, Xa_0, Xm_0, e12_p, XW_next;
+    // functions of the static fields of row r that the OTHER stage of the pair needs for the same row: Pf (ice strength at
+    // the corner), 1 / m at the cell and the corner (results of a step<false>; inputs of a step<true>)
+    double Pf_0, rmc_0, rmf_0;
 
     // do_stress / do_vel (wave-uniform): the rows at the start of a tile only fill the window (strain rates and
     // x-averages); their stresses / velocities would never be used
+    // PRE: Pf_0, rmc_0, rmf_0 were set by the caller (from the producer's results for the same row) instead of being
+    // formed here: they depend on P and the ice mass only, which a sub-cycle does not change
+    template <bool PRE = false>
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks_in, const fm::VelConst& kv_in, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
@@ -114,14 +120,19 @@ struct Stage {
         {
             const double Xe11_0 = fm::sum2(from_left(e11_0), e11_0), Xe22_0 = fm::sum2(from_left(e22_0), e22_0);
             const double Ye12_p = fm::sum2(e12_p, from_right(e12_p));
-            const double XP_0 = fm::sum2(from_left(P_0), P_0);
             Xm_0 = fm::sum2(from_left(m_0), m_0);
             const double e11f = fm::quarter(Xe11_m, Xe11_0);
             const double e22f = fm::quarter(Xe22_m, Xe22_0);
             const double e12c = fm::quarter(Ye12_0, Ye12_p);
-            const double Pf = fm::quarter(XP_m, XP_0);
             const double mf = fm::quarter(Xm_m, Xm_0);
-            Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p; XP_m = XP_0;
+            if constexpr (!PRE) {
+                const double XP_0 = fm::sum2(from_left(P_0), P_0);
+                Pf_0 = fm::quarter(XP_m, XP_0);
+                XP_m = XP_0;
+                rmc_0 = fm::rcp(m_0); rmf_0 = fm::rcp(mf);
+            }
+            const double Pf = Pf_0;
+            Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p;
             if (do_stress) {
                 fm::StressConst ks = ks_in;
                 if (CF) ks.pressure_kind = 0;          // ReplacementPressure is part of the common configuration
@@ -133,7 +144,7 @@ struct Stage {
                 double kc, kf;
                 if constexpr (FULL) { kc = T->K[FK_CA_DT] * c2at(T, C2_RAZC, o2); kf = T->K[FK_CA_DT] * RAZF_0; }
                 else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r); }
-                const fm::StressOut o = fm::stress_update(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, kc, kf, s11, s22, s12);
+                const fm::StressOut o = fm::stress_update_r(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, rmc_0, rmf_0, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
             }
         }
