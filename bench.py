@@ -21,6 +21,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise);
+# exported by the environment already, kept here for launches that build their own
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
