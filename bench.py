@@ -158,8 +158,9 @@ def main():
     ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 32 on tiles so that k = 16)")
     ap.add_argument("--overlap", action="store_true", help="tiles: halo exchange on a second stream beside the interior tiles of the next launch (slower: DESIGN.md section 5)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
-    ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
-                    help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
+    ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2, 3],
+                    help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default), 3: three "
+                         "sub-steps per launch where the grid allows it (fully periodic, one tile, --halo >= 6; measured slower at 2048^2)")
     ap.add_argument("--force-connected", action="store_true",
                     help="debug: on one GPU, route the periodic halos through the RCCL exchange (to self)")
     args = ap.parse_args()

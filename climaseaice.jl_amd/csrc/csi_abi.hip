@@ -114,6 +114,9 @@ struct csi_context {
     double vel_bc_value[2][2] = {{0, 0}, {0, 0}};
     bool snow_set = false;   // layered (snow + ice) step instead of the bare-ice one
     SnowDev snow{};
+    int trios = 0;        // three sub-steps per launch where the configuration allows it: csi_set_fusion level 3 (not the default: measured
+                          // 5 % slower than pairs at 2048^2)
+    int last_trios = 0;   // launches of the last sub-cycle that did three sub-steps
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
     int pairing = 1;      // 1: two sub-steps per launch where supported (csi_set_fusion level 2)
     int last_launches = 0, last_substeps = 0, last_used_pairs = 0;   // kernel launches / sub-steps of the last fused sub-cycle
@@ -608,6 +611,33 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     return G;
 }
 
+// Three sub-steps per launch (evp_fused3.hip): what the plain instantiation of the pair kernel takes, on a fully periodic,
+// untiled grid whose halo holds the 6-cell dependency radius of three sub-steps.
+bool trio_supported(const csi_context* c, const EvpDev& P) {
+    const GridDev& g = c->g;
+    if (!c->trios || !pair_supported(c) || is_tiled(c)) return false;
+    if (g.xlo != SIDE_PERIODIC || g.xhi != SIDE_PERIODIC || g.ylo != SIDE_PERIODIC || g.yhi != SIDE_PERIODIC) return false;
+    if (g.has_mask || P.free_drift || c->metric_kind == CSI_METRIC_FULL || pair_forcing_kind(P) != 0) return false;
+    return c->Hx >= 6 && c->Hy >= 6 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
+}
+FusedGeom trio_geom(const csi_context* c, const Range& dec) {
+    FusedGeom G;
+    G.rs = dec;
+    // (52-column strip) x (rows) tiles, one workgroup of three waves per tile, 40 KB of LDS: 256 CUs x 4 workgroups = 1024 tiles
+    const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
+    G.nstrips = (width + 51) / 52;
+    int target = 1024;
+    if (const char* e = getenv("CSI_TRIO_TILES")) target = atoi(e);   // tuning aid
+    int max_chunks = target / G.nstrips;
+    if (max_chunks < 1) max_chunks = 1;
+    int rows = (height + max_chunks - 1) / max_chunks;
+    if (rows < 8) rows = 8;
+    if (rows > height) rows = height;
+    G.rows = rows;
+    G.nchunks = (height + rows - 1) / rows;
+    return G;
+}
+
 int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first) {
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
@@ -649,7 +679,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     // both buffers start identical, so cells no sub-step ever writes (wall halos, the outermost halo layer of sigma
     // under the one-sub-step kernel) agree in both.  A fully periodic, untiled grid advanced by pair launches only
     // rewrites every cell of the five parents -- interior and all halo images -- at every launch: no copy needed.
-    const bool every_cell_written = pairs && !tiled && !has_walls(c) && substeps % 2 == 0;
+    const bool every_cell_written = pairs && !tiled && !has_walls(c) && (substeps % 2 == 0 || (trio_supported(c, P) && substeps >= 2));
     if (!every_cell_written)
         for (int q = 0; q < 5; ++q) {
             const Bound& b = c->f[kPing[q]];
@@ -658,7 +688,10 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     // tables: singles (position in the exchange batch) x (which buffer is current) x (u first / v first), then
     // pairs (pair position) x (buffer) x (first sub-step u first / v first)
-    constexpr int KMAX = kMaxExchangeInterval, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4;
+    constexpr int KMAX = kMaxExchangeInterval, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4 + 4;      // (+ 4: three sub-steps per launch)
+    constexpr int TRIO0 = NSINGLE + (KMAX / 2) * 4;
+    const bool trios = pairs && trio_supported(c, P);
+    FusedGeom GT{};
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
     FusedGeom G[KMAX], GP[KMAX / 2];
@@ -699,6 +732,21 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                     }
             }
         }
+        if (trios) {
+            const ImageSpec ims11 = image_spec(c, CSI_F_S11), ims22 = image_spec(c, CSI_F_S22), ims12 = image_spec(c, CSI_F_S12);
+            const SideV va = pair_side_v(c, 6, 6), vc = pair_side_v(c, 2, 2);
+            const Range dec = v_stress_range(c, vc), ra = v_stress_range(c, va);
+            GT = trio_geom(c, dec);
+            for (int cur = 0; cur < 2; ++cur)
+                for (int auf = 0; auf < 2; ++auf) {
+                    const bool cuf = auf != 0;                      // the third sub-step has the first one's order
+                    const Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vc, cuf), false),
+                                r2 = clip_store(c, v_second_range(c, vc), false);
+                    FusedTable* t = &host[TRIO0 + cur * 2 + auf];
+                    fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
+                    fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
+                }
+        }
         HIP_TRY(c, hipMemcpyAsync(c->dev_tables, host, sizeof(FusedTable) * (NSINGLE + NPAIR), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
         c->ring_used[slot] = true;
@@ -706,11 +754,17 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
     c->last_overlapped = 0;
+    c->last_trios = 0;
     const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (int s = first; s < end;) {
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
-        if (pairs && end - s >= 2 && m + 1 < kb) {
+        if (trios && end - s >= 3 && end - s != 4) {       // (4 = 2 + 2: never leave a single sub-step behind)
+            launch_fused_trio(c->dev_tables + TRIO0 + cur * 2 + (ufirst ? 1 : 0), c->coef.uniform != 0, ufirst, common_forcing,
+                              GT.nstrips, GT.nchunks, GT.rows, s + 3 == end, c->stream);
+            s += 3; m = 0;
+            ++c->last_trios;
+        } else if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
@@ -845,7 +899,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
         c->launches_per_substep = 1 + ((tiled && k == 1) ? 3 : 0);
-        c->last_fused = c->last_used_pairs ? 2 : 1;
+        c->last_fused = c->last_trios > 0 ? 3 : (c->last_used_pairs ? 2 : 1);
         return CSI_OK;
     }
     c->last_fused = 0;
@@ -1537,6 +1591,7 @@ int32_t csi_set_fusion(csi_context* c, int32_t on) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     c->fusion = on != 0;
     c->pairing = on != 1;         // 1: one sub-step per launch only; any other non-zero value: pairs where supported
+    c->trios = on == 3;            // 3: three sub-steps per launch where supported (evp_fused3.hip), two elsewhere
     return CSI_OK;
 }
 

@@ -387,7 +387,8 @@ class SeaIceModel:
 
     def set_fusion(self, level):
         """FAST mode: 0 / False = three-kernel path, 1 = one fused launch per sub-step, 2 / True (default) = two
-        sub-steps per launch where the configuration allows it; bit-identical results."""
+        sub-steps per launch where the configuration allows it, 3 = three per launch on fully periodic grids with halo >= 6
+        (two elsewhere); bit-identical results."""
         level = 2 if level is True else int(level)
         self.ctx.call("csi_set_fusion", level)
 

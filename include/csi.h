@@ -339,6 +339,10 @@ int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
  * supported) where the halo is >= 4 (and N >= 2 halo) and, on tiles, the exchange
  * interval is even; an odd trailing sub-step uses the level-1 kernel (the three kernels when masked).  All paths execute the same
  * floating-point operations and give bit-identical results. */
+/* level 3: THREE sub-steps per launch (evp_fused3.hip: three waves per tile chained through two LDS rings) on fully periodic,
+ * untiled grids with halo >= 6 and number-valued forcing, two elsewhere.  Bit-identical like the others; not the default: it
+ * trades a third of the HBM traffic for 10 % more arithmetic and measures 5 % slower than level 2 at 2048^2 on MI355X
+ * (faster only around 3072^2). */
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
 /* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
