@@ -11,6 +11,16 @@ Rx x Ry tiles (2x1, 2x2, 2x4: 1024 x 512 per GPU at N = 8, BASELINE config 4's d
 kernels with the RCCL halo exchange of u, v, sigma (width 2k every k sub-steps; halo 32 -> k = 16; `--exchange-interval 1`
 is the north star's one exchange per sub-step and is timed as well, outside the headline region).  `--scaling weak`
 gives every GPU its own 2048 x 2048 tile instead.
+
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment is the PARENT: before anything touches
+HIP it counts the visible GPUs (fewer than N: exit 2, never a fall-back to one rank), starts N ranks as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` (the way
+the reference's distributed tests start themselves: test/test_distributed_sea_ice.jl:41-54, `mpiexec -n 4`), relays rank 0's
+single JSON line and exits with the children's code.  Under torch.distributed.run (WORLD_SIZE set) it is a rank, and
+`--gpus` must equal WORLD_SIZE.  `--print-launch` prints the parent's plan as JSON and exits (host test, no GPU needed).
+N > 1 lines carry `rccl_ranks` (ncclCommCount of the library's communicator), the one-GPU rate of the same global grid
+measured in the same run (`single_gpu`), `parallel_efficiency` = value / (N x that rate) and
+`tiled_equals_untiled_bitwise` (every rank advances the whole grid alone from the same state and compares its tile).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -18,6 +28,8 @@ import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,6 +52,75 @@ PARTITION = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}
 KERNEL_NAMES = {"substep": "csi::fused::k_substep (stress + u + v in one launch)",
                 "pair": "csi::fused::k_pair (two sub-steps: 2 x [stress + u + v] in one launch)",
                 "stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}
+
+
+def visible_gpus():
+    """GPUs this process would see, WITHOUT initialising HIP (a parent that has touched the GPU must not start ranks):
+    the KFD topology's GPU nodes, narrowed by the *_VISIBLE_DEVICES lists; torch.cuda.device_count() (which does not
+    initialise HIP on this image) when the topology is not readable."""
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(base):
+            for line in open(os.path.join(base, d, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except Exception:
+        n = None
+    if n is None:
+        try:
+            import torch
+            return int(torch.cuda.device_count())
+        except Exception:
+            return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_plan(n, argv):
+    """The command the parent runs for N ranks (one process per GPU, rendezvous on 127.0.0.1)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def run_parent(args, argv):
+    """--gpus N > 1 without WORLD_SIZE: start the ranks, relay rank 0's JSON line, exit with their code."""
+    have = visible_gpus()
+    cmd = launch_plan(args.gpus, [a for a in argv if a != "--print-launch"])
+    if args.print_launch:
+        print(json.dumps({"launch": cmd, "ranks": args.gpus, "visible_gpus": have, "would_run": have >= args.gpus}), flush=True)
+        return 0
+    if have < args.gpus and not args.self_test_launch:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible; refusing to fall back to fewer ranks\n")
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CSI_BENCH_LAUNCHED_BY_PARENT="1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)          # stderr passes through
+    line = None
+    for ln in p.stdout.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            sys.stderr.write(ln + "\n")
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit code {p.returncode}, JSON line {'found' if line else 'missing'})\n")
+        return p.returncode or 1
+    try:
+        n = json.loads(line).get("n_gpus")
+    except Exception:
+        n = None
+    if n != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} GPUs, the ranks report n_gpus = {n}\n")
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def usable_cores():
@@ -102,15 +183,12 @@ def cpu_baseline(seconds_budget=12.0):
                       f"a lower bound on what a tuned CPU code would reach"}
 
 
-def local_case(csi, np, nx, ny, Rx, Ry, rank, force_connected=False, halo=4):
-    """Seeded synthetic inputs of one tile, functions of the GLOBAL coordinates:
+def tile_fields(np, nx, ny, Rx, Ry, rx, ry):
+    """Seeded synthetic inputs of tile (rx, ry), functions of the GLOBAL coordinates plus noise seeded by the TILE (so that any
+    rank can rebuild any tile, and the untiled check below assembles the same global state):
     h0 sinusoid + 5 % noise, aice patches (open water / marginal ice), u = 0.1 + 2 % noise."""
-    import cases
-    rx, ry = rank % Rx, rank // Rx
     Nx, Ny = nx * Rx, ny * Ry
-    g = csi.RectilinearGrid((Nx, Ny), x=(0.0, Nx * 2000.0), y=(0.0, Ny * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(halo, halo))
-    tg = csi.TileGrid(g, Rx, Ry, rx, ry, force_connected=force_connected) if (Rx * Ry > 1 or force_connected) else g
-    rng = np.random.default_rng(1000 + rank)
+    rng = np.random.default_rng(1000 + ry * Rx + rx)
     xc = ((np.arange(nx) + rx * nx) + 0.5) / Nx
     yc = ((np.arange(ny) + ry * ny) + 0.5) / Ny
     X, Y = xc[None, :], yc[:, None]
@@ -126,7 +204,27 @@ def local_case(csi, np, nx, ny, Rx, Ry, rank, force_connected=False, halo=4):
     a[thin] = 5e-4; h[thin] = 1e-3
     u = 0.1 + 0.02 * rng.standard_normal((ny, nx))
     v = 0.02 * rng.standard_normal((ny, nx))
-    return tg, dict(h=h, a=a, u=u, v=v)
+    return dict(h=h, a=a, u=u, v=v)
+
+
+def global_fields(np, nx, ny, Rx, Ry):
+    """The whole grid's inputs, assembled from the tiles' (what a one-GPU run of the same job starts from)."""
+    out = {k: np.empty((ny * Ry, nx * Rx)) for k in ("h", "a", "u", "v")}
+    for ry in range(Ry):
+        for rx in range(Rx):
+            t = tile_fields(np, nx, ny, Rx, Ry, rx, ry)
+            for k in out:
+                out[k][ry * ny:(ry + 1) * ny, rx * nx:(rx + 1) * nx] = t[k]
+    return out
+
+
+def local_case(csi, np, nx, ny, Rx, Ry, rank, force_connected=False, halo=4):
+    """This rank's tile grid and inputs."""
+    rx, ry = rank % Rx, rank // Rx
+    Nx, Ny = nx * Rx, ny * Ry
+    g = csi.RectilinearGrid((Nx, Ny), x=(0.0, Nx * 2000.0), y=(0.0, Ny * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(halo, halo))
+    tg = csi.TileGrid(g, Rx, Ry, rx, ry, force_connected=force_connected) if (Rx * Ry > 1 or force_connected) else g
+    return tg, tile_fields(np, nx, ny, Rx, Ry, rx, ry)
 
 
 def counters():
@@ -163,7 +261,32 @@ def main():
                          "sub-steps per launch where the grid allows it (fully periodic, one tile, --halo >= 6; measured slower at 2048^2)")
     ap.add_argument("--force-connected", action="store_true",
                     help="debug: on one GPU, route the periodic halos through the RCCL exchange (to self)")
+    ap.add_argument("--print-launch", action="store_true", help="--gpus N > 1: print the launch command of the N ranks as JSON and exit")
+    ap.add_argument("--self-test-launch", action="store_true",
+                    help="host test of the launcher, no GPU: the ranks rendezvous over gloo, rank 0 prints a stub line (self_test: true)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
     args = ap.parse_args()
+    if args.gpus not in PARTITION:
+        raise SystemExit(f"--gpus must be one of {sorted(PARTITION)}")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1 or args.print_launch:
+            # the parent: nothing below this line has touched HIP (no torch.cuda call, no library load)
+            sys.exit(run_parent(args, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {os.environ['WORLD_SIZE']}: start N ranks with --gpus N "
+                         f"(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), or run `python bench.py --gpus N` alone")
+
+    if args.self_test_launch:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"metric": "self-test of the bench.py launcher", "self_test": True, "n_gpus": int(t.item()),
+                              "launched_by_parent": os.environ.get("CSI_BENCH_LAUNCHED_BY_PARENT") == "1"}), flush=True)
+        dist.destroy_process_group()
+        return
 
     import numpy as np
     import torch
@@ -172,13 +295,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    if world not in PARTITION:
-        raise SystemExit(f"--gpus must be one of {sorted(PARTITION)}")
     Rx, Ry = PARTITION[world]
     if args.tile:
         nx_l, ny_l = (int(s) for s in args.tile.lower().split("x"))
@@ -193,10 +316,14 @@ def main():
         args.halo = 32 if tiled else 4
     device = f"cuda:{local_rank}"
     tg, f = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=args.halo)
-    dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
-                                     top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
-                                     solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
-    model = csi.SeaIceModel(tg, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
+
+    def make_model(grid):
+        dyn = csi.SeaIceMomentumEquation(grid, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
+                                         top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
+                                         solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
+        return csi.SeaIceModel(grid, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
+
+    model = make_model(tg)
     model.set_exchange_interval(args.exchange_interval)
     model.set_overlap(args.overlap)
     model.set_fusion(0 if args.no_fusion else args.fusion_level)
@@ -321,6 +448,56 @@ def main():
               "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
         model.set_exchange_interval(args.exchange_interval)
 
+    # ---- N > 1: the same job on ONE GPU, in the same run -- its rate (for parallel_efficiency) and its answer (every rank
+    # advances the whole grid alone from the same state and compares the cells of its own tile bit for bit) ----------------
+    single = None
+    bitwise = None
+    rccl_ranks = model.ctx.comm_count()
+    if world > 1 and rccl_ranks != world:
+        raise SystemExit(f"bench.py: {world} ranks but the library's RCCL communicator has {rccl_ranks}")
+    if world > 1 and not args.no_verify:
+        gN = (nx_l * Rx, ny_l * Ry)
+        gg = csi.RectilinearGrid(gN, x=(0.0, gN[0] * 2000.0), y=(0.0, gN[1] * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
+        whole = make_model(gg)
+        whole.set_fusion(0 if args.no_fusion else args.fusion_level)
+        gf = global_fields(np, nx_l, ny_l, Rx, Ry)
+        sig = ("s11", "s22", "s12")
+
+        def restart(m, fld):
+            csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
+            for name in sig:
+                getattr(m.dynamics.auxiliaries.fields, name).data.zero_()
+
+        restart(whole, gf)
+        restart(model, f)
+        csi.time_step_momentum(whole, dt)
+        csi.time_step_momentum(model, dt)
+        barrier()
+        whole.synchronize()
+        same = True
+        for name, tf, wf in [("u", model.velocities.u, whole.velocities.u), ("v", model.velocities.v, whole.velocities.v)] + \
+                            [(n, getattr(model.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in sig]:
+            mine = tf.interior_numpy()[:ny_l, :nx_l]
+            ref = wf.interior_numpy()[tg.j_off:tg.j_off + ny_l, tg.i_off:tg.i_off + nx_l]
+            same = same and bool(np.array_equal(mine, ref))
+        t = torch.tensor([1.0 if same else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        bitwise = bool(t.item() > 0.5)
+        # the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported
+        for _ in range(args.warmup):
+            csi.time_step_momentum(whole, dt)
+        whole.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            csi.time_step_momentum(whole, dt)
+        whole.synchronize(); torch.cuda.synchronize()
+        e_single = time.perf_counter() - t0
+        single = {"value": gN[0] * gN[1] * args.substeps * args.steps / e_single, "ms_per_step": 1e3 * e_single / args.steps,
+                  "grid": list(gN), "note": "the same global grid advanced by ONE GPU (rank 0) in this run, same kernels, halo 4"}
+        whole = None
+        if not bitwise:
+            raise SystemExit("bench.py: the tiled run does not reproduce the one-GPU run bit for bit on the owned cells -- result invalid")
+
     out = {
         "metric": "EVP sub-cycle cell-updates/s", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -342,6 +519,14 @@ def main():
     }
     if k1 is not None:
         out["exchange_every_substep"] = k1
+    if world > 1:
+        out["rccl_ranks"] = rccl_ranks
+        out["single_gpu"] = single
+        out["tiled_equals_untiled_bitwise"] = bitwise
+        if single is not None:
+            # strong scaling: same grid on N GPUs vs on one; weak: N tiles of the one-GPU size vs ... the N-times larger grid
+            # on one GPU (its rate, not its time, is what N GPUs are compared with)
+            out["parallel_efficiency"] = value / (world * single["value"])
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     model = None                                   # contexts (and their RCCL communicators) go before the line is printed

@@ -30,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_evp_initialize", "csi_evp_subcycle", "csi_evp_finalize", "csi_time_step_momentum",
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
-           "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_halo_exchange",
+           "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_overlap", "csi_last_overlapped", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
            "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
 
@@ -115,6 +115,7 @@ def load():
         "csi_tile_set": [vp, i32, i32, i32, i32, i32, i32],
         "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],
+        "csi_comm_count": [vp, C.POINTER(i32)],
         "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
         "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_plan_pair": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
@@ -215,6 +216,12 @@ class Context:
         f, k, n = C.c_int32(), C.c_int32(), C.c_int32()
         self.call("csi_last_path", C.byref(f), C.byref(k), C.byref(n))
         return dict(fused=bool(f.value), level=f.value, exchange_interval=k.value, exchanges=n.value)
+
+    def comm_count(self):
+        """ranks of the RCCL communicator (ncclCommCount); 0 without one"""
+        v = C.c_int32()
+        self.call("csi_comm_count", C.byref(v))
+        return v.value
 
     def last_overlapped(self):
         """exchanges of the last fused sub-cycle that ran beside an interior launch (csi_set_overlap)"""

@@ -1545,6 +1545,16 @@ int32_t csi_comm_init(csi_context* c, int32_t world_size, int32_t rank, const ui
     return CSI_OK;
 }
 
+int32_t csi_comm_count(csi_context* c, int32_t* ranks) {
+    if (!c || !ranks) return CSI_ERR_INVALID_ARGUMENT;
+    *ranks = 0;
+    if (!c->comm) return CSI_OK;
+    int n = 0;
+    NCCL_TRY(c, ncclCommCount(c->comm, &n));
+    *ranks = n;
+    return CSI_OK;
+}
+
 int32_t csi_halo_exchange(csi_context* c, const int32_t* field_ids, int32_t nfields, int32_t width) {
     if (!c || !field_ids) return CSI_ERR_INVALID_ARGUMENT;
     if (!c->grid_set) return fail(c, CSI_ERR_NOT_BOUND, "csi_grid_set has not been called");

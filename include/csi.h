@@ -319,6 +319,9 @@ int32_t csi_tile_set(csi_context* ctx, int32_t rank_x, int32_t rank_y, int32_t R
 /* 128-byte RCCL unique id produced on rank 0 (csi_comm_unique_id) and broadcast by the host. */
 int32_t csi_comm_unique_id(uint8_t* id128);
 int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const uint8_t* id128);
+/* Ranks of the context's RCCL communicator as RCCL itself reports them (ncclCommCount; 0 before csi_comm_init): what
+ * bench.py prints as `rccl_ranks`, so that a run that silently fell back to one rank cannot report n_gpus > 1. */
+int32_t csi_comm_count(csi_context* ctx, int32_t* ranks);
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 
