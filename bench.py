@@ -47,10 +47,11 @@ HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARC
 # Compulsory HBM bytes per cell PER LAUNCH of each kernel: what `roofline.frac` is priced on.
 #   k_pair / k_substep: read u, v, P, h, aice, sigma x 3, u^n, v^n + write sigma x 3, u, v = 15 x 8 B (k_pair does two
 #   sub-steps on them); three-kernel path: the per-phase figures of SURVEY.md 8(d).
-KERNEL_BYTES = {"pair": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
+KERNEL_BYTES = {"pair": 120.0, "trio": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
 PARTITION = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}
 KERNEL_NAMES = {"substep": "csi::fused::k_substep (stress + u + v in one launch)",
                 "pair": "csi::fused::k_pair (two sub-steps: 2 x [stress + u + v] in one launch)",
+                "trio": "csi::fused::k_trio (three sub-steps in one launch; --fusion-level 3)",
                 "stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}
 
 
@@ -388,7 +389,7 @@ def main():
     if path["fused"]:
         launches, nsub = model.ctx.last_launches()
         spl = nsub / max(launches, 1)
-        dom = "pair" if path["level"] == 2 else "substep"
+        dom = {2: "pair", 3: "trio"}.get(path["level"], "substep")
         phases = {dom: phases["stress"], "exchange": phases["exchange"]}
         sub_ms = phases[dom] / spl
     else:

@@ -123,6 +123,8 @@ struct csi_context {
     int last_fused = 0;
     double ibc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // csi_immersed_flux_bc_set: [u | v][west, east, south, north]
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
+    // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
+    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, trio_tiles = -1; } tune;
 };
 
 namespace {
@@ -467,7 +469,7 @@ FusedGeom fused_geom(const csi_context* c, int V) {
     int rows = (int)(strip_rows / 6000);
     if (rows < 3) rows = 3;
     if (rows > 12) rows = 12;
-    if (const char* e = getenv("CSI_FUSED_ROWS")) rows = atoi(e);   // tuning aid
+    if (c->tune.fused_rows >= 0) rows = c->tune.fused_rows;         // tuning aid (CSI_FUSED_ROWS)
     if (rows > height) rows = height;
     if (rows < 1) rows = 1;
     G.rows = rows;
@@ -589,7 +591,7 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     // 1024 tiles 22.9, 1536 tiles 18.9, 768 tiles 20.8 G cell-updates/s)
     int target = c->metric_kind == CSI_METRIC_FULL ? 1024 : 1536;
     bool forced = false;
-    if (const char* e = getenv("CSI_PAIR_TILES")) { target = atoi(e); forced = true; }   // tuning aid
+    if (c->tune.pair_tiles >= 0) { target = c->tune.pair_tiles; forced = true; }   // tuning aid (CSI_PAIR_TILES)
     int max_chunks = target / G.nstrips;
     if (max_chunks < 1) max_chunks = 1;
     int rows = (height + max_chunks - 1) / max_chunks;
@@ -601,9 +603,9 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
         rows = (height + max_chunks - 1) / max_chunks;
     }
     int min_rows = 6;                  // small grids: parallelism beats the 6 ring rows
-    if (const char* e = getenv("CSI_PAIR_MINROWS")) min_rows = atoi(e);
+    if (c->tune.pair_minrows >= 0) min_rows = c->tune.pair_minrows;
     if (rows < min_rows) rows = min_rows;
-    if (const char* e = getenv("CSI_PAIR_ROWS")) rows = atoi(e);   // tuning aid
+    if (c->tune.pair_rows >= 0) rows = c->tune.pair_rows;          // tuning aid (CSI_PAIR_ROWS)
     if (rows > height) rows = height;
     if (rows < 1) rows = 1;
     G.rows = rows;
@@ -627,7 +629,7 @@ FusedGeom trio_geom(const csi_context* c, const Range& dec) {
     const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
     G.nstrips = (width + 51) / 52;
     int target = 1024;
-    if (const char* e = getenv("CSI_TRIO_TILES")) target = atoi(e);   // tuning aid
+    if (c->tune.trio_tiles >= 0) target = c->tune.trio_tiles;         // tuning aid (CSI_TRIO_TILES)
     int max_chunks = target / G.nstrips;
     if (max_chunks < 1) max_chunks = 1;
     int rows = (height + max_chunks - 1) / max_chunks;
@@ -654,7 +656,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                          P.pressure_kind == 0;            // ... and the default ReplacementPressure
     if (common_forcing && ocean_at_rest(P.bot.ue_kind, P.bot.ue) && ocean_at_rest(P.bot.ve_kind, P.bot.ve))
         common_forcing = 2;                               // ZeroField ocean velocities (the reference's default)
-    if (const char* e = getenv("CSI_PAIR_COMMON")) common_forcing = common_forcing < atoi(e) ? common_forcing : atoi(e);   // A/B knob
+    if (c->tune.pair_common >= 0 && common_forcing > c->tune.pair_common) common_forcing = c->tune.pair_common;   // A/B knob (CSI_PAIR_COMMON)
     FRef ubar_v{nullptr, 0}, vbar_u{nullptr, 0};
     if (force && P.bot.kind == 3 && (P.bot.ue_kind == 2 || P.bot.ve_kind == 2)) {
         // cross components of the ocean velocity averaged to the velocity points, once per sub-cycle
@@ -974,13 +976,17 @@ int32_t do_time_step_momentum(csi_context* c, double dt, int substeps, int rk_re
     }
     if ((rc = do_initialize(c))) return rc;                 // :130
     // update_external_stress! :133-134: halos of the forcing fields (local boundary conditions, then tiles)
-    for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V})
-        if (c->f[id].p && (rc = fill_halo(c, id))) return rc;
+    // ... and of model.forcing.u / .v when they are arrays: inside an exchange batch the velocity kernels run on ranges that
+    // extend into the halo and read the forcing there (elasto_visco_plastic_rheology.jl:391-401 is evaluated at every point
+    // the step updates), so beyond a connected side the halo must hold the neighbour's values
     if ((c->f[CSI_F_FORCING_U].p != nullptr) != (c->f[CSI_F_FORCING_V].p != nullptr))
         return fail(c, CSI_ERR_NOT_BOUND, "model.forcing arrays: bind both CSI_F_FORCING_U and CSI_F_FORCING_V or neither");
+    const int forcing_ids[6] = {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V, CSI_F_FORCING_U, CSI_F_FORCING_V};
+    for (int id : forcing_ids)
+        if (c->f[id].p && (rc = fill_halo(c, id))) return rc;
     if (is_tiled(c)) {
-        int ff[4], n = 0;
-        for (int id : {CSI_F_TOP_U, CSI_F_TOP_V, CSI_F_BOT_U, CSI_F_BOT_V}) if (c->f[id].p) ff[n++] = id;
+        int ff[6], n = 0;
+        for (int id : forcing_ids) if (c->f[id].p) ff[n++] = id;
         if (n && (rc = exchange(c, ff, n, c->Hx < c->Hy ? c->Hx : c->Hy))) return rc;
     }
     if ((rc = do_subcycle(c, dt, substeps, 1))) return rc;  // :170-189
@@ -1146,6 +1152,12 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
     hipEventCreate(&c->ev1);
     c->stress[0].kind = CSI_STRESS_NONE;
     c->stress[1].kind = CSI_STRESS_NONE;
+    {
+        auto env_int = [](const char* name) { const char* e = getenv(name); return (e && *e) ? atoi(e) : -1; };
+        c->tune.fused_rows = env_int("CSI_FUSED_ROWS"); c->tune.pair_tiles = env_int("CSI_PAIR_TILES");
+        c->tune.pair_minrows = env_int("CSI_PAIR_MINROWS"); c->tune.pair_rows = env_int("CSI_PAIR_ROWS");
+        c->tune.pair_common = env_int("CSI_PAIR_COMMON"); c->tune.trio_tiles = env_int("CSI_TRIO_TILES");
+    }
     *out = c;
     return CSI_OK;
 }

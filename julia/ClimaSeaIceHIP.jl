@@ -73,16 +73,37 @@ function Context(device_id = AMDGPU.device_id(AMDGPU.device()) - 1; stream = AMD
 end
 
 # csi_topology: 0 Periodic, 1 Bounded, 2 FullyConnected, 3 LeftConnected, 4 RightConnected, 5 RightFolded (the y direction
-# of a TripolarGrid: south wall + north fold / Zipper), 6 LeftConnected + RightFolded (northernmost rank of a y partition)
+# of a TripolarGrid: south wall + north fold / Zipper), 6 LeftConnected + RightFolded (northernmost rank of a y partition).
+# The fold the library implements has its pivot on the cell CENTRES of row Ny (Center-in-y fields store that row twice:
+# include/csi.h): Oceananigans' RightCenterFolded / LeftConnectedRightCenterFolded, the topologies the reference lists at
+# SeaIceDynamics/split_explicit_momentum_equations.jl:7-16.  The *FaceFolded variants (pivot on the faces) and the
+# LeftConnectedRight*Connected ones (a fold that crosses ranks: x-partitioned tripolar grids) are refused, not approximated.
+const OG = Oceananigans.Grids
 topo_code(::Type{Periodic}) = Int32(0)
 topo_code(::Type{Bounded}) = Int32(1)
-topo_code(::Type{Oceananigans.Grids.FullyConnected}) = Int32(2)
-topo_code(::Type{Oceananigans.Grids.LeftConnected}) = Int32(3)
-topo_code(::Type{Oceananigans.Grids.RightConnected}) = Int32(4)
-# a TripolarGrid reports (Periodic, RightConnected, ...) on one rank; its north side is the fold, not an exchange
-y_topo_code(grid, TY) = topo_code(TY)
-y_topo_code(grid::TripolarGrid, TY) = TY === Oceananigans.Grids.FullyConnected || TY === Oceananigans.Grids.LeftConnected ? Int32(6) : Int32(5)
-y_topo_code(grid::ImmersedBoundaryGrid, TY) = y_topo_code(grid.underlying_grid, TY)
+topo_code(::Type{OG.FullyConnected}) = Int32(2)
+topo_code(::Type{OG.LeftConnected}) = Int32(3)
+topo_code(::Type{OG.RightConnected}) = Int32(4)
+if isdefined(OG, :RightCenterFolded)
+    topo_code(::Type{OG.RightCenterFolded}) = Int32(5)
+    topo_code(::Type{OG.LeftConnectedRightCenterFolded}) = Int32(6)
+    for T in (:RightFaceFolded, :LeftConnectedRightFaceFolded, :LeftConnectedRightCenterConnected, :LeftConnectedRightFaceConnected)
+        isdefined(OG, T) && @eval topo_code(::Type{OG.$T}) =
+            error("ClimaSeaIceHIP: y topology " * $(string(T)) * " is not supported (only the Center-pivot fold on a y-partitioned or unpartitioned grid)")
+    end
+end
+topo_code(T) = error("ClimaSeaIceHIP: unknown topology $T")
+# Older Oceananigans (no *Folded topologies): a TripolarGrid reports Bounded / RightConnected / FullyConnected / LeftConnected in
+# y and the fold is implied by the grid type; the rank that owns the fold is the last one of the y partition.
+y_topo_code(grid, arch, TY) = topo_code(TY)
+function y_topo_code(grid::TripolarGrid, arch, TY)
+    isdefined(OG, :RightCenterFolded) && return topo_code(TY)
+    Ry = arch isa Distributed ? arch.ranks[2] : 1
+    ry = arch isa Distributed ? arch.local_index[2] : 1
+    ry == Ry && return Ry == 1 ? Int32(5) : Int32(6)           # the northernmost rank holds the fold
+    return ry == 1 ? Int32(4) : Int32(2)                        # southern rank: wall + connected; middle ranks: connected
+end
+y_topo_code(grid::ImmersedBoundaryGrid, arch, TY) = y_topo_code(grid.underlying_grid, arch, TY)
 
 # Oceananigans parent array: column-major (ni, nj, 1); ld = ni
 function bind!(ctx, slot, field)
@@ -127,7 +148,7 @@ function set_grid!(ctx, grid::OrthogonalSphericalShellGrid)
     GC.@preserve arrays begin
         m = Ref(CsiMetrics(0.0, 0.0, C_NULL, C_NULL, C_NULL, C_NULL, ntuple(k -> pointer(arrays[k]), 12), length(is)))
         check(ctx, ccall((:csi_grid_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32, Int32, Ref{CsiMetrics}),
-                         ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), y_topo_code(grid, TY), 2, m))
+                         ctx.handle, Nx, Ny, Hx, Hy, topo_code(TX), y_topo_code(grid, architecture(grid), TY), 2, m))
     end
 end
 
@@ -177,6 +198,10 @@ function attach!(model::SeaIceModel)
         bind!(ctx, F.HS, model.snow_thickness); bind!(ctx, F.GHS, model.timestepper.Gⁿ.hs)
         model.timestepper isa SplitRungeKuttaTimeStepper && bind!(ctx, F.HSM, model.timestepper.Ψ⁻.hs)
     end
+    # diagnostics update_state! masks on immersed grids (sea_ice_model.jl:386-389)
+    mf = model.mass_fluxes
+    bind!(ctx, F.MASS_FLUX, mf.thermodynamics.ice); bind!(ctx, F.MASS_FLUX_SNOW, mf.thermodynamics.snow)
+    bind!(ctx, F.SNOWFALL_INTERCEPTED, mf.intercepted_snowfall)
     r = dyn.rheology
     cor = dyn.coriolis
     p = Ref(CsiEvpParams(r.ice_compressive_strength, r.ice_compaction_hardening, r.yield_curve_eccentricity,
@@ -274,6 +299,12 @@ struct HIPSplitExplicitSolver
 end
 HIPSplitExplicitSolver(; substeps = 120) = HIPSplitExplicitSolver(substeps)
 const HIPMomentumEquation = SeaIceMomentumEquation{<:HIPSplitExplicitSolver}
+# SeaIceModel{GR, TD, SNT, D, TS, ...} (sea_ice_model.jl:22): the dynamics are the FOURTH type parameter, the time stepper the
+# fifth.  The reference's own methods dispatch on the fifth (FESeaIceModel / RKSeaIceModel, sea_ice_fe_step.jl:9,
+# sea_ice_rk_substep.jl:6), so the HIP methods are defined on the intersections -- more specific than either, no ambiguity.
+const HIPSeaIceModel = SeaIceModel{<:Any, <:Any, <:Any, <:HIPMomentumEquation}
+const HIPFESeaIceModel = SeaIceModel{<:Any, <:Any, <:Any, <:HIPMomentumEquation, <:ClimaSeaIce.ForwardEulerTimeStepper}
+const HIPRKSeaIceModel = SeaIceModel{<:Any, <:Any, <:Any, <:HIPMomentumEquation, <:SplitRungeKuttaTimeStepper}
 
 # time_step_momentum!, SeaIceDynamics/split_explicit_momentum_equations.jl:103-195
 function ClimaSeaIce.SeaIceDynamics.time_step_momentum!(model, dynamics::HIPMomentumEquation, Δt)
@@ -288,35 +319,32 @@ function ClimaSeaIce.SeaIceDynamics.time_step_momentum!(model, dynamics::HIPMome
 end
 
 # compute_tracer_tendencies!, tracer_tendency_kernel_functions.jl:9-25
-function ClimaSeaIce.compute_tracer_tendencies!(model::SeaIceModel{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPMomentumEquation})
+function ClimaSeaIce.compute_tracer_tendencies!(model::HIPSeaIceModel)
     ctx = context(model)
     order = Oceananigans.Advection.required_halo_size_x(model.advection) == 4 ? 7 : 5     # WENO(order = 7 | 5)
     GC.@preserve model check(ctx, ccall((:csi_compute_tracer_tendencies, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, order))
     return nothing
 end
 
-# dynamic_time_step!, sea_ice_fe_step.jl:36-50 and sea_ice_rk_substep.jl:134-152
-function ClimaSeaIce.dynamic_time_step!(model::SeaIceModel{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPMomentumEquation}, Δt)
+# dynamic_time_step!, sea_ice_fe_step.jl:36-50 (Forward Euler: from the current fields) and sea_ice_rk_substep.jl:134-152 (RK: from Ψ⁻)
+function hip_dynamic_time_step!(model, Δt, from_cache)
     ctx = context(model)
-    from_cache = model.timestepper isa SplitRungeKuttaTimeStepper ? 1 : 0
     GC.@preserve model check(ctx, ccall((:csi_dynamic_step_tracers, libcsi), Int32, (Ptr{Cvoid}, Cdouble, Int32), ctx.handle, Δt, from_cache))
     return nothing
 end
+ClimaSeaIce.dynamic_time_step!(model::HIPFESeaIceModel, Δt) = hip_dynamic_time_step!(model, Δt, 0)
+ClimaSeaIce.dynamic_time_step!(model::HIPRKSeaIceModel, Δt) = hip_dynamic_time_step!(model, Δt, 1)
 
-# update_state!, sea_ice_model.jl:379-394: mask_immersed_field_xy! + fill_halo_regions! of the prognostic fields.  On one
-# rank csi_update_state does both (masks, local boundary conditions, the Zipper fold); on a Distributed grid the halos of
-# h, aice, u, v then travel over RCCL with the full halo width -- the hand-off Oceananigans' MPI halo pass would do.
-function ClimaSeaIce.update_state!(model::SeaIceModel{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPMomentumEquation}, callbacks = [])
+# update_state!, sea_ice_model.jl:379-394 (a method of Oceananigans.TimeSteppers.update_state!, as in the reference):
+# mask_immersed_field_xy! + fill_halo_regions! of the prognostic fields, the masks of the three mass_fluxes diagnostics
+# (:386-389; bound as CSI_F_MASS_FLUX / _SNOW / SNOWFALL_INTERCEPTED in attach!, so csi_update_state masks them too), then
+# update_model_field_time_series! (:391), which stays Julia.  On one rank csi_update_state does masks, local boundary
+# conditions and the Zipper fold; on a Distributed grid it also sends the halos of h, aice, u, v (, hs) over RCCL with the full
+# halo width -- the hand-off Oceananigans' MPI halo pass would do.
+function Oceananigans.TimeSteppers.update_state!(model::HIPSeaIceModel, callbacks = [])
     ctx = context(model)
-    grid = model.velocities.u.grid
-    GC.@preserve model begin
-        check(ctx, ccall((:csi_update_state, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
-        if architecture(grid) isa Distributed
-            Hx, Hy, _ = halo_size(grid)
-            ids = Int32[F.H, F.A, F.U, F.V]
-            check(ctx, ccall((:csi_halo_exchange, libcsi), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32, Int32), ctx.handle, ids, length(ids), min(Hx, Hy)))
-        end
-    end
+    GC.@preserve model check(ctx, ccall((:csi_update_state, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
+    Oceananigans.Models.update_model_field_time_series!(model, model.clock)
     return nothing
 end
 

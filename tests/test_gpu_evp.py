@@ -382,6 +382,25 @@ def test_pair_kernel_on_tiles_halo8(fc, k, nsub):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
+@pytest.mark.parametrize("k", [1, 2])
+def test_user_forcing_arrays_on_tiles_bitwise(k):
+    """model.forcing.u / .v as arrays on a self-connected tile: inside an exchange batch the velocity kernels read the forcing
+    on ranges that extend into the halo, so its halos beyond connected sides must come through the exchange (they held zeros:
+    ADVICE round 2).  Owned cells equal the untiled run bit for bit."""
+    c = cases.make_case(Nx=96, Ny=64, substeps=10, topo=("periodic", "periodic"), patches=True, random_uv=0.05, user_forcing=True)
+    ref = cases.csi_model(c, mode="fast")
+    ref.set_fusion(0)
+    csi.time_step_momentum(ref, c["dt"])
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, True)))
+    til.set_exchange_interval(k)
+    csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    assert til.ctx.last_path()["exchange_interval"] == k
+    for f in ("u", "v", "s11", "s22", "s12", "alpha"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+
+
 @pytest.mark.parametrize("k", [4, 2])
 def test_pair_kernel_on_channel_tile(k):
     """A tile with two kinds of edges: x connected (to itself), y walls.  Exchange in x, mirror images and in-register

@@ -83,3 +83,18 @@ def test_fused_paths_refuse_parents_beyond_32bit_offsets():
     assert _lib.plan_pair(23160, 23160, 4, 4, P, P) is not None           # just below 4 GiB
     assert _lib.plan_pair(23170, 23170, 4, 4, P, P) is None               # (23179 x 23179 x 8 B >= 2^32)
     assert _lib.plan_pair(40000, 16384, 4, 4, P, P) is None
+
+
+def test_julia_shim_matches_reference_types():
+    """scripts/check_julia_shim.py: the Julia binding dispatches on the reference's real type-parameter positions, extends
+    functions the reference defines, and ccalls symbols include/csi.h declares (static check; no Julia in this image).
+    Skips where /root/reference is absent (the GPU box)."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_julia_shim.py")], capture_output=True, text=True)
+    if p.returncode == 77:
+        pytest.skip("no reference tree here")
+    assert p.returncode == 0, p.stdout

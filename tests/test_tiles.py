@@ -84,6 +84,9 @@ PARTITIONS = [
     ("x2_curvilinear", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "bounded"), curvilinear=0.04)),
     # TripolarGrid-like: north fold (Zipper), partitioned in y only as the reference's own distributed tripolar test
     # (test/distributed_tests_utils.jl:239: Partition(1, 4)); the fold lives on the northernmost tile
+    # model.forcing arrays: their halos beyond connected sides come from the neighbour (read on the extended ranges of k > 1)
+    ("x2_user_forcing", 2, 1, dict(Nx=48, Ny=32, topo=("periodic", "bounded"), user_forcing=True)),
+    ("y2_user_forcing", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"), user_forcing=True)),
     ("y2_folded", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "folded"))),
     ("y2_folded_curvilinear", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "folded"), curvilinear=0.04)),
 ]

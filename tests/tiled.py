@@ -36,6 +36,15 @@ def tile_problem(case, Rx, Ry, rank, force_connected=False):
         p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
     for name, key in (("h", "h"), ("aice", "a"), ("u", "u"), ("v", "v")):
         p.interior(name)[...] = tg.local_interior(case[key], *_LOC[name])
+    if case.get("user_forcing"):
+        # model.forcing.u / .v as arrays: the tile's slice; halos by the local boundary conditions here, beyond connected
+        # sides by the exchange in tiled_time_step_momentum (what csi_abi.hip do_time_step_momentum does)
+        fu = cases._fill_parent_like(p, "u", tg.local_interior(case["force_u"], csi.Face, csi.Center))
+        fv = cases._fill_parent_like(p, "v", tg.local_interior(case["force_v"], csi.Center, csi.Face))
+        for arr, (lx, ly) in ((fu, (O.FACE, O.CENTER)), (fv, (O.CENTER, O.FACE))):
+            p.L.ora_fill_halo_loc(p.ptr, O.Field(arr.ctypes.data_as(O.C.POINTER(O.C.c_double)), arr.shape[1]), lx, ly, -1)
+        p.set_forcing(fu, fv)
+        p.f["forcing_u"], p.f["forcing_v"] = fu, fv
     return tg, p
 
 
@@ -107,6 +116,8 @@ def tiled_time_step_momentum(tg, p, dt, ex, k=1):
     p.update_state()
     ex(p, ["h", "aice", "u", "v"], Hmin)
     p.initialize_rheology()
+    if "forcing_u" in p.f:
+        ex(p, ["forcing_u", "forcing_v"], Hmin)
     p.L.ora_fill_halo_u(p.ptr); p.L.ora_fill_halo_v(p.ptr)
     xf = ["u", "v"] if k == 1 else ["u", "v", "s11", "s22", "s12"]   # sigma is history dependent (csi_abi.hip)
     ex(p, xf, W)
