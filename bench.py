@@ -255,7 +255,8 @@ def main():
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--exchange-interval", type=int, default=0, help="k: exchange width 2k every k sub-steps (0 = auto)")
     ap.add_argument("--halo", type=int, default=0, help="halo width (default: 4 on one GPU, 32 on tiles so that k = 16)")
-    ap.add_argument("--overlap", action="store_true", help="tiles: halo exchange on a second stream beside the interior tiles of the next launch (slower: DESIGN.md section 5)")
+    ap.add_argument("--transport", default="peer", choices=["peer", "rccl"],
+                    help="tiles: peer-direct halo writes over xGMI with flags (default; halo 4) or the k-batched RCCL exchange (halo 32)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
     ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2, 3],
                     help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default), 3: three "
@@ -313,10 +314,8 @@ def main():
             raise SystemExit("--size must be divisible by the partition")
         nx_l, ny_l = args.size // Rx, args.size // Ry
     tiled = world > 1 or args.force_connected
-    if args.halo == 0:
-        args.halo = 32 if tiled else 4
+    user_halo = args.halo
     device = f"cuda:{local_rank}"
-    tg, f = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=args.halo)
 
     def make_model(grid):
         dyn = csi.SeaIceMomentumEquation(grid, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
@@ -324,11 +323,19 @@ def main():
                                          solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
         return csi.SeaIceModel(grid, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
 
-    model = make_model(tg)
-    model.set_exchange_interval(args.exchange_interval)
-    model.set_overlap(args.overlap)
-    model.set_fusion(0 if args.no_fusion else args.fusion_level)
-    csi.set_(model, h=f["h"], aice=f["a"], u=f["u"], v=f["v"])
+    def build(transport):
+        """This rank's tile model.  Tiles: the peer transport needs the halo 4 of an untiled run; the RCCL exchange amortises its
+        pack / send / unpack over k = 16 sub-steps with halo 32."""
+        halo = user_halo or (4 if (not tiled or transport == "peer") else 32)
+        grid, fld = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=halo)
+        m = make_model(grid)
+        m.set_exchange_interval(args.exchange_interval)
+        m.set_halo_transport(transport)
+        m.set_fusion(0 if args.no_fusion else args.fusion_level)
+        csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
+        return grid, fld, m, halo
+
+    tg, f, model, args.halo = build(args.transport)
     dt = 120.0
 
     def barrier():
@@ -355,6 +362,18 @@ def main():
     for _ in range(args.warmup):
         csi.time_step_momentum(model, dt)
     barrier()
+    transport_note = None
+    if tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
+            and not args.no_fusion and args.fusion_level >= 2 and model.ctx.halo_transport() != "peer":
+        # the library could not set the peer transport up (no IPC between these devices, ...): it said so by running RCCL; rebuild
+        # with the halo the RCCL exchange wants instead of timing its k = 2 fallback
+        transport_note = "peer transport unavailable on this node: RCCL exchange (halo 32, k = 16) timed instead"
+        sys.stderr.write("bench.py: " + transport_note + "\n")
+        model = None
+        tg, f, model, args.halo = build("rccl")
+        for _ in range(max(args.warmup, 1)):
+            csi.time_step_momentum(model, dt)
+        barrier()
     # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
     # below is the last thing this process writes
     ctypes.CDLL(None).fflush(None)
@@ -364,7 +383,9 @@ def main():
     value = owned * args.substeps * args.steps / elapsed
     subcycle_ms = model.ctx.last_subcycle_ms()            # HIP events on the launch stream, last step
     path = model.ctx.last_path()
-    path["overlapped_exchanges"] = model.ctx.last_overlapped()
+    path["halo_transport"] = model.ctx.halo_transport() if tiled else "none"
+    if transport_note:
+        path["halo_transport_note"] = transport_note
 
     # ---- result check (outside the timed region): the state the timed steps produced is finite and non-trivial -------
     model.synchronize()
@@ -438,16 +459,29 @@ def main():
         full = max_over_ranks((time.perf_counter() - t1) / nfull)
         model_days_per_hr = 3600.0 / (full * 86400.0 / dt)
 
-    # ---- tiles: the north star's "exchange once per sub-step" (k = 1), timed outside the headline region ---------------
+    # ---- tiles: the other ways to move the halos, timed outside the headline region: the RCCL exchange batched over k = 16
+    # sub-steps (halo 32) and once per sub-step (k = 1) --------------------------------------------------------------------------
     k1 = None
-    if tiled and path["exchange_interval"] != 1:
-        model.set_exchange_interval(1)
-        csi.time_step_momentum(model, dt)
-        e1 = timed(args.steps)
-        p1 = model.ctx.last_path()
-        k1 = {"value": owned * args.substeps * args.steps / e1, "ms_per_step": 1e3 * e1 / args.steps,
-              "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
-        model.set_exchange_interval(args.exchange_interval)
+    rccl16 = None
+    headline_model = model
+    if tiled and args.exchange_interval == 0:
+        if path["halo_transport"] == "peer" and not user_halo:
+            _, _, model, _ = build("rccl")                       # (timed() and barrier() act on `model`)
+            for _ in range(max(args.warmup, 1)):
+                csi.time_step_momentum(model, dt)
+            e16 = timed(args.steps)
+            p16 = model.ctx.last_path()
+            rccl16 = {"value": owned * args.substeps * args.steps / e16, "ms_per_step": 1e3 * e16 / args.steps, "halo": 32,
+                      "exchange_interval": p16["exchange_interval"], "exchanges_per_step": p16["exchanges"], "level": p16["level"]}
+        if model.ctx.halo_transport() == "rccl" and model.ctx.last_path()["exchange_interval"] != 1:
+            model.set_exchange_interval(1)
+            csi.time_step_momentum(model, dt)
+            e1 = timed(args.steps)
+            p1 = model.ctx.last_path()
+            k1 = {"value": owned * args.substeps * args.steps / e1, "ms_per_step": 1e3 * e1 / args.steps,
+                  "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
+            model.set_exchange_interval(args.exchange_interval)
+        model = headline_model
 
     # ---- N > 1: the same job on ONE GPU, in the same run -- its rate (for parallel_efficiency) and its answer (every rank
     # advances the whole grid alone from the same state and compares the cells of its own tile bit for bit) ----------------
@@ -509,8 +543,10 @@ def main():
                    "substeps": args.substeps, "mode": args.mode,
                    "halo": args.halo,
                    "halo_exchange": "none (one tile)" if not tiled
-                   else f"RCCL send/recv of u, v, sigma: width {2 * path['exchange_interval']} every {path['exchange_interval']} sub-steps "
-                        f"({path['exchanges']} exchanges per step)"},
+                   else ("peer-direct halo writes over xGMI (IPC-mapped neighbour arrays, per-tile flags) inside every launch; "
+                         "one RCCL exchange of u, v, sigma per sub-cycle" if path["halo_transport"] == "peer"
+                         else f"RCCL send/recv of u, v, sigma: width {2 * path['exchange_interval']} every {path['exchange_interval']} sub-steps "
+                              f"({path['exchanges']} exchanges per step)")},
         "model_days_per_hr": model_days_per_hr,
         "model_days_per_hr_config": "full RK3 time_step! (3 stages x [WENO7 advection of h, aice + sub-cycle + tracer update]), dt = 120 s",
         "subcycle_ms_hip_events": subcycle_ms,
@@ -520,6 +556,8 @@ def main():
     }
     if k1 is not None:
         out["exchange_every_substep"] = k1
+    if rccl16 is not None:
+        out["rccl_exchange"] = rccl16
     if world > 1:
         out["rccl_ranks"] = rccl_ranks
         out["single_gpu"] = single

@@ -31,7 +31,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_halo_exchange",
-           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_overlap", "csi_last_overlapped", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
+           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
            "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
 
 
@@ -120,7 +120,7 @@ def load():
         "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_plan_pair": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_set_exchange_interval": [vp, i32],
-        "csi_set_overlap": [vp, i32], "csi_last_overlapped": [vp],
+        "csi_set_halo_transport": [vp, i32], "csi_halo_transport": [vp, C.POINTER(i32)],
         "csi_set_fusion": [vp, i32], "csi_free_drift_set": [vp, i32],
         "csi_coriolis_rows_set": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32],
         "csi_velocity_bc_set": [vp, i32, i32, i32, dbl],
@@ -223,9 +223,11 @@ class Context:
         self.call("csi_comm_count", C.byref(v))
         return v.value
 
-    def last_overlapped(self):
-        """exchanges of the last fused sub-cycle that ran beside an interior launch (csi_set_overlap)"""
-        return int(self.L.csi_last_overlapped(self.h))
+    def halo_transport(self):
+        """"peer" / "rccl": what the last sub-cycle moved its halos with (csi_halo_transport)"""
+        v = C.c_int32()
+        self.call("csi_halo_transport", C.byref(v))
+        return "peer" if v.value == 1 else "rccl"
 
     def last_launches(self):
         """(kernel launches, sub-steps) of the last fused sub-cycle."""

@@ -39,6 +39,35 @@ void launch_pack(const ExPlan& pl, double* buf, int unpack, hipStream_t s) {
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((pl.total + 255) / 256)), dim3(256), 0, s, pl, buf, unpack);
 }
 
+struct WaitSpec { int n[8]; };
+__global__ void __launch_bounds__(64) k_wait_peers(const unsigned long long* slots, WaitSpec w, int slots_per_dir, unsigned long long seq, unsigned* err) {
+    const int lane = (int)threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    for (int d = 0; d < 8; ++d) {
+        const int n = w.n[d];
+        const unsigned long long* q = slots + (size_t)d * slots_per_dir;
+        for (;;) {
+            bool behind = false;
+            for (int b0 = 0; b0 < n; b0 += 64) {
+                const int idx = b0 + lane;
+                if (idx < n) behind |= __hip_atomic_load(q + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq;
+            }
+            if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+            if (wall_clock64() - t0 > 300000000ull) { if (lane == 0) *err = 1u; return; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+void launch_wait_peers(const unsigned long long* slots, const int* sync_rank, int slots_per_dir, const int* n, unsigned long long seq,
+                       unsigned* err, hipStream_t s) {
+    WaitSpec w;
+    bool any = false;
+    for (int d = 0; d < 8; ++d) { w.n[d] = sync_rank[d] >= 0 ? n[d] : 0; any |= w.n[d] > 0; }
+    if (any) hipLaunchKernelGGL(k_wait_peers, dim3(1), dim3(64), 0, s, slots, w, slots_per_dir, seq, err);
+}
+
 // Neighbour in direction (dx, dy) of tile (rx, ry); -1 if none.
 int tile_neighbor(const TileInfo& t, int dx, int dy, int xlo, int xhi, int ylo, int yhi) {
     if (dx == 0 && dy == 0) return -1;

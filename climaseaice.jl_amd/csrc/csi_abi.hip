@@ -85,12 +85,28 @@ struct csi_context {
     double *sendbuf = nullptr, *recvbuf = nullptr;
     size_t buf_cap = 0;   // elements per buffer
     int last_exchanges = 0, last_k = 1;
-    // exchange / compute overlap (csi_set_overlap; off by default: measured slower): the grouped send /
-    // receive runs on a second stream beside the tiles of the next launch that read no received cell
-    int overlap = 0;
-    int last_overlapped = 0;             // exchanges of the last sub-cycle that ran beside an interior launch
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_packed = nullptr, ev_received = nullptr;
+    // Halo transport of the two-sub-steps kernel on tiles.  "peer" (default where it can be set up): the neighbouring tiles'
+    // arrays are mapped into this process (HIP IPC; xGMI peer access) and a connected side behaves like a periodic one whose halo
+    // lives on another GPU -- the owner's stores write the halo images straight into the neighbour's arrays, and flags in
+    // device memory order the launches of neighbouring ranks (evp_fused2.hip): no pack, no RCCL kernel, no unpack, no widened
+    // halo.  "rccl": ncclSend / ncclRecv of width-2k strips every k sub-steps (the fallback, and what every other path uses).
+    struct Peer {
+        static constexpr int NARR = 14;      // u, v, sigma11, sigma22, sigma12 (caller's), the same five (library's ping-pong copies), alpha, zeta_c, zeta_f, Delta
+        static constexpr int SLOTS = 1024;   // flag slots per direction
+        int want = 1;                        // csi_set_halo_transport: 1 peer where possible, 0 RCCL only
+        bool ready = false, failed = false;  // set up (collectively) / cannot be set up (stays on RCCL)
+        const void* sig[NARR] = {};          // the local arrays the set-up was made for
+        int img_rank[8], sync_rank[8];       // per direction: the rank whose arrays receive this tile's images there; the neighbour to wait for (-1: none)
+        void* arr[8][NARR] = {};             // that rank's arrays as this process addresses them
+        unsigned long long* nbr_slots[8] = {};   // its flag array
+        unsigned long long* slots = nullptr; // this rank's flag array: 8 directions x SLOTS
+        unsigned* err = nullptr;             // device word set by a wait that timed out
+        unsigned* err_host = nullptr;        // pinned copy, refreshed after every sub-cycle
+        unsigned long long seq = 0;          // launches of the flag protocol so far (the same number on every rank)
+        std::vector<void*> opened;           // IPC mappings
+        uint8_t* xbuf = nullptr;             // device staging of the set-up's all-gather
+        int last = 0;                        // the last sub-cycle used the peer transport
+    } peer;
     ExPlan pending_rp;                   // the receive plan of an exchange that has been begun
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
     FusedTable* dev_tables = nullptr;   // uniform-input tables of the fused kernel
@@ -124,7 +140,7 @@ struct csi_context {
     double ibc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // csi_immersed_flux_bc_set: [u | v][west, east, south, north]
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
-    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, trio_tiles = -1; } tune;
+    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, trio_tiles = -1, peer_kernel = -1; } tune;
 };
 
 namespace {
@@ -361,11 +377,10 @@ int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     return exchange_refs(c, fr, nf, W);
 }
 
-// the same on explicit array references (the fused path exchanges whichever ping-pong buffer is current).
-// exchange_begin: pack on the context stream, the grouped send / receive on `on` (the context stream itself, or the
-// communication stream ordered after the pack by an event); exchange_end: unpack on the context stream (ordered after
-// the receive by an event when it ran on the communication stream).
-int32_t exchange_begin(csi_context* c, const FRef* fr, int nf, int W, bool second_stream) {
+// the same on explicit array references (the fused path exchanges whichever ping-pong buffer is current): pack, one grouped
+// send / receive, unpack, all on the context stream
+int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
+    if (!is_tiled(c)) return CSI_OK;
     if (!c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
     if (!c->comm) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
     if (nf > MAX_EX_FIELDS) return fail(c, CSI_ERR_INVALID_ARGUMENT, "too many fields in one exchange");
@@ -378,7 +393,6 @@ int32_t exchange_begin(csi_context* c, const FRef* fr, int nf, int W, bool secon
     const size_t need_elems = (size_t)(sp.total > c->pending_rp.total ? sp.total : c->pending_rp.total);
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->comm_stream) HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
         if (c->sendbuf) hipFree(c->sendbuf);
         if (c->recvbuf) hipFree(c->recvbuf);
         c->sendbuf = c->recvbuf = nullptr;
@@ -388,39 +402,15 @@ int32_t exchange_begin(csi_context* c, const FRef* fr, int nf, int W, bool secon
         c->buf_cap = cap;
     }
     launch_pack(sp, c->sendbuf, 0, c->stream);
-    hipStream_t on = c->stream;
-    if (second_stream) {
-        if (!c->comm_stream) {
-            int lo = 0, hi = 0;
-            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));                  // (hi: the numerically lowest = highest priority)
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_received, hipEventDisableTiming));
-        }
-        HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
-        on = c->comm_stream;
-    }
     NCCL_TRY(c, ncclGroupStart());
     for (int k = 0; k < 8; ++k)
-        if (speer[k] >= 0 && scnt[k] > 0) NCCL_TRY(c, ncclSend(c->sendbuf + soff[k], (size_t)scnt[k], ncclDouble, speer[k], c->comm, on));
+        if (speer[k] >= 0 && scnt[k] > 0) NCCL_TRY(c, ncclSend(c->sendbuf + soff[k], (size_t)scnt[k], ncclDouble, speer[k], c->comm, c->stream));
     for (int k = 0; k < 8; ++k)
-        if (rpeer[k] >= 0 && rcnt[k] > 0) NCCL_TRY(c, ncclRecv(c->recvbuf + roff[k], (size_t)rcnt[k], ncclDouble, rpeer[k], c->comm, on));
+        if (rpeer[k] >= 0 && rcnt[k] > 0) NCCL_TRY(c, ncclRecv(c->recvbuf + roff[k], (size_t)rcnt[k], ncclDouble, rpeer[k], c->comm, c->stream));
     NCCL_TRY(c, ncclGroupEnd());
-    if (second_stream) HIP_TRY(c, hipEventRecord(c->ev_received, c->comm_stream));
-    return CSI_OK;
-}
-int32_t exchange_end(csi_context* c, bool second_stream) {
-    if (second_stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_received, 0));
     launch_pack(c->pending_rp, c->recvbuf, 1, c->stream);
     HIP_TRY(c, hipGetLastError());
     return CSI_OK;
-}
-int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
-    if (!is_tiled(c)) return CSI_OK;
-    int32_t rc;
-    if ((rc = exchange_begin(c, fr, nf, W, false))) return rc;
-    return exchange_end(c, false);
 }
 
 int32_t fill_halo(csi_context* c, int fid) {
@@ -613,6 +603,208 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     return G;
 }
 
+// ---- peer halo transport (csi_context::Peer) -------------------------------------------------------------------------------
+// Directions: 0 W, 1 E, 2 S, 3 N, 4 SW, 5 SE, 6 NW, 7 NE (the order evp_fused2.hip's D_* and the table's FP_IMG0 rows use).
+const int kPeerDx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, kPeerDy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+const int kPeerOpp[8] = {1, 0, 3, 2, 7, 6, 5, 4};
+
+// Which tiles of a pair launch touch the halo beyond each side -- read it, store images of their own cells into the neighbour's,
+// or share a 128-byte line with it -- and therefore wait for / signal that neighbour: the first nW / last nE strips, the first
+// nS / last nN chunks.  size[d]: tiles in this rank's set of direction d; n[d]: slots to wait for from the neighbour in direction
+// d = the size of ITS set towards this rank (tiles of one decomposition have the same shape, hence the same sets).
+struct PeerSets { int nW, nE, nS, nN, size[8], n[8]; };
+PeerSets peer_wait_counts(const csi_context* c, const FusedGeom& G) {
+    PeerSets ps{};
+    constexpr int P_LO = 4, P_W = 56;                       // evp_pair_stage.h: a strip is 64 lanes wide and owns lanes 4 .. 59
+    for (int st = 0; st < G.nstrips; ++st) {
+        const int i0s = G.rs.i0 - P_LO + st * P_W;
+        if (i0s <= c->Hx + 16) ++ps.nW;
+        if (i0s + 63 + 16 > c->Nx - c->Hx) ++ps.nE;
+    }
+    for (int q = 0; q < G.nchunks; ++q) {
+        const int ja = G.rs.j0 + q * G.rows, jb = std::min(ja + G.rows - 1, G.rs.j1);
+        if (ja <= c->Hy + 4) ++ps.nS;
+        if (jb + 4 > c->Ny - c->Hy) ++ps.nN;
+    }
+    const int sz[8] = {ps.nW * G.nchunks, ps.nE * G.nchunks, ps.nS * G.nstrips, ps.nN * G.nstrips,
+                       ps.nW * ps.nS, ps.nE * ps.nS, ps.nW * ps.nN, ps.nE * ps.nN};
+    for (int d = 0; d < 8; ++d) ps.size[d] = sz[d];
+    for (int d = 0; d < 8; ++d) ps.n[d] = sz[kPeerOpp[d]];
+    return ps;
+}
+
+// the 14 local arrays a neighbour stores images into, in Peer::arr order
+void peer_local_arrays(const csi_context* c, const void* out[csi_context::Peer::NARR]) {
+    for (int q = 0; q < 5; ++q) { out[q] = c->f[kPing[q]].p; out[5 + q] = c->alt[q]; }
+    out[10] = c->f[CSI_F_ALPHA].p; out[11] = c->f[CSI_F_ZETA_C].p; out[12] = c->f[CSI_F_ZETA_F].p; out[13] = c->f[CSI_F_DELTA].p;
+}
+
+void peer_release(csi_context* c) {
+    for (void* m : c->peer.opened) hipIpcCloseMemHandle(m);
+    c->peer.opened.clear();
+    c->peer.ready = false;
+}
+
+struct PeerRec {                 // what a rank tells the others about one of its buffers
+    hipIpcMemHandle_t handle;    // of the allocation that holds it
+    uint64_t offset;             // of the buffer inside that allocation
+    int64_t ld;                  // leading dimension (images use the sender's strides: they must agree)
+    int32_t ok, pad;
+};
+constexpr int kPeerRecs = csi_context::Peer::NARR + 1;      // + the flag array
+
+// Collective over the context's communicator: every rank publishes IPC handles of its arrays and flags, maps its neighbours'.
+// Failure anywhere (no IPC, strides that differ across a side, sets larger than the flag array) makes EVERY rank stay on RCCL.
+int32_t peer_setup(csi_context* c) {
+    csi_context::Peer& pr = c->peer;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    peer_release(c);
+    const int me = c->tile.ry * c->tile.Rx + c->tile.rx;
+    if (!pr.slots) {
+        // fine-grained (uncached) device memory where the runtime offers it: the flags are polled while remote ranks write them
+        if (hipExtMallocWithFlags((void**)&pr.slots, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(c, hipMalloc((void**)&pr.slots, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS));
+        }
+        HIP_TRY(c, hipMalloc((void**)&pr.err, sizeof(unsigned)));
+        HIP_TRY(c, hipHostMalloc((void**)&pr.err_host, sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void**)&pr.xbuf, sizeof(PeerRec) * kPeerRecs * (size_t)(c->world + 1) + 64));
+    }
+    HIP_TRY(c, hipMemset(pr.slots, 0, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS));
+    HIP_TRY(c, hipMemset(pr.err, 0, sizeof(unsigned)));
+    *pr.err_host = 0;
+    pr.seq = 0;
+    // neighbours: where this tile's images go (a periodic or wall component keeps the coordinate: wraps / mirrors are local
+    // in that direction) and whom to wait for (connected components only)
+    for (int d = 0; d < 8; ++d) {
+        pr.sync_rank[d] = tile_neighbor(c->tile, kPeerDx[d], kPeerDy[d], c->g.xlo, c->g.xhi, c->g.ylo, c->g.yhi);
+        int rx = c->tile.rx, ry = c->tile.ry;
+        if (kPeerDx[d] < 0 && c->g.xlo == SIDE_CONNECTED) rx = (rx - 1 + c->tile.Rx) % c->tile.Rx;
+        if (kPeerDx[d] > 0 && c->g.xhi == SIDE_CONNECTED) rx = (rx + 1) % c->tile.Rx;
+        if (kPeerDy[d] < 0 && c->g.ylo == SIDE_CONNECTED) ry = (ry - 1 + c->tile.Ry) % c->tile.Ry;
+        if (kPeerDy[d] > 0 && c->g.yhi == SIDE_CONNECTED) ry = (ry + 1) % c->tile.Ry;
+        pr.img_rank[d] = ry * c->tile.Rx + rx;
+    }
+    const void* local[csi_context::Peer::NARR];
+    peer_local_arrays(c, local);
+    const int64_t lds[csi_context::Peer::NARR] = {c->f[CSI_F_U].ld, c->f[CSI_F_V].ld, c->f[CSI_F_S11].ld, c->f[CSI_F_S22].ld, c->f[CSI_F_S12].ld,
+                                                  c->f[CSI_F_U].ld, c->f[CSI_F_V].ld, c->f[CSI_F_S11].ld, c->f[CSI_F_S22].ld, c->f[CSI_F_S12].ld,
+                                                  c->f[CSI_F_ALPHA].ld, c->f[CSI_F_ZETA_C].ld, c->f[CSI_F_ZETA_F].ld, c->f[CSI_F_DELTA].ld};
+    std::vector<PeerRec> mine(kPeerRecs), all((size_t)kPeerRecs * c->world);
+    int ok = 1;
+    for (int q = 0; q < kPeerRecs; ++q) {
+        const void* ptr = q < csi_context::Peer::NARR ? local[q] : (const void*)pr.slots;
+        PeerRec& r = mine[q];
+        memset(&r, 0, sizeof r);
+        r.ld = q < csi_context::Peer::NARR ? lds[q] : 0;
+        if (c->world > 1) {                                  // (a single rank addresses its own arrays directly)
+            hipDeviceptr_t base = nullptr; size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) != hipSuccess || hipIpcGetMemHandle(&r.handle, base) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = 0;
+            } else {
+                r.offset = (uint64_t)((const char*)ptr - (const char*)base);
+            }
+        }
+        r.ok = ok;
+    }
+    if (c->world > 1) {
+        const size_t nb = sizeof(PeerRec) * kPeerRecs;
+        HIP_TRY(c, hipMemcpy(pr.xbuf, mine.data(), nb, hipMemcpyHostToDevice));
+        NCCL_TRY(c, ncclAllGather(pr.xbuf, pr.xbuf + nb, nb, ncclUint8, c->comm, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(all.data(), pr.xbuf + nb, nb * c->world, hipMemcpyDeviceToHost));
+    } else {
+        all = mine;
+    }
+    // map the neighbours' buffers (one mapping per distinct allocation)
+    struct Mapped { int rank; hipIpcMemHandle_t h; void* p; };
+    std::vector<Mapped> cache;
+    auto resolve = [&](int rank, int q, void** out) -> bool {
+        const PeerRec& r = all[(size_t)rank * kPeerRecs + q];
+        if (!r.ok) return false;
+        for (const Mapped& m : cache)
+            if (m.rank == rank && memcmp(&m.h, &r.handle, sizeof r.handle) == 0) { *out = (char*)m.p + r.offset; return true; }
+        void* mp = nullptr;
+        if (hipIpcOpenMemHandle(&mp, r.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return false; }
+        cache.push_back(Mapped{rank, r.handle, mp});
+        pr.opened.push_back(mp);
+        *out = (char*)mp + r.offset;
+        return true;
+    };
+    for (int d = 0; d < 8 && ok; ++d) {
+        const int r = pr.img_rank[d];
+        for (int q = 0; q < csi_context::Peer::NARR; ++q) {
+            if (r == me) { pr.arr[d][q] = const_cast<void*>(local[q]); continue; }
+            if (!resolve(r, q, &pr.arr[d][q]) || all[(size_t)r * kPeerRecs + q].ld != lds[q]) { ok = 0; break; }
+        }
+        pr.nbr_slots[d] = nullptr;
+        if (ok && pr.sync_rank[d] >= 0) {
+            void* sp = pr.slots;
+            if (pr.sync_rank[d] != me && !resolve(pr.sync_rank[d], csi_context::Peer::NARR, &sp)) ok = 0;
+            pr.nbr_slots[d] = (unsigned long long*)sp;
+        }
+    }
+    if (c->world > 1) {                                      // every rank or none
+        int* flag = (int*)pr.xbuf;
+        HIP_TRY(c, hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice));
+        NCCL_TRY(c, ncclAllReduce(flag, flag, 1, ncclInt32, ncclMin, c->comm, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(&ok, flag, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    if (!ok) { peer_release(c); pr.failed = true; return CSI_OK; }
+    for (int q = 0; q < csi_context::Peer::NARR; ++q) pr.sig[q] = local[q];
+    pr.ready = true;
+    return CSI_OK;
+}
+
+// Does this sub-cycle run on the peer transport?  Every condition is the same on all ranks of a decomposition (they share the
+// configuration and the tile shape), so the ranks agree without talking; the set-up itself is collective.
+int32_t peer_decide(csi_context* c, const EvpDev& P, int substeps, bool* use) {
+    *use = false;
+    csi_context::Peer& pr = c->peer;
+    if (!is_tiled(c) || !pr.want || pr.failed || !c->comm || !c->tile.set) return CSI_OK;
+    if (c->exch_k > 0) return CSI_OK;                        // an explicit exchange interval asks for the RCCL exchange
+    if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 2 || (substeps & 1)) return CSI_OK;
+    if (!pair_supported(c) || pair_forcing_kind(P) < 0) return CSI_OK;
+    if (c->f[CSI_F_U].ld != c->f[CSI_F_S12].ld || c->f[CSI_F_V].ld != c->f[CSI_F_S11].ld) return CSI_OK;
+    if (c->Nx < 128) return CSI_OK;                          // (a wave's x images all go to ONE neighbour: evp_fused2.hip)
+    int32_t rc;
+    if ((rc = ensure_alt(c))) return rc;
+    const void* local[csi_context::Peer::NARR];
+    peer_local_arrays(c, local);
+    bool same = pr.ready;
+    for (int q = 0; q < csi_context::Peer::NARR && same; ++q) same = pr.sig[q] == local[q];
+    if (!same && (rc = peer_setup(c))) return rc;
+    *use = pr.ready;
+    return CSI_OK;
+}
+
+// redirect the halo images of a pair table to the neighbours and describe the flag protocol (G: the launch geometry)
+int32_t peer_fill_table(csi_context* c, const FusedGeom& G, bool out_is_alt, FusedTable* t) {
+    const csi_context::Peer& pr = c->peer;
+    const PeerSets ps = peer_wait_counts(c, G);
+    for (int d = 0; d < 8; ++d)
+        if (ps.size[d] > csi_context::Peer::SLOTS) return fail(c, CSI_ERR_UNSUPPORTED, "peer halo transport: more edge tiles than flag slots");
+    static const int karr[9] = {2, 3, 4, 0, 1, 10, 11, 12, 13};      // kernel order (sigma11, sigma22, sigma12, u, v, alpha, zeta_c, zeta_f, Delta) -> Peer::arr
+    for (int k = 0; k < 9; ++k)
+        for (int d = 0; d < 8; ++d) {
+            const int q = karr[k] < 5 ? karr[k] + (out_is_alt ? 5 : 0) : karr[k];
+            t->P[FP_IMG0 + d * 9 + k] = (unsigned long)pr.arr[d][q];
+        }
+    int mask = 0;
+    for (int d = 0; d < 8; ++d) {
+        t->P[FP_SLOT_IN + d] = (unsigned long)(pr.slots + (size_t)d * csi_context::Peer::SLOTS);
+        t->P[FP_SLOT_OUT + d] = pr.nbr_slots[d] ? (unsigned long)(pr.nbr_slots[d] + (size_t)kPeerOpp[d] * csi_context::Peer::SLOTS) : 0ul;
+        t->I[FI_PWAIT + d] = ps.n[d];
+        if (pr.sync_rank[d] >= 0) mask |= 1 << d;
+    }
+    t->P[FP_PERR] = (unsigned long)pr.err;
+    t->I[FI_PEER] = 1; t->I[FI_PMASK] = mask;
+    t->I[FI_PSET] = ps.nW; t->I[FI_PSET + 1] = ps.nE; t->I[FI_PSET + 2] = ps.nS; t->I[FI_PSET + 3] = ps.nN;
+    return CSI_OK;
+}
+
 // Three sub-steps per launch (evp_fused3.hip): what the plain instantiation of the pair kernel takes, on a fully periodic,
 // untiled grid whose halo holds the 6-cell dependency radius of three sub-steps.
 bool trio_supported(const csi_context* c, const EvpDev& P) {
@@ -640,7 +832,10 @@ FusedGeom trio_geom(const csi_context* c, const Range& dec) {
     return G;
 }
 
-int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first) {
+// peer: the caller (run_fused_peer) has turned the connected sides of c->g / P.g into periodic ones: the launch loop is that of an
+// untiled periodic grid, the halo images of those sides go to the neighbouring tiles' arrays and every pair launch carries a
+// number of the flag protocol
+int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first, bool peer = false) {
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
     const bool tiled = is_tiled(c);
@@ -648,7 +843,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
     const bool masked = P.g.has_mask != 0;
     const bool force = pair_forcing_kind(P) == 1;           // array-valued forcing: two-sub-steps kernel only
-    const bool pairs = pair_supported(c) && (!tiled || k % 2 == 0);
+    const bool pairs = peer || (pair_supported(c) && (!tiled || k % 2 == 0));
     // number-valued top stress (or none) and a bottom SemiImplicitStress with number-valued ocean velocities: the kernels'
     // compile-time forcing kinds
     auto ocean_at_rest = [](int kind, double value) { return kind == 0 || (kind == 1 && value == 0.0 && !std::signbit(value)); };   // (-0.0 would flip signed zeros)
@@ -692,7 +887,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     // pairs (pair position) x (buffer) x (first sub-step u first / v first)
     constexpr int KMAX = kMaxExchangeInterval, NSINGLE = KMAX * 4, NPAIR = (KMAX / 2) * 4 + 4;      // (+ 4: three sub-steps per launch)
     constexpr int TRIO0 = NSINGLE + (KMAX / 2) * 4;
-    const bool trios = pairs && trio_supported(c, P);
+    const bool trios = pairs && !peer && trio_supported(c, P);
     FusedGeom GT{};
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
@@ -731,6 +926,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
                         if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
+                        if (peer && (rc = peer_fill_table(c, GP[mp], cur == 0, t))) return rc;
                     }
             }
         }
@@ -755,7 +951,6 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     }
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
-    c->last_overlapped = 0;
     c->last_trios = 0;
     const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -770,7 +965,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end, 0, c->stream);
+                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
+                              peer ? ++c->peer.seq : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             m += 2; s += 2;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
             // the one-sub-step kernel takes neither masks nor array-valued forcing nor per-point metrics: a trailing
@@ -794,37 +990,18 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         cur ^= 1;
         ++nlaunch;
         if (tiled && (m == kb || s == end)) {
-            // Overlap: when a pair launch follows, the grouped send / receive runs on the communication stream while the
-            // context stream launches the tiles that read no received cell; the others follow the unpack (k_pair's `sel`).
-            // Same tiles, same inputs, same results as the unsplit launch.
-            const bool overlap = c->overlap && pairs && kb >= 2 && end - s >= 2;
-            const FRef* bufs = cur == 0 ? orig : alt;
-            if (!overlap) {
-                if ((rc = exchange_refs(c, bufs, nxf, W))) return rc;
-                m = 0;
-            } else {
-                if ((rc = exchange_begin(c, bufs, nxf, W, true))) return rc;
-                const bool uf2 = (s % 2) == 0;
-                for (int sel = 1; sel <= 2; ++sel) {
-                    if (sel == 2 && (rc = exchange_end(c, true))) return rc;
-                    launch_fused_pair(c->dev_tables + NSINGLE + ((0 * 2 + cur) * 2 + (uf2 ? 1 : 0)),
-                                      c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), uf2,
-                                      has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[0].nstrips, GP[0].nchunks, GP[0].rows, s + 2 == end, sel, c->stream);
-                }
-                m = 2; s += 2; cur ^= 1; ++nlaunch;
-                ++c->last_overlapped;
-                if (m >= kb && s < end) {            // k = 2: the next exchange follows at once (not overlapped: one launch per batch)
-                    if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
-                    m = 0; ++nex;
-                } else if (s == end) {
-                    if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
-                    m = 0; ++nex;
-                }
-            }
+            if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
+            m = 0;
             ++nex;
         } else if (m >= kb) {
             m = 0;
         }
+    }
+    if (peer) {
+        // the neighbours' last launch wrote into this rank's halos: wait for all of it before anything later on this stream
+        // (the copy back, finalize_rheology!, the next exchange) reads them
+        launch_wait_peers(c->peer.slots, c->peer.sync_rank, csi_context::Peer::SLOTS, peer_wait_counts(c, GP[0]).n, c->peer.seq, c->peer.err, c->stream);
+        HIP_TRY(c, hipMemcpyAsync(c->peer.err_host, c->peer.err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     if (cur == 1)   // the result sits in the library's buffers
@@ -839,6 +1016,27 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     c->last_substeps = substeps;
     c->last_used_pairs = pairs && substeps >= 2;
     return CSI_OK;
+}
+
+// One sub-cycle on the peer transport: an RCCL exchange of u, v, sigma brings the halos up to date (and orders this rank behind
+// whatever its neighbours did last), then the connected sides count as periodic ones for the launch loop.
+int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int substeps, int first) {
+    int32_t rc;
+    FRef orig[5];
+    for (int q = 0; q < 5; ++q) orig[q] = ref_of(c, kPing[q]);
+    const int W = std::min(std::min(c->Hx, c->Hy), 4);
+    if ((rc = exchange_refs(c, orig, 5, W))) return rc;
+    struct Swap {
+        csi_context* c; GridDev saved;
+        explicit Swap(csi_context* cc) : c(cc), saved(cc->g) {
+            for (int* side : {&c->g.xlo, &c->g.xhi, &c->g.ylo, &c->g.yhi}) if (*side == SIDE_CONNECTED) *side = SIDE_PERIODIC;
+        }
+        ~Swap() { c->g = saved; }
+    } swap(c);
+    const EvpDev P = evp_dev(c, dt);
+    rc = run_fused(c, P, fc, substeps, first, true);
+    c->last_exchanges = 1;
+    return rc;
 }
 
 int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
@@ -898,13 +1096,17 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
                       (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                  : fused_supported(P));
     if (fuse) {
-        if ((rc = run_fused(c, P, fc, substeps, first))) return rc;
+        bool peer = false;
+        if ((rc = peer_decide(c, P, substeps, &peer))) return rc;
+        c->peer.last = peer ? 1 : 0;
+        if ((rc = peer ? run_fused_peer(c, dt, fc, substeps, first) : run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
         c->launches_per_substep = 1 + ((tiled && k == 1) ? 3 : 0);
         c->last_fused = c->last_trios > 0 ? 3 : (c->last_used_pairs ? 2 : 1);
         return CSI_OK;
     }
     c->last_fused = 0;
+    c->peer.last = 0;
     if (tiled && (rc = exchange(c, uvs, nxf, W))) return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int m = 0, nex = 0;   // position inside the exchange batch
@@ -1157,6 +1359,7 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
         c->tune.fused_rows = env_int("CSI_FUSED_ROWS"); c->tune.pair_tiles = env_int("CSI_PAIR_TILES");
         c->tune.pair_minrows = env_int("CSI_PAIR_MINROWS"); c->tune.pair_rows = env_int("CSI_PAIR_ROWS");
         c->tune.pair_common = env_int("CSI_PAIR_COMMON"); c->tune.trio_tiles = env_int("CSI_TRIO_TILES");
+        c->tune.peer_kernel = env_int("CSI_PEER_KERNEL");      // 1: untiled grids run the PEER instantiation of the pair kernel (no neighbour, no waits): what the instantiation itself costs
     }
     *out = c;
     return CSI_OK;
@@ -1169,9 +1372,11 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->dev_metrics) hipFree(c->dev_metrics);
     if (c->dev_fcor) hipFree(c->dev_fcor);
     if (c->dev_fcor2) hipFree(c->dev_fcor2);
-    if (c->ev_packed) hipEventDestroy(c->ev_packed);
-    if (c->ev_received) hipEventDestroy(c->ev_received);
-    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    peer_release(c);
+    if (c->peer.slots) hipFree(c->peer.slots);
+    if (c->peer.err) hipFree(c->peer.err);
+    if (c->peer.err_host) hipHostFree(c->peer.err_host);
+    if (c->peer.xbuf) hipFree(c->peer.xbuf);
     if (c->dev_coef2) hipFree(c->dev_coef2);
     if (c->host_ring) hipHostFree(c->host_ring);
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
@@ -1193,6 +1398,12 @@ int32_t csi_context_destroy(csi_context* c) {
 int32_t csi_sync(csi_context* c) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->peer.err_host && *c->peer.err_host) {
+        *c->peer.err_host = 0;
+        hipMemset(c->peer.err, 0, sizeof(unsigned));
+        return fail(c, CSI_ERR_COMM, "peer halo transport: a tile waited 3 s for its neighbour's flags and gave up -- the results of that sub-cycle are "
+                                     "invalid (a rank that fell behind or died; csi_set_halo_transport(ctx, CSI_TRANSPORT_RCCL) selects the RCCL exchange)");
+    }
     return CSI_OK;
 }
 
@@ -1624,12 +1835,18 @@ int32_t csi_set_exchange_interval(csi_context* c, int32_t k) {
     return CSI_OK;
 }
 
-int32_t csi_set_overlap(csi_context* c, int32_t on) {
+int32_t csi_set_halo_transport(csi_context* c, int32_t kind) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
-    c->overlap = on != 0;
+    if (kind != CSI_TRANSPORT_RCCL && kind != CSI_TRANSPORT_PEER) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown halo transport");
+    c->peer.want = kind == CSI_TRANSPORT_PEER;
+    if (c->peer.want) c->peer.failed = false;            // (asking again retries the set-up)
     return CSI_OK;
 }
-int32_t csi_last_overlapped(csi_context* c) { return c ? c->last_overlapped : 0; }
+int32_t csi_halo_transport(csi_context* c, int32_t* kind) {
+    if (!c || !kind) return CSI_ERR_INVALID_ARGUMENT;
+    *kind = c->peer.last ? CSI_TRANSPORT_PEER : CSI_TRANSPORT_RCCL;
+    return CSI_OK;
+}
 
 int32_t csi_plan_ranges(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t V, int32_t* out16) {
     if (!out16 || Nx < 1 || Ny < 1 || V < 2) return CSI_ERR_INVALID_ARGUMENT;
@@ -1681,7 +1898,9 @@ int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double
     if (fast && c->fusion && fused_supported(P)) {
         // the fused path: one launch per sub-step or per pair (csi_last_launches); bracket the whole run with two events
         if (substeps & 1) ++substeps;                      // even count: the state ends in the caller's arrays
-        if ((rc = run_fused(c, P, fc, substeps, 1))) return rc;
+        bool peer = false;
+        if ((rc = peer_decide(c, P, substeps, &peer))) return rc;
+        if ((rc = peer ? run_fused_peer(c, dt, fc, substeps, 1) : run_fused(c, P, fc, substeps, 1))) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         float t = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));

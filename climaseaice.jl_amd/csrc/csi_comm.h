@@ -25,5 +25,9 @@ int tile_neighbor(const TileInfo& t, int dx, int dy, int xlo, int xhi, int ylo, 
 void build_plan(const GridDev& g, const TileInfo& t, const FRef* fields, int nf, int W, int halo,
                 ExPlan& pl, long* dir_off, long* dir_cnt, int* dir_peer);
 void launch_pack(const ExPlan& pl, double* buf, int unpack, hipStream_t s);
+// peer halo transport: one wave waits until, for every direction d with a neighbour (sync_rank[d] >= 0), the first n[d] flag
+// slots of that direction have reached `seq`; sets *err after 3 s instead of hanging
+void launch_wait_peers(const unsigned long long* slots, const int* sync_rank, int slots_per_dir, const int* n, unsigned long long seq,
+                       unsigned* err, hipStream_t s);
 
 }  // namespace csi

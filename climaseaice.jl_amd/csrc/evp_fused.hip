@@ -417,6 +417,11 @@ void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec
     const ImageSpec* im[3] = {&ims11, &ims22, &ims12};
     const int base[3] = {FI_IMS11, FI_IMS22, FI_IMS12};
     for (int k = 0; k < 3; ++k) { I[base[k]] = im[k]->xlo; I[base[k] + 1] = im[k]->xhi; I[base[k] + 2] = im[k]->ylo; I[base[k] + 3] = im[k]->yhi; }
+    // halo images go into the arrays themselves (untiled periodic sides, wall mirrors); csi_abi.hip redirects the directions of
+    // peer-connected sides to the neighbouring tiles' arrays
+    for (int k = 0; k < 9; ++k)
+        for (int d = 0; d < 8; ++d) t->P[FP_IMG0 + d * 9 + k] = t->P[k < 5 ? FP_S11_OUT + k : FP_AL + (k - 5)];
+    I[FI_PEER] = 0;
 }
 
 void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst, int nstrips, int nchunks, int rows,

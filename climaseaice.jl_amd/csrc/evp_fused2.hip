@@ -47,6 +47,13 @@
 #define CSI_PAIR_STORES 7       // which of stage B's results the CONSUMER stores itself (bit 0: the stresses, bit 1: the first velocity, bit 2: the
                                 // second); the producer stores the rest, handed over through the out ring, two iterations later
 #endif
+#ifndef CSI_PEER_EXP
+#define CSI_PEER_EXP 3          // how an edge tile publishes its halo images (PEER instantiations).  3 (default): the images are write-through
+                                // stores at system scope (sc0 sc1) and the flags follow a drained store queue (vmcnt(0)); 0: plain stores and a
+                                // system-scope release fence before the flags -- the fence writes the XCD's whole L2 back (buffer_wbl2), once per
+                                // edge tile: +6 us per launch on a 1024 x 512 tile, +20 us at 2048^2 (profiles/r03_peer_protocol.md); bit 0 alone:
+                                // no fence, bit 2: no wait at the start of an edge tile (timing experiments, not valid protocols)
+#endif
 #ifndef CSI_PAIR_PD
 #define CSI_PAIR_PD 1           // rows the producer prefetches ahead (1 or 2; 2 costs 20 more VGPRs)
 #endif
@@ -87,9 +94,9 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
-                                                              int blocks_per_xcd, int write_diag, int sel) {
+                                                              int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool PRE = CSI_PAIR_PRE && !MASK;
     constexpr int RING_FIELDS = PRE ? 13 : 10;
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     bool lanes_uniform;      // fast store path allowed (see flush)
     bool lanes_same;         // every lane stores all three kinds of results or none (x images allowed)
     int row0;                // first row of the parent arrays (1 - Hy)
-    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64, L_VAL_LO = 128, L_VAL_HI = 256 };
+    enum : unsigned { L_RS = 1, L_R1 = 2, L_R2 = 4, L_WALL_U = 8, L_WALL_V = 16, L_MIR_LO = 32, L_MIR_HI = 64, L_VAL_LO = 128, L_VAL_HI = 256, L_LOW = 512 };
     {
         const int Nx = T->I[FI_NX], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
         const int i0s = T->I[FI_DEC + 0] - P_LO + strip * P_W;
@@ -165,21 +172,58 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         lanes_uniform = !wave_has_dx_b && lanes_same;
         rstart = max(ja - 3, T->I[FI_AJ0]);
         rend = min(jb + 3, T->I[FI_AJ1]);
-        if (sel) {
-            // Exchange / compute overlap (csi_abi.hip run_fused): the first launch after a halo exchange runs twice -- beside the
-            // exchange (sel = 1) only the tiles that read no cell the exchange delivers, after it (sel = 2) the others.  A tile
-            // reads columns i0s .. i0s + 63 and rows ja - 4 .. jb + 4 of its inputs (one more row of margin here); the received
-            // cells lie beyond the connected sides.
-            const int NyS = T->I[FI_NY];
-            const bool inside = !(T->I[FI_XLO] == SIDE_CONNECTED && i0s < 1) && !(T->I[FI_XHI] == SIDE_CONNECTED && i0s + 63 > Nx) &&
-                                !(T->I[FI_YLO] == SIDE_CONNECTED && ja - 5 < 1) && !(T->I[FI_YHI] == SIDE_CONNECTED && jb + 5 > NyS);
-            if ((sel == 1) != inside) return;                // (uniform over the workgroup)
-        }
+        if (i <= Hx) flags |= L_LOW;                         // this column's x image lies beyond the HIGH side of the low-side neighbour
         sc = (unsigned)T->I[FI_LD_C] * 8u;
         sf = (unsigned)T->I[FI_LD_F] * 8u;
         if (MASK) {
             sm = (unsigned)T->I[FI_MASK_LD];
             lm = (unsigned)(ic - (1 - Hx));
+        }
+    }
+    // ---- peer-connected sides (halo transport "peer", csi_abi.hip): flags instead of a halo exchange ----------------------------
+    // The neighbours' tiles of launch seq - 1 stored the images this tile is about to read (its halo beyond a connected side),
+    // and read the halo cells this tile's images are about to overwrite; each of them publishes seq - 1 in a slot of THIS rank's
+    // flag array when it is done (below).  Only tiles next to a connected side wait -- the interior of the launch runs while the
+    // edges of the neighbours' previous launch finish, which is all the overlap of communication and computation there is to have.
+    // pdirs: the direction sets (W E S N SW SE NW NE) this tile belongs to, restricted to directions with a neighbour.
+    unsigned pdirs = 0;
+    if constexpr (PEER) {
+        const bool pw = strip < T->I[FI_PSET], pe = strip >= nstrips - T->I[FI_PSET + 1], ps = chunk < T->I[FI_PSET + 2],
+                   pn = chunk >= nchunks - T->I[FI_PSET + 3];
+        pdirs = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
+                 ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)T->I[FI_PMASK];
+        pdirs = (unsigned)__builtin_amdgcn_readfirstlane((int)pdirs);
+        if (pdirs) {
+            if (!consumer && !(CSI_PEER_EXP & 4)) {
+                // One poll = the slots of ALL this tile's directions in flight at once (lane l reads slot l of each direction; the
+                // sets are a few dozen tiles).  No cache invalidate afterwards: every tile whose footprint shares a 128-byte line
+                // with halo cells of a direction is in that direction's set and loads nothing before it has seen the flags, and the
+                // vector L1 starts every launch empty -- so no line of these halos can have been fetched before the neighbour's
+                // stores landed in this GPU's memory (whose L2 is kept coherent with incoming writes by the memory-side probes).
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    bool behind = false;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        if (!((pdirs >> d) & 1u)) continue;
+                        const int nslots = T->I[FI_PWAIT + d];
+                        const unsigned long long* slots = (const unsigned long long*)T->P[FP_SLOT_IN + d];
+#pragma unroll 1
+                        for (int b0 = 0; b0 < nslots; b0 += 64) {
+                            const int idx = b0 + lane;
+                            if (idx < nslots) behind |= __hip_atomic_load(slots + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1ull < seq;   // v < seq - 1
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+                    if (wall_clock64() - t0 > 300000000ull) {            // 3 s at 100 MHz: give up loudly, never hang
+                        if (lane == 0) *(volatile unsigned*)T->P[FP_PERR] = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                                         // (uniform over the workgroup) releases the consumer's stores
         }
     }
     // byte offset of (this lane's column, row j) in a Center-x / Face-x parent, and into the mask
@@ -264,7 +308,6 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     const int rs_lo = max(ja, T->I[FI_RS + 2]), rs_hi = min(jb, T->I[FI_RS + 3]);
     const int r1_lo = max(ja, T->I[FI_R1 + 2]), r1_hi = min(jb, T->I[FI_R1 + 3]);
     const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
-    struct OutPtrs { unsigned long s11, s22, s12, u, v; };
     // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
     auto yimg = [&](int j) __attribute__((always_inline)) {
         return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
@@ -278,36 +321,55 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         return d;
     };
     // one value -> its cell and the halo images of that cell (same semantics as store_with_images); valy / valx: the
-    // value of the y / x image (a ValueBoundaryCondition reflection differs from the cell's own value)
-    auto put4 = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val, double valy, double valx, double valxy) __attribute__((always_inline)) {
+    // value of the y / x image (a ValueBoundaryCondition reflection differs from the cell's own value).
+    // WHERE the images go: into the halo of THIS tile's arrays on an untiled grid and beyond walls (mirrors); on a
+    // peer-connected side (csi_abi.hip, halo transport "peer": the neighbour's arrays are mapped into this process and the side
+    // behaves like a periodic one whose halo lives on another GPU) into the NEIGHBOUR's arrays, over xGMI.  The table holds, per
+    // output array k (sigma11, sigma22, sigma12, u, v, then the diagnostics alpha, zeta_c, zeta_f, Delta) and direction d, the
+    // parent address that receives the image: low columns (1 .. H) are imaged beyond the high side of the WEST neighbour, high
+    // columns beyond the low side of the EAST one, rows likewise (S / N), corners diagonally.
+    enum : int { D_W = 0, D_E, D_S, D_N, D_SW, D_SE, D_NW, D_NE };
+    auto own = [&](int k) __attribute__((always_inline)) { return T->P[k < 5 ? FP_S11_OUT + k : FP_AL + (k - 5)]; };
+    // (direction-major: the bases of one direction are adjacent table entries -- one wide scalar load per row of an edge tile)
+    auto img = [&](int k, int d) __attribute__((always_inline)) { return PEER ? T->P[FP_IMG0 + d * 9 + k] : own(k); };
+    // PEER: the lanes of a wave that store x images all lie on one side of the tile (csi_abi.hip admits tiles of 128 columns or
+    // more), so the neighbour -- the base address -- is wave-uniform
+    const bool wave_low = PEER && __builtin_amdgcn_ballot_w64(((flags & L_LOW) != 0) & ((dx != 0) | (dxv != 0))) != 0;
+    auto put4 = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val, double valy, double valx, double valxy) __attribute__((always_inline)) {
+        const unsigned long base = own(k);
+        auto sti = [&](unsigned long b_, unsigned o_, double v_) __attribute__((always_inline)) {
+            if constexpr (PEER && (CSI_PEER_EXP & 2) != 0)
+                __scoped_atomic_store_n((__attribute__((address_space(1))) long*)((gptr_t)b_ + o_), __builtin_bit_cast(long, v_), __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+            else stg(b_, o_, v_);
+        };
         stg(base, off, val);
-        if (dy != 0u) stg(base, off + dy, valy);
+        if (dy != 0u) sti(PEER ? (ylow ? img(k, D_S) : img(k, D_N)) : base, off + dy, valy);
         if (wave_has_dx) {
             if (dxl != 0) {
-                stg(base, off + (unsigned)dxl, valx);
-                if (dy != 0u) stg(base, off + (unsigned)dxl + dy, valxy);
+                sti(PEER ? (wave_low ? img(k, D_W) : img(k, D_E)) : base, off + (unsigned)dxl, valx);
+                if (dy != 0u) sti(PEER ? (ylow ? (wave_low ? img(k, D_SW) : img(k, D_SE)) : (wave_low ? img(k, D_NW) : img(k, D_NE))) : base, off + (unsigned)dxl + dy, valxy);
             }
         }
     };
-    auto put = [&](unsigned long base, unsigned off, unsigned dy, int dxl, double val) __attribute__((always_inline)) {
-        put4(base, off, dy, dxl, val, val, val, val);
+    auto put = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val) __attribute__((always_inline)) {
+        put4(k, off, dy, ylow, dxl, val, val, val, val);
     };
     // u of row j: its y image is a reflection about 2 val on a ValueBoundaryCondition wall
-    auto put_u = [&](unsigned long base, unsigned off, int j, unsigned dy, double val) __attribute__((always_inline)) {
+    auto put_u = [&](unsigned off, int j, unsigned dy, double val) __attribute__((always_inline)) {
         double vy = val;
         if (WALLS) {
             if (uval_lo & ylo_wall & (j == 1)) vy = 2 * T->K[FK_BCU] - val;
             if (uval_hi & yhi_wall & (j == NyW)) vy = 2 * T->K[FK_BCU + 1] - val;
         }
-        put4(base, off, dy, dx, val, vy, val, vy);
+        put4(3, off, dy, j <= HyW, dx, val, vy, val, vy);
     };
-    auto put_v = [&](unsigned long base, unsigned off, unsigned dy, double val) __attribute__((always_inline)) {
+    auto put_v = [&](unsigned off, unsigned dy, bool ylow, double val) __attribute__((always_inline)) {
         double vx = val;
         if (WALLS && wave_valx) {
             if (flags & L_VAL_LO) vx = 2 * T->K[FK_BCV] - val;
             if (flags & L_VAL_HI) vx = 2 * T->K[FK_BCV + 1] - val;
         }
-        put4(base, off, dy, dxv, val, val, vx, vx);
+        put4(4, off, dy, ylow, dxv, val, val, vx, vx);
     };
     // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
     // store path (two scalar compares per row instead of the full bookkeeping)
@@ -342,11 +404,11 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                     if (which & 2) stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, vfirst);
                     if (which & 4) stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, vsecond);
                 } else {
-                    // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap; v
-                    // mirrors / reflects across an x wall), none of the row bookkeeping of the general path
-                    if (which & 1) { put(T->P[FP_S11_OUT], ocq, 0u, dx, v11); put(T->P[FP_S22_OUT], ocq, 0u, dx, v22); put(T->P[FP_S12_OUT], ofq, 0u, dx, v12); }
-                    if (AUF) { if (which & 2) put_v(T->P[FP_V_OUTP], ocq, 0u, vfirst); if (which & 4) put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vsecond, vsecond, vsecond, vsecond); }
-                    else { if (which & 2) put4(T->P[FP_U_OUTP], ofq - sf, 0u, dx, vfirst, vfirst, vfirst, vfirst); if (which & 4) put_v(T->P[FP_V_OUTP], ocq - sc, 0u, vsecond); }
+                    // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap / the
+                    // neighbouring tile's halo; v mirrors / reflects across an x wall), none of the row bookkeeping of the general path
+                    if (which & 1) { put(0, ocq, 0u, false, dx, v11); put(1, ocq, 0u, false, dx, v22); put(2, ofq, 0u, false, dx, v12); }
+                    if (AUF) { if (which & 2) put_v(ocq, 0u, false, vfirst); if (which & 4) put(3, ofq - sf, 0u, false, dx, vsecond); }
+                    else { if (which & 2) put(3, ofq - sf, 0u, false, dx, vfirst); if (which & 4) put_v(ocq - sc, 0u, false, vsecond); }
                 }
             }
             return;
@@ -358,20 +420,18 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         const unsigned ocq = offc(q), ofq = offf(q);
         const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
         const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
-        OutPtrs P;                                                // adjacent table slots: one wide scalar load
-        P.s11 = T->P[FP_S11_OUT]; P.s22 = T->P[FP_S22_OUT]; P.s12 = T->P[FP_S12_OUT]; P.u = T->P[FP_U_OUTP]; P.v = T->P[FP_V_OUTP];
         // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
         const int yq = yimg(q), y1 = AUF ? yimg(j1) : yimg_u(j1), y2 = AUF ? yimg_u(j2) : yimg(j2);
         if (do_s & ((flags & L_RS) != 0)) {
-            put(P.s11, ocq, (unsigned)yq * sc, dx, v11);
-            put(P.s22, ocq, (unsigned)yq * sc, dx, v22);
-            put(P.s12, ofq, (unsigned)yq * sf, dx, v12);
+            put(0, ocq, (unsigned)yq * sc, q <= HyW, dx, v11);
+            put(1, ocq, (unsigned)yq * sc, q <= HyW, dx, v22);
+            put(2, ofq, (unsigned)yq * sf, q <= HyW, dx, v12);
         }
         if (do_1 & ((flags & L_R1) != 0)) {
-            if (AUF) put_v(P.v, o1, (unsigned)y1 * sc, vfirst); else put_u(P.u, o1, j1, (unsigned)y1 * sf, vfirst);
+            if (AUF) put_v(o1, (unsigned)y1 * sc, j1 <= HyW, vfirst); else put_u(o1, j1, (unsigned)y1 * sf, vfirst);
         }
         if (do_2 & ((flags & L_R2) != 0)) {
-            if (AUF) put_u(P.u, o2, j2, (unsigned)y2 * sf, vsecond); else put_v(P.v, o2, (unsigned)y2 * sc, vsecond);
+            if (AUF) put_u(o2, j2, (unsigned)y2 * sf, vsecond); else put_v(o2, (unsigned)y2 * sc, j2 <= HyW, vsecond);
         }
     };
     // ring slot of row j (lane-private column): element f of row j sits at ring[((j - rstart) & 3) * 5 + f][lane]
@@ -609,10 +669,10 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             if (((flags & L_RS) != 0) & (q >= rs_lo) & (q <= rs_hi)) {
                 const unsigned ocq = offc(q), ofq = offf(q);
                 const int yq = yimg(q);
-                put(T->P[FP_AL], ocq, (unsigned)yq * sc, dx, B.AL_0);
-                put(T->P[FP_ZF], ofq, (unsigned)yq * sf, dx, 0.5 * B.zf);       // the stage carries 2 zeta
-                put(T->P[FP_ZC], ocq, (unsigned)yq * sc, dx, 0.5 * B.zc);
-                put(T->P[FP_DL], ocq, (unsigned)yq * sc, dx, B.Dc * B.rDc);         // ... and Delta^2, 1 / Delta
+                put(5, ocq, (unsigned)yq * sc, q <= HyW, dx, B.AL_0);
+                put(7, ofq, (unsigned)yq * sf, q <= HyW, dx, 0.5 * B.zf);       // the stage carries 2 zeta
+                put(6, ocq, (unsigned)yq * sc, q <= HyW, dx, 0.5 * B.zc);
+                put(8, ocq, (unsigned)yq * sc, q <= HyW, dx, B.Dc * B.rDc);         // ... and Delta^2, 1 / Delta
             }
         }
         B.shift(bu_p, bv_p, bm_0, ba_0);
@@ -627,6 +687,23 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         if (++r > rend) break;
     }
     __syncthreads();                                      // the last row's results are in the out ring: the producer drains them
+    if (PEER && pdirs) {
+        // this tile is done with launch seq: its images are stored (release at system scope) and its halo reads are complete
+        // (the producer's loads were consumed before its last barrier).  One lane per direction publishes seq in this tile's
+        // slot of that neighbour's flag array.
+        if (CSI_PEER_EXP & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: this wave's stores are in their -- possibly remote -- memory
+        if ((lane < 8) && ((pdirs >> lane) & 1u)) {
+            const int nW = T->I[FI_PSET], nE = T->I[FI_PSET + 1], nN = T->I[FI_PSET + 3];
+            const bool xw = (lane == D_W) | (lane == D_SW) | (lane == D_NW), xe = (lane == D_E) | (lane == D_SE) | (lane == D_NE);
+            const bool yn = (lane == D_N) | (lane == D_NW) | (lane == D_NE);
+            const int xs = xe ? strip - (nstrips - nE) : strip, xn = xw ? nW : (xe ? nE : nstrips);
+            const int ys = yn ? chunk - (nchunks - nN) : chunk;
+            typedef const __attribute__((address_space(4))) unsigned long* sptr_t;
+            unsigned long long* out = (unsigned long long*)((sptr_t)&T->P[FP_SLOT_OUT])[lane];
+            __hip_atomic_store(out + (ys * xn + xs), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     PROBE_END(w * 2 + 1);
 }
 
@@ -669,11 +746,13 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 // common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF; 2: zero ocean velocities); the
 // array-forcing variants have one instantiation (kinds read from the table)
 void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int common, int nstrips, int nchunks, int rows,
-                   int write_diag, int sel, hipStream_t s) {
+                   int write_diag, unsigned long long seq, hipStream_t s) {
     const int nblocks = nstrips * nchunks;              // one workgroup (producer wave + consumer wave) per tile
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(128);
-#define CSI_LAUNCH_PAIR_(U, A, C, F) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, sel)
+    // seq != 0: the instantiation with the peer-flag protocol (tiles next to a connected side wait for / signal their neighbours)
+#define CSI_LAUNCH_PAIR_(U, A, C, F) do { if (seq) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); \
+                                          else hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, false>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); } while (0)
 #if CSI_PAIR_VARIANT <= 2
 #define CSI_LAUNCH_PAIR(U, A) do { if (common == 2) CSI_LAUNCH_PAIR_(U, A, 2, false); else if (common) CSI_LAUNCH_PAIR_(U, A, 1, false); else CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #else
@@ -690,22 +769,22 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int c
 }
 
 #if CSI_PAIR_VARIANT == 0
-void launch_fused_pair_walls(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_force(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
-void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, int, hipStream_t);
+void launch_fused_pair_walls(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_mask(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_force(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_mask_force(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
-                       int common, int nstrips, int nchunks, int rows, int write_diag, int sel, hipStream_t s) {
+                       int common, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s) {
     if (metric == 2) walls = true;      // per-point coefficients: the general variants only (none built without walls)
-    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
-    else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
-    else if (force && mask) launch_fused_pair_mask_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
-    else if (force) launch_fused_pair_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
-    else if (mask) launch_fused_pair_mask(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
-    else if (walls) launch_fused_pair_walls(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
-    else launch_fused_pair_plain(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, sel, s);
+    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (force && mask) launch_fused_pair_mask_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (force) launch_fused_pair_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (mask) launch_fused_pair_mask(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (walls) launch_fused_pair_walls(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else launch_fused_pair_plain(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
 }
 #endif
 

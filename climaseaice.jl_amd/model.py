@@ -396,9 +396,10 @@ class SeaIceModel:
         """Tiles: exchange u, v halos of width 2k every k sub-steps (0 = automatic from the halo size)."""
         self.ctx.call("csi_set_exchange_interval", int(k))
 
-    def set_overlap(self, on=True):
-        """Tiles: run the halo exchange beside the tiles of the next launch that read no received cell (default off: slower)."""
-        self.ctx.call("csi_set_overlap", 1 if on else 0)
+    def set_halo_transport(self, kind):
+        """Tiles: "peer" (default) = peer-direct halo writes over xGMI with flags, one RCCL exchange per sub-cycle; "rccl" = the
+        k-batched ncclSend / ncclRecv exchange (include/csi.h, csi_set_halo_transport)."""
+        self.ctx.call("csi_set_halo_transport", {"rccl": 0, "peer": 1}[kind])
 
     def set_mask(self, active):
         """ImmersedBoundaryGrid stand-in: `active` is a (Ny, Nx) boolean array of wet cells of the WHOLE domain (for a

@@ -348,21 +348,30 @@ int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
  * (faster only around 3072^2). */
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
-/* Halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): the largest
- * k <= 16 the halo allows; k = 1: every sub-step (BASELINE.json's north star); the reference is the
- * k = substeps extreme (halo 2*substeps+3, split_explicit_momentum_equations.jl:51-64). */
+/* RCCL halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): automatic -- the peer
+ * transport below where it applies, else the largest k <= 16 the halo allows; k >= 1 selects the RCCL exchange with that
+ * interval (k = 1: every sub-step); the reference is the k = substeps extreme (halo 2*substeps+3,
+ * split_explicit_momentum_equations.jl:51-64). */
 int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 
-/* Exchange / compute overlap on tiles (default OFF: measured slower on MI355X, DESIGN.md section 5 -- the two-sub-steps kernel
- * fills every CU's register files, so the communication kernel does not run beside it, and the split launch pays its row
- * pipeline twice).  The halo exchange that is followed by a two-sub-steps launch runs its
- * grouped send / receive on a second, high-priority stream while the context stream launches the tiles that read no
- * received cell; the tiles that do are launched after the unpack.  Same tiles, same inputs: results are bit-identical with
- * the setting off.  (The reference needs no overlap: it never communicates inside the sub-cycle, at the price of a
- * 2 * substeps + 3 halo, split_explicit_momentum_equations.jl:51-64.)  csi_last_overlapped: how many exchanges of the last
- * sub-cycle ran that way. */
-int32_t csi_set_overlap(csi_context* ctx, int32_t on);
-int32_t csi_last_overlapped(csi_context* ctx);
+/* Halo transport of the sub-cycle on tiles (FAST mode, two sub-steps per launch, an even number of sub-steps).
+ * CSI_TRANSPORT_PEER (default): peer-direct halo writes over xGMI.  The neighbouring tiles' u, v, sigma (and alpha, zeta, Delta)
+ * arrays are mapped into this process (HIP IPC handles, exchanged once over the context's RCCL communicator); a connected side
+ * then behaves like a Periodic one whose halo lives on another GPU: the kernel that owns a cell next to the side stores its halo
+ * image straight into the neighbour's array, and per-tile flags in device memory order the launches of neighbouring ranks (only
+ * the tiles next to a connected side wait, the interior of a launch overlaps the neighbours' edges).  No pack / unpack kernels,
+ * no RCCL kernel inside the sub-cycle, no widened halo: the halo 4 of an untiled run suffices, and one RCCL exchange per
+ * sub-cycle remains (what BASELINE.json's north star asks for; the reference's own design is one exchange per sub-cycle with a
+ * 2 * substeps + 3 halo, split_explicit_momentum_equations.jl:51-64).  Needs tiles of equal shape and strides; set up
+ * collectively at the first sub-cycle (and again when bound arrays change -- bind on all ranks together); if any rank cannot
+ * (no IPC, unequal strides), every rank stays on RCCL.  A tile that waits 3 s for a neighbour gives up, the next csi_sync
+ * returns CSI_ERR_COMM.
+ * CSI_TRANSPORT_RCCL: pack -> grouped ncclSend / ncclRecv -> unpack of width-2k strips every k sub-steps
+ * (csi_set_exchange_interval); what every other path (three kernels, STRICT, odd sub-step counts) uses anyway.
+ * Both give results bit-identical to the untiled run.  csi_halo_transport: what the last sub-cycle used. */
+enum { CSI_TRANSPORT_RCCL = 0, CSI_TRANSPORT_PEER = 1 };
+int32_t csi_set_halo_transport(csi_context* ctx, int32_t kind);
+int32_t csi_halo_transport(csi_context* ctx, int32_t* kind);
 
 /* Index ranges (1-based, inclusive: i0, i1, j0, j1) the launch loop uses for a grid of this shape and
  * topology when `valid_width` (V >= 2) layers of u, v beyond the owned cells are valid on connected sides:

@@ -28,12 +28,14 @@ def main():
         c = cases.make_case(**kw)
         m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7),
                             device=f"cuda:{rank}", tile=(Rx, Ry, rank))
-        m.set_exchange_interval(k)
+        m.set_exchange_interval(max(k, 0))        # k = -1: automatic interval on the RCCL exchange; k = 0: the peer transport
+        if k < 0:
+            m.set_halo_transport("rccl")
         csi.time_step_momentum(m, c["dt"])
         m.synchronize()
         from test_gpu_evp import EVP_FIELDS
         res = {f"mom_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
-        res["path"] = np.array(json.dumps(m.ctx.last_path()))
+        res["path"] = np.array(json.dumps(dict(m.ctx.last_path(), transport=m.ctx.halo_transport())))
         csi.time_step(m, c["dt"])
         m.synchronize()
         res.update({f"step_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v")})

@@ -338,6 +338,7 @@ def test_rccl_self_exchange_bitwise(mode, fc, k):
     ref.set_fusion(False)
     csi.time_step_momentum(ref, c["dt"])
     til = cases.csi_model(c, mode=mode, tile=(1, 1, 0, fc))
+    til.set_halo_transport("rccl")
     til.set_exchange_interval(k)        # k sub-steps per exchange of width 2k (0: automatic = 2 with halo 4)
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
@@ -371,6 +372,7 @@ def test_pair_kernel_on_tiles_halo8(fc, k, nsub):
     ref.set_fusion(0)
     csi.time_step_momentum(ref, c["dt"])
     til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, fc))
+    til.set_halo_transport("rccl")
     til.set_exchange_interval(k)
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
@@ -428,6 +430,7 @@ def test_pair_kernel_on_tiles_halo16_auto_interval():
     ref.set_fusion(0)
     csi.time_step_momentum(ref, c["dt"])
     til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, True)))
+    til.set_halo_transport("rccl")
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
     path = til.ctx.last_path()
@@ -447,6 +450,7 @@ def test_pair_kernel_on_tiles_halo32_interval16(topo):
     ref.set_fusion(0)
     csi.time_step_momentum(ref, c["dt"])
     til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, topo[1] == "periodic")))
+    til.set_halo_transport("rccl")
     csi.time_step_momentum(til, c["dt"])
     ref.synchronize(); til.synchronize()
     path = til.ctx.last_path()
@@ -480,30 +484,80 @@ def test_three_substeps_per_launch_bitwise(Nx, Ny, H, kw, nsub):
         assert np.array_equal(out[0][k], out[3][k]), (k, np.abs(out[0][k] - out[3][k]).max())
 
 
-@pytest.mark.parametrize("topo,land", [(("periodic", "periodic"), 0.0), (("periodic", "bounded"), 0.2)])
-def test_exchange_compute_overlap_bitwise(topo, land):
-    """csi_set_overlap: the exchange that precedes a two-sub-steps launch runs on the communication stream beside the tiles
-    that read no received cell, the others follow the unpack.  Same tiles, same inputs: bit-identical with the setting off and
-    with the untiled three-kernel path; the overlapped exchanges are counted."""
-    c = cases.make_case(Nx=300, Ny=200, H=16, substeps=36, topo=topo, patches=True, random_uv=0.05, land=land)
+PEER_CASES = {
+    # (make_case keywords, which periodic directions are connected to the tile itself)
+    "periodic_xy": (dict(Nx=300, Ny=200, topo=("periodic", "periodic")), (True, True)),
+    "periodic_x": (dict(Nx=300, Ny=200, topo=("periodic", "periodic")), (True, False)),
+    "periodic_y": (dict(Nx=130, Ny=96, topo=("periodic", "periodic")), (False, True)),
+    "small_halo6": (dict(Nx=128, Ny=48, H=6, topo=("periodic", "periodic")), (True, True)),
+    "channel_land": (dict(Nx=300, Ny=200, topo=("periodic", "bounded"), land=0.2), (True, False)),
+    "channel_noslip": (dict(Nx=180, Ny=120, topo=("periodic", "bounded"), noslip=True), (True, False)),
+    "latlon_channel": (dict(Nx=150, Ny=128, topo=("periodic", "bounded"), grid="latlon"), (True, False)),
+    "coupled_arrays": (dict(Nx=200, Ny=150, topo=("periodic", "periodic"), field_forcing=True), (True, True)),
+    "free_drift_land": (dict(Nx=160, Ny=120, topo=("periodic", "bounded"), field_forcing=True, free_drift=True, land=0.25), (True, False)),
+    "curvilinear": (dict(Nx=136, Ny=96, topo=("periodic", "bounded"), curvilinear=0.04), (True, False)),
+    "beta_periodic_x": (dict(Nx=140, Ny=100, topo=("periodic", "bounded"), beta=2e-10), (True, False)),
+}
+
+
+@pytest.mark.parametrize("nsub", [2, 12, 120])
+@pytest.mark.parametrize("name", sorted(PEER_CASES))
+def test_peer_halo_transport_self_connected_bitwise(name, nsub):
+    """csi_set_halo_transport(PEER), the default on tiles: a connected side behaves like a periodic one whose halo lives in the
+    neighbour's arrays -- the owners' stores write the images there, per-tile flags order the launches (evp_fused2.hip).  Here
+    the neighbour is the tile itself (one GPU): same kernels, same flag protocol, every slot index exercised.  The whole parent
+    arrays -- halos included -- of u, v, sigma equal the untiled run bit for bit, and so do the interiors of alpha, zeta, Delta
+    against the three-kernel path; one RCCL exchange per sub-cycle remains."""
+    kw, fc = PEER_CASES[name]
+    c = cases.make_case(substeps=nsub, patches=True, random_uv=0.05, **kw)
+    three = cases.csi_model(c, mode="fast")
+    three.set_fusion(0)
+    csi.time_step_momentum(three, c["dt"])
+    ref = cases.csi_model(c, mode="fast")
+    csi.time_step_momentum(ref, c["dt"])
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, fc))
+    csi.time_step_momentum(til, c["dt"])
+    csi.time_step_momentum(til, c["dt"])       # a second sub-cycle: the launch numbers carry on
+    csi.time_step_momentum(ref, c["dt"])
+    csi.time_step_momentum(three, c["dt"])
+    three.synchronize(); ref.synchronize(); til.synchronize()
+    path = til.ctx.last_path()
+    assert til.ctx.halo_transport() == "peer" and path["level"] == 2 and path["exchanges"] == 1, path
+    assert ref.ctx.last_path()["level"] == 2
+    for f in ("u", "v", "s11", "s22", "s12"):
+        a, b = EVP_FIELDS[f](ref).numpy(), EVP_FIELDS[f](til).numpy()
+        assert np.array_equal(a, b), (f, "parents incl. halos", np.abs(a - b).max(), np.argwhere(a != b)[:5])
+    for f in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
+        a, b = EVP_FIELDS[f](three).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+
+
+def test_peer_halo_transport_falls_back_and_can_be_switched_off():
+    """Odd sub-step counts and explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the
+    peer transport off; all bit-identical."""
+    c = cases.make_case(Nx=120, Ny=72, H=8, substeps=13, topo=("periodic", "periodic"), patches=True, random_uv=0.05)
     ref = cases.csi_model(c, mode="fast")
     ref.set_fusion(0)
     csi.time_step_momentum(ref, c["dt"])
-    out = {}
-    for on in (False, True):
-        til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, topo[1] == "periodic")))
-        til.set_overlap(on)
-        csi.time_step_momentum(til, c["dt"])
+    ref.synchronize()
+    want = {f: EVP_FIELDS[f](ref).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, True)))
+    csi.time_step_momentum(til, c["dt"])                      # 13 sub-steps: odd
+    til.synchronize()
+    assert til.ctx.halo_transport() == "rccl"
+    for f in want:
+        assert np.array_equal(want[f], EVP_FIELDS[f](til).interior_numpy()), f
+    c2 = dict(c, substeps=12)
+    ref2 = cases.csi_model(c2, mode="fast"); ref2.set_fusion(0)
+    csi.time_step_momentum(ref2, c2["dt"]); ref2.synchronize()
+    for setup, expect in ((lambda m: None, "peer"), (lambda m: m.set_halo_transport("rccl"), "rccl"), (lambda m: m.set_exchange_interval(2), "rccl")):
+        til = cases.csi_model(c2, mode="fast", tile=(1, 1, 0, (True, True)))
+        setup(til)
+        csi.time_step_momentum(til, c2["dt"])
         til.synchronize()
-        path = til.ctx.last_path()
-        assert path["exchange_interval"] == 8 and path["level"] == 2 and path["exchanges"] == 5, path
-        assert til.ctx.last_overlapped() == (4 if on else 0)
-        out[on] = {f: EVP_FIELDS[f](til).numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
-        for f in ("u", "v", "s11", "s22", "s12", "alpha"):
-            a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
-            assert np.array_equal(a, b), (on, f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
-    for f in out[True]:
-        assert np.array_equal(out[False][f], out[True][f]), f      # halos included
+        assert til.ctx.halo_transport() == expect
+        for f in want:
+            assert np.array_equal(EVP_FIELDS[f](ref2).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()), (expect, f)
 
 
 EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear", "folded_tripolar", "coriolis_points_tripolar"})

@@ -39,8 +39,10 @@ def _record(name, entry):
     print(f"[fullsize] {name}: {entry}")
 
 
-def run_cycle(c, mode, fusion=None, tile=None, k=None):
+def run_cycle(c, mode, fusion=None, tile=None, k=None, transport=None):
     m = cases.csi_model(c, mode=mode, tile=tile)
+    if transport is not None:
+        m.set_halo_transport(transport)
     if fusion is not None:
         m.set_fusion(fusion)
     if k is not None:
@@ -165,13 +167,14 @@ def test_config4_latlon_rk3_step_fast_vs_strict():
     assert not np.array_equal(model_state(m0)["h"], res["fast"]["h"])
 
 
-@pytest.mark.parametrize("k", [16, 1])
+@pytest.mark.parametrize("k", [16, 1, 0])
 def test_config4_latlon_tile_bitwise(k):
-    """Config 4 on a tile: 2048^2 lat-lon channel (periodic x, walls in y) with bench.py's tile halo 32; the same RK3
-    step on a tile whose x edges are CONNECTED (RCCL exchange with itself: width 2k every k sub-steps, k = 16 as
-    bench.py runs it and k = 1 as BASELINE.json's north star states) equals the untiled run bit for bit."""
+    """Config 4 on a tile: 2048^2 lat-lon channel (periodic x, walls in y); the same RK3 step on a tile whose x edges are
+    CONNECTED equals the untiled run bit for bit -- with the RCCL exchange (to itself: width 2k every k sub-steps, halo 32,
+    k = 16 and k = 1) and with the peer transport (k = 0: halo 4, images stored straight into the neighbour's = its own arrays,
+    one RCCL exchange per sub-cycle)."""
     N = 2048
-    c = latlon_case(N, 32, ("periodic", "bounded"))
+    c = latlon_case(N, 32 if k else 4, ("periodic", "bounded"))
     ref = full_model(c, "fast")
     csi.time_step(ref, c["dt"])
     want = model_state(ref)
@@ -181,8 +184,11 @@ def test_config4_latlon_tile_bitwise(k):
     csi.time_step(til, c["dt"])
     got = model_state(til)
     path = til.ctx.last_path()
-    assert path["exchange_interval"] == k and path["level"] == (2 if k % 2 == 0 else 1), path
-    assert path["exchanges"] == (120 // k + (1 if 120 % k else 0)), path
+    if k == 0:
+        assert til.ctx.halo_transport() == "peer" and path["level"] == 2 and path["exchanges"] == 1, path
+    else:
+        assert path["exchange_interval"] == k and path["level"] == (2 if k % 2 == 0 else 1), path
+        assert path["exchanges"] == (120 // k + (1 if 120 % k else 0)), path
     for f in want:
         assert np.all(np.isfinite(got[f])), f
         assert np.array_equal(want[f], got[f]), (f, np.abs(want[f] - got[f]).max(), np.argwhere(want[f] != got[f])[:4])
@@ -227,12 +233,13 @@ def test_config5_masked_4096_500_substeps():
     _record("config5_4096", {"land_fraction": float(frac), "vmax": float(max(np.abs(pair['u']).max(), np.abs(pair['v']).max()))})
 
 
-def test_config5_tile_2048x1024_bitwise():
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_config5_tile_2048x1024_bitwise(transport):
     """Config 5's tile shape (4096^2 over 2 x 4 GPUs = 2048 x 1024 per tile) as a self-connected masked tile with the
     batched exchange, 120 sub-steps: owned cells equal the untiled run bit for bit."""
     c = cases.make_case(Nx=2048, Ny=1024, H=16, topo=("periodic", "bounded"), patches=True, random_uv=0.02, substeps=120, land=0.3)
     want, p1 = run_cycle(c, "fast", fusion=2)
-    got, p2 = run_cycle(c, "fast", tile=(1, 1, 0, (True, False)))
-    assert p1["level"] == 2 and p2["level"] == 2 and p2["exchange_interval"] == 8, (p1, p2)
+    got, p2 = run_cycle(c, "fast", tile=(1, 1, 0, (True, False)), transport=transport)
+    assert p1["level"] == 2 and p2["level"] == 2 and (p2["exchange_interval"] == 8 if transport == "rccl" else p2["exchanges"] == 1), (p1, p2)
     for f in want:
         assert np.array_equal(want[f], got[f]), (f, np.abs(want[f] - got[f]).max())

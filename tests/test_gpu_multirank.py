@@ -1,6 +1,8 @@
 """Real multi-rank RCCL runs (one process per GPU): tiled == untiled, bit for bit, on the owned cells of every tile.
+k = 1, 2: RCCL exchange every k sub-steps; k = -1: its automatic interval; k = 0: the default, peer-direct halo writes.
 Needs >= 2 visible GPUs; the gpurun boxes have one, so on those this module skips and the N > 1 logic is covered by the
-self-connected RCCL tests (test_gpu_evp.py) and the two-process gloo tests (test_tiles.py)."""
+self-connected tests (test_gpu_evp.py: RCCL and peer transport with the tile as its own neighbour) and the two-process gloo
+tests (test_tiles.py)."""
 import json
 import os
 import subprocess
@@ -31,7 +33,7 @@ def _run(world, Rx, Ry, kw, k, tmp_path):
 
 
 @pytest.mark.skipif(NGPU < 2, reason="needs at least 2 GPUs (one rank per GPU)")
-@pytest.mark.parametrize("k", [1, 2, 0])
+@pytest.mark.parametrize("k", [1, 2, -1, 0])
 @pytest.mark.parametrize("Rx,Ry", [(2, 1), (1, 2)] + ([(2, 2)] if NGPU >= 4 else []) + ([(2, 4)] if NGPU >= 8 else []))
 def test_multirank_rccl_tiles_bitwise(Rx, Ry, k, tmp_path):
     kw = dict(Nx=256, Ny=192, H=8, substeps=14, topo=("periodic", "bounded"), patches=True, random_uv=0.05)
@@ -48,6 +50,9 @@ def test_multirank_rccl_tiles_bitwise(Rx, Ry, k, tmp_path):
             "h": ref.ice_thickness.interior_numpy(), "a": ref.ice_concentration.interior_numpy()}
     for d in _run(Rx * Ry, Rx, Ry, kw, k, tmp_path):
         i0, j0, nx, ny = (int(x) for x in d["offsets"])
+        path = json.loads(str(d["path"]))
+        # k = 0: peer-direct halo writes over xGMI (IPC-mapped neighbours, flags); a fold keeps the three kernels and RCCL
+        assert path["transport"] == ("peer" if (k == 0 and Rx > 1) else "rccl"), path
         for f, want in mom.items():
             got = d[f"mom_{f}"][:ny, :nx]
             assert np.array_equal(got, want[j0:j0 + ny, i0:i0 + nx]), (f, Rx, Ry, k)
