@@ -359,21 +359,81 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
-    for _ in range(args.warmup):
+    def all_ranks(flag):
+        """logical AND over the ranks"""
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    # ---- N > 1: the same job on ONE GPU, in the same run: its answer (every rank advances the whole grid alone from the same
+    # state; its own tile must come out bit for bit) and, after the timed region, its rate (parallel_efficiency) -----------------
+    whole = None
+    gN = (nx_l * Rx, ny_l * Ry)
+    sig = ("s11", "s22", "s12")
+
+    def restart(m, fld):
+        csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
+        for name in sig:
+            getattr(m.dynamics.auxiliaries.fields, name).data.zero_()
+
+    def tile_matches_whole():
+        """One sub-cycle from the same state on the tiles and on the whole grid: owned cells bitwise equal (all ranks agree)."""
+        restart(whole, gf)
+        restart(model, f)
+        csi.time_step_momentum(whole, dt)
         csi.time_step_momentum(model, dt)
-    barrier()
+        model.synchronize(); whole.synchronize()
+        same = True
+        for name, tf, wf in [("u", model.velocities.u, whole.velocities.u), ("v", model.velocities.v, whole.velocities.v)] + \
+                            [(n, getattr(model.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in sig]:
+            mine = tf.interior_numpy()[:ny_l, :nx_l]
+            ref = wf.interior_numpy()[tg.j_off:tg.j_off + ny_l, tg.i_off:tg.i_off + nx_l]
+            same = same and bool(np.array_equal(mine, ref))
+        return same
+
+    verify = world > 1 and not args.no_verify
+    if verify:
+        gg = csi.RectilinearGrid(gN, x=(0.0, gN[0] * 2000.0), y=(0.0, gN[1] * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
+        whole = make_model(gg)
+        whole.set_fusion(0 if args.no_fusion else args.fusion_level)
+        gf = global_fields(np, nx_l, ny_l, Rx, Ry)
     transport_note = None
-    if tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
-            and not args.no_fusion and args.fusion_level >= 2 and model.ctx.halo_transport() != "peer":
-        # the library could not set the peer transport up (no IPC between these devices, ...): it said so by running RCCL; rebuild
-        # with the halo the RCCL exchange wants instead of timing its k = 2 fallback
-        transport_note = "peer transport unavailable on this node: RCCL exchange (halo 32, k = 16) timed instead"
-        sys.stderr.write("bench.py: " + transport_note + "\n")
-        model = None
-        tg, f, model, args.halo = build("rccl")
+    bitwise = None
+    peer_expected = tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
+        and not args.no_fusion and args.fusion_level >= 2 and nx_l >= 128
+    while True:
+        # warm-up, then (N > 1) the bitwise check -- before anything is timed.  A peer transport that cannot be set up (the library
+        # then runs RCCL by itself), times out or gives another answer than one GPU is replaced by the RCCL exchange on ALL ranks.
+        problem = None
+        try:
+            for _ in range(args.warmup):
+                csi.time_step_momentum(model, dt)
+            model.synchronize()
+            if peer_expected and model.ctx.halo_transport() != "peer":
+                problem = "the peer transport could not be set up on this node"
+            elif verify:
+                bitwise = tile_matches_whole()
+                if not bitwise:
+                    problem = "the tiled run did not reproduce the one-GPU run bit for bit"
+        except csi.CsiError as e:
+            problem = f"library error: {e}"
+        if all_ranks(problem is None):
+            break
+        if model.ctx.halo_transport() == "peer" or (peer_expected and transport_note is None):
+            transport_note = f"peer transport given up ({problem or 'another rank reported a problem'}): RCCL exchange (halo 32, k = 16) timed instead"
+            sys.stderr.write(f"bench.py[rank {rank}]: {transport_note}\n")
+            peer_expected = False
+            model = None
+            tg, f, model, args.halo = build("rccl")
+            continue
+        raise SystemExit(f"bench.py[rank {rank}]: invalid run: {problem or 'another rank reported a problem'}")
+    if verify:
+        restart(model, f)                                  # the timed steps start from the seeded state again
         for _ in range(max(args.warmup, 1)):
             csi.time_step_momentum(model, dt)
-        barrier()
+    barrier()
     # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
     # below is the last thing this process writes
     ctypes.CDLL(None).fflush(None)
@@ -483,55 +543,26 @@ def main():
             model.set_exchange_interval(args.exchange_interval)
         model = headline_model
 
-    # ---- N > 1: the same job on ONE GPU, in the same run -- its rate (for parallel_efficiency) and its answer (every rank
-    # advances the whole grid alone from the same state and compares the cells of its own tile bit for bit) ----------------
+    # ---- N > 1: the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported
     single = None
-    bitwise = None
     rccl_ranks = model.ctx.comm_count()
     if world > 1 and rccl_ranks != world:
         raise SystemExit(f"bench.py: {world} ranks but the library's RCCL communicator has {rccl_ranks}")
-    if world > 1 and not args.no_verify:
-        gN = (nx_l * Rx, ny_l * Ry)
-        gg = csi.RectilinearGrid(gN, x=(0.0, gN[0] * 2000.0), y=(0.0, gN[1] * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
-        whole = make_model(gg)
-        whole.set_fusion(0 if args.no_fusion else args.fusion_level)
-        gf = global_fields(np, nx_l, ny_l, Rx, Ry)
-        sig = ("s11", "s22", "s12")
-
-        def restart(m, fld):
-            csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
-            for name in sig:
-                getattr(m.dynamics.auxiliaries.fields, name).data.zero_()
-
+    if verify:
         restart(whole, gf)
-        restart(model, f)
-        csi.time_step_momentum(whole, dt)
-        csi.time_step_momentum(model, dt)
-        barrier()
-        whole.synchronize()
-        same = True
-        for name, tf, wf in [("u", model.velocities.u, whole.velocities.u), ("v", model.velocities.v, whole.velocities.v)] + \
-                            [(n, getattr(model.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in sig]:
-            mine = tf.interior_numpy()[:ny_l, :nx_l]
-            ref = wf.interior_numpy()[tg.j_off:tg.j_off + ny_l, tg.i_off:tg.i_off + nx_l]
-            same = same and bool(np.array_equal(mine, ref))
-        t = torch.tensor([1.0 if same else 0.0], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        bitwise = bool(t.item() > 0.5)
-        # the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 1)):
             csi.time_step_momentum(whole, dt)
         whole.synchronize(); torch.cuda.synchronize()
+        dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             csi.time_step_momentum(whole, dt)
         whole.synchronize(); torch.cuda.synchronize()
         e_single = time.perf_counter() - t0
         single = {"value": gN[0] * gN[1] * args.substeps * args.steps / e_single, "ms_per_step": 1e3 * e_single / args.steps,
-                  "grid": list(gN), "note": "the same global grid advanced by ONE GPU (rank 0) in this run, same kernels, halo 4"}
+                  "grid": list(gN), "note": "the same global grid advanced by ONE GPU (rank 0) in this run, same kernels, halo 4 "
+                                            "(every rank runs its own copy at the same time, each on its own GPU)"}
         whole = None
-        if not bitwise:
-            raise SystemExit("bench.py: the tiled run does not reproduce the one-GPU run bit for bit on the owned cells -- result invalid")
 
     out = {
         "metric": "EVP sub-cycle cell-updates/s", "value": value, "unit": "cell-updates/s",

@@ -215,7 +215,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                         }
                     }
                     if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
-                    if (wall_clock64() - t0 > 300000000ull) {            // 3 s at 100 MHz: give up loudly, never hang
+                    // 3 s at 100 MHz: give up loudly, never hang -- and once a wait has given up (the word stays set until the host
+                    // has reported it, csi_sync), none waits again: the sub-cycle is lost anyway
+                    if (wall_clock64() - t0 > 300000000ull || *(volatile unsigned*)T->P[FP_PERR] != 0u) {
                         if (lane == 0) *(volatile unsigned*)T->P[FP_PERR] = 1u;
                         break;
                     }

@@ -535,7 +535,7 @@ def test_peer_halo_transport_self_connected_bitwise(name, nsub):
 def test_peer_halo_transport_falls_back_and_can_be_switched_off():
     """Odd sub-step counts and explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the
     peer transport off; all bit-identical."""
-    c = cases.make_case(Nx=120, Ny=72, H=8, substeps=13, topo=("periodic", "periodic"), patches=True, random_uv=0.05)
+    c = cases.make_case(Nx=136, Ny=72, H=8, substeps=13, topo=("periodic", "periodic"), patches=True, random_uv=0.05)
     ref = cases.csi_model(c, mode="fast")
     ref.set_fusion(0)
     csi.time_step_momentum(ref, c["dt"])
