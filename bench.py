@@ -495,18 +495,28 @@ def main():
             "substep_ms": sub_ms}
     ctr = counters()
     if ctr and world == 1 and not tiled and (nx_l, ny_l) == (2048, 2048) and args.mode == "fast" and ctr.get("kernel") == dom:
+        # PMC evidence of a committed rocprofv3 run of this kernel (scripts/same_lease_profile.sh): bytes and instruction counts per
+        # launch are properties of the kernel; FRACTIONS of a roof need a time, and only this run's own clock is used for that --
+        # and only when this box runs the kernel as fast as the box the counters were taken on (within 5 %), otherwise the
+        # fractions are withheld rather than mixed across machines
         roof["traffic"] = ctr.get("hbm_bytes_per_launch")
-        roof["traffic_source"] = ctr.get("source", "profiles/counters_latest.json") + " (rocprofv3 --pmc passes of an earlier run of this kernel; not re-measured by bench.py)"
-        if ctr.get("hbm_bytes_per_launch"):
-            roof["traffic_frac"] = ctr["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBS
-        # second roof: FP64 vector issue.  valu_frac = share of the SIMDs' VALU issue time the launch used, from the
-        # same committed counter passes: SQ_ACTIVE_INST_VALU (quad-cycles, summed over SIMDs) x 4 / (1024 SIMDs x
-        # GRBM_GUI_ACTIVE / 8 XCDs); every wave64 VALU instruction, FP64 arithmetic or move, occupies its SIMD 4 cycles
-        if ctr.get("valu_busy_frac") is not None:
-            roof["valu_frac"] = ctr["valu_busy_frac"]
-            roof["valu_insts_per_launch"] = ctr.get("valu_insts_per_launch")
-            roof["valu_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), committed PMC pass; the launch time is the "
-                                 "kernel's HBM traffic at the bandwidth of its marching access pattern (DESIGN.md section 3)")
+        roof["traffic_source"] = ctr.get("source", "profiles/counters_latest.json") + " (rocprofv3 --pmc passes; bytes per launch of this kernel, not re-measured by bench.py)"
+        ref_us = (ctr.get("same_lease_bench") or {}).get("avg_launch_us") or ctr.get("avg_launch_us")
+        same_speed = ref_us is not None and abs(launch_s * 1e6 - ref_us) <= 0.05 * ref_us
+        roof["counters_run_launch_us"] = ref_us
+        roof["counters_run_matches_this_box"] = bool(same_speed)
+        if same_speed:
+            if ctr.get("hbm_bytes_per_launch"):
+                roof["traffic_frac"] = ctr["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBS
+            # second roof: FP64 vector issue.  valu_frac = share of the SIMDs' VALU issue time the launch used, from the
+            # same counter passes: SQ_ACTIVE_INST_VALU (quad-cycles, summed over SIMDs) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+            if ctr.get("valu_busy_frac") is not None:
+                roof["valu_frac"] = ctr["valu_busy_frac"]
+                roof["valu_insts_per_launch"] = ctr.get("valu_insts_per_launch")
+                roof["valu_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), PMC pass of the counters' run"
+        else:
+            roof["traffic_note"] = (f"this box runs the kernel in {launch_s * 1e6:.1f} us per launch, the counters' run took {ref_us:.1f} us: "
+                                    "traffic_frac / valu_frac withheld (not the same speed)")
     model_days_per_hr = None
     if not args.no_full_step:
         nfull = 2
