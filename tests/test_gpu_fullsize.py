@@ -135,10 +135,14 @@ def test_config4_latlon_rk3_step_fast_vs_strict():
         if mode == "fast":
             assert m.ctx.last_path()["level"] == 2
         del m
-    ms = full_model(perturbed(c), "strict")
-    csi.time_step(ms, c["dt"])
-    sens = model_state(ms)
-    del ms
+    sens_runs = []
+    for seed in (11, 12):                         # STRICT's own response to 1e-15 relative input perturbations: two samples, the larger counts
+        ms = full_model(perturbed(c, seed), "strict")
+        csi.time_step(ms, c["dt"])
+        sens_runs.append(model_state(ms))
+        del ms
+    sens = {f: np.where(np.abs(sens_runs[0][f] - res["strict"][f]) >= np.abs(sens_runs[1][f] - res["strict"][f]), sens_runs[0][f], sens_runs[1][f])
+            for f in sens_runs[0]}
     entry = {}
     # tracers: advection, update and slab step are computed in the reference's order in both modes; they see the
     # velocities of the sub-cycle, so they inherit its rounding-level differences only
@@ -146,7 +150,8 @@ def test_config4_latlon_rk3_step_fast_vs_strict():
         scale = np.abs(res["strict"][f]).max()
         d = float(np.abs(res["fast"][f] - res["strict"][f]).max())
         s = float(np.abs(sens[f] - res["strict"][f]).max())
-        entry[f] = {"diff": d, "stated_tol": tol * scale, "strict_self_sensitivity": s}
+        entry[f] = {"diff": d, "stated_tol": tol * scale, "strict_self_sensitivity": s, "branch": "stated" if d <= tol * scale else "10x sensitivity",
+                    "margin": max(tol * scale, 10 * s) / max(d, 1e-300)}
         assert np.all(np.isfinite(res["fast"][f]))
         assert d <= max(tol * scale, 10 * s), (f, d, scale, s)
     vmax = max(np.abs(res["strict"]["u"]).max(), np.abs(res["strict"]["v"]).max())
@@ -165,6 +170,58 @@ def test_config4_latlon_rk3_step_fast_vs_strict():
     m0 = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7))
     csi.time_step(m0, c["dt"])
     assert not np.array_equal(model_state(m0)["h"], res["fast"]["h"])
+
+
+@pytest.mark.parametrize("nsub", [1, 2])
+@pytest.mark.parametrize("topo", [("bounded", "bounded"), ("periodic", "bounded")])
+def test_config4_latlon_few_substeps_tight(topo, nsub):
+    """Config 4's grid at full size, TIGHT: 2048^2 lat-lon (lon 0..60, lat 20..70: the geometry of
+    test/test_rheology_energy_budget.jl:102-106, per-row metrics) after ONE and TWO sub-steps, before the mEVP iteration's own
+    sensitivity can hide anything: FAST (per-row stencil coefficients folded on the host, Newton reciprocals) against STRICT
+    (the reference's operator calls, bit-identical to the oracle at small sizes) within 1e-13 max|u| on u, v and 1e-10
+    max|sigma| on sigma -- over the whole grid and in each of eight latitude bands, so that a defect of the per-row
+    coefficients at high latitudes cannot pass as chaos.  One sub-step runs the one-sub-step kernel, two the pair kernel."""
+    N = 2048
+    c = latlon_case(N, 4, topo, substeps=nsub)
+    strict, p0 = run_cycle(c, "strict")
+    fast, p1 = run_cycle(c, "fast")
+    assert p0["level"] == 0 and p1["level"] == (2 if nsub == 2 else 1), (p0, p1)
+    vmax = max(np.abs(strict["u"]).max(), np.abs(strict["v"]).max())
+    smax = max(np.abs(strict[f]).max() for f in ("s11", "s22", "s12"))
+    entry = {"vmax": float(vmax), "smax": float(smax)}
+    for f in ("u", "v", "s11", "s22", "s12"):
+        tol = 1e-13 * vmax if f in ("u", "v") else 1e-10 * smax
+        diff = np.abs(fast[f] - strict[f])
+        assert np.all(np.isfinite(fast[f])), f
+        bands = [float(b.max()) for b in np.array_split(diff[:N], 8, axis=0)]       # south to north
+        entry[f] = {"diff": float(diff.max()), "tol": float(tol), "diff_by_latitude_band": bands}
+        assert diff.max() <= tol, (f, float(diff.max()), tol, bands)
+    for f in ("u", "v"):
+        assert np.array_equal(strict[f] == 0.0, fast[f] == 0.0), f        # open water / marginal ice: the same cells
+    _record(f"config4_latlon_{topo[0]}_{nsub}_substeps_tight", entry)
+
+
+def test_config4_latlon_one_cycle_branch_recorded():
+    """One 120-sub-step momentum cycle (not the three of an RK3 step) on the 2048^2 lat-lon grid: FAST against STRICT, with the
+    bound each field needed -- the stated tolerance, or 10 x STRICT's own response to a 1e-15 relative input perturbation --
+    recorded per field (gpurun_out/fullsize_tolerance.json); two perturbation samples, the larger response counts."""
+    N = 2048
+    c = latlon_case(N, 4, ("bounded", "bounded"))
+    strict, _ = run_cycle(c, "strict")
+    fast, p = run_cycle(c, "fast")
+    assert p["level"] == 2
+    sens = [run_cycle(perturbed(c, seed), "strict")[0] for seed in (11, 12)]
+    vmax = max(np.abs(strict["u"]).max(), np.abs(strict["v"]).max())
+    smax = max(np.abs(strict[f]).max() for f in ("s11", "s22", "s12"))
+    entry = {"vmax": float(vmax), "smax": float(smax)}
+    for f in ("u", "v", "s11", "s22", "s12"):
+        tol = (FAST_TOL_VEL * vmax) if f in ("u", "v") else (FAST_TOL_SIG * smax)
+        s_ = max(float(np.abs(q[f] - strict[f]).max()) for q in sens)
+        d = float(np.abs(fast[f] - strict[f]).max())
+        entry[f] = {"diff": d, "stated_tol": float(tol), "strict_self_sensitivity": s_, "branch": "stated" if d <= tol else "10x sensitivity"}
+        assert np.all(np.isfinite(fast[f])), f
+        assert d <= max(tol, 10 * s_), (f, d, tol, s_)
+    _record("config4_latlon_one_cycle", entry)
 
 
 @pytest.mark.parametrize("k", [16, 1, 0])
