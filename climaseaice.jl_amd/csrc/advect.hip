@@ -8,12 +8,18 @@
 //   k_tracer_step _dynamic_step_tracers!               sea_ice_fe_step.jl:56-82
 //                 (RK3: h^n, aice^n = Psi^-, sea_ice_rk_substep.jl:140-149)
 //
-// This translation unit is compiled with -ffp-contract=off and keeps the oracle's expression
-// order, so both arithmetic modes give bit-identical tracer tendencies.  Each thread owns one
+// This translation unit is compiled with -ffp-contract=off.  STRICT mode keeps the oracle's expression order and IEEE
+// divisions: bit-identical tracer tendencies.  FAST mode (round 3) evaluates the SAME reconstructions -- same stencils,
+// same smoothness indicators, same WENO-Z weights per tracer, same order reduction -- with the divisions by constants as
+// multiplications, the four or five true divisions of a reconstruction as hardware reciprocal + one Newton step (fm::rcp,
+// <= 11 ulp) and fused multiply-adds: a WENO7 reconstruction is ~150 instead of ~450 instructions (nine IEEE divisions of
+// ~35 instructions each were two thirds of it).  Stated tolerance: |dG| <= 1e-13 max|G| on the tendencies, 1e-13 relative on
+// h, aice after a step (measured ~1e-16); masks, zero sets and the order-reduction decisions are the same code.  Each thread owns one
 // face pair (west, south) of its cell: fluxes are computed once, shared with the east / north
 // neighbours through LDS, so every face flux is evaluated exactly once per tile interior.
 #include "csi_dev.h"
 #include "csi_kernels.h"
+#include "evp_fast_math.h"
 
 namespace csi {
 // Julia's max(a, b) for floats: NaN if either is NaN
@@ -78,6 +84,75 @@ __device__ __forceinline__ double weno3(const double* p) {
 }
 __device__ __forceinline__ double upwind3(const double* p) { return (-p[0] + 5 * p[1] + 2 * p[2]) / 6; }
 
+// ---- FAST-mode reconstructions (see the header).  The smoothness indicators and tau are evaluated EXACTLY as in STRICT mode
+// (same order, no contraction): they are small differences of O(c^2) terms, and a rounding-level change of their evaluation
+// moves the nonlinear weights by ~1e-9 relative (measured: tendencies 7e-13 of max|G| apart with contracted indicators,
+// against ~1e-15 with these).  Candidate polynomials, weights and the final combination are contracted; divisions are
+// reciprocals (fm::rcp: hardware seed + one Newton step) or multiplications by constants.
+__device__ __forceinline__ double weno3_fast(const double* p) {
+    const double b0 = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
+    const double b1 = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
+    const double tau = fabs(b0 - b1);
+    {
+#pragma clang fp contract(fast)
+        const double q0 = 0.5 * (p[1] + p[2]);
+        const double q1 = 0.5 * (3 * p[1] - p[0]);
+        const double r0 = tau * fm::rcp(b0 + WENO_EPS), r1 = tau * fm::rcp(b1 + WENO_EPS);
+        const double a0 = (2.0 / 3) * (1 + r0 * r0);
+        const double a1 = (1.0 / 3) * (1 + r1 * r1);
+        return (a0 * q0 + a1 * q1) * fm::rcp(a0 + a1);
+    }
+}
+__device__ __forceinline__ double upwind3_fast(const double* p) {
+#pragma clang fp contract(fast)
+    return (5 * p[1] + 2 * p[2] - p[0]) * (1.0 / 6);
+}
+__device__ __forceinline__ double weno5_fast(const double* p) {
+    const double b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
+    const double b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
+    const double b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
+    const double tau = fabs(b0 - b2);
+    {
+#pragma clang fp contract(fast)
+        const double q0 = (2 * p[2] + 5 * p[3] - p[4]) * (1.0 / 6);
+        const double q1 = (5 * p[2] + 2 * p[3] - p[1]) * (1.0 / 6);
+        const double q2 = (2 * p[0] - 7 * p[1] + 11 * p[2]) * (1.0 / 6);
+        const double r0 = tau * fm::rcp(b0 + WENO_EPS), r1 = tau * fm::rcp(b1 + WENO_EPS), r2 = tau * fm::rcp(b2 + WENO_EPS);
+        const double a0 = (3.0 / 10) * (1 + r0 * r0);
+        const double a1 = (3.0 / 5) * (1 + r1 * r1);
+        const double a2 = (1.0 / 10) * (1 + r2 * r2);
+        return (a0 * q0 + a1 * q1 + a2 * q2) * fm::rcp(a0 + a1 + a2);
+    }
+}
+__device__ __forceinline__ double upwind5_fast(const double* p) {
+#pragma clang fp contract(fast)
+    return (2 * p[0] - 13 * p[1] + 47 * p[2] + 27 * p[3] - 3 * p[4]) * (1.0 / 60);
+}
+__device__ __forceinline__ double weno7_fast(const double* p) {
+    const double b0 = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
+                      p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
+    const double b1 = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
+                      p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
+    const double b2 = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
+                      p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
+    const double b3 = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
+                      p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
+    const double tau = fabs(b0 + 3 * b1 - 3 * b2 - b3);
+    {
+#pragma clang fp contract(fast)
+        const double q0 = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) * (1.0 / 12);
+        const double q1 = (7 * p[3] + 7 * p[4] - p[2] - p[5]) * (1.0 / 12);
+        const double q2 = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) * (1.0 / 12);
+        const double q3 = (13 * p[1] - 3 * p[0] - 23 * p[2] + 25 * p[3]) * (1.0 / 12);
+        const double r0 = tau * fm::rcp(b0 + WENO_EPS), r1 = tau * fm::rcp(b1 + WENO_EPS), r2 = tau * fm::rcp(b2 + WENO_EPS), r3 = tau * fm::rcp(b3 + WENO_EPS);
+        const double a0 = (4.0 / 35) * (1 + r0 * r0);
+        const double a1 = (18.0 / 35) * (1 + r1 * r1);
+        const double a2 = (12.0 / 35) * (1 + r2 * r2);
+        const double a3 = (1.0 / 35) * (1 + r3 * r3);
+        return (a0 * q0 + a1 * q1 + a2 * q2 + a3 * q3) * fm::rcp(a0 + a1 + a2 + a3);
+    }
+}
+
 // Boundary-order reduction next to walls (upstream topologically_conditional_interpolation, recalled -- SURVEY.md
 // App. B; same rule as oracle/csi_oracle.c::reduced_buffer): the scheme with buffer B (order 2B-1) is used at face
 // idx only if its biased stencil stays inside the domain, else the buffer scheme of order 2B-3, down to upwind 1.
@@ -107,7 +182,7 @@ __device__ __forceinline__ int reduced_buffer_immersed(const GridDev& g, int B, 
 // reconstruct at a face from the line of values through `base` (cell on the high side of the
 // face); st = element stride of the line; left bias (vel > 0): upwind cell is base - st.
 // B: buffer of the scheme to use at this face (after the boundary-order reduction).
-template <int SCHEME>
+template <int SCHEME, bool FAST = false>
 __device__ __forceinline__ double reconstruct(const double* base, long st, bool left, int B) {
     const double* up = left ? base - st : base;
     const long s = left ? st : -st;
@@ -118,18 +193,18 @@ __device__ __forceinline__ double reconstruct(const double* base, long st, bool 
         double p[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) p[k] = up[(k - 1) * s];
-        return WENO ? weno3(p) : upwind3(p);
+        return WENO ? (FAST ? weno3_fast(p) : weno3(p)) : (FAST ? upwind3_fast(p) : upwind3(p));
     }
     if (B == 3 || SCHEME != 7) {
         double p[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) p[k] = up[(k - 2) * s];
-        return WENO ? weno5(p) : upwind5(p);
+        return WENO ? (FAST ? weno5_fast(p) : weno5(p)) : (FAST ? upwind5_fast(p) : upwind5(p));
     }
     double p[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) p[k] = up[(k - 3) * s];
-    return weno7(p);
+    return FAST ? weno7_fast(p) : weno7(p);
 }
 // buffer at face (i, j) of the x / y direction: immersed grid -> the immersed rule (it covers the walls: cells beyond
 // them are inactive); else the topological rule next to walls; else the full scheme
@@ -146,54 +221,46 @@ __device__ __forceinline__ int buffer_at(const GridDev& g, int i, int j, bool al
 
 constexpr int TX = 64, TY = 4;
 
-// One thread per cell of a (TX+1) x (TY+1) flux tile: the extra column / row holds the east /
-// north faces of the tile.  Fx[i] = Ax u c~ at the west face of cell i, Fy[j] at the south face.
-template <int SCHEME>
-__global__ void __launch_bounds__((TX + 1) * (TY + 1) <= 512 ? 512 : 1024) k_tendencies(AdvDev A) {
-    __shared__ double sFxh[TY + 1][TX + 2], sFxa[TY + 1][TX + 2], sFyh[TY + 1][TX + 2], sFya[TY + 1][TX + 2];
-    __shared__ double sFxs[TY + 1][TX + 2], sFys[TY + 1][TX + 2];      // snow thickness, the third tracer (has_snow)
+// One thread per cell AND TRACER of a (TX+1) x (TY+1) flux tile (threadIdx.z: h, aice [, snow thickness]): the extra column /
+// row holds the east / north faces of the tile.  Fx[i] = Ax u c~ at the west face of cell i, Fy[j] at the south face.  (Round 3:
+// the tracers used to share a thread -- four WENO7 reconstructions behind 28 dependent loads; at 512^2 the launch lasts as long
+// as one block, so halving the chain per thread is what shortens it.)
+template <int SCHEME, bool FAST>
+__global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
+    __shared__ double sFx[3][TY + 1][TX + 2], sFy[3][TY + 1][TX + 2];
     const GridDev& g = A.g;
-    const int tx = threadIdx.x, ty = threadIdx.y;          // tx in [0, TX], ty in [0, TY]
+    const int tx = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;          // tx in [0, TX], ty in [0, TY], tz: tracer
     const int i = 1 + blockIdx.x * TX + tx, j = 1 + blockIdx.y * TY + ty;
     const bool in_x = i <= g.Nx + 1, in_y = j <= g.Ny + 1;
+    const FRef& c = tz == 0 ? A.h : (tz == 1 ? A.a : A.hs);
     if (in_x && in_y) {
         // x-face flux (needed for ty < TY rows), y-face flux (needed for tx < TX columns)
         if (ty < TY && j <= g.Ny) {
             const double uu = A.u(i, j);
             const bool left = uu > 0;
             const int B = buffer_at<SCHEME>(g, i, j, false, left);
-            const double ch = reconstruct<SCHEME>(&A.h(i, j), 1, left, B);
-            const double ca = reconstruct<SCHEME>(&A.a(i, j), 1, left, B);
+            const double cc = reconstruct<SCHEME, FAST>(&c(i, j), 1, left, B);
             const bool closed = g.has_mask && peripheral_u(g, i, j);          // conditional_flux_fcc
             const double ax = dym(g, LOC_F, LOC_C, i, j);                    // Ax^{fcc} = dy^{fcc} * dz
-            sFxh[ty][tx] = closed ? 0.0 : ax * uu * ch;
-            sFxa[ty][tx] = closed ? 0.0 : ax * uu * ca;
-            if (A.has_snow) sFxs[ty][tx] = closed ? 0.0 : ax * uu * reconstruct<SCHEME>(&A.hs(i, j), 1, left, B);
+            sFx[tz][ty][tx] = closed ? 0.0 : ax * uu * cc;
         }
         if (tx < TX && i <= g.Nx) {
             const double vv = A.v(i, j);
             const bool left = vv > 0;
             const int B = buffer_at<SCHEME>(g, i, j, true, left);
-            const double ch = reconstruct<SCHEME>(&A.h(i, j), A.h.ld, left, B);
-            const double ca = reconstruct<SCHEME>(&A.a(i, j), A.a.ld, left, B);
+            const double cc = reconstruct<SCHEME, FAST>(&c(i, j), c.ld, left, B);
             const double dxf = dxm(g, LOC_C, LOC_F, i, j);                   // Ay^{cfc} = dx^{cfc} * dz
             const bool closed = g.has_mask && peripheral_v(g, i, j);          // conditional_flux_cfc
-            sFyh[ty][tx] = closed ? 0.0 : dxf * vv * ch;
-            sFya[ty][tx] = closed ? 0.0 : dxf * vv * ca;
-            if (A.has_snow) sFys[ty][tx] = closed ? 0.0 : dxf * vv * reconstruct<SCHEME>(&A.hs(i, j), A.hs.ld, left, B);
+            sFy[tz][ty][tx] = closed ? 0.0 : dxf * vv * cc;
         }
     }
     __syncthreads();
     if (tx < TX && ty < TY && i <= g.Nx && j <= g.Ny) {
         const double V = azm(g, LOC_C, LOC_C, i, j);
-        const double fxh = sFxh[ty][tx + 1] - sFxh[ty][tx], fyh = sFyh[ty + 1][tx] - sFyh[ty][tx];
-        const double fxa = sFxa[ty][tx + 1] - sFxa[ty][tx], fya = sFya[ty + 1][tx] - sFya[ty][tx];
-        A.Gh(i, j) = -(1 / V * (fxh + fyh));
-        A.Ga(i, j) = -(1 / V * (fxa + fya));
-        if (A.has_snow) {            // compute_snow_advection_tendency!, tracer_tendency_kernel_functions.jl:49-52
-            const double fxs = sFxs[ty][tx + 1] - sFxs[ty][tx], fys = sFys[ty + 1][tx] - sFys[ty][tx];
-            A.Ghs(i, j) = -(1 / V * (fxs + fys));
-        }
+        const double fx = sFx[tz][ty][tx + 1] - sFx[tz][ty][tx], fy = sFy[tz][ty + 1][tx] - sFy[tz][ty][tx];
+        const double rV = FAST ? fm::rcp(V) : 1 / V;
+        const FRef& G = tz == 0 ? A.Gh : (tz == 1 ? A.Ga : A.Ghs);         // (snow: compute_snow_advection_tendency!, tracer_tendency_kernel_functions.jl:49-52)
+        G(i, j) = -(rV * (fx + fy));
     }
 }
 
@@ -228,18 +295,22 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
 
 }  // namespace adv
 
-void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
-    (void)mode;
-    dim3 b(adv::TX + 1, adv::TY + 1);
+template <bool FAST>
+static void launch_tendencies_mode(const AdvDev& A, hipStream_t s) {
+    dim3 b(adv::TX + 1, adv::TY + 1, A.has_snow ? 3 : 2);
     dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY - 1) / adv::TY));
     switch (A.scheme) {
-        case 1: hipLaunchKernelGGL(adv::k_tendencies<1>, gr, b, 0, s, A); break;
-        case 3: hipLaunchKernelGGL(adv::k_tendencies<3>, gr, b, 0, s, A); break;
-        case -3: hipLaunchKernelGGL(adv::k_tendencies<-3>, gr, b, 0, s, A); break;
-        case 5: hipLaunchKernelGGL(adv::k_tendencies<5>, gr, b, 0, s, A); break;
-        case -5: hipLaunchKernelGGL(adv::k_tendencies<-5>, gr, b, 0, s, A); break;
-        default: hipLaunchKernelGGL(adv::k_tendencies<7>, gr, b, 0, s, A); break;
+        case 1: hipLaunchKernelGGL((adv::k_tendencies<1, FAST>), gr, b, 0, s, A); break;
+        case 3: hipLaunchKernelGGL((adv::k_tendencies<3, FAST>), gr, b, 0, s, A); break;
+        case -3: hipLaunchKernelGGL((adv::k_tendencies<-3, FAST>), gr, b, 0, s, A); break;
+        case 5: hipLaunchKernelGGL((adv::k_tendencies<5, FAST>), gr, b, 0, s, A); break;
+        case -5: hipLaunchKernelGGL((adv::k_tendencies<-5, FAST>), gr, b, 0, s, A); break;
+        default: hipLaunchKernelGGL((adv::k_tendencies<7, FAST>), gr, b, 0, s, A); break;
     }
+}
+// mode: CSI_MODE_STRICT (0) the oracle's arithmetic, bit for bit; CSI_MODE_FAST (1) reciprocals and contraction (header)
+void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
+    if (mode == 1) launch_tendencies_mode<true>(A, s); else launch_tendencies_mode<false>(A, s);
 }
 void launch_tracer_step(const AdvDev& A, hipStream_t s) {
     dim3 b(64, 4);

@@ -1652,13 +1652,26 @@ int32_t csi_cache_current_fields(csi_context* c) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     int32_t rc = need(c, {CSI_F_H, CSI_F_A, CSI_F_HM, CSI_F_AM});
     if (rc) return rc;
-    if ((rc = copy_parent(c, CSI_F_HM, CSI_F_H))) return rc;
-    if ((rc = copy_parent(c, CSI_F_AM, CSI_F_A))) return rc;
-    if (c->f[CSI_F_HS].p && c->f[CSI_F_HSM].p && (rc = copy_parent(c, CSI_F_HSM, CSI_F_HS))) return rc;
+    // Psi^- = the prognostic fields, whole parents, in one launch
+    CopyBatch B{};
+    B.aligned16 = 1;
+    auto add = [&](int dst, int src) -> int32_t {
+        const Bound &d = c->f[dst], &q = c->f[src];
+        if (d.ld != q.ld || d.nj != q.nj) return fail(c, CSI_ERR_INVALID_ARGUMENT, std::string("parent shape mismatch: ") + kName[dst] + " vs " + kName[src]);
+        B.src[B.count] = q.p; B.dst[B.count] = d.p; B.n[B.count] = (long)d.ld * d.nj; ++B.count;
+        if ((((uintptr_t)q.p) | ((uintptr_t)d.p)) & 15) B.aligned16 = 0;
+        return CSI_OK;
+    };
+    if ((rc = add(CSI_F_HM, CSI_F_H))) return rc;
+    if ((rc = add(CSI_F_AM, CSI_F_A))) return rc;
+    if (c->f[CSI_F_HS].p && c->f[CSI_F_HSM].p && (rc = add(CSI_F_HSM, CSI_F_HS))) return rc;
     if (c->f[CSI_F_U].p && c->f[CSI_F_UM].p) {
-        if ((rc = copy_parent(c, CSI_F_UM, CSI_F_U))) return rc;
-        if ((rc = copy_parent(c, CSI_F_VM, CSI_F_V))) return rc;
+        if ((rc = need(c, {CSI_F_V, CSI_F_VM}))) return rc;
+        if ((rc = add(CSI_F_UM, CSI_F_U))) return rc;
+        if ((rc = add(CSI_F_VM, CSI_F_V))) return rc;
     }
+    launch_copy_batch(B, c->stream);
+    HIP_TRY(c, hipGetLastError());
     return CSI_OK;
 }
 

@@ -80,6 +80,32 @@ void launch_fill_halo_batch(const HaloBatch& B, const GridDev& g, hipStream_t s)
     }
 }
 
+// cache_current_fields! (sea_ice_rk_substep.jl:29-42): whole parents of up to five fields copied by ONE launch (at 512^2 five
+// hipMemcpyAsync launches of 2 MB each cost 25 us of an 87 us step); blockIdx.y selects the pair, 16-byte accesses.
+__global__ void __launch_bounds__(256) k_copy_batch(CopyBatch B) {
+    const double* __restrict__ src = B.src[blockIdx.y];
+    double* __restrict__ dst = B.dst[blockIdx.y];
+    const long n = B.n[blockIdx.y];
+    const long stride = (long)gridDim.x * blockDim.x * 2;
+    for (long t = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; t < n; t += stride) {
+        if (t + 1 < n && B.aligned16) {
+            *reinterpret_cast<double2*>(dst + t) = *reinterpret_cast<const double2*>(src + t);
+        } else {
+            dst[t] = src[t];
+            if (t + 1 < n) dst[t + 1] = src[t + 1];
+        }
+    }
+}
+void launch_copy_batch(const CopyBatch& B, hipStream_t s) {
+    if (B.count <= 0) return;
+    long nmax = 0;
+    for (int k = 0; k < B.count; ++k) nmax = B.n[k] > nmax ? B.n[k] : nmax;
+    unsigned gx = (unsigned)((nmax / 2 + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_copy_batch, dim3(gx, (unsigned)B.count), dim3(256), 0, s, B);
+}
+
 // mask_immersed_field_xy!(field, k = Nz), sea_ice_model.jl:381-389: zero at peripheral nodes of an
 // immersed grid (no-op without a mask).
 __global__ void k_mask(FRef f, GridDev g, int kind) {
