@@ -120,6 +120,8 @@ struct csi_context {
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
     double* fd[2] = {nullptr, nullptr};     // free-drift velocities at u / v points (StressBalanceFreeDrift)
+    double* xd[2] = {nullptr, nullptr};     // stress divergence of the immersed flux boundary conditions at u / v points (two-sub-steps kernel)
+    size_t xd_elems[2] = {0, 0};
     size_t fd_elems[2] = {0, 0};
     int free_drift = 0;                     // csi_free_drift_set
     size_t fbar_elems[2] = {0, 0};
@@ -869,6 +871,29 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         vbar_u.p = c->fbar[1] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[1]->ld; vbar_u.ld = (int)src[1]->ld;
         launch_forcing_bars(P, ubar_v, vbar_u, c->stream);
     }
+    // model.forcing arrays / immersed flux boundary conditions (the EXTRA instantiations of the pair kernel): the divergence of
+    // the immersed fluxes is a function of the mask and the metrics only -- once per sub-cycle into two arrays
+    const bool extra = P.extra != 0;
+    FRef xd_u{nullptr, 0}, xd_v{nullptr, 0};
+    if (extra && P.g.has_mask) {
+        bool any_ibc = false;
+        for (int q = 0; q < 4; ++q) any_ibc |= (P.ibc_u[q] != 0.0) | (P.ibc_v[q] != 0.0);
+        if (any_ibc) {
+            const Bound* src[2] = {&c->f[CSI_F_U], &c->f[CSI_F_V]};
+            for (int q = 0; q < 2; ++q) {
+                const size_t n = (size_t)src[q]->ld * (size_t)src[q]->nj;
+                if (c->xd_elems[q] != n) {
+                    if (c->xd[q]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); hipFree(c->xd[q]); c->xd[q] = nullptr; }
+                    HIP_TRY(c, hipMalloc((void**)&c->xd[q], n * sizeof(double)));
+                    HIP_TRY(c, hipMemsetAsync(c->xd[q], 0, n * sizeof(double), c->stream));
+                    c->xd_elems[q] = n;
+                }
+            }
+            xd_u.p = c->xd[0] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[0]->ld; xd_u.ld = (int)src[0]->ld;
+            xd_v.p = c->xd[1] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[1]->ld; xd_v.ld = (int)src[1]->ld;
+            launch_immersed_div(P, xd_u, xd_v, c->stream);
+        }
+    }
     const int kb = tiled ? k : (pairs ? 2 : 1);             // batch length: positions 0 .. kb-1
     FRef orig[5], alt[5];
     for (int q = 0; q < 5; ++q) { orig[q] = ref_of(c, kPing[q]); alt[q] = alt_ref(c, q); }
@@ -926,6 +951,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
                         if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
+                        if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, GP[mp], cur == 0, t))) return rc;
                     }
             }
@@ -965,7 +991,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             const int mp = m / 2;
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
+                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
                               peer ? ++c->peer.seq : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             m += 2; s += 2;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
@@ -1384,6 +1410,7 @@ int32_t csi_context_destroy(csi_context* c) {
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
     for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
     for (int k = 0; k < 2; ++k) if (c->fd[k]) hipFree(c->fd[k]);
+    for (int k = 0; k < 2; ++k) if (c->xd[k]) hipFree(c->xd[k]);
     if (c->dev_tables) hipFree(c->dev_tables);
     if (c->sendbuf) hipFree(c->sendbuf);
     if (c->recvbuf) hipFree(c->recvbuf);

@@ -40,6 +40,7 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
              FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_FD_U, FP_FD_V,
              FP_FROW_U, FP_FROW_V,      // CSI_METRIC_FULL: per-row Coriolis parameter (device pointers, ptr[j] = row j)
              FP_F2U, FP_F2V,            // ... per-point Coriolis planes (parent addresses)
+             FP_XC_U, FP_XC_V, FP_XD_U, FP_XD_V,   // EXTRA: model.forcing arrays; immersed-flux-BC stress divergence arrays (parent addresses)
              FP_C2_0,
              // halo images of the two-sub-steps kernel: for each of 9 arrays (sigma11, sigma22, sigma12, u, v, alpha, zeta_c, zeta_f, Delta)
              // and 8 directions (W E S N SW SE NW NE) the parent address of the array that receives the image -- the array itself
@@ -54,6 +55,7 @@ enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_
              FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX,
              FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_FREE_DRIFT,
              FI_C2_LD, FI_FKIND,        // CSI_METRIC_FULL: leading dimension of the coefficient / Coriolis planes; f kind 0 number, 1 rows, 2 points
+             FI_EXTRA,                  // EXTRA instantiations: bit 0 model.forcing arrays, bit 1 immersed flux boundary conditions
              FI_PEER,                   // 1: peer-connected sides (flags instead of a halo exchange, evp_fused2.hip)
              FI_PSET, FI_PMASK = FI_PSET + 4,   // tile sets next to the W / E / S / N side: strips, strips, chunks, chunks; directions with a neighbour
              FI_PWAIT, FI_COUNT = FI_PWAIT + 8 };   // slots to wait for per direction (= the size of the neighbour's opposite set)
@@ -79,8 +81,11 @@ void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
                            const ImageSpec& ims12, FusedTable* host_table);
 // seq: launch number of the peer-flag protocol (0 on grids without peer-connected sides)
-void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
+// extra: model.forcing arrays / immersed flux boundary conditions (the EXTRA instantiations; implies force)
+void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, bool extra,
                        int common_forcing, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s);
+// stress divergence of the immersed FluxBoundaryConditions at every u / v point whose stencil stays inside the parents (evp_fast.hip)
+void launch_immersed_div(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, hipStream_t s);
 // array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported;
 // StressBalanceFreeDrift (P.free_drift: free-drift velocity arrays P.ufd / P.vfd) also selects the FORCE variant
 int pair_forcing_kind(const EvpDev& P);
@@ -88,6 +93,7 @@ int pair_forcing_kind(const EvpDev& P);
 // (ubar at v points from fu, vbar at u points from fv), once per sub-cycle (evp_fast.hip)
 void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s);
 void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, FusedTable* host_table);
+void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* host_table);
 
 // halo / masks / copies (halo.hip)
 void launch_fill_halo(const FRef& f, const GridDev& g, const ImageSpec& im, hipStream_t s);

@@ -357,6 +357,22 @@ __global__ void __launch_bounds__(256) k_forcing_bars(FRef fu, FRef fv, FRef uba
     if (has_u) ubar_v(i, j) = fm::avg4(fu(i, j - 1), fu(i + 1, j - 1), fu(i, j), fu(i + 1, j));
 }
 
+// the stress divergence of the immersed FluxBoundaryConditions (csi_dev.h immersed_div_sigma_1 / _2: the reference's operation
+// order) at every u / v point, once per sub-cycle: the two-sub-steps kernel adds the stored numbers where the three kernels
+// evaluate the functions -- the same bits
+__global__ void __launch_bounds__(256) k_immersed_div(EvpDev P, FRef xd_u, FRef xd_v, Range r) {
+    const int i = r.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), j = r.j0 + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+    if (i > r.i1 || j > r.j1) return;
+    xd_u(i, j) = immersed_div_sigma_1(P, i, j);
+    xd_v(i, j) = immersed_div_sigma_2(P, i, j);
+}
+void launch_immersed_div(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, hipStream_t s) {
+    const GridDev& g = P.g;
+    const Range r{2 - g.Hx, g.Nx + g.Hx - 1, 2 - g.Hy, g.Ny + g.Hy - 1};      // (one cell inside the parents: the 2 x 2 stencils)
+    dim3 b(64, 4);
+    hipLaunchKernelGGL(k_immersed_div, dim3((unsigned)((r.i1 - r.i0 + 64) / 64), (unsigned)((r.j1 - r.j0 + 4) / 4)), b, 0, s, P, xd_u, xd_v, r);
+}
+
 void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s) {
     const StressDev& b = P.bot;
     if (b.kind != 3 || (b.ue_kind != 2 && b.ve_kind != 2)) return;

@@ -296,7 +296,9 @@ static bool fused_offsets_fit(const EvpDev& P) {
     return ld * nj * 8 < (1L << 32);
 }
 int pair_forcing_kind(const EvpDev& P) {
-    if (P.extra || P.g.yhi == SIDE_FOLD) return -1;           // model.forcing arrays / immersed flux BCs / north fold: three kernels
+    if (P.g.yhi == SIDE_FOLD) return -1;                      // north fold: three kernels
+    if (P.extra && P.free_drift) return -1;                   // (no instantiation with both)
+    if (P.extra && P.has_forcing && (P.forcing_u.ld != P.u.ld || P.forcing_v.ld != P.h.ld)) return -1;
     const int lc = P.h.ld, lf = P.u.ld;
     if (P.a.ld != lc || P.P.ld != lc || P.s11.ld != lc || P.s22.ld != lc || P.v.ld != lc || P.vn.ld != lc) return -1;
     if (P.un.ld != lf || P.s12.ld != lf) return -1;
@@ -310,7 +312,15 @@ int pair_forcing_kind(const EvpDev& P) {
     if (t_arr && (t.fu.ld != lf || t.fv.ld != lc)) return -1;
     if (b_arr && ((b.ue_kind == 2 && b.fu.ld != lf) || (b.ve_kind == 2 && b.fv.ld != lc))) return -1;
     if (P.free_drift && (P.ufd.ld != lf || P.vfd.ld != lc)) return -1;
-    return (t_arr || b_arr || P.free_drift) ? 1 : 0;
+    return (t_arr || b_arr || P.free_drift || P.extra) ? 1 : 0;
+}
+
+void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* t) {
+    const GridDev& g = P.g;
+    int bits = 0;
+    if (P.has_forcing) { bits |= 1; t->P[FP_XC_U] = parent_addr(P.forcing_u, g); t->P[FP_XC_V] = parent_addr(P.forcing_v, g); }
+    if (xd_u.p && xd_v.p) { bits |= 2; t->P[FP_XD_U] = parent_addr(xd_u, g); t->P[FP_XD_V] = parent_addr(xd_v, g); }
+    t->I[FI_EXTRA] = bits;
 }
 
 void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, FusedTable* t) {

@@ -94,7 +94,7 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, bool EXTRA = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool PRE = CSI_PAIR_PRE && !MASK;
@@ -266,12 +266,17 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         F.t_tau_v = T->K[FK_TOP_TAU_V]; F.t_we_v = T->K[FK_TOP_VE]; F.t_wb_v = T->K[FK_TOP_UE];
         F.b_tau_v = T->K[FK_BOT_TAU_V]; F.b_we_v = T->K[FK_BOT_VE]; F.b_wb_v = T->K[FK_BOT_UE];
         F.fd_u = 0.0; F.fd_v = 0.0; F.fd = FD;
+        F.xc_u = 0.0; F.xd_u = 0.0; F.xc_v = 0.0; F.xd_v = 0.0; F.extra = EXTRA ? T->I[FI_EXTRA] : 0;
     };
     auto arrays = [&](Forcing& F, unsigned ou, unsigned ov) __attribute__((always_inline)) {
         if (T->I[FI_TOP_KIND] == 2) { F.t_tau_u = ldg(T->P[FP_FT_U], ou); F.t_tau_v = ldg(T->P[FP_FT_V], ov); }
         if (T->I[FI_BOT_UEK] == 2) { F.b_we_u = ldg(T->P[FP_FB_U], ou); F.b_wb_v = ldg(T->P[FP_FB_UBAR], ov); }   // u_e: own component at u points, averaged to v points
         if (T->I[FI_BOT_VEK] == 2) { F.b_we_v = ldg(T->P[FP_FB_V], ov); F.b_wb_u = ldg(T->P[FP_FB_VBAR], ou); }   // v_e: own component at v points, averaged to u points
         if (FD) { F.fd_u = ldg(T->P[FP_FD_U], ou); F.fd_v = ldg(T->P[FP_FD_V], ov); }                             // StressBalanceFreeDrift (once per sub-cycle, csi_abi.hip)
+        if (EXTRA) {
+            if (F.extra & 1) { F.xc_u = ldg(T->P[FP_XC_U], ou); F.xc_v = ldg(T->P[FP_XC_V], ov); }              // model.forcing.u / .v
+            if (F.extra & 2) { F.xd_u = ldg(T->P[FP_XD_U], ou); F.xd_v = ldg(T->P[FP_XD_V], ov); }              // immersed flux boundary conditions
+        }
     };
     auto stress_consts = [&](fm::StressConst& ks) __attribute__((always_inline)) {
         ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
@@ -719,7 +724,7 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 
 // One translation unit per variant so that the instantiations compile in parallel.  CSI_PAIR_VARIANT:
 // 0 plain, 1 walls, 2 walls + immersed mask, 3 walls + array-valued forcing, 4 walls + mask + array-valued forcing,
-// 5 / 6: 3 / 4 with StressBalanceFreeDrift (free-drift velocity arrays).
+// 5 / 6: 3 / 4 with StressBalanceFreeDrift (free-drift velocity arrays); 7 / 8: 3 / 4 with model.forcing arrays / immersed flux BCs.
 #ifndef CSI_PAIR_VARIANT
 #define CSI_PAIR_VARIANT 0
 #endif
@@ -741,9 +746,20 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 #elif CSI_PAIR_VARIANT == 5
 #define CSI_PAIR_NAME launch_fused_pair_force_fd
 #define CSI_PAIR_FLAGS true, false, true, true
-#else
+#elif CSI_PAIR_VARIANT == 6
 #define CSI_PAIR_NAME launch_fused_pair_mask_force_fd
 #define CSI_PAIR_FLAGS true, true, true, true
+#elif CSI_PAIR_VARIANT == 7      // 7 / 8: 3 / 4 with model.forcing arrays and / or immersed flux boundary conditions (EXTRA)
+#define CSI_PAIR_NAME launch_fused_pair_force_x
+#define CSI_PAIR_FLAGS true, false, true, false
+#define CSI_PAIR_EXTRA true
+#else
+#define CSI_PAIR_NAME launch_fused_pair_mask_force_x
+#define CSI_PAIR_FLAGS true, true, true, false
+#define CSI_PAIR_EXTRA true
+#endif
+#ifndef CSI_PAIR_EXTRA
+#define CSI_PAIR_EXTRA false
 #endif
 // common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF; 2: zero ocean velocities); the
 // array-forcing variants have one instantiation (kinds read from the table)
@@ -753,8 +769,8 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int c
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(128);
     // seq != 0: the instantiation with the peer-flag protocol (tiles next to a connected side wait for / signal their neighbours)
-#define CSI_LAUNCH_PAIR_(U, A, C, F) do { if (seq) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); \
-                                          else hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, false>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); } while (0)
+#define CSI_LAUNCH_PAIR_(U, A, C, F) do { if (seq) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, true, CSI_PAIR_EXTRA>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); \
+                                          else hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, false, CSI_PAIR_EXTRA>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); } while (0)
 #if CSI_PAIR_VARIANT <= 2
 #define CSI_LAUNCH_PAIR(U, A) do { if (common == 2) CSI_LAUNCH_PAIR_(U, A, 2, false); else if (common) CSI_LAUNCH_PAIR_(U, A, 1, false); else CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #else
@@ -777,10 +793,14 @@ void launch_fused_pair_force(const FusedTable*, int, bool, int, int, int, int, i
 void launch_fused_pair_mask_force(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
 void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
 void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
-void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift,
+void launch_fused_pair_force_x(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_mask_force_x(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, bool extra,
                        int common, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s) {
     if (metric == 2) walls = true;      // per-point coefficients: the general variants only (none built without walls)
-    if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    if (extra && mask) launch_fused_pair_mask_force_x(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (extra) launch_fused_pair_force_x(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
     else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
     else if (force && mask) launch_fused_pair_mask_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
     else if (force) launch_fused_pair_force(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);

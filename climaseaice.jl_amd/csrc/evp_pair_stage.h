@@ -15,6 +15,11 @@ struct Forcing {
     // StressBalanceFreeDrift: velocity of marginal ice at the u / v point being updated (fd: enabled, wave-uniform)
     double fd_u, fd_v;
     bool fd;
+    // EXTRA instantiations: model.forcing.u / .v at the point (xc: added to the Coriolis term, sum_of_forcing_u / _v of
+    // elasto_visco_plastic_rheology.jl:391-401) and the stress divergence of the immersed FluxBoundaryConditions at the point
+    // (xd: added to d_j sigma_ij, ice_stress_divergence.jl:65-123; evaluated once per sub-cycle into library arrays)
+    double xc_u, xd_u, xc_v, xd_v;
+    int extra;           // bit 0: xc present, bit 1: xd present (0 in every other instantiation: the terms vanish at compile time)
 };
 
 struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; };
@@ -218,6 +223,8 @@ struct Stage {
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
                 else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                if (F.extra & 1) cor += F.xc_u;
+                if (F.extra & 2) div += F.xd_u;
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
                            : fm::vel_update_sum(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -236,6 +243,8 @@ struct Stage {
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2 - s2, j) * ubar;
                 else cor = -coef<UNI>(T, FC_FV, j) * ubar;
+                if (F.extra & 1) cor += F.xc_v;
+                if (F.extra & 2) div += F.xd_v;
                 second = F.fd ? fm::vel_update_sum_fd(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
                               : fm::vel_update_sum(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
@@ -257,6 +266,8 @@ struct Stage {
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2, r) * ubar;
                 else cor = -coef<UNI>(T, FC_FV, r) * ubar;
+                if (F.extra & 1) cor += F.xc_v;
+                if (F.extra & 2) div += F.xd_v;
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
                            : fm::vel_update_sum(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -275,6 +286,8 @@ struct Stage {
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
                 else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                if (F.extra & 1) cor += F.xc_u;
+                if (F.extra & 2) div += F.xd_u;
                 second = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
                               : fm::vel_update_sum(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }

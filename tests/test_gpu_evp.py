@@ -99,8 +99,10 @@ CASES = {
                                          immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)), user_forcing=True),
 }
 MASKED = {"curvilinear_periodic", "curvilinear_bounded", "curvilinear_masked", "coriolis_points_curvilinear", "noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
-          "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}   # rare tendency terms: never fused
+          "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip",
+          # round 3: model.forcing arrays and immersed flux boundary conditions (the EXTRA instantiations of the pair kernel)
+          "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}      # configurations only the pair kernel fuses
+THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar"}   # the north fold: never fused
 
 
 def ulp_diff(a, b):
@@ -560,7 +562,7 @@ def test_peer_halo_transport_falls_back_and_can_be_switched_off():
             assert np.array_equal(EVP_FIELDS[f](ref2).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()), (expect, f)
 
 
-EXTRA_CASES = sorted(THREE_KERNEL_ONLY - {"immersed_flux_bc_curvilinear", "folded_tripolar", "coriolis_points_tripolar"})
+EXTRA_CASES = ["folded_uniform", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"]
 FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
