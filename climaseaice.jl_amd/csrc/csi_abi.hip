@@ -902,7 +902,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     // under the one-sub-step kernel) agree in both.  A fully periodic, untiled grid advanced by pair launches only
     // rewrites every cell of the five parents -- interior and all halo images -- at every launch: no copy needed.
     const bool every_cell_written = pairs && !tiled && !has_walls(c) && (substeps % 2 == 0 || (trio_supported(c, P) && substeps >= 2));
-    if (!every_cell_written)
+    if (!every_cell_written && !peer)                      // (peer: run_fused_peer has made the copy, BEFORE its exchange)
         for (int q = 0; q < 5; ++q) {
             const Bound& b = c->f[kPing[q]];
             HIP_TRY(c, hipMemcpyAsync(c->alt[q], b.p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1050,6 +1050,14 @@ int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int subste
     int32_t rc;
     FRef orig[5];
     for (int q = 0; q < 5; ++q) orig[q] = ref_of(c, kPing[q]);
+    // Both ping-pong buffers start identical where no launch ever writes (cells beyond walls).  The copy comes BEFORE the
+    // exchange: once a neighbour has received this rank's message it may start its first launch, whose halo images land in this
+    // rank's second buffer -- they must not be overwritten by a copy that is still on its way.  (Halos beyond connected sides
+    // need no copy: the neighbours' images rewrite all H layers at every launch.)
+    if ((rc = ensure_alt(c))) return rc;
+    if (has_walls(c))
+        for (int q = 0; q < 5; ++q)
+            HIP_TRY(c, hipMemcpyAsync(c->alt[q], c->f[kPing[q]].p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     const int W = std::min(std::min(c->Hx, c->Hy), 4);
     if ((rc = exchange_refs(c, orig, 5, W))) return rc;
     struct Swap {

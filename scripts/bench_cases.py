@@ -19,6 +19,9 @@ CONFIGS = {
     "coupled periodic (arrays, no land)": dict(topo=("periodic", "periodic"), field_forcing=True),
     "OMIP style (arrays, 30 % land, StressBalanceFreeDrift; test/distributed_tests_utils.jl:190-212)":
         dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True),
+    "model.forcing arrays (periodic)": dict(topo=("periodic", "periodic"), user_forcing=True),
+    "immersed flux boundary conditions (channel, 30 % land)": dict(topo=("periodic", "bounded"), land=0.3,
+                                                                     immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))),
     "beta-plane channel (per-row f on uniform metrics)": dict(topo=("periodic", "bounded"), beta=1.6e-11),
     "no-slip channel with 30 % land (coastline-example style)": dict(topo=("periodic", "bounded"), land=0.3, noslip=True),
     "curvilinear channel (twelve 2-D metric arrays, CSI_METRIC_FULL)": dict(topo=("periodic", "bounded"), curvilinear=0.05),
