@@ -105,10 +105,12 @@ def build(force=False):
 
 
 def lib(omp=False):
-    key = "omp" if omp else "serial"
+    """omp = False: the strict-order checker; True: the same with OpenMP over rows; "tuned": -O3 / AVX2 / contraction allowed
+    (bench.py's second CPU figure only -- never a parity reference)."""
+    key = "tuned" if omp == "tuned" else ("omp" if omp else "serial")
     if key not in _lib_cache:
         build()
-        name = "libcsi_oracle_omp.so" if omp else "libcsi_oracle.so"
+        name = {"tuned": "libcsi_oracle_omp_tuned.so", "omp": "libcsi_oracle_omp.so", "serial": "libcsi_oracle.so"}[key]
         L = C.CDLL(os.path.join(_HERE, name))
         P = C.POINTER(ProblemStruct)
         dbl = C.c_double
