@@ -1126,12 +1126,13 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // three kernels inside run_fused)
     const int pfk = pair_forcing_kind(P);
     const bool pair_only = P.g.has_mask || pfk == 1 || c->metric_kind == CSI_METRIC_FULL;      // configurations only the two-sub-steps kernel takes
-    const bool fuse = fast && c->fusion && substeps > 0 &&
-                      (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
-                                 : fused_supported(P));
+    // the peer halo transport (tiles) needs none of the RCCL batching constraints (an even exchange interval): decide it first
+    bool peer = false;
+    if (fast && c->fusion && substeps > 0 && (rc = peer_decide(c, P, substeps, &peer))) return rc;
+    const bool fuse = peer || (fast && c->fusion && substeps > 0 &&
+                               (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
+                                          : fused_supported(P)));
     if (fuse) {
-        bool peer = false;
-        if ((rc = peer_decide(c, P, substeps, &peer))) return rc;
         c->peer.last = peer ? 1 : 0;
         if ((rc = peer ? run_fused_peer(c, dt, fc, substeps, first) : run_fused(c, P, fc, substeps, first))) return rc;
         c->timed = true;
