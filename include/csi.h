@@ -53,9 +53,19 @@ typedef enum {
     CSI_LEFT_CONNECTED = 3,   /* low side exchanged, high side Bounded */
     CSI_RIGHT_CONNECTED = 4,  /* low side Bounded, high side exchanged */
     /* y direction of a TripolarGrid: low side Bounded (the southernmost latitude), high side the north FOLD filled by the
-     * Zipper boundary condition (sea_ice_model.jl:57-64: u, v change sign across the fold, every other field does not;
-     * upstream fold semantics recalled in SURVEY.md App. B / oracle/csi_oracle.c fold_north).  x must be Periodic (or, on
-     * tiles, not partitioned: the reference's own distributed tripolar test uses Partition(1, 4),
+     * Zipper boundary condition.  Sign: fields at the velocity points -- (Face, Center) and (Center, Face): u, v, the stress /
+     * ocean-velocity / forcing arrays there, u^n, v^n -- change sign across the fold (sea_ice_model.jl:57-64 for u, v;
+     * test/distributed_tests_utils.jl:196-197 builds the others with the same conditions), every (Center, Center) and
+     * (Face, Face) field does not.  Pivot: the ONE variant implemented has the fold running through the cell CENTRES of row
+     * Ny (Oceananigans' RightCenterFolded / LeftConnectedRightCenterFolded, the names the reference imports at
+     * split_explicit_momentum_equations.jl:7-16): c[i, Ny + j] = s c[i', Ny - j] for Center-in-y fields (row Ny is stored
+     * twice and its two copies are NOT symmetrised: they evolve independently, as in a fill that only writes halos),
+     * s c[i', Ny - j + 1] for Face-in-y fields, i' = Nx - i + 1 (Center in x) / Nx - i + 2 (Face in x; column 1 maps onto itself
+     * without the sign change).  The F-point pivot (RightFaceFolded) is not implemented.  STATUS: these fill semantics are
+     * RECALLED from the un-vendored Oceananigans, restated three times here (oracle/csi_oracle.c fold_north,
+     * grids.fold_north, the HIP store images) and checked against each other only -- no reference-run fixture exists; run
+     * bench/reference_driver.jl on a tripolar case before relying on them.  x must be Periodic (or, on
+     * tiles, unpartitioned: the reference's own distributed tripolar test partitions y only,
      * test/distributed_tests_utils.jl:239).  The fused kernels do not take folds: three-kernel paths. */
     CSI_RIGHT_FOLDED = 5,
     CSI_LEFT_CONNECTED_RIGHT_FOLDED = 6   /* the northernmost tile of a y partition of such a grid */

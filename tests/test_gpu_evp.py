@@ -652,6 +652,13 @@ def test_fused_paths_fuzz_bitwise(seed):
     if kw["coriolis"] is not None and topo[1] == "bounded" and rng.integers(3) == 0:
         kw["beta"] = 2e-10 if kw["grid"] == "rectilinear" else 1e-6
     nsub = int(rng.integers(2, 12))
+    if seed >= 20000:            # (round 3; earlier seeds keep their configurations) model.forcing arrays, immersed flux boundary conditions
+        if rng.integers(4) == 0:
+            kw["user_forcing"] = True
+        if kw["land"] and rng.integers(4) == 0:
+            kw["immersed_bc"] = ((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))
+        if kw.get("user_forcing") or kw.get("immersed_bc"):
+            kw.pop("free_drift", None)
     c = cases.make_case(substeps=nsub, **kw)
     out = {}
     lvl = {}
