@@ -659,6 +659,7 @@ constexpr int kPeerRecs = csi_context::Peer::NARR + 1;      // + the flag array
 // Failure anywhere (no IPC, strides that differ across a side, sets larger than the flag array) makes EVERY rank stay on RCCL.
 int32_t peer_setup(csi_context* c) {
     csi_context::Peer& pr = c->peer;
+    HIP_TRY(c, hipSetDevice(c->device));                   // (allocations and IPC mappings below belong to the context's device)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     peer_release(c);
     const int me = c->tile.ry * c->tile.Rx + c->tile.rx;
