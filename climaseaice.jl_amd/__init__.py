@@ -14,6 +14,7 @@ from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitu
                     OrthogonalCurvilinearGrid, Periodic, LeftConnectedRightFolded, RightFolded, fold_north,
                     RectilinearGrid, RightConnected, TileGrid)
 from .model import (FieldBoundaryConditions, FluxBoundaryCondition, ImmersedBoundaryCondition, MeltingConstrainedFluxBalance, ValueBoundaryCondition, PrescribedTemperature, SeaIceModel, SlabThermodynamics, SnowSlabThermodynamics,
-                    snow_slab_thermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state)
+                    snow_slab_thermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state,
+                    prognostic_state, restore_prognostic_state)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

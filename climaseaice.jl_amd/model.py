@@ -467,6 +467,47 @@ def update_state(model):
     model.ctx.call("csi_update_state")
 
 
+def _state_fields(model):
+    """name -> Field of everything Oceananigans.prognostic_state(model) saves (sea_ice_model.jl:414-426): velocities, ice
+    thickness / concentration, snow thickness, the time stepper's G^n and Psi^-, the dynamics' auxiliary fields, the mass fluxes."""
+    out = {"u": model.velocities.u, "v": model.velocities.v, "h": model.ice_thickness, "aice": model.ice_concentration}
+    if model.snow_thickness is not None:
+        out["hs"] = model.snow_thickness
+    for k, f in vars(model.timestepper.Gn).items():
+        out["Gn." + k] = f
+    if model.timestepper.Psi_minus is not None:
+        for k, f in vars(model.timestepper.Psi_minus).items():
+            out["Psi_minus." + k] = f
+    if model.dynamics is not None:
+        for k, f in vars(model.dynamics.auxiliaries.fields).items():
+            out["dynamics." + k] = f
+    if model.mass_fluxes is not None:
+        mf = model.mass_fluxes
+        out.update({"mass_fluxes.ice": mf.thermodynamics.ice, "mass_fluxes.snow": mf.thermodynamics.snow,
+                    "mass_fluxes.intercepted_snowfall": mf.intercepted_snowfall})
+    return {k: f for k, f in out.items() if isinstance(f, Field)}
+
+
+def prognostic_state(model):
+    """Oceananigans.prognostic_state(model) (sea_ice_model.jl:414-426): host copies of the whole parent arrays (halos included)
+    plus the clock.  The library keeps no state of its own between calls -- pointers, scratch that every sub-cycle rebuilds --
+    so this is all a checkpoint needs (tests/test_gpu_steps.py::test_checkpoint_round_trip_bitwise)."""
+    model.synchronize()
+    state = {k: f.numpy().copy() for k, f in _state_fields(model).items()}
+    state["clock"] = (model.clock.time, model.clock.iteration)
+    return state
+
+
+def restore_prognostic_state(model, state):
+    """Oceananigans.restore_prognostic_state!(model, state) (sea_ice_model.jl:428-445): writes the saved parents back into the
+    fields the library is bound to (same arrays: nothing to re-attach)."""
+    for k, f in _state_fields(model).items():
+        if k in state:
+            model.copy_to_field(f, state[k])
+    model.clock.time, model.clock.iteration = state["clock"]
+    return model
+
+
 def time_step_momentum(model, dt, rk_reset=False):
     """time_step_momentum!(model, model.dynamics, dt), split_explicit_momentum_equations.jl:103-195."""
     model.ctx.call("csi_time_step_momentum", float(dt), model.substeps, int(rk_reset))

@@ -534,3 +534,47 @@ def test_freezing_bucket_full_run_matches_oracle(oracle_lib):
     got = [(hh, aa) for _, hh, aa in series]
     assert got == want, (got[:2], want[:2])
     assert 0.99 < got[-1][1] <= 1.0 and got[-1][0] > got[0][0] > 0.05        # consolidated, still thickening
+
+
+@pytest.mark.parametrize("name", ["periodic_rk3", "masked_channel_fe_slab", "snow_rk3"])
+def test_checkpoint_round_trip_bitwise(name):
+    """prognostic_state / restore_prognostic_state! (sea_ice_model.jl:414-445) through the library: two steps, checkpoint, two more
+    steps -- against a FRESH model (new context, new library scratch) that restores the checkpoint and takes the same two steps.
+    Every saved field comes out bit for bit, halos included: the library holds pointers and per-call scratch only, so a
+    checkpoint of the Oceananigans-side fields is a complete one."""
+    kw = {"periodic_rk3": dict(Nx=96, Ny=64, topo=("periodic", "periodic"), patches=True, random_uv=0.03),
+          "masked_channel_fe_slab": dict(Nx=80, Ny=56, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.25, field_forcing=True),
+          "snow_rk3": dict(Nx=72, Ny=48, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03)}[name]
+    c = cases.make_case(substeps=12, **kw)
+    stepper = "ForwardEuler" if "fe" in name else "SplitRungeKutta3"
+    extra = {}
+    if "slab" in name:
+        extra["ice_thermodynamics"] = csi.SlabThermodynamics(top_temperature=-10.0, top_heat_flux=100.0, bottom_heat_flux=10.0)
+    if "snow" in name:
+        extra.update(ice_thermodynamics=csi.SlabThermodynamics(top_heat_boundary_condition=csi.MeltingConstrainedFluxBalance(), top_heat_flux=-70.0,
+                                                              bottom_heat_flux=5.0, bottom_salinity=30.0),
+                     snow_thermodynamics=csi.snow_slab_thermodynamics(), snowfall=2e-5)
+
+    def build():
+        return cases.csi_model(c, mode="fast", timestepper=stepper, advection=csi.WENO(order=7), **extra)
+
+    a = build()
+    for _ in range(2):
+        csi.time_step(a, c["dt"])
+    ckpt = csi.prognostic_state(a)
+    for _ in range(2):
+        csi.time_step(a, c["dt"])
+    want = csi.prognostic_state(a)
+    b = build()
+    csi.time_step(b, c["dt"])                     # (a model that has already stepped: the restore must overwrite everything that matters)
+    csi.restore_prognostic_state(b, ckpt)
+    assert b.clock.iteration == 2
+    for _ in range(2):
+        csi.time_step(b, c["dt"])
+    got = csi.prognostic_state(b)
+    assert set(got) == set(want) and got["clock"] == want["clock"]
+    assert {"u", "v", "h", "aice", "Gn.h", "dynamics.s11", "dynamics.alpha"} <= set(want)
+    for k in want:
+        if k != "clock":
+            assert np.array_equal(want[k], got[k]), (k, np.abs(want[k] - got[k]).max())
+    assert not np.array_equal(ckpt["h"], want["h"])
