@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--print-launch", action="store_true", help="--gpus N > 1: print the launch command of the N ranks as JSON and exit")
     ap.add_argument("--self-test-launch", action="store_true",
                     help="host test of the launcher, no GPU: the ranks rendezvous over gloo, rank 0 prints a stub line (self_test: true)")
+    ap.add_argument("--no-compare", action="store_true", help="tiles: do not time the other halo transports (RCCL k = 16, k = 1) after the headline")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
     args = ap.parse_args()
     if args.gpus not in PARTITION:
@@ -541,7 +542,7 @@ def main():
     k1 = None
     rccl16 = None
     headline_model = model
-    if tiled and args.exchange_interval == 0:
+    if tiled and args.exchange_interval == 0 and not args.no_compare:
         if path["halo_transport"] == "peer" and not user_halo:
             _, _, model, _ = build("rccl")                       # (timed() and barrier() act on `model`)
             for _ in range(max(args.warmup, 1)):
