@@ -918,6 +918,9 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
     FusedGeom G[KMAX], GP[KMAX / 2];
+    // configurations only the two-sub-steps kernel takes (masks, array forcing, per-point metrics): a single sub-step (the odd
+    // trailing one) runs through that kernel too, its consumer wave storing stage A's results (evp_fused2.hip, `single`)
+    const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL);
     {
         if (!c->host_ring) {
             HIP_TRY(c, hipHostMalloc((void**)&c->host_ring, sizeof(FusedTable) * (NSINGLE + NPAIR) * csi_context::kRing, hipHostMallocDefault));
@@ -929,6 +932,23 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         for (int m = 0; m < kb; ++m) {
             const int V = tiled ? W - 2 * m : 2;
             G[m] = fused_geom(c, V);
+            if (single_by_pair) {
+                const ImageSpec ims11 = image_spec(c, CSI_F_S11), ims22 = image_spec(c, CSI_F_S22), ims12 = image_spec(c, CSI_F_S12);
+                const SideV vs = pair_side_v(c, V, 2);
+                const Range dec = v_stress_range(c, vs);
+                G[m] = pair_geom(c, dec);
+                for (int cur = 0; cur < 2; ++cur)
+                    for (int uf = 0; uf < 2; ++uf) {
+                        const Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vs, uf != 0), false),
+                                    r2 = clip_store(c, v_second_range(c, vs), false);
+                        FusedTable* t = &host[(m * 2 + cur) * 2 + uf];
+                        fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
+                        fused_fill_pair_extra(dec, dec.j0, dec.j1, ims11, ims22, ims12, t);
+                        if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
+                        if (extra) fused_fill_extra(P, xd_u, xd_v, t);
+                    }
+                continue;
+            }
             for (int cur = 0; cur < 2; ++cur)
                 for (int uf = 0; uf < 2; ++uf) {
                     Range r1, r1c, r2;
@@ -995,9 +1015,15 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                               has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
                               peer ? ++c->peer.seq : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             m += 2; s += 2;
+        } else if (single_by_pair) {
+            // one sub-step through the two-sub-steps kernel (write_diag bit 1): masks, array forcing, per-point metrics
+            launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
+                              c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
+                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
+                              2 | (s + 1 == end ? 1 : 0), 0ull, c->stream);
+            m += 1; s += 1;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
-            // the one-sub-step kernel takes neither masks nor array-valued forcing nor per-point metrics: a trailing
-            // single sub-step runs the three kernels in place on whichever buffer is current
+            // (no pair kernel for this grid -- halo < 4, tiny tiles: the three kernels in place on whichever buffer is current)
             EvpDev Q = P;
             const FRef* b = cur == 0 ? orig : alt;
             Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];

@@ -112,6 +112,10 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     const int chunk = w / nstrips, strip = w - chunk * nstrips;
     const int lane = (int)(threadIdx.x & 63);
     tptr_t T = (tptr_t)table;
+    // write_diag bit 1: ONE sub-step (the odd trailing sub-step of a sub-cycle): the producer runs its stage, the consumer does no
+    // second sub-step and stores the producer's results instead (below).  Bit 0: store the diagnostics (last launch).
+    const bool single = (write_diag & 2) != 0;
+    write_diag &= 1;
 
     int ja, jb, rstart, rend;
     unsigned loff, sc, sf;
@@ -398,8 +402,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     // the producer -- loads, address arithmetic, eleven LDS writes -- became the longer one (probe: 36 + 4 waiting against
     // 30 + 12 waiting) and the stores went back to the consumer: +5 % at 2048^2, +7 % on a 1024 x 512 tile (28 + 13 against
     // 39 + 5 now; splitting the five stores between the waves balances them better and measures the same within noise).
-    auto flush = [&](int q, double v11, double v22, double v12, double vfirst, double vsecond, auto WH) __attribute__((always_inline)) {
-        constexpr int which = decltype(WH)::value;           // bit 0: stresses, bit 1: first velocity, bit 2: second velocity
+    auto flush = [&](int q, double v11, double v22, double v12, double vfirst, double vsecond, auto WH, auto VFT) __attribute__((always_inline)) {
+        constexpr int which = decltype(WH)::value;
+        constexpr bool VF = decltype(VFT)::value != 0;         // the stored stage is v-first (pairs: stage B, i.e. A is u-first; single sub-step: stage A itself)           // bit 0: stresses, bit 1: first velocity, bit 2: second velocity
         if (which == 0) return;
         if ((q >= fast_lo) & (q <= fast_hi)) {
             // interior rows (nearly every call): every kind of store is due, no row has a y image
@@ -408,37 +413,37 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 if (fast_plain) {
                     // interior tile: the owned lanes store five values, no images
                     if (which & 1) { stg(T->P[FP_S11_OUT], ocq, v11); stg(T->P[FP_S22_OUT], ocq, v22); stg(T->P[FP_S12_OUT], ofq, v12); }
-                    if (which & 2) stg(T->P[AUF ? FP_V_OUTP : FP_U_OUTP], AUF ? ocq : ofq - sf, vfirst);
-                    if (which & 4) stg(T->P[AUF ? FP_U_OUTP : FP_V_OUTP], AUF ? ofq - sf : ocq - sc, vsecond);
+                    if (which & 2) stg(T->P[VF ? FP_V_OUTP : FP_U_OUTP], VF ? ocq : ofq - sf, vfirst);
+                    if (which & 4) stg(T->P[VF ? FP_U_OUTP : FP_V_OUTP], VF ? ofq - sf : ocq - sc, vsecond);
                 } else {
                     // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap / the
                     // neighbouring tile's halo; v mirrors / reflects across an x wall), none of the row bookkeeping of the general path
                     if (which & 1) { put(0, ocq, 0u, false, dx, v11); put(1, ocq, 0u, false, dx, v22); put(2, ofq, 0u, false, dx, v12); }
-                    if (AUF) { if (which & 2) put_v(ocq, 0u, false, vfirst); if (which & 4) put(3, ofq - sf, 0u, false, dx, vsecond); }
+                    if (VF) { if (which & 2) put_v(ocq, 0u, false, vfirst); if (which & 4) put(3, ofq - sf, 0u, false, dx, vsecond); }
                     else { if (which & 2) put(3, ofq - sf, 0u, false, dx, vfirst); if (which & 4) put_v(ocq - sc, 0u, false, vsecond); }
                 }
             }
             return;
         }
-        const int j1 = AUF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
+        const int j1 = VF ? q : q - 1, j2 = q - 1;            // rows of the first / second velocity
         const bool do_s = ((which & 1) != 0) & (q >= rs_lo) & (q <= rs_hi), do_1 = ((which & 2) != 0) & (j1 >= r1_lo) & (j1 <= r1_hi),
                    do_2 = ((which & 4) != 0) & (j2 >= r2_lo) & (j2 <= r2_hi);
         if (!(do_s | do_1 | do_2)) return;
         const unsigned ocq = offc(q), ofq = offf(q);
-        const unsigned o1 = AUF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
-        const unsigned o2 = AUF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
+        const unsigned o1 = VF ? ocq : ofq - sf;                 // first velocity: v(q) / u(q-1)
+        const unsigned o2 = VF ? ofq - sf : ocq - sc;            // second velocity: u(q-1) / v(q-1)
         // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
-        const int yq = yimg(q), y1 = AUF ? yimg(j1) : yimg_u(j1), y2 = AUF ? yimg_u(j2) : yimg(j2);
+        const int yq = yimg(q), y1 = VF ? yimg(j1) : yimg_u(j1), y2 = VF ? yimg_u(j2) : yimg(j2);
         if (do_s & ((flags & L_RS) != 0)) {
             put(0, ocq, (unsigned)yq * sc, q <= HyW, dx, v11);
             put(1, ocq, (unsigned)yq * sc, q <= HyW, dx, v22);
             put(2, ofq, (unsigned)yq * sf, q <= HyW, dx, v12);
         }
         if (do_1 & ((flags & L_R1) != 0)) {
-            if (AUF) put_v(o1, (unsigned)y1 * sc, j1 <= HyW, vfirst); else put_u(o1, j1, (unsigned)y1 * sf, vfirst);
+            if (VF) put_v(o1, (unsigned)y1 * sc, j1 <= HyW, vfirst); else put_u(o1, j1, (unsigned)y1 * sf, vfirst);
         }
         if (do_2 & ((flags & L_R2) != 0)) {
-            if (AUF) put_u(o2, j2, (unsigned)y2 * sf, vsecond); else put_v(o2, (unsigned)y2 * sc, j2 <= HyW, vsecond);
+            if (VF) put_u(o2, j2, (unsigned)y2 * sf, vsecond); else put_v(o2, (unsigned)y2 * sc, j2 <= HyW, vsecond);
         }
     };
     // ring slot of row j (lane-private column): element f of row j sits at ring[((j - rstart) & 3) * 5 + f][lane]
@@ -540,7 +545,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             if (PW & 4) osecond = outr[so + 256];
             advance();
             load_row(R[(k + CSI_PAIR_PD) % 3]);           // row r + CSI_PAIR_PD (clamped to rend)
-            flush(r - 4, o11, o22, o12, ofirst, osecond, Idx<PW>{});
+            flush(r - 4, o11, o22, o12, ofirst, osecond, Idx<PW>{}, Idx<AUF ? 1 : 0>{});
             fm::StressConst ks; stress_consts(ks);
             fm::VelConst kv; vel_consts(kv);
             const double m_0 = C.h_0 * T->K[FK_RHO] * C.a_0;
@@ -564,9 +569,15 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 else { ring[s0 + RF_V * 64] = A.first; ring[s1 + RF_U * 64] = A.second; }
                 // the static fields of the rows B reaches two iterations from now: P, m, aice of row r; u^n of row r-1;
                 // v^n of row r-1 (A u-first: B v-first reads it as row q) / row r (B u-first reads it as row q-1 one iteration later)
+                if (single) {
+                    // no second sub-step: the consumer stores this stage's results; the diagnostics of row r ride in the slots
+                    // the static fields would use (alpha, zeta_f, zeta_c, Delta; the stage carries 2 zeta, Delta^2, 1 / Delta)
+                    ring[s0 + RF_P * 64] = A.AL_0; ring[s0 + RF_M * 64] = 0.5 * A.zf; ring[s0 + RF_A * 64] = 0.5 * A.zc; ring[s0 + RF_VN * 64] = A.Dc * A.rDc;
+                } else {
                 ring[s0 + RF_P * 64] = C.P_0; ring[s0 + RF_M * 64] = m_0; ring[s0 + RF_A * 64] = C.a_0;
                 if (PRE) { ring[s0 + RF_PF * 64] = A.Pf_0; ring[s0 + RF_RMC * 64] = A.rmc_0; ring[s0 + RF_RMF * 64] = A.rmf_0; }
                 ring[s1 + RF_UN * 64] = C.un_m; ring[(AUF ? s1 : s0) + RF_VN * 64] = C.vn_x;
+                }
                 if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] = mhist & 3u;
             }
             A.shift(C.u_p, C.v_p, m_0, C.a_0);
@@ -590,11 +601,46 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         // drain: the consumer's last two rows (r = rend + 1: its iteration rend - 1 is complete; one more barrier for rend)
         for (int d = 0; d < 2; ++d) {
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
-            flush(r - 4, outr[so], outr[so + 64], outr[so + 128], outr[so + 192], outr[so + 256], Idx<(7 & ~CSI_PAIR_STORES)>{});
+            flush(r - 4, outr[so], outr[so + 64], outr[so + 128], outr[so + 192], outr[so + 256], Idx<(7 & ~CSI_PAIR_STORES)>{}, Idx<AUF ? 1 : 0>{});
             if (d == 0) __syncthreads();
             ++r;
         }
         PROBE_END(w * 2);
+        return;
+    }
+
+    if (single) {
+        // ===== ONE sub-step: the consumer stores stage A's results of row r behind the barrier of row r ==================
+        // (sigma(r); A u-first: u(r-1), v(r-1); A v-first: v(r), u(r-1) -- the row conventions flush() has for a stored stage
+        // of that order; the table's store ranges are those of a single sub-step, csi_abi.hip)
+        {
+            const int d1 = AUF ? 1 : 0;
+            fast_lo = max(rs_lo, max(r1_lo + d1, r2_lo + 1));
+            fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
+            if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);
+            if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);
+            if (!lanes_same) fast_hi = fast_lo - 1;
+        }
+        for (int r = rstart; r <= rend; ++r) {
+            __syncthreads();                              // the producer has finished row r
+            const unsigned s0 = rslot(r), s1 = rslot(r - 1);
+            const double v11 = ring[s0 + RF_S11 * 64], v22 = ring[s0 + RF_S22 * 64], v12 = ring[s0 + RF_S12 * 64];
+            const double vfirst = AUF ? ring[s1 + RF_U * 64] : ring[s0 + RF_V * 64];
+            const double vsecond = AUF ? ring[s1 + RF_V * 64] : ring[s1 + RF_U * 64];
+            const double dal = ring[s0 + RF_P * 64], dzf = ring[s0 + RF_M * 64], dzc = ring[s0 + RF_A * 64], ddl = ring[s0 + RF_VN * 64];
+            flush(r, v11, v22, v12, vfirst, vsecond, Idx<7>{}, Idx<AUF ? 0 : 1>{});
+            if (write_diag) {
+                if (((flags & L_RS) != 0) & (r >= rs_lo) & (r <= rs_hi)) {
+                    const unsigned ocq = offc(r), ofq = offf(r);
+                    const int yq = yimg(r);
+                    put(5, ocq, (unsigned)yq * sc, r <= HyW, dx, dal);
+                    put(7, ofq, (unsigned)yq * sf, r <= HyW, dx, dzf);
+                    put(6, ocq, (unsigned)yq * sc, r <= HyW, dx, dzc);
+                    put(8, ocq, (unsigned)yq * sc, r <= HyW, dx, ddl);
+                }
+            }
+        }
+        __syncthreads();
         return;
     }
 
@@ -663,7 +709,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         B.template step<PRE>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
                FULL ? off2(max(q, row0)) : 0u, c2s);      // (rows below the planes only fill the window: clamped)
-        flush(q, B.S11_0, B.S22_0, B.S12_0, B.first, B.second, Idx<(CSI_PAIR_STORES & 7)>{});
+        flush(q, B.S11_0, B.S22_0, B.S12_0, B.first, B.second, Idx<(CSI_PAIR_STORES & 7)>{}, Idx<AUF ? 1 : 0>{});
         if ((CSI_PAIR_STORES & 7) != 7) {
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
             if (!(CSI_PAIR_STORES & 1)) { outr[so] = B.S11_0; outr[so + 64] = B.S22_0; outr[so + 128] = B.S12_0; }

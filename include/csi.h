@@ -350,7 +350,8 @@ int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
  * TWO consecutive sub-steps share one launch (csrc/evp_fused2.hip: the first sub-step's results stay in
  * registers; immersed masks, array-valued top stress and array-valued ocean velocities in the bottom drag
  * supported) where the halo is >= 4 (and N >= 2 halo) and, on tiles, the exchange
- * interval is even; an odd trailing sub-step uses the level-1 kernel (the three kernels when masked).  All paths execute the same
+ * interval is even; an odd trailing sub-step uses the level-1 kernel, or -- with masks, array forcing or per-point metrics -- one more launch
+ * of the same kernel whose second wave stores the first sub-step's results instead of computing a second one.  All paths execute the same
  * floating-point operations and give bit-identical results. */
 /* level 3: THREE sub-steps per launch (evp_fused3.hip: three waves per tile chained through two LDS rings) on fully periodic,
  * untiled grids with halo >= 6 and number-valued forcing, two elsewhere.  Bit-identical like the others; not the default: it
