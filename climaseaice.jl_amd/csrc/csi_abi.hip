@@ -768,7 +768,7 @@ int32_t peer_decide(csi_context* c, const EvpDev& P, int substeps, bool* use) {
     csi_context::Peer& pr = c->peer;
     if (!is_tiled(c) || !pr.want || pr.failed || !c->comm || !c->tile.set) return CSI_OK;
     if (c->exch_k > 0) return CSI_OK;                        // an explicit exchange interval asks for the RCCL exchange
-    if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 2 || (substeps & 1)) return CSI_OK;
+    if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 1) return CSI_OK;      // (an odd count ends with one single-mode launch)
     if (!pair_supported(c) || pair_forcing_kind(P) < 0) return CSI_OK;
     if (c->f[CSI_F_U].ld != c->f[CSI_F_S12].ld || c->f[CSI_F_V].ld != c->f[CSI_F_S11].ld) return CSI_OK;
     if (c->Nx < 128) return CSI_OK;                          // (a wave's x images all go to ONE neighbour: evp_fused2.hip)
@@ -920,7 +920,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     FusedGeom G[KMAX], GP[KMAX / 2];
     // configurations only the two-sub-steps kernel takes (masks, array forcing, per-point metrics): a single sub-step (the odd
     // trailing one) runs through that kernel too, its consumer wave storing stage A's results (evp_fused2.hip, `single`)
-    const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL);
+    const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL || peer);      // (peer: the flag protocol lives in this kernel only)
     {
         if (!c->host_ring) {
             HIP_TRY(c, hipHostMalloc((void**)&c->host_ring, sizeof(FusedTable) * (NSINGLE + NPAIR) * csi_context::kRing, hipHostMallocDefault));
@@ -946,6 +946,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         fused_fill_pair_extra(dec, dec.j0, dec.j1, ims11, ims22, ims12, t);
                         if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
+                        if (peer && (rc = peer_fill_table(c, G[m], cur == 0, t))) return rc;
                     }
                 continue;
             }
@@ -1020,7 +1021,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
-                              2 | (s + 1 == end ? 1 : 0), 0ull, c->stream);
+                              2 | (s + 1 == end ? 1 : 0), peer ? ++c->peer.seq : 0ull, c->stream);
             m += 1; s += 1;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
             // (no pair kernel for this grid -- halo < 4, tiny tiles: the three kernels in place on whichever buffer is current)
@@ -1053,7 +1054,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     if (peer) {
         // the neighbours' last launch wrote into this rank's halos: wait for all of it before anything later on this stream
         // (the copy back, finalize_rheology!, the next exchange) reads them
-        launch_wait_peers(c->peer.slots, c->peer.sync_rank, csi_context::Peer::SLOTS, peer_wait_counts(c, GP[0]).n, c->peer.seq, c->peer.err, c->stream);
+        launch_wait_peers(c->peer.slots, c->peer.sync_rank, csi_context::Peer::SLOTS, peer_wait_counts(c, substeps >= 2 ? GP[0] : G[0]).n, c->peer.seq, c->peer.err, c->stream);
         HIP_TRY(c, hipMemcpyAsync(c->peer.err_host, c->peer.err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -609,6 +609,26 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         return;
     }
 
+    auto publish = [&]() __attribute__((always_inline)) {
+        if (PEER && pdirs) {
+            // this tile is done with launch seq: its images are stored (release at system scope) and its halo reads are complete
+            // (the producer's loads were consumed before its last barrier).  One lane per direction publishes seq in this tile's
+            // slot of that neighbour's flag array.
+            if (CSI_PEER_EXP & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: this wave's stores are in their -- possibly remote -- memory
+            if ((lane < 8) && ((pdirs >> lane) & 1u)) {
+                const int nW = T->I[FI_PSET], nE = T->I[FI_PSET + 1], nN = T->I[FI_PSET + 3];
+                const bool xw = (lane == D_W) | (lane == D_SW) | (lane == D_NW), xe = (lane == D_E) | (lane == D_SE) | (lane == D_NE);
+                const bool yn = (lane == D_N) | (lane == D_NW) | (lane == D_NE);
+                const int xs = xe ? strip - (nstrips - nE) : strip, xn = xw ? nW : (xe ? nE : nstrips);
+                const int ys = yn ? chunk - (nchunks - nN) : chunk;
+                typedef const __attribute__((address_space(4))) unsigned long* sptr_t;
+                unsigned long long* out = (unsigned long long*)((sptr_t)&T->P[FP_SLOT_OUT])[lane];
+                __hip_atomic_store(out + (ys * xn + xs), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+
     if (single) {
         // ===== ONE sub-step: the consumer stores stage A's results of row r behind the barrier of row r ==================
         // (sigma(r); A u-first: u(r-1), v(r-1); A v-first: v(r), u(r-1) -- the row conventions flush() has for a stored stage
@@ -641,6 +661,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             }
         }
         __syncthreads();
+        publish();
         return;
     }
 
@@ -740,23 +761,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         if (++r > rend) break;
     }
     __syncthreads();                                      // the last row's results are in the out ring: the producer drains them
-    if (PEER && pdirs) {
-        // this tile is done with launch seq: its images are stored (release at system scope) and its halo reads are complete
-        // (the producer's loads were consumed before its last barrier).  One lane per direction publishes seq in this tile's
-        // slot of that neighbour's flag array.
-        if (CSI_PEER_EXP & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: this wave's stores are in their -- possibly remote -- memory
-        if ((lane < 8) && ((pdirs >> lane) & 1u)) {
-            const int nW = T->I[FI_PSET], nE = T->I[FI_PSET + 1], nN = T->I[FI_PSET + 3];
-            const bool xw = (lane == D_W) | (lane == D_SW) | (lane == D_NW), xe = (lane == D_E) | (lane == D_SE) | (lane == D_NE);
-            const bool yn = (lane == D_N) | (lane == D_NW) | (lane == D_NE);
-            const int xs = xe ? strip - (nstrips - nE) : strip, xn = xw ? nW : (xe ? nE : nstrips);
-            const int ys = yn ? chunk - (nchunks - nN) : chunk;
-            typedef const __attribute__((address_space(4))) unsigned long* sptr_t;
-            unsigned long long* out = (unsigned long long*)((sptr_t)&T->P[FP_SLOT_OUT])[lane];
-            __hip_atomic_store(out + (ys * xn + xs), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    publish();
     PROBE_END(w * 2 + 1);
 }
 

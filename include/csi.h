@@ -365,7 +365,8 @@ int32_t csi_set_fusion(csi_context* ctx, int32_t level);
  * split_explicit_momentum_equations.jl:51-64). */
 int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 
-/* Halo transport of the sub-cycle on tiles (FAST mode, two sub-steps per launch, an even number of sub-steps).
+/* Halo transport of the sub-cycle on tiles (FAST mode, two sub-steps per launch; an odd count ends with one single-sub-step launch
+ * of the same kernel).
  * CSI_TRANSPORT_PEER (default): peer-direct halo writes over xGMI.  The neighbouring tiles' u, v, sigma (and alpha, zeta, Delta)
  * arrays are mapped into this process (HIP IPC handles, exchanged once over the context's RCCL communicator); a connected side
  * then behaves like a Periodic one whose halo lives on another GPU: the kernel that owns a cell next to the side stores its halo
@@ -378,7 +379,7 @@ int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
  * (no IPC, unequal strides), every rank stays on RCCL.  A tile that waits 3 s for a neighbour gives up, the next csi_sync
  * returns CSI_ERR_COMM.
  * CSI_TRANSPORT_RCCL: pack -> grouped ncclSend / ncclRecv -> unpack of width-2k strips every k sub-steps
- * (csi_set_exchange_interval); what every other path (three kernels, STRICT, odd sub-step counts) uses anyway.
+ * (csi_set_exchange_interval); what every other path (three kernels, STRICT) uses anyway.
  * Both give results bit-identical to the untiled run.  csi_halo_transport: what the last sub-cycle used. */
 enum { CSI_TRANSPORT_RCCL = 0, CSI_TRANSPORT_PEER = 1 };
 int32_t csi_set_halo_transport(csi_context* ctx, int32_t kind);

@@ -9,7 +9,7 @@ for seed in range(lo, hi):
     rng = np.random.default_rng(5000 + seed)
     H = int(rng.integers(4, 11))
     k = int(rng.integers(1, H // 2 + 1))
-    peer = bool(rng.integers(2))            # round 3: half of the configurations on the peer transport (k = 0, an even sub-step count)
+    peer = bool(rng.integers(2))            # round 3: half of the configurations on the peer transport (k = 0)
     fc = [(True, True), (True, False), (False, True)][rng.integers(3)]
     topo = ("periodic" if fc[0] or rng.integers(2) else "bounded", "periodic" if fc[1] or rng.integers(2) else "bounded")
     Nx = int(rng.integers(2 * H + 2, 260)); Ny = int(rng.integers(2 * H + 2, 80))
@@ -32,7 +32,6 @@ for seed in range(lo, hi):
         kw["free_drift"] = False
     if peer:
         k = 0
-        nsub += nsub % 2
     try:
         c = cases.make_case(substeps=nsub, **kw)
         ref = cases.csi_model(c, mode="fast"); ref.set_fusion(0)

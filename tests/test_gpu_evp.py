@@ -502,14 +502,16 @@ PEER_CASES = {
 }
 
 
-@pytest.mark.parametrize("nsub", [2, 12, 120])
+@pytest.mark.parametrize("nsub", [1, 2, 7, 12, 120])
 @pytest.mark.parametrize("name", sorted(PEER_CASES))
 def test_peer_halo_transport_self_connected_bitwise(name, nsub):
     """csi_set_halo_transport(PEER), the default on tiles: a connected side behaves like a periodic one whose halo lives in the
     neighbour's arrays -- the owners' stores write the images there, per-tile flags order the launches (evp_fused2.hip).  Here
     the neighbour is the tile itself (one GPU): same kernels, same flag protocol, every slot index exercised.  The whole parent
     arrays -- halos included -- of u, v, sigma equal the untiled run bit for bit, and so do the interiors of alpha, zeta, Delta
-    against the three-kernel path; one RCCL exchange per sub-cycle remains."""
+    against the three-kernel path; one RCCL exchange per sub-cycle remains.  An odd count ends with one launch of the same
+    kernel in its single-sub-step mode (the untiled run's trailing launch may be another kernel, which leaves other by-products
+    in never-read halo layers: interiors are compared then)."""
     kw, fc = PEER_CASES[name]
     c = cases.make_case(substeps=nsub, patches=True, random_uv=0.05, **kw)
     three = cases.csi_model(c, mode="fast")
@@ -524,10 +526,13 @@ def test_peer_halo_transport_self_connected_bitwise(name, nsub):
     csi.time_step_momentum(three, c["dt"])
     three.synchronize(); ref.synchronize(); til.synchronize()
     path = til.ctx.last_path()
-    assert til.ctx.halo_transport() == "peer" and path["level"] == 2 and path["exchanges"] == 1, path
-    assert ref.ctx.last_path()["level"] == 2
+    assert til.ctx.halo_transport() == "peer" and path["exchanges"] == 1, path
+    assert til.ctx.last_launches() == ((nsub + 1) // 2, nsub)
+    assert path["level"] == (2 if nsub >= 2 else 1)
+    assert nsub < 2 or ref.ctx.last_path()["level"] == 2      # (one sub-step with masks / array forcing, untiled: three kernels)
     for f in ("u", "v", "s11", "s22", "s12"):
-        a, b = EVP_FIELDS[f](ref).numpy(), EVP_FIELDS[f](til).numpy()
+        get = (lambda m: EVP_FIELDS[f](m).numpy()) if nsub % 2 == 0 else (lambda m: EVP_FIELDS[f](m).interior_numpy())
+        a, b = get(ref), get(til)
         assert np.array_equal(a, b), (f, "parents incl. halos", np.abs(a - b).max(), np.argwhere(a != b)[:5])
     for f in ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta"):
         a, b = EVP_FIELDS[f](three).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
@@ -535,8 +540,8 @@ def test_peer_halo_transport_self_connected_bitwise(name, nsub):
 
 
 def test_peer_halo_transport_falls_back_and_can_be_switched_off():
-    """Odd sub-step counts and explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the
-    peer transport off; all bit-identical."""
+    """Explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the peer transport off; odd
+    sub-step counts stay on it; all bit-identical."""
     c = cases.make_case(Nx=136, Ny=72, H=8, substeps=13, topo=("periodic", "periodic"), patches=True, random_uv=0.05)
     ref = cases.csi_model(c, mode="fast")
     ref.set_fusion(0)
@@ -546,7 +551,7 @@ def test_peer_halo_transport_falls_back_and_can_be_switched_off():
     til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, (True, True)))
     csi.time_step_momentum(til, c["dt"])                      # 13 sub-steps: odd
     til.synchronize()
-    assert til.ctx.halo_transport() == "rccl"
+    assert til.ctx.halo_transport() == "peer"
     for f in want:
         assert np.array_equal(want[f], EVP_FIELDS[f](til).interior_numpy()), f
     c2 = dict(c, substeps=12)
