@@ -835,14 +835,57 @@ FusedGeom trio_geom(const csi_context* c, const Range& dec) {
     return G;
 }
 
+// ---- north fold: a band of rows next to the fold on the three kernels, everything below on the two-sub-steps kernel -------
+// The two-sub-steps kernel cannot reproduce the reference next to a fold (it would have to recompute halo rows the reference
+// READS as stored images).  But only the rows within reach of the fold need that: rows 1 .. M
+// (M = Ny - Hy - 4) run through the pair kernel as a tile whose north side is "connected" -- its halo rows M + 1 .. M + 4 are
+// interior rows of the same arrays --, rows above M through the three kernels, which store and read fold images exactly like
+// the reference's.  Per pair of sub-steps, in stream order: copy rows >= M - 7 of u, v, sigma from the current buffer to the
+// other one, advance them there by two three-kernel sub-steps on shrinking row ranges (valid from row M on after the second),
+// then the pair launch: it reads the current buffer only and overwrites rows <= M + 1 of the other one -- where the band
+// left intermediate values, and on rows M, M + 1 the very same bits.
+struct FoldBand {
+    int M;
+    EvpDev P;                       // the whole grid (fold geometry)
+    ImageSpec imu, imv;
+    Range rs, ru1, rv1, r2;         // the three kernels' ranges on the whole grid
+};
+// one three-kernel sub-step on rows >= jlo of the buffers `b` (in place); jlo <= -(1 << 20): the whole grid
+int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* b, bool ufirst, int jlo, bool last) {
+    EvpDev Q = bd.P;
+    Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
+    Q.write_diag = last;
+    auto from = [&](Range r, int j0) { if (j0 > r.j0) r.j0 = j0; return r; };
+    launch_fast_stress(Q, from(bd.rs, jlo), fc, c->stream);
+    if (ufirst) { launch_fast_ustep(Q, from(bd.ru1, jlo + 1), bd.imu, fc, c->stream); launch_fast_vstep(Q, from(bd.r2, jlo + 1), bd.imv, fc, c->stream); }
+    else { launch_fast_vstep(Q, from(bd.rv1, jlo + 1), bd.imv, fc, c->stream); launch_fast_ustep(Q, from(bd.r2, jlo + 1), bd.imu, fc, c->stream); }
+    return CSI_OK;
+}
+// two sub-steps of the band: buffer `cur` (0: the caller's arrays) -> the other one
+int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* orig, const FRef* alt, int cur, int s, bool last) {
+    const int j0 = bd.M - 7;
+    for (int q = 0; q < 5; ++q) {
+        const Bound& b = c->f[kPing[q]];
+        const size_t row = (size_t)(j0 - 1 + c->Hy), off = row * (size_t)b.ld, n = ((size_t)b.nj - row) * (size_t)b.ld;
+        const double *src = cur == 0 ? b.p : c->alt[q];
+        double* dst = cur == 0 ? c->alt[q] : b.p;
+        HIP_TRY(c, hipMemcpyAsync(dst + off, src + off, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    const FRef* b = cur == 0 ? alt : orig;
+    // validity after the first sub-step: sigma from row M - 5, velocities from M - 3; after the second: sigma M - 2, velocities M
+    int32_t rc;
+    if ((rc = band_substep(c, bd, fc, b, (s % 2) == 0, bd.M - 5, false))) return rc;
+    return band_substep(c, bd, fc, b, ((s + 1) % 2) == 0, bd.M - 2, last);
+}
+
 // peer: the caller (run_fused_peer) has turned the connected sides of c->g / P.g into periodic ones: the launch loop is that of an
 // untiled periodic grid, the halo images of those sides go to the neighbouring tiles' arrays and every pair launch carries a
-// number of the flag protocol
-int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first, bool peer = false) {
+// number of the flag protocol.  band: the caller (run_fused_fold) has cut the rows next to a north fold off c->g / P.g.
+int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first, bool peer = false, const FoldBand* band = nullptr) {
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
-    const bool tiled = is_tiled(c);
-    const int k = exchange_interval(c), W = 2 * k;
+    const bool tiled = is_tiled(c) && !band;
+    const int k = band ? 2 : exchange_interval(c), W = 2 * k;
     const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
     const bool masked = P.g.has_mask != 0;
     const bool force = pair_forcing_kind(P) == 1;           // array-valued forcing: two-sub-steps kernel only
@@ -1011,11 +1054,17 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             ++c->last_trios;
         } else if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
+            if (band) { if ((rc = band_two_substeps(c, *band, fc, orig, alt, cur, s, s + 2 == end))) return rc; nlaunch += 6; }
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
                               peer ? ++c->peer.seq : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             m += 2; s += 2;
+        } else if (band) {
+            if ((rc = band_substep(c, *band, fc, cur == 0 ? orig : alt, ufirst, -(1 << 30), s + 1 == end))) return rc;
+            m += 1; s += 1;
+            cur ^= 1;           // undone below: in place
+            nlaunch += 2;
         } else if (single_by_pair) {
             // one sub-step through the two-sub-steps kernel (write_diag bit 1): masks, array forcing, per-point metrics
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
@@ -1101,6 +1150,38 @@ int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int subste
     return rc;
 }
 
+// A north fold on an untiled grid (RightFolded y, Periodic x): see FoldBand.
+bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps) {
+    const GridDev& g = c->g;
+    if (g.yhi != SIDE_FOLD || g.ylo == SIDE_CONNECTED || g.xlo != SIDE_PERIODIC || g.xhi != SIDE_PERIODIC) return false;
+    if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 2 || c->Hy < 4) return false;
+    const int M = c->Ny - c->Hy - 4;
+    if (M < 2 * c->Hy + 8) return false;
+    struct Swap {
+        csi_context* c; GridDev g; int Ny;
+        Swap(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
+        ~Swap() { c->g = g; c->Ny = Ny; }
+    } swap(c, M);
+    EvpDev P = Pfull;
+    P.g = c->g;
+    return pair_supported(c) && pair_forcing_kind(P) >= 0;
+}
+int32_t run_fused_fold(csi_context* c, const EvpDev& Pfull, const FastCoef& fc, int substeps, int first) {
+    FoldBand bd;
+    bd.M = c->Ny - c->Hy - 4;
+    bd.P = Pfull;
+    bd.imu = image_spec(c, CSI_F_U); bd.imv = image_spec(c, CSI_F_V);
+    bd.rs = stress_range(c); bd.ru1 = first_u_range(c); bd.rv1 = first_v_range(c); bd.r2 = second_range(c);
+    struct Swap {
+        csi_context* c; GridDev g; int Ny;
+        Swap(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
+        ~Swap() { c->g = g; c->Ny = Ny; }
+    } swap(c, bd.M);
+    EvpDev P = Pfull;
+    P.g = c->g;
+    return run_fused(c, P, fc, substeps, first, false, &bd);
+}
+
 int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     int32_t rc;
     {                                                // :170-171, both fields in one batch of two launches
@@ -1157,6 +1238,14 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     // the peer halo transport (tiles) needs none of the RCCL batching constraints (an even exchange interval): decide it first
     bool peer = false;
     if (fast && c->fusion && substeps > 0 && (rc = peer_decide(c, P, substeps, &peer))) return rc;
+    if (!peer && fast && fold_band_supported(c, P, substeps)) {
+        c->peer.last = 0;
+        if ((rc = run_fused_fold(c, P, fc, substeps, first))) return rc;
+        c->timed = true;
+        c->launches_per_substep = 1;
+        c->last_fused = 2;
+        return CSI_OK;
+    }
     const bool fuse = peer || (fast && c->fusion && substeps > 0 &&
                                (pair_only ? (pfk >= 0 && pair_supported(c) && (!tiled || k % 2 == 0) && substeps >= 2)
                                           : fused_supported(P)));

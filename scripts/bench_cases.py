@@ -26,7 +26,8 @@ CONFIGS = {
     "no-slip channel with 30 % land (coastline-example style)": dict(topo=("periodic", "bounded"), land=0.3, noslip=True),
     "curvilinear channel (twelve 2-D metric arrays, CSI_METRIC_FULL)": dict(topo=("periodic", "bounded"), curvilinear=0.05),
     "curvilinear channel with 30 % land": dict(topo=("periodic", "bounded"), curvilinear=0.05, land=0.3),
-    "tripolar-like (north fold, curvilinear, 30 % land, arrays, free drift): three kernels": dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True),
+    "north fold on uniform metrics (periodic x, RightFolded y)": dict(topo=("periodic", "folded")),
+    "tripolar-like (north fold, curvilinear, 30 % land, arrays, free drift)": dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True),
 }
 if len(sys.argv) > 2:
     CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}

@@ -102,7 +102,7 @@ MASKED = {"curvilinear_periodic", "curvilinear_bounded", "curvilinear_masked", "
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip",
           # round 3: model.forcing arrays and immersed flux boundary conditions (the EXTRA instantiations of the pair kernel)
           "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}      # configurations only the pair kernel fuses
-THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar"}   # the north fold: never fused
+THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar"}   # the north fold: never fused at level 1; level 2: three kernels on the rows next to the fold only
 
 
 def ulp_diff(a, b):
@@ -567,7 +567,7 @@ def test_peer_halo_transport_falls_back_and_can_be_switched_off():
             assert np.array_equal(EVP_FIELDS[f](ref2).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()), (expect, f)
 
 
-EXTRA_CASES = ["folded_uniform", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"]
+EXTRA_CASES = ["folded_uniform", "folded_tripolar", "coriolis_points_tripolar", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"]
 FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
                "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
@@ -598,14 +598,15 @@ def test_fused_kernels_bitwise_equal_three_kernel_path(name, nsub):
         level[fusion] = m.ctx.last_path()["level"]
         assert m.ctx.launches_per_substep() == (1 if level[fusion] else 3)
         diag = (lambda f: f.numpy()) if fusion < 2 else (lambda f: f.interior_numpy())
-        walls = "bounded" in CASES[name]["topo"]
+        walls = "bounded" in CASES[name]["topo"] or "folded" in CASES[name]["topo"]      # (a RightFolded y has a wall in the south)
         out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22") + (() if walls else ("s12",))}
         out[fusion].update({k: (EVP_FIELDS[k](m).numpy().copy(), EVP_FIELDS[k](m).interior_numpy().copy())
                             for k in ("alpha", "zeta_c", "zeta_f", "Delta") + (("s12",) if walls else ())})
     single = 0 if (name in MASKED or name in THREE_KERNEL_ONLY) else 1   # the one-sub-step kernel takes neither masks nor array-valued forcing
     assert level[0] == 0 and level[1] == single
-    assert level[2] == (2 if (name in PAIR_CASES and nsub >= 2) else single), level
-    if level[2] == 2:
+    # (round 3: a north fold runs the pair kernel below a band of three-kernel rows next to the fold, csi_abi.hip FoldBand)
+    assert level[2] == (2 if ((name in PAIR_CASES or name in THREE_KERNEL_ONLY) and nsub >= 2) else single), level
+    if level[2] == 2 and name not in THREE_KERNEL_ONLY:
         launches, substeps = m.ctx.last_launches()
         assert substeps == nsub and launches == (nsub + 1) // 2        # (round 3: the odd trailing sub-step of masked / array-forced configurations is ONE launch too)
     for fusion in (1, 2):
@@ -681,6 +682,44 @@ def test_fused_paths_fuzz_bitwise(seed):
             a, b = out[0][k], out[fusion][k]
             assert np.all(np.isfinite(b)), (k, kw)
             assert np.array_equal(a, b), (seed, fusion, kw, nsub, k, np.abs(a - b).max(), np.argwhere(a != b)[:4])
+
+
+FOLD_BAND_CASES = {
+    "uniform": dict(Nx=64, Ny=48),
+    "uniform_halo7_ragged": dict(Nx=117, Ny=61, H=7),
+    "one_chunk_below_the_band": dict(Nx=200, Ny=24),
+    "tripolar_coupled": dict(Nx=120, Ny=70, curvilinear=0.04, land=0.2, field_forcing=True, free_drift=True),
+    "tripolar_coriolis_points": dict(Nx=90, Ny=64, H=5, curvilinear=0.04, land=0.25, coriolis_points=True),
+    "tripolar_user_forcing": dict(Nx=72, Ny=56, curvilinear=0.04, land=0.2, user_forcing=True,
+                                  immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))),
+    "coupled_arrays": dict(Nx=128, Ny=80, field_forcing=True),
+    "masked_noslip": dict(Nx=100, Ny=52, land=0.3, noslip=True),
+}
+
+
+@pytest.mark.parametrize("nsub", [2, 5, 120])
+@pytest.mark.parametrize("name", sorted(FOLD_BAND_CASES))
+def test_north_fold_band_bitwise(name, nsub):
+    """A north fold (TripolarGrid: RightFolded y) at fusion level 2: rows 1 .. Ny - Hy - 4 through the two-sub-steps kernel, the rows
+    next to the fold through the three kernels (which read and store fold images like the reference's), csi_abi.hip FoldBand.
+    Everything -- the parents of u, v, sigma where anything reads them, the diagnostics' interiors -- equals the three-kernel run
+    of the whole grid bit for bit, for two sub-cycles in a row."""
+    kw = dict(topo=("periodic", "folded"), patches=True, random_uv=0.04)
+    kw.update(FOLD_BAND_CASES[name])
+    c = cases.make_case(substeps=nsub, **kw)
+    ref = cases.csi_model(c, mode="fast"); ref.set_fusion(0)
+    new = cases.csi_model(c, mode="fast")
+    for _ in range(2):
+        csi.time_step_momentum(ref, c["dt"]); csi.time_step_momentum(new, c["dt"])
+    ref.synchronize(); new.synchronize()
+    assert ref.ctx.last_path()["level"] == 0 and new.ctx.last_path()["level"] == 2
+    for f in ("u", "v", "s11", "s22", "s12"):
+        a, b = cmp_region(c, f, EVP_FIELDS[f](ref).numpy()), cmp_region(c, f, EVP_FIELDS[f](new).numpy())
+        assert np.all(np.isfinite(b)), f
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
+    for f in ("alpha", "zeta_c", "zeta_f", "Delta"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](new).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
 @pytest.mark.parametrize("topo", [("periodic", "periodic"), ("bounded", "bounded"), ("periodic", "bounded")])
