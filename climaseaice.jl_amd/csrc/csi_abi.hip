@@ -118,6 +118,12 @@ struct csi_context {
     bool ring_used[kRing] = {false, false, false, false};
     unsigned ring_pos = 0;
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // north fold (FoldBand): the band's own copies of u, v, sigma and of the four diagnostics, its stream and the two events
+    // that order it against the pair launches
+    double* band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t band_elems[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipStream_t band_stream = nullptr;
+    hipEvent_t band_ev_pair = nullptr, band_ev_band = nullptr;
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
     double* fd[2] = {nullptr, nullptr};     // free-drift velocities at u / v points (StressBalanceFreeDrift)
     double* xd[2] = {nullptr, nullptr};     // stress divergence of the immersed flux boundary conditions at u / v points (two-sub-steps kernel)
@@ -840,42 +846,88 @@ FusedGeom trio_geom(const csi_context* c, const Range& dec) {
 // READS as stored images).  But only the rows within reach of the fold need that: rows 1 .. M
 // (M = Ny - Hy - 4) run through the pair kernel as a tile whose north side is "connected" -- its halo rows M + 1 .. M + 4 are
 // interior rows of the same arrays --, rows above M through the three kernels, which store and read fold images exactly like
-// the reference's.  Per pair of sub-steps, in stream order: copy rows >= M - 7 of u, v, sigma from the current buffer to the
-// other one, advance them there by two three-kernel sub-steps on shrinking row ranges (valid from row M on after the second),
-// then the pair launch: it reads the current buffer only and overwrites rows <= M + 1 of the other one -- where the band
-// left intermediate values, and on rows M, M + 1 the very same bits.
+// the reference's.  Per pair of sub-steps the band, on its own stream and in its own copies of the arrays: copy rows >= M - 7
+// of u, v, sigma from the current buffer, advance them by two three-kernel sub-steps on shrinking row ranges (valid from row M
+// on after the second), copy rows >= M + 1 into the other buffer -- while the pair launch reads the current buffer and stores
+// rows <= M of the other one.  Two events: a pair launch waits for the previous band (its halo rows), a band for the previous
+// pair launch (rows M - 7 .. M of its input).
 struct FoldBand {
     int M;
     EvpDev P;                       // the whole grid (fold geometry)
     ImageSpec imu, imv;
     Range rs, ru1, rv1, r2;         // the three kernels' ranges on the whole grid
 };
-// one three-kernel sub-step on rows >= jlo of the buffers `b` (in place); jlo <= -(1 << 20): the whole grid
-int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* b, bool ufirst, int jlo, bool last) {
-    EvpDev Q = bd.P;
-    Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
-    Q.write_diag = last;
-    auto from = [&](Range r, int j0) { if (j0 > r.j0) r.j0 = j0; return r; };
-    launch_fast_stress(Q, from(bd.rs, jlo), fc, c->stream);
-    if (ufirst) { launch_fast_ustep(Q, from(bd.ru1, jlo + 1), bd.imu, fc, c->stream); launch_fast_vstep(Q, from(bd.r2, jlo + 1), bd.imv, fc, c->stream); }
-    else { launch_fast_vstep(Q, from(bd.rv1, jlo + 1), bd.imv, fc, c->stream); launch_fast_ustep(Q, from(bd.r2, jlo + 1), bd.imu, fc, c->stream); }
+const int kBandDiag[4] = {CSI_F_ALPHA, CSI_F_ZETA_C, CSI_F_ZETA_F, CSI_F_DELTA};
+const Bound& band_bound(const csi_context* c, int q) { return c->f[q < 5 ? kPing[q] : kBandDiag[q - 5]]; }
+FRef band_ref(const csi_context* c, int q) {
+    const Bound& b = band_bound(c, q);
+    FRef r;
+    r.p = c->band[q] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * b.ld;
+    r.ld = (int)b.ld;
+    return r;
+}
+int32_t ensure_band(csi_context* c) {
+    for (int q = 0; q < 9; ++q) {
+        const Bound& b = band_bound(c, q);
+        const size_t n = (size_t)b.ld * (size_t)b.nj;
+        if (c->band_elems[q] != n) {
+            if (c->band[q]) { HIP_TRY(c, hipDeviceSynchronize()); hipFree(c->band[q]); c->band[q] = nullptr; }
+            HIP_TRY(c, hipMalloc((void**)&c->band[q], n * sizeof(double)));
+            HIP_TRY(c, hipMemsetAsync(c->band[q], 0, n * sizeof(double), c->stream));
+            c->band_elems[q] = n;
+        }
+    }
+    if (!c->band_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_pair, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_band, hipEventDisableTiming));
+    }
     return CSI_OK;
 }
-// two sub-steps of the band: buffer `cur` (0: the caller's arrays) -> the other one
-int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* orig, const FRef* alt, int cur, int s, bool last) {
-    const int j0 = bd.M - 7;
+// one three-kernel sub-step on rows >= jlo, in place: u, v, sigma in b[0..4], diagnostics (last sub-step) in d[0..3] (alpha,
+// zeta_c, zeta_f, Delta; nullptr: the caller's arrays); jlo hugely negative: the whole grid
+int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* b, const FRef* d, bool ufirst, int jlo, bool last, hipStream_t st) {
+    EvpDev Q = bd.P;
+    Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
+    if (d) { Q.al = d[0]; Q.zc = d[1]; Q.zf = d[2]; Q.Dl = d[3]; }
+    Q.write_diag = last;
+    auto from = [&](Range r, int j0) { if (j0 > r.j0) r.j0 = j0; return r; };
+    launch_fast_stress(Q, from(bd.rs, jlo), fc, st);
+    if (ufirst) { launch_fast_ustep(Q, from(bd.ru1, jlo + 1), bd.imu, fc, st); launch_fast_vstep(Q, from(bd.r2, jlo + 1), bd.imv, fc, st); }
+    else { launch_fast_vstep(Q, from(bd.rv1, jlo + 1), bd.imv, fc, st); launch_fast_ustep(Q, from(bd.r2, jlo + 1), bd.imu, fc, st); }
+    return CSI_OK;
+}
+// two sub-steps of the band: buffer `cur` (0: the caller's arrays) -> the other one, on the band's stream
+int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, bool last) {
+    hipStream_t st = c->band_stream;
+    HIP_TRY(c, hipStreamWaitEvent(st, c->band_ev_pair, 0));
+    auto rows_from = [&](int q, int j0, const double* src, double* dst, CopyBatch& B) {
+        const Bound& b = band_bound(c, q);
+        const size_t row = (size_t)(j0 - 1 + c->Hy), off = row * (size_t)b.ld;
+        B.src[B.count] = src + off; B.dst[B.count] = dst + off; B.n[B.count] = (long)(((size_t)b.nj - row) * (size_t)b.ld);
+        ++B.count;
+    };
+    CopyBatch in{}, out{}, diag{};
     for (int q = 0; q < 5; ++q) {
-        const Bound& b = c->f[kPing[q]];
-        const size_t row = (size_t)(j0 - 1 + c->Hy), off = row * (size_t)b.ld, n = ((size_t)b.nj - row) * (size_t)b.ld;
-        const double *src = cur == 0 ? b.p : c->alt[q];
-        double* dst = cur == 0 ? c->alt[q] : b.p;
-        HIP_TRY(c, hipMemcpyAsync(dst + off, src + off, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        const Bound& b = band_bound(c, q);
+        rows_from(q, bd.M - 7, cur == 0 ? b.p : c->alt[q], c->band[q], in);
+        rows_from(q, bd.M + 1, c->band[q], cur == 0 ? c->alt[q] : b.p, out);
     }
-    const FRef* b = cur == 0 ? alt : orig;
+    launch_copy_batch(in, st);
+    FRef b[5], d[4];
+    for (int q = 0; q < 5; ++q) b[q] = band_ref(c, q);
+    for (int q = 0; q < 4; ++q) d[q] = band_ref(c, 5 + q);
     // validity after the first sub-step: sigma from row M - 5, velocities from M - 3; after the second: sigma M - 2, velocities M
     int32_t rc;
-    if ((rc = band_substep(c, bd, fc, b, (s % 2) == 0, bd.M - 5, false))) return rc;
-    return band_substep(c, bd, fc, b, ((s + 1) % 2) == 0, bd.M - 2, last);
+    if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 5, false, st))) return rc;
+    if ((rc = band_substep(c, bd, fc, b, d, ((s + 1) % 2) == 0, bd.M - 2, last, st))) return rc;
+    launch_copy_batch(out, st);
+    if (last) {
+        for (int q = 5; q < 9; ++q) rows_from(q, bd.M + 1, c->band[q], band_bound(c, q).p, diag);
+        launch_copy_batch(diag, st);
+    }
+    HIP_TRY(c, hipEventRecord(c->band_ev_band, st));
+    return CSI_OK;
 }
 
 // peer: the caller (run_fused_peer) has turned the connected sides of c->g / P.g into periodic ones: the launch loop is that of an
@@ -884,6 +936,7 @@ int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc
 int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first, bool peer = false, const FoldBand* band = nullptr) {
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
+    if (band && (rc = ensure_band(c))) return rc;
     const bool tiled = is_tiled(c) && !band;
     const int k = band ? 2 : exchange_interval(c), W = 2 * k;
     const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
@@ -1010,8 +1063,11 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                 for (int cur = 0; cur < 2; ++cur)
                     for (int auf = 0; auf < 2; ++auf) {
                         const bool buf = auf == 0;                  // the second sub-step has the other order
-                        const Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vb, buf), false),
-                                    r2 = clip_store(c, v_second_range(c, vb), false);
+                        Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vb, buf), false),
+                              r2 = clip_store(c, v_second_range(c, vb), false);
+                        if (band) {         // rows above M are the band's: it stores them into the same buffer meanwhile
+                            rs.j1 = std::min(rs.j1, c->Ny); r1.j1 = std::min(r1.j1, c->Ny); r2.j1 = std::min(r2.j1, c->Ny);
+                        }
                         FusedTable* t = &host[NSINGLE + (mp * 2 + cur) * 2 + auf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
@@ -1045,6 +1101,10 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     c->last_trios = 0;
     const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (band) {
+        HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));      // the first band starts behind everything queued so far
+        HIP_TRY(c, hipEventRecord(c->band_ev_band, c->stream));      // (nothing for the first pair launch to wait for)
+    }
     for (int s = first; s < end;) {
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
         if (trios && end - s >= 3 && end - s != 4) {       // (4 = 2 + 2: never leave a single sub-step behind)
@@ -1054,14 +1114,20 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             ++c->last_trios;
         } else if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
-            if (band) { if ((rc = band_two_substeps(c, *band, fc, orig, alt, cur, s, s + 2 == end))) return rc; nlaunch += 6; }
+            if (band) {
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));       // the previous band: this launch's rows M + 1 .. M + 4
+                if ((rc = band_two_substeps(c, *band, fc, cur, s, s + 2 == end))) return rc;
+                nlaunch += 8;
+            }
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
                               peer ? ++c->peer.seq : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
+            if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 2; s += 2;
         } else if (band) {
-            if ((rc = band_substep(c, *band, fc, cur == 0 ? orig : alt, ufirst, -(1 << 30), s + 1 == end))) return rc;
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
+            if ((rc = band_substep(c, *band, fc, cur == 0 ? orig : alt, nullptr, ufirst, -(1 << 30), s + 1 == end, c->stream))) return rc;
             m += 1; s += 1;
             cur ^= 1;           // undone below: in place
             nlaunch += 2;
@@ -1100,6 +1166,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             m = 0;
         }
     }
+    if (band) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
     if (peer) {
         // the neighbours' last launch wrote into this rank's halos: wait for all of it before anything later on this stream
         // (the copy back, finalize_rheology!, the next exchange) reads them
@@ -1534,6 +1601,10 @@ int32_t csi_context_destroy(csi_context* c) {
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
+    for (int k = 0; k < 9; ++k) if (c->band[k]) hipFree(c->band[k]);
+    if (c->band_ev_pair) hipEventDestroy(c->band_ev_pair);
+    if (c->band_ev_band) hipEventDestroy(c->band_ev_band);
+    if (c->band_stream) hipStreamDestroy(c->band_stream);
     for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
     for (int k = 0; k < 2; ++k) if (c->fd[k]) hipFree(c->fd[k]);
     for (int k = 0; k < 2; ++k) if (c->xd[k]) hipFree(c->xd[k]);

@@ -1,9 +1,11 @@
 """Throughput of the EVP sub-cycle on the other SURVEY.md 8(d) style configurations (not the bench.py headline):
 2048^2, 120 sub-steps, FAST mode, fusion levels 0 / 1 / 2.  Run on the GPU box: python scripts/bench_cases.py"""
-import sys, time, json
+import os, sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import climaseaice_jl_amd as csi
 import cases
 
@@ -31,11 +33,12 @@ CONFIGS = {
 }
 if len(sys.argv) > 2:
     CONFIGS = {k: v for k, v in CONFIGS.items() if sys.argv[2] in k}
+LEVELS = (2,) if (len(sys.argv) > 3 and sys.argv[3] == "level2") else (0, 1, 2)
 out = {}
 for name, kw in CONFIGS.items():
     c = cases.make_case(Nx=N, Ny=N, substeps=120, patches=False, noise=0.05, **kw)
     row = {}
-    for level in (0, 1, 2):
+    for level in LEVELS:
         m = cases.csi_model(c, mode="fast")
         m.set_fusion(level)
         for _ in range(2):
