@@ -6,7 +6,7 @@ host-side mirror of the reference's `SeaIceModel` / `time_step!` surface.  The d
 contains a dot, so import it through the repo-root shim: `import climaseaice_jl_amd as csi`.
 """
 from . import _lib
-from ._lib import Context, CsiError, plan_exchange, plan_ranges
+from ._lib import Context, CsiError, LocalGroup, plan_exchange, plan_ranges
 from .dynamics import (Auxiliaries, BetaPlane, PointwiseCoriolis, ElastoViscoPlasticRheology, FPlane, IceStrength, ReplacementPressure,
                        SeaIceMomentumEquation, SemiImplicitStress, SplitExplicitSolver, StressBalanceFreeDrift)
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField

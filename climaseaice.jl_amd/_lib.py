@@ -30,7 +30,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_evp_initialize", "csi_evp_subcycle", "csi_evp_finalize", "csi_time_step_momentum",
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
-           "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_halo_exchange",
+           "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_local_group_create", "csi_local_group_destroy", "csi_comm_init_local", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
            "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
 
@@ -116,6 +116,7 @@ def load():
         "csi_comm_unique_id": [C.POINTER(C.c_uint8)],
         "csi_comm_init": [vp, i32, i32, C.POINTER(C.c_uint8)],
         "csi_comm_count": [vp, C.POINTER(i32)],
+        "csi_local_group_create": [i32, C.POINTER(vp)], "csi_comm_init_local": [vp, vp, i32],
         "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
         "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_plan_pair": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
@@ -136,6 +137,8 @@ def load():
         fn = getattr(L, name)
         fn.restype = i32
         fn.argtypes = args
+    L.csi_local_group_destroy.restype = None
+    L.csi_local_group_destroy.argtypes = [vp]
     _lib = L
     return L
 
@@ -172,6 +175,24 @@ def plan_exchange(Nx, Ny, Hx, Hy, topo_x, topo_y, rx, ry, Rx, Ry, periodic_x, pe
         raise CsiError(rc, "csi_plan_exchange")
     v = list(out)
     return [tuple(v[5 * k:5 * k + 5]) for k in range(8)]
+
+
+class LocalGroup:
+    """csi_local_group: the tiles of one process (one thread each) exchange halos through device copies instead of RCCL
+    (include/csi.h).  Pass it to TileGrid(..., local_group=...); keep it alive as long as its models."""
+
+    def __init__(self, world_size):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.csi_local_group_create(int(world_size), C.byref(self.h))
+        if rc != OK:
+            raise CsiError(rc, "csi_local_group_create")
+        self.world_size = int(world_size)
+
+    def close(self):
+        if self.h:
+            self.L.csi_local_group_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class Context:

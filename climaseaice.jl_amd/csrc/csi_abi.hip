@@ -17,6 +17,10 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +56,25 @@ std::string g_create_error;
 
 }  // namespace
 
+// ---- in-process tile group (csi_local_group_create / csi_comm_init_local) --------------------------------------------------
+// Several contexts of ONE process, one host thread each, exchange halos through device-to-device copies: what RCCL's grouped
+// ncclSend / ncclRecv do between processes, with the same matching rule (messages between a pair of ranks match in the order
+// they were posted).  Host-synchronous -- a sender waits for its pack kernel before it posts, a receiver for its copies before
+// it acknowledges -- because it exists for correctness runs of real decompositions on one GPU (RCCL refuses two ranks on one
+// device), not for speed.  The peer halo transport on such a group addresses the neighbours' arrays directly.
+struct csi_local_group {
+    struct Msg { const double* ptr; size_t count; };
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::deque<Msg>> box;              // [src * world + dst]
+    std::vector<long> posted, consumed;            // per sender: messages posted / copied out of its send buffer
+    // collectives (all ranks call them in the same order)
+    std::vector<std::vector<uint8_t>> payload;
+    long arrived = 0, generation = 0;
+    int joined = 0;
+};
+
 struct csi_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -81,6 +104,7 @@ struct csi_context {
     // multi-GPU tiles
     TileInfo tile;
     ncclComm_t comm = nullptr;
+    csi_local_group* local = nullptr;      // in-process tile group instead of an RCCL communicator (csi_comm_init_local)
     int world = 1, rank = 0;
     double *sendbuf = nullptr, *recvbuf = nullptr;
     size_t buf_cap = 0;   // elements per buffer
@@ -385,12 +409,89 @@ int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     return exchange_refs(c, fr, nf, W);
 }
 
+bool has_comm(const csi_context* c) { return c->comm != nullptr || c->local != nullptr; }
+
+constexpr int kLocalTimeoutSeconds = 120;
+// all ranks of the group: rank r's `nb` bytes end up in out[r * nb ...] everywhere
+int32_t local_allgather(csi_context* c, const void* mine, size_t nb, std::vector<uint8_t>& out) {
+    csi_local_group* G = c->local;
+    std::unique_lock<std::mutex> lk(G->mu);
+    const long gen = G->generation;
+    G->payload[c->rank].assign((const uint8_t*)mine, (const uint8_t*)mine + nb);
+    if (++G->arrived == G->world) {
+        // the last one in publishes: the payloads stay untouched until everybody of the NEXT collective has arrived
+        G->arrived = 0; ++G->generation;
+        G->cv.notify_all();
+    } else if (!G->cv.wait_for(lk, std::chrono::seconds(kLocalTimeoutSeconds), [&] { return G->generation != gen; })) {
+        return fail(c, CSI_ERR_COMM, "in-process tile group: a collective timed out (a rank did not arrive)");
+    }
+    out.resize(nb * (size_t)G->world);
+    for (int r = 0; r < G->world; ++r) {
+        if (G->payload[r].size() != nb) return fail(c, CSI_ERR_COMM, "in-process tile group: payload sizes differ");
+        memcpy(out.data() + (size_t)r * nb, G->payload[r].data(), nb);
+    }
+    // second phase: nobody overwrites its payload before all have read
+    const long gen2 = G->generation;
+    if (++G->arrived == G->world) { G->arrived = 0; ++G->generation; G->cv.notify_all(); }
+    else if (!G->cv.wait_for(lk, std::chrono::seconds(kLocalTimeoutSeconds), [&] { return G->generation != gen2; }))
+        return fail(c, CSI_ERR_COMM, "in-process tile group: a collective timed out (a rank did not arrive)");
+    return CSI_OK;
+}
+int32_t local_allreduce_min(csi_context* c, int* v) {
+    std::vector<uint8_t> all;
+    int32_t rc;
+    if ((rc = local_allgather(c, v, sizeof(int), all))) return rc;
+    for (int r = 0; r < c->world; ++r) { int x; memcpy(&x, all.data() + (size_t)r * sizeof(int), sizeof(int)); if (x < *v) *v = x; }
+    return CSI_OK;
+}
+// before the send buffer is packed again: every message posted from it has been copied out
+int32_t local_wait_consumed(csi_context* c) {
+    csi_local_group* G = c->local;
+    std::unique_lock<std::mutex> lk(G->mu);
+    if (!G->cv.wait_for(lk, std::chrono::seconds(kLocalTimeoutSeconds), [&] { return G->consumed[c->rank] == G->posted[c->rank]; }))
+        return fail(c, CSI_ERR_COMM, "in-process tile group: a neighbour never received this rank's previous halo message");
+    return CSI_OK;
+}
+// the grouped send / receive of exchange_refs
+int32_t local_sendrecv(csi_context* c, const long* soff, const long* scnt, const int* speer, const long* roff, const long* rcnt, const int* rpeer) {
+    csi_local_group* G = c->local;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                         // the pack kernel has filled the send buffer
+    int from[8], nfrom = 0;
+    {
+        std::unique_lock<std::mutex> lk(G->mu);
+        for (int k = 0; k < 8; ++k)
+            if (speer[k] >= 0 && scnt[k] > 0) {
+                G->box[(size_t)c->rank * G->world + speer[k]].push_back(csi_local_group::Msg{c->sendbuf + soff[k], (size_t)scnt[k]});
+                ++G->posted[c->rank];
+            }
+        G->cv.notify_all();
+        for (int k = 0; k < 8; ++k)
+            if (rpeer[k] >= 0 && rcnt[k] > 0) {
+                std::deque<csi_local_group::Msg>& q = G->box[(size_t)rpeer[k] * G->world + c->rank];
+                if (!G->cv.wait_for(lk, std::chrono::seconds(kLocalTimeoutSeconds), [&] { return !q.empty(); }))
+                    return fail(c, CSI_ERR_COMM, "in-process tile group: a halo message never arrived (a rank fell behind or died)");
+                const csi_local_group::Msg m = q.front();
+                q.pop_front();
+                if (m.count != (size_t)rcnt[k]) return fail(c, CSI_ERR_COMM, "in-process tile group: halo message of unexpected size (send / receive plans do not match)");
+                HIP_TRY(c, hipMemcpyAsync(c->recvbuf + roff[k], m.ptr, m.count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                from[nfrom++] = rpeer[k];
+            }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                         // the copies are done: the senders may repack
+    {
+        std::unique_lock<std::mutex> lk(G->mu);
+        for (int q = 0; q < nfrom; ++q) ++G->consumed[from[q]];
+        G->cv.notify_all();
+    }
+    return CSI_OK;
+}
+
 // the same on explicit array references (the fused path exchanges whichever ping-pong buffer is current): pack, one grouped
 // send / receive, unpack, all on the context stream
 int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
     if (!is_tiled(c)) return CSI_OK;
     if (!c->tile.set) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_tile_set has not been called");
-    if (!c->comm) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
+    if (!has_comm(c)) return fail(c, CSI_ERR_NOT_BOUND, "connected topology but csi_comm_init has not been called");
     if (nf > MAX_EX_FIELDS) return fail(c, CSI_ERR_INVALID_ARGUMENT, "too many fields in one exchange");
     if (W < 1 || W > c->Hx || W > c->Hy || W > c->Nx || W > c->Ny) return fail(c, CSI_ERR_INVALID_ARGUMENT, "exchange width out of range");
     ExPlan sp;
@@ -399,6 +500,8 @@ int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
     build_plan(c->g, c->tile, fr, nf, W, 0, sp, soff, scnt, speer);
     build_plan(c->g, c->tile, fr, nf, W, 1, c->pending_rp, roff, rcnt, rpeer);
     const size_t need_elems = (size_t)(sp.total > c->pending_rp.total ? sp.total : c->pending_rp.total);
+    int32_t lrc;
+    if (c->local && (lrc = local_wait_consumed(c))) return lrc;      // (before the send buffer is repacked -- or freed)
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->sendbuf) hipFree(c->sendbuf);
@@ -410,6 +513,12 @@ int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
         c->buf_cap = cap;
     }
     launch_pack(sp, c->sendbuf, 0, c->stream);
+    if (c->local) {
+        if ((lrc = local_sendrecv(c, soff, scnt, speer, roff, rcnt, rpeer))) return lrc;
+        launch_pack(c->pending_rp, c->recvbuf, 1, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        return CSI_OK;
+    }
     NCCL_TRY(c, ncclGroupStart());
     for (int k = 0; k < 8; ++k)
         if (speer[k] >= 0 && scnt[k] > 0) NCCL_TRY(c, ncclSend(c->sendbuf + soff[k], (size_t)scnt[k], ncclDouble, speer[k], c->comm, c->stream));
@@ -658,12 +767,13 @@ struct PeerRec {                 // what a rank tells the others about one of it
     uint64_t offset;             // of the buffer inside that allocation
     int64_t ld;                  // leading dimension (images use the sender's strides: they must agree)
     int32_t ok, pad;
+    uint64_t local_ptr;          // in-process tile group: the buffer itself (same address space)
 };
 constexpr int kPeerRecs = csi_context::Peer::NARR + 1;      // + the flag array
 
 // Collective over the context's communicator: every rank publishes IPC handles of its arrays and flags, maps its neighbours'.
 // Failure anywhere (no IPC, strides that differ across a side, sets larger than the flag array) makes EVERY rank stay on RCCL.
-int32_t peer_setup(csi_context* c) {
+int32_t peer_setup(csi_context* c, bool local_ok) {
     csi_context::Peer& pr = c->peer;
     HIP_TRY(c, hipSetDevice(c->device));                   // (allocations and IPC mappings below belong to the context's device)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -700,13 +810,14 @@ int32_t peer_setup(csi_context* c) {
                                                   c->f[CSI_F_U].ld, c->f[CSI_F_V].ld, c->f[CSI_F_S11].ld, c->f[CSI_F_S22].ld, c->f[CSI_F_S12].ld,
                                                   c->f[CSI_F_ALPHA].ld, c->f[CSI_F_ZETA_C].ld, c->f[CSI_F_ZETA_F].ld, c->f[CSI_F_DELTA].ld};
     std::vector<PeerRec> mine(kPeerRecs), all((size_t)kPeerRecs * c->world);
-    int ok = 1;
+    int ok = local_ok ? 1 : 0;          // (a rank whose own configuration rules the transport out still takes part: every rank or none)
     for (int q = 0; q < kPeerRecs; ++q) {
         const void* ptr = q < csi_context::Peer::NARR ? local[q] : (const void*)pr.slots;
         PeerRec& r = mine[q];
         memset(&r, 0, sizeof r);
         r.ld = q < csi_context::Peer::NARR ? lds[q] : 0;
-        if (c->world > 1) {                                  // (a single rank addresses its own arrays directly)
+        r.local_ptr = (uint64_t)ptr;
+        if (ok && c->world > 1 && !c->local) {               // (a single rank / an in-process group addresses the arrays directly)
             hipDeviceptr_t base = nullptr; size_t size = 0;
             if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) != hipSuccess || hipIpcGetMemHandle(&r.handle, base) != hipSuccess) {
                 (void)hipGetLastError();
@@ -717,7 +828,12 @@ int32_t peer_setup(csi_context* c) {
         }
         r.ok = ok;
     }
-    if (c->world > 1) {
+    if (c->local) {
+        std::vector<uint8_t> bytes;
+        int32_t lrc;
+        if ((lrc = local_allgather(c, mine.data(), sizeof(PeerRec) * kPeerRecs, bytes))) return lrc;
+        memcpy(all.data(), bytes.data(), bytes.size());
+    } else if (c->world > 1) {
         const size_t nb = sizeof(PeerRec) * kPeerRecs;
         HIP_TRY(c, hipMemcpy(pr.xbuf, mine.data(), nb, hipMemcpyHostToDevice));
         NCCL_TRY(c, ncclAllGather(pr.xbuf, pr.xbuf + nb, nb, ncclUint8, c->comm, c->stream));
@@ -732,6 +848,7 @@ int32_t peer_setup(csi_context* c) {
     auto resolve = [&](int rank, int q, void** out) -> bool {
         const PeerRec& r = all[(size_t)rank * kPeerRecs + q];
         if (!r.ok) return false;
+        if (c->local) { *out = (void*)r.local_ptr; return true; }
         for (const Mapped& m : cache)
             if (m.rank == rank && memcmp(&m.h, &r.handle, sizeof r.handle) == 0) { *out = (char*)m.p + r.offset; return true; }
         void* mp = nullptr;
@@ -754,7 +871,10 @@ int32_t peer_setup(csi_context* c) {
             pr.nbr_slots[d] = (unsigned long long*)sp;
         }
     }
-    if (c->world > 1) {                                      // every rank or none
+    if (c->local) {
+        int32_t lrc;
+        if ((lrc = local_allreduce_min(c, &ok))) return lrc;
+    } else if (c->world > 1) {                               // every rank or none
         int* flag = (int*)pr.xbuf;
         HIP_TRY(c, hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice));
         NCCL_TRY(c, ncclAllReduce(flag, flag, 1, ncclInt32, ncclMin, c->comm, c->stream));
@@ -772,20 +892,23 @@ int32_t peer_setup(csi_context* c) {
 int32_t peer_decide(csi_context* c, const EvpDev& P, int substeps, bool* use) {
     *use = false;
     csi_context::Peer& pr = c->peer;
-    if (!is_tiled(c) || !pr.want || pr.failed || !c->comm || !c->tile.set) return CSI_OK;
+    if (!is_tiled(c) || !pr.want || pr.failed || !has_comm(c) || !c->tile.set) return CSI_OK;
     if (c->exch_k > 0) return CSI_OK;                        // an explicit exchange interval asks for the RCCL exchange
     if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 1) return CSI_OK;      // (an odd count ends with one single-mode launch)
-    if (!pair_supported(c) || pair_forcing_kind(P) < 0) return CSI_OK;
-    if (c->f[CSI_F_U].ld != c->f[CSI_F_S12].ld || c->f[CSI_F_V].ld != c->f[CSI_F_S11].ld) return CSI_OK;
-    if (c->Nx < 128) return CSI_OK;                          // (a wave's x images all go to ONE neighbour: evp_fused2.hip)
+    // Everything above is the same on every rank; what follows may differ from tile to tile (the fold lives on the northernmost
+    // tile of a y partition only, a Bounded x partition has tiles of unequal strides): those conditions go INTO the collective
+    // set-up, which answers with the minimum over the ranks -- every rank or none.
+    const bool local_ok = pair_supported(c) && pair_forcing_kind(P) >= 0 &&
+                          c->f[CSI_F_U].ld == c->f[CSI_F_S12].ld && c->f[CSI_F_V].ld == c->f[CSI_F_S11].ld &&
+                          c->Nx >= 128;                      // (a wave's x images all go to ONE neighbour: evp_fused2.hip)
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
     const void* local[csi_context::Peer::NARR];
     peer_local_arrays(c, local);
     bool same = pr.ready;
     for (int q = 0; q < csi_context::Peer::NARR && same; ++q) same = pr.sig[q] == local[q];
-    if (!same && (rc = peer_setup(c))) return rc;
-    *use = pr.ready;
+    if (!same && (rc = peer_setup(c, local_ok))) return rc;
+    *use = pr.ready && local_ok;
     return CSI_OK;
 }
 
@@ -1998,6 +2121,7 @@ int32_t csi_comm_init(csi_context* c, int32_t world_size, int32_t rank, const ui
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank / world_size out of range");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    c->local = nullptr;
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     NCCL_TRY(c, ncclCommInitRank(&c->comm, world_size, id, rank));
@@ -2005,9 +2129,34 @@ int32_t csi_comm_init(csi_context* c, int32_t world_size, int32_t rank, const ui
     return CSI_OK;
 }
 
+int32_t csi_local_group_create(int32_t world_size, csi_local_group** out) {
+    if (!out || world_size < 1) return CSI_ERR_INVALID_ARGUMENT;
+    csi_local_group* G = new csi_local_group;
+    G->world = world_size;
+    G->box.resize((size_t)world_size * world_size);
+    G->posted.assign(world_size, 0); G->consumed.assign(world_size, 0);
+    G->payload.resize(world_size);
+    *out = G;
+    return CSI_OK;
+}
+
+void csi_local_group_destroy(csi_local_group* G) { delete G; }
+
+int32_t csi_comm_init_local(csi_context* c, csi_local_group* G, int32_t rank) {
+    if (!c || !G) return CSI_ERR_INVALID_ARGUMENT;
+    if (rank < 0 || rank >= G->world) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank out of range for this group");
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    c->local = G;
+    c->world = G->world; c->rank = rank;
+    std::unique_lock<std::mutex> lk(G->mu);
+    ++G->joined;
+    return CSI_OK;
+}
+
 int32_t csi_comm_count(csi_context* c, int32_t* ranks) {
     if (!c || !ranks) return CSI_ERR_INVALID_ARGUMENT;
     *ranks = 0;
+    if (c->local) { *ranks = c->local->world; return CSI_OK; }
     if (!c->comm) return CSI_OK;
     int n = 0;
     NCCL_TRY(c, ncclCommCount(c->comm, &n));

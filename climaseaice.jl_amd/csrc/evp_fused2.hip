@@ -147,10 +147,10 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         // halo images of a periodic side (the pair kernel only runs on periodic / connected / wall sides, N >= 2H):
         // column i in [1, H] is also stored at i + N, column in (N - H, N] at i - N; rows likewise
         dx = 0;
-        if (T->I[FI_XLO] == SIDE_PERIODIC) {
-            if ((i >= 1) & (i <= Hx)) dx = Nx * 8;
-            else if ((i > Nx - Hx) & (i <= Nx)) dx = -Nx * 8;
-        }
+        // (per side: on the peer transport a tile may have a wall on one side and a neighbour -- "periodic" -- on the other; the
+        //  images of the low columns serve the neighbour beyond the LOW side, whose high halo they fill)
+        if ((T->I[FI_XLO] == SIDE_PERIODIC) & (i >= 1) & (i <= Hx)) dx = Nx * 8;
+        else if ((T->I[FI_XHI] == SIDE_PERIODIC) & (i > Nx - Hx) & (i <= Nx)) dx = -Nx * 8;
         dxv = dx;
         if (WALLS) {
             // Walls (Bounded sides): faces on / beyond the wall are peripheral nodes (velocity 0); v, Center in x, is
@@ -240,16 +240,17 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     auto off2 = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * c2s; };
     const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
     // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
-    const bool wrap_y_b = T->I[FI_YLO] == SIDE_PERIODIC;
+    const bool wrap_lo_b = T->I[FI_YLO] == SIDE_PERIODIC, wrap_hi_b = T->I[FI_YHI] == SIDE_PERIODIC;      // (per side, as in x)
     const bool ylo_wall_b = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall_b = WALLS && T->I[FI_YHI] == SIDE_WALL;
     // ... unless that wall carries a ValueBoundaryCondition (IMG_VALUE): then ONE halo row, 2 val - u
     const bool uval_lo_b = WALLS && T->I[FI_IMU + 2] == IMG_VALUE, uval_hi_b = WALLS && T->I[FI_IMU + 3] == IMG_VALUE;
     // the wave-uniform switches of the row loop, packed into one scalar register (as separate bools each is a 64-bit lane mask)
-    enum : unsigned { U_WRAPY = 1, U_YLO = 2, U_YHI = 4, U_UVLO = 8, U_UVHI = 16, U_HASDX = 32, U_VALX = 64 };
-    const unsigned UF = (unsigned)__builtin_amdgcn_readfirstlane((int)((wrap_y_b ? U_WRAPY : 0u) | (ylo_wall_b ? U_YLO : 0u) | (yhi_wall_b ? U_YHI : 0u) |
+    enum : unsigned { U_WRAPLO = 1, U_YLO = 2, U_YHI = 4, U_UVLO = 8, U_UVHI = 16, U_HASDX = 32, U_VALX = 64, U_WRAPHI = 128 };
+    const unsigned UF = (unsigned)__builtin_amdgcn_readfirstlane((int)((wrap_lo_b ? U_WRAPLO : 0u) | (wrap_hi_b ? U_WRAPHI : 0u) | (ylo_wall_b ? U_YLO : 0u) | (yhi_wall_b ? U_YHI : 0u) |
                                                                          (uval_lo_b ? U_UVLO : 0u) | (uval_hi_b ? U_UVHI : 0u) |
                                                                          (wave_has_dx_b ? U_HASDX : 0u) | (wave_valx_b ? U_VALX : 0u)));
-#define wrap_y ((UF & U_WRAPY) != 0)
+#define wrap_lo ((UF & U_WRAPLO) != 0)
+#define wrap_hi ((UF & U_WRAPHI) != 0)
 #define ylo_wall (WALLS && (UF & U_YLO) != 0)
 #define yhi_wall (WALLS && (UF & U_YHI) != 0)
 #define uval_lo (WALLS && (UF & U_UVLO) != 0)
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
     // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
     auto yimg = [&](int j) __attribute__((always_inline)) {
-        return wrap_y ? (((j >= 1) & (j <= HyW)) ? NyW : (((j > NyW - HyW) & (j <= NyW)) ? -NyW : 0)) : 0;
+        return (wrap_lo & (j >= 1) & (j <= HyW)) ? NyW : ((wrap_hi & (j > NyW - HyW) & (j <= NyW)) ? -NyW : 0);
     };
     auto yimg_u = [&](int j) __attribute__((always_inline)) {
         int d = yimg(j);
@@ -389,8 +390,8 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         const int d1 = AUF ? 0 : 1;                                            // first velocity row = q - d1, second = q - 1
         fast_lo = max(rs_lo, max(r1_lo + d1, r2_lo + 1));
         fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
-        if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
-        if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
+        if (wrap_lo | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
+        if (wrap_hi | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
         if (!lanes_same) fast_hi = fast_lo - 1;
     }
     const bool fast_plain = lanes_uniform;                // no lane of the wave has an x image either
@@ -637,8 +638,8 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             const int d1 = AUF ? 1 : 0;
             fast_lo = max(rs_lo, max(r1_lo + d1, r2_lo + 1));
             fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
-            if (wrap_y | ylo_wall) fast_lo = max(fast_lo, HyW + 2);
-            if (wrap_y | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);
+            if (wrap_lo | ylo_wall) fast_lo = max(fast_lo, HyW + 2);
+            if (wrap_hi | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);
             if (!lanes_same) fast_hi = fast_lo - 1;
         }
         for (int r = rstart; r <= rend; ++r) {

@@ -316,6 +316,12 @@ class SeaIceModel:
         (torch.distributed when there is more than one process; plumbing only)."""
         self.ctx.call("csi_tile_set", g.rx, g.ry, g.Rx, g.Ry, int(g.periodic[0]), int(g.periodic[1]))
         world = g.Rx * g.Ry
+        if getattr(g, "local_group", None) is not None:      # several tiles in this process (one thread each): no RCCL
+            if g.local_group.world_size != world:
+                raise RuntimeError("the local group's size does not match the partition")
+            self._keep.append(g.local_group)
+            self.ctx.call("csi_comm_init_local", g.local_group.h, g.rank)
+            return
         idbuf = (C.c_uint8 * 128)()
         if world > 1:
             import torch.distributed as dist

@@ -335,6 +335,19 @@ int32_t csi_comm_init(csi_context* ctx, int32_t world_size, int32_t rank, const 
 /* Ranks of the context's RCCL communicator as RCCL itself reports them (ncclCommCount; 0 before csi_comm_init): what
  * bench.py prints as `rccl_ranks`, so that a run that silently fell back to one rank cannot report n_gpus > 1. */
 int32_t csi_comm_count(csi_context* ctx, int32_t* ranks);
+
+/* In-process tile group: several contexts of ONE process -- one host thread each, normally all on one GPU -- exchange their halos
+ * through device-to-device copies instead of RCCL (which refuses two ranks on one device), with RCCL's matching rule (messages
+ * between a pair of ranks match in the order they were posted: the same send / receive plans run); the peer halo transport
+ * addresses the neighbours' arrays directly.  Host-synchronous, built for correctness runs of real decompositions on a one-GPU
+ * machine (tests/test_gpu_local_tiles.py: 2 x 2, 1 x 4 with the fold tile, a Bounded x partition) and for a single process that
+ * drives several tiles.  Every context of a group calls the sub-cycle from its own thread; a rank that never arrives makes the
+ * others fail with CSI_ERR_COMM after two minutes instead of hanging.  The group outlives its contexts' use of it (destroy it
+ * after them).  csi_comm_init_local replaces csi_comm_init (csi_tile_set as usual); csi_comm_count reports the group size. */
+typedef struct csi_local_group csi_local_group;
+int32_t csi_local_group_create(int32_t world_size, csi_local_group** out);
+void csi_local_group_destroy(csi_local_group* group);
+int32_t csi_comm_init_local(csi_context* ctx, csi_local_group* group, int32_t rank);
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 

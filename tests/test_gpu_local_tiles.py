@@ -1,0 +1,113 @@
+"""Real decompositions on ONE GPU: every tile is its own context and host thread, the halos travel through the in-process tile
+group (csi_local_group: device-to-device copies with RCCL's matching rule instead of ncclSend / ncclRecv, include/csi.h) or --
+k = 0 -- through the peer transport, whose flags and image stores then connect DISTINCT tiles.  Same plans, same pack / unpack
+kernels, same launch loops as a multi-process RCCL run (tests/test_gpu_multirank.py, which needs one GPU per rank); tiled ==
+untiled bit for bit on the owned cells of every tile, for the sub-cycle and for one whole RK3 time step."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import climaseaice_jl_amd as csi
+from test_gpu_evp import EVP_FIELDS
+
+pytestmark = pytest.mark.gpu
+
+
+def run_tiles(c, Rx, Ry, k, full_step=True):
+    world = Rx * Ry
+    group = csi.LocalGroup(world)
+    out, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=(Rx, Ry, rank),
+                                local_group=group)
+            m.set_exchange_interval(max(k, 0))        # k = -1: automatic interval of the message exchange; k = 0: the peer transport
+            if k < 0:
+                m.set_halo_transport("rccl")
+            csi.time_step_momentum(m, c["dt"])
+            csi.time_step_momentum(m, c["dt"])
+            m.synchronize()
+            res = {f"mom_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+            res["path"] = dict(m.ctx.last_path(), transport=m.ctx.halo_transport(), ranks=m.ctx.comm_count())
+            if full_step:
+                csi.time_step(m, c["dt"])
+                m.synchronize()
+                res.update({f"step_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v")})
+                res["step_h"] = m.ice_thickness.interior_numpy().copy()
+                res["step_a"] = m.ice_concentration.interior_numpy().copy()
+            g = m.grid
+            res["offsets"] = (g.i_off, g.j_off, g.Nx, g.Ny)
+            out[rank] = res
+            del m
+        except BaseException as e:       # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, e))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a tile thread hangs"
+    if errors:
+        raise errors[0][1]
+    group.close()
+    return out
+
+
+def reference(c, full_step=True):
+    ref = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7))
+    csi.time_step_momentum(ref, c["dt"])
+    csi.time_step_momentum(ref, c["dt"])
+    ref.synchronize()
+    mom = {f: EVP_FIELDS[f](ref).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+    step = {}
+    if full_step:
+        csi.time_step(ref, c["dt"])
+        ref.synchronize()
+        step = {"u": ref.velocities.u.interior_numpy().copy(), "v": ref.velocities.v.interior_numpy().copy(),
+                "h": ref.ice_thickness.interior_numpy().copy(), "a": ref.ice_concentration.interior_numpy().copy()}
+    return mom, step
+
+
+def check(tiles, mom, step, what):
+    for rank, d in enumerate(tiles):
+        i0, j0, nx, ny = d["offsets"]
+        for f, want in mom.items():
+            got = d[f"mom_{f}"][:ny, :nx]
+            w = want[j0:j0 + ny, i0:i0 + nx]
+            assert np.array_equal(got, w), (what, "rank", rank, f, np.abs(got - w).max(), np.argwhere(got != w)[:4].tolist())
+        for f, want in step.items():
+            got = d[f"step_{f}"][:ny, :nx]
+            w = want[j0:j0 + ny, i0:i0 + nx]
+            assert np.array_equal(got, w), (what, "rank", rank, "step", f, np.abs(got - w).max(), np.argwhere(got != w)[:4].tolist())
+
+
+DECOMPOSITIONS = {
+    # name: (Rx, Ry, make_case keywords, does the peer transport apply (k = 0)?)
+    "2x2_periodic": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "periodic")), True),
+    "2x2_channel_land_arrays": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), land=0.2, field_forcing=True), True),
+    "4x1_periodic_x": (4, 1, dict(Nx=512, Ny=96, topo=("periodic", "bounded")), True),
+    "1x4_periodic_y": (1, 4, dict(Nx=160, Ny=256, topo=("periodic", "periodic")), True),
+    "2x1_bounded_x": (2, 1, dict(Nx=256, Ny=96, topo=("bounded", "periodic")), False),      # tiles of unequal strides: messages
+    "2x2_latlon": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), grid="latlon"), True),
+    "1x2_fold": (1, 2, dict(Nx=192, Ny=192, topo=("periodic", "folded")), False),           # the fold tile: three kernels
+    "1x4_fold_tripolar": (1, 4, dict(Nx=128, Ny=256, topo=("periodic", "folded"), curvilinear=0.04, land=0.2, field_forcing=True), False),
+}
+
+
+@pytest.mark.parametrize("k", [0, -1, 1, 2])
+@pytest.mark.parametrize("name", sorted(DECOMPOSITIONS))
+def test_local_tiles_bitwise(name, k):
+    Rx, Ry, kw, peer_ok = DECOMPOSITIONS[name]
+    c = cases.make_case(H=8, substeps=14, patches=True, random_uv=0.05, **kw)
+    mom, step = reference(c)
+    tiles = run_tiles(c, Rx, Ry, k)
+    for d in tiles:
+        assert d["path"]["ranks"] == Rx * Ry
+        if "fold" not in name:
+            assert d["path"]["transport"] == ("peer" if (k == 0 and peer_ok) else "rccl"), d["path"]
+    check(tiles, mom, step, (name, k))
