@@ -976,6 +976,10 @@ FusedGeom trio_geom(const csi_context* c, const Range& dec) {
 // pair launch (rows M - 7 .. M of its input).
 struct FoldBand {
     int M;
+    bool tiled;                     // the fold tile of a y partition: its south side is connected
+    int k;                          // exchange interval (tiled; 2 otherwise: one pair launch per band step)
+    GridDev g_full, g_cut;          // the tile as it is / with the band cut off and the north side "connected"
+    int Ny_full;
     EvpDev P;                       // the whole grid (fold geometry)
     ImageSpec imu, imv;
     Range rs, ru1, rv1, r2;         // the three kernels' ranges on the whole grid
@@ -1053,6 +1057,8 @@ int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc
     return CSI_OK;
 }
 
+static inline int nxf_of(int k) { return k > 1 ? 5 : 2; }     // sigma travels with u, v when k > 1 (see do_subcycle)
+
 // peer: the caller (run_fused_peer) has turned the connected sides of c->g / P.g into periodic ones: the launch loop is that of an
 // untiled periodic grid, the halo images of those sides go to the neighbouring tiles' arrays and every pair launch carries a
 // number of the flag protocol.  band: the caller (run_fused_fold) has cut the rows next to a north fold off c->g / P.g.
@@ -1060,9 +1066,15 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     int32_t rc;
     if ((rc = ensure_alt(c))) return rc;
     if (band && (rc = ensure_band(c))) return rc;
-    const bool tiled = is_tiled(c) && !band;
-    const int k = band ? 2 : exchange_interval(c), W = 2 * k;
-    const int nxf = k > 1 ? 5 : 2;                          // sigma travels with u, v when k > 1 (see do_subcycle)
+    const bool tiled = band ? band->tiled : is_tiled(c);
+    const int k = band ? band->k : exchange_interval(c), W = 2 * k;
+    // (band: the halo exchange of the fold tile is that of the tile as it is -- its north side has no neighbour)
+    auto exchange_tile = [&](const FRef* fr) -> int32_t {
+        if (band) { c->g = band->g_full; c->Ny = band->Ny_full; }
+        const int32_t r = exchange_refs(c, fr, nxf_of(k), W);
+        if (band) { c->g = band->g_cut; c->Ny = band->M; }
+        return r;
+    };
     const bool masked = P.g.has_mask != 0;
     const bool force = pair_forcing_kind(P) == 1;           // array-valued forcing: two-sub-steps kernel only
     const bool pairs = peer || (pair_supported(c) && (!tiled || k % 2 == 0));
@@ -1117,7 +1129,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     const int kb = tiled ? k : (pairs ? 2 : 1);             // batch length: positions 0 .. kb-1
     FRef orig[5], alt[5];
     for (int q = 0; q < 5; ++q) { orig[q] = ref_of(c, kPing[q]); alt[q] = alt_ref(c, q); }
-    if (tiled && (rc = exchange_refs(c, orig, nxf, W))) return rc;
+    if (tiled && (rc = exchange_tile(orig))) return rc;
     // both buffers start identical, so cells no sub-step ever writes (wall halos, the outermost halo layer of sigma
     // under the one-sub-step kernel) agree in both.  A fully periodic, untiled grid advanced by pair launches only
     // rewrites every cell of the five parents -- interior and all halo images -- at every launch: no copy needed.
@@ -1282,7 +1294,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         cur ^= 1;
         ++nlaunch;
         if (tiled && (m == kb || s == end)) {
-            if ((rc = exchange_refs(c, cur == 0 ? orig : alt, nxf, W))) return rc;
+            if ((rc = exchange_tile(cur == 0 ? orig : alt))) return rc;
             m = 0;
             ++nex;
         } else if (m >= kb) {
@@ -1341,17 +1353,24 @@ int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int subste
 }
 
 // A north fold on an untiled grid (RightFolded y, Periodic x): see FoldBand.
+struct FoldCut {        // RAII: the tile with the band cut off (rows 1 .. M, north side "connected")
+    csi_context* c; GridDev g; int Ny;
+    FoldCut(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
+    ~FoldCut() { c->g = g; c->Ny = Ny; }
+};
 bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps) {
     const GridDev& g = c->g;
-    if (g.yhi != SIDE_FOLD || g.ylo == SIDE_CONNECTED || g.xlo != SIDE_PERIODIC || g.xhi != SIDE_PERIODIC) return false;
+    if (g.yhi != SIDE_FOLD || g.xlo != SIDE_PERIODIC || g.xhi != SIDE_PERIODIC) return false;
     if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 2 || c->Hy < 4) return false;
+    if (g.ylo == SIDE_CONNECTED) {
+        // the fold tile of a y partition: the k-batched message exchange with the tile below, pair launches need an even k
+        // (and an even sub-step count: a trailing single sub-step would need the three kernels' batch-position ranges)
+        const int k = exchange_interval(c);
+        if (k % 2 != 0 || substeps % 2 != 0 || !has_comm(c) || !c->tile.set) return false;
+    }
     const int M = c->Ny - c->Hy - 4;
     if (M < 2 * c->Hy + 8) return false;
-    struct Swap {
-        csi_context* c; GridDev g; int Ny;
-        Swap(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
-        ~Swap() { c->g = g; c->Ny = Ny; }
-    } swap(c, M);
+    FoldCut cut(c, M);
     EvpDev P = Pfull;
     P.g = c->g;
     return pair_supported(c) && pair_forcing_kind(P) >= 0;
@@ -1359,14 +1378,14 @@ bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps) {
 int32_t run_fused_fold(csi_context* c, const EvpDev& Pfull, const FastCoef& fc, int substeps, int first) {
     FoldBand bd;
     bd.M = c->Ny - c->Hy - 4;
+    bd.tiled = c->g.ylo == SIDE_CONNECTED;
+    bd.k = bd.tiled ? exchange_interval(c) : 2;
+    bd.g_full = c->g; bd.Ny_full = c->Ny;
     bd.P = Pfull;
     bd.imu = image_spec(c, CSI_F_U); bd.imv = image_spec(c, CSI_F_V);
     bd.rs = stress_range(c); bd.ru1 = first_u_range(c); bd.rv1 = first_v_range(c); bd.r2 = second_range(c);
-    struct Swap {
-        csi_context* c; GridDev g; int Ny;
-        Swap(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
-        ~Swap() { c->g = g; c->Ny = Ny; }
-    } swap(c, bd.M);
+    FoldCut cut(c, bd.M);
+    bd.g_cut = c->g;
     EvpDev P = Pfull;
     P.g = c->g;
     return run_fused(c, P, fc, substeps, first, false, &bd);

@@ -108,6 +108,7 @@ def test_local_tiles_bitwise(name, k):
     tiles = run_tiles(c, Rx, Ry, k)
     for d in tiles:
         assert d["path"]["ranks"] == Rx * Ry
-        if "fold" not in name:
-            assert d["path"]["transport"] == ("peer" if (k == 0 and peer_ok) else "rccl"), d["path"]
+        assert d["path"]["transport"] == ("peer" if (k == 0 and peer_ok) else "rccl"), d["path"]
+        # the fold tile too runs the two-sub-steps kernel (below its three-kernel band) whenever the exchange interval is even
+        assert (d["path"]["level"] in (0, 1)) if k == 1 else (d["path"]["level"] == 2), d["path"]
     check(tiles, mom, step, (name, k))
