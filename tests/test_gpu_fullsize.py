@@ -251,6 +251,40 @@ def test_config4_latlon_tile_bitwise(k):
         assert np.array_equal(want[f], got[f]), (f, np.abs(want[f] - got[f]).max(), np.argwhere(want[f] != got[f])[:4])
 
 
+@pytest.mark.parametrize("k", [0, -1])
+def test_config4_latlon_2x4_decomposition_bitwise(k):
+    """Config 4 in its own decomposition: the 2048^2 lat-lon channel as 2 x 4 DISTINCT tiles (1024 x 512 each; a wall on one y
+    side, a neighbour on the other for the top and bottom rows of tiles), one RK3 step with WENO7 advection, 3 x 120 EVP
+    sub-steps and slab thermodynamics per tile -- every tile its own context, stream and host thread on this one GPU, halos
+    through the in-process tile group (tests/test_gpu_local_tiles.py): k = 0 the peer transport (halo 4, images stored straight
+    into the neighbours' arrays, per-tile flags between distinct tiles), k = -1 the message exchange at its automatic interval.
+    Owned cells of all eight tiles equal the untiled run bit for bit."""
+    from test_gpu_local_tiles import run_tile_threads
+    N, Rx, Ry = 2048, 2, 4
+    c = latlon_case(N, 4 if k == 0 else 16, ("periodic", "bounded"))
+    ref = full_model(c, "fast")
+    csi.time_step(ref, c["dt"])
+    want = model_state(ref)
+    del ref
+
+    def tile(rank, group):
+        m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=(Rx, Ry, rank),
+                            local_group=group, ice_thermodynamics=slab())
+        if k < 0:
+            m.set_halo_transport("rccl")
+        csi.time_step(m, c["dt"])
+        got = model_state(m)
+        g = m.grid
+        return got, (g.i_off, g.j_off, g.Nx, g.Ny), dict(m.ctx.last_path(), transport=m.ctx.halo_transport())
+
+    for rank, (got, (i0, j0, nx, ny), path) in enumerate(run_tile_threads(Rx * Ry, tile)):
+        assert path["transport"] == ("peer" if k == 0 else "rccl") and path["level"] == 2, path
+        for f in want:
+            w = want[f][j0:j0 + ny, i0:i0 + nx]
+            g_ = got[f][:ny, :nx]
+            assert np.array_equal(w, g_), (rank, f, np.abs(w - g_).max(), np.argwhere(w != g_)[:4].tolist())
+
+
 def config5_case(N, substeps):
     """4096^2 uniform 2 km channel (periodic x, walls in y), land = seeded discs covering 30 % + solid caps of N / 32
     rows at both walls, h = aice = 0 on land."""
@@ -300,3 +334,29 @@ def test_config5_tile_2048x1024_bitwise(transport):
     assert p1["level"] == 2 and p2["level"] == 2 and (p2["exchange_interval"] == 8 if transport == "rccl" else p2["exchanges"] == 1), (p1, p2)
     for f in want:
         assert np.array_equal(want[f], got[f]), (f, np.abs(want[f] - got[f]).max())
+
+
+def test_config5_masked_4096_2x4_decomposition_bitwise():
+    """Config 5 in its own decomposition: the 4096^2 masked channel, 500 sub-steps, as 2 x 4 DISTINCT tiles of 2048 x 1024 on
+    this one GPU (in-process tile group), peer transport: images stored into the neighbours' arrays, flags between distinct
+    tiles, one message exchange per sub-cycle.  Owned cells of all eight tiles equal the untiled run bit for bit."""
+    from test_gpu_local_tiles import run_tile_threads
+    N, Rx, Ry = 4096, 2, 4
+    c = config5_case(N, 500)
+    want, p1 = run_cycle(c, "fast", fusion=2)
+    assert p1["level"] == 2
+
+    def tile(rank, group):
+        m = cases.csi_model(c, mode="fast", tile=(Rx, Ry, rank), local_group=group)
+        csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        got = {f: EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+        g = m.grid
+        return got, (g.i_off, g.j_off, g.Nx, g.Ny), dict(m.ctx.last_path(), transport=m.ctx.halo_transport())
+
+    for rank, (got, (i0, j0, nx, ny), path) in enumerate(run_tile_threads(Rx * Ry, tile)):
+        assert path["transport"] == "peer" and path["level"] == 2 and path["exchanges"] == 1, path
+        for f in want:
+            w = want[f][j0:j0 + ny, i0:i0 + nx]
+            g_ = got[f][:ny, :nx]
+            assert np.array_equal(w, g_), (rank, f, np.abs(w - g_).max(), np.argwhere(w != g_)[:4].tolist())

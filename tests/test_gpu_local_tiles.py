@@ -16,33 +16,14 @@ from test_gpu_evp import EVP_FIELDS
 pytestmark = pytest.mark.gpu
 
 
-def run_tiles(c, Rx, Ry, k, full_step=True):
-    world = Rx * Ry
+def run_tile_threads(world, tile_fn):
+    """tile_fn(rank, group) -> result, one host thread per tile of a csi.LocalGroup; the results in rank order"""
     group = csi.LocalGroup(world)
     out, errors = [None] * world, []
 
     def work(rank):
         try:
-            m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=(Rx, Ry, rank),
-                                local_group=group)
-            m.set_exchange_interval(max(k, 0))        # k = -1: automatic interval of the message exchange; k = 0: the peer transport
-            if k < 0:
-                m.set_halo_transport("rccl")
-            csi.time_step_momentum(m, c["dt"])
-            csi.time_step_momentum(m, c["dt"])
-            m.synchronize()
-            res = {f"mom_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
-            res["path"] = dict(m.ctx.last_path(), transport=m.ctx.halo_transport(), ranks=m.ctx.comm_count())
-            if full_step:
-                csi.time_step(m, c["dt"])
-                m.synchronize()
-                res.update({f"step_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v")})
-                res["step_h"] = m.ice_thickness.interior_numpy().copy()
-                res["step_a"] = m.ice_concentration.interior_numpy().copy()
-            g = m.grid
-            res["offsets"] = (g.i_off, g.j_off, g.Nx, g.Ny)
-            out[rank] = res
-            del m
+            out[rank] = tile_fn(rank, group)
         except BaseException as e:       # noqa: BLE001 -- reported by the main thread
             errors.append((rank, e))
 
@@ -50,12 +31,38 @@ def run_tiles(c, Rx, Ry, k, full_step=True):
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=600)
+        t.join(timeout=900)
     assert not any(t.is_alive() for t in threads), "a tile thread hangs"
     if errors:
         raise errors[0][1]
     group.close()
     return out
+
+
+def run_tiles(c, Rx, Ry, k, full_step=True):
+    def tile(rank, group):
+        m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=(Rx, Ry, rank),
+                            local_group=group)
+        m.set_exchange_interval(max(k, 0))        # k = -1: automatic interval of the message exchange; k = 0: the peer transport
+        if k < 0:
+            m.set_halo_transport("rccl")
+        csi.time_step_momentum(m, c["dt"])
+        csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        res = {f"mom_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+        res["path"] = dict(m.ctx.last_path(), transport=m.ctx.halo_transport(), ranks=m.ctx.comm_count())
+        if full_step:
+            csi.time_step(m, c["dt"])
+            m.synchronize()
+            res.update({f"step_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v")})
+            res["step_h"] = m.ice_thickness.interior_numpy().copy()
+            res["step_a"] = m.ice_concentration.interior_numpy().copy()
+        g = m.grid
+        res["offsets"] = (g.i_off, g.j_off, g.Nx, g.Ny)
+        del m
+        return res
+
+    return run_tile_threads(Rx * Ry, tile)
 
 
 def reference(c, full_step=True):
