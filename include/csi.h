@@ -69,7 +69,8 @@ typedef enum {
      * test/distributed_tests_utils.jl:239).  Fusion level 2 on an untiled RIGHT_FOLDED grid: rows 1 .. Ny - Hy - 4 run
      * through the two-sub-steps kernel, the rows next to the fold through the three kernels on their own stream (they read and
      * store fold images like the reference's kernels; csi_abi.hip FoldBand) -- bit-identical to the three-kernel run of the whole
-     * grid.  The fold tile of a y partition (LEFT_CONNECTED_RIGHT_FOLDED) and fusion level 1 stay on the three kernels. */
+     * grid; the fold tile of a y partition (LEFT_CONNECTED_RIGHT_FOLDED) does the same when the exchange interval is even.  Fusion
+     * level 1 stays on the three kernels. */
     CSI_RIGHT_FOLDED = 5,
     CSI_LEFT_CONNECTED_RIGHT_FOLDED = 6   /* the northernmost tile of a y partition of such a grid */
 } csi_topology;
