@@ -118,6 +118,7 @@ struct csi_context {
         static constexpr int NARR = 14;      // u, v, sigma11, sigma22, sigma12 (caller's), the same five (library's ping-pong copies), alpha, zeta_c, zeta_f, Delta
         static constexpr int SLOTS = 1024;   // flag slots per direction
         int want = 1;                        // csi_set_halo_transport: 1 peer where possible, 0 RCCL only
+        int dld[8][2] = {};                  // per direction x {Center, Face in x}: the neighbour's row stride minus this tile's, bytes
         bool ready = false, failed = false;  // set up (collectively) / cannot be set up (stays on RCCL)
         const void* sig[NARR] = {};          // the local arrays the set-up was made for
         int img_rank[8], sync_rank[8];       // per direction: the rank whose arrays receive this tile's images there; the neighbour to wait for (-1: none)
@@ -862,7 +863,19 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         const int r = pr.img_rank[d];
         for (int q = 0; q < csi_context::Peer::NARR; ++q) {
             if (r == me) { pr.arr[d][q] = const_cast<void*>(local[q]); continue; }
-            if (!resolve(r, q, &pr.arr[d][q]) || all[(size_t)r * kPeerRecs + q].ld != lds[q]) { ok = 0; break; }
+            if (!resolve(r, q, &pr.arr[d][q])) { ok = 0; break; }
+        }
+        // the neighbour's row strides may differ from this tile's (a Bounded x direction partitioned in x gives the easternmost
+        // tile one more column of Face points): one difference per direction and location in x, which the image stores add per
+        // parent row -- provided the neighbour's arrays of one location share a stride, as this tile's do
+        pr.dld[d][0] = pr.dld[d][1] = 0;
+        if (ok && r != me) {
+            static const int cls[csi_context::Peer::NARR] = {1, 0, 0, 0, 1, 1, 0, 0, 0, 1, 0, 0, 1, 0};      // Face in x: u, sigma12, zeta_f
+            for (int q = 0; q < csi_context::Peer::NARR; ++q) {
+                const int64_t diff = all[(size_t)r * kPeerRecs + q].ld - lds[q];
+                if (diff != all[(size_t)r * kPeerRecs + (cls[q] ? 0 : 1)].ld - lds[cls[q] ? 0 : 1] || diff < -64 || diff > 64) { ok = 0; break; }
+                pr.dld[d][cls[q]] = (int)diff * 8;
+            }
         }
         pr.nbr_slots[d] = nullptr;
         if (ok && pr.sync_rank[d] >= 0) {
@@ -931,6 +944,10 @@ int32_t peer_fill_table(csi_context* c, const FusedGeom& G, bool out_is_alt, Fus
         t->I[FI_PWAIT + d] = ps.n[d];
         if (pr.sync_rank[d] >= 0) mask |= 1 << d;
     }
+    int any = 0;
+    for (int d = 0; d < 8; ++d)
+        for (int q = 0; q < 2; ++q) { t->I[FI_PDLD + d * 2 + q] = pr.dld[d][q]; any |= pr.dld[d][q] != 0; }
+    t->I[FI_PHASDLD] = any;
     t->P[FP_PERR] = (unsigned long)pr.err;
     t->I[FI_PEER] = 1; t->I[FI_PMASK] = mask;
     t->I[FI_PSET] = ps.nW; t->I[FI_PSET + 1] = ps.nE; t->I[FI_PSET + 2] = ps.nS; t->I[FI_PSET + 3] = ps.nN;
@@ -1231,6 +1248,9 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
         c->ring_used[slot] = true;
     }
+    unsigned long long peer_dld_bit = 0ull;      // neighbours with other row strides: the DLD instantiation (bit 63 of the launch number)
+    if (peer)
+        for (int d = 0; d < 8; ++d) if (c->peer.dld[d][0] | c->peer.dld[d][1]) peer_dld_bit = 1ull << 63;
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0;
     c->last_trios = 0;
@@ -1256,8 +1276,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             }
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
-                              peer ? ++c->peer.seq : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
+                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
+                              peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 2; s += 2;
         } else if (band) {
@@ -1270,8 +1290,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             // one sub-step through the two-sub-steps kernel (write_diag bit 1): masks, array forcing, per-point metrics
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force, masked, force, P.free_drift != 0, extra, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
-                              2 | (s + 1 == end ? 1 : 0), peer ? ++c->peer.seq : 0ull, c->stream);
+                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
+                              2 | (s + 1 == end ? 1 : 0), peer ? (++c->peer.seq | peer_dld_bit) : 0ull, c->stream);
             m += 1; s += 1;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
             // (no pair kernel for this grid -- halo < 4, tiny tiles: the three kernels in place on whichever buffer is current)

@@ -58,7 +58,10 @@ enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_
              FI_EXTRA,                  // EXTRA instantiations: bit 0 model.forcing arrays, bit 1 immersed flux boundary conditions
              FI_PEER,                   // 1: peer-connected sides (flags instead of a halo exchange, evp_fused2.hip)
              FI_PSET, FI_PMASK = FI_PSET + 4,   // tile sets next to the W / E / S / N side: strips, strips, chunks, chunks; directions with a neighbour
-             FI_PWAIT, FI_COUNT = FI_PWAIT + 8 };   // slots to wait for per direction (= the size of the neighbour's opposite set)
+             FI_PWAIT,                  // slots to wait for per direction (= the size of the neighbour's opposite set)
+             FI_PDLD = FI_PWAIT + 8,    // per direction x {Center in x, Face in x}: the neighbour's row stride minus this tile's, in bytes
+             FI_PHASDLD = FI_PDLD + 16, // any of them non-zero (a Bounded x direction partitioned in x: the easternmost tile's Face fields are one column wider)
+             FI_COUNT };
 struct FusedTable {
     double K[FK_COUNT];
     unsigned long P[FP_COUNT];

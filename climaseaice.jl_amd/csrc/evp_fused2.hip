@@ -94,7 +94,7 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, bool EXTRA = false>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, bool EXTRA = false, bool DLD = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool PRE = CSI_PAIR_PRE && !MASK;
@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
 #define uval_hi (WALLS && (UF & U_UVHI) != 0)
 #define wave_has_dx ((UF & U_HASDX) != 0)
 #define wave_valx (WALLS && (UF & U_VALX) != 0)
+#define has_dld (PEER && DLD)      // (an instantiation of its own: compiled into the common PEER one it cost 3 - 4 % of its launch time, not taken)
     // peripheral nodes of a row (walls only): u faces of rows beyond a y wall, v faces on / beyond it
     auto wall_row = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j < 1)) | (yhi_wall & (j > NyW)); };
     auto wall_vrow = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j <= 1)) | (yhi_wall & (j > NyW)); };
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     // PEER: the lanes of a wave that store x images all lie on one side of the tile (csi_abi.hip admits tiles of 128 columns or
     // more), so the neighbour -- the base address -- is wave-uniform
     const bool wave_low = PEER && __builtin_amdgcn_ballot_w64(((flags & L_LOW) != 0) & ((dx != 0) | (dxv != 0))) != 0;
-    auto put4 = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val, double valy, double valx, double valxy) __attribute__((always_inline)) {
+    auto put4 = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val, double valy, double valx, double valxy, int j, int yr) __attribute__((always_inline)) {
         const unsigned long base = own(k);
         auto sti = [&](unsigned long b_, unsigned o_, double v_) __attribute__((always_inline)) {
             if constexpr (PEER && (CSI_PEER_EXP & 2) != 0)
@@ -355,6 +356,22 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             else stg(b_, o_, v_);
         };
         stg(base, off, val);
+        if constexpr (PEER) {
+            // neighbours whose arrays have another row stride (FI_PDLD): the image of parent row p sits p * (their stride - ours)
+            // bytes further on (j: the row of `off`, wave-uniform -- scalar arithmetic, in a branch of its own)
+            if (has_dld) {
+                const int cls = (k == 2 || k == 3 || k == 7) ? 1 : 0;          // sigma12, u, zeta_f: Face in x
+                const int p0 = j + HyW - 1, p1 = p0 + yr;                      // parent rows of the cell / of its y image (yr rows away)
+                const int dY = ylow ? D_S : D_N, dX = wave_low ? D_W : D_E;
+                const int dXY = ylow ? (wave_low ? D_SW : D_SE) : (wave_low ? D_NW : D_NE);
+                if (dy != 0u) sti(img(k, dY), off + dy + (unsigned)(p1 * T->I[FI_PDLD + dY * 2 + cls]), valy);
+                if (wave_has_dx && dxl != 0) {
+                    sti(img(k, dX), off + (unsigned)dxl + (unsigned)(p0 * T->I[FI_PDLD + dX * 2 + cls]), valx);
+                    if (dy != 0u) sti(img(k, dXY), off + (unsigned)dxl + dy + (unsigned)(p1 * T->I[FI_PDLD + dXY * 2 + cls]), valxy);
+                }
+                return;
+            }
+        }
         if (dy != 0u) sti(PEER ? (ylow ? img(k, D_S) : img(k, D_N)) : base, off + dy, valy);
         if (wave_has_dx) {
             if (dxl != 0) {
@@ -363,25 +380,25 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             }
         }
     };
-    auto put = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val) __attribute__((always_inline)) {
-        put4(k, off, dy, ylow, dxl, val, val, val, val);
+    auto put = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val, int j, int yr) __attribute__((always_inline)) {
+        put4(k, off, dy, ylow, dxl, val, val, val, val, j, yr);
     };
     // u of row j: its y image is a reflection about 2 val on a ValueBoundaryCondition wall
-    auto put_u = [&](unsigned off, int j, unsigned dy, double val) __attribute__((always_inline)) {
+    auto put_u = [&](unsigned off, int j, unsigned dy, double val, int yr) __attribute__((always_inline)) {
         double vy = val;
         if (WALLS) {
             if (uval_lo & ylo_wall & (j == 1)) vy = 2 * T->K[FK_BCU] - val;
             if (uval_hi & yhi_wall & (j == NyW)) vy = 2 * T->K[FK_BCU + 1] - val;
         }
-        put4(3, off, dy, j <= HyW, dx, val, vy, val, vy);
+        put4(3, off, dy, j <= HyW, dx, val, vy, val, vy, j, yr);
     };
-    auto put_v = [&](unsigned off, unsigned dy, bool ylow, double val) __attribute__((always_inline)) {
+    auto put_v = [&](unsigned off, unsigned dy, bool ylow, double val, int j, int yr) __attribute__((always_inline)) {
         double vx = val;
         if (WALLS && wave_valx) {
             if (flags & L_VAL_LO) vx = 2 * T->K[FK_BCV] - val;
             if (flags & L_VAL_HI) vx = 2 * T->K[FK_BCV + 1] - val;
         }
-        put4(4, off, dy, ylow, dxv, val, val, vx, vx);
+        put4(4, off, dy, ylow, dxv, val, val, vx, vx, j, yr);
     };
     // rows q for which every kind of store is due and no row has a y image: with lanes_uniform this is the common
     // store path (two scalar compares per row instead of the full bookkeeping)
@@ -419,9 +436,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 } else {
                     // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap / the
                     // neighbouring tile's halo; v mirrors / reflects across an x wall), none of the row bookkeeping of the general path
-                    if (which & 1) { put(0, ocq, 0u, false, dx, v11); put(1, ocq, 0u, false, dx, v22); put(2, ofq, 0u, false, dx, v12); }
-                    if (VF) { if (which & 2) put_v(ocq, 0u, false, vfirst); if (which & 4) put(3, ofq - sf, 0u, false, dx, vsecond); }
-                    else { if (which & 2) put(3, ofq - sf, 0u, false, dx, vfirst); if (which & 4) put_v(ocq - sc, 0u, false, vsecond); }
+                    if (which & 1) { put(0, ocq, 0u, false, dx, v11, q, 0); put(1, ocq, 0u, false, dx, v22, q, 0); put(2, ofq, 0u, false, dx, v12, q, 0); }
+                    if (VF) { if (which & 2) put_v(ocq, 0u, false, vfirst, q, 0); if (which & 4) put(3, ofq - sf, 0u, false, dx, vsecond, q - 1, 0); }
+                    else { if (which & 2) put(3, ofq - sf, 0u, false, dx, vfirst, q - 1, 0); if (which & 4) put_v(ocq - sc, 0u, false, vsecond, q - 1, 0); }
                 }
             }
             return;
@@ -436,15 +453,15 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         // rows of the images: sigma wraps only; u (the first velocity when B is u-first) may mirror
         const int yq = yimg(q), y1 = VF ? yimg(j1) : yimg_u(j1), y2 = VF ? yimg_u(j2) : yimg(j2);
         if (do_s & ((flags & L_RS) != 0)) {
-            put(0, ocq, (unsigned)yq * sc, q <= HyW, dx, v11);
-            put(1, ocq, (unsigned)yq * sc, q <= HyW, dx, v22);
-            put(2, ofq, (unsigned)yq * sf, q <= HyW, dx, v12);
+            put(0, ocq, (unsigned)yq * sc, q <= HyW, dx, v11, q, yq);
+            put(1, ocq, (unsigned)yq * sc, q <= HyW, dx, v22, q, yq);
+            put(2, ofq, (unsigned)yq * sf, q <= HyW, dx, v12, q, yq);
         }
         if (do_1 & ((flags & L_R1) != 0)) {
-            if (VF) put_v(o1, (unsigned)y1 * sc, j1 <= HyW, vfirst); else put_u(o1, j1, (unsigned)y1 * sf, vfirst);
+            if (VF) put_v(o1, (unsigned)y1 * sc, j1 <= HyW, vfirst, j1, y1); else put_u(o1, j1, (unsigned)y1 * sf, vfirst, y1);
         }
         if (do_2 & ((flags & L_R2) != 0)) {
-            if (VF) put_u(o2, j2, (unsigned)y2 * sf, vsecond); else put_v(o2, (unsigned)y2 * sc, j2 <= HyW, vsecond);
+            if (VF) put_u(o2, j2, (unsigned)y2 * sf, vsecond, y2); else put_v(o2, (unsigned)y2 * sc, j2 <= HyW, vsecond, j2, y2);
         }
     };
     // ring slot of row j (lane-private column): element f of row j sits at ring[((j - rstart) & 3) * 5 + f][lane]
@@ -654,10 +671,10 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 if (((flags & L_RS) != 0) & (r >= rs_lo) & (r <= rs_hi)) {
                     const unsigned ocq = offc(r), ofq = offf(r);
                     const int yq = yimg(r);
-                    put(5, ocq, (unsigned)yq * sc, r <= HyW, dx, dal);
-                    put(7, ofq, (unsigned)yq * sf, r <= HyW, dx, dzf);
-                    put(6, ocq, (unsigned)yq * sc, r <= HyW, dx, dzc);
-                    put(8, ocq, (unsigned)yq * sc, r <= HyW, dx, ddl);
+                    put(5, ocq, (unsigned)yq * sc, r <= HyW, dx, dal, r, yq);
+                    put(7, ofq, (unsigned)yq * sf, r <= HyW, dx, dzf, r, yq);
+                    put(6, ocq, (unsigned)yq * sc, r <= HyW, dx, dzc, r, yq);
+                    put(8, ocq, (unsigned)yq * sc, r <= HyW, dx, ddl, r, yq);
                 }
             }
         }
@@ -744,10 +761,10 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             if (((flags & L_RS) != 0) & (q >= rs_lo) & (q <= rs_hi)) {
                 const unsigned ocq = offc(q), ofq = offf(q);
                 const int yq = yimg(q);
-                put(5, ocq, (unsigned)yq * sc, q <= HyW, dx, B.AL_0);
-                put(7, ofq, (unsigned)yq * sf, q <= HyW, dx, 0.5 * B.zf);       // the stage carries 2 zeta
-                put(6, ocq, (unsigned)yq * sc, q <= HyW, dx, 0.5 * B.zc);
-                put(8, ocq, (unsigned)yq * sc, q <= HyW, dx, B.Dc * B.rDc);         // ... and Delta^2, 1 / Delta
+                put(5, ocq, (unsigned)yq * sc, q <= HyW, dx, B.AL_0, q, yq);
+                put(7, ofq, (unsigned)yq * sf, q <= HyW, dx, 0.5 * B.zf, q, yq);       // the stage carries 2 zeta
+                put(6, ocq, (unsigned)yq * sc, q <= HyW, dx, 0.5 * B.zc, q, yq);
+                put(8, ocq, (unsigned)yq * sc, q <= HyW, dx, B.Dc * B.rDc, q, yq);         // ... and Delta^2, 1 / Delta
             }
         }
         B.shift(bu_p, bv_p, bm_0, ba_0);
@@ -821,8 +838,18 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int c
     const int per_xcd = (nblocks + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(128);
     // seq != 0: the instantiation with the peer-flag protocol (tiles next to a connected side wait for / signal their neighbours)
+    // ... bit 63 of seq: neighbours with other row strides (FI_PDLD; walls somewhere, so not in the plain variant)
+    const bool dld = (seq >> 63) != 0;
+    seq &= ~(1ull << 63);
+    (void)dld;
+#if CSI_PAIR_VARIANT >= 1
+#define CSI_LAUNCH_PAIR_(U, A, C, F) do { if (seq && dld) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, true, CSI_PAIR_EXTRA, true>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); \
+                                          else if (seq) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, true, CSI_PAIR_EXTRA>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); \
+                                          else hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, false, CSI_PAIR_EXTRA>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); } while (0)
+#else
 #define CSI_LAUNCH_PAIR_(U, A, C, F) do { if (seq) hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, true, CSI_PAIR_EXTRA>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); \
                                           else hipLaunchKernelGGL((fused::k_pair<U, A, CSI_PAIR_FLAGS, C, F, false, CSI_PAIR_EXTRA>), grid, block, 0, s, dev_table, nstrips, nchunks, rows, per_xcd, write_diag, seq); } while (0)
+#endif
 #if CSI_PAIR_VARIANT <= 2
 #define CSI_LAUNCH_PAIR(U, A) do { if (common == 2) CSI_LAUNCH_PAIR_(U, A, 2, false); else if (common) CSI_LAUNCH_PAIR_(U, A, 1, false); else CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #else

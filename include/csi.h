@@ -391,9 +391,9 @@ int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
  * the tiles next to a connected side wait, the interior of a launch overlaps the neighbours' edges).  No pack / unpack kernels,
  * no RCCL kernel inside the sub-cycle, no widened halo: the halo 4 of an untiled run suffices, and one RCCL exchange per
  * sub-cycle remains (what BASELINE.json's north star asks for; the reference's own design is one exchange per sub-cycle with a
- * 2 * substeps + 3 halo, split_explicit_momentum_equations.jl:51-64).  Needs tiles of equal shape and strides; set up
+ * 2 * substeps + 3 halo, split_explicit_momentum_equations.jl:51-64).  Needs tiles of equal shape (their row strides may differ: the easternmost tile of a Bounded x partition); set up
  * collectively at the first sub-cycle (and again when bound arrays change -- bind on all ranks together); if any rank cannot
- * (no IPC, unequal strides), every rank stays on RCCL.  A tile that waits 3 s for a neighbour gives up, the next csi_sync
+ * (no IPC, a tile the two-sub-steps kernel does not take), every rank stays on RCCL.  A tile that waits 3 s for a neighbour gives up, the next csi_sync
  * returns CSI_ERR_COMM.
  * CSI_TRANSPORT_RCCL: pack -> grouped ncclSend / ncclRecv -> unpack of width-2k strips every k sub-steps
  * (csi_set_exchange_interval); what every other path (three kernels, STRICT) uses anyway.

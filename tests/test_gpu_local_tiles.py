@@ -99,7 +99,10 @@ DECOMPOSITIONS = {
     "2x2_channel_land_arrays": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), land=0.2, field_forcing=True), True),
     "4x1_periodic_x": (4, 1, dict(Nx=512, Ny=96, topo=("periodic", "bounded")), True),
     "1x4_periodic_y": (1, 4, dict(Nx=160, Ny=256, topo=("periodic", "periodic")), True),
-    "2x1_bounded_x": (2, 1, dict(Nx=256, Ny=96, topo=("bounded", "periodic")), False),      # tiles of unequal strides: messages
+    # a Bounded x direction partitioned in x: the easternmost tile's Face fields are one column wider -- unequal row strides
+    "2x1_bounded_x": (2, 1, dict(Nx=256, Ny=96, topo=("bounded", "periodic")), True),
+    "3x2_bounded_land": (3, 2, dict(Nx=384, Ny=128, topo=("bounded", "bounded"), land=0.2, field_forcing=True), True),
+    "2x2_bounded_noslip": (2, 2, dict(Nx=256, Ny=128, topo=("bounded", "bounded"), noslip=True), True),
     "2x2_latlon": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), grid="latlon"), True),
     "1x2_fold": (1, 2, dict(Nx=192, Ny=192, topo=("periodic", "folded")), False),           # the fold tile: three kernels
     "1x4_fold_tripolar": (1, 4, dict(Nx=128, Ny=256, topo=("periodic", "folded"), curvilinear=0.04, land=0.2, field_forcing=True), False),
