@@ -39,9 +39,9 @@ def run_tile_threads(world, tile_fn):
     return out
 
 
-def run_tiles(c, Rx, Ry, k, full_step=True):
+def run_tiles(c, Rx, Ry, k, full_step=True, mode="fast"):
     def tile(rank, group):
-        m = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=(Rx, Ry, rank),
+        m = cases.csi_model(c, mode=mode, timestepper="SplitRungeKutta3", advection=csi.WENO(order=7), tile=(Rx, Ry, rank),
                             local_group=group)
         m.set_exchange_interval(max(k, 0))        # k = -1: automatic interval of the message exchange; k = 0: the peer transport
         if k < 0:
@@ -65,8 +65,8 @@ def run_tiles(c, Rx, Ry, k, full_step=True):
     return run_tile_threads(Rx * Ry, tile)
 
 
-def reference(c, full_step=True):
-    ref = cases.csi_model(c, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=7))
+def reference(c, full_step=True, mode="fast"):
+    ref = cases.csi_model(c, mode=mode, timestepper="SplitRungeKutta3", advection=csi.WENO(order=7))
     csi.time_step_momentum(ref, c["dt"])
     csi.time_step_momentum(ref, c["dt"])
     ref.synchronize()
@@ -122,3 +122,63 @@ def test_local_tiles_bitwise(name, k):
         # the fold tile too runs the two-sub-steps kernel (below its three-kernel band) whenever the exchange interval is even
         assert (d["path"]["level"] in (0, 1)) if k == 1 else (d["path"]["level"] == 2), d["path"]
     check(tiles, mom, step, (name, k))
+
+
+@pytest.mark.parametrize("name", ["2x2_periodic", "1x2_fold", "2x1_bounded_x", "2x2_channel_land_arrays"])
+def test_local_tiles_strict_mode_bitwise(name):
+    """STRICT mode (the reference's operation order, three kernels, an exchange every sub-step): tiled == untiled too."""
+    Rx, Ry, kw, _ = DECOMPOSITIONS[name]
+    c = cases.make_case(H=4, substeps=6, patches=True, random_uv=0.05, **kw)
+    mom, step = reference(c, mode="strict")
+    tiles = run_tiles(c, Rx, Ry, 1, mode="strict")
+    for d in tiles:
+        assert d["path"]["transport"] == "rccl" and d["path"]["level"] == 0 and d["path"]["exchange_interval"] == 1, d["path"]
+    check(tiles, mom, step, (name, "strict"))
+
+
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+@pytest.mark.parametrize("Rx,Ry", [(2, 1), (2, 2), (2, 4)])
+def test_bench_decompositions_in_process(Rx, Ry, transport):
+    """bench.py's own N = 2 / 4 / 8 jobs, scaled down: the headline configuration (periodic f-plane, bench.py's seeded inputs
+    built per tile by bench.tile_fields / local_case) as 2 x 1, 2 x 2, 2 x 4 distinct tiles on this one GPU, on the peer transport
+    (halo 4) and on the message exchange bench.py falls back to (halo 32, every 16 sub-steps): each tile equals the one-GPU run
+    of the assembled global state bit for bit -- the check bench.py itself makes before it times anything, here on hardware."""
+    import bench
+    size, substeps = 512, 120
+    nx, ny = size // Rx, size // Ry
+    halo = 4 if transport == "peer" else 32
+
+    def make_model(grid):
+        dyn = csi.SeaIceMomentumEquation(grid, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
+                                         top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
+                                         solver=csi.SplitExplicitSolver(substeps=substeps))
+        return csi.SeaIceModel(grid, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", mode="fast")
+
+    whole = csi.RectilinearGrid((size, size), x=(0.0, size * 2000.0), y=(0.0, size * 2000.0), topology=(csi.Periodic, csi.Periodic),
+                                halo=(halo, halo))
+    ref = make_model(whole)
+    gf = bench.global_fields(np, nx, ny, Rx, Ry)
+    csi.set_(ref, h=gf["h"], aice=gf["a"], u=gf["u"], v=gf["v"])
+    for _ in range(2):
+        csi.time_step_momentum(ref, 120.0)
+    ref.synchronize()
+    want = {f: EVP_FIELDS[f](ref).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+
+    def tile(rank, group):
+        tg, fld = bench.local_case(csi, np, nx, ny, Rx, Ry, rank, halo=halo)
+        tg.local_group = group
+        m = make_model(tg)
+        m.set_halo_transport(transport)
+        csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
+        for _ in range(2):
+            csi.time_step_momentum(m, 120.0)
+        m.synchronize()
+        got = {f: EVP_FIELDS[f](m).interior_numpy().copy() for f in want}
+        return got, (tg.i_off, tg.j_off), dict(m.ctx.last_path(), transport=m.ctx.halo_transport())
+
+    for rank, (got, (i0, j0), path) in enumerate(run_tile_threads(Rx * Ry, tile)):
+        assert path["transport"] == transport and path["level"] == 2, path
+        assert path["exchanges"] == (1 if transport == "peer" else 8), path
+        for f in want:
+            w = want[f][j0:j0 + ny, i0:i0 + nx]
+            assert np.array_equal(w, got[f][:ny, :nx]), (rank, f, np.abs(w - got[f][:ny, :nx]).max())
