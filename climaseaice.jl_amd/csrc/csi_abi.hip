@@ -1041,8 +1041,8 @@ int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, con
     else { launch_fast_vstep(Q, from(bd.rv1, jlo + 1), bd.imv, fc, st); launch_fast_ustep(Q, from(bd.r2, jlo + 1), bd.imu, fc, st); }
     return CSI_OK;
 }
-// two sub-steps of the band: buffer `cur` (0: the caller's arrays) -> the other one, on the band's stream
-int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, bool last) {
+// two sub-steps (or the trailing single one) of the band: buffer `cur` (0: the caller's arrays) -> the other one, on the band's stream
+int32_t band_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, int n, bool last) {
     hipStream_t st = c->band_stream;
     HIP_TRY(c, hipStreamWaitEvent(st, c->band_ev_pair, 0));
     auto rows_from = [&](int q, int j0, const double* src, double* dst, CopyBatch& B) {
@@ -1063,8 +1063,10 @@ int32_t band_two_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc
     for (int q = 0; q < 4; ++q) d[q] = band_ref(c, 5 + q);
     // validity after the first sub-step: sigma from row M - 5, velocities from M - 3; after the second: sigma M - 2, velocities M
     int32_t rc;
-    if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 5, false, st))) return rc;
-    if ((rc = band_substep(c, bd, fc, b, d, ((s + 1) % 2) == 0, bd.M - 2, last, st))) return rc;
+    if (n == 2) {
+        if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 5, false, st))) return rc;
+        if ((rc = band_substep(c, bd, fc, b, d, ((s + 1) % 2) == 0, bd.M - 2, last, st))) return rc;
+    } else if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 3, last, st))) return rc;
     launch_copy_batch(out, st);
     if (last) {
         for (int q = 5; q < 9; ++q) rows_from(q, bd.M + 1, c->band[q], band_bound(c, q).p, diag);
@@ -1168,7 +1170,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     FusedGeom G[KMAX], GP[KMAX / 2];
     // configurations only the two-sub-steps kernel takes (masks, array forcing, per-point metrics): a single sub-step (the odd
     // trailing one) runs through that kernel too, its consumer wave storing stage A's results (evp_fused2.hip, `single`)
-    const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL || peer);      // (peer: the flag protocol lives in this kernel only)
+    const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL || peer || band);      // (peer: the flag protocol lives in this kernel only; band: its cut tile)
     {
         if (!c->host_ring) {
             HIP_TRY(c, hipHostMalloc((void**)&c->host_ring, sizeof(FusedTable) * (NSINGLE + NPAIR) * csi_context::kRing, hipHostMallocDefault));
@@ -1187,8 +1189,9 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                 G[m] = pair_geom(c, dec);
                 for (int cur = 0; cur < 2; ++cur)
                     for (int uf = 0; uf < 2; ++uf) {
-                        const Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vs, uf != 0), false),
-                                    r2 = clip_store(c, v_second_range(c, vs), false);
+                        Range rs = clip_store(c, dec, true), r1 = clip_store(c, v_first_range(c, vs, uf != 0), false),
+                              r2 = clip_store(c, v_second_range(c, vs), false);
+                        if (band) { rs.j1 = std::min(rs.j1, c->Ny); r1.j1 = std::min(r1.j1, c->Ny); r2.j1 = std::min(r2.j1, c->Ny); }
                         FusedTable* t = &host[(m * 2 + cur) * 2 + uf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, dec.j0, dec.j1, ims11, ims22, ims12, t);
@@ -1271,7 +1274,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             const int mp = m / 2;
             if (band) {
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));       // the previous band: this launch's rows M + 1 .. M + 4
-                if ((rc = band_two_substeps(c, *band, fc, cur, s, s + 2 == end))) return rc;
+                if ((rc = band_substeps(c, *band, fc, cur, s, 2, s + 2 == end))) return rc;
                 nlaunch += 8;
             }
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
@@ -1280,18 +1283,18 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                               peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 2; s += 2;
-        } else if (band) {
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
-            if ((rc = band_substep(c, *band, fc, cur == 0 ? orig : alt, nullptr, ufirst, -(1 << 30), s + 1 == end, c->stream))) return rc;
-            m += 1; s += 1;
-            cur ^= 1;           // undone below: in place
-            nlaunch += 2;
         } else if (single_by_pair) {
             // one sub-step through the two-sub-steps kernel (write_diag bit 1): masks, array forcing, per-point metrics
+            if (band) {
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
+                if ((rc = band_substeps(c, *band, fc, cur, s, 1, s + 1 == end))) return rc;
+                nlaunch += 5;
+            }
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
                               2 | (s + 1 == end ? 1 : 0), peer ? (++c->peer.seq | peer_dld_bit) : 0ull, c->stream);
+            if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 1; s += 1;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
             // (no pair kernel for this grid -- halo < 4, tiny tiles: the three kernels in place on whichever buffer is current)
@@ -1384,9 +1387,8 @@ bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps) {
     if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 2 || c->Hy < 4) return false;
     if (g.ylo == SIDE_CONNECTED) {
         // the fold tile of a y partition: the k-batched message exchange with the tile below, pair launches need an even k
-        // (and an even sub-step count: a trailing single sub-step would need the three kernels' batch-position ranges)
         const int k = exchange_interval(c);
-        if (k % 2 != 0 || substeps % 2 != 0 || !has_comm(c) || !c->tile.set) return false;
+        if (k % 2 != 0 || !has_comm(c) || !c->tile.set) return false;
     }
     const int M = c->Ny - c->Hy - 4;
     if (M < 2 * c->Hy + 8) return false;
