@@ -119,6 +119,8 @@ struct csi_context {
         static constexpr int SLOTS = 1024;   // flag slots per direction
         int want = 1;                        // csi_set_halo_transport: 1 peer where possible, 0 RCCL only
         int dld[8][2] = {};                  // per direction x {Center, Face in x}: the neighbour's row stride minus this tile's, bytes
+        int nbr_wait[8] = {};                // flags to wait for per direction: the size of the NEIGHBOUR's opposite set (its own geometry)
+        int ny_below = 0;                    // rows of the tile below (all tiles of a decomposition have this tile's UNCUT height)
         bool ready = false, failed = false;  // set up (collectively) / cannot be set up (stays on RCCL)
         const void* sig[NARR] = {};          // the local arrays the set-up was made for
         int img_rank[8], sync_rank[8];       // per direction: the rank whose arrays receive this tile's images there; the neighbour to wait for (-1: none)
@@ -769,8 +771,42 @@ struct PeerRec {                 // what a rank tells the others about one of it
     int64_t ld;                  // leading dimension (images use the sender's strides: they must agree)
     int32_t ok, pad;
     uint64_t local_ptr;          // in-process tile group: the buffer itself (same address space)
+    int32_t set_size[8];         // (record 0) tiles of this rank's launches in each direction's set: what the neighbour waits for
 };
 constexpr int kPeerRecs = csi_context::Peer::NARR + 1;      // + the flag array
+
+// The grid descriptor the launches of the peer transport see: connected sides count as periodic ones; a fold tile is cut below
+// its three-kernel band (FoldBand), whose side then counts as "connected" (halo rows = interior rows of the same arrays).
+struct PeerView {
+    csi_context* c; GridDev g; int Ny;
+    explicit PeerView(csi_context* cc) : c(cc), g(cc->g), Ny(cc->Ny) {
+        for (int* side : {&c->g.xlo, &c->g.xhi, &c->g.ylo, &c->g.yhi}) if (*side == SIDE_CONNECTED) *side = SIDE_PERIODIC;
+        if (c->g.yhi == SIDE_FOLD) { const int M = c->Ny - c->Hy - 4; c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
+    }
+    ~PeerView() { c->g = g; c->Ny = Ny; }
+};
+bool fold_cut_possible(const csi_context* c) {
+    const GridDev& g = c->g;
+    return g.yhi == SIDE_FOLD && g.xlo == SIDE_PERIODIC && g.xhi == SIDE_PERIODIC && c->Hy >= 4 && c->Ny - c->Hy - 4 >= 2 * c->Hy + 8;
+}
+// does the two-sub-steps kernel take this tile on the peer transport?  (P: the tile as it is)
+bool peer_tile_supported(csi_context* c, const EvpDev& Pfull) {
+    if (c->g.yhi != SIDE_FOLD) return pair_supported(c) && pair_forcing_kind(Pfull) >= 0;      // (the tile as it is: connected sides)
+    if (!fold_cut_possible(c)) return false;
+    const GridDev g = c->g;
+    const int Ny = c->Ny, M = c->Ny - c->Hy - 4;
+    c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED;                                        // cut below the band
+    EvpDev P = Pfull;
+    P.g = c->g;
+    const bool ok = pair_supported(c) && pair_forcing_kind(P) >= 0;
+    c->g = g; c->Ny = Ny;
+    return ok;
+}
+PeerSets peer_my_sets(csi_context* c) {
+    PeerView view(c);
+    const Range dec = v_stress_range(c, pair_side_v(c, 2, 2));
+    return peer_wait_counts(c, pair_geom(c, dec));
+}
 
 // Collective over the context's communicator: every rank publishes IPC handles of its arrays and flags, maps its neighbours'.
 // Failure anywhere (no IPC, strides that differ across a side, sets larger than the flag array) makes EVERY rank stay on RCCL.
@@ -794,6 +830,7 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
     HIP_TRY(c, hipMemset(pr.err, 0, sizeof(unsigned)));
     *pr.err_host = 0;
     pr.seq = 0;
+    pr.ny_below = c->Ny;
     // neighbours: where this tile's images go (a periodic or wall component keeps the coordinate: wraps / mirrors are local
     // in that direction) and whom to wait for (connected components only)
     for (int d = 0; d < 8; ++d) {
@@ -818,6 +855,10 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         memset(&r, 0, sizeof r);
         r.ld = q < csi_context::Peer::NARR ? lds[q] : 0;
         r.local_ptr = (uint64_t)ptr;
+        if (q == 0 && local_ok) {
+            const PeerSets ps = peer_my_sets(c);
+            for (int d = 0; d < 8; ++d) { r.set_size[d] = ps.size[d]; if (ps.size[d] > csi_context::Peer::SLOTS) ok = 0; }
+        }
         if (ok && c->world > 1 && !c->local) {               // (a single rank / an in-process group addresses the arrays directly)
             hipDeviceptr_t base = nullptr; size_t size = 0;
             if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) != hipSuccess || hipIpcGetMemHandle(&r.handle, base) != hipSuccess) {
@@ -878,6 +919,7 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
             }
         }
         pr.nbr_slots[d] = nullptr;
+        pr.nbr_wait[d] = (ok && pr.sync_rank[d] >= 0) ? all[(size_t)pr.sync_rank[d] * kPeerRecs].set_size[kPeerOpp[d]] : 0;
         if (ok && pr.sync_rank[d] >= 0) {
             void* sp = pr.slots;
             if (pr.sync_rank[d] != me && !resolve(pr.sync_rank[d], csi_context::Peer::NARR, &sp)) ok = 0;
@@ -911,7 +953,7 @@ int32_t peer_decide(csi_context* c, const EvpDev& P, int substeps, bool* use) {
     // Everything above is the same on every rank; what follows may differ from tile to tile (the fold lives on the northernmost
     // tile of a y partition only, a Bounded x partition has tiles of unequal strides): those conditions go INTO the collective
     // set-up, which answers with the minimum over the ranks -- every rank or none.
-    const bool local_ok = pair_supported(c) && pair_forcing_kind(P) >= 0 &&
+    const bool local_ok = peer_tile_supported(c, P) &&
                           c->f[CSI_F_U].ld == c->f[CSI_F_S12].ld && c->f[CSI_F_V].ld == c->f[CSI_F_S11].ld &&
                           c->Nx >= 128;                      // (a wave's x images all go to ONE neighbour: evp_fused2.hip)
     int32_t rc;
@@ -941,13 +983,14 @@ int32_t peer_fill_table(csi_context* c, const FusedGeom& G, bool out_is_alt, Fus
     for (int d = 0; d < 8; ++d) {
         t->P[FP_SLOT_IN + d] = (unsigned long)(pr.slots + (size_t)d * csi_context::Peer::SLOTS);
         t->P[FP_SLOT_OUT + d] = pr.nbr_slots[d] ? (unsigned long)(pr.nbr_slots[d] + (size_t)kPeerOpp[d] * csi_context::Peer::SLOTS) : 0ul;
-        t->I[FI_PWAIT + d] = ps.n[d];
+        t->I[FI_PWAIT + d] = pr.nbr_wait[d];      // (the neighbour's own set: a fold tile's launches have another geometry)
         if (pr.sync_rank[d] >= 0) mask |= 1 << d;
     }
     int any = 0;
     for (int d = 0; d < 8; ++d)
         for (int q = 0; q < 2; ++q) { t->I[FI_PDLD + d * 2 + q] = pr.dld[d][q]; any |= pr.dld[d][q] != 0; }
     t->I[FI_PHASDLD] = any;
+    t->I[FI_NYLO] = c->peer.ny_below > 0 ? c->peer.ny_below : c->Ny;
     t->P[FP_PERR] = (unsigned long)pr.err;
     t->I[FI_PEER] = 1; t->I[FI_PMASK] = mask;
     t->I[FI_PSET] = ps.nW; t->I[FI_PSET + 1] = ps.nE; t->I[FI_PSET + 2] = ps.nS; t->I[FI_PSET + 3] = ps.nN;
@@ -1328,7 +1371,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     if (peer) {
         // the neighbours' last launch wrote into this rank's halos: wait for all of it before anything later on this stream
         // (the copy back, finalize_rheology!, the next exchange) reads them
-        launch_wait_peers(c->peer.slots, c->peer.sync_rank, csi_context::Peer::SLOTS, peer_wait_counts(c, substeps >= 2 ? GP[0] : G[0]).n, c->peer.seq, c->peer.err, c->stream);
+        launch_wait_peers(c->peer.slots, c->peer.sync_rank, csi_context::Peer::SLOTS, c->peer.nbr_wait, c->peer.seq, c->peer.err, c->stream);
         HIP_TRY(c, hipMemcpyAsync(c->peer.err_host, c->peer.err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1357,20 +1400,29 @@ int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int subste
     // rank's second buffer -- they must not be overwritten by a copy that is still on its way.  (Halos beyond connected sides
     // need no copy: the neighbours' images rewrite all H layers at every launch.)
     if ((rc = ensure_alt(c))) return rc;
-    if (has_walls(c))
+    const bool fold = c->g.yhi == SIDE_FOLD;
+    if (has_walls(c) || fold)
         for (int q = 0; q < 5; ++q)
             HIP_TRY(c, hipMemcpyAsync(c->alt[q], c->f[kPing[q]].p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     const int W = std::min(std::min(c->Hx, c->Hy), 4);
     if ((rc = exchange_refs(c, orig, 5, W))) return rc;
-    struct Swap {
-        csi_context* c; GridDev saved;
-        explicit Swap(csi_context* cc) : c(cc), saved(cc->g) {
-            for (int* side : {&c->g.xlo, &c->g.xhi, &c->g.ylo, &c->g.yhi}) if (*side == SIDE_CONNECTED) *side = SIDE_PERIODIC;
-        }
-        ~Swap() { c->g = saved; }
-    } swap(c);
-    const EvpDev P = evp_dev(c, dt);
-    rc = run_fused(c, P, fc, substeps, first, true);
+    // the fold tile of a y partition: its three-kernel band works on the tile as it is (FoldBand); the pair launches see the
+    // tile cut below the band, like every other tile with its connected sides turned into periodic ones (PeerView)
+    FoldBand bd;
+    const EvpDev Pfull = evp_dev(c, dt);
+    if (fold) {
+        bd.M = c->Ny - c->Hy - 4;
+        bd.tiled = false; bd.k = 2;
+        bd.g_full = c->g; bd.Ny_full = c->Ny;
+        bd.P = Pfull;
+        bd.imu = image_spec(c, CSI_F_U); bd.imv = image_spec(c, CSI_F_V);
+        bd.rs = stress_range(c); bd.ru1 = first_u_range(c); bd.rv1 = first_v_range(c); bd.r2 = second_range(c);
+    }
+    PeerView view(c);
+    bd.g_cut = c->g;
+    EvpDev P = Pfull;           // (arrays and per-row pointers of the tile as it is; only the grid descriptor differs)
+    P.g = c->g;
+    rc = run_fused(c, P, fc, substeps, first, true, fold ? &bd : nullptr);
     c->last_exchanges = 1;
     return rc;
 }

@@ -61,6 +61,7 @@ enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_
              FI_PWAIT,                  // slots to wait for per direction (= the size of the neighbour's opposite set)
              FI_PDLD = FI_PWAIT + 8,    // per direction x {Center in x, Face in x}: the neighbour's row stride minus this tile's, in bytes
              FI_PHASDLD = FI_PDLD + 16, // any of them non-zero (a Bounded x direction partitioned in x: the easternmost tile's Face fields are one column wider)
+             FI_NYLO,                   // PEER: Ny of the neighbour beyond the LOW y side (rows of the image shift of this tile's low rows; a fold tile's own Ny is cut)
              FI_COUNT };
 struct FusedTable {
     double K[FK_COUNT];

@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     const unsigned c2s = FULL ? (unsigned)T->I[FI_C2_LD] * 8u : 0u;         // row stride of the per-point coefficient planes
     auto off2 = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * c2s; };
     const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
+    const int NyLoW = PEER ? T->I[FI_NYLO] : NyW;       // rows from a low row to its image: the height of the tile BELOW (a fold tile's own is cut)
     // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
     const bool wrap_lo_b = T->I[FI_YLO] == SIDE_PERIODIC, wrap_hi_b = T->I[FI_YHI] == SIDE_PERIODIC;      // (per side, as in x)
     const bool ylo_wall_b = WALLS && T->I[FI_YLO] == SIDE_WALL, yhi_wall_b = WALLS && T->I[FI_YHI] == SIDE_WALL;
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     const int r2_lo = max(ja, T->I[FI_R2 + 2]), r2_hi = min(jb, T->I[FI_R2 + 3]);
     // rows (uniform): +Ny / -Ny / 0 rows to the halo image of row j
     auto yimg = [&](int j) __attribute__((always_inline)) {
-        return (wrap_lo & (j >= 1) & (j <= HyW)) ? NyW : ((wrap_hi & (j > NyW - HyW) & (j <= NyW)) ? -NyW : 0);
+        return (wrap_lo & (j >= 1) & (j <= HyW)) ? NyLoW : ((wrap_hi & (j > NyW - HyW) & (j <= NyW)) ? -NyW : 0);
     };
     auto yimg_u = [&](int j) __attribute__((always_inline)) {
         int d = yimg(j);

@@ -104,8 +104,10 @@ DECOMPOSITIONS = {
     "3x2_bounded_land": (3, 2, dict(Nx=384, Ny=128, topo=("bounded", "bounded"), land=0.2, field_forcing=True), True),
     "2x2_bounded_noslip": (2, 2, dict(Nx=256, Ny=128, topo=("bounded", "bounded"), noslip=True), True),
     "2x2_latlon": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), grid="latlon"), True),
-    "1x2_fold": (1, 2, dict(Nx=192, Ny=192, topo=("periodic", "folded")), False),           # the fold tile: three kernels
-    "1x4_fold_tripolar": (1, 4, dict(Nx=128, Ny=256, topo=("periodic", "folded"), curvilinear=0.04, land=0.2, field_forcing=True), False),
+    # the y-partitioned north fold (the reference's distributed tripolar layout): the fold tile runs the pair kernel below its
+    # three-kernel band, on either transport
+    "1x2_fold": (1, 2, dict(Nx=192, Ny=192, topo=("periodic", "folded")), True),
+    "1x4_fold_tripolar": (1, 4, dict(Nx=128, Ny=256, topo=("periodic", "folded"), curvilinear=0.04, land=0.2, field_forcing=True), True),
 }
 
 

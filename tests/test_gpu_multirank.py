@@ -51,8 +51,8 @@ def test_multirank_rccl_tiles_bitwise(Rx, Ry, k, tmp_path):
     for d in _run(Rx * Ry, Rx, Ry, kw, k, tmp_path):
         i0, j0, nx, ny = (int(x) for x in d["offsets"])
         path = json.loads(str(d["path"]))
-        # k = 0: peer-direct halo writes over xGMI (IPC-mapped neighbours, flags); a fold keeps the three kernels and RCCL
-        assert path["transport"] == ("peer" if (k == 0 and Rx > 1) else "rccl"), path
+        # k = 0: peer-direct halo writes over xGMI (IPC-mapped neighbours, flags) -- the fold tile of a y partition included
+        assert path["transport"] == ("peer" if k == 0 else "rccl"), path
         for f, want in mom.items():
             got = d[f"mom_{f}"][:ny, :nx]
             assert np.array_equal(got, want[j0:j0 + ny, i0:i0 + nx]), (f, Rx, Ry, k)
