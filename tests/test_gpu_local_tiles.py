@@ -184,3 +184,53 @@ def test_bench_decompositions_in_process(Rx, Ry, transport):
         for f in want:
             w = want[f][j0:j0 + ny, i0:i0 + nx]
             assert np.array_equal(w, got[f][:ny, :nx]), (rank, f, np.abs(w - got[f][:ny, :nx]).max())
+
+
+@pytest.mark.parametrize("k", [0, -1])
+@pytest.mark.parametrize("stepper", ["ForwardEuler", "SplitRungeKutta3"])
+def test_whole_time_step_with_snow_on_2x2_tiles(stepper, k):
+    """Whole time_step! on a real 2 x 2 decomposition of an immersed channel: EVP sub-cycle, WENO7 advection of h, aice AND the
+    snow thickness, the layered (ice + snow) thermodynamic step, update_state!'s halo refresh of every prognostic field -- three
+    steps in a row; h, aice, hs, u, v and the masked mass-flux diagnostics of every tile equal the untiled run bit for bit."""
+    Rx, Ry = 2, 2
+    c = cases.make_case(Nx=256, Ny=96, H=8, substeps=12, topo=("periodic", "bounded"), patches=True, random_uv=0.02, land=0.2)
+    rng = np.random.default_rng(41)
+    hs0 = np.where(c["a"] > 0, 0.3 * rng.random(c["a"].shape), 0.0)
+
+    def build(tile=None, group=None):
+        ice = csi.SlabThermodynamics(top_heat_flux=-80.0, bottom_heat_flux=6.0, bottom_salinity=30.0,
+                                     top_heat_boundary_condition=csi.MeltingConstrainedFluxBalance())
+        m = cases.csi_model(c, mode="fast", timestepper=stepper, advection=csi.WENO(order=7), tile=tile, local_group=group,
+                            ice_thermodynamics=ice, snow_thermodynamics=csi.snow_slab_thermodynamics(), snowfall=3e-5)
+        g = m.grid
+        hs = hs0 if tile is None else g.local_interior(hs0, csi.Center, csi.Center)
+        csi.set_(m, hs=hs)
+        return m
+
+    def state(m):
+        m.synchronize()
+        out = {"h": m.ice_thickness, "a": m.ice_concentration, "hs": m.snow_thickness, "u": m.velocities.u, "v": m.velocities.v,
+               "mf_ice": m.mass_fluxes.thermodynamics.ice, "mf_snow": m.mass_fluxes.thermodynamics.snow}
+        return {k_: f.interior_numpy().copy() for k_, f in out.items()}
+
+    ref = build()
+    for _ in range(3):
+        csi.time_step(ref, c["dt"])
+    want = state(ref)
+    assert np.abs(want["hs"] - hs0).max() > 1e-4
+
+    def tile(rank, group):
+        m = build((Rx, Ry, rank), group)
+        if k < 0:
+            m.set_halo_transport("rccl")
+        for _ in range(3):
+            csi.time_step(m, c["dt"])
+        g = m.grid
+        return state(m), (g.i_off, g.j_off, g.Nx, g.Ny), m.ctx.halo_transport()
+
+    for rank, (got, (i0, j0, nx, ny), transport) in enumerate(run_tile_threads(Rx * Ry, tile)):
+        assert transport == ("peer" if k == 0 else "rccl")
+        for f in want:
+            w = want[f][j0:j0 + ny, i0:i0 + nx]
+            g_ = got[f][:ny, :nx]
+            assert np.array_equal(w, g_), (rank, f, np.abs(w - g_).max(), np.argwhere(w != g_)[:4].tolist())
