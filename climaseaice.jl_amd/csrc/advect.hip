@@ -225,14 +225,54 @@ constexpr int TX = 64, TY = 4;
 // row holds the east / north faces of the tile.  Fx[i] = Ax u c~ at the west face of cell i, Fy[j] at the south face.  (Round 3:
 // the tracers used to share a thread -- four WENO7 reconstructions behind 28 dependent loads; at 512^2 the launch lasts as long
 // as one block, so halving the chain per thread is what shortens it.)
-template <int SCHEME, bool FAST>
+// store_with_images for a tracer on a grid with N >= 2 H and no fold: a cell is within H of at most one side per direction, so it
+// has at most one x image, one y image and their corner -- scalars instead of store_with_images' index lists (which live in
+// scratch memory: inside the tendency kernel they cost more than the separate update launch they were meant to save)
+__device__ __forceinline__ void store_tracer_images(const FRef& f, const GridDev& g, const ImageSpec& im, int i, int j, double val) {
+    f(i, j) = val;
+    int ix = 0, jy = 0;
+    bool hx = false, hy = false;
+    if (i <= g.Hx) {
+        if (im.xhi == IMG_WRAP) { ix = i + g.Nx; hx = true; }
+        if (im.xlo == IMG_MIRROR) { ix = 1 - i; hx = true; }
+    } else if (i > g.Nx - g.Hx) {
+        if (im.xlo == IMG_WRAP) { ix = i - g.Nx; hx = true; }
+        if (im.xhi == IMG_MIRROR) { ix = 2 * g.Nx + 1 - i; hx = true; }
+    }
+    if (j <= g.Hy) {
+        if (im.yhi == IMG_WRAP) { jy = j + g.Ny; hy = true; }
+        if (im.ylo == IMG_MIRROR) { jy = 1 - j; hy = true; }
+    } else if (j > g.Ny - g.Hy) {
+        if (im.ylo == IMG_WRAP) { jy = j - g.Ny; hy = true; }
+        if (im.yhi == IMG_MIRROR) { jy = 2 * g.Ny + 1 - j; hy = true; }
+    }
+    if (hx) f(ix, j) = val;
+    if (hy) f(i, jy) = val;
+    if (hx & hy) f(ix, jy) = val;
+}
+
+// STEP (launch_advect_stage): the launch is a whole RK stage of an advection-only model -- the h thread of a cell also does
+// _dynamic_step_tracers! (k_tracer_step's arithmetic, statement for statement) with the two tendencies of its cell, into the
+// stage's OUTPUT arrays.
+template <int SCHEME, bool FAST, bool STEP = false>
 __global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
     __shared__ double sFx[3][TY + 1][TX + 2], sFy[3][TY + 1][TX + 2];
+    __shared__ double sG[STEP ? 2 : 1][STEP ? TY : 1][STEP ? TX : 1];
     const GridDev& g = A.g;
     const int tx = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;          // tx in [0, TX], ty in [0, TY], tz: tracer
     const int i = 1 + blockIdx.x * TX + tx, j = 1 + blockIdx.y * TY + ty;
     const bool in_x = i <= g.Nx + 1, in_y = j <= g.Ny + 1;
     const FRef& c = tz == 0 ? A.h : (tz == 1 ? A.a : A.hs);
+    // STEP: the update's base values are independent of the fluxes: loaded (and, first stage, cached as Psi^-) up front, so that
+    // behind the fluxes only a few flops and one store remain; the h thread stores h, the aice thread aice
+    const bool owns = tx < TX && ty < TY && i <= g.Nx && j <= g.Ny;
+    double hn = 0.0, an = 0.0;
+    if (STEP && owns) {
+        hn = A.hb(i, j); an = A.ab(i, j);
+        if (A.write_cache) {              // Psi^- = the state this step starts from (its halos: images, like the state's)
+            if (tz == 0) store_tracer_images(A.hm, A.g, A.im, i, j, hn); else store_tracer_images(A.am, A.g, A.im, i, j, an);
+        }
+    }
     if (in_x && in_y) {
         // x-face flux (needed for ty < TY rows), y-face flux (needed for tx < TX columns)
         if (ty < TY && j <= g.Ny) {
@@ -260,7 +300,23 @@ __global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
         const double fx = sFx[tz][ty][tx + 1] - sFx[tz][ty][tx], fy = sFy[tz][ty + 1][tx] - sFy[tz][ty][tx];
         const double rV = FAST ? fm::rcp(V) : 1 / V;
         const FRef& G = tz == 0 ? A.Gh : (tz == 1 ? A.Ga : A.Ghs);         // (snow: compute_snow_advection_tendency!, tracer_tendency_kernel_functions.jl:49-52)
-        G(i, j) = -(rV * (fx + fy));
+        const double Gv = -(rV * (fx + fy));
+        G(i, j) = Gv;
+        if (STEP) sG[tz][ty][tx] = Gv;
+    }
+    if (STEP) {
+        __syncthreads();
+        if (owns) {
+            double hp = hn + A.dt * sG[0][ty][tx];
+            double ap = an + A.dt * sG[1][ty][tx];
+            ap = jmax(0.0, ap);
+            hp = jmax(0.0, hp);
+            ap = (hp == 0) ? 0.0 : ap;
+            hp = (ap == 0) ? 0.0 : hp;
+            const double Vp = hp * ap;
+            const double a1 = (ap > 1) ? 1.0 : ap, h1 = (ap > 1) ? Vp : hp;
+            if (tz == 0) store_tracer_images(A.ho, A.g, A.im, i, j, h1); else store_tracer_images(A.ao, A.g, A.im, i, j, a1);
+        }
     }
 }
 
@@ -311,6 +367,23 @@ static void launch_tendencies_mode(const AdvDev& A, hipStream_t s) {
 // mode: CSI_MODE_STRICT (0) the oracle's arithmetic, bit for bit; CSI_MODE_FAST (1) reciprocals and contraction (header)
 void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
     if (mode == 1) launch_tendencies_mode<true>(A, s); else launch_tendencies_mode<false>(A, s);
+}
+template <bool FAST>
+static void launch_stage_mode(const AdvDev& A, hipStream_t s) {
+    dim3 b(adv::TX + 1, adv::TY + 1, 2);
+    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY - 1) / adv::TY));
+    switch (A.scheme) {
+        case 1: hipLaunchKernelGGL((adv::k_tendencies<1, FAST, true>), gr, b, 0, s, A); break;
+        case 3: hipLaunchKernelGGL((adv::k_tendencies<3, FAST, true>), gr, b, 0, s, A); break;
+        case -3: hipLaunchKernelGGL((adv::k_tendencies<-3, FAST, true>), gr, b, 0, s, A); break;
+        case 5: hipLaunchKernelGGL((adv::k_tendencies<5, FAST, true>), gr, b, 0, s, A); break;
+        case -5: hipLaunchKernelGGL((adv::k_tendencies<-5, FAST, true>), gr, b, 0, s, A); break;
+        default: hipLaunchKernelGGL((adv::k_tendencies<7, FAST, true>), gr, b, 0, s, A); break;
+    }
+}
+// one RK stage of an advection-only model without snow: tendencies of (A.h, A.a), update A.hb + dt G -> A.ho (A.ab, A.ao)
+void launch_advect_stage(const AdvDev& A, int mode, hipStream_t s) {
+    if (mode == 1) launch_stage_mode<true>(A, s); else launch_stage_mode<false>(A, s);
 }
 void launch_tracer_step(const AdvDev& A, hipStream_t s) {
     dim3 b(64, 4);

@@ -145,6 +145,8 @@ struct csi_context {
     bool ring_used[kRing] = {false, false, false, false};
     unsigned ring_pos = 0;
     double* alt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* adv_buf[4] = {nullptr, nullptr, nullptr, nullptr};      // RK stages of an advection-only model in one launch each: (h, a) x 2 rotating copies
+    size_t adv_elems[4] = {0, 0, 0, 0};
     // north fold (FoldBand): the band's own copies of u, v, sigma and of the four diagnostics, its stream and the two events
     // that order it against the pair launches
     double* band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1817,6 +1819,7 @@ int32_t csi_context_destroy(csi_context* c) {
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
     if (c->dev_coef) hipFree(c->dev_coef);
     for (int k = 0; k < 5; ++k) if (c->alt[k]) hipFree(c->alt[k]);
+    for (int k = 0; k < 4; ++k) if (c->adv_buf[k]) hipFree(c->adv_buf[k]);
     for (int k = 0; k < 9; ++k) if (c->band[k]) hipFree(c->band[k]);
     if (c->band_ev_pair) hipEventDestroy(c->band_ev_pair);
     if (c->band_ev_band) hipEventDestroy(c->band_ev_band);
@@ -2145,12 +2148,67 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
     return do_update_state(c, true, fused_fill);                          // :31
 }
 
+// An RK3 step of an advection-only model (prescribed velocities: examples/ice_advected_by_anticyclone.jl's family, BASELINE
+// config 2) with ONE launch per stage: nothing happens between a stage's tendencies and its tracer update, so the kernel that
+// computes G also applies it -- into another copy of (h, a), because its neighbours still read the stage's input: the state
+// rotates bound arrays -> copy 1 -> copy 2 -> bound arrays.  The first stage also writes Psi^- (cache_current_fields!).  Same
+// arithmetic as the separate kernels, statement for statement: bit-identical (tests/test_gpu_steps.py).
+bool advect_stage_supported(const csi_context* c, int scheme) {
+    const ImageSpec im = image_spec(c, CSI_F_H);
+    for (int side : {im.xlo, im.xhi, im.ylo, im.yhi}) if (side != IMG_WRAP && side != IMG_MIRROR) return false;      // (periodic / no-flux walls)
+    if (c->Nx < 2 * c->Hx || c->Ny < 2 * c->Hy) return false;
+    // measured (scripts/r03_adv_sizes.sh, WENO7, us per RK3 step, separate launches -> one per stage): 256^2 38 -> 23,
+    // 512^2 71 -> 55, 1024^2 219 -> 187, 1536^2 427 -> 384, 2048^2 768 -> 794: the separate update is a pure streaming kernel,
+    // which wins once the grid is large enough for launch latencies not to matter
+    if ((long)c->Nx * c->Ny > 3000000L) return false;
+    return !c->evp_set && scheme != 0 && c->fusion && !c->slab_set && !c->g.has_mask && !is_tiled(c) &&
+           c->f[CSI_F_HS].p == nullptr && c->f[CSI_F_H].ld == c->f[CSI_F_HM].ld && c->f[CSI_F_A].ld == c->f[CSI_F_AM].ld;
+}
+int32_t rk3_advection_only(csi_context* c, double dt, int scheme) {
+    int32_t rc;
+    if ((rc = need(c, {CSI_F_U, CSI_F_V, CSI_F_H, CSI_F_A, CSI_F_GH, CSI_F_GA, CSI_F_HM, CSI_F_AM}))) return rc;
+    const int src[4] = {CSI_F_H, CSI_F_A, CSI_F_H, CSI_F_A};
+    for (int q = 0; q < 4; ++q) {
+        const Bound& b = c->f[src[q]];
+        const size_t n = (size_t)b.ld * (size_t)b.nj;
+        if (c->adv_elems[q] != n) {
+            if (c->adv_buf[q]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); hipFree(c->adv_buf[q]); c->adv_buf[q] = nullptr; }
+            HIP_TRY(c, hipMalloc((void**)&c->adv_buf[q], n * sizeof(double)));
+            // beyond walls the halo holds mirror images the stores rewrite; cells nobody writes (wall corners) start as the state's
+            HIP_TRY(c, hipMemcpyAsync(c->adv_buf[q], b.p, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            c->adv_elems[q] = n;
+        }
+    }
+    auto buf = [&](int q) { FRef r; const Bound& b = c->f[src[q]]; r.p = c->adv_buf[q] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * b.ld; r.ld = (int)b.ld; return r; };
+    const FRef H0 = ref_of(c, CSI_F_H), A0 = ref_of(c, CSI_F_A), H1 = buf(0), A1 = buf(1), H2 = buf(2), A2 = buf(3);
+    const FRef hin[3] = {H0, H1, H2}, ain[3] = {A0, A1, A2}, hout[3] = {H1, H2, H0}, aout[3] = {A1, A2, A0};
+    int stage = 0;
+    for (int beta = 3; beta >= 1; --beta, ++stage) {
+        AdvDev A = adv_dev(c, scheme, dt / beta, 1);
+        A.h = hin[stage]; A.a = ain[stage];
+        A.hb = stage == 0 ? H0 : A.hm; A.ab = stage == 0 ? A0 : A.am;
+        A.ho = hout[stage]; A.ao = aout[stage];
+        A.write_cache = stage == 0;
+        A.fill_images = 1;
+        launch_advect_stage(A, c->mode, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return CSI_OK;
+}
+
 int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t scheme) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     const bool dynamics = c->evp_set;                                     // see csi_time_step_fe
     int32_t rc = dynamics ? need_evp(c) : need(c, {CSI_F_H, CSI_F_A});
     if (rc) return rc;
     if ((rc = dynamics ? need(c, {CSI_F_HM, CSI_F_AM, CSI_F_UM, CSI_F_VM}) : need(c, {CSI_F_HM, CSI_F_AM}))) return rc;
+    if (advect_stage_supported(c, scheme)) {
+        const bool third = scheme == CSI_ADVECT_WENO3 || scheme == CSI_ADVECT_UPWIND3;
+        const int need_h = scheme == CSI_ADVECT_WENO7 ? 4 : (scheme == CSI_ADVECT_UPWIND1 ? 1 : (third ? 2 : 3));
+        if (c->Hx >= need_h && c->Hy >= need_h &&
+            (scheme == CSI_ADVECT_UPWIND1 || scheme == CSI_ADVECT_WENO5 || scheme == CSI_ADVECT_WENO7 || scheme == CSI_ADVECT_UPWIND5 || third))
+            return rk3_advection_only(c, dt, scheme);
+    }
     if ((rc = csi_cache_current_fields(c))) return rc;                    // sea_ice_rk_substep.jl:29-42
     for (int beta = 3; beta >= 1; --beta) {                               // upstream stage loop
         const double dtau = dt / beta;

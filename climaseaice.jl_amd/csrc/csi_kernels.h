@@ -120,9 +120,14 @@ struct AdvDev {
     int scheme;
     double dt;
     int from_cache;
+    // one RK stage in ONE launch (launch_advect_stage): tendencies of (h, a) -- the stage's input --, then the tracer update
+    // base + dt G written to OTHER arrays (ho, ao; with their halo images), so that no block reads what another has updated
+    FRef hb, ab, ho, ao;    // the update's base (Psi^-) and output
+    int write_cache;        // first stage: also store the base values into hm, am (cache_current_fields!, with halo images)
 };
 void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s);
 void launch_tracer_step(const AdvDev& A, hipStream_t s);
+void launch_advect_stage(const AdvDev& A, int mode, hipStream_t s);
 
 // slab thermodynamics (thermo.hip)
 struct SlabDev {

@@ -1,7 +1,7 @@
 """BASELINE.json config 2: ice_advected_by_anticyclone-style 512^2 periodic grid, WENO(order = 7) advection of h and aice
 only -- prescribed cyclonic velocities, dynamics = nothing -- RK3 time stepping, dt = 2 minutes.
 
-    python examples/advection_only.py [N] [steps]       (needs the GPU)
+    python examples/advection_only.py [N] [steps] [fusion level]       (needs the GPU)
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +22,8 @@ X, Y = np.meshgrid(xc, yc)
 h0 = 0.3 + 0.005 * (np.sin(60 * X / 1000e3) + np.sin(30 * Y / 1000e3))
 a0 = np.clip(1 - 0.1 * np.random.default_rng(2).random((N, N)), 0, 1)
 model = csi.SeaIceModel(grid, dynamics=None, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3")
+if len(sys.argv) > 3:
+    model.set_fusion(int(sys.argv[3]))      # 0: separate tendency / update launches instead of one launch per RK stage
 csi.set_(model, h=h0, aice=a0, u=u, v=v)
 V0 = (model.ice_thickness.interior_numpy() * model.ice_concentration.interior_numpy()).sum()
 for n in range(10):

@@ -232,6 +232,34 @@ def test_advection_only_time_step_bitwise(stepper, mode, oracle_lib):
     assert np.abs(p.interior("h") - c["h"]).max() > 1e-4
 
 
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("bounded", "bounded"), ("periodic", "bounded")])
+@pytest.mark.parametrize("adv", ["WENO7", "WENO5", "WENO3", "Upwind5", "Upwind3", "Upwind1"])
+def test_rk3_advection_only_one_launch_per_stage_bitwise(adv, topo, mode):
+    """An RK3 step of an advection-only model runs ONE launch per stage (tendencies + tracer update into rotating copies of
+    h, aice; csi_abi.hip rk3_advection_only).  Against the separate kernels (csi_set_fusion(0)): h, aice, Psi^- and the
+    tendencies, whole parents with halos, bit for bit after four steps."""
+    scheme = {"WENO7": csi.WENO(order=7), "WENO5": csi.WENO(order=5), "WENO3": csi.WENO(order=3), "Upwind5": csi.UpwindBiased(order=5),
+              "Upwind3": csi.UpwindBiased(order=3), "Upwind1": csi.UpwindBiased(order=1)}[adv]
+    c = cases.make_case(Nx=100, Ny=72, H=4, topo=topo, patches=True, random_uv=0.3)
+    out = {}
+    for fusion in (0, 2):
+        m = csi.SeaIceModel(c["g"], dynamics=None, advection=scheme, timestepper="SplitRungeKutta3", mode=mode)
+        m.set_fusion(fusion)
+        csi.set_(m, h=c["h"], aice=c["a"], u=c["u"], v=c["v"])
+        for _ in range(4):
+            csi.time_step(m, 300.0)
+        m.synchronize()
+        ts = m.timestepper
+        out[fusion] = {"h": m.ice_thickness.numpy().copy(), "a": m.ice_concentration.numpy().copy(),
+                       "hm": ts.Psi_minus.h.numpy().copy(), "am": ts.Psi_minus.aice.numpy().copy(),
+                       "Gh": ts.Gn.h.interior_numpy().copy(), "Ga": ts.Gn.aice.interior_numpy().copy(),
+                       "hi": m.ice_thickness.interior_numpy().copy()}
+    assert np.abs(out[0]["hi"] - c["h"]).max() > 1e-5          # the advection did something
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[2][k]), (k, np.abs(out[0][k] - out[2][k]).max(), np.argwhere(out[0][k] != out[2][k])[:4])
+
+
 def test_advection_conserves_volume_at_full_size():
     """Config 2 at 512^2: flux-form divergence on a periodic grid conserves sum(h) and sum(aice) to rounding
     (a size-independent property, checked without the oracle)."""
