@@ -154,6 +154,8 @@ struct csi_context {
     hipStream_t band_stream = nullptr;
     hipEvent_t band_ev_pair = nullptr, band_ev_band = nullptr;
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
+    double* fbar_top[2] = {nullptr, nullptr};   // the same of the air velocities (array-valued wind drag)
+    size_t fbar_top_elems[2] = {0, 0};
     double* fd[2] = {nullptr, nullptr};     // free-drift velocities at u / v points (StressBalanceFreeDrift)
     double* xd[2] = {nullptr, nullptr};     // stress divergence of the immersed flux boundary conditions at u / v points (two-sub-steps kernel)
     size_t xd_elems[2] = {0, 0};
@@ -1167,6 +1169,23 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         vbar_u.p = c->fbar[1] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[1]->ld; vbar_u.ld = (int)src[1]->ld;
         launch_forcing_bars(P, ubar_v, vbar_u, c->stream);
     }
+    FRef tbar_v{nullptr, 0}, tbar_u{nullptr, 0};              // wind drag: the air velocities' cross averages
+    const bool wind = force && P.top.kind == 3 && (P.top.ue_kind == 2 || P.top.ve_kind == 2);
+    if (wind) {
+        const Bound* src[2] = {&c->f[CSI_F_V], &c->f[CSI_F_U]};
+        for (int q = 0; q < 2; ++q) {
+            const size_t n = (size_t)src[q]->ld * (size_t)src[q]->nj;
+            if (c->fbar_top_elems[q] != n) {
+                if (c->fbar_top[q]) { HIP_TRY(c, hipStreamSynchronize(c->stream)); hipFree(c->fbar_top[q]); c->fbar_top[q] = nullptr; }
+                HIP_TRY(c, hipMalloc((void**)&c->fbar_top[q], n * sizeof(double)));
+                HIP_TRY(c, hipMemsetAsync(c->fbar_top[q], 0, n * sizeof(double), c->stream));
+                c->fbar_top_elems[q] = n;
+            }
+        }
+        tbar_v.p = c->fbar_top[0] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[0]->ld; tbar_v.ld = (int)src[0]->ld;
+        tbar_u.p = c->fbar_top[1] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * src[1]->ld; tbar_u.ld = (int)src[1]->ld;
+        launch_forcing_bars(P, tbar_v, tbar_u, c->stream, true);
+    }
     // model.forcing arrays / immersed flux boundary conditions (the EXTRA instantiations of the pair kernel): the divergence of
     // the immersed fluxes is a function of the mask and the metrics only -- once per sub-cycle into two arrays
     const bool extra = P.extra != 0;
@@ -1240,7 +1259,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         FusedTable* t = &host[(m * 2 + cur) * 2 + uf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, dec.j0, dec.j1, ims11, ims22, ims12, t);
-                        if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
+                        if (force) { fused_fill_forcing(P, ubar_v, vbar_u, t); if (wind) fused_fill_forcing_top(P, tbar_v, tbar_u, t); }
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, G[m], cur == 0, t))) return rc;
                     }
@@ -1271,7 +1290,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         FusedTable* t = &host[NSINGLE + (mp * 2 + cur) * 2 + auf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
                         fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t);
-                        if (force) fused_fill_forcing(P, ubar_v, vbar_u, t);
+                        if (force) { fused_fill_forcing(P, ubar_v, vbar_u, t); if (wind) fused_fill_forcing_top(P, tbar_v, tbar_u, t); }
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, GP[mp], cur == 0, t))) return rc;
                     }
@@ -1825,6 +1844,7 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->band_ev_band) hipEventDestroy(c->band_ev_band);
     if (c->band_stream) hipStreamDestroy(c->band_stream);
     for (int k = 0; k < 2; ++k) if (c->fbar[k]) hipFree(c->fbar[k]);
+    for (int k = 0; k < 2; ++k) if (c->fbar_top[k]) hipFree(c->fbar_top[k]);
     for (int k = 0; k < 2; ++k) if (c->fd[k]) hipFree(c->fd[k]);
     for (int k = 0; k < 2; ++k) if (c->xd[k]) hipFree(c->xd[k]);
     if (c->dev_tables) hipFree(c->dev_tables);

@@ -38,6 +38,7 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
              FP_U_OUT, FP_V_OUT, FP_S11_OUT0, FP_S22_OUT0, FP_S12_OUT0,                               // (0,0)-offset addresses for stores with halo images
              FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_MASK,
              FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_FD_U, FP_FD_V,
+             FP_FT_UBAR, FP_FT_VBAR,      // wind drag (a SemiImplicitStress on top with array-valued air velocities, in FP_FT_U / _V): their cross averages
              FP_FROW_U, FP_FROW_V,      // CSI_METRIC_FULL: per-row Coriolis parameter (device pointers, ptr[j] = row j)
              FP_F2U, FP_F2V,            // ... per-point Coriolis planes (parent addresses)
              FP_XC_U, FP_XC_V, FP_XD_U, FP_XD_V,   // EXTRA: model.forcing arrays; immersed-flux-BC stress divergence arrays (parent addresses)
@@ -53,7 +54,7 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
 enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_LD_C, FI_LD_F,
              FI_RS, FI_R1 = FI_RS + 4, FI_R1C = FI_R1 + 4, FI_R2 = FI_R1C + 4, FI_IMU = FI_R2 + 4, FI_IMV = FI_IMU + 4,
              FI_PRESSURE_KIND = FI_IMV + 4, FI_HAS_COR, FI_TOP_KIND, FI_BOT_KIND, FI_COEF_STRIDE, FI_COEF_JMIN, FI_COEF_JMAX,
-             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_FREE_DRIFT,
+             FI_DEC, FI_AJ0 = FI_DEC + 4, FI_AJ1, FI_IMS11, FI_IMS22 = FI_IMS11 + 4, FI_IMS12 = FI_IMS22 + 4, FI_MASK_LD = FI_IMS12 + 4, FI_BOT_UEK, FI_BOT_VEK, FI_FREE_DRIFT, FI_TOP_UEK, FI_TOP_VEK,
              FI_C2_LD, FI_FKIND,        // CSI_METRIC_FULL: leading dimension of the coefficient / Coriolis planes; f kind 0 number, 1 rows, 2 points
              FI_EXTRA,                  // EXTRA instantiations: bit 0 model.forcing arrays, bit 1 immersed flux boundary conditions
              FI_PEER,                   // 1: peer-connected sides (flags instead of a halo exchange, evp_fused2.hip)
@@ -95,7 +96,8 @@ void launch_immersed_div(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, hi
 int pair_forcing_kind(const EvpDev& P);
 // bottom SemiImplicitStress with array-valued ocean velocities: the cross component averaged to the u / v points
 // (ubar at v points from fu, vbar at u points from fv), once per sub-cycle (evp_fast.hip)
-void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s);
+void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s, bool top = false);
+void fused_fill_forcing_top(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, FusedTable* t);
 void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, FusedTable* host_table);
 void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* host_table);
 

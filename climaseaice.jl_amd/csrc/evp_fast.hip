@@ -373,8 +373,8 @@ void launch_immersed_div(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, hi
     hipLaunchKernelGGL(k_immersed_div, dim3((unsigned)((r.i1 - r.i0 + 64) / 64), (unsigned)((r.j1 - r.j0 + 4) / 4)), b, 0, s, P, xd_u, xd_v, r);
 }
 
-void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s) {
-    const StressDev& b = P.bot;
+void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s, bool top) {
+    const StressDev& b = top ? P.top : P.bot;
     if (b.kind != 3 || (b.ue_kind != 2 && b.ve_kind != 2)) return;
     // every point whose four neighbours lie inside the parent arrays
     const Range r{2 - P.g.Hx, P.g.Nx + P.g.Hx - 1, 2 - P.g.Hy, P.g.Ny + P.g.Hy - 1};

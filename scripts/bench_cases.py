@@ -22,6 +22,7 @@ CONFIGS = {
     "OMIP style (arrays, 30 % land, StressBalanceFreeDrift; test/distributed_tests_utils.jl:190-212)":
         dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True),
     "model.forcing arrays (periodic)": dict(topo=("periodic", "periodic"), user_forcing=True),
+    "wind drag: SemiImplicitStress on top with air-velocity arrays + ocean-velocity arrays (periodic)": dict(topo=("periodic", "periodic"), wind_drag="arrays", field_forcing=True),
     "immersed flux boundary conditions (channel, 30 % land)": dict(topo=("periodic", "bounded"), land=0.3,
                                                                      immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))),
     "beta-plane channel (per-row f on uniform metrics)": dict(topo=("periodic", "bounded"), beta=1.6e-11),

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+python scripts/bench_cases.py 2048 "wind drag" 2>/dev/null | grep -v "^{" | grep -v "version\|Hostname\|Librccl\|amdgpu.ids"
+bash scripts/gpu_tests.sh

@@ -15,7 +15,7 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
               field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None, noslip=False,
-              user_forcing=False, immersed_bc=None, coriolis_points=False):
+              user_forcing=False, immersed_bc=None, coriolis_points=False, wind_drag=None):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
@@ -23,7 +23,8 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
              noslip=noslip,                        # ValueBoundaryCondition(0) on the tangential velocity at every wall
              user_forcing=user_forcing,            # model.forcing.u / .v as arrays
              immersed_bc=immersed_bc,              # ((uW, uE, uS, uN), (vW, vE, vS, vN)): immersed FluxBoundaryCondition numbers
-             coriolis_points=coriolis_points)      # per-point f planes on a curvilinear grid (PointwiseCoriolis)
+             coriolis_points=coriolis_points,      # per-point f planes on a curvilinear grid (PointwiseCoriolis)
+             wind_drag=wind_drag)                  # top stress = SemiImplicitStress(air velocities; rho 1.3, Cd 1.2e-3): "numbers" / "arrays"
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded, "folded": csi.RightFolded}     # "folded": y of a TripolarGrid
     tt = (T[topo[0]], T[topo[1]])
     if grid == "rectilinear":
@@ -98,6 +99,9 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
         # an acceleration of a few 1e-6 m s^-2 (comparable to the Coriolis term), smooth + seeded noise
         c["force_u"] = 3e-6 * np.sin(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 1e-6 * rng.standard_normal((nyu, nxu))
         c["force_v"] = -2e-6 * np.cos(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1)) + 1e-6 * rng.standard_normal((nyv, nxv))
+    if wind_drag == "arrays":
+        c["ua_f"] = 6.0 * np.cos(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 0.5 * rng.standard_normal((nyu, nxu))
+        c["va_f"] = 4.0 * np.sin(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1)) + 0.5 * rng.standard_normal((nyv, nxv))
     if field_forcing:
         c["top_u"] = 0.01 * (1 + 0.5 * np.sin(2 * np.pi * X)) * np.ones((nyu, 1))[:, :1] * np.ones((1, 1))
         c["top_u"] = np.broadcast_to(0.01 * (1 + 0.5 * np.sin(2 * np.pi * np.linspace(0, 1, nxu)))[None, :], (nyu, nxu)).copy()
@@ -168,6 +172,13 @@ def oracle_problem(case, omp=False):
             p.set_stress("top", O.STRESS_CONST, tau=case["top"])
         if case["bottom"] == "semi":
             p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    if case.get("wind_drag") == "numbers":
+        p.set_stress("top", O.STRESS_SEMI_IMPLICIT, ue=5.0, ve=-3.0, rho_e=1.3, Cd=1.2e-3)
+    elif case.get("wind_drag") == "arrays":
+        ua = _fill_parent_like(p, "u", case["ua_f"]); va = _fill_parent_like(p, "v", case["va_f"])
+        p.set_stress("top", O.STRESS_SEMI_IMPLICIT, ue=ua, ve=va, rho_e=1.3, Cd=1.2e-3)
+        for arr, (lx, ly) in ((ua, (O.FACE, O.CENTER)), (va, (O.CENTER, O.FACE))):
+            p.L.ora_fill_halo_loc(p.ptr, O.Field(arr.ctypes.data_as(O.C.POINTER(O.C.c_double)), arr.shape[1]), lx, ly, -1)
     if case.get("free_drift"):
         p.s.free_drift_kind = 1                     # StressBalanceFreeDrift on the model's own stresses
     if case.get("user_forcing"):
@@ -222,6 +233,13 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
     else:
         top = case["top"]
         bottom = csi.SemiImplicitStress(ue=case["ue"] or None, ve=case["ve"] or None) if case["bottom"] == "semi" else None
+    if case.get("wind_drag") == "numbers":
+        top = csi.SemiImplicitStress(ue=5.0, ve=-3.0, rho_e=1.3, Cd=1.2e-3)
+    elif case.get("wind_drag") == "arrays":
+        ua, va = case["ua_f"], case["va_f"]
+        if tile is not None:
+            ua, va = g.local_interior(ua, csi.Face, csi.Center), g.local_interior(va, csi.Center, csi.Face)
+        top = csi.SemiImplicitStress(ue=ua, ve=va, rho_e=1.3, Cd=1.2e-3)
     rheo = csi.ElastoViscoPlasticRheology()
     if case["pressure"] != "replacement":
         rheo.pressure_formulation = csi.IceStrength()
@@ -246,8 +264,8 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
             fu, fv = g.local_interior(fu, csi.Face, csi.Center), g.local_interior(fv, csi.Center, csi.Face)
         model_kw = dict(model_kw, forcing=dict(u=fu, v=fv))
     model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode, **model_kw)
-    if case.get("field_forcing"):
-        for slot in ("TOP", "BOT"):
+    if case.get("field_forcing") or case.get("wind_drag") == "arrays":
+        for slot in (("TOP", "BOT") if case.get("field_forcing") else ("TOP",)):
             for comp in ("U", "V"):
                 model.ctx.call("csi_fill_halo_local", csi._lib.F[f"{slot}_{comp}"])
     if case.get("mask") is not None:

@@ -85,6 +85,11 @@ CASES = {
     # immersed FluxBoundaryCondition numbers on u and v (ice_stress_divergence.jl:65-123)
     "immersed_flux_bc": dict(Nx=80, Ny=64, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.3,
                              immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))),
+    # wind drag: a SemiImplicitStress on TOP (sea_ice_external_stress.jl:162-202), air velocities as numbers / as arrays
+    "wind_drag_numbers": dict(Nx=64, Ny=48, topo=("periodic", "bounded"), patches=True, random_uv=0.05, wind_drag="numbers"),
+    "wind_drag_arrays": dict(Nx=72, Ny=56, topo=("periodic", "periodic"), patches=True, random_uv=0.05, wind_drag="arrays"),
+    "wind_drag_arrays_coupled": dict(Nx=64, Ny=48, topo=("periodic", "bounded"), patches=True, random_uv=0.05, wind_drag="arrays",
+                                     field_forcing=True, land=0.2),
     # TripolarGrid-like grids: north fold filled by the Zipper boundary condition (u, v change sign; sea_ice_model.jl:57-64)
     "folded_uniform": dict(Nx=64, Ny=48, topo=("periodic", "folded"), patches=True, random_uv=0.05),
     # ... and the reference's own tripolar test configuration (test/distributed_tests_utils.jl:190-212): curvilinear metrics,
@@ -101,7 +106,9 @@ CASES = {
 MASKED = {"curvilinear_periodic", "curvilinear_bounded", "curvilinear_masked", "coriolis_points_curvilinear", "noslip_coastline", "masked_periodic", "masked_channel", "masked_latlon", "field_forcing", "forced_seams", "coupled_channel", "coupled_latlon",
           "beta_masked", "free_drift", "free_drift_coupled", "free_drift_omip",
           # round 3: model.forcing arrays and immersed flux boundary conditions (the EXTRA instantiations of the pair kernel)
-          "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"}      # configurations only the pair kernel fuses
+          "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear",
+          # ... and array-valued wind drag (a SemiImplicitStress on top)
+          "wind_drag_arrays", "wind_drag_arrays_coupled"}      # configurations only the pair kernel fuses
 THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar"}   # the north fold: never fused at level 1; level 2: three kernels on the rows next to the fold only
 
 
@@ -499,6 +506,7 @@ PEER_CASES = {
     "free_drift_land": (dict(Nx=160, Ny=120, topo=("periodic", "bounded"), field_forcing=True, free_drift=True, land=0.25), (True, False)),
     "curvilinear": (dict(Nx=136, Ny=96, topo=("periodic", "bounded"), curvilinear=0.04), (True, False)),
     "beta_periodic_x": (dict(Nx=140, Ny=100, topo=("periodic", "bounded"), beta=2e-10), (True, False)),
+    "wind_drag_arrays": (dict(Nx=160, Ny=96, topo=("periodic", "periodic"), wind_drag="arrays", field_forcing=True), (True, True)),
 }
 
 
@@ -570,11 +578,11 @@ def test_peer_halo_transport_falls_back_and_can_be_switched_off():
 EXTRA_CASES = ["folded_uniform", "folded_tripolar", "coriolis_points_tripolar", "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear"]
 FUSED_CASES = EXTRA_CASES + ["periodic_patches", "periodic_full_ice", "bounded", "channel", "latlon_bounded", "latlon_channel",
                "ice_strength_nocoriolis", "ragged", "periodic_seams", "periodic_halo6", "bounded_seams",
-               "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded",
+               "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded", "wind_drag_numbers",
                ] + sorted(MASKED)
 PAIR_CASES = {"periodic_patches", "periodic_full_ice", "ice_strength_nocoriolis", "periodic_seams", "periodic_halo6",
               "bounded", "channel", "latlon_bounded", "latlon_channel", "bounded_seams",
-              "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded"} | MASKED
+              "beta_bounded", "beta_channel", "beta_latlon", "beta_periodic", "noslip_channel", "noslip_bounded", "wind_drag_numbers"} | MASKED
 
 
 @pytest.mark.parametrize("nsub", [1, 2, 7, 120])

@@ -103,6 +103,7 @@ DECOMPOSITIONS = {
     "2x1_bounded_x": (2, 1, dict(Nx=256, Ny=96, topo=("bounded", "periodic")), True),
     "3x2_bounded_land": (3, 2, dict(Nx=384, Ny=128, topo=("bounded", "bounded"), land=0.2, field_forcing=True), True),
     "2x2_bounded_noslip": (2, 2, dict(Nx=256, Ny=128, topo=("bounded", "bounded"), noslip=True), True),
+    "2x2_wind_drag_arrays": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), wind_drag="arrays", field_forcing=True, land=0.2), True),
     "2x2_latlon": (2, 2, dict(Nx=256, Ny=192, topo=("periodic", "bounded"), grid="latlon"), True),
     # the y-partitioned north fold (the reference's distributed tripolar layout): the fold tile runs the pair kernel below its
     # three-kernel band, on either transport
