@@ -308,12 +308,13 @@ int pair_forcing_kind(const EvpDev& P) {
     const StressDev &t = P.top, &b = P.bot;
     const bool t_arr = t.kind == 2, b_arr = b.kind == 3 && (b.ue_kind == 2 || b.ve_kind == 2);
     const bool t_wind = t.kind == 3 && (t.ue_kind == 2 || t.ve_kind == 2);   // wind drag with array-valued air velocities
-    if (b.kind == 2) return -1;
+    const bool b_tau = b.kind == 2;                                          // explicit bottom stress arrays
+    if (b_tau && (b.fu.ld != lf || b.fv.ld != lc)) return -1;
     if (t_arr && (t.fu.ld != lf || t.fv.ld != lc)) return -1;
     if (t_wind && ((t.ue_kind == 2 && t.fu.ld != lf) || (t.ve_kind == 2 && t.fv.ld != lc))) return -1;
     if (b_arr && ((b.ue_kind == 2 && b.fu.ld != lf) || (b.ve_kind == 2 && b.fv.ld != lc))) return -1;
     if (P.free_drift && (P.ufd.ld != lf || P.vfd.ld != lc)) return -1;
-    return (t_arr || t_wind || b_arr || P.free_drift || P.extra) ? 1 : 0;
+    return (t_arr || t_wind || b_arr || b_tau || P.free_drift || P.extra) ? 1 : 0;
 }
 
 void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* t) {
@@ -336,6 +337,7 @@ void fused_fill_forcing(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u,
     t->I[FI_TOP_UEK] = P.top.kind == 3 ? P.top.ue_kind : 0;
     t->I[FI_TOP_VEK] = P.top.kind == 3 ? P.top.ve_kind : 0;
     if (P.top.kind == 2) { Q[FP_FT_U] = parent_addr(P.top.fu, g); Q[FP_FT_V] = parent_addr(P.top.fv, g); }
+    if (P.bot.kind == 2) { Q[FP_FB_U] = parent_addr(P.bot.fu, g); Q[FP_FB_V] = parent_addr(P.bot.fv, g); }
     t->I[FI_BOT_UEK] = P.bot.kind == 3 ? P.bot.ue_kind : 0;
     t->I[FI_BOT_VEK] = P.bot.kind == 3 ? P.bot.ve_kind : 0;
     if (P.bot.kind == 3 && P.bot.ue_kind == 2) { Q[FP_FB_U] = parent_addr(P.bot.fu, g); Q[FP_FB_UBAR] = parent_addr(ubar_v, g); }

@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         if (T->I[FI_TOP_KIND] == 2) { F.t_tau_u = ldg(T->P[FP_FT_U], ou); F.t_tau_v = ldg(T->P[FP_FT_V], ov); }
         if (T->I[FI_TOP_UEK] == 2) { F.t_we_u = ldg(T->P[FP_FT_U], ou); F.t_wb_v = ldg(T->P[FP_FT_UBAR], ov); }   // wind drag: air velocities as arrays, like the ocean's below
         if (T->I[FI_TOP_VEK] == 2) { F.t_we_v = ldg(T->P[FP_FT_V], ov); F.t_wb_u = ldg(T->P[FP_FT_VBAR], ou); }
+        if (T->I[FI_BOT_KIND] == 2) { F.b_tau_u = ldg(T->P[FP_FB_U], ou); F.b_tau_v = ldg(T->P[FP_FB_V], ov); }      // an explicit bottom stress given as arrays
         if (T->I[FI_BOT_UEK] == 2) { F.b_we_u = ldg(T->P[FP_FB_U], ou); F.b_wb_v = ldg(T->P[FP_FB_UBAR], ov); }   // u_e: own component at u points, averaged to v points
         if (T->I[FI_BOT_VEK] == 2) { F.b_we_v = ldg(T->P[FP_FB_V], ov); F.b_wb_u = ldg(T->P[FP_FB_VBAR], ou); }   // v_e: own component at v points, averaged to u points
         if (FD) { F.fd_u = ldg(T->P[FP_FD_U], ou); F.fd_v = ldg(T->P[FP_FD_V], ov); }                             // StressBalanceFreeDrift (once per sub-cycle, csi_abi.hip)

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python scripts/bench_cases.py 2048 "wind drag" 2>/dev/null | grep -v "^{" | grep -v "version\|Hostname\|Librccl\|amdgpu.ids"
-bash scripts/gpu_tests.sh
+python -m pytest tests/test_gpu_evp.py -m gpu -q -k "bottom_stress_arrays or wind_drag" > gpurun_out/wind_tests.log 2>&1
+echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|AssertionError|Error" gpurun_out/wind_tests.log | cut -c1-300 | head -20

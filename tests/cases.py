@@ -99,6 +99,9 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
         # an acceleration of a few 1e-6 m s^-2 (comparable to the Coriolis term), smooth + seeded noise
         c["force_u"] = 3e-6 * np.sin(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 1e-6 * rng.standard_normal((nyu, nxu))
         c["force_v"] = -2e-6 * np.cos(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1)) + 1e-6 * rng.standard_normal((nyv, nxv))
+    if bottom == "arrays":
+        c["bot_u"] = -0.004 * np.cos(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 5e-4 * rng.standard_normal((nyu, nxu))
+        c["bot_v"] = 0.003 * np.sin(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1)) + 5e-4 * rng.standard_normal((nyv, nxv))
     if wind_drag == "arrays":
         c["ua_f"] = 6.0 * np.cos(2 * np.pi * np.linspace(0, 1, nyu))[:, None] * np.ones((1, nxu)) + 0.5 * rng.standard_normal((nyu, nxu))
         c["va_f"] = 4.0 * np.sin(2 * np.pi * np.linspace(0, 1, nxv))[None, :] * np.ones((nyv, 1)) + 0.5 * rng.standard_normal((nyv, nxv))
@@ -172,6 +175,11 @@ def oracle_problem(case, omp=False):
             p.set_stress("top", O.STRESS_CONST, tau=case["top"])
         if case["bottom"] == "semi":
             p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    if case.get("bottom") == "arrays":              # an explicit bottom stress given as arrays (sea_ice_external_stress.jl:54-61)
+        bu = _fill_parent_like(p, "u", case["bot_u"]); bv = _fill_parent_like(p, "v", case["bot_v"])
+        p.set_stress("bottom", O.STRESS_FIELD, fu=bu, fv=bv)
+        for arr, (lx, ly) in ((bu, (O.FACE, O.CENTER)), (bv, (O.CENTER, O.FACE))):
+            p.L.ora_fill_halo_loc(p.ptr, O.Field(arr.ctypes.data_as(O.C.POINTER(O.C.c_double)), arr.shape[1]), lx, ly, -1)
     if case.get("wind_drag") == "numbers":
         p.set_stress("top", O.STRESS_SEMI_IMPLICIT, ue=5.0, ve=-3.0, rho_e=1.3, Cd=1.2e-3)
     elif case.get("wind_drag") == "arrays":
@@ -233,6 +241,11 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
     else:
         top = case["top"]
         bottom = csi.SemiImplicitStress(ue=case["ue"] or None, ve=case["ve"] or None) if case["bottom"] == "semi" else None
+    if case.get("bottom") == "arrays":
+        bu, bv = case["bot_u"], case["bot_v"]
+        if tile is not None:
+            bu, bv = g.local_interior(bu, csi.Face, csi.Center), g.local_interior(bv, csi.Center, csi.Face)
+        bottom = (bu, bv)
     if case.get("wind_drag") == "numbers":
         top = csi.SemiImplicitStress(ue=5.0, ve=-3.0, rho_e=1.3, Cd=1.2e-3)
     elif case.get("wind_drag") == "arrays":
@@ -264,8 +277,10 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
             fu, fv = g.local_interior(fu, csi.Face, csi.Center), g.local_interior(fv, csi.Center, csi.Face)
         model_kw = dict(model_kw, forcing=dict(u=fu, v=fv))
     model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode, **model_kw)
-    if case.get("field_forcing") or case.get("wind_drag") == "arrays":
-        for slot in (("TOP", "BOT") if case.get("field_forcing") else ("TOP",)):
+    if case.get("field_forcing") or case.get("wind_drag") == "arrays" or case.get("bottom") == "arrays":
+        slots = [sl for sl, on in (("TOP", case.get("field_forcing") or case.get("wind_drag") == "arrays"),
+                                   ("BOT", case.get("field_forcing") or case.get("bottom") == "arrays")) if on]
+        for slot in slots:
             for comp in ("U", "V"):
                 model.ctx.call("csi_fill_halo_local", csi._lib.F[f"{slot}_{comp}"])
     if case.get("mask") is not None:

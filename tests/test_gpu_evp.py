@@ -90,6 +90,8 @@ CASES = {
     "wind_drag_arrays": dict(Nx=72, Ny=56, topo=("periodic", "periodic"), patches=True, random_uv=0.05, wind_drag="arrays"),
     "wind_drag_arrays_coupled": dict(Nx=64, Ny=48, topo=("periodic", "bounded"), patches=True, random_uv=0.05, wind_drag="arrays",
                                      field_forcing=True, land=0.2),
+    # an explicit bottom stress given as arrays (any (u, v) NamedTuple works in either slot: sea_ice_external_stress.jl:54-61)
+    "bottom_stress_arrays": dict(Nx=64, Ny=48, topo=("periodic", "bounded"), patches=True, random_uv=0.05, bottom="arrays", land=0.2),
     # TripolarGrid-like grids: north fold filled by the Zipper boundary condition (u, v change sign; sea_ice_model.jl:57-64)
     "folded_uniform": dict(Nx=64, Ny=48, topo=("periodic", "folded"), patches=True, random_uv=0.05),
     # ... and the reference's own tripolar test configuration (test/distributed_tests_utils.jl:190-212): curvilinear metrics,
@@ -108,7 +110,7 @@ MASKED = {"curvilinear_periodic", "curvilinear_bounded", "curvilinear_masked", "
           # round 3: model.forcing arrays and immersed flux boundary conditions (the EXTRA instantiations of the pair kernel)
           "user_forcing", "user_forcing_latlon", "immersed_flux_bc", "immersed_flux_bc_curvilinear",
           # ... and array-valued wind drag (a SemiImplicitStress on top)
-          "wind_drag_arrays", "wind_drag_arrays_coupled"}      # configurations only the pair kernel fuses
+          "wind_drag_arrays", "wind_drag_arrays_coupled", "bottom_stress_arrays"}      # configurations only the pair kernel fuses
 THREE_KERNEL_ONLY = {"coriolis_points_tripolar", "folded_uniform", "folded_tripolar"}   # the north fold: never fused at level 1; level 2: three kernels on the rows next to the fold only
 
 
