@@ -344,7 +344,10 @@ int32_t csi_comm_count(csi_context* ctx, int32_t* ranks);
  * machine (tests/test_gpu_local_tiles.py: 2 x 2, 1 x 4 with the fold tile, a Bounded x partition) and for a single process that
  * drives several tiles.  Every context of a group calls the sub-cycle from its own thread; a rank that never arrives makes the
  * others fail with CSI_ERR_COMM after two minutes instead of hanging.  The group outlives its contexts' use of it (destroy it
- * after them).  csi_comm_init_local replaces csi_comm_init (csi_tile_set as usual); csi_comm_count reports the group size. */
+ * after them).  csi_comm_init_local replaces csi_comm_init (csi_tile_set as usual); csi_comm_count reports the group size.
+ * With the peer transport the tiles' kernels wait for each other's flags, so their streams must not share a hardware queue (two
+ * streams on one queue run in submission order): set GPU_MAX_HW_QUEUES (default 4) to more than the number of tiles before the
+ * HIP runtime initialises. */
 typedef struct csi_local_group csi_local_group;
 int32_t csi_local_group_create(int32_t world_size, csi_local_group** out);
 void csi_local_group_destroy(csi_local_group* group);
