@@ -1171,6 +1171,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     }
     FRef tbar_v{nullptr, 0}, tbar_u{nullptr, 0};              // wind drag: the air velocities' cross averages
     const bool wind = force && P.top.kind == 3 && (P.top.ue_kind == 2 || P.top.ve_kind == 2);
+    const int extra_kind = P.extra ? 1 : ((wind || (force && P.bot.kind == 2)) ? 2 : 0);      // which family of array-forcing instantiations
     if (wind) {
         const Bound* src[2] = {&c->f[CSI_F_V], &c->f[CSI_F_U]};
         for (int q = 0; q < 2; ++q) {
@@ -1343,7 +1344,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             }
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
+                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
                               peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 2; s += 2;
@@ -1356,7 +1357,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             }
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
+                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
                               2 | (s + 1 == end ? 1 : 0), peer ? (++c->peer.seq | peer_dld_bit) : 0ull, c->stream);
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 1; s += 1;

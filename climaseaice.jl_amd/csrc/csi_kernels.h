@@ -87,7 +87,7 @@ void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec
                            const ImageSpec& ims12, FusedTable* host_table);
 // seq: launch number of the peer-flag protocol (0 on grids without peer-connected sides)
 // extra: model.forcing arrays / immersed flux boundary conditions (the EXTRA instantiations; implies force)
-void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, bool extra,
+void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, int extra,
                        int common_forcing, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s);
 // stress divergence of the immersed FluxBoundaryConditions at every u / v point whose stencil stays inside the parents (evp_fast.hip)
 void launch_immersed_div(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, hipStream_t s);

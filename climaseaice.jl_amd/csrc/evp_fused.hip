@@ -314,6 +314,7 @@ int pair_forcing_kind(const EvpDev& P) {
     if (t_wind && ((t.ue_kind == 2 && t.fu.ld != lf) || (t.ve_kind == 2 && t.fv.ld != lc))) return -1;
     if (b_arr && ((b.ue_kind == 2 && b.fu.ld != lf) || (b.ve_kind == 2 && b.fv.ld != lc))) return -1;
     if (P.free_drift && (P.ufd.ld != lf || P.vfd.ld != lc)) return -1;
+    if ((t_wind || b_tau) && (P.free_drift || P.extra)) return -1;         // (no instantiation with both)
     return (t_arr || t_wind || b_arr || b_tau || P.free_drift || P.extra) ? 1 : 0;
 }
 

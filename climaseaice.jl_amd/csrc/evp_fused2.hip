@@ -94,7 +94,7 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
-template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, bool EXTRA = false, bool DLD = false>
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool PRE = CSI_PAIR_PRE && !MASK;
@@ -273,17 +273,22 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         F.t_tau_v = T->K[FK_TOP_TAU_V]; F.t_we_v = T->K[FK_TOP_VE]; F.t_wb_v = T->K[FK_TOP_UE];
         F.b_tau_v = T->K[FK_BOT_TAU_V]; F.b_we_v = T->K[FK_BOT_VE]; F.b_wb_v = T->K[FK_BOT_UE];
         F.fd_u = 0.0; F.fd_v = 0.0; F.fd = FD;
-        F.xc_u = 0.0; F.xd_u = 0.0; F.xc_v = 0.0; F.xd_v = 0.0; F.extra = EXTRA ? T->I[FI_EXTRA] : 0;
+        F.xc_u = 0.0; F.xd_u = 0.0; F.xc_v = 0.0; F.xd_v = 0.0; F.extra = EXTRA == 1 ? T->I[FI_EXTRA] : 0;
     };
     auto arrays = [&](Forcing& F, unsigned ou, unsigned ov) __attribute__((always_inline)) {
         if (T->I[FI_TOP_KIND] == 2) { F.t_tau_u = ldg(T->P[FP_FT_U], ou); F.t_tau_v = ldg(T->P[FP_FT_V], ov); }
-        if (T->I[FI_TOP_UEK] == 2) { F.t_we_u = ldg(T->P[FP_FT_U], ou); F.t_wb_v = ldg(T->P[FP_FT_UBAR], ov); }   // wind drag: air velocities as arrays, like the ocean's below
-        if (T->I[FI_TOP_VEK] == 2) { F.t_we_v = ldg(T->P[FP_FT_V], ov); F.t_wb_u = ldg(T->P[FP_FT_VBAR], ou); }
-        if (T->I[FI_BOT_KIND] == 2) { F.b_tau_u = ldg(T->P[FP_FB_U], ou); F.b_tau_v = ldg(T->P[FP_FB_V], ov); }      // an explicit bottom stress given as arrays
+        if constexpr (EXTRA == 2) {
+            // wind drag (air velocities as arrays, like the ocean's below) and an explicit bottom stress given as arrays: instantiations
+            // of their own -- as run-time branches of the common array-forcing ones their six per-lane values (uniform numbers
+            // there) pushed those over the register budget (scratch spills: model.forcing arrays 55 -> 42 G, measured)
+            if (T->I[FI_TOP_UEK] == 2) { F.t_we_u = ldg(T->P[FP_FT_U], ou); F.t_wb_v = ldg(T->P[FP_FT_UBAR], ov); }
+            if (T->I[FI_TOP_VEK] == 2) { F.t_we_v = ldg(T->P[FP_FT_V], ov); F.t_wb_u = ldg(T->P[FP_FT_VBAR], ou); }
+            if (T->I[FI_BOT_KIND] == 2) { F.b_tau_u = ldg(T->P[FP_FB_U], ou); F.b_tau_v = ldg(T->P[FP_FB_V], ov); }
+        }
         if (T->I[FI_BOT_UEK] == 2) { F.b_we_u = ldg(T->P[FP_FB_U], ou); F.b_wb_v = ldg(T->P[FP_FB_UBAR], ov); }   // u_e: own component at u points, averaged to v points
         if (T->I[FI_BOT_VEK] == 2) { F.b_we_v = ldg(T->P[FP_FB_V], ov); F.b_wb_u = ldg(T->P[FP_FB_VBAR], ou); }   // v_e: own component at v points, averaged to u points
         if (FD) { F.fd_u = ldg(T->P[FP_FD_U], ou); F.fd_v = ldg(T->P[FP_FD_V], ov); }                             // StressBalanceFreeDrift (once per sub-cycle, csi_abi.hip)
-        if (EXTRA) {
+        if (EXTRA == 1) {
             if (F.extra & 1) { F.xc_u = ldg(T->P[FP_XC_U], ou); F.xc_v = ldg(T->P[FP_XC_V], ov); }              // model.forcing.u / .v
             if (F.extra & 2) { F.xd_u = ldg(T->P[FP_XD_U], ou); F.xd_v = ldg(T->P[FP_XD_V], ov); }              // immersed flux boundary conditions
         }
@@ -825,14 +830,22 @@ extern "C" int csi_debug_probe(unsigned long long* dst) {
 #elif CSI_PAIR_VARIANT == 7      // 7 / 8: 3 / 4 with model.forcing arrays and / or immersed flux boundary conditions (EXTRA)
 #define CSI_PAIR_NAME launch_fused_pair_force_x
 #define CSI_PAIR_FLAGS true, false, true, false
-#define CSI_PAIR_EXTRA true
-#else
+#define CSI_PAIR_EXTRA 1
+#elif CSI_PAIR_VARIANT == 8
 #define CSI_PAIR_NAME launch_fused_pair_mask_force_x
 #define CSI_PAIR_FLAGS true, true, true, false
-#define CSI_PAIR_EXTRA true
+#define CSI_PAIR_EXTRA 1
+#elif CSI_PAIR_VARIANT == 9      // 9 / 10: 3 / 4 with array-valued wind drag and / or an explicit bottom stress given as arrays (EXTRA == 2)
+#define CSI_PAIR_NAME launch_fused_pair_force_w
+#define CSI_PAIR_FLAGS true, false, true, false
+#define CSI_PAIR_EXTRA 2
+#else
+#define CSI_PAIR_NAME launch_fused_pair_mask_force_w
+#define CSI_PAIR_FLAGS true, true, true, false
+#define CSI_PAIR_EXTRA 2
 #endif
 #ifndef CSI_PAIR_EXTRA
-#define CSI_PAIR_EXTRA false
+#define CSI_PAIR_EXTRA 0
 #endif
 // common: number-valued top stress + bottom SemiImplicitStress with number-valued ocean velocities (Stage's CF; 2: zero ocean velocities); the
 // array-forcing variants have one instantiation (kinds read from the table)
@@ -878,10 +891,14 @@ void launch_fused_pair_force_fd(const FusedTable*, int, bool, int, int, int, int
 void launch_fused_pair_mask_force_fd(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
 void launch_fused_pair_force_x(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
 void launch_fused_pair_mask_force_x(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
-void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, bool extra,
+void launch_fused_pair_force_w(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair_mask_force_w(const FusedTable*, int, bool, int, int, int, int, int, unsigned long long, hipStream_t);
+void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, int extra,
                        int common, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s) {
     if (metric == 2) walls = true;      // per-point coefficients: the general variants only (none built without walls)
-    if (extra && mask) launch_fused_pair_mask_force_x(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    if (extra == 2 && mask) launch_fused_pair_mask_force_w(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (extra == 2) launch_fused_pair_force_w(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
+    else if (extra && mask) launch_fused_pair_mask_force_x(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
     else if (extra) launch_fused_pair_force_x(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
     else if (free_drift && mask) launch_fused_pair_mask_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);
     else if (free_drift) launch_fused_pair_force_fd(dev_table, metric, a_ufirst, common, nstrips, nchunks, rows, write_diag, seq, s);

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/full_pmc; rm -rf $OUT; mkdir -p $OUT
-ARGS="$REPO/scripts/bench_cases.py 2048 twelve level2"
+ARGS="$REPO/scripts/bench_cases.py 2048 ${1:-twelve} level2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
