@@ -98,3 +98,38 @@ def test_julia_shim_matches_reference_types():
     if p.returncode == 77:
         pytest.skip("no reference tree here")
     assert p.returncode == 0, p.stdout
+
+
+def test_exchange_plans_of_all_ranks_match_in_posting_order():
+    """RCCL (and the in-process tile group) match the messages between a pair of ranks in the order they were posted.  For every
+    decomposition up to 4 x 4 of periodic / bounded / north-folded grids: the sizes of the messages rank a sends to rank b, in a's
+    plan order, are the sizes b expects from a, in b's plan order -- and what b receives is the strip a sent: its global
+    coordinates (periodic wrap applied) equal those of the halo cells it fills."""
+    import itertools
+    L = csi._lib
+    Nx, Ny, H, W = 12, 10, 4, 3
+    matched = 0
+    for (Rx, Ry), (tx, ty) in itertools.product(itertools.product(range(1, 5), range(1, 5)),
+                                                itertools.product(("periodic", "bounded"), ("periodic", "bounded", "folded"))):
+        if Rx * Ry == 1 or (ty == "folded" and (Rx > 1 or tx != "periodic")):
+            continue
+        glob = {"periodic": csi.Periodic, "bounded": csi.Bounded, "folded": csi.RightFolded}
+        G = csi.RectilinearGrid((Nx * Rx, Ny * Ry), x=(0.0, 1.0), y=(0.0, 1.0), topology=(glob[tx], glob[ty]), halo=(H, H))
+        code = {csi.Periodic: L.PERIODIC, csi.Bounded: L.BOUNDED, csi.FullyConnected: L.FULLY_CONNECTED, csi.LeftConnected: L.LEFT_CONNECTED,
+                csi.RightConnected: L.RIGHT_CONNECTED, csi.RightFolded: L.RIGHT_FOLDED, csi.LeftConnectedRightFolded: L.LEFT_CONNECTED_RIGHT_FOLDED}
+        plans = {}
+        for rank in range(Rx * Ry):
+            t = csi.TileGrid(G, Rx, Ry, rank % Rx, rank // Rx)
+            args = (t.Nx, t.Ny, t.Hx, t.Hy, code[t.topology[0]], code[t.topology[1]], t.rx, t.ry, Rx, Ry, t.periodic[0], t.periodic[1], W)
+            plans[rank] = (csi.plan_exchange(*args, 0), csi.plan_exchange(*args, 1), t)
+        for a, b in itertools.product(range(Rx * Ry), repeat=2):
+            sent = [(i0, j0, ni, nj) for (peer, i0, j0, ni, nj) in plans[a][0] if peer == b]
+            want = [(i0, j0, ni, nj) for (peer, i0, j0, ni, nj) in plans[b][1] if peer == a]
+            assert [(s[2], s[3]) for s in sent] == [(w[2], w[3]) for w in want], ((Rx, Ry), (tx, ty), a, b, sent, want)
+            ta, tb = plans[a][2], plans[b][2]
+            for (si, sj, ni, nj), (wi, wj, _, _) in zip(sent, want):
+                gx = (ta.i_off + si - 1) % (Nx * Rx), (tb.i_off + wi - 1) % (Nx * Rx)
+                gy = (ta.j_off + sj - 1) % (Ny * Ry), (tb.j_off + wj - 1) % (Ny * Ry)
+                assert gx[0] == gx[1] and gy[0] == gy[1], ((Rx, Ry), (tx, ty), a, b, (si, sj), (wi, wj))
+                matched += 1
+    assert matched > 2000, matched
