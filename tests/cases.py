@@ -278,7 +278,7 @@ def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, dev
         model_kw = dict(model_kw, forcing=dict(u=fu, v=fv))
     model = csi.SeaIceModel(g, dynamics=dyn, advection=advection, timestepper=timestepper, device=device, mode=mode, **model_kw)
     if case.get("field_forcing") or case.get("wind_drag") == "arrays" or case.get("bottom") == "arrays":
-        slots = [sl for sl, on in (("TOP", case.get("field_forcing") or case.get("wind_drag") == "arrays"),
+        slots = [sl for sl, on in (("TOP", (case.get("field_forcing") and case.get("wind_drag") != "numbers") or case.get("wind_drag") == "arrays"),
                                    ("BOT", case.get("field_forcing") or case.get("bottom") == "arrays")) if on]
         for slot in slots:
             for comp in ("U", "V"):

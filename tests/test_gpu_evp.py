@@ -675,6 +675,14 @@ def test_fused_paths_fuzz_bitwise(seed):
             kw["immersed_bc"] = ((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015))
         if kw.get("user_forcing") or kw.get("immersed_bc"):
             kw.pop("free_drift", None)
+    if seed >= 40000:            # (later in round 3) wind drag (a SemiImplicitStress on top) and explicit bottom-stress arrays
+        r = rng.integers(6)
+        if r < 2:
+            kw["wind_drag"] = ("numbers", "arrays")[r]
+            kw.pop("free_drift", None)          # (StressBalanceFreeDrift takes exactly one SemiImplicitStress)
+        elif r == 2 and not kw["field_forcing"]:
+            kw["bottom"] = "arrays"
+            kw.pop("free_drift", None)
     c = cases.make_case(substeps=nsub, **kw)
     out = {}
     lvl = {}
@@ -686,7 +694,8 @@ def test_fused_paths_fuzz_bitwise(seed):
         out[fusion] = {k: cmp_region(c, k, EVP_FIELDS[k](m).numpy()).copy() for k in ("u", "v", "s11", "s22", "s12")}
         out[fusion]["alpha"] = EVP_FIELDS["alpha"](m).interior_numpy().copy()
         lvl[fusion] = m.ctx.last_path()["level"]
-    assert lvl[2] == 2 and lvl[3] in (2, 3), (kw, nsub, lvl)
+    unfused = (kw.get("wind_drag") == "arrays" or kw.get("bottom") == "arrays") and (kw.get("free_drift") or kw.get("user_forcing") or kw.get("immersed_bc"))
+    assert (lvl[2] == 0 and lvl[3] == 0) if unfused else (lvl[2] == 2 and lvl[3] in (2, 3)), (kw, nsub, lvl)   # (no instantiation with both families of arrays)
     for fusion in (2, 3):
         for k in out[0]:
             a, b = out[0][k], out[fusion][k]
