@@ -219,7 +219,15 @@ __device__ __forceinline__ int buffer_at(const GridDev& g, int i, int j, bool al
 }
 
 
-constexpr int TX = 64, TY = 4;
+// measured (scripts/r03_adv_shapes.sh, us per RK3 step at 512^2 / 1024^2 / 2048^2): 64 x 4 cells per block 55 / 185 / 762, 64 x 6: 52 / 171 / 704,
+// 32 x 12: 51 / 176 / 693, 40 x 10: 54 / 171 / 709, 64 x 2: 64 / 208 / 849 (the extra face row / column of a tile is redundant work)
+#ifndef CSI_ADV_TY
+#define CSI_ADV_TY 6
+#endif
+#ifndef CSI_ADV_TX
+#define CSI_ADV_TX 64
+#endif
+constexpr int TX = CSI_ADV_TX, TY2 = CSI_ADV_TY, TY3 = 4;      // rows of a flux tile with two tracers / with three (snow): (TX + 1)(TY + 1) tracers <= 1024 threads
 
 // One thread per cell AND TRACER of a (TX+1) x (TY+1) flux tile (threadIdx.z: h, aice [, snow thickness]): the extra column /
 // row holds the east / north faces of the tile.  Fx[i] = Ax u c~ at the west face of cell i, Fy[j] at the south face.  (Round 3:
@@ -254,7 +262,7 @@ __device__ __forceinline__ void store_tracer_images(const FRef& f, const GridDev
 // STEP (launch_advect_stage): the launch is a whole RK stage of an advection-only model -- the h thread of a cell also does
 // _dynamic_step_tracers! (k_tracer_step's arithmetic, statement for statement) with the two tendencies of its cell, into the
 // stage's OUTPUT arrays.
-template <int SCHEME, bool FAST, bool STEP = false>
+template <int SCHEME, bool FAST, bool STEP = false, int TY = TY2>
 __global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
     __shared__ double sFx[3][TY + 1][TX + 2], sFy[3][TY + 1][TX + 2];
     __shared__ double sG[STEP ? 2 : 1][STEP ? TY : 1][STEP ? TX : 1];
@@ -353,16 +361,20 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
 
 template <bool FAST>
 static void launch_tendencies_mode(const AdvDev& A, hipStream_t s) {
-    dim3 b(adv::TX + 1, adv::TY + 1, A.has_snow ? 3 : 2);
-    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY - 1) / adv::TY));
+    const int ty = A.has_snow ? adv::TY3 : adv::TY2;
+    dim3 b(adv::TX + 1, ty + 1, A.has_snow ? 3 : 2);
+    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + ty - 1) / ty));
+#define CSI_ADV_LAUNCH(S) do { if (A.has_snow) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY3>), gr, b, 0, s, A); \
+                               else hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY2>), gr, b, 0, s, A); } while (0)
     switch (A.scheme) {
-        case 1: hipLaunchKernelGGL((adv::k_tendencies<1, FAST>), gr, b, 0, s, A); break;
-        case 3: hipLaunchKernelGGL((adv::k_tendencies<3, FAST>), gr, b, 0, s, A); break;
-        case -3: hipLaunchKernelGGL((adv::k_tendencies<-3, FAST>), gr, b, 0, s, A); break;
-        case 5: hipLaunchKernelGGL((adv::k_tendencies<5, FAST>), gr, b, 0, s, A); break;
-        case -5: hipLaunchKernelGGL((adv::k_tendencies<-5, FAST>), gr, b, 0, s, A); break;
-        default: hipLaunchKernelGGL((adv::k_tendencies<7, FAST>), gr, b, 0, s, A); break;
+        case 1: CSI_ADV_LAUNCH(1); break;
+        case 3: CSI_ADV_LAUNCH(3); break;
+        case -3: CSI_ADV_LAUNCH(-3); break;
+        case 5: CSI_ADV_LAUNCH(5); break;
+        case -5: CSI_ADV_LAUNCH(-5); break;
+        default: CSI_ADV_LAUNCH(7); break;
     }
+#undef CSI_ADV_LAUNCH
 }
 // mode: CSI_MODE_STRICT (0) the oracle's arithmetic, bit for bit; CSI_MODE_FAST (1) reciprocals and contraction (header)
 void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
@@ -370,8 +382,8 @@ void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
 }
 template <bool FAST>
 static void launch_stage_mode(const AdvDev& A, hipStream_t s) {
-    dim3 b(adv::TX + 1, adv::TY + 1, 2);
-    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY - 1) / adv::TY));
+    dim3 b(adv::TX + 1, adv::TY2 + 1, 2);
+    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY2 - 1) / adv::TY2));
     switch (A.scheme) {
         case 1: hipLaunchKernelGGL((adv::k_tendencies<1, FAST, true>), gr, b, 0, s, A); break;
         case 3: hipLaunchKernelGGL((adv::k_tendencies<3, FAST, true>), gr, b, 0, s, A); break;
