@@ -281,6 +281,28 @@ function attach_tiles!(ctx, arch::Distributed, grid)
     check(ctx, ccall((:csi_comm_init, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), ctx.handle, Rx * Ry, arch.local_rank, id))
 end
 
+# Inside the sub-cycle the library moves the halos by peer-direct stores over xGMI by default (it maps its neighbours' arrays over HIP
+# IPC itself, at the first sub-cycle, through the communicator given above: halo 4 suffices); `set_halo_transport!(ctx, :rccl)`
+# selects the k-batched RCCL exchange instead (halo >= 2 k).  include/csi.h: csi_set_halo_transport.
+function set_halo_transport!(ctx, kind::Symbol)
+    kind in (:peer, :rccl) || throw(ArgumentError("halo transport :peer or :rccl"))
+    check(ctx, ccall((:csi_set_halo_transport, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, kind === :peer ? 1 : 0))
+end
+
+# Several tiles driven by ONE process (one task per tile; RCCL refuses two ranks on one device): an in-process tile group instead of
+# the RCCL communicator.  `group = local_tile_group(Rx * Ry)` once, then `attach_tiles_local!(ctx, group, rank, ...)` per tile.
+function local_tile_group(world::Integer)
+    g = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:csi_local_group_create, libcsi), Int32, (Int32, Ptr{Ptr{Cvoid}}), world, g)
+    rc == 0 || error("csi_local_group_create failed ($rc)")
+    return g[]
+end
+function attach_tiles_local!(ctx, group::Ptr{Cvoid}, rank::Integer, rx, ry, Rx, Ry, px::Bool, py::Bool)
+    check(ctx, ccall((:csi_tile_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32),
+                     ctx.handle, rx, ry, Rx, Ry, px ? 1 : 0, py ? 1 : 0))
+    check(ctx, ccall((:csi_comm_init_local, libcsi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), ctx.handle, group, rank))
+end
+
 # row whose value a halo row images: the wrapped row of a Periodic y direction, the row itself otherwise
 wrap_row(grid, j) = topology(grid, 2) == Periodic ? mod1(j, grid.Ny) : j
 
