@@ -1605,6 +1605,15 @@ int32_t do_finalize(csi_context* c) {
     for (int fid : {CSI_F_S11, CSI_F_S12, CSI_F_S22}) { B.f[B.n] = ref_of(c, fid); B.im[B.n] = image_spec(c, fid); ++B.n; }
     launch_fill_halo_batch(B, c->g, c->stream);
     HIP_TRY(c, hipGetLastError());
+    // fill_halo_regions!(sigma) across tiles.  After a sub-cycle on the peer transport there is nothing to move: the neighbours' last
+    // launch stored the images of their sigma into all H halo layers beyond the connected sides (and k_wait_peers has seen them
+    // land) -- exactly the values an exchange would bring; what it would ALSO bring are the neighbours' own y fills in the corners
+    // (beyond a wall next to a connected x side: nobody stores mirror images of sigma): the same fill on this tile's halo columns
+    if (c->peer.last && is_tiled(c)) {
+        launch_fill_halo_xcolumns(B, c->g, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        return CSI_OK;
+    }
     const int sg[3] = {CSI_F_S11, CSI_F_S12, CSI_F_S22};
     return exchange(c, sg, 3, c->Hx < c->Hy ? c->Hx : c->Hy);
 }

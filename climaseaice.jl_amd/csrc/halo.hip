@@ -68,6 +68,40 @@ __global__ void k_fill_halo_batch(HaloBatch B, GridDev g, int strip) {
     }
     store_with_images(f, g, im, i, j, f(i, j));
 }
+// The y images (mirror / wrap) of the halo COLUMNS beyond connected x sides: what a halo exchange of full-height strips brings
+// along in the corners (the neighbour's own y fill), done locally where the columns themselves are already current -- after a
+// sub-cycle on the peer halo transport (csi_abi.hip do_finalize).  Rows within Hy of the y edges, columns 1 - Hx .. 0 and Nx + 1 .. Nx + Hx.
+__global__ void k_fill_halo_xcolumns(HaloBatch B, GridDev g, int rows) {
+    const FRef f = B.f[blockIdx.z];
+    const ImageSpec im = B.im[blockIdx.z];
+    const int Nx = g.Nx, Ny = g.Ny, Hx = g.Hx, Hy = g.Hy;
+    int ii = blockIdx.x * blockDim.x + threadIdx.x, jj = blockIdx.y * blockDim.y + threadIdx.y;
+    int i, j;
+    if (!rows) {
+        // halo columns beyond connected x sides, rows within Hy of the y edges: their y images
+        if (ii >= 2 * Hx + 1 || jj >= 2 * Hy + im.ey) return;
+        i = ii < Hx ? 1 - Hx + ii : Nx + 1 + (ii - Hx);
+        if ((i < 1 && g.xlo != SIDE_CONNECTED) || (i > Nx && g.xhi != SIDE_CONNECTED) || i > Nx + Hx) return;
+        j = jj < Hy ? 1 + jj : Ny - 2 * Hy + 1 + jj;
+        if (j < 1 || j > Ny + im.ey || (jj >= Hy && j <= Hy)) return;
+    } else {
+        // halo rows beyond connected y sides, columns within Hx of the x edges: their x images
+        if (jj >= 2 * Hy + 1 || ii >= 2 * Hx + im.ex) return;
+        j = jj < Hy ? 1 - Hy + jj : Ny + 1 + (jj - Hy);
+        if ((j < 1 && g.ylo != SIDE_CONNECTED) || (j > Ny && g.yhi != SIDE_CONNECTED) || j > Ny + Hy) return;
+        i = ii < Hx ? 1 + ii : Nx - 2 * Hx + 1 + ii;
+        if (i < 1 || i > Nx + im.ex || (ii >= Hx && i <= Hx)) return;
+    }
+    store_with_images(f, g, im, i, j, f(i, j));                  // (outside the interior in one direction: the images of the other only)
+}
+void launch_fill_halo_xcolumns(const HaloBatch& B, const GridDev& g, hipStream_t s) {
+    if (B.n <= 0) return;
+    dim3 b(16, 16);
+    const dim3 gr((unsigned)((2 * g.Hx + 1 + 15) / 16), (unsigned)((2 * g.Hy + 1 + 15) / 16), (unsigned)B.n);
+    if (g.xlo == SIDE_CONNECTED || g.xhi == SIDE_CONNECTED) hipLaunchKernelGGL(k_fill_halo_xcolumns, gr, b, 0, s, B, g, 0);
+    if (g.ylo == SIDE_CONNECTED || g.yhi == SIDE_CONNECTED) hipLaunchKernelGGL(k_fill_halo_xcolumns, gr, b, 0, s, B, g, 1);
+}
+
 void launch_fill_halo_batch(const HaloBatch& B, const GridDev& g, hipStream_t s) {
     if (B.n <= 0) return;
     dim3 b(64, 4);
