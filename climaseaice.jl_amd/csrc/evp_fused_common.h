@@ -73,8 +73,12 @@ __device__ __forceinline__ unsigned ldub(unsigned long base, unsigned off) {
     return *(const __attribute__((address_space(1))) unsigned char*)((gptr_t)base + off);
 }
 __device__ __forceinline__ void stg(unsigned long base, unsigned off, double v) {
-#if CSI_NT_STORE
+#if CSI_NT_STORE == 1
     __builtin_nontemporal_store(v, (__attribute__((address_space(1))) double*)((gptr_t)base + off));
+#elif CSI_NT_STORE == 2      // write-through at agent scope (sc1): the line leaves the XCD's L2 during the launch, not at its end
+    __scoped_atomic_store_n((__attribute__((address_space(1))) long*)((gptr_t)base + off), __builtin_bit_cast(long, v), __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+#elif CSI_NT_STORE == 3      // ... at system scope (sc0 sc1)
+    __scoped_atomic_store_n((__attribute__((address_space(1))) long*)((gptr_t)base + off), __builtin_bit_cast(long, v), __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
 #else
     *(__attribute__((address_space(1))) double*)((gptr_t)base + off) = v;
 #endif

@@ -673,61 +673,78 @@ void ora_time_step_momentum(ora_problem* g, double dt, int rk_reset) {
 /* ------------------------------------------------------------------------ */
 #define WENO_EPS 1e-8
 
-static double weno5(const double* p) {
+/* (the *_parts functions expose the candidate values q, the smoothness indicators b, the unnormalised weights a and tau
+ * to tests/test_weno_published.py through ora_test_weno; weno5 / weno7 / weno3 combine them in the order they always did) */
+static void weno5_parts(const double* p, double* q, double* b, double* a, double* tau_out) {
     /* p[0..4] = psi at (upwind-2, upwind-1, upwind, downwind, downwind+1) */
-    double q0 = (2 * p[2] + 5 * p[3] - p[4]) / 6;      /* stencil 0: (upwind, dw, dw+1) */
-    double q1 = (-p[1] + 5 * p[2] + 2 * p[3]) / 6;     /* stencil 1 */
-    double q2 = (2 * p[0] - 7 * p[1] + 11 * p[2]) / 6; /* stencil 2 */
-    double b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
-    double b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
-    double b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
-    double tau = fabs(b0 - b2);
-    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS), r2 = tau / (b2 + WENO_EPS);
-    double a0 = (3.0 / 10) * (1 + r0 * r0);
-    double a1 = (3.0 / 5) * (1 + r1 * r1);
-    double a2 = (1.0 / 10) * (1 + r2 * r2);
-    double s = a0 + a1 + a2;
-    return (a0 * q0 + a1 * q1 + a2 * q2) / s;
+    q[0] = (2 * p[2] + 5 * p[3] - p[4]) / 6;      /* stencil 0: (upwind, dw, dw+1) */
+    q[1] = (-p[1] + 5 * p[2] + 2 * p[3]) / 6;     /* stencil 1 */
+    q[2] = (2 * p[0] - 7 * p[1] + 11 * p[2]) / 6; /* stencil 2 */
+    b[0] = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
+    b[1] = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
+    b[2] = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
+    double tau = fabs(b[0] - b[2]);
+    double r0 = tau / (b[0] + WENO_EPS), r1 = tau / (b[1] + WENO_EPS), r2 = tau / (b[2] + WENO_EPS);
+    a[0] = (3.0 / 10) * (1 + r0 * r0);
+    a[1] = (3.0 / 5) * (1 + r1 * r1);
+    a[2] = (1.0 / 10) * (1 + r2 * r2);
+    *tau_out = tau;
+}
+static double weno5(const double* p) {
+    double q[3], b[3], a[3], tau;
+    weno5_parts(p, q, b, a, &tau);
+    double s = a[0] + a[1] + a[2];
+    return (a[0] * q[0] + a[1] * q[1] + a[2] * q[2]) / s;
 }
 static double upwind5(const double* p) {
     /* UpwindBiased(order=5): optimal linear combination of the three stencils */
     return (2 * p[0] - 13 * p[1] + 47 * p[2] + 27 * p[3] - 3 * p[4]) / 60;
 }
-static double weno7(const double* p) {
+static void weno7_parts(const double* p, double* q, double* b, double* a, double* tau_out) {
     /* p[0..6] = psi at (up-3, up-2, up-1, up, dw, dw+1, dw+2) */
-    double q0 = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) / 12;
-    double q1 = (-p[2] + 7 * p[3] + 7 * p[4] - p[5]) / 12;
-    double q2 = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) / 12;
-    double q3 = (-3 * p[0] + 13 * p[1] - 23 * p[2] + 25 * p[3]) / 12;
-    double b0 = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
-                p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
-    double b1 = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
-                p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
-    double b2 = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
-                p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
-    double b3 = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
-                p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
-    double tau = fabs(b0 + 3 * b1 - 3 * b2 - b3);
-    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS), r2 = tau / (b2 + WENO_EPS), r3 = tau / (b3 + WENO_EPS);
-    double a0 = (4.0 / 35) * (1 + r0 * r0);
-    double a1 = (18.0 / 35) * (1 + r1 * r1);
-    double a2 = (12.0 / 35) * (1 + r2 * r2);
-    double a3 = (1.0 / 35) * (1 + r3 * r3);
-    double s = a0 + a1 + a2 + a3;
-    return (a0 * q0 + a1 * q1 + a2 * q2 + a3 * q3) / s;
+    q[0] = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) / 12;
+    q[1] = (-p[2] + 7 * p[3] + 7 * p[4] - p[5]) / 12;
+    q[2] = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) / 12;
+    q[3] = (-3 * p[0] + 13 * p[1] - 23 * p[2] + 25 * p[3]) / 12;
+    b[0] = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
+           p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
+    b[1] = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
+           p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
+    b[2] = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
+           p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
+    b[3] = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
+           p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
+    double tau = fabs(b[0] + 3 * b[1] - 3 * b[2] - b[3]);
+    double r0 = tau / (b[0] + WENO_EPS), r1 = tau / (b[1] + WENO_EPS), r2 = tau / (b[2] + WENO_EPS), r3 = tau / (b[3] + WENO_EPS);
+    a[0] = (4.0 / 35) * (1 + r0 * r0);
+    a[1] = (18.0 / 35) * (1 + r1 * r1);
+    a[2] = (12.0 / 35) * (1 + r2 * r2);
+    a[3] = (1.0 / 35) * (1 + r3 * r3);
+    *tau_out = tau;
+}
+static double weno7(const double* p) {
+    double q[4], b[4], a[4], tau;
+    weno7_parts(p, q, b, a, &tau);
+    double s = a[0] + a[1] + a[2] + a[3];
+    return (a[0] * q[0] + a[1] * q[1] + a[2] * q[2] + a[3] * q[3]) / s;
+}
+static void weno3_parts(const double* p, double* q, double* b, double* a, double* tau_out) {
+    /* p[0..2] = psi at (upwind-1, upwind, downwind): WENO(order = 3), the buffer scheme of order 5 */
+    q[0] = (p[1] + p[2]) / 2;                     /* stencil 0: (upwind, dw) */
+    q[1] = (-p[0] + 3 * p[1]) / 2;                /* stencil 1: (upwind-1, upwind) */
+    b[0] = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
+    b[1] = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
+    double tau = fabs(b[0] - b[1]);
+    double r0 = tau / (b[0] + WENO_EPS), r1 = tau / (b[1] + WENO_EPS);
+    a[0] = (2.0 / 3) * (1 + r0 * r0);
+    a[1] = (1.0 / 3) * (1 + r1 * r1);
+    *tau_out = tau;
 }
 static double weno3(const double* p) {
-    /* p[0..2] = psi at (upwind-1, upwind, downwind): WENO(order = 3), the buffer scheme of order 5 */
-    double q0 = (p[1] + p[2]) / 2;                     /* stencil 0: (upwind, dw) */
-    double q1 = (-p[0] + 3 * p[1]) / 2;                /* stencil 1: (upwind-1, upwind) */
-    double b0 = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
-    double b1 = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
-    double tau = fabs(b0 - b1);
-    double r0 = tau / (b0 + WENO_EPS), r1 = tau / (b1 + WENO_EPS);
-    double a0 = (2.0 / 3) * (1 + r0 * r0);
-    double a1 = (1.0 / 3) * (1 + r1 * r1);
-    double s = a0 + a1;
-    return (a0 * q0 + a1 * q1) / s;
+    double q[2], b[2], a[2], tau;
+    weno3_parts(p, q, b, a, &tau);
+    double s = a[0] + a[1];
+    return (a[0] * q[0] + a[1] * q[1]) / s;
 }
 static double upwind3(const double* p) {
     /* UpwindBiased(order = 3), the buffer scheme of UpwindBiased(order = 5) */
@@ -777,6 +794,22 @@ static double reconstruct(int scheme, const double* line, int64_t up, int64_t st
     }
     for (int k = 0; k < 7; ++k) p[k] = line[up + (k - 3) * st];
     return weno7(p);
+}
+/* Test hook (tests/test_weno_published.py): the parts of one reconstruction.  order 3 / 5 / 7: WENO; -3 / -5: UpwindBiased
+ * (value only).  p: the 2B - 1 stencil values, upwind-most first (B = (|order| + 1) / 2); out: value, then for WENO
+ * q[0..B-1], beta[0..B-1], alpha[0..B-1] (unnormalised weights), tau.  Returns the number of doubles written. */
+int ora_test_weno(int order, const double* p, double* out) {
+    double q[4], b[4], a[4], tau = 0.0;
+    int B = 0;
+    if (order == -3) { out[0] = upwind3(p); return 1; }
+    if (order == -5) { out[0] = upwind5(p); return 1; }
+    if (order == 3) { B = 2; out[0] = weno3(p); weno3_parts(p, q, b, a, &tau); }
+    else if (order == 5) { B = 3; out[0] = weno5(p); weno5_parts(p, q, b, a, &tau); }
+    else if (order == 7) { B = 4; out[0] = weno7(p); weno7_parts(p, q, b, a, &tau); }
+    else return 0;
+    for (int k = 0; k < B; ++k) { out[1 + k] = q[k]; out[1 + B + k] = b[k]; out[1 + 2 * B + k] = a[k]; }
+    out[1 + 3 * B] = tau;
+    return 2 + 3 * B;
 }
 static int buffer_at(const ora_problem* g, int scheme, int i, int j, int dir, int left) {
     const int B0 = scheme == 7 ? 4 : (scheme == 1 ? 1 : ((scheme == 3 || scheme == -3) ? 2 : 3));   /* order 2B - 1 */

@@ -177,6 +177,7 @@ void ora_compute_tracer_tendencies(ora_problem* g, int scheme);
 /* _dynamic_step_tracers!, sea_ice_fe_step.jl:56-82; from_cache: (h^n, aice^n) = Psi^- (sea_ice_rk_substep.jl:140-149) */
 void ora_dynamic_step_tracers(ora_problem* g, double dt, int from_cache);
 double ora_weno_flux_x(const ora_problem* g, int scheme, ora_field c, int i, int j);
+int ora_test_weno(int order, const double* p, double* out);   /* test hook: parts of one reconstruction */
 double ora_weno_flux_y(const ora_problem* g, int scheme, ora_field c, int i, int j);
 
 /* ---- whole steps: FE (sea_ice_fe_step.jl:13-34) and RK3 (sea_ice_rk_substep.jl:29-94 + upstream stage loop) ---- */
