@@ -409,6 +409,8 @@ def main():
         gf = global_fields(np, nx_l, ny_l, Rx, Ry)
     transport_note = None
     bitwise = None
+    peer_tier = 0                 # run-time ladder of the peer protocol (include/csi.h, csi_set_peer_tier): 0 -> 1 -> 2 -> RCCL exchange
+    ladder = []
     peer_expected = tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
         and not args.no_fusion and args.fusion_level >= 2 and nx_l >= 128
     while True:
@@ -427,8 +429,17 @@ def main():
                     problem = "the tiled run did not reproduce the one-GPU run bit for bit"
         except csi.CsiError as e:
             problem = f"library error: {e}"
+        on_peer = tiled and model.ctx.halo_transport() == "peer"
+        if on_peer:
+            ladder.append({"tier": peer_tier, "passed": problem is None, "problem": problem})
         if all_ranks(problem is None):
             break
+        if all_ranks(on_peer) and peer_tier < 2:
+            # every rank is on the peer transport and some rank's check failed: the next tier of its memory-ordering protocol, on ALL ranks
+            peer_tier += 1
+            sys.stderr.write(f"bench.py[rank {rank}]: peer transport, tier {peer_tier - 1}: {problem or 'another rank reported a problem'}; trying tier {peer_tier}\n")
+            model.set_peer_tier(peer_tier)
+            continue
         if model.ctx.halo_transport() == "peer" or (peer_expected and transport_note is None):
             transport_note = f"peer transport given up ({problem or 'another rank reported a problem'}): RCCL exchange (halo 32, k = 16) timed instead"
             sys.stderr.write(f"bench.py[rank {rank}]: {transport_note}\n")
@@ -454,6 +465,10 @@ def main():
     path["halo_transport"] = model.ctx.halo_transport() if tiled else "none"
     if transport_note:
         path["halo_transport_note"] = transport_note
+    if tiled and path["halo_transport"] == "peer":
+        path["peer_tier"] = model.ctx.peer_tier()
+    if ladder:
+        path["peer_tier_ladder"] = ladder          # which tiers were tried before the timed region, and what each check said
 
     # ---- result check (outside the timed region): the state the timed steps produced is finite and non-trivial -------
     model.synchronize()

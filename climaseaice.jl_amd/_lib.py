@@ -31,7 +31,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_local_group_create", "csi_local_group_destroy", "csi_comm_init_local", "csi_halo_exchange",
-           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
+           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_set_peer_tier", "csi_peer_tier", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
            "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
 
 
@@ -122,6 +122,7 @@ def load():
         "csi_plan_pair": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_set_exchange_interval": [vp, i32],
         "csi_set_halo_transport": [vp, i32], "csi_halo_transport": [vp, C.POINTER(i32)],
+        "csi_set_peer_tier": [vp, i32], "csi_peer_tier": [vp, C.POINTER(i32)],
         "csi_set_fusion": [vp, i32], "csi_free_drift_set": [vp, i32],
         "csi_coriolis_rows_set": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32],
         "csi_velocity_bc_set": [vp, i32, i32, i32, dbl],
@@ -249,6 +250,12 @@ class Context:
         v = C.c_int32()
         self.call("csi_halo_transport", C.byref(v))
         return "peer" if v.value == 1 else "rccl"
+
+    def peer_tier(self):
+        """protocol tier of the peer halo transport (csi_peer_tier): 0 write-through + flags, 1 + acquire fence, 2 + release fence"""
+        v = C.c_int32()
+        self.call("csi_peer_tier", C.byref(v))
+        return v.value
 
     def last_launches(self):
         """(kernel launches, sub-steps) of the last fused sub-cycle."""

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(64) k_wait_peers(const unsigned long long* slo
                 if (idx < n) behind |= __hip_atomic_load(q + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq;
             }
             if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
-            if (wall_clock64() - t0 > 300000000ull || *(volatile unsigned*)err != 0u) { if (lane == 0) *err = 1u; return; }
+            // (the abort word of the block: a neighbour's wait has given up, evp_fused2.hip)
+            const bool poison = lane == 63 && __hip_atomic_load(q + (slots_per_dir - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+            if (__builtin_amdgcn_ballot_w64(poison | (*(volatile unsigned*)err != 0u)) != 0 || wall_clock64() - t0 > 300000000ull) { if (lane == 0) *err = 1u; return; }
             __builtin_amdgcn_s_sleep(16);
         }
     }

@@ -116,7 +116,7 @@ struct csi_context {
     // halo.  "rccl": ncclSend / ncclRecv of width-2k strips every k sub-steps (the fallback, and what every other path uses).
     struct Peer {
         static constexpr int NARR = 14;      // u, v, sigma11, sigma22, sigma12 (caller's), the same five (library's ping-pong copies), alpha, zeta_c, zeta_f, Delta
-        static constexpr int SLOTS = 1024;   // flag slots per direction
+        static constexpr int SLOTS = kPeerSlots;   // flag slots per direction (the last one is the block's abort word)
         int want = 1;                        // csi_set_halo_transport: 1 peer where possible, 0 RCCL only
         int dld[8][2] = {};                  // per direction x {Center, Face in x}: the neighbour's row stride minus this tile's, bytes
         int nbr_wait[8] = {};                // flags to wait for per direction: the size of the NEIGHBOUR's opposite set (its own geometry)
@@ -133,6 +133,7 @@ struct csi_context {
         std::vector<void*> opened;           // IPC mappings
         uint8_t* xbuf = nullptr;             // device staging of the set-up's all-gather
         int last = 0;                        // the last sub-cycle used the peer transport
+        int tier = 0;                        // protocol tier (csi_set_peer_tier; FI_PTIER of the kernel tables)
     } peer;
     ExPlan pending_rp;                   // the receive plan of an exchange that has been begun
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
@@ -861,7 +862,7 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         r.local_ptr = (uint64_t)ptr;
         if (q == 0 && local_ok) {
             const PeerSets ps = peer_my_sets(c);
-            for (int d = 0; d < 8; ++d) { r.set_size[d] = ps.size[d]; if (ps.size[d] > csi_context::Peer::SLOTS) ok = 0; }
+            for (int d = 0; d < 8; ++d) { r.set_size[d] = ps.size[d]; if (ps.size[d] >= csi_context::Peer::SLOTS) ok = 0; }
         }
         if (ok && c->world > 1 && !c->local) {               // (a single rank / an in-process group addresses the arrays directly)
             hipDeviceptr_t base = nullptr; size_t size = 0;
@@ -976,7 +977,7 @@ int32_t peer_fill_table(csi_context* c, const FusedGeom& G, bool out_is_alt, Fus
     const csi_context::Peer& pr = c->peer;
     const PeerSets ps = peer_wait_counts(c, G);
     for (int d = 0; d < 8; ++d)
-        if (ps.size[d] > csi_context::Peer::SLOTS) return fail(c, CSI_ERR_UNSUPPORTED, "peer halo transport: more edge tiles than flag slots");
+        if (ps.size[d] >= csi_context::Peer::SLOTS) return fail(c, CSI_ERR_UNSUPPORTED, "peer halo transport: more edge tiles than flag slots");
     static const int karr[9] = {2, 3, 4, 0, 1, 10, 11, 12, 13};      // kernel order (sigma11, sigma22, sigma12, u, v, alpha, zeta_c, zeta_f, Delta) -> Peer::arr
     for (int k = 0; k < 9; ++k)
         for (int d = 0; d < 8; ++d) {
@@ -997,6 +998,7 @@ int32_t peer_fill_table(csi_context* c, const FusedGeom& G, bool out_is_alt, Fus
     t->I[FI_NYLO] = c->peer.ny_below > 0 ? c->peer.ny_below : c->Ny;
     t->P[FP_PERR] = (unsigned long)pr.err;
     t->I[FI_PEER] = 1; t->I[FI_PMASK] = mask;
+    t->I[FI_PTIER] = pr.tier;
     t->I[FI_PSET] = ps.nW; t->I[FI_PSET + 1] = ps.nE; t->I[FI_PSET + 2] = ps.nS; t->I[FI_PSET + 3] = ps.nN;
     return CSI_OK;
 }
@@ -1411,6 +1413,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     return CSI_OK;
 }
 
+int32_t peer_check_entry(csi_context* c);      // (defined with csi_sync)
+
 // One sub-cycle on the peer transport: an RCCL exchange of u, v, sigma brings the halos up to date (and orders this rank behind
 // whatever its neighbours did last), then the connected sides count as periodic ones for the launch loop.
 int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int substeps, int first) {
@@ -1489,6 +1493,7 @@ int32_t run_fused_fold(csi_context* c, const EvpDev& Pfull, const FastCoef& fc, 
 
 int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     int32_t rc;
+    if ((rc = peer_check_entry(c))) return rc;
     {                                                // :170-171, both fields in one batch of two launches
         HaloBatch B{};
         B.f[0] = ref_of(c, CSI_F_U); B.im[0] = image_spec(c, CSI_F_U);
@@ -1868,16 +1873,28 @@ int32_t csi_context_destroy(csi_context* c) {
     return CSI_OK;
 }
 
+// A wait of the peer halo transport has given up (this rank's error word, copied to pinned memory behind every sub-cycle): the
+// sub-cycle that saw it is invalid on this rank and -- through the abort words -- on its neighbours.  Reported by EVERY entry
+// point that advances the model (at its start and at its end) and by csi_sync, whichever comes first; the words are cleared so
+// that the caller may go on (the launch numbers stay in step on all ranks: they are counted on the host).
+static int32_t peer_check(csi_context* c);
+namespace { int32_t peer_check_entry(csi_context* c) { return peer_check(c); } }
+static int32_t peer_check(csi_context* c) {
+    if (c->peer.err_host && *c->peer.err_host) {
+        *c->peer.err_host = 0;
+        hipMemsetAsync(c->peer.err, 0, sizeof(unsigned), c->stream);
+        for (int d = 0; d < 8; ++d)
+            hipMemsetAsync(c->peer.slots + (size_t)d * csi_context::Peer::SLOTS + (csi_context::Peer::SLOTS - 1), 0, sizeof(unsigned long long), c->stream);
+        return fail(c, CSI_ERR_COMM, "peer halo transport: a tile waited 3 s for its neighbour's flags and gave up (or a neighbouring rank did) -- the results of "
+                                     "that sub-cycle are invalid (a rank that fell behind or died; csi_set_halo_transport(ctx, CSI_TRANSPORT_RCCL) selects "
+                                     "the RCCL exchange)");
+    }
+    return CSI_OK;
+}
 int32_t csi_sync(csi_context* c) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->peer.err_host && *c->peer.err_host) {
-        *c->peer.err_host = 0;
-        hipMemset(c->peer.err, 0, sizeof(unsigned));
-        return fail(c, CSI_ERR_COMM, "peer halo transport: a tile waited 3 s for its neighbour's flags and gave up -- the results of that sub-cycle are "
-                                     "invalid (a rank that fell behind or died; csi_set_halo_transport(ctx, CSI_TRANSPORT_RCCL) selects the RCCL exchange)");
-    }
-    return CSI_OK;
+    return peer_check(c);
 }
 
 int32_t csi_set_mode(csi_context* c, int32_t mode) {
@@ -2093,7 +2110,8 @@ int32_t csi_evp_subcycle(csi_context* c, double dt, int32_t substeps, int32_t fi
     int32_t rc = need_evp(c);
     if (rc) return rc;
     if (substeps < 0 || first_substep < 1) return fail(c, CSI_ERR_INVALID_ARGUMENT, "substeps >= 0 and first_substep >= 1 required");
-    return do_subcycle(c, dt, substeps, first_substep);
+    rc = do_subcycle(c, dt, substeps, first_substep);
+    return rc ? rc : peer_check(c);
 }
 
 int32_t csi_evp_finalize(csi_context* c) {
@@ -2108,7 +2126,8 @@ int32_t csi_time_step_momentum(csi_context* c, double dt, int32_t substeps, int3
     int32_t rc = need_evp(c);
     if (rc) return rc;
     if (substeps < 0) return fail(c, CSI_ERR_INVALID_ARGUMENT, "substeps >= 0 required");
-    return do_time_step_momentum(c, dt, substeps, rk_reset);
+    rc = do_time_step_momentum(c, dt, substeps, rk_reset);
+    return rc ? rc : peer_check(c);
 }
 
 int32_t csi_compute_tracer_tendencies(csi_context* c, int32_t scheme) {
@@ -2175,7 +2194,8 @@ int32_t csi_time_step_fe(csi_context* c, double dt, int32_t substeps, int32_t sc
     const bool fused_fill = !c->g.has_mask && !c->slab_set;
     if ((rc = do_tracer_step(c, dt, 0, fused_fill))) return rc;           // :25
     if ((rc = do_thermo(c, dt))) return rc;                               // :28 thermodynamic_time_step!
-    return do_update_state(c, true, fused_fill);                          // :31
+    if ((rc = do_update_state(c, true, fused_fill))) return rc;           // :31
+    return peer_check(c);
 }
 
 // An RK3 step of an advection-only model (prescribed velocities: examples/ice_advected_by_anticyclone.jl's family, BASELINE
@@ -2249,7 +2269,7 @@ int32_t csi_time_step_rk3(csi_context* c, double dt, int32_t substeps, int32_t s
         if ((rc = do_thermo(c, dtau))) return rc;                         // :91 thermodynamic_time_step!
         if ((rc = do_update_state(c, true, fused_fill))) return rc;
     }
-    return CSI_OK;
+    return peer_check(c);
 }
 
 int32_t csi_slab_thermo_step(csi_context* c, const csi_slab_params* p, double dt) {
@@ -2412,6 +2432,17 @@ int32_t csi_set_halo_transport(csi_context* c, int32_t kind) {
 int32_t csi_halo_transport(csi_context* c, int32_t* kind) {
     if (!c || !kind) return CSI_ERR_INVALID_ARGUMENT;
     *kind = c->peer.last ? CSI_TRANSPORT_PEER : CSI_TRANSPORT_RCCL;
+    return CSI_OK;
+}
+int32_t csi_set_peer_tier(csi_context* c, int32_t tier) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (tier < 0 || tier > 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "peer protocol tier must be 0, 1 or 2");
+    c->peer.tier = tier;
+    return CSI_OK;
+}
+int32_t csi_peer_tier(csi_context* c, int32_t* tier) {
+    if (!c || !tier) return CSI_ERR_INVALID_ARGUMENT;
+    *tier = c->peer.tier;
     return CSI_OK;
 }
 

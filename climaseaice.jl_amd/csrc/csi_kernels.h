@@ -63,7 +63,12 @@ enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_
              FI_PDLD = FI_PWAIT + 8,    // per direction x {Center in x, Face in x}: the neighbour's row stride minus this tile's, in bytes
              FI_PHASDLD = FI_PDLD + 16, // any of them non-zero (a Bounded x direction partitioned in x: the easternmost tile's Face fields are one column wider)
              FI_NYLO,                   // PEER: Ny of the neighbour beyond the LOW y side (rows of the image shift of this tile's low rows; a fold tile's own Ny is cut)
+             FI_PTIER,                  // peer protocol tier (csi_set_peer_tier): 0 write-through images + drained stores + flags; 1: + a system-scope acquire
+                                        // fence once the flags have been seen; 2: + a system-scope release fence before the flags are published
              FI_COUNT };
+// peer flag arrays: slots per direction block; the LAST slot of a block is the abort word (a neighbour whose wait has given up sets
+// it: this rank's waits stop at once)
+constexpr int kPeerSlots = 1024;
 struct FusedTable {
     double K[FK_COUNT];
     unsigned long P[FP_COUNT];

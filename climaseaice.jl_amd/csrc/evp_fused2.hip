@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[RING_ROWS * 64];
     __shared__ double outr[2 * 5 * 64];                    // stage B's results on their way to the producer's stores
+    __shared__ unsigned peer_abort;                        // PEER: the producer's wait has given up
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
     if (w >= nstrips * nchunks) return;                      // (uniform over the workgroup: both waves leave)
@@ -204,9 +205,15 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 // with halo cells of a direction is in that direction's set and loads nothing before it has seen the flags, and the
                 // vector L1 starts every launch empty -- so no line of these halos can have been fetched before the neighbour's
                 // stores landed in this GPU's memory (whose L2 is kept coherent with incoming writes by the memory-side probes).
+                // A wait that gives up (3 s at 100 MHz; or this rank's error word / a neighbour's abort word is already set) never
+                // hangs and never lets the tile run on stale halos: the workgroup leaves WITHOUT storing or publishing anything, sets
+                // this rank's error word (the host reports it at the next ABI call, csi_sync included) and the abort word of every
+                // neighbour's flag array (the last slot of each direction's block), so that the ranks around stop waiting at once
+                // instead of three seconds later each.  The sub-cycle is lost on every rank that sees it.
                 const unsigned long long t0 = wall_clock64();
+                bool dead = false;
                 for (;;) {
-                    bool behind = false;
+                    bool behind = false, poison = false;
 #pragma unroll
                     for (int d = 0; d < 8; ++d) {
                         if (!((pdirs >> d) & 1u)) continue;
@@ -217,19 +224,30 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                             const int idx = b0 + lane;
                             if (idx < nslots) behind |= __hip_atomic_load(slots + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1ull < seq;   // v < seq - 1
                         }
+                        if (lane == 63) poison |= __hip_atomic_load(slots + (kPeerSlots - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
                     }
                     if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
-                    // 3 s at 100 MHz: give up loudly, never hang -- and once a wait has given up (the word stays set until the host
-                    // has reported it, csi_sync), none waits again: the sub-cycle is lost anyway
-                    if (wall_clock64() - t0 > 300000000ull || *(volatile unsigned*)T->P[FP_PERR] != 0u) {
-                        if (lane == 0) *(volatile unsigned*)T->P[FP_PERR] = 1u;
-                        break;
-                    }
+                    if (__builtin_amdgcn_ballot_w64(poison | (*(volatile unsigned*)T->P[FP_PERR] != 0u)) != 0 || wall_clock64() - t0 > 300000000ull) { dead = true; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
+                if (dead) {
+                    if (lane == 0) *(volatile unsigned*)T->P[FP_PERR] = 1u;
+                    if (lane < 8) {
+                        typedef const __attribute__((address_space(4))) unsigned long* sptr_t;
+                        unsigned long long* out = (unsigned long long*)((sptr_t)&T->P[FP_SLOT_OUT])[lane];       // (the whole block of direction `lane` at the neighbour)
+                        if (out) __hip_atomic_store(out + (kPeerSlots - 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+                if (lane == 0) peer_abort = dead ? 1u : 0u;
+                // Run-time protocol tiers (FI_PTIER, csi_set_peer_tier; chosen by the host for ALL ranks).  0: the reasoning above.
+                // >= 1: the textbook acquire as well -- a system-scope fence once the flags have been seen (invalidates this
+                // CU's vector L1 and the L2 lines that are not kept coherent by hardware), should that reasoning not hold
+                // between two devices.  (>= 2: the publishing side fences too, see publish.)
+                if (T->I[FI_PTIER] >= 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();                                         // (uniform over the workgroup) releases the consumer's stores
+            if (peer_abort) return;                                  // (LDS word: both waves take the same way)
         }
     }
     // byte offset of (this lane's column, row j) in a Center-x / Face-x parent, and into the mask
@@ -641,8 +659,10 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             // this tile is done with launch seq: its images are stored (release at system scope) and its halo reads are complete
             // (the producer's loads were consumed before its last barrier).  One lane per direction publishes seq in this tile's
             // slot of that neighbour's flag array.
-            if (CSI_PEER_EXP & 1) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: this wave's stores are in their -- possibly remote -- memory
+            // tier >= 2: a system-scope release fence (writes this XCD's L2 back: + 6 us per launch on a 1024 x 512 tile) on top of
+            // the write-through image stores and the drained store queue
+            if ((CSI_PEER_EXP & 1) && T->I[FI_PTIER] < 2) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // system scope: this wave's stores are in their -- possibly remote -- memory
             if ((lane < 8) && ((pdirs >> lane) & 1u)) {
                 const int nW = T->I[FI_PSET], nE = T->I[FI_PSET + 1], nN = T->I[FI_PSET + 3];
                 const bool xw = (lane == D_W) | (lane == D_SW) | (lane == D_NW), xe = (lane == D_E) | (lane == D_SE) | (lane == D_NE);

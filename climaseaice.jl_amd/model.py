@@ -407,6 +407,11 @@ class SeaIceModel:
         k-batched ncclSend / ncclRecv exchange (include/csi.h, csi_set_halo_transport)."""
         self.ctx.call("csi_set_halo_transport", {"rccl": 0, "peer": 1}[kind])
 
+    def set_peer_tier(self, tier):
+        """Tiles on the peer transport: the memory-ordering tier of its flag protocol, the SAME on every rank (0 default, 1 + acquire
+        fence behind the flags, 2 + release fence before them; include/csi.h, csi_set_peer_tier)."""
+        self.ctx.call("csi_set_peer_tier", int(tier))
+
     def set_mask(self, active):
         """ImmersedBoundaryGrid stand-in: `active` is a (Ny, Nx) boolean array of wet cells of the WHOLE domain (for a
         tile: of the global grid; the tile's mask, halo included, is sliced from it -- the mask is static, so no

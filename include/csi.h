@@ -404,6 +404,17 @@ int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 enum { CSI_TRANSPORT_RCCL = 0, CSI_TRANSPORT_PEER = 1 };
 int32_t csi_set_halo_transport(csi_context* ctx, int32_t kind);
 int32_t csi_halo_transport(csi_context* ctx, int32_t* kind);
+/* Run-time tiers of the peer transport's memory-ordering protocol.  Every rank of a decomposition must set the SAME tier (the
+ * host decides for all ranks: bench.py walks the ladder 0 -> 1 -> 2 -> RCCL and keeps the first tier whose tiled run reproduces
+ * the one-GPU run bit for bit).
+ *   0 (default): halo images are write-through stores at system scope, flags follow the drained store queue; a waiting tile
+ *      loads nothing before it has seen the flags and issues no cache maintenance (measured fastest);
+ *   1: + a system-scope acquire fence (buffer_inv sc0 sc1) in every waiting tile once the flags have been seen;
+ *   2: + a system-scope release fence (buffer_wbl2 sc0 sc1) before a tile publishes its flags -- the textbook protocol.
+ * A wait that gives up after 3 s makes its workgroup leave without storing or publishing, sets this rank's error word and the
+ * abort word of every neighbour's flag array; every entry point that advances the model and csi_sync report CSI_ERR_COMM. */
+int32_t csi_set_peer_tier(csi_context* ctx, int32_t tier);
+int32_t csi_peer_tier(csi_context* ctx, int32_t* tier);
 
 /* Index ranges (1-based, inclusive: i0, i1, j0, j1) the launch loop uses for a grid of this shape and
  * topology when `valid_width` (V >= 2) layers of u, v beyond the owned cells are valid on connected sides:

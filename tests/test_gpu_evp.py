@@ -549,6 +549,30 @@ def test_peer_halo_transport_self_connected_bitwise(name, nsub):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
+@pytest.mark.parametrize("tier", [1, 2])
+@pytest.mark.parametrize("name", ["periodic_xy", "channel_land", "coupled_arrays"])
+def test_peer_protocol_tiers_bitwise(name, tier):
+    """csi_set_peer_tier: the run-time ladder of the peer transport's memory ordering (1: + a system-scope acquire fence once the
+    flags have been seen; 2: + a system-scope release fence before the flags are published).  Every tier gives the untiled run's
+    answer bit for bit -- the tiers differ in what they assume of the memory system between two devices, not in the result."""
+    kw, fc = PEER_CASES[name]
+    c = cases.make_case(substeps=13, patches=True, random_uv=0.05, **kw)
+    ref = cases.csi_model(c, mode="fast")
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, fc))
+    assert til.ctx.peer_tier() == 0
+    til.set_peer_tier(tier)
+    for _ in range(2):
+        csi.time_step_momentum(ref, c["dt"])
+        csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    assert til.ctx.halo_transport() == "peer" and til.ctx.peer_tier() == tier
+    for f in ("u", "v", "s11", "s22", "s12"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, tier, np.abs(a - b).max())
+    with pytest.raises(csi.CsiError):
+        til.set_peer_tier(3)
+
+
 def test_peer_halo_transport_falls_back_and_can_be_switched_off():
     """Explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the peer transport off; odd
     sub-step counts stay on it; all bit-identical."""
