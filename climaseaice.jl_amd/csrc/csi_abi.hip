@@ -9,6 +9,7 @@
 #include "../../include/csi.h"
 #include "csi_dev.h"
 #include "csi_kernels.h"
+#include "csi_hostgroup.h"
 #include "csi_comm.h"
 
 #include <rccl/rccl.h>
@@ -105,6 +106,7 @@ struct csi_context {
     TileInfo tile;
     ncclComm_t comm = nullptr;
     csi_local_group* local = nullptr;      // in-process tile group instead of an RCCL communicator (csi_comm_init_local)
+    HostGroup* hostg = nullptr;            // host-channel group of PROCESSES (shared memory + HIP IPC, csi_comm_init_host): RCCL-free runs of several ranks on one GPU
     int world = 1, rank = 0;
     double *sendbuf = nullptr, *recvbuf = nullptr;
     size_t buf_cap = 0;   // elements per buffer
@@ -417,7 +419,7 @@ int32_t exchange(csi_context* c, const int* fids, int nf, int W) {
     return exchange_refs(c, fr, nf, W);
 }
 
-bool has_comm(const csi_context* c) { return c->comm != nullptr || c->local != nullptr; }
+bool has_comm(const csi_context* c) { return c->comm != nullptr || c->local != nullptr || c->hostg != nullptr; }
 
 constexpr int kLocalTimeoutSeconds = 120;
 // all ranks of the group: rank r's `nb` bytes end up in out[r * nb ...] everywhere
@@ -510,6 +512,7 @@ int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
     const size_t need_elems = (size_t)(sp.total > c->pending_rp.total ? sp.total : c->pending_rp.total);
     int32_t lrc;
     if (c->local && (lrc = local_wait_consumed(c))) return lrc;      // (before the send buffer is repacked -- or freed)
+    if (c->hostg && !hostgroup_wait_consumed(c->hostg, &c->err)) return CSI_ERR_COMM;
     if (need_elems > c->buf_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->sendbuf) hipFree(c->sendbuf);
@@ -519,10 +522,17 @@ int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W) {
         HIP_TRY(c, hipMalloc((void**)&c->sendbuf, cap * sizeof(double)));
         HIP_TRY(c, hipMalloc((void**)&c->recvbuf, cap * sizeof(double)));
         c->buf_cap = cap;
+        if (c->hostg && !hostgroup_set_sendbuf(c->hostg, c->sendbuf, cap * sizeof(double), &c->err)) return CSI_ERR_COMM;
     }
     launch_pack(sp, c->sendbuf, 0, c->stream);
     if (c->local) {
         if ((lrc = local_sendrecv(c, soff, scnt, speer, roff, rcnt, rpeer))) return lrc;
+        launch_pack(c->pending_rp, c->recvbuf, 1, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        return CSI_OK;
+    }
+    if (c->hostg) {
+        if (!hostgroup_sendrecv(c->hostg, c->stream, c->recvbuf, soff, scnt, speer, roff, rcnt, rpeer, &c->err)) return CSI_ERR_COMM;
         launch_pack(c->pending_rp, c->recvbuf, 1, c->stream);
         HIP_TRY(c, hipGetLastError());
         return CSI_OK;
@@ -880,6 +890,10 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         int32_t lrc;
         if ((lrc = local_allgather(c, mine.data(), sizeof(PeerRec) * kPeerRecs, bytes))) return lrc;
         memcpy(all.data(), bytes.data(), bytes.size());
+    } else if (c->hostg) {
+        std::vector<uint8_t> bytes;
+        if (!hostgroup_allgather(c->hostg, mine.data(), sizeof(PeerRec) * kPeerRecs, bytes, &c->err)) return CSI_ERR_COMM;
+        memcpy(all.data(), bytes.data(), bytes.size());
     } else if (c->world > 1) {
         const size_t nb = sizeof(PeerRec) * kPeerRecs;
         HIP_TRY(c, hipMemcpy(pr.xbuf, mine.data(), nb, hipMemcpyHostToDevice));
@@ -934,6 +948,10 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
     if (c->local) {
         int32_t lrc;
         if ((lrc = local_allreduce_min(c, &ok))) return lrc;
+    } else if (c->hostg) {
+        std::vector<uint8_t> bytes;
+        if (!hostgroup_allgather(c->hostg, &ok, sizeof(int), bytes, &c->err)) return CSI_ERR_COMM;
+        for (int r = 0; r < c->world; ++r) { int x; memcpy(&x, bytes.data() + (size_t)r * sizeof(int), sizeof(int)); if (x < ok) ok = x; }
     } else if (c->world > 1) {                               // every rank or none
         int* flag = (int*)pr.xbuf;
         HIP_TRY(c, hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice));
@@ -1866,6 +1884,7 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->sendbuf) hipFree(c->sendbuf);
     if (c->recvbuf) hipFree(c->recvbuf);
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->hostg) hostgroup_leave(c->hostg);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -2322,7 +2341,9 @@ int32_t csi_comm_init(csi_context* c, int32_t world_size, int32_t rank, const ui
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank / world_size out of range");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->hostg) { hostgroup_leave(c->hostg); c->hostg = nullptr; }
     c->local = nullptr;
+    peer_release(c); c->peer.failed = false;           // (mappings of the previous communicator's neighbours)
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     NCCL_TRY(c, ncclCommInitRank(&c->comm, world_size, id, rank));
@@ -2347,6 +2368,8 @@ int32_t csi_comm_init_local(csi_context* c, csi_local_group* G, int32_t rank) {
     if (!c || !G) return CSI_ERR_INVALID_ARGUMENT;
     if (rank < 0 || rank >= G->world) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank out of range for this group");
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->hostg) { hostgroup_leave(c->hostg); c->hostg = nullptr; }
+    peer_release(c); c->peer.failed = false;
     c->local = G;
     c->world = G->world; c->rank = rank;
     std::unique_lock<std::mutex> lk(G->mu);
@@ -2354,10 +2377,26 @@ int32_t csi_comm_init_local(csi_context* c, csi_local_group* G, int32_t rank) {
     return CSI_OK;
 }
 
+int32_t csi_comm_init_host(csi_context* c, const char* shm_name, int32_t world_size, int32_t rank) {
+    if (!c || !shm_name) return CSI_ERR_INVALID_ARGUMENT;
+    if (world_size < 2 || rank < 0 || rank >= world_size) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank / world_size out of range (a host-channel group has at least two ranks)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->hostg) { hostgroup_leave(c->hostg); c->hostg = nullptr; }
+    c->local = nullptr;
+    peer_release(c); c->peer.failed = false;
+    std::string e;
+    c->hostg = hostgroup_join(shm_name, world_size, rank, &e);
+    if (!c->hostg) return fail(c, CSI_ERR_COMM, e);
+    c->world = world_size; c->rank = rank;
+    if (c->sendbuf && !hostgroup_set_sendbuf(c->hostg, c->sendbuf, c->buf_cap * sizeof(double), &c->err)) return CSI_ERR_COMM;
+    return CSI_OK;
+}
 int32_t csi_comm_count(csi_context* c, int32_t* ranks) {
     if (!c || !ranks) return CSI_ERR_INVALID_ARGUMENT;
     *ranks = 0;
     if (c->local) { *ranks = c->local->world; return CSI_OK; }
+    if (c->hostg) { *ranks = hostgroup_world(c->hostg); return CSI_OK; }
     if (!c->comm) return CSI_OK;
     int n = 0;
     NCCL_TRY(c, ncclCommCount(c->comm, &n));

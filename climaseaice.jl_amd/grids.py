@@ -284,9 +284,10 @@ class TileGrid(_Grid2D):
 
     Metrics are SLICES of the global grid's metric vectors, so a tiled run uses bit-identical metric values."""
 
-    def __init__(self, global_grid, Rx, Ry, rx, ry, force_connected=False, local_group=None):
+    def __init__(self, global_grid, Rx, Ry, rx, ry, force_connected=False, local_group=None, host_group=None):
         G = global_grid
         self.local_group = local_group      # _lib.LocalGroup: the tiles of this process talk through it instead of RCCL
+        self.host_group = host_group        # name of a POSIX shared-memory segment: the ranks are processes that talk over the host (csi_comm_init_host)
         if G.Nx % Rx or G.Ny % Ry:
             raise ValueError("grid size must be divisible by the partition")
         self.global_grid, self.Rx, self.Ry, self.rx, self.ry = G, Rx, Ry, rx, ry

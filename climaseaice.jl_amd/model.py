@@ -322,6 +322,9 @@ class SeaIceModel:
             self._keep.append(g.local_group)
             self.ctx.call("csi_comm_init_local", g.local_group.h, g.rank)
             return
+        if getattr(g, "host_group", None) is not None:       # one process per tile, no RCCL: shared memory + HIP IPC
+            self.ctx.call("csi_comm_init_host", str(g.host_group).encode(), world, g.rank)
+            return
         idbuf = (C.c_uint8 * 128)()
         if world > 1:
             import torch.distributed as dist

@@ -352,6 +352,14 @@ typedef struct csi_local_group csi_local_group;
 int32_t csi_local_group_create(int32_t world_size, csi_local_group** out);
 void csi_local_group_destroy(csi_local_group* group);
 int32_t csi_comm_init_local(csi_context* ctx, csi_local_group* group, int32_t rank);
+/* Host-channel tile group: the ranks are PROCESSES (one context each, any devices -- in particular several on ONE GPU, where RCCL
+ * refuses to form a communicator) that share the POSIX shared-memory segment `shm_name` (e.g. "/csi-<job>"; every rank passes
+ * the same name; the name is unlinked once all have joined).  The halo exchanges and the two small collectives of the peer
+ * set-up travel over the host and HIP IPC copies; the peer halo transport maps the neighbours' arrays and flag words with
+ * hipIpcOpenMemHandle exactly as one process per GPU does under RCCL.  Host-synchronous: for correctness runs, not for speed.
+ * Stands where the reference's distributed tests start `mpiexec -n 4` on whatever devices there are
+ * (test/test_distributed_sea_ice.jl:41-54). */
+int32_t csi_comm_init_host(csi_context* ctx, const char* shm_name, int32_t world_size, int32_t rank);
 /* Exchange `width` halo layers of the fields in `field_ids` with the neighbouring tiles. */
 int32_t csi_halo_exchange(csi_context* ctx, const int32_t* field_ids, int32_t nfields, int32_t width);
 

@@ -289,6 +289,23 @@ function set_halo_transport!(ctx, kind::Symbol)
     check(ctx, ccall((:csi_set_halo_transport, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, kind === :peer ? 1 : 0))
 end
 
+# The memory-ordering tier of the peer transport's flag protocol (0 default; 1: + an acquire fence behind the flags; 2: + a release
+# fence before them), the SAME on every rank.  include/csi.h: csi_set_peer_tier.
+set_peer_tier!(ctx, tier::Integer) = check(ctx, ccall((:csi_set_peer_tier, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, tier))
+
+# Waits for the library's stream and reports a peer-transport wait that gave up (a rank that fell behind or died: the library
+# never hangs, it fails).  Every entry point that advances the model reports such an error too, at its start and at its end, so an
+# explicit call is needed only where the host must KNOW that a step is complete and valid (before output, before a checkpoint).
+synchronize!(ctx) = check(ctx, ccall((:csi_sync, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
+
+# One PROCESS per tile without RCCL (several ranks on one GPU: RCCL refuses that): a host-channel group over a POSIX shared-memory
+# segment every rank names alike; the peer transport maps the neighbours' arrays over HIP IPC as under RCCL.  include/csi.h.
+function attach_tiles_host!(ctx, shm_name::AbstractString, rank::Integer, rx, ry, Rx, Ry, px::Bool, py::Bool)
+    check(ctx, ccall((:csi_tile_set, libcsi), Int32, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Int32, Int32),
+                     ctx.handle, rx, ry, Rx, Ry, px ? 1 : 0, py ? 1 : 0))
+    check(ctx, ccall((:csi_comm_init_host, libcsi), Int32, (Ptr{Cvoid}, Cstring, Int32, Int32), ctx.handle, shm_name, Rx * Ry, rank))
+end
+
 # Several tiles driven by ONE process (one task per tile; RCCL refuses two ranks on one device): an in-process tile group instead of
 # the RCCL communicator.  `group = local_tile_group(Rx * Ry)` once, then `attach_tiles_local!(ctx, group, rank, ...)` per tile.
 function local_tile_group(world::Integer)
@@ -366,6 +383,9 @@ ClimaSeaIce.dynamic_time_step!(model::HIPRKSeaIceModel, Δt) = hip_dynamic_time_
 function Oceananigans.TimeSteppers.update_state!(model::HIPSeaIceModel, callbacks = [])
     ctx = context(model)
     GC.@preserve model check(ctx, ccall((:csi_update_state, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
+    # a Distributed grid: the end of a stage is where the host learns that the stage is valid on EVERY rank (a peer-transport wait
+    # that gave up anywhere fails here, not a call later)
+    model.grid.architecture isa Distributed && synchronize!(ctx)
     Oceananigans.Models.update_model_field_time_series!(model, model.clock)
     return nothing
 end

@@ -219,13 +219,14 @@ def oracle_problem(case, omp=False):
     return p
 
 
-def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0", tile=None, local_group=None, **model_kw):
+def csi_model(case, mode="fast", timestepper="ForwardEuler", advection=None, device="cuda:0", tile=None, local_group=None, host_group=None, **model_kw):
     """tile = (Rx, Ry, rank[, force_connected]): build the model of one tile of the global case (local_group: the tiles of this
     process exchange through a csi.LocalGroup instead of RCCL)."""
     g = case["g"]
     if tile is not None:
         Rx, Ry, rank = tile[:3]
-        g = csi.TileGrid(g, Rx, Ry, rank % Rx, rank // Rx, force_connected=tile[3] if len(tile) > 3 else False, local_group=local_group)
+        g = csi.TileGrid(g, Rx, Ry, rank % Rx, rank // Rx, force_connected=tile[3] if len(tile) > 3 else False, local_group=local_group,
+                         host_group=host_group)
         case = dict(case)
         for key, loc in (("h", (csi.Center, csi.Center)), ("a", (csi.Center, csi.Center)), ("u", (csi.Face, csi.Center)),
                          ("v", (csi.Center, csi.Face))):

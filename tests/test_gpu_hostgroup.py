@@ -1,0 +1,97 @@
+"""The peer halo transport across a real PROCESS boundary, on the one GPU a development box has: two (or four) processes, one tile
+each, joined by a host-channel group (csi_comm_init_host: shared memory + HIP IPC; RCCL refuses two ranks on one device).  What
+runs here is the multi-process path of csrc/csi_abi.hip peer_setup that one process per GPU takes on a real node -- IPC handles of
+caller-owned (torch) and library-owned arrays and of the fine-grained flag words, exchanged and opened with hipIpcOpenMemHandle,
+halo images and flags written into ANOTHER process's memory by the pair kernel -- none of which the in-process tile group
+(tests/test_gpu_local_tiles.py: one address space, plain pointers) or a tile connected to itself can exercise.
+The reference's distributed tests start ranks and compare them with the serial run the same way
+(/root/reference/test/distributed_tests_utils.jl:40-88; test/test_distributed_sea_ice.jl:41-54).
+Still NOT covered: two DEVICES (peer access over xGMI) -- tests/test_gpu_multirank.py, skipped on one-GPU boxes."""
+import multiprocessing as mp
+import os
+import uuid
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("u", "v", "s11", "s22", "s12")
+
+
+def _get(m, f):
+    import climaseaice_jl_amd as csi  # noqa: F401
+    return (getattr(m.velocities, f) if f in ("u", "v") else getattr(m.dynamics.auxiliaries.fields, f)).interior_numpy().copy()
+
+
+def _rank(conn, name, kw, Rx, Ry, rank, transport, cycles, tier):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        import cases
+        import climaseaice_jl_amd as csi
+        c = cases.make_case(**kw)
+        m = cases.csi_model(c, mode="fast", tile=(Rx, Ry, rank), host_group=name)
+        m.set_halo_transport(transport)
+        if tier:
+            m.set_peer_tier(tier)
+        for _ in range(cycles):
+            csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        out = {f: _get(m, f) for f in FIELDS}
+        out["transport"] = m.ctx.halo_transport()
+        out["path"] = m.ctx.last_path()
+        out["ranks"] = m.ctx.comm_count()
+        g = m.grid
+        out["offsets"] = (g.i_off, g.j_off, g.Nx, g.Ny)
+        conn.send(out)
+    except Exception as e:      # noqa: BLE001  (reported to the parent, which fails the test)
+        conn.send({"error": repr(e)})
+
+
+HOST_CASES = {
+    "2x1_periodic": (dict(Nx=280, Ny=96, topo=("periodic", "periodic")), 2, 1),
+    "1x2_periodic": (dict(Nx=160, Ny=144, topo=("periodic", "periodic")), 1, 2),
+    "2x1_channel_land_arrays": (dict(Nx=300, Ny=100, topo=("periodic", "bounded"), land=0.2, field_forcing=True), 2, 1),
+    "1x2_bounded_noslip": (dict(Nx=150, Ny=128, topo=("bounded", "bounded"), noslip=True), 1, 2),
+    "2x2_periodic": (dict(Nx=272, Ny=128, topo=("periodic", "periodic")), 2, 2),
+}
+
+
+@pytest.mark.parametrize("transport,nsub,tier", [("peer", 12, 0), ("peer", 7, 0), ("peer", 12, 1), ("rccl", 12, 0)])
+@pytest.mark.parametrize("name", sorted(HOST_CASES))
+def test_processes_on_one_gpu_tiled_equals_untiled_bitwise(name, transport, nsub, tier):
+    import cases
+    import climaseaice_jl_amd as csi
+    kw, Rx, Ry = HOST_CASES[name]
+    kw = dict(kw, substeps=nsub, patches=True, random_uv=0.05, H=8 if transport == "rccl" else 4)
+    cycles = 2
+    c = cases.make_case(**kw)
+    ref = cases.csi_model(c, mode="fast")
+    for _ in range(cycles):
+        csi.time_step_momentum(ref, c["dt"])
+    ref.synchronize()
+    want = {f: _get(ref, f) for f in FIELDS}
+    world = Rx * Ry
+    shm = f"/csi-test-{uuid.uuid4().hex[:12]}"
+    ctx = mp.get_context("spawn")
+    procs, pipes = [], []
+    for r in range(world):
+        a, b = ctx.Pipe()
+        p = ctx.Process(target=_rank, args=(b, shm, kw, Rx, Ry, r, transport, cycles, tier))
+        p.start()
+        procs.append(p); pipes.append(a)
+    got = []
+    for r in range(world):
+        assert pipes[r].poll(300), f"rank {r} did not answer"
+        got.append(pipes[r].recv())
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert "error" not in got[r], (r, got[r].get("error"))
+        assert got[r]["ranks"] == world
+        # "peer": every rank mapped its neighbours' arrays over HIP IPC and ran the flag protocol; one host exchange per sub-cycle
+        assert got[r]["transport"] == transport, (r, got[r]["transport"], got[r]["path"])
+        i0, j0, nx, ny = got[r]["offsets"]
+        for f in FIELDS:
+            mine, w = got[r][f][:ny, :nx], want[f][j0:j0 + ny, i0:i0 + nx]
+            assert np.array_equal(mine, w), (name, "rank", r, f, np.abs(mine - w).max(), np.argwhere(mine != w)[:4].tolist())
