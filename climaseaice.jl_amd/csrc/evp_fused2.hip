@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
                 const unsigned om2 = off2(jm), o02 = off2(rstart);
                 full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m);
                 A.e12_0 = full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0);
-                A.full_init(T, o02);
+                A.full_init(T, o02, om2, c2s);
             } else {
             fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                             coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
@@ -588,8 +588,11 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             if (PW & 1) { o11 = outr[so]; o22 = outr[so + 64]; o12 = outr[so + 128]; }
             if (PW & 2) ofirst = outr[so + 192];
             if (PW & 4) osecond = outr[so + 256];
-            advance();
-            load_row(R[(k + CSI_PAIR_PD) % 3]);           // row r + CSI_PAIR_PD (clamped to rend)
+            // (FULL: the next row's loads are issued between the phases of the step below, with the plane prefetch)
+            if constexpr (!FULL) {
+                advance();
+                load_row(R[(k + CSI_PAIR_PD) % 3]);           // row r + CSI_PAIR_PD (clamped to rend)
+            }
             flush(r - 4, o11, o22, o12, ofirst, osecond, Idx<PW>{}, Idx<AUF ? 1 : 0>{});
             fm::StressConst ks; stress_consts(ks);
             fm::VelConst kv; vel_consts(kv);
@@ -604,8 +607,13 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
             Forcing FA;
             numbers(FA);
             if (FORCE) arrays(FA, offf(r - 1), AUF ? offc(r - 1) : offc(r));      // u points of row r-1, v points of row r-1 / r
-            A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA,
-                   FULL ? off2(r) : 0u, c2s);
+            if constexpr (FULL) {
+                static_assert(CSI_PAIR_PD == 1, "the per-point-metric producer prefetches one row ahead");
+                auto mid = [&]() __attribute__((always_inline)) { advance(); load_row(R[(k + 1) % 3]); };
+                A.template step<false>(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA,
+                                       off2(r), c2s, off2(min(r + 1, rend)), off2(max(r - 1, row0)), mid);
+            } else
+            A.step(T, ks, kv, r, C.u_p, C.v_p, C.P_0, m_0, C.a_0, C.s11, C.s22, C.s12, C.un_m, C.vn_x, true, r > rstart, pa1, pa2, mhist, FA);
             // ---- hand-off to the consumer: sigma(r); u(r-1); v(r-1) [u first] or v(r) [v first] --------------------------
             {
                 const unsigned s0 = rslot(r), s1 = rslot(r - 1);
@@ -722,7 +730,17 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0; B.Pf_0 = 0; B.rmc_0 = 0; B.rmf_0 = 0;
-    if constexpr (FULL) B.full_init(T, off2(max(rstart - 2, row0)));
+    if constexpr (FULL) {
+        B.full_init(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)), c2s);
+        B.full_prefetch_vel(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)));
+    }
+    // FULL: stage B's results of row q are stored at the START of the next iteration (fq, f11 .. fsecond): the wave's vector-memory
+    // queue then holds, when the prefetched plane values are waited for at the top of an iteration, stores that are a whole
+    // iteration old and loads that are half an iteration old -- nothing younger (the counter is in order: a younger store would
+    // have to be waited for too)
+    int fq = 0;
+    bool fhave = false;
+    double f11 = 0, f22 = 0, f12 = 0, ffirst = 0, fsecond = 0;
     // Stage B's row inputs all come from the ring (the producer read them from memory two or three iterations earlier):
     // the consumer issues no global loads (FORCE: except its forcing arrays), so it never waits for its own stores.
     const int rlo = rstart - 1;
@@ -746,6 +764,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
         vn_delay = vn_new;
         const unsigned bmk = MASK ? ringm[(unsigned)((r - 2 - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] : 0u;
+        if constexpr (FULL) {
+            if (fhave) flush(fq, f11, f22, f12, ffirst, fsecond, Idx<(CSI_PAIR_STORES & 7)>{}, Idx<AUF ? 1 : 0>{});
+        }
         PROBE(pacc1);
         fm::StressConst ks; stress_consts(ks);
         fm::VelConst kv; vel_consts(kv);
@@ -775,9 +796,15 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
-        B.template step<PRE>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
-               FULL ? off2(max(q, row0)) : 0u, c2s);      // (rows below the planes only fill the window: clamped)
+        if constexpr (FULL) {
+            // (rows below the planes only fill the window: clamped)
+            B.template step<PRE, typename decltype(B)::NoMid, true>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
+                   off2(max(q, row0)), c2s, off2(max(q + 1, row0)), off2(max(q - 1, row0)), typename decltype(B)::NoMid(), off2(max(q, row0)));
+            fq = q; f11 = B.S11_0; f22 = B.S22_0; f12 = B.S12_0; ffirst = B.first; fsecond = B.second; fhave = true;
+        } else {
+        B.template step<PRE>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB);
         flush(q, B.S11_0, B.S22_0, B.S12_0, B.first, B.second, Idx<(CSI_PAIR_STORES & 7)>{}, Idx<AUF ? 1 : 0>{});
+        }
         if ((CSI_PAIR_STORES & 7) != 7) {
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
             if (!(CSI_PAIR_STORES & 1)) { outr[so] = B.S11_0; outr[so + 64] = B.S22_0; outr[so + 128] = B.S12_0; }
@@ -806,6 +833,9 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         if (++r > rend) break;
         bodyB(Idx<2>{});
         if (++r > rend) break;
+    }
+    if constexpr (FULL) {
+        if (fhave) flush(fq, f11, f22, f12, ffirst, fsecond, Idx<(CSI_PAIR_STORES & 7)>{}, Idx<AUF ? 1 : 0>{});
     }
     __syncthreads();                                      // the last row's results are in the out ring: the producer drains them
     publish();

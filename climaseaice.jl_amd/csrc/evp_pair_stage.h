@@ -74,9 +74,32 @@ struct Stage {
     double DXV_0, RDXV_0, RDYV_0, RDXU_0, DXF2_0, DYF2_0, RAZF_0;
     double DXV_m, RDXV_m, RDYV_m, RDXU_m, DXF2_m, DYF2_m, DYU_m, RDYU_m, DYC2_m, DXC2_m, DXC2_mm;
     double DXV_p, RDXV_p, RDYV_p, RDXU_p, DXF2_p, DYF2_p, RAZF_p, DYU_0, RDYU_0, DYC2_0, DXC2_0;      // pending (shift)
+    double RAZC_0, RAZU_m, RAZV_x, FU_m, FV_x;       // this step's 1 / Az at the cell (row r), the u point (row r - 1), the v point (row r - 1 / r); f likewise
 
-    // FULL: before the first step(r): o = plane offset of row r, u_0 / v_0 = u, v of row r
-    __device__ __forceinline__ void full_init(tptr_t T, unsigned o) {
+    // FULL, round 4: the plane values a step needs are loaded DURING THE PREVIOUS step, between its stress phase and its velocity
+    // phase (N_*: a phase of arithmetic and the row barrier lie between a load and its use; loaded at use -- round 3 -- every
+    // iteration of both waves exposed a full memory latency at the top of its strain phase and, through the in-order vmcnt, gave
+    // up the state rows' prefetch: 54 % of all wave-cycles waiting, profiles/r03_full_metric_kernel.md).  Same values, same
+    // operations.  N_DXV .. N_RAZF: row r + 1 of the NEXT step; N_DYU .. N_RAZC: its row r.  (1 / Az at the velocity points and the
+    // per-point Coriolis planes are issued at the top of the step that uses them, a phase ahead too; prefetched with the rest
+    // they cost 28 more registers across the velocity phase: scratch spills, measured.)
+    double N_DXV, N_RDYV, N_RDXU, N_DXF2, N_DYF2, N_RAZF, N_DYU, N_DYC2, N_DXC2, N_RAZC;
+    double N_RAZU, N_RAZV, N_FU, N_FV;       // ALLPRE steps only (the consumer wave: no vector-memory instruction at the top of its iteration)
+    // on: plane offset of the next step's row
+    // the velocity phase's plane values of the next step too (om: plane offset of the row below the next step's row, clamped)
+    __device__ __forceinline__ void full_prefetch_vel(tptr_t T, unsigned on, unsigned om) {
+        N_RAZU = c2at(T, C2_RAZU, om); N_RAZV = c2at(T, C2_RAZV, UFIRST ? om : on);
+        N_FU = 0.0; N_FV = 0.0;
+        if (T->I[FI_FKIND] == 2) { N_FU = ldg(T->P[FP_F2U], om); N_FV = ldg(T->P[FP_F2V], UFIRST ? om : on); }
+    }
+    __device__ __forceinline__ void full_prefetch(tptr_t T, unsigned on, unsigned s2) {
+        N_DXV = c2at(T, C2_DXV, on + s2); N_RDYV = c2at(T, C2_RDYV, on + s2); N_RDXU = c2at(T, C2_RDXU, on + s2);
+        N_DXF2 = c2at(T, C2_DXF2, on + s2); N_DYF2 = c2at(T, C2_DYF2, on + s2); N_RAZF = c2at(T, C2_RAZF, on + s2);
+        N_DYU = c2at(T, C2_DYU, on); N_DYC2 = c2at(T, C2_DYC2, on); N_DXC2 = c2at(T, C2_DXC2, on); N_RAZC = c2at(T, C2_RAZC, on);
+    }
+    // FULL: before the first step(r): o = plane offset of row r, u_0 / v_0 = u, v of row r; om: of row r - 1 (clamped)
+    __device__ __forceinline__ void full_init(tptr_t T, unsigned o, unsigned om, unsigned s2) {
+        full_prefetch(T, o, s2);
         DXV_0 = c2at(T, C2_DXV, o); RDXV_0 = fm::rcp(DXV_0); RDYV_0 = c2at(T, C2_RDYV, o); RDXU_0 = c2at(T, C2_RDXU, o);
         DXF2_0 = c2at(T, C2_DXF2, o); DYF2_0 = c2at(T, C2_DYF2, o); RAZF_0 = c2at(T, C2_RAZF, o);
         // rows r - 1, r - 2: multiplied by zero stresses until their real values have been shifted in (any finite number)
@@ -96,24 +119,38 @@ struct Stage {
     // x-averages); their stresses / velocities would never be used
     // PRE: Pf_0, rmc_0, rmf_0 were set by the caller (from the producer's results for the same row) instead of being
     // formed here: they depend on P and the ice mass only, which a sub-cycle does not change
-    template <bool PRE = false>
+    struct NoMid { __device__ __forceinline__ void operator()() const {} };
+    // mid: called between the stress phase and the velocity phase (FULL: the producer issues the NEXT row's state loads there,
+    // next to the plane prefetch, instead of at the top of the iteration -- they are then live across the velocity phase only,
+    // not across the stress phase, where the register pressure peaks)
+    // ALLPRE (FULL): 1 / Az at the velocity points and the per-point Coriolis planes were prefetched by the previous step as well
+    // (full_prefetch_vel; o2nm: the row below the next step's row) -- the consumer wave, which has the registers for it
+    template <bool PRE = false, class MID = NoMid, bool ALLPRE = false>
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks_in, const fm::VelConst& kv_in, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
                                          bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
-                                         const Forcing& F, unsigned o2 = 0u, unsigned s2 = 0u) {
+                                         const Forcing& F, unsigned o2 = 0u, unsigned s2 = 0u, unsigned o2n = 0u, unsigned o2m = 0u, MID mid = MID(), unsigned o2nm = 0u) {
         Xa_0 = fm::sum2(from_left(a_0), a_0);               // SUMS too (Xa, Xm, XAL): fm::vel_update_sum
         Xv_p = fm::sum2(from_left(v_p), v_p);               // x-SUMS (Xv, Xe11, Xe22, Ye12, XP, XW): scaled once, in quarter()
         double e11_0, e22_0;
         if constexpr (FULL) {
             // strain_cell2 / strain_corner2 of evp_fast.hip: cell (i, r), corner (i, r + 1)
             // (full_cell / full_corner above with the plane values of rows already in the window taken from registers)
-            DXV_p = c2at(T, C2_DXV, o2 + s2); RDXV_p = fm::rcp(DXV_p); RDYV_p = c2at(T, C2_RDYV, o2 + s2); RDXU_p = c2at(T, C2_RDXU, o2 + s2);
-            DXF2_p = c2at(T, C2_DXF2, o2 + s2); DYF2_p = c2at(T, C2_DYF2, o2 + s2); RAZF_p = c2at(T, C2_RAZF, o2 + s2);
-            DYU_0 = c2at(T, C2_DYU, o2); RDYU_0 = fm::rcp(DYU_0); DYC2_0 = c2at(T, C2_DYC2, o2); DXC2_0 = c2at(T, C2_DXC2, o2);
+            DXV_p = N_DXV; RDXV_p = fm::rcp(DXV_p); RDYV_p = N_RDYV; RDXU_p = N_RDXU;
+            DXF2_p = N_DXF2; DYF2_p = N_DYF2; RAZF_p = N_RAZF;
+            DYU_0 = N_DYU; RDYU_0 = fm::rcp(DYU_0); DYC2_0 = N_DYC2; DXC2_0 = N_DXC2;
+            RAZC_0 = N_RAZC;
+            // what the velocity phase reads at rows r - 1 / r: issued here, a phase ahead of their use (o2m: row r - 1, clamped)
+            if constexpr (ALLPRE) {
+                RAZU_m = N_RAZU; RAZV_x = N_RAZV; FU_m = N_FU; FV_x = N_FV;
+            } else if (do_vel) {
+                RAZU_m = c2at(T, C2_RAZU, o2m); RAZV_x = c2at(T, C2_RAZV, UFIRST ? o2m : o2);
+                if (T->I[FI_FKIND] == 2) { FU_m = ldg(T->P[FP_F2U], o2m); FV_x = ldg(T->P[FP_F2V], UFIRST ? o2m : o2); }
+            }
             const double Uy_w = DYU_0 * u_0, Ur_w = RDYU_0 * u_0;
             fm::full_strain_cell(from_right(Uy_w), Uy_w, DXV_p * v_p, DXV_0 * v_0, from_right(Ur_w), Ur_w, RDXV_p * v_p, RDXV_0 * v_0,
-                                 DYC2_0, DXC2_0, c2at(T, C2_RAZC, o2), e11_0, e22_0);
+                                 DYC2_0, DXC2_0, RAZC_0, e11_0, e22_0);
             const double Vy_e = RDYV_p * v_p;
             e12_p = fm::full_strain_corner(RDXU_p * u_p, RDXU_0 * u_0, Vy_e, from_left(Vy_e), DXF2_p, DYF2_p, RAZF_p);
         } else {
@@ -147,7 +184,7 @@ struct Stage {
                     ks.amax2 = T->K[FK_AMAX2]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
                 }
                 double kc, kf;
-                if constexpr (FULL) { kc = T->K[FK_CA_DT] * c2at(T, C2_RAZC, o2); kf = T->K[FK_CA_DT] * RAZF_0; }
+                if constexpr (FULL) { kc = T->K[FK_CA_DT] * RAZC_0; kf = T->K[FK_CA_DT] * RAZF_0; }
                 else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r); }
                 const fm::StressOut o = fm::stress_update_r(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, rmc_0, rmf_0, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
@@ -182,24 +219,32 @@ struct Stage {
             const double S_e = d11_m + d22_m, T_e = DYC2_m * (d11_m - d22_m);
             const double S_w = MASK ? from_left(S_e) : d11_mL + d22_mL;
             const double T_w = MASK ? from_left(T_e) : from_left(DYC2_m) * (d11_mL - d22_mL);
-            return fm::full_div1(DYU_m, RDYU_m, RDXU_m, c2at(T, C2_RAZU, o2 - s2), S_e, S_w, T_e, T_w, DXF2_0 * d12_0, DXF2_m * d12_m);
+            return fm::full_div1(DYU_m, RDYU_m, RDXU_m, RAZU_m, S_e, S_w, T_e, T_w, DXF2_0 * d12_0, DXF2_m * d12_m);
         };
         auto div2_full = [&](bool low) __attribute__((always_inline)) {
             if (low) {
                 const double Zw = DYF2_m * d12_m;
-                return fm::full_div2(DXV_m, RDXV_m, RDYV_m, c2at(T, C2_RAZV, o2 - s2), d11_m + d22_m, d11_mm + d22_mm,
+                return fm::full_div2(DXV_m, RDXV_m, RDYV_m, RAZV_x, d11_m + d22_m, d11_mm + d22_mm,
                                      DXC2_m * (d11_m - d22_m), DXC2_mm * (d11_mm - d22_mm), from_right(Zw), Zw);
             }
             const double Zw = DYF2_0 * d12_0;
-            return fm::full_div2(DXV_0, RDXV_0, RDYV_0, c2at(T, C2_RAZV, o2), d11_0 + d22_0, d11_m + d22_m,
+            return fm::full_div2(DXV_0, RDXV_0, RDYV_0, RAZV_x, d11_0 + d22_0, d11_m + d22_m,
                                  DXC2_0 * (d11_0 - d22_0), DXC2_m * (d11_m - d22_m), from_right(Zw), Zw);
         };
         auto f_full = [&](int which_row, int which_plane, unsigned o, int j) __attribute__((always_inline)) {
             const int kind = T->I[FI_FKIND];
-            if (kind == 2) return ldg(T->P[which_plane], o);
+            if (kind == 2) return which_plane == FP_F2U ? FU_m : FV_x;        // (prefetched by the previous step: full_prefetch)
             if (kind == 1) { typedef const __attribute__((address_space(4))) double* vptr_t; return ((vptr_t)T->P[which_row])[j]; }
             return T->K[FK_FCOR];
         };
+        if constexpr (FULL) {
+            // the next step's plane values: issued here, behind the stress phase, consumed after the velocity phase and the row barrier
+            __builtin_amdgcn_sched_barrier(0);
+            full_prefetch(T, o2n, s2);
+            if constexpr (ALLPRE) full_prefetch_vel(T, o2n, o2nm);
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         fm::VelConst kv = kv_in;
         if (TIGHT) {
             asm volatile("" : "+s"(T));
