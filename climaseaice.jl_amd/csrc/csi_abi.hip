@@ -181,6 +181,7 @@ struct csi_context {
     int last_fused = 0;
     double ibc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // csi_immersed_flux_bc_set: [u | v][west, east, south, north]
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
+    int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, trio_tiles = -1, peer_kernel = -1; } tune;
 };
@@ -715,6 +716,11 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     // (per-point coefficients: the kernel is compiled for 2 waves per SIMD -> 1024 resident tiles; measured at 2048^2:
     // 1024 tiles 22.9, 1536 tiles 18.9, 768 tiles 20.8 G cell-updates/s)
     int target = c->metric_kind == CSI_METRIC_FULL ? 1024 : 1536;
+    // Beside a fold band (its own stream: eight small launches per pair of sub-steps) the pair launch leaves a third of the wave
+    // slots free, so that the band runs DURING the launch instead of in its tail -- a launch that fills every slot lets only the
+    // band's first kernel in (round 3: 123 + 31 us per pair of sub-steps at 2048^2).  Measured at 2048^2, round 4: fold on uniform
+    // metrics 1536 tiles 53.1, 1280 52.6, 1024 58.7, 896 56.1 G; tripolar-like (per-point metrics) 1024 tiles 20.4, 896 21.9, 768 20.5
+    if (c->geom_band) target = c->metric_kind == CSI_METRIC_FULL ? 896 : 1024;
     bool forced = false;
     if (c->tune.pair_tiles >= 0) { target = c->tune.pair_tiles; forced = true; }   // tuning aid (CSI_PAIR_TILES)
     int max_chunks = target / G.nstrips;
@@ -796,9 +802,10 @@ struct PeerView {
     csi_context* c; GridDev g; int Ny;
     explicit PeerView(csi_context* cc) : c(cc), g(cc->g), Ny(cc->Ny) {
         for (int* side : {&c->g.xlo, &c->g.xhi, &c->g.ylo, &c->g.yhi}) if (*side == SIDE_CONNECTED) *side = SIDE_PERIODIC;
-        if (c->g.yhi == SIDE_FOLD) { const int M = c->Ny - c->Hy - 4; c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
+        if (c->g.yhi == SIDE_FOLD) { const int M = c->Ny - c->Hy - 4; c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; band = c->geom_band; c->geom_band = 1; }
     }
-    ~PeerView() { c->g = g; c->Ny = Ny; }
+    int band = -1;
+    ~PeerView() { c->g = g; c->Ny = Ny; if (band >= 0) c->geom_band = band; }
 };
 bool fold_cut_possible(const csi_context* c) {
     const GridDev& g = c->g;
@@ -1473,9 +1480,9 @@ int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int subste
 
 // A north fold on an untiled grid (RightFolded y, Periodic x): see FoldBand.
 struct FoldCut {        // RAII: the tile with the band cut off (rows 1 .. M, north side "connected")
-    csi_context* c; GridDev g; int Ny;
-    FoldCut(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; }
-    ~FoldCut() { c->g = g; c->Ny = Ny; }
+    csi_context* c; GridDev g; int Ny, band;
+    FoldCut(csi_context* cc, int M) : c(cc), g(cc->g), Ny(cc->Ny), band(cc->geom_band) { c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; c->geom_band = 1; }
+    ~FoldCut() { c->g = g; c->Ny = Ny; c->geom_band = band; }
 };
 bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps) {
     const GridDev& g = c->g;
