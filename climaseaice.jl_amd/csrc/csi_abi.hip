@@ -136,6 +136,8 @@ struct csi_context {
         uint8_t* xbuf = nullptr;             // device staging of the set-up's all-gather
         int last = 0;                        // the last sub-cycle used the peer transport
         int tier = 0;                        // protocol tier (csi_set_peer_tier; FI_PTIER of the kernel tables)
+        bool local_queues_ok = true;         // in-process tile group: GPU_MAX_HW_QUEUES > tiles (csi_comm_init_local)
+        size_t xbuf_cap = 0;                 // bytes of xbuf
     } peer;
     ExPlan pending_rp;                   // the receive plan of an exchange that has been begun
     // fused sub-step kernel: ping-pong copies of u, v, sigma11, sigma22, sigma12
@@ -846,7 +848,15 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         }
         HIP_TRY(c, hipMalloc((void**)&pr.err, sizeof(unsigned)));
         HIP_TRY(c, hipHostMalloc((void**)&pr.err_host, sizeof(unsigned), hipHostMallocDefault));
-        HIP_TRY(c, hipMalloc((void**)&pr.xbuf, sizeof(PeerRec) * kPeerRecs * (size_t)(c->world + 1) + 64));
+    }
+    {
+        const size_t need_x = sizeof(PeerRec) * kPeerRecs * (size_t)(c->world + 1) + 64;      // (a later csi_comm_init may have a larger world)
+        if (need_x > pr.xbuf_cap) {
+            if (pr.xbuf) hipFree(pr.xbuf);
+            pr.xbuf = nullptr; pr.xbuf_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&pr.xbuf, need_x));
+            pr.xbuf_cap = need_x;
+        }
     }
     HIP_TRY(c, hipMemset(pr.slots, 0, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS));
     HIP_TRY(c, hipMemset(pr.err, 0, sizeof(unsigned)));
@@ -2043,6 +2053,15 @@ int32_t csi_field_bind(csi_context* c, int32_t fid, void* dev_ptr, int64_t ld, i
     }
     if (ld > 0x7fffffff) return fail(c, CSI_ERR_INVALID_ARGUMENT, "ld too large");
     if (((uintptr_t)dev_ptr) & 7) return fail(c, CSI_ERR_INVALID_ARGUMENT, "field pointer must be 8-byte aligned");
+    const bool peer_field = fid == CSI_F_U || fid == CSI_F_V || fid == CSI_F_S11 || fid == CSI_F_S22 || fid == CSI_F_S12 || fid == CSI_F_ALPHA ||
+                            fid == CSI_F_ZETA_C || fid == CSI_F_ZETA_F || fid == CSI_F_DELTA;
+    if (peer_field && c->f[fid].p != (double*)dev_ptr && c->peer.ready) {
+        // the neighbours hold mappings of the OLD array: the next sub-cycle sets the peer transport up again.  That set-up is
+        // collective -- on a tiled model, re-binding one of these nine arrays is something every rank has to do between the same
+        // two steps (include/csi.h)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        peer_release(c);
+    }
     c->f[fid].p = (double*)dev_ptr; c->f[fid].ld = ld; c->f[fid].ni = ni; c->f[fid].nj = nj;
     return CSI_OK;
 }
@@ -2330,6 +2349,7 @@ int32_t csi_tile_set(csi_context* c, int32_t rx, int32_t ry, int32_t Rx, int32_t
     c->tile.rx = rx; c->tile.ry = ry; c->tile.Rx = Rx; c->tile.Ry = Ry;
     c->tile.periodic_x = periodic_x != 0; c->tile.periodic_y = periodic_y != 0;
     c->tile.set = true;
+    peer_release(c); c->peer.failed = false;           // (the neighbours may be other ranks now)
     return CSI_OK;
 }
 
@@ -2379,6 +2399,17 @@ int32_t csi_comm_init_local(csi_context* c, csi_local_group* G, int32_t rank) {
     peer_release(c); c->peer.failed = false;
     c->local = G;
     c->world = G->world; c->rank = rank;
+    // The peer transport's kernels wait for flags the OTHER tiles' kernels of this process publish.  HIP maps streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share one run in submission order: with fewer queues
+    // than tiles a waiting kernel can sit in front of the one it waits for until its 3 s time-out.  The variable has to be set
+    // before the runtime initialises, so the library can only check it: without enough queues the group runs the message
+    // exchange (device copies), and asking for the peer transport fails with a clear error instead of timing out at run time.
+    {
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int queues = (q && *q) ? atoi(q) : 4;
+        c->peer.local_queues_ok = queues > G->world;
+        if (!c->peer.local_queues_ok) c->peer.want = 0;
+    }
     std::unique_lock<std::mutex> lk(G->mu);
     ++G->joined;
     return CSI_OK;
@@ -2471,6 +2502,10 @@ int32_t csi_set_exchange_interval(csi_context* c, int32_t k) {
 int32_t csi_set_halo_transport(csi_context* c, int32_t kind) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     if (kind != CSI_TRANSPORT_RCCL && kind != CSI_TRANSPORT_PEER) return fail(c, CSI_ERR_INVALID_ARGUMENT, "unknown halo transport");
+    if (kind == CSI_TRANSPORT_PEER && c->local && !c->peer.local_queues_ok)
+        return fail(c, CSI_ERR_UNSUPPORTED, "peer halo transport on an in-process tile group needs GPU_MAX_HW_QUEUES > number of tiles, set BEFORE the HIP "
+                                            "runtime initialises (the tiles' kernels wait for each other; with fewer hardware queues a waiting kernel can "
+                                            "block the one it waits for): export GPU_MAX_HW_QUEUES=16, or keep the message exchange (CSI_TRANSPORT_RCCL)");
     c->peer.want = kind == CSI_TRANSPORT_PEER;
     if (c->peer.want) c->peer.failed = false;            // (asking again retries the set-up)
     return CSI_OK;

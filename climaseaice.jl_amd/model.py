@@ -482,8 +482,10 @@ def update_state(model):
 
 
 def _state_fields(model):
-    """name -> Field of everything Oceananigans.prognostic_state(model) saves (sea_ice_model.jl:414-426): velocities, ice
-    thickness / concentration, snow thickness, the time stepper's G^n and Psi^-, the dynamics' auxiliary fields, the mass fluxes."""
+    """name -> Field of what Oceananigans.prognostic_state(model) saves (sea_ice_model.jl:414-426): velocities, ice
+    thickness / concentration, snow thickness, the time stepper's G^n and Psi^-, the dynamics' auxiliary fields, the mass fluxes,
+    the thermodynamics' top surface temperatures.  Not mirrored: `tracers` (the HIP path advects h, aice, hs only; a model with
+    further tracers is not attached) and the clock's fields beyond (time, iteration)."""
     out = {"u": model.velocities.u, "v": model.velocities.v, "h": model.ice_thickness, "aice": model.ice_concentration}
     if model.snow_thickness is not None:
         out["hs"] = model.snow_thickness
@@ -499,6 +501,13 @@ def _state_fields(model):
         mf = model.mass_fluxes
         out.update({"mass_fluxes.ice": mf.thermodynamics.ice, "mass_fluxes.snow": mf.thermodynamics.snow,
                     "mass_fluxes.intercepted_snowfall": mf.intercepted_snowfall})
+    # ice_thermodynamics / snow_thermodynamics (sea_ice_model.jl:422-423): their top_surface_temperature fields (the layered
+    # step's outputs, bound as TU / TUS) where the model has them
+    for key, name in (("ice_thermodynamics.top_surface_temperature", "ice_top_temperature"),
+                      ("snow_thermodynamics.top_surface_temperature", "snow_top_temperature")):
+        f = getattr(model, name, None)
+        if f is not None:
+            out[key] = f
     return {k: f for k, f in out.items() if isinstance(f, Field)}
 
 

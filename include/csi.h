@@ -214,7 +214,9 @@ int32_t csi_grid_set(csi_context* ctx, int32_t Nx, int32_t Ny, int32_t Hx, int32
  * ice_stress_divergence.jl:21-24; mask_immersed_field_xy!, sea_ice_model.jl:381-389) */
 int32_t csi_mask_set(csi_context* ctx, const uint8_t* dev_mask, int64_t ld);
 /* Bind the parent array of one field: device pointer, leading dimension and parent extents
- * (validated against the grid: ni = Nx + 2Hx [+1], nj = Ny + 2Hy [+1]). */
+ * (validated against the grid: ni = Nx + 2Hx [+1], nj = Ny + 2Hy [+1]).  * On a tiled model with the peer halo transport the neighbouring ranks map u, v, sigma11, sigma22, sigma12, alpha, zeta_c, zeta_f and
+ * Delta: binding another array to one of these slots makes the next sub-cycle set the transport up again, COLLECTIVELY -- every
+ * rank of the decomposition has to re-bind between the same two steps (like any collective). */
 int32_t csi_field_bind(csi_context* ctx, int32_t field_id, void* dev_ptr, int64_t ld, int32_t ni, int32_t nj);
 int32_t csi_evp_params_set(csi_context* ctx, const csi_evp_params* p);
 int32_t csi_stress_set(csi_context* ctx, int32_t side, const csi_stress* s);
