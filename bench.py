@@ -48,11 +48,10 @@ HBM_ACHIEVABLE_GBS = 6300.0                                    # ... and the mea
 # Compulsory HBM bytes per cell PER LAUNCH of each kernel: what `roofline.frac` is priced on.
 #   k_pair / k_substep: read u, v, P, h, aice, sigma x 3, u^n, v^n + write sigma x 3, u, v = 15 x 8 B (k_pair does two
 #   sub-steps on them); three-kernel path: the per-phase figures of SURVEY.md 8(d).
-KERNEL_BYTES = {"pair": 120.0, "trio": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
+KERNEL_BYTES = {"pair": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
 PARTITION = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}
 KERNEL_NAMES = {"substep": "csi::fused::k_substep (stress + u + v in one launch)",
                 "pair": "csi::fused::k_pair (two sub-steps: 2 x [stress + u + v] in one launch)",
-                "trio": "csi::fused::k_trio (three sub-steps in one launch; --fusion-level 3)",
                 "stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}
 
 
@@ -266,9 +265,8 @@ def main():
     ap.add_argument("--transport", default="peer", choices=["peer", "rccl"],
                     help="tiles: peer-direct halo writes over xGMI with flags (default; halo 4) or the k-batched RCCL exchange (halo 32)")
     ap.add_argument("--no-fusion", action="store_true", help="three-kernel FAST path instead of the fused sub-step kernels")
-    ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2, 3],
-                    help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default), 3: three "
-                         "sub-steps per launch where the grid allows it (fully periodic, one tile, --halo >= 6; measured slower at 2048^2)")
+    ap.add_argument("--fusion-level", type=int, default=2, choices=[0, 1, 2],
+                    help="0: three kernels per sub-step, 1: one fused launch per sub-step, 2: two sub-steps per launch (default)")
     ap.add_argument("--force-connected", action="store_true",
                     help="debug: on one GPU, route the periodic halos through the RCCL exchange (to self)")
     ap.add_argument("--print-launch", action="store_true", help="--gpus N > 1: print the launch command of the N ranks as JSON and exit")
@@ -495,7 +493,7 @@ def main():
     if path["fused"]:
         launches, nsub = model.ctx.last_launches()
         spl = nsub / max(launches, 1)
-        dom = {2: "pair", 3: "trio"}.get(path["level"], "substep")
+        dom = {2: "pair"}.get(path["level"], "substep")
         phases = {dom: phases["stress"], "exchange": phases["exchange"]}
         sub_ms = phases[dom] / spl
     else:

@@ -1,0 +1,125 @@
+// csi_fold.hip -- north fold: the band of rows next to the fold on the three kernels, beside the pair launches  (split out of csi_abi.hip in round 4; see csi_ctx.h)
+#include "csi_ctx.h"
+
+namespace csi_host {
+
+// ---- north fold: a band of rows next to the fold on the three kernels, everything below on the two-sub-steps kernel -------
+// The two-sub-steps kernel cannot reproduce the reference next to a fold (it would have to recompute halo rows the reference
+// READS as stored images).  But only the rows within reach of the fold need that: rows 1 .. M
+// (M = Ny - Hy - 4) run through the pair kernel as a tile whose north side is "connected" -- its halo rows M + 1 .. M + 4 are
+// interior rows of the same arrays --, rows above M through the three kernels, which store and read fold images exactly like
+// the reference's.  Per pair of sub-steps the band, on its own stream and in its own copies of the arrays: copy rows >= M - 7
+// of u, v, sigma from the current buffer, advance them by two three-kernel sub-steps on shrinking row ranges (valid from row M
+// on after the second), copy rows >= M + 1 into the other buffer -- while the pair launch reads the current buffer and stores
+// rows <= M of the other one.  Two events: a pair launch waits for the previous band (its halo rows), a band for the previous
+// pair launch (rows M - 7 .. M of its input).
+const Bound& band_bound(const csi_context* c, int q) { return c->f[q < 5 ? kPing[q] : kBandDiag[q - 5]]; }
+FRef band_ref(const csi_context* c, int q) {
+    const Bound& b = band_bound(c, q);
+    FRef r;
+    r.p = c->band[q] + (c->Hx - 1) + (int64_t)(c->Hy - 1) * b.ld;
+    r.ld = (int)b.ld;
+    return r;
+}
+int32_t ensure_band(csi_context* c) {
+    for (int q = 0; q < 9; ++q) {
+        const Bound& b = band_bound(c, q);
+        const size_t n = (size_t)b.ld * (size_t)b.nj;
+        if (c->band_elems[q] != n) {
+            if (c->band[q]) { HIP_TRY(c, hipDeviceSynchronize()); hipFree(c->band[q]); c->band[q] = nullptr; }
+            HIP_TRY(c, hipMalloc((void**)&c->band[q], n * sizeof(double)));
+            HIP_TRY(c, hipMemsetAsync(c->band[q], 0, n * sizeof(double), c->stream));
+            c->band_elems[q] = n;
+        }
+    }
+    if (!c->band_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_pair, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_band, hipEventDisableTiming));
+    }
+    return CSI_OK;
+}
+// one three-kernel sub-step on rows >= jlo, in place: u, v, sigma in b[0..4], diagnostics (last sub-step) in d[0..3] (alpha,
+// zeta_c, zeta_f, Delta; nullptr: the caller's arrays); jlo hugely negative: the whole grid
+int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* b, const FRef* d, bool ufirst, int jlo, bool last, hipStream_t st) {
+    EvpDev Q = bd.P;
+    Q.u = b[0]; Q.v = b[1]; Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
+    if (d) { Q.al = d[0]; Q.zc = d[1]; Q.zf = d[2]; Q.Dl = d[3]; }
+    Q.write_diag = last;
+    auto from = [&](Range r, int j0) { if (j0 > r.j0) r.j0 = j0; return r; };
+    launch_fast_stress(Q, from(bd.rs, jlo), fc, st);
+    if (ufirst) { launch_fast_ustep(Q, from(bd.ru1, jlo + 1), bd.imu, fc, st); launch_fast_vstep(Q, from(bd.r2, jlo + 1), bd.imv, fc, st); }
+    else { launch_fast_vstep(Q, from(bd.rv1, jlo + 1), bd.imv, fc, st); launch_fast_ustep(Q, from(bd.r2, jlo + 1), bd.imu, fc, st); }
+    return CSI_OK;
+}
+// two sub-steps (or the trailing single one) of the band: buffer `cur` (0: the caller's arrays) -> the other one, on the band's stream
+int32_t band_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, int n, bool last) {
+    hipStream_t st = c->band_stream;
+    HIP_TRY(c, hipStreamWaitEvent(st, c->band_ev_pair, 0));
+    auto rows_from = [&](int q, int j0, const double* src, double* dst, CopyBatch& B) {
+        const Bound& b = band_bound(c, q);
+        const size_t row = (size_t)(j0 - 1 + c->Hy), off = row * (size_t)b.ld;
+        B.src[B.count] = src + off; B.dst[B.count] = dst + off; B.n[B.count] = (long)(((size_t)b.nj - row) * (size_t)b.ld);
+        ++B.count;
+    };
+    CopyBatch in{}, out{}, diag{};
+    for (int q = 0; q < 5; ++q) {
+        const Bound& b = band_bound(c, q);
+        rows_from(q, bd.M - 7, cur == 0 ? b.p : c->alt[q], c->band[q], in);
+        rows_from(q, bd.M + 1, c->band[q], cur == 0 ? c->alt[q] : b.p, out);
+    }
+    launch_copy_batch(in, st);
+    FRef b[5], d[4];
+    for (int q = 0; q < 5; ++q) b[q] = band_ref(c, q);
+    for (int q = 0; q < 4; ++q) d[q] = band_ref(c, 5 + q);
+    // validity after the first sub-step: sigma from row M - 5, velocities from M - 3; after the second: sigma M - 2, velocities M
+    int32_t rc;
+    if (n == 2) {
+        if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 5, false, st))) return rc;
+        if ((rc = band_substep(c, bd, fc, b, d, ((s + 1) % 2) == 0, bd.M - 2, last, st))) return rc;
+    } else if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 3, last, st))) return rc;
+    launch_copy_batch(out, st);
+    if (last) {
+        for (int q = 5; q < 9; ++q) rows_from(q, bd.M + 1, c->band[q], band_bound(c, q).p, diag);
+        launch_copy_batch(diag, st);
+    }
+    HIP_TRY(c, hipEventRecord(c->band_ev_band, st));
+    return CSI_OK;
+}
+
+
+// A north fold on an untiled grid (RightFolded y, Periodic x): see FoldBand.
+bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps) {
+    const GridDev& g = c->g;
+    if (g.yhi != SIDE_FOLD || g.xlo != SIDE_PERIODIC || g.xhi != SIDE_PERIODIC) return false;
+    if (c->mode != CSI_MODE_FAST || !c->fusion || !c->pairing || substeps < 2 || c->Hy < 4) return false;
+    if (g.ylo == SIDE_CONNECTED) {
+        // the fold tile of a y partition: the k-batched message exchange with the tile below, pair launches need an even k
+        const int k = exchange_interval(c);
+        if (k % 2 != 0 || !has_comm(c) || !c->tile.set) return false;
+    }
+    const int M = c->Ny - c->Hy - 4;
+    if (M < 2 * c->Hy + 8) return false;
+    FoldCut cut(c, M);
+    EvpDev P = Pfull;
+    P.g = c->g;
+    return pair_supported(c) && pair_forcing_kind(P) >= 0;
+}
+int32_t run_fused_fold(csi_context* c, const EvpDev& Pfull, const FastCoef& fc, int substeps, int first) {
+    FoldBand bd;
+    bd.M = c->Ny - c->Hy - 4;
+    bd.tiled = c->g.ylo == SIDE_CONNECTED;
+    bd.k = bd.tiled ? exchange_interval(c) : 2;
+    bd.g_full = c->g; bd.Ny_full = c->Ny;
+    bd.P = Pfull;
+    bd.imu = image_spec(c, CSI_F_U); bd.imv = image_spec(c, CSI_F_V);
+    bd.rs = stress_range(c); bd.ru1 = first_u_range(c); bd.rv1 = first_v_range(c); bd.r2 = second_range(c);
+    FoldCut cut(c, bd.M);
+    bd.g_cut = c->g;
+    EvpDev P = Pfull;
+    P.g = c->g;
+    return run_fused(c, P, fc, substeps, first, false, &bd);
+}
+
+
+}  // namespace csi_host

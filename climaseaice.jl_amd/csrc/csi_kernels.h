@@ -79,9 +79,6 @@ bool fused_supported_forcing(const EvpDev& P);   // everything but the mask rest
 void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const FRef* out,
                       const Range& rs, const Range& r1, const Range& r1c, const Range& r2,
                       const ImageSpec& imu, const ImageSpec& imv, FusedTable* host_table);
-// three sub-steps per launch (evp_fused3.hip): fully periodic, untiled grids with halo >= 6, number-valued forcing
-void launch_fused_trio(const FusedTable* dev_table, bool uniform, bool a_ufirst, int common_forcing, int nstrips, int nchunks, int rows,
-                       int write_diag, hipStream_t s);
 void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst, int nstrips, int nchunks, int rows,
                           int write_diag, hipStream_t s);
 // two sub-steps per launch (evp_fused2.hip); metric: 0 uniform coefficients, 1 per-row table, 2 per-point planes (CSI_METRIC_FULL).

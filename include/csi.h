@@ -383,10 +383,9 @@ int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
  * interval is even; an odd trailing sub-step uses the level-1 kernel, or -- with masks, array forcing or per-point metrics -- one more launch
  * of the same kernel whose second wave stores the first sub-step's results instead of computing a second one.  All paths execute the same
  * floating-point operations and give bit-identical results. */
-/* level 3: THREE sub-steps per launch (evp_fused3.hip: three waves per tile chained through two LDS rings) on fully periodic,
- * untiled grids with halo >= 6 and number-valued forcing, two elsewhere.  Bit-identical like the others; not the default: it
- * trades a third of the HBM traffic for 10 % more arithmetic and measures 5 % slower than level 2 at 2048^2 on MI355X
- * (faster only around 3072^2). */
+/* (Round 2 built a level 3 -- three sub-steps per launch, three waves per tile chained through two LDS rings; it traded a third of
+ * the HBM traffic for 10 % more arithmetic and measured slower than level 2 at every size but 3072^2, so round 4 removed it:
+ * DESIGN.md section 3.)  Levels other than 0, 1, 2 are refused. */
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
 /* RCCL halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): automatic -- the peer

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4: A/B of library builds on selected bench_cases configurations. usage: r04_cases_ab.sh <tag> "<case substrings ...>" <lib> ...
+# Round 4: A/B of library builds on selected bench_cases configurations. usage: cases_ab.sh <tag> "<case substrings ...>" <lib> ...
 TAG=$1; CASES=$2; shift; shift
 R=$GRAFT_REPO_ROOT/climaseaice.jl_amd
 mkdir -p gpurun_out; : > gpurun_out/${TAG}.log

@@ -471,30 +471,6 @@ def test_pair_kernel_on_tiles_halo32_interval16(topo):
         assert np.array_equal(a, b), (f, np.abs(a - b).max(), np.argwhere(a != b)[:5])
 
 
-@pytest.mark.parametrize("nsub", [3, 4, 5, 7, 8, 120])
-@pytest.mark.parametrize("Nx,Ny,H,kw", [(64, 48, 6, {}), (130, 96, 6, {}), (200, 150, 8, dict(beta=1.6e-11)), (57, 40, 6, dict(top=None)),
-                                        (120, 64, 7, dict(ue=0.03, ve=-0.02))])
-def test_three_substeps_per_launch_bitwise(Nx, Ny, H, kw, nsub):
-    """csi_set_fusion(3), csrc/evp_fused3.hip: three waves per tile (stages A, B, C of three consecutive sub-steps) chained
-    through two LDS rings on fully periodic grids with halo >= 6; any sub-step count is a mixture of triples and pairs.
-    Bit-identical with the three-kernel path on every field, halos included."""
-    c = cases.make_case(Nx=Nx, Ny=Ny, H=H, substeps=nsub, topo=("periodic", "periodic"), patches=True, random_uv=0.05, **kw)
-    out = {}
-    for fusion in (0, 3):
-        m = cases.csi_model(c, mode="fast")
-        m.set_fusion(fusion)
-        csi.time_step_momentum(m, c["dt"])
-        m.synchronize()
-        out[fusion] = {k: EVP_FIELDS[k](m).numpy().copy() for k in ("u", "v", "s11", "s22", "s12")}
-        out[fusion].update({k: EVP_FIELDS[k](m).interior_numpy().copy() for k in ("alpha", "zeta_c", "zeta_f", "Delta")})
-    assert m.ctx.last_path()["level"] == (3 if nsub != 4 else 2)
-    launches, substeps = m.ctx.last_launches()
-    assert substeps == nsub and launches == {3: 1, 4: 2, 5: 2, 7: 3, 8: 3, 120: 40}[nsub]
-    for k in out[0]:
-        assert np.all(np.isfinite(out[3][k])), k
-        assert np.array_equal(out[0][k], out[3][k]), (k, np.abs(out[0][k] - out[3][k]).max())
-
-
 PEER_CASES = {
     # (make_case keywords, which periodic directions are connected to the tile itself)
     "periodic_xy": (dict(Nx=300, Ny=200, topo=("periodic", "periodic")), (True, True)),
@@ -710,7 +686,7 @@ def test_fused_paths_fuzz_bitwise(seed):
     c = cases.make_case(substeps=nsub, **kw)
     out = {}
     lvl = {}
-    for fusion in (0, 2, 3):          # 3: three sub-steps per launch where the configuration allows it (periodic, halo >= 6, numbers), else pairs
+    for fusion in (0, 2):
         m = cases.csi_model(c, mode="fast")
         m.set_fusion(fusion)
         csi.time_step_momentum(m, c["dt"])
@@ -719,8 +695,8 @@ def test_fused_paths_fuzz_bitwise(seed):
         out[fusion]["alpha"] = EVP_FIELDS["alpha"](m).interior_numpy().copy()
         lvl[fusion] = m.ctx.last_path()["level"]
     unfused = (kw.get("wind_drag") == "arrays" or kw.get("bottom") == "arrays") and (kw.get("free_drift") or kw.get("user_forcing") or kw.get("immersed_bc"))
-    assert (lvl[2] == 0 and lvl[3] == 0) if unfused else (lvl[2] == 2 and lvl[3] in (2, 3)), (kw, nsub, lvl)   # (no instantiation with both families of arrays)
-    for fusion in (2, 3):
+    assert (lvl[2] == 0) if unfused else (lvl[2] == 2), (kw, nsub, lvl)   # (no instantiation with both families of arrays)
+    for fusion in (2,):
         for k in out[0]:
             a, b = out[0][k], out[fusion][k]
             assert np.all(np.isfinite(b)), (k, kw)
