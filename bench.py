@@ -7,7 +7,7 @@ inputs resident in HBM.  value = cell-updates/s = owned cells * substeps * steps
 
 N = 1: the 2048 x 2048 periodic f-plane grid the metric is quoted on.
 N > 1 (torch.distributed.run, one rank per GPU): STRONG scaling by default -- the SAME 2048 x 2048 grid split into
-Rx x Ry tiles (2x1, 2x2, 2x4: 1024 x 512 per GPU at N = 8, BASELINE config 4's decomposition), advanced by the same
+y slabs (1x2, 1x4, 1x8: 2048 x 256 per GPU at N = 8, the fastest tile shape measured; `--partition 2x4`: BASELINE config 4's), advanced by the same
 kernels with the RCCL halo exchange of u, v, sigma (width 2k every k sub-steps; halo 32 -> k = 16; `--exchange-interval 1`
 is the north star's one exchange per sub-step and is timed as well, outside the headline region).  `--scaling weak`
 gives every GPU its own 2048 x 2048 tile instead.
@@ -49,7 +49,13 @@ HBM_ACHIEVABLE_GBS = 6300.0                                    # ... and the mea
 #   k_pair / k_substep: read u, v, P, h, aice, sigma x 3, u^n, v^n + write sigma x 3, u, v = 15 x 8 B (k_pair does two
 #   sub-steps on them); three-kernel path: the per-phase figures of SURVEY.md 8(d).
 KERNEL_BYTES = {"pair": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
-PARTITION = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}
+# Default decomposition of the metric's grid on N GPUs: slabs in y (Rx = 1).  Measured per tile shape on one MI355X, the tile connected
+# to itself over the peer transport in the directions its partition connects (scripts/tile_shapes.py, profiles/r04_tile_1024x512.md; G
+# cell-updates/s): N = 8: 1x8 (2048 x 256) 39.9, 2x4 (1024 x 512) 36.8, 8x1 35.9, 4x2 35.5; N = 4: 1x4 54.4, 2x2 51.4; N = 2: 1x2 65.9,
+# 2x1 63.5.  A slab keeps x periodic inside the tile (no x images into another GPU's memory: those are 8-byte write-through stores),
+# has two neighbours instead of eight and loses 1 % of its lanes to the strip width instead of 4 %.  `--partition 2x4` selects
+# BASELINE config 4's decomposition (also what tests/test_gpu_fullsize.py runs at full size, in process).
+PARTITION = {1: (1, 1), 2: (1, 2), 4: (1, 4), 8: (1, 8)}
 KERNEL_NAMES = {"substep": "csi::fused::k_substep (stress + u + v in one launch)",
                 "pair": "csi::fused::k_pair (two sub-steps: 2 x [stress + u + v] in one launch)",
                 "stress": "csi::fast::k_stress", "ustep": "csi::fast::k_ustep", "vstep": "csi::fast::k_vstep"}
@@ -273,6 +279,7 @@ def main():
     ap.add_argument("--self-test-launch", action="store_true",
                     help="host test of the launcher, no GPU: the ranks rendezvous over gloo, rank 0 prints a stub line (self_test: true)")
     ap.add_argument("--no-compare", action="store_true", help="tiles: do not time the other halo transports (RCCL k = 16, k = 1) after the headline")
+    ap.add_argument("--partition", type=str, default="", help="RxxRy tiles instead of the default y slabs (e.g. 2x4: BASELINE config 4's decomposition); Rx * Ry = --gpus")
     ap.add_argument("--no-unfused", action="store_true", help="one GPU: do not time the unfused three-kernel path (roofline.unfused) after the headline")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
     args = ap.parse_args()
@@ -313,6 +320,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     Rx, Ry = PARTITION[world]
+    if args.partition:
+        Rx, Ry = (int(t) for t in args.partition.lower().split("x"))
+        if Rx * Ry != world:
+            raise SystemExit(f"--partition {args.partition}: {Rx} x {Ry} tiles but {world} rank(s)")
     if args.tile:
         nx_l, ny_l = (int(s) for s in args.tile.lower().split("x"))
     elif args.scaling == "weak":

@@ -401,6 +401,24 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     if (rows < 1) rows = 1;
     G.rows = rows;
     G.nchunks = (height + rows - 1) / rows;
+    // Peer transport: the chunk next to a connected y side waits for its neighbour's flags, stores the halo images (write-through,
+    // into the neighbour's memory) and publishes -- about four row iterations' worth -- and a launch is as long as its slowest
+    // tile: that chunk gets four rows less (not fewer than the halo: the next chunk must stay out of the side's tile set).
+    // Measured on a 2048 x 256 tile connected to itself in y (round 4): profiles/r04_tile_1024x512.md.
+    if (c->geom_peer && !forced && c->tune.pair_rows < 0 && c->tune.peer_edge != 0) {
+        const int e = std::max(std::max(c->Hy, 4), rows - (c->tune.peer_edge > 0 ? c->tune.peer_edge : 4));
+        const bool lo = c->peer.sync_rank[2] >= 0, hi = c->peer.sync_rank[3] >= 0;
+        if (e < rows && height >= 4 * rows && (lo || hi)) {
+            G.elo = lo ? e : rows;
+            G.ehi = hi ? e : 0;
+            const int mid = height - G.elo - G.ehi;
+            G.nchunks = 1 + (mid + rows - 1) / rows + (hi ? 1 : 0);
+            if (!hi) {
+                // (no short chunk at the high side: the formula's last chunk is simply what is left behind chunk 0)
+                G.nchunks = 1 + (height - G.elo + rows - 1) / rows;
+            }
+        }
+    }
     return G;
 }
 

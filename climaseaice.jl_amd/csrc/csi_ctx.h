@@ -22,6 +22,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <initializer_list>
 
 using namespace csi;
@@ -183,8 +184,9 @@ struct csi_context {
     double ibc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // csi_immersed_flux_bc_set: [u | v][west, east, south, north]
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
     int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
+    int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
-    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1; } tune;
+    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1; } tune;
 };
 
 namespace csi_host {
@@ -208,7 +210,16 @@ static inline int nxf_of(int k) { return k > 1 ? 5 : 2; }     // sigma travels w
 struct FoldBand;
 // ---- functions shared by the translation units (definitions: see the list at the top) ----
 static const int kPing[5] = {CSI_F_U, CSI_F_V, CSI_F_S11, CSI_F_S22, CSI_F_S12};
-struct FusedGeom { Range rs; int nstrips, nchunks, rows; };
+// (elo / ehi: rows of the FIRST / LAST chunk where they differ from `rows` -- shorter tiles next to a peer-connected y side,
+//  pair_geom; elo == rows and ehi == 0: every chunk `rows` rows, the last one what is left)
+struct FusedGeom { Range rs; int nstrips, nchunks, rows; int elo = 0, ehi = 0; };
+// rows [ja, jb] of chunk q (the kernels' formula: evp_fused2.hip)
+static inline void chunk_rows(const FusedGeom& G, int q, int* ja, int* jb) {
+    const int elo = G.elo > 0 ? G.elo : G.rows;
+    const bool last_short = G.ehi > 0 && q == G.nchunks - 1 && q > 0;
+    *ja = last_short ? G.rs.j1 - G.ehi + 1 : G.rs.j0 + (q == 0 ? 0 : elo + (q - 1) * G.rows);
+    *jb = q == 0 ? std::min(*ja + elo - 1, G.rs.j1) : (q == G.nchunks - 1 ? G.rs.j1 : std::min(*ja + G.rows - 1, G.rs.j1 - G.ehi));
+}
 constexpr int kMaxExchangeInterval = 16;
 struct SideV { int xlo, xhi, ylo, yhi; };
 static const int kPeerDx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, kPeerDy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
@@ -227,12 +238,13 @@ constexpr int kPeerRecs = csi_context::Peer::NARR + 1;      // + the flag array
 // its three-kernel band (FoldBand), whose side then counts as "connected" (halo rows = interior rows of the same arrays).
 struct PeerView {
     csi_context* c; GridDev g; int Ny;
-    explicit PeerView(csi_context* cc) : c(cc), g(cc->g), Ny(cc->Ny) {
+    explicit PeerView(csi_context* cc) : c(cc), g(cc->g), Ny(cc->Ny), peer_was(cc->geom_peer) {
+        c->geom_peer = 1;
         for (int* side : {&c->g.xlo, &c->g.xhi, &c->g.ylo, &c->g.yhi}) if (*side == SIDE_CONNECTED) *side = SIDE_PERIODIC;
         if (c->g.yhi == SIDE_FOLD) { const int M = c->Ny - c->Hy - 4; c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; band = c->geom_band; c->geom_band = 1; }
     }
-    int band = -1;
-    ~PeerView() { c->g = g; c->Ny = Ny; if (band >= 0) c->geom_band = band; }
+    int band = -1, peer_was = 0;
+    ~PeerView() { c->g = g; c->Ny = Ny; if (band >= 0) c->geom_band = band; c->geom_peer = peer_was; }
 };
 struct FoldBand {
     int M;

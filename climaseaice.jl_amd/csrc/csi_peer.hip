@@ -19,9 +19,14 @@ PeerSets peer_wait_counts(const csi_context* c, const FusedGeom& G) {
         if (i0s + 63 + 16 > c->Nx - c->Hx) ++ps.nE;
     }
     for (int q = 0; q < G.nchunks; ++q) {
-        const int ja = G.rs.j0 + q * G.rows, jb = std::min(ja + G.rows - 1, G.rs.j1);
-        if (ja <= c->Hy + 4) ++ps.nS;
-        if (jb + 4 > c->Ny - c->Hy) ++ps.nN;
+        int ja, jb;
+        chunk_rows(G, q, &ja, &jb);
+        // in a side's set: the chunk reads halo rows beyond it (its footprint reaches 4 rows beyond its own: ja - 4 <= 0) or owns
+        // rows whose images it stores there (rows 1 .. Hy / Ny - Hy + 1 .. Ny).  (Until round 4 the test was Hy + 4 rows wide:
+        // correct but one chunk more than needed once the chunk next to the side is shorter than that.)
+        const int reach = std::max(c->Hy, 4);
+        if (ja <= reach) ++ps.nS;
+        if (jb + reach > c->Ny) ++ps.nN;
     }
     const int sz[8] = {ps.nW * G.nchunks, ps.nE * G.nchunks, ps.nS * G.nstrips, ps.nN * G.nstrips,
                        ps.nW * ps.nS, ps.nE * ps.nS, ps.nW * ps.nN, ps.nE * ps.nN};

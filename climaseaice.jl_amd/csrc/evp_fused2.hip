@@ -135,8 +135,15 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
         const int Nx = T->I[FI_NX], Hx = T->I[FI_HX], Hy = T->I[FI_HY];
         const int i0s = T->I[FI_DEC + 0] - P_LO + strip * P_W;
         i = i0s + lane;
-        ja = T->I[FI_DEC + 2] + chunk * rows;
-        jb = min(ja + rows - 1, T->I[FI_DEC + 3]);
+        // chunk 0 may be shorter (FI_ELO rows), the last chunk is what FI_EHI keeps for it: tiles next to a peer-connected y
+        // side wait for / signal a neighbour and store its halo images -- fewer rows take them off the launch's critical path
+        {
+            const int elo = T->I[FI_ELO] > 0 ? T->I[FI_ELO] : rows;
+            ja = (T->I[FI_EHI] > 0 && chunk == nchunks - 1 && chunk > 0) ? T->I[FI_DEC + 3] - T->I[FI_EHI] + 1
+                                                                         : T->I[FI_DEC + 2] + (chunk == 0 ? 0 : elo + (chunk - 1) * rows);
+            jb = chunk == 0 ? min(ja + elo - 1, T->I[FI_DEC + 3])
+                            : (chunk == nchunks - 1 ? T->I[FI_DEC + 3] : min(ja + rows - 1, T->I[FI_DEC + 3] - T->I[FI_EHI]));
+        }
         const int ic = min(max(i, 1 - Hx), Nx + Hx);
         loff = (unsigned)(ic - (1 - Hx)) * 8u;
         row0 = 1 - Hy;

@@ -140,14 +140,15 @@ def test_local_tiles_strict_mode_bitwise(name):
 
 
 @pytest.mark.parametrize("transport", ["peer", "rccl"])
-@pytest.mark.parametrize("Rx,Ry", [(2, 1), (2, 2), (2, 4)])
+@pytest.mark.parametrize("Rx,Ry", [(1, 2), (1, 4), (1, 8), (2, 1), (2, 2), (2, 4)])
 def test_bench_decompositions_in_process(Rx, Ry, transport):
     """bench.py's own N = 2 / 4 / 8 jobs, scaled down: the headline configuration (periodic f-plane, bench.py's seeded inputs
-    built per tile by bench.tile_fields / local_case) as 2 x 1, 2 x 2, 2 x 4 distinct tiles on this one GPU, on the peer transport
+    built per tile by bench.tile_fields / local_case) as y slabs (1 x 2, 1 x 4, 1 x 8: bench.py's default since round 4) and as
+    2 x 1, 2 x 2, 2 x 4 (`--partition`) distinct tiles on this one GPU, on the peer transport
     (halo 4) and on the message exchange bench.py falls back to (halo 32, every 16 sub-steps): each tile equals the one-GPU run
     of the assembled global state bit for bit -- the check bench.py itself makes before it times anything, here on hardware."""
     import bench
-    size, substeps = 512, 120
+    size, substeps = (512 if Ry < 8 else 1024), 120          # (a slab must be taller than 2 halos + the pair kernel's rings)
     nx, ny = size // Rx, size // Ry
     halo = 4 if transport == "peer" else 32
 
