@@ -94,15 +94,17 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
+// The kernel's body is a function of its own (not inlined: its registers are allocated for it alone), so that the PEER kernels can
+// run their INTERIOR tiles -- no neighbour to wait for, no image into another rank's memory -- through the body of the untiled
+// instantiation: compiled into one function with the flag protocol and the redirected image stores, the row loops of every tile
+// were 6 % slower (1.7 us per launch on a 1024 x 512 tile with no neighbour at all; round 4, profiles/r04_tile_1024x512.md).
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
-__global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
-                                                              int blocks_per_xcd, int write_diag, unsigned long long seq) {
+__device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+                                       int blocks_per_xcd, int write_diag, unsigned long long seq,
+                                       double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p) {
     constexpr bool PRE = CSI_PAIR_PRE && !MASK;
     constexpr int RING_FIELDS = PRE ? 13 : 10;
-    __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
-    __shared__ unsigned ringm[RING_ROWS * 64];
-    __shared__ double outr[2 * 5 * 64];                    // stage B's results on their way to the producer's stores
-    __shared__ unsigned peer_abort;                        // PEER: the producer's wait has given up
+#define peer_abort (*peer_abort_p)
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
     if (w >= nstrips * nchunks) return;                      // (uniform over the workgroup: both waves leave)
@@ -851,6 +853,35 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
     __syncthreads();                                      // the last row's results are in the out ring: the producer drains them
     publish();
     PROBE_END(w * 2 + 1);
+#undef peer_abort
+}
+
+template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
+__global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+                                                              int blocks_per_xcd, int write_diag, unsigned long long seq) {
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK;
+    constexpr int RING_FIELDS = PRE ? 13 : 10;
+    __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
+    __shared__ unsigned ringm[MASK ? RING_ROWS * 64 : 1];
+    __shared__ double outr[(CSI_PAIR_STORES & 7) != 7 ? 2 * 5 * 64 : 1];      // stage B's results on their way to the producer's stores
+    __shared__ unsigned peer_abort_w;                      // PEER: the producer's wait has given up
+    if constexpr (PEER) {
+        // an interior tile of a peer-connected launch (in no direction's set): the untiled instantiation's body
+        const int b = (int)blockIdx.x;
+        const int w = (b & 7) * blocks_per_xcd + (b >> 3);
+        if (w >= nstrips * nchunks) return;
+        const int chunk = w / nstrips, strip = w - chunk * nstrips;
+        tptr_t T = (tptr_t)table;
+        const bool pw = strip < T->I[FI_PSET], pe = strip >= nstrips - T->I[FI_PSET + 1], ps = chunk < T->I[FI_PSET + 2],
+                   pn = chunk >= nchunks - T->I[FI_PSET + 3];
+        const unsigned pd = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
+                             ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)T->I[FI_PMASK];
+        if (__builtin_amdgcn_readfirstlane((int)pd) == 0) {
+            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w);
+            return;
+        }
+    }
+    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w);
 }
 
 }  // namespace fused
