@@ -104,10 +104,12 @@ def run_parent(args, argv):
     if args.print_launch:
         print(json.dumps({"launch": cmd, "ranks": args.gpus, "visible_gpus": have, "would_run": have >= args.gpus}), flush=True)
         return 0
-    if have < args.gpus and not args.self_test_launch:
+    if have < args.gpus and not args.self_test_launch and not (args.rehearse_on_one_gpu and have >= 1):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible; refusing to fall back to fewer ranks\n")
         return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CSI_BENCH_LAUNCHED_BY_PARENT="1")
+    if args.rehearse_on_one_gpu:
+        env["CSI_BENCH_HOST_GROUP"] = f"/csi-bench-{os.getpid()}"        # the shared-memory segment every rank joins
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)          # stderr passes through
     line = None
     for ln in p.stdout.splitlines():
@@ -279,6 +281,11 @@ def main():
     ap.add_argument("--self-test-launch", action="store_true",
                     help="host test of the launcher, no GPU: the ranks rendezvous over gloo, rank 0 prints a stub line (self_test: true)")
     ap.add_argument("--no-compare", action="store_true", help="tiles: do not time the other halo transports (RCCL k = 16, k = 1) after the headline")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 path on a one-GPU box: the N ranks are processes that all use GPU 0, joined by the library's "
+                         "host-channel group (shared memory + HIP IPC; RCCL refuses two ranks on one device) and gloo; every step of the N > 1 "
+                         "path runs -- launcher, peer set-up over IPC, tier ladder, tiled == untiled check, timing, the JSON line -- but the "
+                         "numbers are those of N processes SHARING one GPU: the line says `rehearsal_on_one_gpu` and is not a scaling result")
     ap.add_argument("--partition", type=str, default="", help="RxxRy tiles instead of the default y slabs (e.g. 2x4: BASELINE config 4's decomposition); Rx * Ry = --gpus")
     ap.add_argument("--no-unfused", action="store_true", help="one GPU: do not time the unfused three-kernel path (roofline.unfused) after the headline")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
@@ -312,13 +319,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = bool(args.rehearse_on_one_gpu and world > 1)
+    if rehearsal:
+        local_rank = 0                                     # every rank on GPU 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    coll_device = "cpu" if rehearsal else None             # gloo reduces host tensors
     Rx, Ry = PARTITION[world]
     if args.partition:
         Rx, Ry = (int(t) for t in args.partition.lower().split("x"))
@@ -342,11 +356,19 @@ def main():
                                          solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
         return csi.SeaIceModel(grid, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
 
+    nonlocal_builds = [0]
+
     def build(transport):
         """This rank's tile model.  Tiles: the peer transport needs the halo 4 of an untiled run; the RCCL exchange amortises its
         pack / send / unpack over k = 16 sub-steps with halo 32."""
         halo = user_halo or (4 if (not tiled or transport == "peer") else 32)
         grid, fld = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=halo)
+        if rehearsal:
+            nonlocal_builds[0] += 1
+            # (a fresh segment per model -- every rank builds its models in the same order; without the parent the name comes from
+            #  the rendezvous port, which is the same on every rank of a job)
+            base = os.environ.get("CSI_BENCH_HOST_GROUP") or f"/csi-bench-{os.environ.get('MASTER_PORT', '0')}"
+            grid.host_group = f"{base}-{nonlocal_builds[0]}"
         m = make_model(grid)
         m.set_exchange_interval(args.exchange_interval)
         m.set_halo_transport(transport)
@@ -366,7 +388,7 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], device=device, dtype=torch.float64)
+        t = torch.tensor([x], device=coll_device or device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -382,7 +404,7 @@ def main():
         """logical AND over the ranks"""
         if dist is None:
             return bool(flag)
-        t = torch.tensor([1.0 if flag else 0.0], device=device, dtype=torch.float64)
+        t = torch.tensor([1.0 if flag else 0.0], device=coll_device or device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
 
@@ -491,7 +513,7 @@ def main():
     ok = all(c["finite"] for c in chk.values()) and 0 < chk["u"]["max_abs"] < 10.0 and chk["u"]["nonzero_frac"] > 0.5 \
         and chk["s11"]["max_abs"] > 0
     if dist is not None:
-        t = torch.tensor([1.0 if ok else 0.0], device=device, dtype=torch.float64)
+        t = torch.tensor([1.0 if ok else 0.0], device=coll_device or device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         ok = bool(t.item() > 0.5)
     if not ok:
@@ -661,6 +683,10 @@ def main():
         out["exchange_every_substep"] = k1
     if rccl16 is not None:
         out["rccl_exchange"] = rccl16
+    if rehearsal:
+        out["rehearsal_on_one_gpu"] = True
+        out["rehearsal_note"] = (f"{world} ranks are PROCESSES sharing GPU 0 (host-channel group: shared memory + HIP IPC, gloo): a rehearsal of the "
+                                 "N > 1 path, NOT a scaling measurement -- value, ms_per_step and parallel_efficiency are those of a shared device")
     if world > 1:
         out["rccl_ranks"] = rccl_ranks
         out["single_gpu"] = single

@@ -95,3 +95,28 @@ def test_processes_on_one_gpu_tiled_equals_untiled_bitwise(name, transport, nsub
         for f in FIELDS:
             mine, w = got[r][f][:ny, :nx], want[f][j0:j0 + ny, i0:i0 + nx]
             assert np.array_equal(mine, w), (name, "rank", r, f, np.abs(mine - w).max(), np.argwhere(mine != w)[:4].tolist())
+
+
+@pytest.mark.parametrize("n,partition", [(2, ""), (4, ""), (4, "2x2")])
+def test_bench_rehearsal_of_the_multi_rank_path_on_one_gpu(n, partition):
+    """bench.py --gpus N --rehearse-on-one-gpu: the WHOLE N > 1 path of the benchmark the driver runs on an 8-GPU node -- parent,
+    torch.distributed.run launch, one rank per process, peer set-up over HIP IPC, the tier ladder, the tiled == untiled check before
+    anything is timed, the timed region with its barriers, the one-GPU rate of the same grid, the single JSON line -- with the
+    ranks sharing GPU 0 over the host-channel group.  Its numbers are not scaling results (the line says so); what is asserted is
+    that every step of that path runs and that the bitwise check passed on the peer transport at tier 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--rehearse-on-one-gpu", "--size", "512", "--substeps", "24",
+           "--steps", "2", "--warmup", "1", "--no-full-step"] + (["--partition", partition] if partition else [])
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == n and d["rehearsal_on_one_gpu"] is True and d["rccl_ranks"] == n
+    assert d["tiled_equals_untiled_bitwise"] is True
+    assert d["path"]["halo_transport"] == "peer" and d["path"]["peer_tier"] == 0, d["path"]
+    assert d["path"]["peer_tier_ladder"] == [{"tier": 0, "passed": True, "problem": None}]
+    assert d["config"]["partition"] == ([int(t) for t in partition.split("x")] if partition else [1, n])
+    assert d["single_gpu"]["value"] > 0 and d["parallel_efficiency"] > 0 and d["value"] > 0
