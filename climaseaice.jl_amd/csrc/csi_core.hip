@@ -364,6 +364,7 @@ bool pair_supported(const csi_context* c) {
     if (c->metric_kind == CSI_METRIC_PER_J && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;   // (BetaPlane rows wrap: csi.h)
     return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
 }
+constexpr long kWriteThroughCells = 1152L * 1024L;      // (scripts/wt_sweep.py, profiles/r04_wt_sweep.txt: 512^2 +4 %, 1024 x 512 +3.4 %, 2048 x 256 +3.7 %, 2048 x 512 +1.8 %, 1024^2 +0.6 %; 1536^2 -1 %, 2048^2 -9 %)
 FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     FusedGeom G;
     G.rs = dec;
@@ -401,6 +402,8 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     if (rows < 1) rows = 1;
     G.rows = rows;
     G.nchunks = (height + rows - 1) / rows;
+    // write-through result stores on small grids (evp_fused2.hip, FI_WT): measured round 4 (profiles/r04_tile_1024x512.md)
+    G.wt = c->tune.write_through >= 0 ? (c->tune.write_through != 0) : ((long)width * height <= kWriteThroughCells);
     // Peer transport: the chunk next to a connected y side waits for its neighbour's flags, stores the halo images (write-through,
     // into the neighbour's memory) and publishes -- about four row iterations' worth -- and a launch is as long as its slowest
     // tile: that chunk gets four rows less (not fewer than the halo: the next chunk must stay out of the side's tile set).

@@ -186,7 +186,7 @@ struct csi_context {
     int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
     int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
-    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1; } tune;
+    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1; } tune;
 };
 
 namespace csi_host {
@@ -212,7 +212,7 @@ struct FoldBand;
 static const int kPing[5] = {CSI_F_U, CSI_F_V, CSI_F_S11, CSI_F_S22, CSI_F_S12};
 // (elo / ehi: rows of the FIRST / LAST chunk where they differ from `rows` -- shorter tiles next to a peer-connected y side,
 //  pair_geom; elo == rows and ehi == 0: every chunk `rows` rows, the last one what is left)
-struct FusedGeom { Range rs; int nstrips, nchunks, rows; int elo = 0, ehi = 0; };
+struct FusedGeom { Range rs; int nstrips, nchunks, rows; int elo = 0, ehi = 0; int wt = 0; };      // wt: write-through result stores (FI_WT)
 // rows [ja, jb] of chunk q (the kernels' formula: evp_fused2.hip)
 static inline void chunk_rows(const FusedGeom& G, int q, int* ja, int* jb) {
     const int elo = G.elo > 0 ? G.elo : G.rows;

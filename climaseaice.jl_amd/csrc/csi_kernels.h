@@ -64,6 +64,7 @@ enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_
              FI_PHASDLD = FI_PDLD + 16, // any of them non-zero (a Bounded x direction partitioned in x: the easternmost tile's Face fields are one column wider)
              FI_NYLO,                   // PEER: Ny of the neighbour beyond the LOW y side (rows of the image shift of this tile's low rows; a fold tile's own Ny is cut)
              FI_ELO, FI_EHI,            // rows of the first chunk / rows kept for the last chunk (0: `rows` / what is left): shorter tiles next to peer-connected y sides
+             FI_WT,                     // 1: the pair kernel stores its results write-through (small grids: the launch does not end on a write-back of its dirty lines)
              FI_PTIER,                  // peer protocol tier (csi_set_peer_tier): 0 write-through images + drained stores + flags; 1: + a system-scope acquire
                                         // fence once the flags have been seen; 2: + a system-scope release fence before the flags are published
              FI_COUNT };
@@ -87,7 +88,7 @@ void launch_fused_substep(const FusedTable* dev_table, bool uniform, bool ufirst
 // sub-step's store ranges (rs, r1, r2; r1c unused) plus: dec = the second sub-step's compute (stress) range that
 // the wave tiles decompose, a_j0 / a_j1 = the first sub-step's stress rows, sigma image specs.
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
-                           const ImageSpec& ims12, FusedTable* host_table, int elo = 0, int ehi = 0);
+                           const ImageSpec& ims12, FusedTable* host_table, int elo = 0, int ehi = 0, int write_through = 0);
 // seq: launch number of the peer-flag protocol (0 on grids without peer-connected sides)
 // extra: model.forcing arrays / immersed flux boundary conditions (the EXTRA instantiations; implies force)
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, int extra,

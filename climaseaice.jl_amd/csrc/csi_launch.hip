@@ -134,7 +134,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         if (band) { rs.j1 = std::min(rs.j1, c->Ny); r1.j1 = std::min(r1.j1, c->Ny); r2.j1 = std::min(r2.j1, c->Ny); }
                         FusedTable* t = &host[(m * 2 + cur) * 2 + uf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
-                        fused_fill_pair_extra(dec, dec.j0, dec.j1, ims11, ims22, ims12, t, G[m].elo, G[m].ehi);
+                        fused_fill_pair_extra(dec, dec.j0, dec.j1, ims11, ims22, ims12, t, G[m].elo, G[m].ehi, G[m].wt);
                         if (force) { fused_fill_forcing(P, ubar_v, vbar_u, t); if (wind) fused_fill_forcing_top(P, tbar_v, tbar_u, t); }
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, G[m], cur == 0, t))) return rc;
@@ -165,7 +165,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         }
                         FusedTable* t = &host[NSINGLE + (mp * 2 + cur) * 2 + auf];
                         fused_fill_table(P, fc, cur == 0 ? orig : alt, cur == 0 ? alt : orig, rs, r1, r1, r2, imu, imv, t);
-                        fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t, GP[mp].elo, GP[mp].ehi);
+                        fused_fill_pair_extra(dec, ra.j0, ra.j1, ims11, ims22, ims12, t, GP[mp].elo, GP[mp].ehi, GP[mp].wt);
                         if (force) { fused_fill_forcing(P, ubar_v, vbar_u, t); if (wind) fused_fill_forcing_top(P, tbar_v, tbar_u, t); }
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, GP[mp], cur == 0, t))) return rc;

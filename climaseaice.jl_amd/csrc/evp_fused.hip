@@ -432,9 +432,9 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
 }
 
 void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec& ims11, const ImageSpec& ims22,
-                           const ImageSpec& ims12, FusedTable* t, int elo, int ehi) {
+                           const ImageSpec& ims12, FusedTable* t, int elo, int ehi, int write_through) {
     int* I = t->I;
-    I[FI_ELO] = elo; I[FI_EHI] = ehi;
+    I[FI_ELO] = elo; I[FI_EHI] = ehi; I[FI_WT] = write_through;
     I[FI_DEC] = dec.i0; I[FI_DEC + 1] = dec.i1; I[FI_DEC + 2] = dec.j0; I[FI_DEC + 3] = dec.j1;
     I[FI_AJ0] = a_j0; I[FI_AJ1] = a_j1;
     const ImageSpec* im[3] = {&ims11, &ims22, &ims12};

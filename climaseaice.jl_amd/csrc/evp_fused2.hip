@@ -384,14 +384,21 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     // PEER: the lanes of a wave that store x images all lie on one side of the tile (csi_abi.hip admits tiles of 128 columns or
     // more), so the neighbour -- the base address -- is wave-uniform
     const bool wave_low = PEER && __builtin_amdgcn_ballot_w64(((flags & L_LOW) != 0) & ((dx != 0) | (dxv != 0))) != 0;
+    // a result into this tile's own arrays: write-through on small grids (FI_WT; csi_core.hip pair_geom) -- at the end of a launch
+    // the XCDs' L2s write their dirty lines back before the next launch may start (+ bytes / 6 TB/s at the boundary,
+    // MI355X_MICROARCH.md): on a 1024 x 512 tile that is 4 - 5 % of the launch; at 2048^2 the 8-byte write-through stores cost 11 %
+    const bool wt = T->I[FI_WT] != 0;
+    auto sto = [&](unsigned long b_, unsigned o_, double v_) __attribute__((always_inline)) {
+        if (wt) stg_agent(b_, o_, v_); else stg(b_, o_, v_);
+    };
     auto put4 = [&](int k, unsigned off, unsigned dy, bool ylow, int dxl, double val, double valy, double valx, double valxy, int j, int yr) __attribute__((always_inline)) {
         const unsigned long base = own(k);
         auto sti = [&](unsigned long b_, unsigned o_, double v_) __attribute__((always_inline)) {
             if constexpr (PEER && (CSI_PEER_EXP & 2) != 0)
                 __scoped_atomic_store_n((__attribute__((address_space(1))) long*)((gptr_t)b_ + o_), __builtin_bit_cast(long, v_), __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
-            else stg(b_, o_, v_);
+            else sto(b_, o_, v_);
         };
-        stg(base, off, val);
+        sto(base, off, val);
         if constexpr (PEER) {
             // neighbours whose arrays have another row stride (FI_PDLD): the image of parent row p sits p * (their stride - ours)
             // bytes further on (j: the row of `off`, wave-uniform -- scalar arithmetic, in a branch of its own)
@@ -466,9 +473,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 const unsigned ocq = offc(q), ofq = offf(q);
                 if (fast_plain) {
                     // interior tile: the owned lanes store five values, no images
-                    if (which & 1) { stg(T->P[FP_S11_OUT], ocq, v11); stg(T->P[FP_S22_OUT], ocq, v22); stg(T->P[FP_S12_OUT], ofq, v12); }
-                    if (which & 2) stg(T->P[VF ? FP_V_OUTP : FP_U_OUTP], VF ? ocq : ofq - sf, vfirst);
-                    if (which & 4) stg(T->P[VF ? FP_U_OUTP : FP_V_OUTP], VF ? ofq - sf : ocq - sc, vsecond);
+                    if (which & 1) { sto(T->P[FP_S11_OUT], ocq, v11); sto(T->P[FP_S22_OUT], ocq, v22); sto(T->P[FP_S12_OUT], ofq, v12); }
+                    if (which & 2) sto(T->P[VF ? FP_V_OUTP : FP_U_OUTP], VF ? ocq : ofq - sf, vfirst);
+                    if (which & 4) sto(T->P[VF ? FP_U_OUTP : FP_V_OUTP], VF ? ofq - sf : ocq - sc, vsecond);
                 } else {
                     // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap / the
                     // neighbouring tile's halo; v mirrors / reflects across an x wall), none of the row bookkeeping of the general path

@@ -69,6 +69,10 @@ __device__ __forceinline__ double ldg(unsigned long base, unsigned off) {
     return ldg_keep(base, off);
 #endif
 }
+// write-through at agent scope (sc1): the line leaves the XCD's L2 when the store completes, not at the end of the launch
+__device__ __forceinline__ void stg_agent(unsigned long base, unsigned off, double v) {
+    __scoped_atomic_store_n((__attribute__((address_space(1))) long*)((gptr_t)base + off), __builtin_bit_cast(long, v), __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+}
 __device__ __forceinline__ unsigned ldub(unsigned long base, unsigned off) {
     return *(const __attribute__((address_space(1))) unsigned char*)((gptr_t)base + off);
 }
