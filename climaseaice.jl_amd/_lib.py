@@ -31,7 +31,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_compute_tracer_tendencies", "csi_dynamic_step_tracers", "csi_cache_current_fields",
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_local_group_create", "csi_local_group_destroy", "csi_comm_init_local", "csi_comm_init_host", "csi_halo_exchange",
-           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_set_peer_tier", "csi_peer_tier", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
+           "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_set_peer_tier", "csi_peer_tier", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_plan_peer_chunks", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
            "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
 
 
@@ -121,6 +121,7 @@ def load():
         "csi_halo_exchange": [vp, C.POINTER(i32), i32, i32],
         "csi_plan_ranges": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
         "csi_plan_pair": [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32)],
+        "csi_plan_peer_chunks": [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), i32],
         "csi_set_exchange_interval": [vp, i32],
         "csi_set_halo_transport": [vp, i32], "csi_halo_transport": [vp, C.POINTER(i32)],
         "csi_set_peer_tier": [vp, i32], "csi_peer_tier": [vp, C.POINTER(i32)],
@@ -167,6 +168,20 @@ def plan_pair(Nx, Ny, Hx, Hy, topo_x, topo_y, k=1, m=0):
     r = lambda q: tuple(out[4 + 4 * q: 8 + 4 * q])
     return dict(nstrips=out[1], nchunks=out[2], rows=out[3], first_compute=r(0), second_compute=r(1), store_sigma=r(2),
                 store_first_u=r(3), store_first_v=r(4), store_second=r(5), walls=bool(out[28]))
+
+
+def plan_peer_chunks(Nx, Ny, Hx, Hy, peer_south=True, peer_north=True):
+    """csi_plan_peer_chunks as a dict: the chunk layout of a pair launch on the peer transport (None: the pair kernel does not apply)."""
+    out = (C.c_int32 * 8)()
+    rows = (C.c_int32 * 4096)()
+    rc = load().csi_plan_peer_chunks(Nx, Ny, Hx, Hy, int(peer_south), int(peer_north), 256, out, rows, 2048)
+    if rc != OK:
+        raise CsiError(rc, "csi_plan_peer_chunks")
+    if not out[0]:
+        return None
+    n = out[2]
+    return dict(nstrips=out[1], nchunks=n, rows=out[3], elo=out[4], ehi=out[5], nS=out[6], nN=out[7],
+                chunks=[(rows[2 * q], rows[2 * q + 1]) for q in range(min(n, 2048))])
 
 
 def plan_exchange(Nx, Ny, Hx, Hy, topo_x, topo_y, rx, ry, Rx, Ry, periodic_x, periodic_y, width, halo):

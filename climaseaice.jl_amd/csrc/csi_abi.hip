@@ -782,6 +782,29 @@ int32_t csi_plan_pair(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t to
     return CSI_OK;
 }
 
+int32_t csi_plan_peer_chunks(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t peer_south, int32_t peer_north, int32_t cus,
+                             int32_t* out8, int32_t* rows_out, int32_t max_chunks) {
+    if (!out8 || !rows_out || Nx < 1 || Ny < 1 || max_chunks < 1) return CSI_ERR_INVALID_ARGUMENT;
+    csi_context tmp;
+    tmp.Nx = Nx; tmp.Ny = Ny; tmp.Hx = Hx; tmp.Hy = Hy;
+    // the launch loop of the peer transport sees connected sides as periodic ones (PeerView)
+    tmp.g.xlo = tmp.g.xhi = tmp.g.ylo = tmp.g.yhi = SIDE_PERIODIC;
+    tmp.coef.uniform = 1; tmp.metric_kind = CSI_METRIC_UNIFORM;
+    tmp.geom_peer = 1;
+    for (int d = 0; d < 8; ++d) tmp.peer.sync_rank[d] = -1;
+    if (peer_south) tmp.peer.sync_rank[2] = 0;
+    if (peer_north) tmp.peer.sync_rank[3] = 0;
+    (void)cus;
+    memset(out8, 0, 8 * sizeof(int32_t));
+    if (!pair_supported(&tmp)) return CSI_OK;
+    const Range dec = v_stress_range(&tmp, pair_side_v(&tmp, 2, 2));
+    const FusedGeom G = pair_geom(&tmp, dec);
+    const PeerSets ps = peer_wait_counts(&tmp, G);
+    out8[0] = 1; out8[1] = G.nstrips; out8[2] = G.nchunks; out8[3] = G.rows; out8[4] = G.elo; out8[5] = G.ehi; out8[6] = ps.nS; out8[7] = ps.nN;
+    for (int q = 0; q < G.nchunks && q < max_chunks; ++q) { int ja, jb; chunk_rows(G, q, &ja, &jb); rows_out[2 * q] = ja; rows_out[2 * q + 1] = jb; }
+    return CSI_OK;
+}
+
 int32_t csi_profile_substeps(csi_context* c, double dt, int32_t substeps, double* out_ms4) {
     if (!c || !out_ms4) return CSI_ERR_INVALID_ARGUMENT;
     int32_t rc = need_evp(c);

@@ -409,11 +409,14 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     // tile: that chunk gets four rows less (not fewer than the halo: the next chunk must stay out of the side's tile set).
     // Measured on a 2048 x 256 tile connected to itself in y (round 4): profiles/r04_tile_1024x512.md.
     if (c->geom_peer && !forced && c->tune.pair_rows < 0 && c->tune.peer_edge != 0) {
-        const int e = std::max(std::max(c->Hy, 4), rows - (c->tune.peer_edge > 0 ? c->tune.peer_edge : 4));
-        const bool lo = c->peer.sync_rank[2] >= 0, hi = c->peer.sync_rank[3] >= 0;
-        if (e < rows && height >= 4 * rows && (lo || hi)) {
-            G.elo = lo ? e : rows;
-            G.ehi = hi ? e : 0;
+        // (the NEXT chunk must stay out of the side's tile set: it may neither read halo rows nor own rows whose images go to the
+        //  neighbour -- rows 1 .. max(Hy, 4) / the last max(Hy, 4) rows; dec starts at row 0 / ends at row Ny + 1)
+        const int reach = std::max(c->Hy, 4), want = rows - (c->tune.peer_edge > 0 ? c->tune.peer_edge : 4);
+        const int e_lo = std::max(reach + 1 - dec.j0, want), e_hi = std::max(reach + (dec.j1 - c->Ny), want);
+        const bool lo = c->peer.sync_rank[2] >= 0 && e_lo < rows, hi = c->peer.sync_rank[3] >= 0 && e_hi < rows;
+        if (height >= 4 * rows && (lo || hi)) {
+            G.elo = lo ? e_lo : rows;
+            G.ehi = hi ? e_hi : 0;
             const int mid = height - G.elo - G.ehi;
             G.nchunks = 1 + (mid + rows - 1) / rows + (hi ? 1 : 0);
             if (!hi) {

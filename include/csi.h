@@ -458,6 +458,13 @@ int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
  * connected sides store the ring the next pair needs.  Pure host function. */
 int32_t csi_plan_pair(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y, int32_t k, int32_t m,
                       int32_t* out32);
+/* How a pair launch of the PEER transport cuts a tile of this shape into chunks of rows (pure host function; periodic f-plane tile,
+ * sides as the launch loop sees them): out8 = {applies, strips, chunks, rows per chunk, rows of the first chunk (0: as the others),
+ * rows kept for the last chunk (0: what is left), chunks in the south side's tile set, in the north side's}; rows_out[2q], [2q + 1]
+ * = first / last row of chunk q (at most max_chunks of them).  peer_south / peer_north: a neighbour beyond that y side -- its chunk
+ * is four rows shorter, never shorter than the halo. */
+int32_t csi_plan_peer_chunks(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t peer_south, int32_t peer_north, int32_t cus,
+                             int32_t* out8, int32_t* rows_out, int32_t max_chunks);
 
 /* Per-phase device time: runs `substeps` (2..64) further EVP sub-steps from the current state with HIP
  * events between the launches on the context's stream and returns the average milliseconds of

@@ -74,6 +74,41 @@ def test_pair_plan_geometry_and_ranges():
     assert _lib.plan_pair(256, 256, 8, 8, FC, FC, 3, 0) is None
 
 
+def test_peer_launch_chunks_tile_the_rows_and_keep_edge_tiles_short():
+    """csi_plan_peer_chunks (pure host logic, csrc/csi_core.hip pair_geom + csi_peer.hip peer_wait_counts; the kernel applies the same
+    formula, evp_fused2.hip): the chunks of a pair launch on the peer transport cover the decomposed rows exactly once, in order; the
+    chunk next to a peer-connected y side is shorter than the others but not shorter than the halo, so that exactly ONE chunk per
+    side waits for / signals the neighbour (the side's tile set), and the launch stays within one round of 1024 two-wave tiles on
+    small grids (the third wave per SIMD beyond that makes its tiles 1.5x slower: profiles/r04_tile_1024x512.md)."""
+    from climaseaice_jl_amd import _lib
+    for (Nx, Ny, H) in [(2048, 256, 4), (2048, 512, 4), (1024, 512, 4), (2048, 1024, 4), (2048, 2048, 4), (512, 512, 4), (1024, 1024, 6),
+                        (300, 200, 4), (2048, 256, 8), (4096, 512, 4), (130, 96, 6), (128, 48, 6), (2048, 260, 5)]:
+        for south, north in ((True, True), (True, False), (False, True), (False, False)):
+            p = _lib.plan_peer_chunks(Nx, Ny, H, H, south, north)
+            assert p is not None, (Nx, Ny, H)
+            ch = p["chunks"]
+            assert len(ch) == p["nchunks"]
+            assert ch[0][0] == 0 and ch[-1][1] == Ny + 1                      # the second sub-step's stress rows 2 - V .. N + V - 1, V = 2
+            for (a0, b0), (a1, b1) in zip(ch, ch[1:]):
+                assert a1 == b0 + 1 and b0 >= a0, (Nx, Ny, H, south, north, ch)
+            assert all(b - a + 1 <= p["rows"] for a, b in ch)
+            reach = max(H, 4)
+            short = p["elo"] not in (0, p["rows"]) or p["ehi"] != 0
+            if short:
+                if south:
+                    assert p["elo"] >= reach and p["elo"] < p["rows"] and ch[0][1] - ch[0][0] + 1 == p["elo"]
+                    assert ch[1][0] > reach and p["nS"] == 1               # the second chunk reads no halo row and owns no imaged row
+                if north:
+                    assert p["ehi"] >= reach and ch[-1][1] - ch[-1][0] + 1 == p["ehi"]
+                    assert ch[-2][1] + reach <= Ny and p["nN"] == 1
+            if Nx * Ny <= 2048 * 512:
+                assert p["nstrips"] * p["nchunks"] <= 1024 or p["rows"] == 6, (Nx, Ny, p["nstrips"], p["nchunks"])
+    # tall enough tiles get the short edge chunks (the metric's slabs: 2048 x 256 at N = 8, 2048 x 512 at N = 4)
+    for Ny in (256, 512):
+        p = _lib.plan_peer_chunks(2048, Ny, 4, 4, True, True)
+        assert p["elo"] == p["rows"] - 4 == p["ehi"], p
+
+
 def test_fused_paths_refuse_parents_beyond_32bit_offsets():
     """The fused kernels address fields with 32-bit byte offsets: a parent array of 4 GiB or more (about 23k x 23k cells)
     must fall back to the three-kernel path (64-bit indexing) instead of wrapping (csi_abi.hip: offsets_fit_32bit)."""
