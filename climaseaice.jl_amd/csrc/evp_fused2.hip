@@ -91,6 +91,17 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 #ifndef CSI_PAIR_PRE
 #define CSI_PAIR_PRE 1
 #endif
+// FULL (per-point metric planes): nine of the twelve plane values of a stage-row travel through the ring as well (fields 10 .. 18:
+// what the producer's step consumed for row r is what the consumer's step needs for the same row two iterations later), the
+// consumer loads the other three itself (1 / Az at the cell and at the velocity points).  Loaded by both waves -- rounds 3 / 4 --
+// the consumer, the longer wave of the pair, issued twelve to fourteen vector loads per row, every one of them a miss in the XCD's
+// L2 (128 tiles x 27 streams x 512 B per row iteration push a row out before the consumer reaches it: FETCH_SIZE 635 -> 416 MB
+// per launch with those loads redirected to resident rows), and the producer waited at the row barrier for half of every
+// iteration (in-kernel probe: 4235 of 8061 cycles).  Without the consumer's plane loads: 35.6 -> 41.8 G (timing experiment).
+// 19 fields x 4 rows x 512 B = 38 KB per workgroup: four workgroups per CU still fit (no PRE fields here: the consumer forms
+// the corner ice strength and the reciprocal masses itself).
+constexpr int RF_PLANES = 9;
+enum : int { RF_PL_DXV = 10, RF_PL_RDYV, RF_PL_RDXU, RF_PL_DXF2, RF_PL_DYF2, RF_PL_RAZF, RF_PL_DYU, RF_PL_DYC2, RF_PL_DXC2 };
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
@@ -102,8 +113,8 @@ template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF
 __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
                                        double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p) {
-    constexpr bool PRE = CSI_PAIR_PRE && !MASK;
-    constexpr int RING_FIELDS = PRE ? 13 : 10;
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL;
+    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (PRE ? 13 : 10);
 #define peer_abort (*peer_abort_p)
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
@@ -553,7 +564,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         // the ring starts clean: the consumer's first iterations read rows the producer never wrote (their results only
         // fill B's window and are never used -- but they must not be NaN patterns left in LDS by an earlier workgroup)
 #pragma unroll
-        for (int q = 0; q < RING_ROWS * RING_FIELDS; ++q) ring[q * 64 + lane] = 0.0;
+        for (int q = 0; q < RING_ROWS * RING_FIELDS; ++q) ring[q * 64 + lane] = (FULL && (q % RING_FIELDS) >= 10) ? 1.0 : 0.0;     // (plane values: finite reciprocals)
         // MASK: two bits per row (bit 0 inactive, bit 1 beyond a wall), newest row in bits 1:0; row rstart-1 from memory,
         // older rows count as beyond the domain (their results are never used)
         unsigned mhist = 0xffffffffu;
@@ -650,6 +661,12 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 ring[s0 + RF_P * 64] = C.P_0; ring[s0 + RF_M * 64] = m_0; ring[s0 + RF_A * 64] = C.a_0;
                 if (PRE) { ring[s0 + RF_PF * 64] = A.Pf_0; ring[s0 + RF_RMC * 64] = A.rmc_0; ring[s0 + RF_RMF * 64] = A.rmf_0; }
                 ring[s1 + RF_UN * 64] = C.un_m; ring[(AUF ? s1 : s0) + RF_VN * 64] = C.vn_x;
+                }
+                if constexpr (FULL) {
+                    // the plane values this step consumed (v-point and corner planes of row r + 1, u-point and cell planes of row r)
+                    ring[s0 + RF_PL_DXV * 64] = A.DXV_p; ring[s0 + RF_PL_RDYV * 64] = A.RDYV_p; ring[s0 + RF_PL_RDXU * 64] = A.RDXU_p;
+                    ring[s0 + RF_PL_DXF2 * 64] = A.DXF2_p; ring[s0 + RF_PL_DYF2 * 64] = A.DYF2_p; ring[s0 + RF_PL_RAZF * 64] = A.RAZF_p;
+                    ring[s0 + RF_PL_DYU * 64] = A.DYU_0; ring[s0 + RF_PL_DYC2 * 64] = A.DYC2_0; ring[s0 + RF_PL_DXC2 * 64] = A.DXC2_0;
                 }
                 if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] = mhist & 3u;
             }
@@ -780,6 +797,12 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         const double s11 = ring[s2 + RF_S11 * 64], s22 = ring[s2 + RF_S22 * 64], s12 = ring[s2 + RF_S12 * 64];
         const double bP_0 = ring[s2 + RF_P * 64], bm_0 = ring[s2 + RF_M * 64], ba_0 = ring[s2 + RF_A * 64];
         if (PRE) { B.Pf_0 = ring[s2 + RF_PF * 64]; B.rmc_0 = ring[s2 + RF_RMC * 64]; B.rmf_0 = ring[s2 + RF_RMF * 64]; }
+        if constexpr (FULL) {
+            // rows the producer never ran (the consumer's first two iterations of a tile only fill its window): the ring's initial 1.0
+            B.N_DXV = ring[s2 + RF_PL_DXV * 64]; B.N_RDYV = ring[s2 + RF_PL_RDYV * 64]; B.N_RDXU = ring[s2 + RF_PL_RDXU * 64];
+            B.N_DXF2 = ring[s2 + RF_PL_DXF2 * 64]; B.N_DYF2 = ring[s2 + RF_PL_DYF2 * 64]; B.N_RAZF = ring[s2 + RF_PL_RAZF * 64];
+            B.N_DYU = ring[s2 + RF_PL_DYU * 64]; B.N_DYC2 = ring[s2 + RF_PL_DYC2 * 64]; B.N_DXC2 = ring[s2 + RF_PL_DXC2 * 64];
+        }
         const double bun = ring[s3 + RF_UN * 64], vn_new = ring[s2 + RF_VN * 64];
         const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
         vn_delay = vn_new;
@@ -818,7 +841,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         if constexpr (FULL) {
             // (rows below the planes only fill the window: clamped)
-            B.template step<PRE, typename decltype(B)::NoMid, true>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
+            B.template step<PRE, typename decltype(B)::NoMid, true, true>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
                    off2(max(q, row0)), c2s, off2(max(q + 1, row0)), off2(max(q - 1, row0)), typename decltype(B)::NoMid(), off2(max(q, row0)));
             fq = q; f11 = B.S11_0; f22 = B.S22_0; f12 = B.S12_0; ffirst = B.first; fsecond = B.second; fhave = true;
         } else {
@@ -866,8 +889,8 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
 __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
-    constexpr bool PRE = CSI_PAIR_PRE && !MASK;
-    constexpr int RING_FIELDS = PRE ? 13 : 10;
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL;
+    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (PRE ? 13 : 10);
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[MASK ? RING_ROWS * 64 : 1];
     __shared__ double outr[(CSI_PAIR_STORES & 7) != 7 ? 2 * 5 * 64 : 1];      // stage B's results on their way to the producer's stores

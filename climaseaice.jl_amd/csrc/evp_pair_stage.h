@@ -125,7 +125,9 @@ struct Stage {
     // not across the stress phase, where the register pressure peaks)
     // ALLPRE (FULL): 1 / Az at the velocity points and the per-point Coriolis planes were prefetched by the previous step as well
     // (full_prefetch_vel; o2nm: the row below the next step's row) -- the consumer wave, which has the registers for it
-    template <bool PRE = false, class MID = NoMid, bool ALLPRE = false>
+    // PLR (FULL): the nine plane values of full_prefetch but 1 / Az at the cell come from the pair kernel's ring (the caller has set
+    // N_DXV .. N_DXC2 for THIS step); the step prefetches 1 / Az at the next row's cells only
+    template <bool PRE = false, class MID = NoMid, bool ALLPRE = false, bool PLR = false>
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks_in, const fm::VelConst& kv_in, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
                                          double s11, double s22, double s12, double un_m, double vn_x,
@@ -240,7 +242,8 @@ struct Stage {
         if constexpr (FULL) {
             // the next step's plane values: issued here, behind the stress phase, consumed after the velocity phase and the row barrier
             __builtin_amdgcn_sched_barrier(0);
-            full_prefetch(T, o2n, s2);
+            if constexpr (PLR) N_RAZC = c2at(T, C2_RAZC, o2n);
+            else full_prefetch(T, o2n, s2);
             if constexpr (ALLPRE) full_prefetch_vel(T, o2n, o2nm);
             mid();
             __builtin_amdgcn_sched_barrier(0);
