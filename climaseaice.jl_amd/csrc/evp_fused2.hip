@@ -62,13 +62,14 @@ namespace csi {
 namespace fused {
 
 #ifdef CSI_PAIR_PROBE
-__device__ unsigned long long g_probe[8192 * 16];
+static __device__ unsigned long long g_probe[8192 * 16];
 #define PROBE_DECL unsigned long long pacc0 = 0, pacc1 = 0, pacc2 = 0, ptprev = 0, pit = 0; const unsigned long long pwall0 = wall_clock64()
 #define PROBE_START do { __builtin_amdgcn_sched_barrier(0); ptprev = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); ++pit; } while (0)
 #define PROBE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
                         __builtin_amdgcn_sched_barrier(0); acc += t_ - ptprev; ptprev = t_; } while (0)
-#define PROBE_END(slot) do { if (lane == 0 && (slot) < 8192) { unsigned long long* dbg = g_probe + (size_t)(slot) * 16; \
+#define PROBE_END(slot) do { if (lane == 0 && (slot) < 8192 && !write_diag) { unsigned long long* dbg = g_probe + (size_t)(slot) * 16; \
                         dbg[0] = pacc0; dbg[1] = pacc1; dbg[2] = pacc2; dbg[6] = pit; dbg[8] = pwall0; dbg[9] = wall_clock64(); \
+                        dbg[12] = PSTAGE.sp0; dbg[13] = PSTAGE.sp1; dbg[14] = PSTAGE.sp2; dbg[15] = PSTAGE.sp3; \
                         dbg[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); dbg[11] = (unsigned long long)blockIdx.x; } } while (0)
 #else
 #define PROBE_DECL do { } while (0)
@@ -695,7 +696,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             if (d == 0) __syncthreads();
             ++r;
         }
+#define PSTAGE A
         PROBE_END(w * 2);
+#undef PSTAGE
         return;
     }
 
@@ -882,7 +885,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     }
     __syncthreads();                                      // the last row's results are in the out ring: the producer drains them
     publish();
+#define PSTAGE B
     PROBE_END(w * 2 + 1);
+#undef PSTAGE
 #undef peer_abort
 }
 
@@ -918,6 +923,13 @@ __global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAV
 
 #if defined(CSI_PAIR_PROBE) && (!defined(CSI_PAIR_VARIANT) || CSI_PAIR_VARIANT == 0)
 extern "C" int csi_debug_probe(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_probe), sizeof(unsigned long long) * 8192 * 16);
+}
+#endif
+#if defined(CSI_PAIR_PROBE) && defined(CSI_PAIR_VARIANT) && CSI_PAIR_VARIANT >= 1
+#define CSI_PROBE_NAME_(v) csi_debug_probe_v##v
+#define CSI_PROBE_NAME(v) CSI_PROBE_NAME_(v)
+extern "C" int CSI_PROBE_NAME(CSI_PAIR_VARIANT)(unsigned long long* dst) {      // (the probe buffer of this variant's translation unit)
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fused::g_probe), sizeof(unsigned long long) * 8192 * 16);
 }
 #endif

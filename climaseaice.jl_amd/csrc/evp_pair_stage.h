@@ -107,6 +107,15 @@ struct Stage {
         DYU_m = c2at(T, C2_DYU, o); RDYU_m = fm::rcp(DYU_m); DYC2_m = c2at(T, C2_DYC2, o); DXC2_m = c2at(T, C2_DXC2, o); DXC2_mm = DXC2_m;
     }
     double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
+#ifdef CSI_PAIR_PROBE
+    unsigned long long sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, spt = 0;      // cycles in: strain rates | stress phase | prefetch issue | velocity phase
+#define SPROBE_START do { __builtin_amdgcn_sched_barrier(0); spt = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SPROBE(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                         __builtin_amdgcn_sched_barrier(0); acc += t_ - spt; spt = t_; } while (0)
+#else
+#define SPROBE_START do { } while (0)
+#define SPROBE(acc) do { } while (0)
+#endif
     // results of the last step()
     double S11_0, S22_0, S12_0, AL_0, zc, zf, Dc, rDc, first, second;
     // pending window updates
@@ -133,6 +142,7 @@ struct Stage {
                                          double s11, double s22, double s12, double un_m, double vn_x,
                                          bool do_stress, bool do_vel, bool per_first, bool per_second, unsigned mh,
                                          const Forcing& F, unsigned o2 = 0u, unsigned s2 = 0u, unsigned o2n = 0u, unsigned o2m = 0u, MID mid = MID(), unsigned o2nm = 0u) {
+        SPROBE_START;
         Xa_0 = fm::sum2(from_left(a_0), a_0);               // SUMS too (Xa, Xm, XAL): fm::vel_update_sum
         Xv_p = fm::sum2(from_left(v_p), v_p);               // x-SUMS (Xv, Xe11, Xe22, Ye12, XP, XW): scaled once, in quarter()
         double e11_0, e22_0;
@@ -177,6 +187,7 @@ struct Stage {
             }
             const double Pf = Pf_0;
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p;
+            SPROBE(sp0);
             if (do_stress) {
                 fm::StressConst ks = ks_in;
                 if (CF) ks.pressure_kind = 0;          // ReplacementPressure is part of the common configuration
@@ -239,6 +250,7 @@ struct Stage {
             if (kind == 1) { typedef const __attribute__((address_space(4))) double* vptr_t; return ((vptr_t)T->P[which_row])[j]; }
             return T->K[FK_FCOR];
         };
+        SPROBE(sp1);
         if constexpr (FULL) {
             // the next step's plane values: issued here, behind the stress phase, consumed after the velocity phase and the row barrier
             __builtin_amdgcn_sched_barrier(0);
@@ -248,6 +260,7 @@ struct Stage {
             mid();
             __builtin_amdgcn_sched_barrier(0);
         }
+        SPROBE(sp2);
         fm::VelConst kv = kv_in;
         if (TIGHT) {
             asm volatile("" : "+s"(T));
@@ -342,6 +355,7 @@ struct Stage {
             first = W_0;
             XW_next = XW_0;
         }
+        SPROBE(sp3);
     }
 
     // slide the row window: row r becomes row r-1 (inputs of the step just done are passed again)
