@@ -8,18 +8,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import climaseaice_jl_amd as csi
 import cases
-KW = {"twelve": dict(topo=("periodic", "bounded"), curvilinear=0.05),
-      "channel": dict(topo=("periodic", "bounded"))}
+# case -> (make_case arguments, translation unit of its pair-kernel instantiation: CSI_PAIR_VARIANT)
+KW = {"twelve": (dict(topo=("periodic", "bounded"), curvilinear=0.05), 1),
+      "channel": (dict(topo=("periodic", "bounded")), 1),
+      "coupled": (dict(topo=("periodic", "periodic"), field_forcing=True), 3),
+      "omip": (dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True), 6),
+      "tripolar": (dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True), 6)}
 name = sys.argv[1] if len(sys.argv) > 1 else "twelve"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-c = cases.make_case(Nx=N, Ny=N, substeps=12, patches=False, noise=0.05, **KW[name])
+c = cases.make_case(Nx=N, Ny=N, substeps=12, patches=False, noise=0.05, **KW[name][0])
 m = cases.csi_model(c, mode="fast")
 m.set_fusion(2)
 csi.time_step_momentum(m, c["dt"])
 m.synchronize()
 L = C.CDLL(csi._lib.LIB_PATH)
 buf = np.zeros(8192 * 16, dtype=np.uint64)
-L.csi_debug_probe_walls(buf.ctypes.data_as(C.c_void_p))
+getattr(L, "csi_debug_probe_v%d" % KW[name][1])(buf.ctypes.data_as(C.c_void_p))
 p = buf.reshape(8192, 16)
 names = {0: ["wait for rows (vmcnt)", "loads issue + stage A + LDS writes", "barrier (wait for consumer)"],
          1: ["barrier (wait for producer)", "LDS reads (+ delayed stores)", "stage B + stores"]}
