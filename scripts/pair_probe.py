@@ -15,7 +15,7 @@ ny = int(sys.argv[2]) if len(sys.argv) > 2 else nx
 tg, f = bench.local_case(csi, np, nx, ny, 1, 1, 0, force_connected=False, halo=4)
 dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
                                  top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
-                                 solver=csi.SplitExplicitSolver(substeps=4), device="cuda:0")
+                                 solver=csi.SplitExplicitSolver(substeps=int(sys.argv[3]) if len(sys.argv) > 3 else 12), device="cuda:0")
 model = csi.SeaIceModel(tg, dynamics=dyn, advection=None, timestepper="ForwardEuler", device="cuda:0", mode="fast")
 csi.set_(model, h=f["h"], aice=f["a"], u=f["u"], v=f["v"])
 csi.time_step_momentum(model, 120.0)
