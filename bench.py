@@ -44,6 +44,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 ALGO_BYTES = {"stress": 96.0, "ustep": 80.0, "vstep": 80.0}   # SURVEY.md 8(d); 256 B per cell-update
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_ISSUE_NS = 2.29                                           # measured sustained issue interval of one FP64 vector instruction per SIMD (v_fma_f64 /
+                                                               # v_mul_f64, 2-4 waves per SIMD: scripts/microbench, profiles/r01_microbenchmarks.md `valu_rate`;
+                                                               # the 78.6 TFLOP/s data-sheet rate would be 1.67 ns)
 HBM_ACHIEVABLE_GBS = 6300.0                                    # ... and the measured copy ceiling (same guide)
 # Compulsory HBM bytes per cell PER LAUNCH of each kernel: what `roofline.frac` is priced on.
 #   k_pair / k_substep: read u, v, P, h, aice, sigma x 3, u^n, v^n + write sigma x 3, u, v = 15 x 8 B (k_pair does two
@@ -587,6 +590,13 @@ def main():
         roof["traffic_source"] = ctr.get("source", "profiles/counters_latest.json") + " (rocprofv3 --pmc passes; bytes per launch of this kernel, not re-measured by bench.py)"
         ref_us = (ctr.get("same_lease_bench") or {}).get("avg_launch_us") or ctr.get("avg_launch_us")
         same_speed = ref_us is not None and abs(launch_s * 1e6 - ref_us) <= 0.05 * ref_us
+        if ctr.get("valu_insts_per_launch"):
+            # third view: the kernel's vector instructions per launch (a property of the kernel, from the counters) at the FP64 issue
+            # interval this chip sustains, over THIS run's launch time.  A lower bound of the true share: the ~5 % of them that
+            # are v_rcp_f64 / v_rsq_f64 take 3 x as long (profiles/r04b_full_metric_kernel.md section 4)
+            roof["fp64_issue_frac"] = ctr["valu_insts_per_launch"] * FP64_ISSUE_NS * 1e-9 / 1024.0 / launch_s
+            roof["fp64_issue_note"] = (f"{ctr['valu_insts_per_launch'] / 1e6:.1f} M vector instructions per launch x {FP64_ISSUE_NS} ns (measured FP64 issue interval per SIMD, "
+                                       "profiles/r01_microbenchmarks.md) / 1024 SIMDs / this run's launch time")
         roof["counters_run_launch_us"] = ref_us
         roof["counters_run_matches_this_box"] = bool(same_speed)
         if same_speed:
