@@ -549,6 +549,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 const unsigned om2 = off2(jm), o02 = off2(rstart);
                 full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m);
                 A.e12_0 = full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0);
+                A.hoist_planes(T);
                 A.full_init(T, o02, om2, c2s);
             } else {
             fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
@@ -580,11 +581,29 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         // top of an iteration leaves exactly the younger rows in flight.  (Measured: one row ahead already hides the
         // memory latency -- 9 cycles of 2500 per iteration are spent in that wait.)
         RowIn R[3];
+#ifndef CSI_FULL_HOISTP
+#define CSI_FULL_HOISTP 1
+#endif
+        // FULL (no hoisting of the table by the compiler, see body): the ten input addresses read ONCE (CSI_FULL_HOISTP >= 2)
+#ifndef CSI_FORCE_HOIST
+#define CSI_FORCE_HOIST 0
+#endif
+        constexpr bool HIN = (FULL && CSI_FULL_HOISTP >= 2) || (FORCE && !FULL && (CSI_FORCE_HOIST & 1));
+        const unsigned long hU = HIN ? T->P[FP_U_IN] : 0ul, hV = HIN ? T->P[FP_V_IN] : 0ul, hP = HIN ? T->P[FP_P] : 0ul, hH = HIN ? T->P[FP_H] : 0ul,
+                            hA = HIN ? T->P[FP_A] : 0ul, h11 = HIN ? T->P[FP_S11_IN] : 0ul, h22 = HIN ? T->P[FP_S22_IN] : 0ul, h12 = HIN ? T->P[FP_S12_IN] : 0ul,
+                            hUN = HIN ? T->P[FP_UN] : 0ul, hVN = HIN ? T->P[FP_VN] : 0ul;
         auto load_row = [&](RowIn& Q) __attribute__((always_inline)) {
+            if constexpr (HIN) {
+                Q.u_p = ldg(hU, of + sf); Q.v_p = ldg(hV, oc + sc);
+                Q.P_0 = ldg(hP, oc); Q.h_0 = ldg(hH, oc); Q.a_0 = ldg(hA, oc);
+                Q.s11 = ldg(h11, oc); Q.s22 = ldg(h22, oc); Q.s12 = ldg(h12, of);
+                Q.un_m = ldg(hUN, of - sf); Q.vn_x = ldg(hVN, AUF ? oc - sc : oc);
+            } else {
             Q.u_p = ldg(T->P[FP_U_IN], of + sf); Q.v_p = ldg(T->P[FP_V_IN], oc + sc);
             Q.P_0 = ldg(T->P[FP_P], oc); Q.h_0 = ldg(T->P[FP_H], oc); Q.a_0 = ldg(T->P[FP_A], oc);
             Q.s11 = ldg(T->P[FP_S11_IN], oc); Q.s22 = ldg(T->P[FP_S22_IN], oc); Q.s12 = ldg(T->P[FP_S12_IN], of);
             Q.un_m = ldg(T->P[FP_UN], of - sf); Q.vn_x = ldg(T->P[FP_VN], AUF ? oc - sc : oc);
+            }
             Q.mk = MASK ? ldub(T->P[FP_MASK], om) : 1u;
         };
         // oc / of / om: offsets of the row the NEXT load_row fetches; advance by one row, stopping at rend (the last
@@ -771,6 +790,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0; B.Pf_0 = 0; B.rmc_0 = 0; B.rmf_0 = 0;
     if constexpr (FULL) {
+        B.hoist_planes(T);
         B.full_init(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)), c2s);
         B.full_prefetch_vel(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)));
     }

@@ -74,6 +74,22 @@ struct Stage {
     double DXV_0, RDXV_0, RDYV_0, RDXU_0, DXF2_0, DYF2_0, RAZF_0;
     double DXV_m, RDXV_m, RDYV_m, RDXU_m, DXF2_m, DYF2_m, DYU_m, RDYU_m, DYC2_m, DXC2_m, DXC2_mm;
     double DXV_p, RDXV_p, RDYV_p, RDXU_p, DXF2_p, DYF2_p, RAZF_p, DYU_0, RDYU_0, DYC2_0, DXC2_0;      // pending (shift)
+#ifndef CSI_FULL_HOISTP
+#define CSI_FULL_HOISTP 1
+#endif
+#if CSI_FULL_HOISTP >= 1
+    // FULL: the twelve plane base addresses, read from the table ONCE (the row loop's reload fence on the table pointer does not reach
+    // them): two wide scalar loads and their waits per stage-row less
+    unsigned long c2p[12];
+    __device__ __forceinline__ void hoist_planes(tptr_t T) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) c2p[k] = T->P[FP_C2_0 + k];
+    }
+    __device__ __forceinline__ double c2m(tptr_t, int which, unsigned off) const { return ldg_keep(c2p[which], off); }
+#else
+    __device__ __forceinline__ void hoist_planes(tptr_t) {}
+    __device__ __forceinline__ double c2m(tptr_t T, int which, unsigned off) const { return c2at(T, which, off); }
+#endif
     double RAZC_0, RAZU_m, RAZV_x, FU_m, FV_x;       // this step's 1 / Az at the cell (row r), the u point (row r - 1), the v point (row r - 1 / r); f likewise
 
     // FULL, round 4: the plane values a step needs are loaded DURING THE PREVIOUS step, between its stress phase and its velocity
@@ -88,23 +104,23 @@ struct Stage {
     // on: plane offset of the next step's row
     // the velocity phase's plane values of the next step too (om: plane offset of the row below the next step's row, clamped)
     __device__ __forceinline__ void full_prefetch_vel(tptr_t T, unsigned on, unsigned om) {
-        N_RAZU = c2at(T, C2_RAZU, om); N_RAZV = c2at(T, C2_RAZV, UFIRST ? om : on);
+        N_RAZU = c2m(T, C2_RAZU, om); N_RAZV = c2m(T, C2_RAZV, UFIRST ? om : on);
         N_FU = 0.0; N_FV = 0.0;
         if (T->I[FI_FKIND] == 2) { N_FU = ldg(T->P[FP_F2U], om); N_FV = ldg(T->P[FP_F2V], UFIRST ? om : on); }
     }
     __device__ __forceinline__ void full_prefetch(tptr_t T, unsigned on, unsigned s2) {
-        N_DXV = c2at(T, C2_DXV, on + s2); N_RDYV = c2at(T, C2_RDYV, on + s2); N_RDXU = c2at(T, C2_RDXU, on + s2);
-        N_DXF2 = c2at(T, C2_DXF2, on + s2); N_DYF2 = c2at(T, C2_DYF2, on + s2); N_RAZF = c2at(T, C2_RAZF, on + s2);
-        N_DYU = c2at(T, C2_DYU, on); N_DYC2 = c2at(T, C2_DYC2, on); N_DXC2 = c2at(T, C2_DXC2, on); N_RAZC = c2at(T, C2_RAZC, on);
+        N_DXV = c2m(T, C2_DXV, on + s2); N_RDYV = c2m(T, C2_RDYV, on + s2); N_RDXU = c2m(T, C2_RDXU, on + s2);
+        N_DXF2 = c2m(T, C2_DXF2, on + s2); N_DYF2 = c2m(T, C2_DYF2, on + s2); N_RAZF = c2m(T, C2_RAZF, on + s2);
+        N_DYU = c2m(T, C2_DYU, on); N_DYC2 = c2m(T, C2_DYC2, on); N_DXC2 = c2m(T, C2_DXC2, on); N_RAZC = c2m(T, C2_RAZC, on);
     }
     // FULL: before the first step(r): o = plane offset of row r, u_0 / v_0 = u, v of row r; om: of row r - 1 (clamped)
     __device__ __forceinline__ void full_init(tptr_t T, unsigned o, unsigned om, unsigned s2) {
         full_prefetch(T, o, s2);
-        DXV_0 = c2at(T, C2_DXV, o); RDXV_0 = fm::rcp(DXV_0); RDYV_0 = c2at(T, C2_RDYV, o); RDXU_0 = c2at(T, C2_RDXU, o);
-        DXF2_0 = c2at(T, C2_DXF2, o); DYF2_0 = c2at(T, C2_DYF2, o); RAZF_0 = c2at(T, C2_RAZF, o);
+        DXV_0 = c2m(T, C2_DXV, o); RDXV_0 = fm::rcp(DXV_0); RDYV_0 = c2m(T, C2_RDYV, o); RDXU_0 = c2m(T, C2_RDXU, o);
+        DXF2_0 = c2m(T, C2_DXF2, o); DYF2_0 = c2m(T, C2_DYF2, o); RAZF_0 = c2m(T, C2_RAZF, o);
         // rows r - 1, r - 2: multiplied by zero stresses until their real values have been shifted in (any finite number)
         DXV_m = DXV_0; RDXV_m = RDXV_0; RDYV_m = RDYV_0; RDXU_m = RDXU_0; DXF2_m = DXF2_0; DYF2_m = DYF2_0;
-        DYU_m = c2at(T, C2_DYU, o); RDYU_m = fm::rcp(DYU_m); DYC2_m = c2at(T, C2_DYC2, o); DXC2_m = c2at(T, C2_DXC2, o); DXC2_mm = DXC2_m;
+        DYU_m = c2m(T, C2_DYU, o); RDYU_m = fm::rcp(DYU_m); DYC2_m = c2m(T, C2_DYC2, o); DXC2_m = c2m(T, C2_DXC2, o); DXC2_mm = DXC2_m;
     }
     double S11_mm, S22_mm, S12_mm, AL_mm, S11_m, S22_m, S12_m, AL_m;
 #ifdef CSI_PAIR_PROBE
@@ -157,7 +173,7 @@ struct Stage {
             if constexpr (ALLPRE) {
                 RAZU_m = N_RAZU; RAZV_x = N_RAZV; FU_m = N_FU; FV_x = N_FV;
             } else if (do_vel) {
-                RAZU_m = c2at(T, C2_RAZU, o2m); RAZV_x = c2at(T, C2_RAZV, UFIRST ? o2m : o2);
+                RAZU_m = c2m(T, C2_RAZU, o2m); RAZV_x = c2m(T, C2_RAZV, UFIRST ? o2m : o2);
                 if (T->I[FI_FKIND] == 2) { FU_m = ldg(T->P[FP_F2U], o2m); FV_x = ldg(T->P[FP_F2V], UFIRST ? o2m : o2); }
             }
             const double Uy_w = DYU_0 * u_0, Ur_w = RDYU_0 * u_0;
@@ -254,7 +270,7 @@ struct Stage {
         if constexpr (FULL) {
             // the next step's plane values: issued here, behind the stress phase, consumed after the velocity phase and the row barrier
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PLR) N_RAZC = c2at(T, C2_RAZC, o2n);
+            if constexpr (PLR) N_RAZC = c2m(T, C2_RAZC, o2n);
             else full_prefetch(T, o2n, s2);
             if constexpr (ALLPRE) full_prefetch_vel(T, o2n, o2nm);
             mid();
