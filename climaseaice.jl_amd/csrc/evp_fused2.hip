@@ -1027,7 +1027,13 @@ void CSI_PAIR_NAME(const FusedTable* dev_table, int metric, bool a_ufirst, int c
 #define CSI_LAUNCH_PAIR(U, A) do { (void)common; CSI_LAUNCH_PAIR_(U, A, 0, false); } while (0)
 #endif
     if (metric == 2) {
-#if CSI_PAIR_VARIANT >= 1
+#if CSI_PAIR_VARIANT >= 1 && CSI_PAIR_VARIANT <= 2
+        // per-point metrics: the forcing kinds fixed at compile time for the reference's default (number-valued top stress, ocean at
+        // rest) as well: four wave-uniform branches, the explicit parts and a dozen scalar loads per stage-row less (+6 % measured on
+        // the uniform-grid walls variant, CSI_PAIR_COMMON=0 / 2)
+        if (common == 2) { if (a_ufirst) CSI_LAUNCH_PAIR_(false, true, 2, true); else CSI_LAUNCH_PAIR_(false, false, 2, true); }
+        else { if (a_ufirst) CSI_LAUNCH_PAIR_(false, true, 0, true); else CSI_LAUNCH_PAIR_(false, false, 0, true); }
+#elif CSI_PAIR_VARIANT >= 1
         if (a_ufirst) CSI_LAUNCH_PAIR_(false, true, 0, true); else CSI_LAUNCH_PAIR_(false, false, 0, true);
 #endif
     } else if (metric == 0) { if (a_ufirst) CSI_LAUNCH_PAIR(true, true); else CSI_LAUNCH_PAIR(true, false); }
