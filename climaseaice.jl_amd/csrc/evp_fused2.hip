@@ -43,6 +43,9 @@
 #define CSI_PAIR_HOIST 1        // 1: let the compiler keep the table constants in SGPRs across rows (no per-row reload fence); not in the
                                 // array-forcing and per-point-metric instantiations (scalar spills: curvilinear 30.3 -> 27.1 G with it)
 #endif
+#ifndef CSI_FULL_FENCE
+#define CSI_FULL_FENCE 1        // per-point-metric instantiations: reload the table constants every row (1) or let the compiler keep them (0: scalar spills)
+#endif
 #ifndef CSI_PAIR_STORES
 #define CSI_PAIR_STORES 7       // which of stage B's results the CONSUMER stores itself (bit 0: the stresses, bit 1: the first velocity, bit 2: the
                                 // second); the producer stores the rest, handed over through the out ring, two iterations later
@@ -618,7 +621,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         int r = rstart;
         auto body = [&](auto KK) __attribute__((always_inline)) {
             constexpr int k = decltype(KK)::value;
-            if (!CSI_PAIR_HOIST || FORCE || FULL) asm volatile("" : "+s"(T));
+            if (!CSI_PAIR_HOIST || FORCE || (FULL && CSI_FULL_FENCE)) asm volatile("" : "+s"(T));
             set_prio(k);
             PROBE_START;
             // rows r and r + 1 are in flight (loads return in order; FORCE: the array loads of the previous iteration were
@@ -808,7 +811,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     double vn_delay = 0.0;                                // B u-first: v^n of row q - 1 (read one iteration earlier as row q)
     int r = rstart;
     auto bodyB = [&](auto KK) __attribute__((always_inline)) {
-        if (!CSI_PAIR_HOIST || FORCE || FULL) asm volatile("" : "+s"(T));
+        if (!CSI_PAIR_HOIST || FORCE || (FULL && CSI_FULL_FENCE)) asm volatile("" : "+s"(T));
         set_prio(decltype(KK)::value);
         const int q = r - 2;
         PROBE_START;
