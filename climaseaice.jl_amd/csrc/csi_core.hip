@@ -114,7 +114,8 @@ int32_t sync_coriolis(csi_context* c) {
         const int n = c->Ny + 2 * c->Hy + 1;
         // device layout: ROW-major, the FC_COUNT coefficients of one row contiguous (a kernel reads a row's
         // coefficients with a few wide scalar loads from one base address)
-        std::vector<double> host((size_t)FC_COUNT * n);
+        // (rows n .. 2n - 1: the pair kernel's copy, scaled by exact powers of two: pair_coef_scale)
+        std::vector<double> host((size_t)FC_COUNT * n * 2);
         for (int w = 0; w < FC_COUNT; ++w)
             for (int t = 0; t < n; ++t)
                 host[(size_t)t * FC_COUNT + w] = metrics_uniform ? c->coef.uni[w] : c->coef_host[(size_t)w * n + t];
@@ -122,10 +123,14 @@ int32_t sync_coriolis(csi_context* c) {
             host[(size_t)t * FC_COUNT + FC_FU] = rows ? c->fcor_rows[0][t] : f0;
             host[(size_t)t * FC_COUNT + FC_FV] = rows ? c->fcor_rows[1][t] : f0;
         }
+        for (int t = 0; t < n; ++t)
+            for (int w = 0; w < FC_COUNT; ++w)
+                host[(size_t)(n + t) * FC_COUNT + w] = pair_coef_scale(w) * host[(size_t)t * FC_COUNT + w];
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!c->dev_coef) HIP_TRY(c, hipMalloc((void**)&c->dev_coef, sizeof(double) * host.size()));
         HIP_TRY(c, hipMemcpy(c->dev_coef, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
         c->coef.vec = c->dev_coef + (size_t)(c->Hy - 1) * FC_COUNT;      // so that vec[j * stride + which] is row j
+        c->coef.vec_pair = c->coef.vec + (size_t)n * FC_COUNT;
         c->coef.stride = FC_COUNT;
         c->coef.jmin = 1 - c->Hy;
         c->coef.jmax = c->Ny + c->Hy + 1;

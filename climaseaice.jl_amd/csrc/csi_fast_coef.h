@@ -52,9 +52,20 @@ enum : int {
     C2_COUNT
 };
 
+// The two-sub-steps kernel's row pipelines (evp_pair_stage.h) read their own copy of the coefficients, scaled by exact powers of
+// two: the corner strain rate times 8 and the stress divergences times 2 (fm::stress_update_s, fm::vel_update_sum)
+inline double pair_coef_scale(int which) {
+    switch (which) {
+        case FC_SN: case FC_SS: case FC_SV: return 8.0;
+        case FC_E: case FC_FN: case FC_FS: case FC_Q1N: case FC_Q2N: case FC_Q1S: case FC_Q2S: case FC_K: return 2.0;
+        default: return 1.0;
+    }
+}
+
 struct FastCoef {
     double uni[FC_COUNT];   // uniform grid: the (row-independent) values
     const double* vec;      // per-j: device array [rows][FC_COUNT] (row-major), pre-offset so vec[j*stride + w] is row j
+    const double* vec_pair; // ... and the copy scaled by pair_coef_scale
     int stride;
     int uniform;
     int jmin, jmax;         // valid row range of `vec`

@@ -32,11 +32,14 @@ enum : int { FK_EM2 = 0, FK_DMIN, FK_DMIN2, FK_AMIN2, FK_AMAX2, FK_HK1, FK_HKC, 
              FK_BOT_TAU_U, FK_BOT_TAU_V, FK_BOT_RHOCD, FK_BOT_UE, FK_BOT_VE,
              FK_BCU, FK_BCV = FK_BCU + 2,      // ValueBoundaryCondition values: u at the y walls (low, high), v at the x walls
              FK_CA_DT = FK_BCV + 2, FK_RDMIN, FK_AMIN, FK_AMAX, FK_RAMIN, FK_RAMAX, FK_FCOR,
-             FK_COEF0, FK_COUNT = FK_COEF0 + FC_COUNT };
+             FK_COEF0,
+             FK_PCOEF0 = FK_COEF0 + FC_COUNT,      // the pair kernel's scaled copy of the uniform-grid coefficients (pair_coef_scale)
+             FK_PK_EM2_8 = FK_PCOEF0 + FC_COUNT, FK_PK_DMIN2_16, FK_PK_HKF4, FK_PK_CA_DT4,      // e^-2 / 8, 16 Delta_min^2, 4 hkf, 4 x (c_alpha dt / 2): fm::stress_update_s
+             FK_COUNT };
 enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, FP_A, FP_UN, FP_VN,     // 10 inputs, contiguous
              FP_S11_OUT, FP_S22_OUT, FP_S12_OUT, FP_U_OUTP, FP_V_OUTP,                                // 5 outputs (parent addresses), contiguous
              FP_U_OUT, FP_V_OUT, FP_S11_OUT0, FP_S22_OUT0, FP_S12_OUT0,                               // (0,0)-offset addresses for stores with halo images
-             FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_MASK,
+             FP_AL, FP_ZC, FP_ZF, FP_DL, FP_COEF_VEC, FP_PCOEF_VEC, FP_MASK,
              FP_FT_U, FP_FT_V, FP_FB_U, FP_FB_V, FP_FB_UBAR, FP_FB_VBAR, FP_FD_U, FP_FD_V,
              FP_FT_UBAR, FP_FT_VBAR,      // wind drag (a SemiImplicitStress on top with array-valued air velocities, in FP_FT_U / _V): their cross averages
              FP_FROW_U, FP_FROW_V,      // CSI_METRIC_FULL: per-row Coriolis parameter (device pointers, ptr[j] = row j)

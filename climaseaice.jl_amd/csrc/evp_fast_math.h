@@ -56,7 +56,7 @@ __device__ __forceinline__ double rsqrt(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double g = x * y, h = 0.5 * y;
     const double r = fma_(-h, g, 0.5);
-    return 2.0 * fma_(h, r, h);
+    return fma_(y, r, y);          // = 2 (h r + h) exactly (y = 2 h): one multiplication less, the same bits
 }
 // s = sqrt(x) to 0.5 ulp (coupled step + one residual correction; a second correction changes nothing), rs = 1 / sqrt(x)
 // from the coupled step alone
@@ -103,6 +103,7 @@ struct StressConst {
     double em2, Dmin, Dmin2, rDmin, amin, amax, amin2, amax2, ramin, ramax;
     double hk1;      // (1 - e^-2) / 2
     int pressure_kind;
+    double em2_8, Dmin2_16;      // stress_update_s only: e^-2 / 8, 16 Delta_min^2
 };
 
 struct StressOut {
@@ -153,6 +154,48 @@ __device__ __forceinline__ StressOut stress_update_r(const StressConst& k, doubl
     // sigma += (mass > 0) ? (sigma' - sigma) / gamma : 0 (evp:343-347): the mask goes onto 1 / gamma (sigma' is finite
     // where there is no ice: zeta = 0 or the ice strength is finite), and the update is one fused multiply-add
     const double wc = (mc > 0) ? rgc : 0.0, wf = (mf > 0) ? rgf : 0.0;
+    o.s11 = fma_(s11n - s11, wc, s11);
+    o.s22 = fma_(s22n - s22, wc, s22);
+    o.s12 = fma_(s12n - s12, wf, s12);
+    o.alpha = gc;
+    o.zc2 = zc2; o.zf2 = zf2; o.xc = xc; o.rDc = rDc;
+    return o;
+}
+
+// The same with the CORNER's inputs as SUMS (the pair kernel's row pipeline, evp_pair_stage.h): every average over four points
+// reaches this function unscaled, and the corner strain rate arrives times 8 -- exact powers of two all through, so every
+// result has the bits stress_update_r gives, with six multiplications fewer per stress index:
+//   S11f, S22f : 4 e11f, 4 e22f (sums of the four cell strain rates around the corner)
+//   E12f       : 8 e12f         (strain_corner with its coefficients times 8)
+//   y2         : 2 e12c         (1/16 of the sum of the four corners' E12)
+//   XP, M4     : 4 Pf, 4 mf     (sums of the four cells' ice strength / mass);  rM4 = rcp(M4) = rmf / 4
+//   hkf4       : 4 hkf;   k.em2_8 = e^-2 / 8, k.Dmin2_16 = 16 Delta_min^2
+// Delta_f^2 comes out times 16, 1 / Delta_f divided by 4, 2 zeta_f = XP / (4 Delta_f) exactly as before.
+__device__ __forceinline__ StressOut stress_update_s(const StressConst& k, double e11c, double e22c, double E12f,
+                                                     double S11f, double S22f, double y2, double Pc, double XP,
+                                                     double mc, double M4, double rmc, double rM4, double hkc, double hkf4,
+                                                     double s11, double s22, double s12) {
+    StressOut o;
+    const double dc = e11c + e22c, DF = S11f + S22f;
+    const double tc = e11c - e22c, TF = S11f - S22f;
+    const double sc2 = fma_(tc, tc, y2 * y2);
+    const double sf2 = fma_(TF, TF, E12f * E12f);
+    const double xc = fmax_(fma_(dc, dc, sc2 * k.em2), k.Dmin2), xf = fmax_(fma_(DF, DF, sf2 * k.em2), k.Dmin2_16);
+    const double rDc = rsqrt(xc), rDf = rsqrt(xf);
+    const double zc2 = Pc * rDc, zf2 = XP * rDf;
+    const double Pr = (k.pressure_kind == 0) ? Pc * rcp(fma_(k.Dmin, rDc, 1.0)) : Pc;
+    const double ec2 = zc2 * k.em2, ef2 = zf2 * k.em2_8;
+    const double bulk = fma_(zc2 * k.hk1, dc, -0.5 * Pr);
+    const double s11n = fma_(ec2, e11c, bulk);
+    const double s22n = fma_(ec2, e22c, bulk);
+    const double s12n = ef2 * E12f;
+    const double g2c_raw = zc2 * hkc * rmc, g2f_raw = zf2 * hkf4 * rM4;
+    const double g2c = fmax_(fmin_(g2c_raw, k.amax2), k.amin2);
+    const double g2f = fmax_(fmin_(g2f_raw, k.amax2), k.amin2);
+    double gc, rgc, gf, rgf;
+    sqrt_rsqrt(g2c, gc, rgc);
+    sqrt_rsqrt(g2f, gf, rgf);
+    const double wc = (mc > 0) ? rgc : 0.0, wf = (M4 > 0) ? rgf : 0.0;
     o.s11 = fma_(s11n - s11, wc, s11);
     o.s22 = fma_(s22n - s22, wc, s22);
     o.s12 = fma_(s12n - s12, wf, s12);
@@ -247,11 +290,13 @@ __device__ __forceinline__ double vel_update_fd(const VelConst& k, double w, dou
 // min_mass, min_conc are DOUBLED (rdt is not): every intermediate is vel_update_avg's scaled by an exact power of two
 // (also through rcp: seed and Newton step scale exactly), so the result has the same bits -- the three halvings of the
 // averages become one doubling of 1 / m.  The row pipelines of the pair kernel (evp_pair_stage.h) use these.
+// div2: TWICE the stress divergence (the row pipelines form it with doubled coefficients: div2 / (2 mi) instead of div x (1 / (2 mi) +
+// 1 / (2 mi)), one addition less, the same bits)
 __device__ __forceinline__ double vel_update_sum(const VelConst& k2, double w, double wn, double m2, double a2, double al2,
-                                                 double div, double cor, double ext, double imt, double exb, double imb, bool peripheral) {
+                                                 double div2, double cor, double ext, double imt, double exb, double imb, bool peripheral) {
     const double rm2 = rcp(m2);                             // 1 / (2 mi)
     const double rai = rm2 * a2;                            // ai / mi
-    const double G = fma_(wn - w, k2.rdt, fma_(div, rm2 + rm2, fma_(exb - ext, rai, cor)));
+    const double G = fma_(wn - w, k2.rdt, fma_(div2, rm2, fma_(exb - ext, rai, cor)));
     const double tau_i = (imb - imt) * rai;
     const double wD = fma_(k2.dt, G, al2 * w) * rcp(fma_(k2.dt, tau_i, al2));
     const bool active_ice = (m2 >= k2.min_mass) & (a2 >= k2.min_conc);
@@ -259,9 +304,9 @@ __device__ __forceinline__ double vel_update_sum(const VelConst& k2, double w, d
     return peripheral ? 0.0 : res;
 }
 __device__ __forceinline__ double vel_update_sum_fd(const VelConst& k2, double w, double wn, double m2, double a2, double al2,
-                                                    double div, double cor, double ext, double imt, double exb, double imb,
+                                                    double div2, double cor, double ext, double imt, double exb, double imb,
                                                     bool peripheral, double wf) {
-    const double wD = vel_update_sum(k2, w, wn, m2, a2, al2, div, cor, ext, imt, exb, imb, false);
+    const double wD = vel_update_sum(k2, w, wn, m2, a2, al2, div2, cor, ext, imt, exb, imb, false);
     const bool active_ice = (m2 >= k2.min_mass) & (a2 >= k2.min_conc);
     const bool marginal = (m2 > 2.0 * CSI_EPS64) & (a2 > 2.0 * CSI_EPS64);
     const double res = active_ice ? wD : (marginal ? wf : 0.0);
@@ -310,6 +355,19 @@ __device__ __forceinline__ double full_div1(double dyu, double rdyu, double rdxu
 __device__ __forceinline__ double full_div2(double dxv, double rdxv, double rdyv, double razv, double S_n, double S_s, double T_n, double T_s,
                                             double Z_e, double Z_w) {
     return razv * fma_(0.5 * dxv, S_n - S_s, fma_(-0.5 * rdxv, T_n - T_s, rdyv * (Z_e - Z_w)));
+}
+
+// the pair kernel's scaled forms (evp_pair_stage.h): 8 e12 and TWICE the divergences -- the halvings inside become exact factors
+__device__ __forceinline__ double full_strain_corner8(double Ux_n, double Ux_s, double Vy_e, double Vy_w, double dxf2, double dyf2, double razf) {
+    return (4.0 * razf) * fma_(dxf2, Ux_n - Ux_s, dyf2 * (Vy_e - Vy_w));
+}
+__device__ __forceinline__ double full_div1_x2(double dyu, double rdyu, double rdxu, double razu, double S_e, double S_w, double T_e, double T_w,
+                                               double Z_n, double Z_s) {
+    return razu * fma_(dyu, S_e - S_w, fma_(rdyu, T_e - T_w, (rdxu + rdxu) * (Z_n - Z_s)));
+}
+__device__ __forceinline__ double full_div2_x2(double dxv, double rdxv, double rdyv, double razv, double S_n, double S_s, double T_n, double T_s,
+                                               double Z_e, double Z_w) {
+    return razv * fma_(dxv, S_n - S_s, fma_(-rdxv, T_n - T_s, (rdyv + rdyv) * (Z_e - Z_w)));
 }
 
 }  // namespace fm

@@ -387,6 +387,8 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     K[FK_BOT_TAU_U] = P.bot.kind == 1 ? P.bot.tau_u : 0.0; K[FK_BOT_TAU_V] = P.bot.kind == 1 ? P.bot.tau_v : 0.0; K[FK_BOT_RHOCD] = P.bot.rho_e * P.bot.Cd;
     K[FK_BOT_UE] = eff(P.bot.ue_kind, P.bot.ue); K[FK_BOT_VE] = eff(P.bot.ve_kind, P.bot.ve);
     for (int k = 0; k < FC_COUNT; ++k) K[FK_COEF0 + k] = c.uni[k];
+    for (int k = 0; k < FC_COUNT; ++k) K[FK_PCOEF0 + k] = pair_coef_scale(k) * c.uni[k];
+    K[FK_PK_EM2_8] = 0.125 * c.em2; K[FK_PK_DMIN2_16] = 16.0 * c.Dmin2; K[FK_PK_HKF4] = 4.0 * c.hkf; K[FK_PK_CA_DT4] = 4.0 * c.ca_dt;
     unsigned long* Q = t->P;
     Q[FP_U_IN] = parent_addr(in[0], g); Q[FP_V_IN] = parent_addr(in[1], g);
     Q[FP_S11_IN] = parent_addr(in[2], g); Q[FP_S22_IN] = parent_addr(in[3], g); Q[FP_S12_IN] = parent_addr(in[4], g);
@@ -396,6 +398,7 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
     Q[FP_UN] = parent_addr(P.un, g); Q[FP_VN] = parent_addr(P.vn, g);
     Q[FP_AL] = parent_addr(P.al, g); Q[FP_ZC] = parent_addr(P.zc, g); Q[FP_ZF] = parent_addr(P.zf, g); Q[FP_DL] = parent_addr(P.Dl, g);
     Q[FP_COEF_VEC] = (unsigned long)c.vec;
+    Q[FP_PCOEF_VEC] = (unsigned long)c.vec_pair;
     Q[FP_S11_OUT0] = (unsigned long)out[2].p; Q[FP_S22_OUT0] = (unsigned long)out[3].p; Q[FP_S12_OUT0] = (unsigned long)out[4].p;
     Q[FP_U_OUTP] = parent_addr(out[0], g); Q[FP_V_OUTP] = parent_addr(out[1], g);
     int* I = t->I;

@@ -339,6 +339,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.rDmin = T->K[FK_RDMIN];
         ks.amin = T->K[FK_AMIN]; ks.amax = T->K[FK_AMAX]; ks.amin2 = T->K[FK_AMIN2]; ks.amax2 = T->K[FK_AMAX2];
         ks.ramin = T->K[FK_RAMIN]; ks.ramax = T->K[FK_RAMAX]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+        ks.em2_8 = T->K[FK_PK_EM2_8]; ks.Dmin2_16 = T->K[FK_PK_DMIN2_16];
     };
     auto vel_consts = [&](fm::VelConst& kv) __attribute__((always_inline)) {
         // doubled dt and thresholds: Stage updates the velocities from sums over the two cells of a face (fm::vel_update_sum)
@@ -551,13 +552,13 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             if constexpr (FULL) {
                 const unsigned om2 = off2(jm), o02 = off2(rstart);
                 full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m);
-                A.e12_0 = full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0);
+                A.e12_0 = 8.0 * full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0);      // (the stage carries 8 e12: evp_pair_stage.h)
                 A.hoist_planes(T);
                 A.full_init(T, o02, om2, c2s);
             } else {
             fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
                             coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
-            A.e12_0 = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, rstart), coef<UNI>(T, FC_SS, rstart), coef<UNI>(T, FC_SV, rstart), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
+            A.e12_0 = fm::strain_corner<UNI>(pcoef<UNI>(T, FC_SN, rstart), pcoef<UNI>(T, FC_SS, rstart), pcoef<UNI>(T, FC_SV, rstart), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
             }
             A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);
             A.Xe22_m = fm::sum2(from_left(e22_m), e22_m);

@@ -38,6 +38,15 @@ __device__ __forceinline__ double coef(tptr_t T, int which, int j) {
     return vec[(long)min(max(j, T->I[FI_COEF_JMIN]), T->I[FI_COEF_JMAX]) * FC_COUNT + which];   // row-major; ring rows may fall off the table
 }
 
+// the pair kernel's scaled copy (csi_fast_coef.h pair_coef_scale)
+template <bool UNI>
+__device__ __forceinline__ double pcoef(tptr_t T, int which, int j) {
+    if (UNI) return T->K[FK_PCOEF0 + which];
+    typedef const __attribute__((address_space(4))) double* vptr_t;
+    vptr_t vec = (vptr_t)T->P[FP_PCOEF_VEC];
+    return vec[(long)min(max(j, T->I[FI_COEF_JMIN]), T->I[FI_COEF_JMAX]) * FC_COUNT + which];
+}
+
 // Addressing: uniform base = parent array start, per-lane unsigned byte offset in a VGPR ->
 // `global_load v, v_off, s[base]` with no 64-bit address arithmetic.  All Center-in-x fields share one leading
 // dimension and all Face-in-x fields another (dense Oceananigans parents; checked on the host), so two running

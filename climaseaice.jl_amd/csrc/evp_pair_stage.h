@@ -180,26 +180,30 @@ struct Stage {
             fm::full_strain_cell(from_right(Uy_w), Uy_w, DXV_p * v_p, DXV_0 * v_0, from_right(Ur_w), Ur_w, RDXV_p * v_p, RDXV_0 * v_0,
                                  DYC2_0, DXC2_0, RAZC_0, e11_0, e22_0);
             const double Vy_e = RDYV_p * v_p;
-            e12_p = fm::full_strain_corner(RDXU_p * u_p, RDXU_0 * u_0, Vy_e, from_left(Vy_e), DXF2_p, DYF2_p, RAZF_p);
+            e12_p = fm::full_strain_corner8(RDXU_p * u_p, RDXU_0 * u_0, Vy_e, from_left(Vy_e), DXF2_p, DYF2_p, RAZF_p);      // 8 e12 (see below)
         } else {
         fm::strain_cell<UNI>(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
                         coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
-        e12_p = fm::strain_corner<UNI>(coef<UNI>(T, FC_SN, r + 1), coef<UNI>(T, FC_SS, r + 1), coef<UNI>(T, FC_SV, r + 1),
+        e12_p = fm::strain_corner<UNI>(pcoef<UNI>(T, FC_SN, r + 1), pcoef<UNI>(T, FC_SS, r + 1), pcoef<UNI>(T, FC_SV, r + 1),
                                   u_p, u_0, v_p, from_left(v_p));
         }
+        // Scaled quantities (round 4): the corner strain rate is carried times 8 (e12_0, e12_p, Ye12_*: scaled coefficients, pcoef /
+        // full_strain_corner8), the averages over four points stay sums (S11f, S22f, M4, the ice strength XP), the stress divergences
+        // come out doubled (pcoef / full_div*_x2) -- exact powers of two, undone inside constants (fm::stress_update_s,
+        // fm::vel_update_sum): ten multiplications / additions per stage-row less, every stored value bit for bit what it was.
         {
             const double Xe11_0 = fm::sum2(from_left(e11_0), e11_0), Xe22_0 = fm::sum2(from_left(e22_0), e22_0);
             const double Ye12_p = fm::sum2(e12_p, from_right(e12_p));
             Xm_0 = fm::sum2(from_left(m_0), m_0);
-            const double e11f = fm::quarter(Xe11_m, Xe11_0);
-            const double e22f = fm::quarter(Xe22_m, Xe22_0);
-            const double e12c = fm::quarter(Ye12_0, Ye12_p);
-            const double mf = fm::quarter(Xm_m, Xm_0);
+            const double e11f = fm::sum2(Xe11_m, Xe11_0);                     // 4 e11f
+            const double e22f = fm::sum2(Xe22_m, Xe22_0);                     // 4 e22f
+            const double e12c = 0.0625 * fm::sum2(Ye12_0, Ye12_p);            // 2 e12c (the corners' values are 8 e12)
+            const double mf = fm::sum2(Xm_m, Xm_0);                           // 4 mf
             if constexpr (!PRE) {
                 const double XP_0 = fm::sum2(from_left(P_0), P_0);
-                Pf_0 = fm::quarter(XP_m, XP_0);
+                Pf_0 = fm::sum2(XP_m, XP_0);                                  // 4 Pf
                 XP_m = XP_0;
-                rmc_0 = fm::rcp(m_0); rmf_0 = fm::rcp(mf);
+                rmc_0 = fm::rcp(m_0); rmf_0 = fm::rcp(mf);                    // 1 / m, 1 / (4 mf)
             }
             const double Pf = Pf_0;
             Xe11_m = Xe11_0; Xe22_m = Xe22_0; Ye12_0 = Ye12_p;
@@ -211,11 +215,12 @@ struct Stage {
                     asm volatile("" : "+s"(T));
                     ks.em2 = T->K[FK_EM2]; ks.Dmin = T->K[FK_DMIN]; ks.Dmin2 = T->K[FK_DMIN2]; ks.amin2 = T->K[FK_AMIN2];
                     ks.amax2 = T->K[FK_AMAX2]; ks.hk1 = T->K[FK_HK1]; ks.pressure_kind = T->I[FI_PRESSURE_KIND];
+                    ks.em2_8 = T->K[FK_PK_EM2_8]; ks.Dmin2_16 = T->K[FK_PK_DMIN2_16];
                 }
-                double kc, kf;
-                if constexpr (FULL) { kc = T->K[FK_CA_DT] * RAZC_0; kf = T->K[FK_CA_DT] * RAZF_0; }
-                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_HKF] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZF, r); }
-                const fm::StressOut o = fm::stress_update_r(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, rmc_0, rmf_0, kc, kf, s11, s22, s12);
+                double kc, kf;      // kf: FOUR times c_alpha dt / (2 Az) at the corner
+                if constexpr (FULL) { kc = T->K[FK_CA_DT] * RAZC_0; kf = T->K[FK_PK_CA_DT4] * RAZF_0; }
+                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_PK_HKF4] : T->K[FK_PK_CA_DT4] * coef<UNI>(T, FC_RAZF, r); }
+                const fm::StressOut o = fm::stress_update_s(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, rmc_0, rmf_0, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
             }
         }
@@ -248,16 +253,16 @@ struct Stage {
             const double S_e = d11_m + d22_m, T_e = DYC2_m * (d11_m - d22_m);
             const double S_w = MASK ? from_left(S_e) : d11_mL + d22_mL;
             const double T_w = MASK ? from_left(T_e) : from_left(DYC2_m) * (d11_mL - d22_mL);
-            return fm::full_div1(DYU_m, RDYU_m, RDXU_m, RAZU_m, S_e, S_w, T_e, T_w, DXF2_0 * d12_0, DXF2_m * d12_m);
+            return fm::full_div1_x2(DYU_m, RDYU_m, RDXU_m, RAZU_m, S_e, S_w, T_e, T_w, DXF2_0 * d12_0, DXF2_m * d12_m);
         };
         auto div2_full = [&](bool low) __attribute__((always_inline)) {
             if (low) {
                 const double Zw = DYF2_m * d12_m;
-                return fm::full_div2(DXV_m, RDXV_m, RDYV_m, RAZV_x, d11_m + d22_m, d11_mm + d22_mm,
+                return fm::full_div2_x2(DXV_m, RDXV_m, RDYV_m, RAZV_x, d11_m + d22_m, d11_mm + d22_mm,
                                      DXC2_m * (d11_m - d22_m), DXC2_mm * (d11_mm - d22_mm), from_right(Zw), Zw);
             }
             const double Zw = DYF2_0 * d12_0;
-            return fm::full_div2(DXV_0, RDXV_0, RDYV_0, RAZV_x, d11_0 + d22_0, d11_m + d22_m,
+            return fm::full_div2_x2(DXV_0, RDXV_0, RDYV_0, RAZV_x, d11_0 + d22_0, d11_m + d22_m,
                                  DXC2_0 * (d11_0 - d22_0), DXC2_m * (d11_m - d22_m), from_right(Zw), Zw);
         };
         auto f_full = [&](int which_row, int which_plane, unsigned o, int j) __attribute__((always_inline)) {
@@ -291,7 +296,7 @@ struct Stage {
                 const double vbar = fm::quarter(Xv_m, Xv_0);
                 double div;
                 if constexpr (FULL) div = div1_full();
-                else div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
+                else div = fm::div1(pcoef<UNI>(T, FC_E, j), pcoef<UNI>(T, FC_FN, j), pcoef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
@@ -301,7 +306,7 @@ struct Stage {
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
                 else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 if (F.extra & 1) cor += F.xc_u;
-                if (F.extra & 2) div += F.xd_u;
+                if (F.extra & 2) div = fm::fma_(2.0, F.xd_u, div);      // (div is twice the divergence)
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
                            : fm::vel_update_sum(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -310,8 +315,8 @@ struct Stage {
                 const double ubar = fm::quarter(XW, XW_0);
                 double div;
                 if constexpr (FULL) div = div2_full(true);
-                else div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, j), coef<UNI>(T, FC_Q2N, j), coef<UNI>(T, FC_Q1S, j),
-                                            coef<UNI>(T, FC_Q2S, j), coef<UNI>(T, FC_K, j),
+                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, j), pcoef<UNI>(T, FC_Q2N, j), pcoef<UNI>(T, FC_Q1S, j),
+                                            pcoef<UNI>(T, FC_Q2S, j), pcoef<UNI>(T, FC_K, j),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
@@ -321,7 +326,7 @@ struct Stage {
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2 - s2, j) * ubar;
                 else cor = -coef<UNI>(T, FC_FV, j) * ubar;
                 if (F.extra & 1) cor += F.xc_v;
-                if (F.extra & 2) div += F.xd_v;
+                if (F.extra & 2) div = fm::fma_(2.0, F.xd_v, div);
                 second = F.fd ? fm::vel_update_sum_fd(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
                               : fm::vel_update_sum(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second);
             }
@@ -333,8 +338,8 @@ struct Stage {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
                 double div;
                 if constexpr (FULL) div = div2_full(false);
-                else div = fm::div2<UNI>(coef<UNI>(T, FC_Q1N, r), coef<UNI>(T, FC_Q2N, r), coef<UNI>(T, FC_Q1S, r),
-                                            coef<UNI>(T, FC_Q2S, r), coef<UNI>(T, FC_K, r),
+                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, r), pcoef<UNI>(T, FC_Q2N, r), pcoef<UNI>(T, FC_Q1S, r),
+                                            pcoef<UNI>(T, FC_Q2S, r), pcoef<UNI>(T, FC_K, r),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
@@ -344,7 +349,7 @@ struct Stage {
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2, r) * ubar;
                 else cor = -coef<UNI>(T, FC_FV, r) * ubar;
                 if (F.extra & 1) cor += F.xc_v;
-                if (F.extra & 2) div += F.xd_v;
+                if (F.extra & 2) div = fm::fma_(2.0, F.xd_v, div);
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
                            : fm::vel_update_sum(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first);
             }
@@ -354,7 +359,7 @@ struct Stage {
                 const double vbar = fm::quarter(XW, XW_0);
                 double div;
                 if constexpr (FULL) div = div1_full();
-                else div = fm::div1(coef<UNI>(T, FC_E, j), coef<UNI>(T, FC_FN, j), coef<UNI>(T, FC_FS, j),
+                else div = fm::div1(pcoef<UNI>(T, FC_E, j), pcoef<UNI>(T, FC_FN, j), pcoef<UNI>(T, FC_FS, j),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
@@ -364,7 +369,7 @@ struct Stage {
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
                 else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 if (F.extra & 1) cor += F.xc_u;
-                if (F.extra & 2) div += F.xd_u;
+                if (F.extra & 2) div = fm::fma_(2.0, F.xd_u, div);      // (div is twice the divergence)
                 second = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
                               : fm::vel_update_sum(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second);
             }
