@@ -288,10 +288,12 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     // ... unless that wall carries a ValueBoundaryCondition (IMG_VALUE): then ONE halo row, 2 val - u
     const bool uval_lo_b = WALLS && T->I[FI_IMU + 2] == IMG_VALUE, uval_hi_b = WALLS && T->I[FI_IMU + 3] == IMG_VALUE;
     // the wave-uniform switches of the row loop, packed into one scalar register (as separate bools each is a 64-bit lane mask)
-    enum : unsigned { U_WRAPLO = 1, U_YLO = 2, U_YHI = 4, U_UVLO = 8, U_UVHI = 16, U_HASDX = 32, U_VALX = 64, U_WRAPHI = 128 };
+    enum : unsigned { U_WRAPLO = 1, U_YLO = 2, U_YHI = 4, U_UVLO = 8, U_UVHI = 16, U_HASDX = 32, U_VALX = 64, U_WRAPHI = 128, U_MIR = 256 };
+    // WALLS: some lane of the wave is the first mirror cell beyond an x wall (L_MIR_LO / L_MIR_HI): only the two edge strips of a grid
+    const bool wave_mir_b = WALLS && __builtin_amdgcn_ballot_w64((flags & (L_MIR_LO | L_MIR_HI)) != 0) != 0;
     const unsigned UF = (unsigned)__builtin_amdgcn_readfirstlane((int)((wrap_lo_b ? U_WRAPLO : 0u) | (wrap_hi_b ? U_WRAPHI : 0u) | (ylo_wall_b ? U_YLO : 0u) | (yhi_wall_b ? U_YHI : 0u) |
                                                                          (uval_lo_b ? U_UVLO : 0u) | (uval_hi_b ? U_UVHI : 0u) |
-                                                                         (wave_has_dx_b ? U_HASDX : 0u) | (wave_valx_b ? U_VALX : 0u)));
+                                                                         (wave_has_dx_b ? U_HASDX : 0u) | (wave_valx_b ? U_VALX : 0u) | (wave_mir_b ? U_MIR : 0u)));
 #define wrap_lo ((UF & U_WRAPLO) != 0)
 #define wrap_hi ((UF & U_WRAPHI) != 0)
 #define ylo_wall (WALLS && (UF & U_YLO) != 0)
@@ -300,6 +302,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 #define uval_hi (WALLS && (UF & U_UVHI) != 0)
 #define wave_has_dx ((UF & U_HASDX) != 0)
 #define wave_valx (WALLS && (UF & U_VALX) != 0)
+#define wave_mir (WALLS && (UF & U_MIR) != 0)
 #define has_dld (PEER && DLD)      // (an instantiation of its own: compiled into the common PEER one it cost 3 - 4 % of its launch time, not taken)
     // peripheral nodes of a row (walls only): u faces of rows beyond a y wall, v faces on / beyond it
     auto wall_row = [&](int j) __attribute__((always_inline)) { return (ylo_wall & (j < 1)) | (yhi_wall & (j > NyW)); };
@@ -844,6 +847,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             // What the reference reads from mirror halos, stage B reads from A's results: v of the first cell
             // beyond an x wall is its neighbour's; u of the first row beyond a y wall is the wall row's (row 0 is
             // patched when row 1 arrives, row N + 1 copies row N).  Deeper halo cells only feed halo results.
+            if (wave_mir) {      // (wave-uniform: interior strips skip the two lane shifts and the selects)
             const double vl = from_left(bv_p), vr = from_right(bv_p);
             // (a ValueBoundaryCondition wall reflects about 2 val instead: 2 val - v, 2 val - u)
             double ml = vr, mh = vl;
@@ -852,6 +856,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 if (flags & L_VAL_HI) mh = 2 * T->K[FK_BCV + 1] - vl;
             }
             bv_p = (flags & L_MIR_LO) ? ml : ((flags & L_MIR_HI) ? mh : bv_p);
+            }
             if (ylo_wall & (q == 0)) B.u_0 = uval_lo ? 2 * T->K[FK_BCU] - bu_p : bu_p;
             if (yhi_wall & (q == NyW)) bu_p = uval_hi ? 2 * T->K[FK_BCU + 1] - B.u_0 : B.u_0;
         }
