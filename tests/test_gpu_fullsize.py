@@ -360,3 +360,26 @@ def test_config5_masked_4096_2x4_decomposition_bitwise():
             w = want[f][j0:j0 + ny, i0:i0 + nx]
             g_ = got[f][:ny, :nx]
             assert np.array_equal(w, g_), (rank, f, np.abs(w - g_).max(), np.argwhere(w != g_)[:4].tolist())
+
+
+# ---- the realistic global configurations at the metric's size (round 4): the pair kernel's per-point-metric instantiations run
+# 999 / 888 tiles of 76 / 86 rows there (plane values through the LDS ring, the fold band beside the launch) -- shapes the small
+# named cases do not reach.  FAST three-kernel path == pair kernel, bit for bit, every field.
+FULLSIZE_GLOBAL = {
+    "curvilinear_channel": dict(topo=("periodic", "bounded"), curvilinear=0.05),
+    "curvilinear_channel_land": dict(topo=("periodic", "bounded"), curvilinear=0.05, land=0.3),
+    "curvilinear_coupled": dict(topo=("periodic", "bounded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True),
+    "tripolar_like": dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True),
+}
+
+
+@pytest.mark.parametrize("nsub", [12, 7])
+@pytest.mark.parametrize("name", sorted(FULLSIZE_GLOBAL))
+def test_global_configurations_2048_pair_equals_three_kernels(name, nsub):
+    c = cases.make_case(Nx=2048, Ny=2048, substeps=nsub, patches=False, noise=0.05, **FULLSIZE_GLOBAL[name])
+    ref, p0 = run_cycle(c, "fast", fusion=0)
+    got, p2 = run_cycle(c, "fast", fusion=2)
+    assert p0["level"] == 0 and p2["level"] == 2, (p0, p2)
+    for f in ref:
+        assert np.isfinite(got[f]).all(), f
+        assert got[f].tobytes() == ref[f].tobytes(), (name, f, float(np.abs(got[f] - ref[f]).max()))
