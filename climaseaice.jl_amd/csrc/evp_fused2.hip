@@ -559,8 +559,8 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 A.hoist_planes(T);
                 A.full_init(T, o02, om2, c2s);
             } else {
-            fm::strain_cell<UNI>(coef<UNI>(T, FC_A, jm), coef<UNI>(T, FC_BN, jm), coef<UNI>(T, FC_BS, jm), coef<UNI>(T, FC_CN, jm),
-                            coef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
+            fm::strain_cell<UNI>(pcoef<UNI>(T, FC_A, jm), pcoef<UNI>(T, FC_BN, jm), pcoef<UNI>(T, FC_BS, jm), pcoef<UNI>(T, FC_CN, jm),
+                            pcoef<UNI>(T, FC_CS, jm), from_right(A.u_m), A.u_m, A.v_0, A.v_m, e11_m, e22_m);
             A.e12_0 = fm::strain_corner<UNI>(pcoef<UNI>(T, FC_SN, rstart), pcoef<UNI>(T, FC_SS, rstart), pcoef<UNI>(T, FC_SV, rstart), A.u_0, A.u_m, A.v_0, from_left(A.v_0));
             }
             A.Xe11_m = fm::sum2(from_left(e11_m), e11_m);

@@ -38,7 +38,9 @@ __device__ __forceinline__ double coef(tptr_t T, int which, int j) {
     return vec[(long)min(max(j, T->I[FI_COEF_JMIN]), T->I[FI_COEF_JMAX]) * FC_COUNT + which];   // row-major; ring rows may fall off the table
 }
 
-// the pair kernel's scaled copy (csi_fast_coef.h pair_coef_scale)
+// the pair kernel's copy, some entries scaled (csi_fast_coef.h pair_coef_scale): it reads EVERY coefficient from this copy -- one base
+// address, one row, the same few wide scalar loads per stage-row as before (read from both tables the per-row instantiations lost
+// 17 %: lat-lon 2048^2 61.3 -> 51.6 G, measured and undone)
 template <bool UNI>
 __device__ __forceinline__ double pcoef(tptr_t T, int which, int j) {
     if (UNI) return T->K[FK_PCOEF0 + which];

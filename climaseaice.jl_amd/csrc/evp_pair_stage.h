@@ -182,8 +182,8 @@ struct Stage {
             const double Vy_e = RDYV_p * v_p;
             e12_p = fm::full_strain_corner8(RDXU_p * u_p, RDXU_0 * u_0, Vy_e, from_left(Vy_e), DXF2_p, DYF2_p, RAZF_p);      // 8 e12 (see below)
         } else {
-        fm::strain_cell<UNI>(coef<UNI>(T, FC_A, r), coef<UNI>(T, FC_BN, r), coef<UNI>(T, FC_BS, r), coef<UNI>(T, FC_CN, r),
-                        coef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
+        fm::strain_cell<UNI>(pcoef<UNI>(T, FC_A, r), pcoef<UNI>(T, FC_BN, r), pcoef<UNI>(T, FC_BS, r), pcoef<UNI>(T, FC_CN, r),
+                        pcoef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
         e12_p = fm::strain_corner<UNI>(pcoef<UNI>(T, FC_SN, r + 1), pcoef<UNI>(T, FC_SS, r + 1), pcoef<UNI>(T, FC_SV, r + 1),
                                   u_p, u_0, v_p, from_left(v_p));
         }
@@ -219,7 +219,7 @@ struct Stage {
                 }
                 double kc, kf;      // kf: FOUR times c_alpha dt / (2 Az) at the corner
                 if constexpr (FULL) { kc = T->K[FK_CA_DT] * RAZC_0; kf = T->K[FK_PK_CA_DT4] * RAZF_0; }
-                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * coef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_PK_HKF4] : T->K[FK_PK_CA_DT4] * coef<UNI>(T, FC_RAZF, r); }
+                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * pcoef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_PK_HKF4] : T->K[FK_PK_CA_DT4] * pcoef<UNI>(T, FC_RAZF, r); }
                 const fm::StressOut o = fm::stress_update_s(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, rmc_0, rmf_0, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
             }
@@ -304,7 +304,7 @@ struct Stage {
                 else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
-                else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                else cor = pcoef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 if (F.extra & 1) cor += F.xc_u;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_u, div);      // (div is twice the divergence)
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
@@ -324,7 +324,7 @@ struct Stage {
                 else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2 - s2, j) * ubar;
-                else cor = -coef<UNI>(T, FC_FV, j) * ubar;
+                else cor = -pcoef<UNI>(T, FC_FV, j) * ubar;
                 if (F.extra & 1) cor += F.xc_v;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_v, div);
                 second = F.fd ? fm::vel_update_sum_fd(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
@@ -347,7 +347,7 @@ struct Stage {
                 else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2, r) * ubar;
-                else cor = -coef<UNI>(T, FC_FV, r) * ubar;
+                else cor = -pcoef<UNI>(T, FC_FV, r) * ubar;
                 if (F.extra & 1) cor += F.xc_v;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_v, div);
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
@@ -367,7 +367,7 @@ struct Stage {
                 else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
-                else cor = coef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                else cor = pcoef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 if (F.extra & 1) cor += F.xc_u;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_u, div);      // (div is twice the divergence)
                 second = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
