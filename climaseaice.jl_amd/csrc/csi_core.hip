@@ -381,7 +381,10 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     G.nstrips = (width + 55) / 56;
     // (per-point coefficients: the kernel is compiled for 2 waves per SIMD -> 1024 resident tiles; measured at 2048^2:
     // 1024 tiles 22.9, 1536 tiles 18.9, 768 tiles 20.8 G cell-updates/s)
-    int target = c->metric_kind == CSI_METRIC_FULL ? 1024 : 1536;
+    // (array forcing on uniform / per-row metrics, round 4: the forcing values travel through the LDS ring, 36 KB per workgroup ->
+    //  four workgroups per CU, two waves per SIMD, like the per-point-metric instantiations)
+    const bool force_ring = c->metric_kind != CSI_METRIC_FULL && evp_ring_forcing(evp_dev(c, 0.0));
+    int target = (c->metric_kind == CSI_METRIC_FULL || force_ring) ? 1024 : 1536;
     // Beside a fold band (its own stream: eight small launches per pair of sub-steps) the pair launch leaves a third of the wave
     // slots free, so that the band runs DURING the launch instead of in its tail -- a launch that fills every slot lets only the
     // band's first kernel in (round 3: 123 + 31 us per pair of sub-steps at 2048^2).  Measured at 2048^2, round 4: fold on uniform

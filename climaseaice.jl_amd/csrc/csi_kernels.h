@@ -101,6 +101,8 @@ void launch_immersed_div(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, hi
 // array-valued forcing the pair kernel takes: 0 none needed, 1 supported (FORCE variant), -1 not supported;
 // StressBalanceFreeDrift (P.free_drift: free-drift velocity arrays P.ufd / P.vfd) also selects the FORCE variant
 int pair_forcing_kind(const EvpDev& P);
+bool evp_array_forcing(const EvpDev& P);
+bool evp_ring_forcing(const EvpDev& P);
 // bottom SemiImplicitStress with array-valued ocean velocities: the cross component averaged to the u / v points
 // (ubar at v points from fu, vbar at u points from fv), once per sub-cycle (evp_fast.hip)
 void launch_forcing_bars(const EvpDev& P, const FRef& ubar_v, const FRef& vbar_u, hipStream_t s, bool top = false);

@@ -315,7 +315,21 @@ int pair_forcing_kind(const EvpDev& P) {
     if (b_arr && ((b.ue_kind == 2 && b.fu.ld != lf) || (b.ve_kind == 2 && b.fv.ld != lc))) return -1;
     if (P.free_drift && (P.ufd.ld != lf || P.vfd.ld != lc)) return -1;
     if ((t_wind || b_tau) && (P.free_drift || P.extra)) return -1;         // (no instantiation with both)
-    return (t_arr || t_wind || b_arr || b_tau || P.free_drift || P.extra) ? 1 : 0;
+    return evp_array_forcing(P) ? 1 : 0;
+}
+// any array-valued forcing / free drift / extras: the pair kernel's FORCE instantiations (also what sizes their tiles: csi_core.hip pair_geom)
+bool evp_array_forcing(const EvpDev& P) {
+    const StressDev &t = P.top, &b = P.bot;
+    const bool t_arr = t.kind == 2, b_arr = b.kind == 3 && (b.ue_kind == 2 || b.ve_kind == 2);
+    const bool t_wind = t.kind == 3 && (t.ue_kind == 2 || t.ve_kind == 2);
+    const bool b_tau = b.kind == 2;
+    return t_arr || t_wind || b_arr || b_tau || P.free_drift || P.extra;
+}
+// ... of the kinds whose values travel through the pair kernel's ring (evp_fused2.hip FRING: the instantiations without extras)
+bool evp_ring_forcing(const EvpDev& P) {
+    const StressDev &t = P.top, &b = P.bot;
+    const bool t_wind = t.kind == 3 && (t.ue_kind == 2 || t.ve_kind == 2), b_tau = b.kind == 2;
+    return evp_array_forcing(P) && !P.extra && !t_wind && !b_tau;
 }
 
 void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* t) {

@@ -104,6 +104,20 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 // iteration (in-kernel probe: 4235 of 8061 cycles).  Without the consumer's plane loads: 35.6 -> 41.8 G (timing experiment).
 // 19 fields x 4 rows x 512 B = 38 KB per workgroup: four workgroups per CU still fit (no PRE fields here: the consumer forms
 // the corner ice strength and the reciprocal masses itself).
+// Array forcing on uniform / per-row metrics (FRING): the eight forcing values of a stage-row -- top stress, own and cross component of
+// the ocean velocity, free-drift velocity, at the u point and at the v point -- travel through the ring as well (fields 10 .. 17, no
+// PRE fields: 18 x 4 x 512 B = 36 KB per workgroup, four workgroups per CU: these instantiations are compiled for two waves per
+// SIMD and 256 registers, which also ends their scratch spills).  The consumer loaded them itself -- six to eight vector loads per
+// row on the longer wave of the pair, each a miss in the XCD's L2 like the metric planes above: the producer waited at the row
+// barrier for 28 % of every iteration (in-kernel probe).  Timing experiment without those loads at two waves per SIMD: OMIP
+// style 40.5 -> 48-49 G.  Not in the EXTRA instantiations (model.forcing arrays, immersed-flux-BC divergences, wind drag / bottom
+// stress arrays: their consumer would still load the extras, and at two waves per SIMD that measured worse: model.forcing arrays
+// 54.5 -> 50.3 G).
+#ifndef CSI_PAIR_FRING
+#define CSI_PAIR_FRING 1
+#endif
+constexpr int RF_FORCING = 8;
+enum : int { RF_FU_TAU = 10, RF_FU_WE, RF_FU_WB, RF_FU_FD, RF_FV_TAU, RF_FV_WE, RF_FV_WB, RF_FV_FD };
 constexpr int RF_PLANES = 9;
 enum : int { RF_PL_DXV = 10, RF_PL_RDYV, RF_PL_RDXU, RF_PL_DXF2, RF_PL_DYF2, RF_PL_RAZF, RF_PL_DYU, RF_PL_DYC2, RF_PL_DXC2 };
 
@@ -117,8 +131,9 @@ template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF
 __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
                                        double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p) {
-    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL;
-    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (PRE ? 13 : 10);
+    constexpr bool FRING = FORCE && !FULL && EXTRA == 0 && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
+    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
 #define peer_abort (*peer_abort_p)
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
@@ -689,6 +704,11 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 if (PRE) { ring[s0 + RF_PF * 64] = A.Pf_0; ring[s0 + RF_RMC * 64] = A.rmc_0; ring[s0 + RF_RMF * 64] = A.rmf_0; }
                 ring[s1 + RF_UN * 64] = C.un_m; ring[(AUF ? s1 : s0) + RF_VN * 64] = C.vn_x;
                 }
+                if constexpr (FRING) {
+                    // the forcing values this step used: u points of row r - 1, v points of row r - 1 (A u-first) / r (A v-first)
+                    ring[s0 + RF_FU_TAU * 64] = FA.t_tau_u; ring[s0 + RF_FU_WE * 64] = FA.b_we_u; ring[s0 + RF_FU_WB * 64] = FA.b_wb_u; ring[s0 + RF_FU_FD * 64] = FA.fd_u;
+                    ring[s0 + RF_FV_TAU * 64] = FA.t_tau_v; ring[s0 + RF_FV_WE * 64] = FA.b_we_v; ring[s0 + RF_FV_WB * 64] = FA.b_wb_v; ring[s0 + RF_FV_FD * 64] = FA.fd_v;
+                }
                 if constexpr (FULL) {
                     // the plane values this step consumed (v-point and corner planes of row r + 1, u-point and cell planes of row r)
                     ring[s0 + RF_PL_DXV * 64] = A.DXV_p; ring[s0 + RF_PL_RDYV * 64] = A.RDYV_p; ring[s0 + RF_PL_RDXU * 64] = A.RDXU_p;
@@ -813,6 +833,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     const int rlo = rstart - 1;
     unsigned mhistB = 0xffffffffu;
     double vn_delay = 0.0;                                // B u-first: v^n of row q - 1 (read one iteration earlier as row q)
+    double fvd_tau = 0.0, fvd_we = 0.0, fvd_wb = 0.0, fvd_fd = 0.0;      // FRING, B u-first: the v-point forcing values of row q - 1 likewise
     int r = rstart;
     auto bodyB = [&](auto KK) __attribute__((always_inline)) {
         if (!CSI_PAIR_HOIST || FORCE || (FULL && CSI_FULL_FENCE)) asm volatile("" : "+s"(T));
@@ -863,7 +884,20 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         if (MASK) mhistB = (mhistB << 2) | ((q >= rlo) ? bmk : 3u);           // the producer's 2-bit code of row q
         Forcing FB;
         numbers(FB);
-        if (FORCE) {
+        if constexpr (FRING) {
+            // From the ring.  u points of row q - 1: the producer's step q (slot s2).  v points: B v-first needs row q = the producer's
+            // (u-first) step q + 1 (slot s1); B u-first needs row q - 1, which the producer (v-first) had at its step q - 1 -- three
+            // iterations ago, its slot is being rewritten -- so the values of its step q are read now and used one iteration later
+            // (fvd_*), like v^n above
+            FB.t_tau_u = ring[s2 + RF_FU_TAU * 64]; FB.b_we_u = ring[s2 + RF_FU_WE * 64]; FB.b_wb_u = ring[s2 + RF_FU_WB * 64]; FB.fd_u = ring[s2 + RF_FU_FD * 64];
+            if (AUF) {
+                FB.t_tau_v = ring[s1 + RF_FV_TAU * 64]; FB.b_we_v = ring[s1 + RF_FV_WE * 64]; FB.b_wb_v = ring[s1 + RF_FV_WB * 64]; FB.fd_v = ring[s1 + RF_FV_FD * 64];
+            } else {
+                const double n0 = ring[s2 + RF_FV_TAU * 64], n1 = ring[s2 + RF_FV_WE * 64], n2 = ring[s2 + RF_FV_WB * 64], n3 = ring[s2 + RF_FV_FD * 64];
+                FB.t_tau_v = fvd_tau; FB.b_we_v = fvd_we; FB.b_wb_v = fvd_wb; FB.fd_v = fvd_fd;
+                fvd_tau = n0; fvd_we = n1; fvd_wb = n2; fvd_fd = n3;
+            }
+        } else if (FORCE) {
             // u points of row q-1, v points of row q (B v-first) / q-1 (B u-first); B's first rows of a tile only fill its
             // window: clamp their row to the array instead of running off it
             const int qm = max(q - 1, row0), qa = max(q, row0);
@@ -921,10 +955,11 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 }
 
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
-__global__ void __launch_bounds__(128, FULL ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+__global__ void __launch_bounds__(128, (FULL || (FORCE && EXTRA == 0 && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
-    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL;
-    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (PRE ? 13 : 10);
+    constexpr bool FRING = FORCE && !FULL && EXTRA == 0 && CSI_PAIR_FRING;
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
+    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ unsigned ringm[MASK ? RING_ROWS * 64 : 1];
     __shared__ double outr[(CSI_PAIR_STORES & 7) != 7 ? 2 * 5 * 64 : 1];      // stage B's results on their way to the producer's stores

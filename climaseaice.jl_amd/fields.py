@@ -52,10 +52,16 @@ class Field:
         else:
             arr = np.asarray(value, dtype=np.float64)
             dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(dst.device))
+        # torch wrote on ITS stream, the library works on its own (non-blocking) one: without this a library call issued right after
+        # a set could read the field before the copy had landed (seen once in 30-odd runs of tests/test_gpu_steps.py under load)
+        if dst.is_cuda:
+            torch.cuda.current_stream(dst.device).synchronize()
         return self
 
     def fill_parent(self, value):
         self.data.fill_(float(value))
+        if self.data.is_cuda:
+            torch.cuda.current_stream(self.data.device).synchronize()
         return self
 
 
