@@ -328,8 +328,8 @@ bool evp_array_forcing(const EvpDev& P) {
 // ... of the kinds whose values travel through the pair kernel's ring (evp_fused2.hip FRING: the instantiations without extras)
 bool evp_ring_forcing(const EvpDev& P) {
     const StressDev &t = P.top, &b = P.bot;
-    const bool t_wind = t.kind == 3 && (t.ue_kind == 2 || t.ve_kind == 2), b_tau = b.kind == 2;
-    return evp_array_forcing(P) && !P.extra && !t_wind && !b_tau;
+    (void)t; (void)b;
+    return evp_array_forcing(P) && !P.extra;      // (EXTRA 1 -- model.forcing arrays / immersed flux BCs -- keeps the consumer's own loads)
 }
 
 void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* t) {

@@ -110,9 +110,10 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 // SIMD and 256 registers, which also ends their scratch spills).  The consumer loaded them itself -- six to eight vector loads per
 // row on the longer wave of the pair, each a miss in the XCD's L2 like the metric planes above: the producer waited at the row
 // barrier for 28 % of every iteration (in-kernel probe).  Timing experiment without those loads at two waves per SIMD: OMIP
-// style 40.5 -> 48-49 G.  Not in the EXTRA instantiations (model.forcing arrays, immersed-flux-BC divergences, wind drag / bottom
-// stress arrays: their consumer would still load the extras, and at two waves per SIMD that measured worse: model.forcing arrays
-// 54.5 -> 50.3 G).
+// style 40.5 -> 48-49 G.  The wind-drag / bottom-stress-array instantiations (EXTRA 2, no free drift there) map their own eight
+// values onto the same slots.  Not in the EXTRA 1 instantiations (model.forcing arrays, immersed-flux-BC divergences: ten values --
+// one field too many for four workgroups per CU; with the extras still loaded by the consumer, at two waves per SIMD, model.forcing
+// arrays measured 54.5 -> 50.3 G).
 #ifndef CSI_PAIR_FRING
 #define CSI_PAIR_FRING 1
 #endif
@@ -131,7 +132,7 @@ template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF
 __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
                                        double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p) {
-    constexpr bool FRING = FORCE && !FULL && EXTRA == 0 && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
+    constexpr bool FRING = FORCE && !FULL && EXTRA != 1 && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
     constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
 #define peer_abort (*peer_abort_p)
@@ -706,8 +707,18 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 }
                 if constexpr (FRING) {
                     // the forcing values this step used: u points of row r - 1, v points of row r - 1 (A u-first) / r (A v-first)
+                    if constexpr (EXTRA == 2) {
+                        // wind drag / bottom stress arrays (no free drift there): top stress OR the air velocity's own component, its cross
+                        // component, bottom stress OR the ocean velocity's own component, its cross component
+                        const bool tt = T->I[FI_TOP_KIND] == 2, bt = T->I[FI_BOT_KIND] == 2;
+                        ring[s0 + RF_FU_TAU * 64] = tt ? FA.t_tau_u : FA.t_we_u; ring[s0 + RF_FU_FD * 64] = FA.t_wb_u;
+                        ring[s0 + RF_FU_WE * 64] = bt ? FA.b_tau_u : FA.b_we_u; ring[s0 + RF_FU_WB * 64] = FA.b_wb_u;
+                        ring[s0 + RF_FV_TAU * 64] = tt ? FA.t_tau_v : FA.t_we_v; ring[s0 + RF_FV_FD * 64] = FA.t_wb_v;
+                        ring[s0 + RF_FV_WE * 64] = bt ? FA.b_tau_v : FA.b_we_v; ring[s0 + RF_FV_WB * 64] = FA.b_wb_v;
+                    } else {
                     ring[s0 + RF_FU_TAU * 64] = FA.t_tau_u; ring[s0 + RF_FU_WE * 64] = FA.b_we_u; ring[s0 + RF_FU_WB * 64] = FA.b_wb_u; ring[s0 + RF_FU_FD * 64] = FA.fd_u;
                     ring[s0 + RF_FV_TAU * 64] = FA.t_tau_v; ring[s0 + RF_FV_WE * 64] = FA.b_we_v; ring[s0 + RF_FV_WB * 64] = FA.b_wb_v; ring[s0 + RF_FV_FD * 64] = FA.fd_v;
+                    }
                 }
                 if constexpr (FULL) {
                     // the plane values this step consumed (v-point and corner planes of row r + 1, u-point and cell planes of row r)
@@ -889,13 +900,23 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             // (u-first) step q + 1 (slot s1); B u-first needs row q - 1, which the producer (v-first) had at its step q - 1 -- three
             // iterations ago, its slot is being rewritten -- so the values of its step q are read now and used one iteration later
             // (fvd_*), like v^n above
-            FB.t_tau_u = ring[s2 + RF_FU_TAU * 64]; FB.b_we_u = ring[s2 + RF_FU_WE * 64]; FB.b_wb_u = ring[s2 + RF_FU_WB * 64]; FB.fd_u = ring[s2 + RF_FU_FD * 64];
+            const double u0 = ring[s2 + RF_FU_TAU * 64], u1 = ring[s2 + RF_FU_WE * 64], u2 = ring[s2 + RF_FU_WB * 64], u3 = ring[s2 + RF_FU_FD * 64];
+            double v0, v1, v2, v3;
             if (AUF) {
-                FB.t_tau_v = ring[s1 + RF_FV_TAU * 64]; FB.b_we_v = ring[s1 + RF_FV_WE * 64]; FB.b_wb_v = ring[s1 + RF_FV_WB * 64]; FB.fd_v = ring[s1 + RF_FV_FD * 64];
+                v0 = ring[s1 + RF_FV_TAU * 64]; v1 = ring[s1 + RF_FV_WE * 64]; v2 = ring[s1 + RF_FV_WB * 64]; v3 = ring[s1 + RF_FV_FD * 64];
             } else {
                 const double n0 = ring[s2 + RF_FV_TAU * 64], n1 = ring[s2 + RF_FV_WE * 64], n2 = ring[s2 + RF_FV_WB * 64], n3 = ring[s2 + RF_FV_FD * 64];
-                FB.t_tau_v = fvd_tau; FB.b_we_v = fvd_we; FB.b_wb_v = fvd_wb; FB.fd_v = fvd_fd;
+                v0 = fvd_tau; v1 = fvd_we; v2 = fvd_wb; v3 = fvd_fd;
                 fvd_tau = n0; fvd_we = n1; fvd_wb = n2; fvd_fd = n3;
+            }
+            if constexpr (EXTRA == 2) {      // (the producer's mapping, above)
+                if (T->I[FI_TOP_KIND] == 2) { FB.t_tau_u = u0; FB.t_tau_v = v0; } else { FB.t_we_u = u0; FB.t_we_v = v0; }
+                FB.t_wb_u = u3; FB.t_wb_v = v3;
+                if (T->I[FI_BOT_KIND] == 2) { FB.b_tau_u = u1; FB.b_tau_v = v1; } else { FB.b_we_u = u1; FB.b_we_v = v1; }
+                FB.b_wb_u = u2; FB.b_wb_v = v2;
+            } else {
+                FB.t_tau_u = u0; FB.b_we_u = u1; FB.b_wb_u = u2; FB.fd_u = u3;
+                FB.t_tau_v = v0; FB.b_we_v = v1; FB.b_wb_v = v2; FB.fd_v = v3;
             }
         } else if (FORCE) {
             // u points of row q-1, v points of row q (B v-first) / q-1 (B u-first); B's first rows of a tile only fill its
@@ -955,9 +976,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 }
 
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
-__global__ void __launch_bounds__(128, (FULL || (FORCE && EXTRA == 0 && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+__global__ void __launch_bounds__(128, (FULL || (FORCE && EXTRA != 1 && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
-    constexpr bool FRING = FORCE && !FULL && EXTRA == 0 && CSI_PAIR_FRING;
+    constexpr bool FRING = FORCE && !FULL && EXTRA != 1 && CSI_PAIR_FRING;
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
     constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
