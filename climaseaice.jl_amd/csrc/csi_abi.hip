@@ -84,7 +84,7 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
         auto env_int = [](const char* name) { const char* e = getenv(name); return (e && *e) ? atoi(e) : -1; };
         c->tune.fused_rows = env_int("CSI_FUSED_ROWS"); c->tune.pair_tiles = env_int("CSI_PAIR_TILES");
         c->tune.pair_minrows = env_int("CSI_PAIR_MINROWS"); c->tune.pair_rows = env_int("CSI_PAIR_ROWS");
-        c->tune.pair_common = env_int("CSI_PAIR_COMMON");
+        c->tune.pair_common = env_int("CSI_PAIR_COMMON"); c->tune.no_geom_sig = env_int("CSI_DEBUG_NO_GEOM_SIG");
         c->tune.peer_edge = env_int("CSI_PEER_EDGE");          // rows the chunks next to a peer-connected y side are shorter by (default 4; 0: uniform chunks)
         c->tune.write_through = env_int("CSI_WRITE_THROUGH");  // 0 / 1: never / always store the pair kernel's results write-through (default: by grid size)
         c->tune.peer_kernel = env_int("CSI_PEER_KERNEL");      // 1: untiled grids run the PEER instantiation of the pair kernel (no neighbour, no waits): what the instantiation itself costs

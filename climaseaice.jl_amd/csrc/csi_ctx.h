@@ -128,6 +128,7 @@ struct csi_context {
         int ny_below = 0;                    // rows of the tile below (all tiles of a decomposition have this tile's UNCUT height)
         bool ready = false, failed = false;  // set up (collectively) / cannot be set up (stays on RCCL)
         const void* sig[NARR] = {};          // the local arrays the set-up was made for
+        int set_sig[8] = {};                 // ... and the sizes of this rank's tile sets then (the launch geometry depends on the forcing kinds too)
         int img_rank[8], sync_rank[8];       // per direction: the rank whose arrays receive this tile's images there; the neighbour to wait for (-1: none)
         void* arr[8][NARR] = {};             // that rank's arrays as this process addresses them
         unsigned long long* nbr_slots[8] = {};   // its flag array
@@ -186,7 +187,9 @@ struct csi_context {
     int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
     int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
-    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1; } tune;
+    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
+                    no_geom_sig = -1;      // debugging aid (CSI_DEBUG_NO_GEOM_SIG=1): skip the launch-geometry check of the peer set-up (tests/test_gpu_local_tiles.py)
+    } tune;
 };
 
 namespace csi_host {

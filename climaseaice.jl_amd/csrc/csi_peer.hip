@@ -128,7 +128,7 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         r.local_ptr = (uint64_t)ptr;
         if (q == 0 && local_ok) {
             const PeerSets ps = peer_my_sets(c);
-            for (int d = 0; d < 8; ++d) { r.set_size[d] = ps.size[d]; if (ps.size[d] >= csi_context::Peer::SLOTS) ok = 0; }
+            for (int d = 0; d < 8; ++d) { r.set_size[d] = ps.size[d]; pr.set_sig[d] = ps.size[d]; if (ps.size[d] >= csi_context::Peer::SLOTS) ok = 0; }
         }
         if (ok && c->world > 1 && !c->local) {               // (a single rank / an in-process group addresses the arrays directly)
             hipDeviceptr_t base = nullptr; size_t size = 0;
@@ -241,6 +241,13 @@ int32_t peer_decide(csi_context* c, const EvpDev& P, int substeps, bool* use) {
     peer_local_arrays(c, local);
     bool same = pr.ready;
     for (int q = 0; q < csi_context::Peer::NARR && same; ++q) same = pr.sig[q] == local[q];
+    if (same && local_ok && c->tune.no_geom_sig <= 0) {
+        // the neighbours wait for as many flags as this rank's tile sets had at set-up: a launch geometry that has changed since
+        // (the tile count follows the forcing kinds: array forcing bound after the first sub-cycle) needs a new set-up -- on every
+        // rank, like a re-bound array (the model's configuration is the same on all of them)
+        const PeerSets now = peer_my_sets(c);
+        for (int d = 0; d < 8 && same; ++d) same = now.size[d] == pr.set_sig[d];
+    }
     if (!same && (rc = peer_setup(c, local_ok))) return rc;
     *use = pr.ready && local_ok;
     return CSI_OK;

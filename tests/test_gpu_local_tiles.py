@@ -236,3 +236,53 @@ def test_whole_time_step_with_snow_on_2x2_tiles(stepper, k):
             w = want[f][j0:j0 + ny, i0:i0 + nx]
             g_ = got[f][:ny, :nx]
             assert np.array_equal(w, g_), (rank, f, np.abs(w - g_).max(), np.argwhere(w != g_)[:4].tolist())
+
+
+def test_peer_transport_follows_a_change_of_the_forcing_kinds():
+    """The pair kernel's tile count depends on the forcing kinds (array forcing: 1024 tiles at two waves per SIMD), and the neighbours
+    wait for as many flags as a rank's tile sets had when the peer transport was set up: binding array forcing AFTER the first
+    sub-cycle must lead to a new (collective) set-up, not to waits that time out.  2 x 1 tiles, peer transport, number-valued forcing
+    for one sub-cycle, then wind-stress and ocean-velocity arrays: tiled == untiled bit for bit after each."""
+    from climaseaice_jl_amd import _lib
+    # (512 x 2560 tiles: 10 strips x 153 chunks of 17 rows without array forcing, x 102 chunks of 26 rows with it -- small grids have
+    #  the same geometry either way)
+    Rx, Ry = 2, 1
+    kw = dict(Nx=1024, Ny=2560, topo=("periodic", "bounded"), land=0.2)
+    c0 = cases.make_case(H=8, substeps=6, patches=True, random_uv=0.05, **kw)
+    c1 = cases.make_case(H=8, substeps=6, patches=True, random_uv=0.05, field_forcing=True, **kw)
+
+    def switch(m, tile_grid=None):
+        loc = (lambda a, lx, ly: a) if tile_grid is None else tile_grid.local_interior
+        m._set_stress(_lib.STRESS_TOP, (loc(c1["top_u"], csi.Face, csi.Center), loc(c1["top_v"], csi.Center, csi.Face)), "TOP")
+        m._set_stress(_lib.STRESS_BOTTOM, csi.SemiImplicitStress(ue=loc(c1["ue_f"], csi.Face, csi.Center), ve=loc(c1["ve_f"], csi.Center, csi.Face)), "BOT")
+
+    def fields(m):
+        return {f: EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
+
+    ref = cases.csi_model(c0, mode="fast")
+    csi.time_step_momentum(ref, c0["dt"]); ref.synchronize()
+    want0 = fields(ref)
+    switch(ref)
+    csi.time_step_momentum(ref, c0["dt"]); ref.synchronize()
+    want1 = fields(ref)
+    assert not np.array_equal(want0["u"], want1["u"])
+
+    def tile(rank, group):
+        m = cases.csi_model(c0, mode="fast", tile=(Rx, Ry, rank), local_group=group)
+        m.set_exchange_interval(0)
+        csi.time_step_momentum(m, c0["dt"]); m.synchronize()
+        a = fields(m)
+        switch(m, m.grid)
+        csi.time_step_momentum(m, c0["dt"]); m.synchronize()
+        b = fields(m)
+        g = m.grid
+        res = dict(a=a, b=b, offsets=(g.i_off, g.j_off, g.Nx, g.Ny), transport=m.ctx.halo_transport())
+        del m
+        return res
+
+    for rank, d in enumerate(run_tile_threads(Rx * Ry, tile)):
+        assert d["transport"] == "peer", d["transport"]
+        i0, j0, nx, ny = d["offsets"]
+        for got, want, what in ((d["a"], want0, "numbers"), (d["b"], want1, "arrays")):
+            for f in want:
+                assert np.array_equal(got[f][:ny, :nx], want[f][j0:j0 + ny, i0:i0 + nx]), (what, rank, f)
