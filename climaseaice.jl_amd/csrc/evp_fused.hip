@@ -329,7 +329,7 @@ bool evp_array_forcing(const EvpDev& P) {
 bool evp_ring_forcing(const EvpDev& P) {
     const StressDev &t = P.top, &b = P.bot;
     (void)t; (void)b;
-    return evp_array_forcing(P) && !P.extra;      // (EXTRA 1 -- model.forcing arrays / immersed flux BCs -- keeps the consumer's own loads)
+    return evp_array_forcing(P) && (!P.extra || !P.g.has_mask);      // (EXTRA 1 on a masked grid -- immersed flux BCs -- keeps the consumer's own loads)
 }
 
 void fused_fill_extra(const EvpDev& P, const FRef& xd_u, const FRef& xd_v, FusedTable* t) {

@@ -111,9 +111,8 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 // row on the longer wave of the pair, each a miss in the XCD's L2 like the metric planes above: the producer waited at the row
 // barrier for 28 % of every iteration (in-kernel probe).  Timing experiment without those loads at two waves per SIMD: OMIP
 // style 40.5 -> 48-49 G.  The wind-drag / bottom-stress-array instantiations (EXTRA 2, no free drift there) map their own eight
-// values onto the same slots.  Not in the EXTRA 1 instantiations (model.forcing arrays, immersed-flux-BC divergences: ten values --
-// one field too many for four workgroups per CU; with the extras still loaded by the consumer, at two waves per SIMD, model.forcing
-// arrays measured 54.5 -> 50.3 G).
+// values onto the same slots, and so do model.forcing arrays on unmasked grids (EXTRA 1 without MASK: in the free-drift slots).  Not
+// with immersed-flux-BC divergences (EXTRA 1 with MASK: ten values and the mask rows -- more than four workgroups per CU hold).
 #ifndef CSI_PAIR_FRING
 #define CSI_PAIR_FRING 1
 #endif
@@ -132,7 +131,7 @@ template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF
 __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
                                        double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p) {
-    constexpr bool FRING = FORCE && !FULL && EXTRA != 1 && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
+    constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
     constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
 #define peer_abort (*peer_abort_p)
@@ -716,8 +715,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                         ring[s0 + RF_FV_TAU * 64] = tt ? FA.t_tau_v : FA.t_we_v; ring[s0 + RF_FV_FD * 64] = FA.t_wb_v;
                         ring[s0 + RF_FV_WE * 64] = bt ? FA.b_tau_v : FA.b_we_v; ring[s0 + RF_FV_WB * 64] = FA.b_wb_v;
                     } else {
-                    ring[s0 + RF_FU_TAU * 64] = FA.t_tau_u; ring[s0 + RF_FU_WE * 64] = FA.b_we_u; ring[s0 + RF_FU_WB * 64] = FA.b_wb_u; ring[s0 + RF_FU_FD * 64] = FA.fd_u;
-                    ring[s0 + RF_FV_TAU * 64] = FA.t_tau_v; ring[s0 + RF_FV_WE * 64] = FA.b_we_v; ring[s0 + RF_FV_WB * 64] = FA.b_wb_v; ring[s0 + RF_FV_FD * 64] = FA.fd_v;
+                    // (EXTRA 1 without a mask: model.forcing arrays -- no free drift, no immersed-flux term there -- in the free-drift slots)
+                    ring[s0 + RF_FU_TAU * 64] = FA.t_tau_u; ring[s0 + RF_FU_WE * 64] = FA.b_we_u; ring[s0 + RF_FU_WB * 64] = FA.b_wb_u; ring[s0 + RF_FU_FD * 64] = EXTRA == 1 ? FA.xc_u : FA.fd_u;
+                    ring[s0 + RF_FV_TAU * 64] = FA.t_tau_v; ring[s0 + RF_FV_WE * 64] = FA.b_we_v; ring[s0 + RF_FV_WB * 64] = FA.b_wb_v; ring[s0 + RF_FV_FD * 64] = EXTRA == 1 ? FA.xc_v : FA.fd_v;
                     }
                 }
                 if constexpr (FULL) {
@@ -915,8 +915,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 if (T->I[FI_BOT_KIND] == 2) { FB.b_tau_u = u1; FB.b_tau_v = v1; } else { FB.b_we_u = u1; FB.b_we_v = v1; }
                 FB.b_wb_u = u2; FB.b_wb_v = v2;
             } else {
-                FB.t_tau_u = u0; FB.b_we_u = u1; FB.b_wb_u = u2; FB.fd_u = u3;
-                FB.t_tau_v = v0; FB.b_we_v = v1; FB.b_wb_v = v2; FB.fd_v = v3;
+                FB.t_tau_u = u0; FB.b_we_u = u1; FB.b_wb_u = u2;
+                FB.t_tau_v = v0; FB.b_we_v = v1; FB.b_wb_v = v2;
+                if (EXTRA == 1) { FB.xc_u = u3; FB.xc_v = v3; } else { FB.fd_u = u3; FB.fd_v = v3; }
             }
         } else if (FORCE) {
             // u points of row q-1, v points of row q (B v-first) / q-1 (B u-first); B's first rows of a tile only fill its
@@ -976,9 +977,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 }
 
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
-__global__ void __launch_bounds__(128, (FULL || (FORCE && EXTRA != 1 && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+__global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
-    constexpr bool FRING = FORCE && !FULL && EXTRA != 1 && CSI_PAIR_FRING;
+    constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
     constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
