@@ -486,7 +486,6 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
         if (wrap_lo | ylo_wall) fast_lo = max(fast_lo, HyW + 2);                // rows q-1 .. q clear of the low image rows 1 .. H
         if (wrap_hi | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);              // ... and of the high ones N-H+1 .. N
-        if (!lanes_same) fast_hi = fast_lo - 1;
     }
     const bool fast_plain = lanes_uniform;                // no lane of the wave has an x image either
     // Stage B's results of row q (sigma(q); first velocity v(q) / u(q-1); second velocity u(q-1) / v(q-1)) go to memory from
@@ -503,20 +502,24 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         if (which == 0) return;
         if ((q >= fast_lo) & (q <= fast_hi)) {
             // interior rows (nearly every call): every kind of store is due, no row has a y image
-            if (flags & L_RS) {
-                const unsigned ocq = offc(q), ofq = offf(q);
-                if (fast_plain) {
-                    // interior tile: the owned lanes store five values, no images
+            const unsigned ocq = offc(q), ofq = offf(q);
+            if (fast_plain) {
+                // interior tile: the owned lanes store five values, no images
+                if (flags & L_RS) {
                     if (which & 1) { sto(T->P[FP_S11_OUT], ocq, v11); sto(T->P[FP_S22_OUT], ocq, v22); sto(T->P[FP_S12_OUT], ofq, v12); }
                     if (which & 2) sto(T->P[VF ? FP_V_OUTP : FP_U_OUTP], VF ? ocq : ofq - sf, vfirst);
                     if (which & 4) sto(T->P[VF ? FP_U_OUTP : FP_V_OUTP], VF ? ofq - sf : ocq - sc, vsecond);
-                } else {
-                    // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap / the
-                    // neighbouring tile's halo; v mirrors / reflects across an x wall), none of the row bookkeeping of the general path
-                    if (which & 1) { put(0, ocq, 0u, false, dx, v11, q, 0); put(1, ocq, 0u, false, dx, v22, q, 0); put(2, ofq, 0u, false, dx, v12, q, 0); }
-                    if (VF) { if (which & 2) put_v(ocq, 0u, false, vfirst, q, 0); if (which & 4) put(3, ofq - sf, 0u, false, dx, vsecond, q - 1, 0); }
-                    else { if (which & 2) put(3, ofq - sf, 0u, false, dx, vfirst, q - 1, 0); if (which & 4) put_v(ocq - sc, 0u, false, vsecond, q - 1, 0); }
                 }
+            } else {
+                // tile on an x edge of the domain: some lanes also store the x image of their column (periodic wrap / the
+                // neighbouring tile's halo; v mirrors / reflects across an x wall), none of the row bookkeeping of the general path.
+                // Each kind of store under its own lane flag: next to an x wall the three column ranges differ (the face ON the
+                // wall is no u to store), and such a strip took the general path for every row -- the east strip of a Bounded grid
+                // 25 % longer than the others, which set the launch's end (bounded 2048^2: 147 us against 125 for the interior strips)
+                const bool ls = (flags & L_RS) != 0, l1 = (flags & L_R1) != 0, l2 = (flags & L_R2) != 0;
+                if ((which & 1) && ls) { put(0, ocq, 0u, false, dx, v11, q, 0); put(1, ocq, 0u, false, dx, v22, q, 0); put(2, ofq, 0u, false, dx, v12, q, 0); }
+                if (VF) { if ((which & 2) && l1) put_v(ocq, 0u, false, vfirst, q, 0); if ((which & 4) && l2) put(3, ofq - sf, 0u, false, dx, vsecond, q - 1, 0); }
+                else { if ((which & 2) && l1) put(3, ofq - sf, 0u, false, dx, vfirst, q - 1, 0); if ((which & 4) && l2) put_v(ocq - sc, 0u, false, vsecond, q - 1, 0); }
             }
             return;
         }
@@ -791,8 +794,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             fast_hi = min(rs_hi, min(r1_hi + d1, r2_hi + 1));
             if (wrap_lo | ylo_wall) fast_lo = max(fast_lo, HyW + 2);
             if (wrap_hi | yhi_wall) fast_hi = min(fast_hi, NyW - HyW);
-            if (!lanes_same) fast_hi = fast_lo - 1;
-        }
+            }
         for (int r = rstart; r <= rend; ++r) {
             __syncthreads();                              // the producer has finished row r
             const unsigned s0 = rslot(r), s1 = rslot(r - 1);

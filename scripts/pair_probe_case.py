@@ -11,6 +11,7 @@ import cases
 # case -> (make_case arguments, translation unit of its pair-kernel instantiation: CSI_PAIR_VARIANT)
 KW = {"twelve": (dict(topo=("periodic", "bounded"), curvilinear=0.05), 1),
       "channel": (dict(topo=("periodic", "bounded")), 1),
+      "bounded": (dict(topo=("bounded", "bounded")), 1),
       "coupled": (dict(topo=("periodic", "periodic"), field_forcing=True), 3),
       "omip": (dict(topo=("periodic", "bounded"), land=0.3, field_forcing=True, free_drift=True), 6),
       "tripolar": (dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True), 6)}
@@ -44,3 +45,8 @@ for role in (0, 1):
     print("   sum %.0f cycles per iteration; wave lifetime mean %.1f us (min %.1f max %.1f); kernel span %.1f us"
           % (tot, (w1 - w0).mean() / 100, (w1 - w0).min() / 100, (w1 - w0).max() / 100, (w1.max() - w0.min()) / 100))
     print("   lifetime percentiles (us):", np.percentile((w1 - w0) / 100, [0, 5, 25, 50, 75, 90, 95, 99, 100]).round(1))
+    nstr = -(-(N + 2) // 56)
+    life = (w1 - w0) / 100
+    strip = np.arange(len(life)) % nstr
+    print("   mean lifetime by strip (us):", np.array([life[strip == s_].mean() for s_ in range(nstr)]).round(0))
+    print("   end time by strip (us):", np.array([(w1[strip == s_].max() - w0.min()) / 100 for s_ in range(nstr)]).round(0))
