@@ -1,5 +1,7 @@
 #!/bin/bash
 # PC sampling of one bench_cases configuration (rocprofv3 beta feature): scripts/pc_sample.sh <tag> <case substring> [method] [interval]
+# NOT available on this pool (round 4: `rocprofv3-avail list --pc-sampling` names no agent, rocprofv3 answers "configuration is not supported
+# on any of the agents"); kept for a box that has it.  The in-kernel probes (pair_probe.py, pair_probe_case.py) stand in for it.
 TAG=$1; CASE=$2; METHOD=${3:-host_trap}; INT=${4:-200}
 UNIT=time; [ "$METHOD" = stochastic ] && UNIT=cycles
 cd /tmp && export TMPDIR=/tmp
