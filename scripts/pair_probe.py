@@ -12,7 +12,8 @@ import climaseaice_jl_amd as csi
 
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ny = int(sys.argv[2]) if len(sys.argv) > 2 else nx
-tg, f = bench.local_case(csi, np, nx, ny, 1, 1, 0, force_connected=False, halo=4)
+FC = (False, True) if (len(sys.argv) > 4 and sys.argv[4] == "peer-y") else False
+tg, f = bench.local_case(csi, np, nx, ny, 1, 1, 0, force_connected=FC, halo=4)
 dyn = csi.SeaIceMomentumEquation(tg, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
                                  top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
                                  solver=csi.SplitExplicitSolver(substeps=int(sys.argv[3]) if len(sys.argv) > 3 else 12), device="cuda:0")
