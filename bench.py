@@ -259,6 +259,15 @@ def counters():
         return None
 
 
+def isa_mix():
+    """Instruction mix of the dominant kernel's row loops from its ISA listing (scripts/isa_mix.py -> profiles/isa_mix_k_pair.json)."""
+    f = os.path.join(ROOT, "profiles", "isa_mix_k_pair.json")
+    try:
+        return json.load(open(f))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +298,10 @@ def main():
                          "host-channel group (shared memory + HIP IPC; RCCL refuses two ranks on one device) and gloo; every step of the N > 1 "
                          "path runs -- launcher, peer set-up over IPC, tier ladder, tiled == untiled check, timing, the JSON line -- but the "
                          "numbers are those of N processes SHARING one GPU: the line says `rehearsal_on_one_gpu` and is not a scaling result")
+    ap.add_argument("--peer-tier", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="tiles on the peer transport: the memory-ordering tier the ladder STARTS at (-1: the library's automatic choice -- tier 1 "
+                         "across processes / devices; 0 is the explicit opt-in to the fence-free protocol, timed as `peer_tier0` otherwise)")
+    ap.add_argument("--no-second-partition", action="store_true", help="N > 1: do not time the other decomposition (2x4-style vs y slabs) after the headline")
     ap.add_argument("--partition", type=str, default="", help="RxxRy tiles instead of the default y slabs (e.g. 2x4: BASELINE config 4's decomposition); Rx * Ry = --gpus")
     ap.add_argument("--no-unfused", action="store_true", help="one GPU: do not time the unfused three-kernel path (roofline.unfused) after the headline")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
@@ -361,20 +374,23 @@ def main():
 
     nonlocal_builds = [0]
 
-    def build(transport):
+    def build(transport, part=None):
         """This rank's tile model.  Tiles: the peer transport needs the halo 4 of an untiled run; the RCCL exchange amortises its
-        pack / send / unpack over k = 16 sub-steps with halo 32."""
+        pack / send / unpack over k = 16 sub-steps with halo 32.  part = (Rx, Ry, nx, ny): another decomposition of the same grid."""
         halo = user_halo or (4 if (not tiled or transport == "peer") else 32)
-        grid, fld = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, force_connected=args.force_connected, halo=halo)
+        pRx, pRy, pnx, pny = part or (Rx, Ry, nx_l, ny_l)
+        grid, fld = local_case(csi, np, pnx, pny, pRx, pRy, rank, force_connected=args.force_connected, halo=halo)
         if rehearsal:
             nonlocal_builds[0] += 1
             # (a fresh segment per model -- every rank builds its models in the same order; without the parent the name comes from
             #  the rendezvous port, which is the same on every rank of a job)
-            base = os.environ.get("CSI_BENCH_HOST_GROUP") or f"/csi-bench-{os.environ.get('MASTER_PORT', '0')}"
+            base = os.environ.get("CSI_BENCH_HOST_GROUP") or f"/csi-bench-{os.environ.get('MASTER_PORT', '0')}-{os.getppid()}"      # (the ranks of one launcher share their parent: no name of an earlier job)
             grid.host_group = f"{base}-{nonlocal_builds[0]}"
         m = make_model(grid)
         m.set_exchange_interval(args.exchange_interval)
         m.set_halo_transport(transport)
+        if args.peer_tier >= 0:
+            m.set_peer_tier(args.peer_tier)
         m.set_fusion(0 if args.no_fusion else args.fusion_level)
         csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
         return grid, fld, m, halo
@@ -395,13 +411,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(nsteps):
+    region = {}
+
+    def timed(nsteps, stats=False):
+        """K steps between two barriers, max over the ranks.  stats: HIP events around every sub-step loop INSIDE this region
+        (csi_subcycle_stats_*): the dominant kernel's average launch time then comes from the timed launches themselves."""
         barrier()
+        if stats:
+            model.ctx.subcycle_stats_begin()
         t0 = time.perf_counter()
         for _ in range(nsteps):
             csi.time_step_momentum(model, dt)
         barrier()
-        return max_over_ranks(time.perf_counter() - t0)
+        e = max_over_ranks(time.perf_counter() - t0)
+        if stats:
+            tot, ncyc, nl = model.ctx.subcycle_stats_end()
+            region.update(total_ms=tot, cycles=ncyc, launches=nl)
+        return e
 
     def all_ranks(flag):
         """logical AND over the ranks"""
@@ -422,18 +448,22 @@ def main():
         for name in sig:
             getattr(m.dynamics.auxiliaries.fields, name).data.zero_()
 
-    def tile_matches_whole():
-        """One sub-cycle from the same state on the tiles and on the whole grid: owned cells bitwise equal (all ranks agree)."""
-        restart(whole, gf)
-        restart(model, f)
+    def tile_matches_whole(m=None, grid=None, fld=None, gfld=None):
+        """One sub-cycle from the same state on the tiles and on the whole grid: owned cells bitwise equal (all ranks agree).
+        (gfld: the global state assembled from THAT decomposition's tiles -- the noise of the inputs is seeded per tile.)"""
+        m = model if m is None else m
+        grid = tg if grid is None else grid
+        fld = f if fld is None else fld
+        restart(whole, gf if gfld is None else gfld)
+        restart(m, fld)
         csi.time_step_momentum(whole, dt)
-        csi.time_step_momentum(model, dt)
-        model.synchronize(); whole.synchronize()
+        csi.time_step_momentum(m, dt)
+        m.synchronize(); whole.synchronize()
         same = True
-        for name, tf, wf in [("u", model.velocities.u, whole.velocities.u), ("v", model.velocities.v, whole.velocities.v)] + \
-                            [(n, getattr(model.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in sig]:
-            mine = tf.interior_numpy()[:ny_l, :nx_l]
-            ref = wf.interior_numpy()[tg.j_off:tg.j_off + ny_l, tg.i_off:tg.i_off + nx_l]
+        for name, tf, wf in [("u", m.velocities.u, whole.velocities.u), ("v", m.velocities.v, whole.velocities.v)] + \
+                            [(n, getattr(m.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in sig]:
+            mine = tf.interior_numpy()[:grid.Ny, :grid.Nx]
+            ref = wf.interior_numpy()[grid.j_off:grid.j_off + grid.Ny, grid.i_off:grid.i_off + grid.Nx]
             same = same and bool(np.array_equal(mine, ref))
         return same
 
@@ -445,7 +475,11 @@ def main():
         gf = global_fields(np, nx_l, ny_l, Rx, Ry)
     transport_note = None
     bitwise = None
-    peer_tier = 0                 # run-time ladder of the peer protocol (include/csi.h, csi_set_peer_tier): 0 -> 1 -> 2 -> RCCL exchange
+    # run-time ladder of the peer protocol (include/csi.h, csi_set_peer_tier): it starts at the tier the library chooses by itself (1
+    # as soon as a neighbour lives in another process or on another device; --peer-tier overrides) and goes up to 2, then to the RCCL
+    # exchange.  A BITWISE mismatch raises the tier; a library error (a wait that timed out: sticky, the flags cannot recover) goes
+    # straight to the RCCL exchange on freshly built models.
+    peer_tier = None
     ladder = []
     peer_expected = tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
         and not args.no_fusion and args.fusion_level >= 2 and nx_l >= 128
@@ -453,6 +487,9 @@ def main():
         # warm-up, then (N > 1) the bitwise check -- before anything is timed.  A peer transport that cannot be set up (the library
         # then runs RCCL by itself), times out or gives another answer than one GPU is replaced by the RCCL exchange on ALL ranks.
         problem = None
+        lib_error = False
+        if peer_tier is None and tiled:
+            peer_tier = model.ctx.peer_tier()
         try:
             for _ in range(args.warmup):
                 csi.time_step_momentum(model, dt)
@@ -465,12 +502,13 @@ def main():
                     problem = "the tiled run did not reproduce the one-GPU run bit for bit"
         except csi.CsiError as e:
             problem = f"library error: {e}"
+            lib_error = True
         on_peer = tiled and model.ctx.halo_transport() == "peer"
         if on_peer:
             ladder.append({"tier": peer_tier, "passed": problem is None, "problem": problem})
         if all_ranks(problem is None):
             break
-        if all_ranks(on_peer) and peer_tier < 2:
+        if all_ranks(on_peer) and all_ranks(not lib_error) and peer_tier < 2:
             # every rank is on the peer transport and some rank's check failed: the next tier of its memory-ordering protocol, on ALL ranks
             peer_tier += 1
             sys.stderr.write(f"bench.py[rank {rank}]: peer transport, tier {peer_tier - 1}: {problem or 'another rank reported a problem'}; trying tier {peer_tier}\n")
@@ -492,7 +530,7 @@ def main():
     # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
     # below is the last thing this process writes
     ctypes.CDLL(None).fflush(None)
-    elapsed = timed(args.steps)
+    elapsed = timed(args.steps, stats=True)
 
     owned = nx_l * ny_l * world
     value = owned * args.substeps * args.steps / elapsed
@@ -535,6 +573,17 @@ def main():
     else:
         dom = max(("stress", "ustep", "vstep"), key=lambda k: phases[k])
         sub_ms = phases["stress"] + phases["ustep"] + phases["vstep"]
+    # The dominant kernel's average launch time comes from the TIMED region (round 5): HIP events around every sub-step loop of the
+    # K timed steps, divided by the launches inside them -- so that launches x average <= ms_per_step holds by construction.  The
+    # figure of the separate profiling pass above (a short run behind the timed region, 10-15 % colder) stays in the line as
+    # `profile_pass_launch_ms`; the three-kernel paths, whose loops mix three kernels, keep their per-kernel events.
+    profile_pass_ms = phases[dom]
+    launch_src = "csi_profile_substeps: a separate pass of 32 sub-steps behind the timed region"
+    if path["fused"] and region.get("launches"):
+        phases[dom] = region["total_ms"] / region["launches"]
+        sub_ms = phases[dom] / spl
+        launch_src = (f"HIP events around the sub-step loops of the {region['cycles']} TIMED steps: {region['total_ms']:.3f} ms / "
+                      f"{region['launches']} launches")
     launch_s = phases[dom] * 1e-3
     # roofline.achieved: the kernel's compulsory HBM bytes per launch (owned cells; ring re-reads and the extra cells of a
     # tile's valid-halo ring are overhead, not counted) / its average launch duration from HIP events on the launch stream
@@ -547,7 +596,10 @@ def main():
             "traffic": None, "traffic_source": None,
             "kernel": KERNEL_NAMES[dom] if args.mode == "fast" else dom,
             "kernel_bytes_per_launch": kernel_bytes, "kernel_bytes_per_cell": KERNEL_BYTES[dom],
-            "avg_launch_ms": phases[dom], "substeps_per_launch": spl, "all_phases_ms": phases,
+            "avg_launch_ms": phases[dom], "avg_launch_source": launch_src, "profile_pass_launch_ms": profile_pass_ms,
+            "launches_per_step": (region["launches"] / region["cycles"]) if region.get("cycles") else None,
+            "launches_x_avg_ms": (region["total_ms"] / region["cycles"]) if region.get("cycles") else None,
+            "substeps_per_launch": spl, "all_phases_ms": phases,
             "algorithmic_bytes_per_launch": cells_launch * (256.0 * spl if path["fused"] else ALGO_BYTES[dom]),
             "algorithmic_frac": algorithmic_rate / HBM_PEAK_GBS,
             "algorithmic_note": "SURVEY.md 8(d): 256 B per cell-update of the unfused stress / u / v split; above 1 = traffic removed by fusion",
@@ -597,6 +649,25 @@ def main():
             roof["fp64_issue_frac"] = ctr["valu_insts_per_launch"] * FP64_ISSUE_NS * 1e-9 / 1024.0 / launch_s
             roof["fp64_issue_note"] = (f"{ctr['valu_insts_per_launch'] / 1e6:.1f} M vector instructions per launch x {FP64_ISSUE_NS} ns (measured FP64 issue interval per SIMD, "
                                        "profiles/r01_microbenchmarks.md) / 1024 SIMDs / this run's launch time")
+            dyn = ctr.get("valu_mix_per_launch")
+            if dyn:
+                # the same from the DYNAMIC mix (PMC pass SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64, same committed counter run): every
+                # class at its measured issue interval (profiles/r01_microbenchmarks.md): fma / mul 2.29 ns, add 2.00, transcendental
+                # (v_rcp_f64 / v_rsq_f64) 7.03, integer 1.31, the rest (DPP shifts, compares, selects, 64-bit moves) 2.0
+                w = {"fma_f64": 2.29, "mul_f64": 2.29, "add_f64": 2.00, "trans_f64": 7.03, "int32": 1.31, "int64": 1.79, "other": 2.0}
+                busy_ns = sum(dyn.get(k, 0.0) * w[k] for k in w)
+                roof["fp64_issue_frac_dynamic"] = busy_ns * 1e-9 / 1024.0 / launch_s
+                roof["fp64_issue_dynamic_mix"] = {"per_launch": dyn, "issue_ns": w}
+            mix = isa_mix()
+            if mix and mix.get("kernel") == dom:
+                # the same with every class of vector instruction at ITS measured issue interval (profiles/r01_microbenchmarks.md
+                # `valu_rate` at >= 2 waves per SIMD): v_rcp_f64 / v_rsq_f64 take 7.03 ns, FP64 fma / mul 2.29, add 2.00, max / min /
+                # compares 1.9-2.2, DPP shifts 2.18, 64-bit moves 1.79, 32-bit 1.31.  Shares from the ISA listing of this
+                # instantiation (scripts/isa_mix.py, static counts of the two row loops).
+                ns = sum(mix["share"][k] * mix["issue_ns"][k] for k in mix["share"])
+                roof["fp64_issue_frac_weighted"] = ctr["valu_insts_per_launch"] * ns * 1e-9 / 1024.0 / launch_s
+                roof["fp64_issue_mix"] = {"share": mix["share"], "issue_ns": mix["issue_ns"], "mean_issue_ns": ns,
+                                          "valu_per_stage_row": mix.get("valu_per_stage_row"), "source": mix.get("source")}
         roof["counters_run_launch_us"] = ref_us
         roof["counters_run_matches_this_box"] = bool(same_speed)
         if same_speed:
@@ -646,6 +717,49 @@ def main():
                   "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
             model.set_exchange_interval(args.exchange_interval)
         model = headline_model
+
+    # ---- N > 1: the OTHER decomposition of the same grid, same run (round 5): BASELINE config 4 names 2 x 4 tiles, the headline runs y
+    # slabs (the faster shape on every one-GPU stand-in) -- both are checked bit for bit and timed, so that
+    # the first run on a real node answers the contract's layout as written and tells whether the slab choice holds over xGMI ----
+    second = None
+    if world > 1 and not args.no_second_partition and not args.tile and args.scaling == "strong" and verify:
+        alt = None
+        if Rx == 1 and world >= 2:
+            alt = (2, world // 2)
+        elif Ry != world or Rx != 1:
+            alt = (1, world)
+        if alt and args.size % alt[0] == 0 and args.size % alt[1] == 0 and alt != (Rx, Ry):
+            part = (alt[0], alt[1], args.size // alt[0], args.size // alt[1])
+            try:
+                g2, f2, model, _ = build(args.transport if not transport_note else "rccl", part)
+                for _ in range(max(args.warmup, 1)):
+                    csi.time_step_momentum(model, dt)
+                same2 = all_ranks(tile_matches_whole(model, g2, f2, global_fields(np, part[2], part[3], part[0], part[1])))
+                restart(model, f2)
+                for _ in range(max(args.warmup, 1)):
+                    csi.time_step_momentum(model, dt)
+                e2 = timed(args.steps)
+                second = {"partition": list(alt), "tile": [part[2], part[3]], "value": owned * args.substeps * args.steps / e2,
+                          "ms_per_step": 1e3 * e2 / args.steps, "bitwise": bool(same2),
+                          "halo_transport": model.ctx.halo_transport(), "peer_tier": model.ctx.peer_tier() if model.ctx.halo_transport() == "peer" else None}
+            except csi.CsiError as e:
+                second = {"partition": list(alt), "error": str(e)}
+            model = headline_model
+    # ---- the fence-free tier 0 of the peer protocol as an explicit opt-in, timed next to the default (never the default across
+    # devices: include/csi.h) ----
+    tier0 = None
+    if tiled and path["halo_transport"] == "peer" and args.peer_tier < 0 and path.get("peer_tier", 0) >= 1 and verify and not args.no_compare:
+        try:
+            model.set_peer_tier(0)
+            same0 = all_ranks(tile_matches_whole())
+            restart(model, f)
+            csi.time_step_momentum(model, dt)
+            e0 = timed(args.steps)
+            tier0 = {"value": owned * args.substeps * args.steps / e0, "ms_per_step": 1e3 * e0 / args.steps, "bitwise": bool(same0),
+                     "note": "opt-in (--peer-tier 0): no acquire fence behind the flags; a passing check does not prove the protocol"}
+        except csi.CsiError as e:
+            tier0 = {"error": str(e)}
+        model.set_peer_tier(path["peer_tier"])
 
     # ---- N > 1: the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported
     single = None
@@ -705,6 +819,15 @@ def main():
             # strong scaling: same grid on N GPUs vs on one; weak: N tiles of the one-GPU size vs ... the N-times larger grid
             # on one GPU (its rate, not its time, is what N GPUs are compared with)
             out["parallel_efficiency"] = value / (world * single["value"])
+        if second is not None:
+            if single is not None and "value" in second:
+                second["parallel_efficiency"] = second["value"] / (world * single["value"])
+            out[f"partition_{second['partition'][0]}x{second['partition'][1]}"] = second
+        if tier0 is not None:
+            out["peer_tier0"] = tier0
+        out["partition_note"] = ("headline = y slabs (1 x N): the faster tile shape on every one-GPU stand-in (a tile connected to itself: "
+                                 "scripts/tile_shapes.py), NOT yet measured over xGMI; BASELINE config 4's 2 x 4 layout is timed in the same run "
+                                 "(partition_2x4), `--partition 2x4` makes it the headline") if Rx == 1 and world > 1 else None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     model = None                                   # contexts (and their RCCL communicators) go before the line is printed

@@ -155,6 +155,17 @@ function run_case(dir)
     end
     open(joinpath(dir, "DONE"), "w") do io
         println(io, "ClimaSeaIce ", pkgversion(ClimaSeaIce), " Oceananigans ", pkgversion(Oceananigans), " julia ", VERSION)
+        # which arithmetic the advection scheme ran in (round 5): the full type -- a second float type parameter, where this upstream
+        # version has one, is the precision of the smoothness / weight arithmetic (the library's weight_dtype f64 | f32) -- and every
+        # field's type, so that tests/golden/reference_io.py can pick the matching oracle mode when it imports these outputs
+        scheme = WENO(order = 7)
+        println(io, "advection_type ", typeof(scheme))
+        floats = [p for p in typeof(scheme).parameters if p isa Type && p <: AbstractFloat]
+        println(io, "advection_float_parameters ", join(string.(floats), " "))
+        println(io, "weight_dtype ", (length(floats) >= 2 && floats[2] === Float32) ? "f32" : "f64")
+        for name in fieldnames(typeof(scheme))
+            println(io, "advection_field ", name, " :: ", typeof(getfield(scheme, name)))
+        end
     end
 end
 

@@ -32,7 +32,7 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_local_group_create", "csi_local_group_destroy", "csi_comm_init_local", "csi_comm_init_host", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_set_peer_tier", "csi_peer_tier", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_plan_peer_chunks", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
-           "csi_immersed_flux_bc_set", "csi_coriolis_points_set"]
+           "csi_immersed_flux_bc_set", "csi_coriolis_points_set", "csi_validate_all", "csi_debug_peer_abort", "csi_set_weno_weight_dtype", "csi_weno_weight_dtype", "csi_subcycle_stats_begin", "csi_subcycle_stats_end"]
 
 
 class Metrics(C.Structure):
@@ -135,6 +135,8 @@ def load():
         "csi_last_path": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
         "csi_last_subcycle_ms": [vp, C.POINTER(dbl)], "csi_launches_per_substep": [vp, C.POINTER(i32)],
         "csi_last_launches": [vp, C.POINTER(i32), C.POINTER(i32)],
+        "csi_validate_all": [vp], "csi_debug_peer_abort": [vp], "csi_set_weno_weight_dtype": [vp, i32], "csi_weno_weight_dtype": [vp, C.POINTER(i32)], "csi_subcycle_stats_begin": [vp],
+        "csi_subcycle_stats_end": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -244,6 +246,19 @@ class Context:
         v = C.c_double()
         self.call("csi_last_subcycle_ms", C.byref(v))
         return v.value
+
+    def subcycle_stats_begin(self):
+        self.call("csi_subcycle_stats_begin")
+
+    def subcycle_stats_end(self):
+        """(total device ms, sub-cycles, kernel launches) of every sub-cycle since subcycle_stats_begin (synchronises)."""
+        t, n, l = C.c_double(), C.c_int32(), C.c_int32()
+        self.call("csi_subcycle_stats_end", C.byref(t), C.byref(n), C.byref(l))
+        return t.value, n.value, l.value
+
+    def validate_all(self):
+        """csi_sync + the halo transport's status over ALL ranks (collective)."""
+        self.call("csi_validate_all")
 
     def profile_substeps(self, dt, substeps=16):
         out = (C.c_double * 4)()

@@ -17,6 +17,8 @@
 // h, aice after a step (measured ~1e-16); masks, zero sets and the order-reduction decisions are the same code.  Each thread owns one
 // face pair (west, south) of its cell: fluxes are computed once, shared with the east / north
 // neighbours through LDS, so every face flux is evaluated exactly once per tile interior.
+#include <cstdlib>
+
 #include "csi_dev.h"
 #include "csi_kernels.h"
 #include "evp_fast_math.h"
@@ -153,6 +155,96 @@ __device__ __forceinline__ double weno7_fast(const double* p) {
     }
 }
 
+// ---- weight_dtype f32 (csi_set_weno_weight_dtype; oracle/csi_oracle.c weno*_f32, whose statement of the ASSUMED upstream semantics
+// -- newer Oceananigans versions carry a second float type FT2 = Float32 for a WENO scheme's smoothness / weight arithmetic -- this
+// follows): stencil values converted to float, indicators, tau, ratios, unnormalised weights and their sum in float (same
+// expressions, same order, this unit is compiled without contraction; fp32 division is correctly rounded by default), candidates in
+// double, result (sum alpha_s q_s) / (sum alpha_s) in double.  STRICT: that, bit for bit.  FAST: the same float weights -- they are
+// a dozen full-rate instructions, nothing to gain -- with the double part contracted and the last division a reciprocal.
+#define WENO_EPS_F 1e-8f
+template <bool FAST>
+__device__ __forceinline__ double weno3_w32(const double* p) {
+    float f[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[k] = (float)p[k];
+    const float b0 = f[1] * (f[1] - 2 * f[2]) + f[2] * f[2];
+    const float b1 = f[0] * (f[0] - 2 * f[1]) + f[1] * f[1];
+    const float tau = fabsf(b0 - b1);
+    const float r0 = tau / (b0 + WENO_EPS_F), r1 = tau / (b1 + WENO_EPS_F);
+    const float a0 = (float)(2.0 / 3) * (1 + r0 * r0);
+    const float a1 = (float)(1.0 / 3) * (1 + r1 * r1);
+    const float s = a0 + a1;
+    if (FAST) {
+#pragma clang fp contract(fast)
+        const double q0 = 0.5 * (p[1] + p[2]);
+        const double q1 = 0.5 * (3 * p[1] - p[0]);
+        return ((double)a0 * q0 + (double)a1 * q1) * fm::rcp((double)s);
+    }
+    const double q0 = (p[1] + p[2]) / 2;
+    const double q1 = (-p[0] + 3 * p[1]) / 2;
+    return ((double)a0 * q0 + (double)a1 * q1) / (double)s;
+}
+template <bool FAST>
+__device__ __forceinline__ double weno5_w32(const double* p) {
+    float f[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) f[k] = (float)p[k];
+    const float b0 = (f[2] * (10 * f[2] - 31 * f[3] + 11 * f[4]) + f[3] * (25 * f[3] - 19 * f[4]) + f[4] * (4 * f[4])) / 3;
+    const float b1 = (f[1] * (4 * f[1] - 13 * f[2] + 5 * f[3]) + f[2] * (13 * f[2] - 13 * f[3]) + f[3] * (4 * f[3])) / 3;
+    const float b2 = (f[0] * (4 * f[0] - 19 * f[1] + 11 * f[2]) + f[1] * (25 * f[1] - 31 * f[2]) + f[2] * (10 * f[2])) / 3;
+    const float tau = fabsf(b0 - b2);
+    const float r0 = tau / (b0 + WENO_EPS_F), r1 = tau / (b1 + WENO_EPS_F), r2 = tau / (b2 + WENO_EPS_F);
+    const float a0 = (float)(3.0 / 10) * (1 + r0 * r0);
+    const float a1 = (float)(3.0 / 5) * (1 + r1 * r1);
+    const float a2 = (float)(1.0 / 10) * (1 + r2 * r2);
+    const float s = a0 + a1 + a2;
+    if (FAST) {
+#pragma clang fp contract(fast)
+        const double q0 = (2 * p[2] + 5 * p[3] - p[4]) * (1.0 / 6);
+        const double q1 = (5 * p[2] + 2 * p[3] - p[1]) * (1.0 / 6);
+        const double q2 = (2 * p[0] - 7 * p[1] + 11 * p[2]) * (1.0 / 6);
+        return ((double)a0 * q0 + (double)a1 * q1 + (double)a2 * q2) * fm::rcp((double)s);
+    }
+    const double q0 = (2 * p[2] + 5 * p[3] - p[4]) / 6;
+    const double q1 = (-p[1] + 5 * p[2] + 2 * p[3]) / 6;
+    const double q2 = (2 * p[0] - 7 * p[1] + 11 * p[2]) / 6;
+    return ((double)a0 * q0 + (double)a1 * q1 + (double)a2 * q2) / (double)s;
+}
+template <bool FAST>
+__device__ __forceinline__ double weno7_w32(const double* p) {
+    float f[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) f[k] = (float)p[k];
+    const float b0 = f[3] * (2.107f * f[3] - 9.402f * f[4] + 7.042f * f[5] - 1.854f * f[6]) +
+                     f[4] * (11.003f * f[4] - 17.246f * f[5] + 4.642f * f[6]) + f[5] * (7.043f * f[5] - 3.882f * f[6]) + f[6] * (0.547f * f[6]);
+    const float b1 = f[2] * (0.547f * f[2] - 2.522f * f[3] + 1.922f * f[4] - 0.494f * f[5]) +
+                     f[3] * (3.443f * f[3] - 5.966f * f[4] + 1.602f * f[5]) + f[4] * (2.843f * f[4] - 1.642f * f[5]) + f[5] * (0.267f * f[5]);
+    const float b2 = f[1] * (0.267f * f[1] - 1.642f * f[2] + 1.602f * f[3] - 0.494f * f[4]) +
+                     f[2] * (2.843f * f[2] - 5.966f * f[3] + 1.922f * f[4]) + f[3] * (3.443f * f[3] - 2.522f * f[4]) + f[4] * (0.547f * f[4]);
+    const float b3 = f[0] * (0.547f * f[0] - 3.882f * f[1] + 4.642f * f[2] - 1.854f * f[3]) +
+                     f[1] * (7.043f * f[1] - 17.246f * f[2] + 7.042f * f[3]) + f[2] * (11.003f * f[2] - 9.402f * f[3]) + f[3] * (2.107f * f[3]);
+    const float tau = fabsf(b0 + 3 * b1 - 3 * b2 - b3);
+    const float r0 = tau / (b0 + WENO_EPS_F), r1 = tau / (b1 + WENO_EPS_F), r2 = tau / (b2 + WENO_EPS_F), r3 = tau / (b3 + WENO_EPS_F);
+    const float a0 = (float)(4.0 / 35) * (1 + r0 * r0);
+    const float a1 = (float)(18.0 / 35) * (1 + r1 * r1);
+    const float a2 = (float)(12.0 / 35) * (1 + r2 * r2);
+    const float a3 = (float)(1.0 / 35) * (1 + r3 * r3);
+    const float s = a0 + a1 + a2 + a3;
+    if (FAST) {
+#pragma clang fp contract(fast)
+        const double q0 = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) * (1.0 / 12);
+        const double q1 = (7 * p[3] + 7 * p[4] - p[2] - p[5]) * (1.0 / 12);
+        const double q2 = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) * (1.0 / 12);
+        const double q3 = (13 * p[1] - 3 * p[0] - 23 * p[2] + 25 * p[3]) * (1.0 / 12);
+        return ((double)a0 * q0 + (double)a1 * q1 + (double)a2 * q2 + (double)a3 * q3) * fm::rcp((double)s);
+    }
+    const double q0 = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) / 12;
+    const double q1 = (-p[2] + 7 * p[3] + 7 * p[4] - p[5]) / 12;
+    const double q2 = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) / 12;
+    const double q3 = (-3 * p[0] + 13 * p[1] - 23 * p[2] + 25 * p[3]) / 12;
+    return ((double)a0 * q0 + (double)a1 * q1 + (double)a2 * q2 + (double)a3 * q3) / (double)s;
+}
+
 // Boundary-order reduction next to walls (upstream topologically_conditional_interpolation, recalled -- SURVEY.md
 // App. B; same rule as oracle/csi_oracle.c::reduced_buffer): the scheme with buffer B (order 2B-1) is used at face
 // idx only if its biased stencil stays inside the domain, else the buffer scheme of order 2B-3, down to upwind 1.
@@ -182,7 +274,7 @@ __device__ __forceinline__ int reduced_buffer_immersed(const GridDev& g, int B, 
 // reconstruct at a face from the line of values through `base` (cell on the high side of the
 // face); st = element stride of the line; left bias (vel > 0): upwind cell is base - st.
 // B: buffer of the scheme to use at this face (after the boundary-order reduction).
-template <int SCHEME, bool FAST = false>
+template <int SCHEME, bool FAST = false, bool W32 = false>
 __device__ __forceinline__ double reconstruct(const double* base, long st, bool left, int B) {
     const double* up = left ? base - st : base;
     const long s = left ? st : -st;
@@ -193,18 +285,18 @@ __device__ __forceinline__ double reconstruct(const double* base, long st, bool 
         double p[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) p[k] = up[(k - 1) * s];
-        return WENO ? (FAST ? weno3_fast(p) : weno3(p)) : (FAST ? upwind3_fast(p) : upwind3(p));
+        return WENO ? (W32 ? weno3_w32<FAST>(p) : (FAST ? weno3_fast(p) : weno3(p))) : (FAST ? upwind3_fast(p) : upwind3(p));
     }
     if (B == 3 || SCHEME != 7) {
         double p[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) p[k] = up[(k - 2) * s];
-        return WENO ? (FAST ? weno5_fast(p) : weno5(p)) : (FAST ? upwind5_fast(p) : upwind5(p));
+        return WENO ? (W32 ? weno5_w32<FAST>(p) : (FAST ? weno5_fast(p) : weno5(p))) : (FAST ? upwind5_fast(p) : upwind5(p));
     }
     double p[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) p[k] = up[(k - 3) * s];
-    return FAST ? weno7_fast(p) : weno7(p);
+    return W32 ? weno7_w32<FAST>(p) : (FAST ? weno7_fast(p) : weno7(p));
 }
 // buffer at face (i, j) of the x / y direction: immersed grid -> the immersed rule (it covers the walls: cells beyond
 // them are inactive); else the topological rule next to walls; else the full scheme
@@ -262,12 +354,18 @@ __device__ __forceinline__ void store_tracer_images(const FRef& f, const GridDev
 // STEP (launch_advect_stage): the launch is a whole RK stage of an advection-only model -- the h thread of a cell also does
 // _dynamic_step_tracers! (k_tracer_step's arithmetic, statement for statement) with the two tendencies of its cell, into the
 // stage's OUTPUT arrays.
-template <int SCHEME, bool FAST, bool STEP = false, int TY = TY2>
-__global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
-    __shared__ double sFx[3][TY + 1][TX + 2], sFy[3][TY + 1][TX + 2];
-    __shared__ double sG[STEP ? 2 : 1][STEP ? TY : 1][STEP ? TX : 1];
+// NT (round 5): tracers per thread.  1: one thread per cell AND tracer (threadIdx.z), the latency-optimal layout of small grids
+// (round 3: at 512^2 a launch lasts as long as one block).  2: one thread per cell does h AND aice -- the face velocity and its
+// sign, the order-reduction decision, the closed-face test, the face area and the stencil's address arithmetic are the same for
+// both tracers and were half of a thread's instructions (ISA: ~300 of ~590 per cell and tracer were not the reconstruction's
+// arithmetic); large grids, which are throughput-bound (VALU busy 0.68 at 2048^2), take this one.  Same operations per value:
+// bit-identical to NT = 1.
+template <int SCHEME, bool FAST, bool STEP = false, int TY = TY2, bool W32 = false, int NT = 1>
+__global__ void __launch_bounds__(NT == 2 ? (TX + 1) * (TY + 1) : 1024) k_tendencies(AdvDev A) {
+    __shared__ double sFx[NT == 2 ? 2 : 3][TY + 1][TX + 2], sFy[NT == 2 ? 2 : 3][TY + 1][TX + 2];
+    __shared__ double sG[(STEP && NT == 1) ? 2 : 1][(STEP && NT == 1) ? TY : 1][(STEP && NT == 1) ? TX : 1];
     const GridDev& g = A.g;
-    const int tx = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;          // tx in [0, TX], ty in [0, TY], tz: tracer
+    const int tx = threadIdx.x, ty = threadIdx.y, tz = NT == 2 ? 0 : threadIdx.z;          // tx in [0, TX], ty in [0, TY], tz: tracer
     const int i = 1 + blockIdx.x * TX + tx, j = 1 + blockIdx.y * TY + ty;
     const bool in_x = i <= g.Nx + 1, in_y = j <= g.Ny + 1;
     const FRef& c = tz == 0 ? A.h : (tz == 1 ? A.a : A.hs);
@@ -278,7 +376,8 @@ __global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
     if (STEP && owns) {
         hn = A.hb(i, j); an = A.ab(i, j);
         if (A.write_cache) {              // Psi^- = the state this step starts from (its halos: images, like the state's)
-            if (tz == 0) store_tracer_images(A.hm, A.g, A.im, i, j, hn); else store_tracer_images(A.am, A.g, A.im, i, j, an);
+            if (NT == 2 || tz == 0) store_tracer_images(A.hm, A.g, A.im, i, j, hn);
+            if (NT == 2 || tz != 0) store_tracer_images(A.am, A.g, A.im, i, j, an);
         }
     }
     if (in_x && in_y) {
@@ -287,43 +386,58 @@ __global__ void __launch_bounds__(1024) k_tendencies(AdvDev A) {
             const double uu = A.u(i, j);
             const bool left = uu > 0;
             const int B = buffer_at<SCHEME>(g, i, j, false, left);
-            const double cc = reconstruct<SCHEME, FAST>(&c(i, j), 1, left, B);
             const bool closed = g.has_mask && peripheral_u(g, i, j);          // conditional_flux_fcc
             const double ax = dym(g, LOC_F, LOC_C, i, j);                    // Ax^{fcc} = dy^{fcc} * dz
+            const double cc = reconstruct<SCHEME, FAST, W32>(&c(i, j), 1, left, B);
             sFx[tz][ty][tx] = closed ? 0.0 : ax * uu * cc;
+            if (NT == 2) {
+                const double c2 = reconstruct<SCHEME, FAST, W32>(&A.a(i, j), 1, left, B);
+                sFx[1][ty][tx] = closed ? 0.0 : ax * uu * c2;
+            }
         }
         if (tx < TX && i <= g.Nx) {
             const double vv = A.v(i, j);
             const bool left = vv > 0;
             const int B = buffer_at<SCHEME>(g, i, j, true, left);
-            const double cc = reconstruct<SCHEME, FAST>(&c(i, j), c.ld, left, B);
             const double dxf = dxm(g, LOC_C, LOC_F, i, j);                   // Ay^{cfc} = dx^{cfc} * dz
             const bool closed = g.has_mask && peripheral_v(g, i, j);          // conditional_flux_cfc
+            const double cc = reconstruct<SCHEME, FAST, W32>(&c(i, j), c.ld, left, B);
             sFy[tz][ty][tx] = closed ? 0.0 : dxf * vv * cc;
+            if (NT == 2) {
+                const double c2 = reconstruct<SCHEME, FAST, W32>(&A.a(i, j), A.a.ld, left, B);
+                sFy[1][ty][tx] = closed ? 0.0 : dxf * vv * c2;
+            }
         }
     }
     __syncthreads();
+    double G0 = 0.0, G1 = 0.0;
     if (tx < TX && ty < TY && i <= g.Nx && j <= g.Ny) {
         const double V = azm(g, LOC_C, LOC_C, i, j);
-        const double fx = sFx[tz][ty][tx + 1] - sFx[tz][ty][tx], fy = sFy[tz][ty + 1][tx] - sFy[tz][ty][tx];
         const double rV = FAST ? fm::rcp(V) : 1 / V;
+        const double fx = sFx[tz][ty][tx + 1] - sFx[tz][ty][tx], fy = sFy[tz][ty + 1][tx] - sFy[tz][ty][tx];
         const FRef& G = tz == 0 ? A.Gh : (tz == 1 ? A.Ga : A.Ghs);         // (snow: compute_snow_advection_tendency!, tracer_tendency_kernel_functions.jl:49-52)
         const double Gv = -(rV * (fx + fy));
         G(i, j) = Gv;
-        if (STEP) sG[tz][ty][tx] = Gv;
+        G0 = Gv;
+        if (NT == 2) {
+            const double fx2 = sFx[1][ty][tx + 1] - sFx[1][ty][tx], fy2 = sFy[1][ty + 1][tx] - sFy[1][ty][tx];
+            G1 = -(rV * (fx2 + fy2));
+            A.Ga(i, j) = G1;
+        } else if (STEP) sG[tz][ty][tx] = Gv;
     }
     if (STEP) {
-        __syncthreads();
+        if (NT == 1) __syncthreads();
         if (owns) {
-            double hp = hn + A.dt * sG[0][ty][tx];
-            double ap = an + A.dt * sG[1][ty][tx];
+            double hp = hn + A.dt * (NT == 2 ? G0 : sG[0][ty][tx]);
+            double ap = an + A.dt * (NT == 2 ? G1 : sG[1][ty][tx]);
             ap = jmax(0.0, ap);
             hp = jmax(0.0, hp);
             ap = (hp == 0) ? 0.0 : ap;
             hp = (ap == 0) ? 0.0 : hp;
             const double Vp = hp * ap;
             const double a1 = (ap > 1) ? 1.0 : ap, h1 = (ap > 1) ? Vp : hp;
-            if (tz == 0) store_tracer_images(A.ho, A.g, A.im, i, j, h1); else store_tracer_images(A.ao, A.g, A.im, i, j, a1);
+            if (NT == 2 || tz == 0) store_tracer_images(A.ho, A.g, A.im, i, j, h1);
+            if (NT == 2 || tz != 0) store_tracer_images(A.ao, A.g, A.im, i, j, a1);
         }
     }
 }
@@ -359,43 +473,62 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
 
 }  // namespace adv
 
-template <bool FAST>
+// W32: the WENO weights in single precision (AdvDev::w32; only the WENO schemes have weights)
+// NT: tracers per thread (k_tendencies): 2 from kTwoTracerCells cells on -- measured round 5 (scripts/adv_nt_ab.sh): the two-tracer
+// threads win where the launch is throughput-bound, the one-tracer threads where it is as long as one block
+#ifndef CSI_ADV_NT2_CELLS
+#define CSI_ADV_NT2_CELLS 600000L
+#endif
+static bool adv_two_tracers(const AdvDev& A) {
+    if (A.has_snow) return false;
+    if (A.nt > 0) return A.nt == 2;              // tuning aid / tests (CSI_ADV_NT, read when the context is created)
+    return (long)A.g.Nx * (long)A.g.Ny >= CSI_ADV_NT2_CELLS;
+}
+template <bool FAST, bool W32>
 static void launch_tendencies_mode(const AdvDev& A, hipStream_t s) {
     const int ty = A.has_snow ? adv::TY3 : adv::TY2;
-    dim3 b(adv::TX + 1, ty + 1, A.has_snow ? 3 : 2);
+    const bool two = adv_two_tracers(A);
+    dim3 b(adv::TX + 1, ty + 1, A.has_snow ? 3 : (two ? 1 : 2));
     dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + ty - 1) / ty));
-#define CSI_ADV_LAUNCH(S) do { if (A.has_snow) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY3>), gr, b, 0, s, A); \
-                               else hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY2>), gr, b, 0, s, A); } while (0)
+#define CSI_ADV_LAUNCH(S, W) do { if (A.has_snow) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY3, W>), gr, b, 0, s, A); \
+                                  else if (two) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY2, W, 2>), gr, b, 0, s, A); \
+                                  else hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY2, W>), gr, b, 0, s, A); } while (0)
     switch (A.scheme) {
-        case 1: CSI_ADV_LAUNCH(1); break;
-        case 3: CSI_ADV_LAUNCH(3); break;
-        case -3: CSI_ADV_LAUNCH(-3); break;
-        case 5: CSI_ADV_LAUNCH(5); break;
-        case -5: CSI_ADV_LAUNCH(-5); break;
-        default: CSI_ADV_LAUNCH(7); break;
+        case 1: CSI_ADV_LAUNCH(1, false); break;
+        case 3: CSI_ADV_LAUNCH(3, W32); break;
+        case -3: CSI_ADV_LAUNCH(-3, false); break;
+        case 5: CSI_ADV_LAUNCH(5, W32); break;
+        case -5: CSI_ADV_LAUNCH(-5, false); break;
+        default: CSI_ADV_LAUNCH(7, W32); break;
     }
 #undef CSI_ADV_LAUNCH
 }
 // mode: CSI_MODE_STRICT (0) the oracle's arithmetic, bit for bit; CSI_MODE_FAST (1) reciprocals and contraction (header)
 void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
-    if (mode == 1) launch_tendencies_mode<true>(A, s); else launch_tendencies_mode<false>(A, s);
+    if (A.w32) { if (mode == 1) launch_tendencies_mode<true, true>(A, s); else launch_tendencies_mode<false, true>(A, s); }
+    else { if (mode == 1) launch_tendencies_mode<true, false>(A, s); else launch_tendencies_mode<false, false>(A, s); }
 }
-template <bool FAST>
+template <bool FAST, bool W32>
 static void launch_stage_mode(const AdvDev& A, hipStream_t s) {
-    dim3 b(adv::TX + 1, adv::TY2 + 1, 2);
+    const bool two = adv_two_tracers(A);
+    dim3 b(adv::TX + 1, adv::TY2 + 1, two ? 1 : 2);
     dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY2 - 1) / adv::TY2));
+#define CSI_ADV_STAGE(S, W) do { if (two) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, adv::TY2, W, 2>), gr, b, 0, s, A); \
+                                 else hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, adv::TY2, W>), gr, b, 0, s, A); } while (0)
     switch (A.scheme) {
-        case 1: hipLaunchKernelGGL((adv::k_tendencies<1, FAST, true>), gr, b, 0, s, A); break;
-        case 3: hipLaunchKernelGGL((adv::k_tendencies<3, FAST, true>), gr, b, 0, s, A); break;
-        case -3: hipLaunchKernelGGL((adv::k_tendencies<-3, FAST, true>), gr, b, 0, s, A); break;
-        case 5: hipLaunchKernelGGL((adv::k_tendencies<5, FAST, true>), gr, b, 0, s, A); break;
-        case -5: hipLaunchKernelGGL((adv::k_tendencies<-5, FAST, true>), gr, b, 0, s, A); break;
-        default: hipLaunchKernelGGL((adv::k_tendencies<7, FAST, true>), gr, b, 0, s, A); break;
+        case 1: CSI_ADV_STAGE(1, false); break;
+        case 3: CSI_ADV_STAGE(3, W32); break;
+        case -3: CSI_ADV_STAGE(-3, false); break;
+        case 5: CSI_ADV_STAGE(5, W32); break;
+        case -5: CSI_ADV_STAGE(-5, false); break;
+        default: CSI_ADV_STAGE(7, W32); break;
     }
+#undef CSI_ADV_STAGE
 }
 // one RK stage of an advection-only model without snow: tendencies of (A.h, A.a), update A.hb + dt G -> A.ho (A.ab, A.ao)
 void launch_advect_stage(const AdvDev& A, int mode, hipStream_t s) {
-    if (mode == 1) launch_stage_mode<true>(A, s); else launch_stage_mode<false>(A, s);
+    if (A.w32) { if (mode == 1) launch_stage_mode<true, true>(A, s); else launch_stage_mode<false, true>(A, s); }
+    else { if (mode == 1) launch_stage_mode<true, false>(A, s); else launch_stage_mode<false, false>(A, s); }
 }
 void launch_tracer_step(const AdvDev& A, hipStream_t s) {
     dim3 b(64, 4);

@@ -87,6 +87,7 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
         c->tune.pair_common = env_int("CSI_PAIR_COMMON"); c->tune.no_geom_sig = env_int("CSI_DEBUG_NO_GEOM_SIG");
         c->tune.peer_edge = env_int("CSI_PEER_EDGE");          // rows the chunks next to a peer-connected y side are shorter by (default 4; 0: uniform chunks)
         c->tune.write_through = env_int("CSI_WRITE_THROUGH");  // 0 / 1: never / always store the pair kernel's results write-through (default: by grid size)
+        c->tune.adv_nt = env_int("CSI_ADV_NT");
         c->tune.peer_kernel = env_int("CSI_PEER_KERNEL");      // 1: untiled grids run the PEER instantiation of the pair kernel (no neighbour, no waits): what the instantiation itself costs
     }
     *out = c;
@@ -124,6 +125,7 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->recvbuf) hipFree(c->recvbuf);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->hostg) hostgroup_leave(c->hostg);
+    for (hipEvent_t e : c->stats.ev) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -133,25 +135,49 @@ int32_t csi_context_destroy(csi_context* c) {
 
 // A wait of the peer halo transport has given up (this rank's error word, copied to pinned memory behind every sub-cycle): the
 // sub-cycle that saw it is invalid on this rank and -- through the abort words -- on its neighbours.  Reported by EVERY entry
-// point that advances the model (at its start and at its end) and by csi_sync, whichever comes first; the words are cleared so
-// that the caller may go on (the launch numbers stay in step on all ranks: they are counted on the host).
+// point that advances the model (at its start and at its end) and by csi_sync, whichever comes first.
+// The error is STICKY (round 5): the flag protocol cannot recover by itself -- aborted edge tiles never published
+// their launch number while the host kept counting, so every later launch would wait three seconds for flags that never come, and a
+// neighbour still inside its aborted sub-cycle can raise the abort words again behind any local clean-up.  From here on every entry
+// point that advances the model returns CSI_ERR_COMM until the CALLER re-arms the transport on ALL ranks: csi_set_halo_transport
+// (either kind; CSI_TRANSPORT_PEER makes the next sub-cycle run the collective set-up again, which clears flags, abort words and
+// launch numbers once every rank has arrived) or a new csi_comm_init*.  Ranks that are not neighbours of the rank that gave up
+// learn of it when their own waits time out in turn (each within 3 s), or at once through csi_validate_all.
 static int32_t peer_check(csi_context* c);
 extern "C++" { namespace csi_host { int32_t peer_check_entry(csi_context* c) { return peer_check(c); } } }
 static int32_t peer_check(csi_context* c) {
-    if (c->peer.err_host && *c->peer.err_host) {
-        *c->peer.err_host = 0;
-        hipMemsetAsync(c->peer.err, 0, sizeof(unsigned), c->stream);
-        for (int d = 0; d < 8; ++d)
-            hipMemsetAsync(c->peer.slots + (size_t)d * csi_context::Peer::SLOTS + (csi_context::Peer::SLOTS - 1), 0, sizeof(unsigned long long), c->stream);
+    if (c->peer.err_host && *c->peer.err_host) c->peer.aborted = true;
+    if (c->peer.aborted)
         return fail(c, CSI_ERR_COMM, "peer halo transport: a tile waited 3 s for its neighbour's flags and gave up (or a neighbouring rank did) -- the results of "
-                                     "that sub-cycle are invalid (a rank that fell behind or died; csi_set_halo_transport(ctx, CSI_TRANSPORT_RCCL) selects "
-                                     "the RCCL exchange)");
-    }
+                                     "that sub-cycle are invalid (a rank that fell behind or died) and the transport stays refused until EVERY rank has called "
+                                     "csi_set_halo_transport again (CSI_TRANSPORT_PEER: a new collective set-up at the next sub-cycle; CSI_TRANSPORT_RCCL: the "
+                                     "message exchange)");
     return CSI_OK;
 }
 int32_t csi_sync(csi_context* c) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return peer_check(c);
+}
+// testing aid: what a wait of the flag protocol that gave up leaves behind on the host side (the pinned error word), without the
+// three seconds -- tests/test_gpu_evp.py::test_peer_abort_is_sticky_until_rearmed drives the recovery path with it
+int32_t csi_debug_peer_abort(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (!c->peer.err_host) return fail(c, CSI_ERR_NOT_BOUND, "the peer transport has not been set up");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *c->peer.err_host = 1u;
+    return CSI_OK;
+}
+// csi_sync on every rank + the transport's status reduced over ALL ranks (collective: every rank of the communicator calls it
+// between the same two steps).  What output writers / checkpointers call before they read a tiled model's fields: a peer-transport
+// abort reaches only the direct neighbours' abort words, this makes every rank see it -- and take the same decision.
+int32_t csi_validate_all(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int bad = (c->peer.aborted || (c->peer.err_host && *c->peer.err_host)) ? 1 : 0;
+    int32_t rc;
+    if ((rc = comm_allreduce_max(c, &bad))) return rc;
+    if (bad) c->peer.aborted = true;
     return peer_check(c);
 }
 
@@ -571,7 +597,7 @@ int32_t csi_tile_set(csi_context* c, int32_t rx, int32_t ry, int32_t Rx, int32_t
     c->tile.rx = rx; c->tile.ry = ry; c->tile.Rx = Rx; c->tile.Ry = Ry;
     c->tile.periodic_x = periodic_x != 0; c->tile.periodic_y = periodic_y != 0;
     c->tile.set = true;
-    peer_release(c); c->peer.failed = false;           // (the neighbours may be other ranks now)
+    peer_release(c); c->peer.failed = false; c->peer.aborted = false; if (c->peer.err_host) *c->peer.err_host = 0;           // (the neighbours may be other ranks now)
     return CSI_OK;
 }
 
@@ -592,7 +618,7 @@ int32_t csi_comm_init(csi_context* c, int32_t world_size, int32_t rank, const ui
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->hostg) { hostgroup_leave(c->hostg); c->hostg = nullptr; }
     c->local = nullptr;
-    peer_release(c); c->peer.failed = false;           // (mappings of the previous communicator's neighbours)
+    peer_release(c); c->peer.failed = false; c->peer.aborted = false; if (c->peer.err_host) *c->peer.err_host = 0;           // (mappings of the previous communicator's neighbours)
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     NCCL_TRY(c, ncclCommInitRank(&c->comm, world_size, id, rank));
@@ -618,7 +644,7 @@ int32_t csi_comm_init_local(csi_context* c, csi_local_group* G, int32_t rank) {
     if (rank < 0 || rank >= G->world) return fail(c, CSI_ERR_INVALID_ARGUMENT, "rank out of range for this group");
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->hostg) { hostgroup_leave(c->hostg); c->hostg = nullptr; }
-    peer_release(c); c->peer.failed = false;
+    peer_release(c); c->peer.failed = false; c->peer.aborted = false; if (c->peer.err_host) *c->peer.err_host = 0;
     c->local = G;
     c->world = G->world; c->rank = rank;
     // The peer transport's kernels wait for flags the OTHER tiles' kernels of this process publish.  HIP maps streams onto
@@ -644,7 +670,7 @@ int32_t csi_comm_init_host(csi_context* c, const char* shm_name, int32_t world_s
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->hostg) { hostgroup_leave(c->hostg); c->hostg = nullptr; }
     c->local = nullptr;
-    peer_release(c); c->peer.failed = false;
+    peer_release(c); c->peer.failed = false; c->peer.aborted = false; if (c->peer.err_host) *c->peer.err_host = 0;
     std::string e;
     c->hostg = hostgroup_join(shm_name, world_size, rank, &e);
     if (!c->hostg) return fail(c, CSI_ERR_COMM, e);
@@ -706,6 +732,18 @@ int32_t csi_free_drift_set(csi_context* c, int32_t kind) {
     return CSI_OK;
 }
 
+int32_t csi_set_weno_weight_dtype(csi_context* c, int32_t dtype) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (dtype != CSI_WEIGHTS_F64 && dtype != CSI_WEIGHTS_F32) return fail(c, CSI_ERR_INVALID_ARGUMENT, "WENO weight dtype: CSI_WEIGHTS_F64 or CSI_WEIGHTS_F32");
+    c->weno_w32 = dtype == CSI_WEIGHTS_F32;
+    return CSI_OK;
+}
+int32_t csi_weno_weight_dtype(csi_context* c, int32_t* dtype) {
+    if (!c || !dtype) return CSI_ERR_INVALID_ARGUMENT;
+    *dtype = c->weno_w32 ? CSI_WEIGHTS_F32 : CSI_WEIGHTS_F64;
+    return CSI_OK;
+}
+
 int32_t csi_set_fusion(csi_context* c, int32_t on) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     c->fusion = on != 0;
@@ -730,6 +768,16 @@ int32_t csi_set_halo_transport(csi_context* c, int32_t kind) {
                                             "block the one it waits for): export GPU_MAX_HW_QUEUES=16, or keep the message exchange (CSI_TRANSPORT_RCCL)");
     c->peer.want = kind == CSI_TRANSPORT_PEER;
     if (c->peer.want) c->peer.failed = false;            // (asking again retries the set-up)
+    if (c->peer.aborted) {
+        // re-arming after a wait that gave up (peer_check): the caller does this on EVERY rank.  The stream is drained (this rank's
+        // aborted launches are over), the mappings go, and the next sub-cycle on the peer transport runs the collective set-up.
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        peer_release(c);
+        if (c->peer.err_host) *c->peer.err_host = 0;
+        if (c->peer.err) HIP_TRY(c, hipMemset(c->peer.err, 0, sizeof(unsigned)));
+        c->peer.aborted = false;
+        c->peer.last = 0;
+    }
     return CSI_OK;
 }
 int32_t csi_halo_transport(csi_context* c, int32_t* kind) {
@@ -739,13 +787,13 @@ int32_t csi_halo_transport(csi_context* c, int32_t* kind) {
 }
 int32_t csi_set_peer_tier(csi_context* c, int32_t tier) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
-    if (tier < 0 || tier > 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "peer protocol tier must be 0, 1 or 2");
+    if (tier < -1 || tier > 2) return fail(c, CSI_ERR_INVALID_ARGUMENT, "peer protocol tier must be -1 (automatic), 0, 1 or 2");
     c->peer.tier = tier;
     return CSI_OK;
 }
 int32_t csi_peer_tier(csi_context* c, int32_t* tier) {
     if (!c || !tier) return CSI_ERR_INVALID_ARGUMENT;
-    *tier = c->peer.tier;
+    *tier = peer_effective_tier(c);      // (what the kernels run: automatic resolves to 1 across processes / devices, 0 otherwise)
     return CSI_OK;
 }
 
@@ -869,6 +917,29 @@ int32_t csi_last_subcycle_ms(csi_context* c, double* ms) {
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(&t, c->ev0, c->ev1));
     *ms = (double)t;
+    return CSI_OK;
+}
+
+int32_t csi_subcycle_stats_begin(csi_context* c) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    for (hipEvent_t e : c->stats.ev) hipEventDestroy(e);
+    c->stats.ev.clear(); c->stats.launches.clear();
+    c->stats.on = true;
+    return CSI_OK;
+}
+int32_t csi_subcycle_stats_end(csi_context* c, double* total_ms, int32_t* cycles, int32_t* launches) {
+    if (!c || !total_ms || !cycles || !launches) return CSI_ERR_INVALID_ARGUMENT;
+    c->stats.on = false;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0; int n = 0, nl = 0;
+    for (size_t k = 0; k + 1 < c->stats.ev.size() && k / 2 < c->stats.launches.size(); k += 2) {
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->stats.ev[k], c->stats.ev[k + 1]));
+        sum += t; ++n; nl += c->stats.launches[k / 2];
+    }
+    for (hipEvent_t e : c->stats.ev) hipEventDestroy(e);
+    c->stats.ev.clear(); c->stats.launches.clear();
+    *total_ms = sum; *cycles = n; *launches = nl;
     return CSI_OK;
 }
 

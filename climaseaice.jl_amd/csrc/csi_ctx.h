@@ -103,6 +103,8 @@ struct csi_context {
     csi_stress stress[2]{};
     int mode = CSI_MODE_STRICT;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // csi_subcycle_stats_begin / _end: one more event pair around every sub-step loop while `on` (bench.py's timed region)
+    struct Stats { bool on = false; std::vector<hipEvent_t> ev; std::vector<int> launches; } stats;
     bool timed = false;
     int launches_per_substep = 0;
     // multi-GPU tiles
@@ -139,7 +141,10 @@ struct csi_context {
         std::vector<void*> opened;           // IPC mappings
         uint8_t* xbuf = nullptr;             // device staging of the set-up's all-gather
         int last = 0;                        // the last sub-cycle used the peer transport
-        int tier = 0;                        // protocol tier (csi_set_peer_tier; FI_PTIER of the kernel tables)
+        int tier = -1;                       // protocol tier asked for (csi_set_peer_tier; -1: automatic -- peer_effective_tier: 1 as soon as a
+                                             // neighbour lives in another process or on another device, 0 for a tile connected to itself / an in-process group)
+        bool aborted = false;                // a wait of the flag protocol gave up (here or at a neighbour): the transport is refused until every rank has
+                                             // called csi_set_halo_transport / csi_comm_init* again (sticky: the flags cannot recover, csi_abi.hip peer_check)
         bool local_queues_ok = true;         // in-process tile group: GPU_MAX_HW_QUEUES > tiles (csi_comm_init_local)
         size_t xbuf_cap = 0;                 // bytes of xbuf
     } peer;
@@ -178,6 +183,7 @@ struct csi_context {
     double vel_bc_value[2][2] = {{0, 0}, {0, 0}};
     bool snow_set = false;   // layered (snow + ice) step instead of the bare-ice one
     SnowDev snow{};
+    int weno_w32 = 0;     // csi_set_weno_weight_dtype: 1 = WENO weights in single precision (upstream's FT2 = Float32, recalled)
     int fusion = 1;       // 1: use the fused sub-step kernel when the configuration allows it
     int pairing = 1;      // 1: two sub-steps per launch where supported (csi_set_fusion level 2)
     int last_launches = 0, last_substeps = 0, last_used_pairs = 0;   // kernel launches / sub-steps of the last fused sub-cycle
@@ -188,6 +194,7 @@ struct csi_context {
     int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
+                    adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
                     no_geom_sig = -1;      // debugging aid (CSI_DEBUG_NO_GEOM_SIG=1): skip the launch-geometry check of the peer set-up (tests/test_gpu_local_tiles.py)
     } tune;
 };
@@ -285,6 +292,8 @@ bool is_tiled(const csi_context* c);
 int32_t exchange(csi_context* c, const int* fids, int nf, int W);
 int32_t local_allgather(csi_context* c, const void* mine, size_t nb, std::vector<uint8_t>& out);
 int32_t local_allreduce_min(csi_context* c, int* v);
+int32_t comm_allreduce_max(csi_context* c, int* v);      // over whatever joins the ranks (RCCL communicator, in-process group, host-channel group)
+int peer_effective_tier(const csi_context* c);
 int32_t local_wait_consumed(csi_context* c);
 int32_t local_sendrecv(csi_context* c, const long* soff, const long* scnt, const int* speer, const long* roff, const long* rcnt, const int* rpeer);
 int32_t exchange_refs(csi_context* c, const FRef* fr, int nf, int W);

@@ -52,6 +52,32 @@ int32_t local_allreduce_min(csi_context* c, int* v) {
     for (int r = 0; r < c->world; ++r) { int x; memcpy(&x, all.data() + (size_t)r * sizeof(int), sizeof(int)); if (x < *v) *v = x; }
     return CSI_OK;
 }
+// max of one int over all ranks of whatever joins them: the in-process group, the host-channel group or the RCCL communicator
+// (one rank: nothing to do).  Host-synchronous on the RCCL path (a 4-byte all-reduce on the context's stream).
+int32_t comm_allreduce_max(csi_context* c, int* v) {
+    if (c->world <= 1 || !has_comm(c)) return CSI_OK;
+    std::vector<uint8_t> all;
+    if (c->local) {
+        int32_t rc;
+        if ((rc = local_allgather(c, v, sizeof(int), all))) return rc;
+    } else if (c->hostg) {
+        if (!hostgroup_allgather(c->hostg, v, sizeof(int), all, &c->err)) return CSI_ERR_COMM;
+    } else {
+        int* flag = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&flag, sizeof(int)));
+        hipError_t e = hipMemcpy(flag, v, sizeof(int), hipMemcpyHostToDevice);
+        ncclResult_t r = ncclSuccess;
+        if (e == hipSuccess) r = ncclAllReduce(flag, flag, 1, ncclInt32, ncclMax, c->comm, c->stream);
+        if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(v, flag, sizeof(int), hipMemcpyDeviceToHost);
+        hipFree(flag);
+        if (r != ncclSuccess) return fail(c, CSI_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+        if (e != hipSuccess) return fail(c, CSI_ERR_HIP, std::string("all-reduce of a status word: ") + hipGetErrorString(e));
+        return CSI_OK;
+    }
+    for (int r = 0; r < c->world; ++r) { int x; memcpy(&x, all.data() + (size_t)r * sizeof(int), sizeof(int)); if (x > *v) *v = x; }
+    return CSI_OK;
+}
 // before the send buffer is packed again: every message posted from it has been copied out
 int32_t local_wait_consumed(csi_context* c) {
     csi_local_group* G = c->local;

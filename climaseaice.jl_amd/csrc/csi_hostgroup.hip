@@ -4,7 +4,9 @@
 // `long` / `int`), every wait bounded by a time-out: a rank that never arrives makes the others fail, not hang.
 #include "csi_hostgroup.h"
 
+#include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -34,8 +36,10 @@ struct RankArea {
     uint8_t payload[kPayload];
 };
 struct Shared {
-    std::atomic<int> state;            // 0 fresh (zero-filled by the kernel), 1 being initialised, 2 ready
+    std::atomic<int> state;            // 0 fresh (zero-filled by the kernel), 2 ready
     int world;
+    long creator_pid;                  // rank 0's pid: a segment whose creator is gone is a stale one (hostgroup_join)
+    std::atomic<int> joined;           // ranks that have accepted this segment
     std::atomic<long> arrived, generation;
     RankArea rank[kMaxWorld];
     Queue box[kMaxWorld * kMaxWorld];  // [src * world + dst]
@@ -84,29 +88,58 @@ static bool phase(HostGroup* g) {
     return spin_until([&] { return sh->generation.load(std::memory_order_acquire) != gen; });
 }
 
+// Joining.  Rank 0 OWNS the name: it removes whatever an earlier run may have left under it (a run that crashed or timed out
+// inside its join never unlinked its segment, whose arrival counters, generation and payloads would release this run's barriers
+// early or never and hand out garbage IPC handles -- ADVICE round 4), creates the segment with O_EXCL and stamps it with its pid.
+// The other ranks never create: they open what exists and accept it only if it is complete (size), initialised (state 2), for this
+// world size and stamped by a LIVING process -- a stale segment's creator is gone -- and otherwise drop it and look again, until
+// the time-out.  The name is unlinked as soon as everybody has it mapped, and also on every failure path of rank 0.
+static bool pid_alive(long pid) { return pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM); }
+
 HostGroup* hostgroup_join(const char* shm_name, int world, int rank, std::string* err) {
     if (!shm_name || world < 1 || world > kMaxWorld || rank < 0 || rank >= world) { fail(err, "bad name / world size / rank (at most 16 ranks)"); return nullptr; }
-    const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) { fail(err, std::string("shm_open(") + shm_name + ") failed"); return nullptr; }
-    if (ftruncate(fd, (off_t)sizeof(Shared)) != 0) { close(fd); fail(err, "ftruncate failed"); return nullptr; }
-    void* p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) { fail(err, "mmap failed"); return nullptr; }
-    Shared* sh = (Shared*)p;
-    int expect = 0;
-    if (sh->state.compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
-        sh->world = world;                       // (everything else starts as the zeros of a fresh segment)
+    Shared* sh = nullptr;
+    if (rank == 0) {
+        (void)shm_unlink(shm_name);                      // a stale segment of an earlier run, if any
+        const int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { fail(err, std::string("shm_open(") + shm_name + ", O_CREAT | O_EXCL) failed: another job is using this name"); return nullptr; }
+        if (ftruncate(fd, (off_t)sizeof(Shared)) != 0) { close(fd); shm_unlink(shm_name); fail(err, "ftruncate failed"); return nullptr; }
+        void* p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { shm_unlink(shm_name); fail(err, "mmap failed"); return nullptr; }
+        sh = (Shared*)p;                                 // (a fresh segment is zero-filled by the kernel)
+        sh->world = world;
+        sh->creator_pid = (long)getpid();
         sh->state.store(2, std::memory_order_release);
-    } else if (!spin_until([&] { return sh->state.load(std::memory_order_acquire) == 2; })) {
-        munmap(p, sizeof(Shared));
-        fail(err, "the segment was never initialised (stale name of an earlier run?)");
-        return nullptr;
+    } else {
+        const double t0 = now_seconds();
+        for (long it = 0; !sh; ++it) {
+            if (now_seconds() - t0 > kTimeoutSeconds) { fail(err, "rank 0 never created the segment (or only a stale one of an earlier run was found)"); return nullptr; }
+            if (it) usleep(it < 200 ? 500 : 5000);
+            const int fd = shm_open(shm_name, O_RDWR, 0600);
+            if (fd < 0) continue;                        // not there yet
+            struct stat st;
+            if (fstat(fd, &st) != 0 || st.st_size != (off_t)sizeof(Shared)) { close(fd); continue; }      // rank 0 is between shm_open and ftruncate
+            void* p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p == MAP_FAILED) continue;
+            Shared* cand = (Shared*)p;
+            const bool good = cand->state.load(std::memory_order_acquire) == 2 && cand->world == world && pid_alive(cand->creator_pid) &&
+                              cand->joined.load(std::memory_order_acquire) < world;
+            if (!good) { munmap(p, sizeof(Shared)); continue; }      // being initialised, or stale: look again (rank 0 replaces a stale one)
+            sh = cand;
+        }
     }
-    if (sh->world != world) { munmap(p, sizeof(Shared)); fail(err, "the ranks disagree about the world size"); return nullptr; }
+    sh->joined.fetch_add(1, std::memory_order_acq_rel);
     HostGroup* g = new HostGroup;
     g->sh = sh; g->world = world; g->rank = rank;
     // everybody has the segment mapped: the name can go (no leak if a rank dies later)
-    if (!phase(g)) { fail(err, "a rank did not join within two minutes"); munmap(p, sizeof(Shared)); delete g; return nullptr; }
+    if (!phase(g)) {
+        fail(err, "a rank did not join within two minutes");
+        if (rank == 0) shm_unlink(shm_name);
+        munmap(sh, sizeof(Shared)); delete g;
+        return nullptr;
+    }
     if (rank == 0) shm_unlink(shm_name);
     return g;
 }

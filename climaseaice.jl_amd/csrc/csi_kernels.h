@@ -136,6 +136,8 @@ struct AdvDev {
     // base + dt G written to OTHER arrays (ho, ao; with their halo images), so that no block reads what another has updated
     FRef hb, ab, ho, ao;    // the update's base (Psi^-) and output
     int write_cache;        // first stage: also store the base values into hm, am (cache_current_fields!, with halo images)
+    int nt;                 // tracers per thread of the tendency kernel: 0 by grid size, 1 / 2 forced (CSI_ADV_NT)
+    int w32;                // WENO schemes: smoothness indicators / weights in single precision (csi_set_weno_weight_dtype; advect.hip)
 };
 void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s);
 void launch_tracer_step(const AdvDev& A, hipStream_t s);

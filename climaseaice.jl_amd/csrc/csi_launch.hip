@@ -3,6 +3,17 @@
 
 namespace csi_host {
 
+// csi_subcycle_stats_*: an extra event behind ev0 / ev1 of every sub-step loop while the statistics are on
+static int32_t stats_mark(csi_context* c) {
+    if (!c->stats.on || c->stats.ev.size() >= 2 * 4096) return CSI_OK;
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    HIP_TRY(c, hipEventRecord(e, c->stream));
+    c->stats.ev.push_back(e);
+    return CSI_OK;
+}
+static void stats_launches(csi_context* c, int n) { if (c->stats.on && c->stats.launches.size() * 2 < c->stats.ev.size()) c->stats.launches.push_back(n); }
+
 // peer: the caller (run_fused_peer) has turned the connected sides of c->g / P.g into periodic ones: the launch loop is that of an
 // untiled periodic grid, the halo images of those sides go to the neighbouring tiles' arrays and every pair launch carries a
 // number of the flag protocol.  band: the caller (run_fused_fold) has cut the rows next to a north fold off c->g / P.g.
@@ -183,6 +194,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     int m = 0, nex = 0, nlaunch = 0;
     const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if ((rc = stats_mark(c))) return rc;
     if (band) {
         HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));      // the first band starts behind everything queued so far
         HIP_TRY(c, hipEventRecord(c->band_ev_band, c->stream));      // (nothing for the first pair launch to wait for)
@@ -251,6 +263,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipMemcpyAsync(c->peer.err_host, c->peer.err, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if ((rc = stats_mark(c))) return rc;
+    stats_launches(c, nlaunch);
     if (cur == 1)   // the result sits in the library's buffers
         for (int q = 0; q < 5; ++q) {
             const Bound& b = c->f[kPing[q]];
@@ -385,6 +399,7 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     c->peer.last = 0;
     if (tiled && (rc = exchange(c, uvs, nxf, W))) return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if ((rc = stats_mark(c))) return rc;
     int m = 0, nex = 0;   // position inside the exchange batch
     for (int s = first; s < first + substeps; ++s) {
         const int V = W - 2 * m;
@@ -411,6 +426,8 @@ int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if ((rc = stats_mark(c))) return rc;
+    stats_launches(c, substeps * (fast ? 3 : 4));
     HIP_TRY(c, hipGetLastError());
     c->timed = true;
     c->launches_per_substep = (fast ? 3 : 4) + ((tiled && k == 1) ? 3 : 0);
@@ -488,6 +505,8 @@ AdvDev adv_dev(const csi_context* c, int scheme, double dt, int from_cache) {
     A.has_snow = c->f[CSI_F_HS].p != nullptr && c->f[CSI_F_GHS].p != nullptr;     // snow thickness: the third tracer
     if (A.has_snow) { A.hs = ref_of(c, CSI_F_HS); A.Ghs = ref_of(c, CSI_F_GHS); A.hsm = ref_of(c, CSI_F_HSM); }
     A.scheme = scheme; A.dt = dt; A.from_cache = from_cache;
+    A.w32 = c->weno_w32;
+    A.nt = c->tune.adv_nt > 0 ? c->tune.adv_nt : 0;
     A.fill_images = 0; A.im = image_spec(c, CSI_F_H);
     return A;
 }

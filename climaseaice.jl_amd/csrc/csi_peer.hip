@@ -73,33 +73,56 @@ PeerSets peer_my_sets(csi_context* c) {
 
 // Collective over the context's communicator: every rank publishes IPC handles of its arrays and flags, maps its neighbours'.
 // Failure anywhere (no IPC, strides that differ across a side, sets larger than the flag array) makes EVERY rank stay on RCCL.
+// Protocol tier the kernels run (FI_PTIER).  Automatic (csi_set_peer_tier(-1), the default): tier 1 -- an acquire fence behind the
+// flags of every waiting tile -- as soon as a neighbour lives in another PROCESS or on another DEVICE; tier 0 (no fence: it rests on
+// the reasoning of evp_fused2.hip about what cannot be cached) only where that reasoning has been soaked: one tile connected to itself
+// and the tiles of an in-process group on one device.  Tier 0 across devices is an explicit opt-in (a passing
+// bitwise check cannot prove a protocol whose failure would be a rare, timing-dependent stale line).
+int peer_effective_tier(const csi_context* c) {
+    if (c->peer.tier >= 0) return c->peer.tier;
+    return (c->world > 1 && !c->local) ? 1 : 0;
+}
+
+// Collective over the context's communicator: every rank publishes IPC handles of its arrays and flags, maps its neighbours'.
+// Failure anywhere (no IPC, strides that differ across a side, sets larger than the flag array) makes EVERY rank stay on RCCL.
+// Every LOCAL failure before the collectives (a device call, an allocation, an IPC handle) turns into ok = 0 and this rank still
+// takes part in both of them -- an early return here would strand the other ranks inside ncclAllGather / ncclAllReduce (ADVICE
+// round 3 / 4).  The one exception is the staging buffer of the RCCL all-gather itself: without it this rank cannot take part.
 int32_t peer_setup(csi_context* c, bool local_ok) {
     csi_context::Peer& pr = c->peer;
-    HIP_TRY(c, hipSetDevice(c->device));                   // (allocations and IPC mappings below belong to the context's device)
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int ok = local_ok ? 1 : 0;          // (a rank whose own configuration rules the transport out still takes part: every rank or none)
+    std::string soft_err;
+    auto soft = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        (void)hipGetLastError();
+        if (soft_err.empty()) soft_err = std::string("peer set-up: ") + what + ": " + hipGetErrorString(e);
+        ok = 0;
+        return false;
+    };
+    soft(hipSetDevice(c->device), "hipSetDevice");           // (allocations and IPC mappings below belong to the context's device)
+    soft(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     peer_release(c);
     const int me = c->tile.ry * c->tile.Rx + c->tile.rx;
     if (!pr.slots) {
         // fine-grained (uncached) device memory where the runtime offers it: the flags are polled while remote ranks write them
         if (hipExtMallocWithFlags((void**)&pr.slots, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
-            HIP_TRY(c, hipMalloc((void**)&pr.slots, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS));
+            pr.slots = nullptr;
+            if (!soft(hipMalloc((void**)&pr.slots, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS), "hipMalloc(flags)")) pr.slots = nullptr;
         }
-        HIP_TRY(c, hipMalloc((void**)&pr.err, sizeof(unsigned)));
-        HIP_TRY(c, hipHostMalloc((void**)&pr.err_host, sizeof(unsigned), hipHostMallocDefault));
     }
+    if (!pr.err && !soft(hipMalloc((void**)&pr.err, sizeof(unsigned)), "hipMalloc(error word)")) pr.err = nullptr;
+    if (!pr.err_host && !soft(hipHostMalloc((void**)&pr.err_host, sizeof(unsigned), hipHostMallocDefault), "hipHostMalloc(error word)")) pr.err_host = nullptr;
     {
         const size_t need_x = sizeof(PeerRec) * kPeerRecs * (size_t)(c->world + 1) + 64;      // (a later csi_comm_init may have a larger world)
         if (need_x > pr.xbuf_cap) {
             if (pr.xbuf) hipFree(pr.xbuf);
             pr.xbuf = nullptr; pr.xbuf_cap = 0;
-            HIP_TRY(c, hipMalloc((void**)&pr.xbuf, need_x));
+            HIP_TRY(c, hipMalloc((void**)&pr.xbuf, need_x));      // (the all-gather's own staging: the one failure this rank cannot report collectively)
             pr.xbuf_cap = need_x;
         }
     }
-    HIP_TRY(c, hipMemset(pr.slots, 0, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS));
-    HIP_TRY(c, hipMemset(pr.err, 0, sizeof(unsigned)));
-    *pr.err_host = 0;
+    if (!pr.slots || !pr.err || !pr.err_host) ok = 0;
     pr.seq = 0;
     pr.ny_below = c->Ny;
     // neighbours: where this tile's images go (a periodic or wall component keeps the coordinate: wraps / mirrors are local
@@ -119,14 +142,13 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
                                                   c->f[CSI_F_U].ld, c->f[CSI_F_V].ld, c->f[CSI_F_S11].ld, c->f[CSI_F_S22].ld, c->f[CSI_F_S12].ld,
                                                   c->f[CSI_F_ALPHA].ld, c->f[CSI_F_ZETA_C].ld, c->f[CSI_F_ZETA_F].ld, c->f[CSI_F_DELTA].ld};
     std::vector<PeerRec> mine(kPeerRecs), all((size_t)kPeerRecs * c->world);
-    int ok = local_ok ? 1 : 0;          // (a rank whose own configuration rules the transport out still takes part: every rank or none)
     for (int q = 0; q < kPeerRecs; ++q) {
         const void* ptr = q < csi_context::Peer::NARR ? local[q] : (const void*)pr.slots;
         PeerRec& r = mine[q];
         memset(&r, 0, sizeof r);
         r.ld = q < csi_context::Peer::NARR ? lds[q] : 0;
         r.local_ptr = (uint64_t)ptr;
-        if (q == 0 && local_ok) {
+        if (q == 0 && local_ok) {      // (the launch geometry is host arithmetic: independent of the soft failures above)
             const PeerSets ps = peer_my_sets(c);
             for (int d = 0; d < 8; ++d) { r.set_size[d] = ps.size[d]; pr.set_sig[d] = ps.size[d]; if (ps.size[d] >= csi_context::Peer::SLOTS) ok = 0; }
         }
@@ -152,13 +174,22 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         memcpy(all.data(), bytes.data(), bytes.size());
     } else if (c->world > 1) {
         const size_t nb = sizeof(PeerRec) * kPeerRecs;
-        HIP_TRY(c, hipMemcpy(pr.xbuf, mine.data(), nb, hipMemcpyHostToDevice));
-        NCCL_TRY(c, ncclAllGather(pr.xbuf, pr.xbuf + nb, nb, ncclUint8, c->comm, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(all.data(), pr.xbuf + nb, nb * c->world, hipMemcpyDeviceToHost));
+        // (a local copy that fails must not keep this rank out of the collectives: it takes part and votes 0 below)
+        soft(hipMemcpy(pr.xbuf, mine.data(), nb, hipMemcpyHostToDevice), "hipMemcpy(records)");
+        NCCL_TRY(c, ncclAllGather(pr.xbuf, pr.xbuf + nb, nb, ncclUint8, c->comm, c->stream));      // (an RCCL error is fatal for the communicator anyway)
+        if (!soft(hipStreamSynchronize(c->stream), "hipStreamSynchronize(all-gather)") ||
+            !soft(hipMemcpy(all.data(), pr.xbuf + nb, nb * c->world, hipMemcpyDeviceToHost), "hipMemcpy(all records)"))
+            for (PeerRec& r : all) r.ok = 0;
     } else {
         all = mine;
     }
+    // Every rank has arrived (and drained its stream on entry): no kernel anywhere still publishes into this rank's flag array or
+    // raises its abort words.  NOW the flags, the abort words and the error word are cleared -- cleared before the all-gather, a
+    // neighbour still finishing its last launch (or its aborted sub-cycle) could write them again behind the memset and the
+    // restarted launch numbers would meet stale flags.  No rank launches before the all-reduce below has returned.
+    if (pr.slots) soft(hipMemset(pr.slots, 0, sizeof(unsigned long long) * 8 * csi_context::Peer::SLOTS), "hipMemset(flags)");
+    if (pr.err) soft(hipMemset(pr.err, 0, sizeof(unsigned)), "hipMemset(error word)");
+    if (pr.err_host) *pr.err_host = 0;
     // map the neighbours' buffers (one mapping per distinct allocation)
     struct Mapped { int rank; hipIpcMemHandle_t h; void* p; };
     std::vector<Mapped> cache;
@@ -210,12 +241,17 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         for (int r = 0; r < c->world; ++r) { int x; memcpy(&x, bytes.data() + (size_t)r * sizeof(int), sizeof(int)); if (x < ok) ok = x; }
     } else if (c->world > 1) {                               // every rank or none
         int* flag = (int*)pr.xbuf;
-        HIP_TRY(c, hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice));
+        // (a failing upload votes with a zeroed word: hipMemset is tried, and whatever the word holds this rank itself ends with ok = 0)
+        const bool up = soft(hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(vote)");
+        if (!up) (void)hipMemset(flag, 0, sizeof(int));
         NCCL_TRY(c, ncclAllReduce(flag, flag, 1, ncclInt32, ncclMin, c->comm, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(&ok, flag, sizeof(int), hipMemcpyDeviceToHost));
+        int voted = 0;
+        if (soft(hipStreamSynchronize(c->stream), "hipStreamSynchronize(vote)") && soft(hipMemcpy(&voted, flag, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy(vote back)"))
+            ok = ok && voted;
+        else ok = 0;
     }
-    if (!ok) { peer_release(c); pr.failed = true; return CSI_OK; }
+    if (!ok) { peer_release(c); pr.failed = true; if (!soft_err.empty()) c->err = soft_err + " (every rank stays on the RCCL exchange)"; return CSI_OK; }
+    pr.aborted = false;
     for (int q = 0; q < csi_context::Peer::NARR; ++q) pr.sig[q] = local[q];
     pr.ready = true;
     return CSI_OK;
@@ -279,7 +315,7 @@ int32_t peer_fill_table(csi_context* c, const FusedGeom& G, bool out_is_alt, Fus
     t->I[FI_NYLO] = c->peer.ny_below > 0 ? c->peer.ny_below : c->Ny;
     t->P[FP_PERR] = (unsigned long)pr.err;
     t->I[FI_PEER] = 1; t->I[FI_PMASK] = mask;
-    t->I[FI_PTIER] = pr.tier;
+    t->I[FI_PTIER] = peer_effective_tier(c);
     t->I[FI_PSET] = ps.nW; t->I[FI_PSET + 1] = ps.nE; t->I[FI_PSET + 2] = ps.nS; t->I[FI_PSET + 3] = ps.nN;
     return CSI_OK;
 }

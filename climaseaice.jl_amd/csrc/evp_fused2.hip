@@ -57,6 +57,9 @@
                                 // edge tile: +6 us per launch on a 1024 x 512 tile, +20 us at 2048^2 (profiles/r03_peer_protocol.md); bit 0 alone:
                                 // no fence, bit 2: no wait at the start of an edge tile (timing experiments, not valid protocols)
 #endif
+#ifndef CSI_PAIR_SKIPB
+#define CSI_PAIR_SKIPB 0       // 1: the consumer wave skips its first iterations of a tile (pure pipeline lag; see bodyB).  Measured round 5, same-box A/B: 2048 x 256 43.0 G with, 43.4 without; 1024 x 512 43.1 / 43.5 -- the test in every iteration costs more than two idle iterations save: off
+#endif
 #ifndef CSI_PAIR_PD
 #define CSI_PAIR_PD 1           // rows the producer prefetches ahead (1 or 2; 2 costs 20 more VGPRs)
 #endif
@@ -545,7 +548,18 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         }
     };
     // ring slot of row j (lane-private column): element f of row j sits at ring[((j - rstart) & 3) * 5 + f][lane]
-    auto rslot = [&](int j) __attribute__((always_inline)) { return (unsigned)((j - rstart) & (RING_ROWS - 1)) * (RING_FIELDS * 64) + (unsigned)lane; };
+    // MASK instantiations (their row loops are a few registers over the 168 of three waves per SIMD): the lane index is formed
+    // again in every iteration (two v_mbcnt, volatile so that it is not hoisted) instead of being kept -- kept, it was spilled to
+    // scratch memory and came back behind an s_waitcnt vmcnt(0) that also drained the producer's row prefetch (round 5, ISA listing)
+    unsigned lane_it = (unsigned)lane;
+    auto fresh_lane = [&]() __attribute__((always_inline)) {
+        if constexpr (MASK && !FULL) {
+            unsigned l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            lane_it = l;
+        }
+    };
+    auto rslot = [&](int j) __attribute__((always_inline)) { return (unsigned)((j - rstart) & (RING_ROWS - 1)) * (RING_FIELDS * 64) + lane_it; };
 
 #ifndef CSI_PAIR_UNROLL
 #define CSI_PAIR_UNROLL 3
@@ -645,6 +659,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             constexpr int k = decltype(KK)::value;
             if (!CSI_PAIR_HOIST || FORCE || (FULL && CSI_FULL_FENCE)) asm volatile("" : "+s"(T));
             set_prio(k);
+            fresh_lane();
             PROBE_START;
             // rows r and r + 1 are in flight (loads return in order; FORCE: the array loads of the previous iteration were
             // consumed there): wait until only row r + 1's remain
@@ -729,7 +744,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                     ring[s0 + RF_PL_DXF2 * 64] = A.DXF2_p; ring[s0 + RF_PL_DYF2 * 64] = A.DYF2_p; ring[s0 + RF_PL_RAZF * 64] = A.RAZF_p;
                     ring[s0 + RF_PL_DYU * 64] = A.DYU_0; ring[s0 + RF_PL_DYC2 * 64] = A.DYC2_0; ring[s0 + RF_PL_DXC2 * 64] = A.DXC2_0;
                 }
-                if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] = mhist & 3u;
+                if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + lane_it] = mhist & 3u;
             }
             A.shift(C.u_p, C.v_p, m_0, C.a_0);
             PROBE(pacc1);
@@ -855,6 +870,13 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         PROBE_START;
         __syncthreads();                                  // the producer has finished row r
         PROBE(pacc0);
+        // The consumer's first iterations of a tile (q < ja - 3: q = rstart - 2, rstart - 1 unless the tile starts at the low end of
+        // the first sub-step's range) read ring rows the producer has not written yet: pure pipeline lag, whose results the next two
+        // iterations -- which fill the window from rows ja - 2, ja - 1 -- overwrite completely (the first stress row is ja - 1, the
+        // first velocity row ja).  They are skipped (round 5): the wave only keeps the barrier count, and the SIMD's other wave has
+        // the vector ALU to itself meanwhile.  (Not with per-point metrics: their steps carry the plane prefetch of the next one.)
+        if constexpr (!FULL && CSI_PAIR_SKIPB) { if (q < ja - 3) return; }
+        fresh_lane();
         // ---- stage A's results from the ring: u, v of row q + 1, sigma of row q; P, m, aice of row q, u^n of row q - 1, v^n
         const unsigned s1 = rslot(r - 1), s2 = rslot(r - 2), s3 = rslot(r - 3);
         double bu_p = ring[s1 + RF_U * 64], bv_p = ring[s1 + RF_V * 64];
@@ -870,7 +892,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         const double bun = ring[s3 + RF_UN * 64], vn_new = ring[s2 + RF_VN * 64];
         const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
         vn_delay = vn_new;
-        const unsigned bmk = MASK ? ringm[(unsigned)((r - 2 - rstart) & (RING_ROWS - 1)) * 64 + (unsigned)lane] : 0u;
+        const unsigned bmk = MASK ? ringm[(unsigned)((r - 2 - rstart) & (RING_ROWS - 1)) * 64 + lane_it] : 0u;
         if constexpr (FULL) {
             if (fhave) flush(fq, f11, f22, f12, ffirst, fsecond, Idx<(CSI_PAIR_STORES & 7)>{}, Idx<AUF ? 1 : 0>{});
         }

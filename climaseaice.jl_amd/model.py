@@ -127,11 +127,18 @@ def snow_slab_thermodynamics(grid=None, conductivity=0.31, **kw):
 
 
 class WENO:
-    def __init__(self, order=5):
+    """WENO(order = 3 | 5 | 7), upstream's upwind-biased WENO-Z scheme (called at sea_ice_advection.jl:51-58).
+    weight_dtype: "f64" (default) or "f32" -- the precision of the smoothness indicators and nonlinear weights, mirroring the second
+    float type parameter FT2 of newer upstream versions (include/csi.h: csi_set_weno_weight_dtype; recalled, unverified)."""
+
+    def __init__(self, order=5, weight_dtype="f64"):
         if order not in (3, 5, 7):
             raise NotImplementedError("WENO order 3, 5 or 7")
+        if weight_dtype not in ("f64", "f32"):
+            raise ValueError("weight_dtype must be 'f64' or 'f32'")
         self.order = order
         self.scheme = order
+        self.weight_dtype = weight_dtype
 
 
 class UpwindBiased:
@@ -202,6 +209,7 @@ class SeaIceModel:
         self.ctx = _lib.Context(dev.index or 0, stream)
         self._configure()
         self.set_mode(mode)
+        self.ctx.call("csi_set_weno_weight_dtype", 1 if getattr(advection, "weight_dtype", "f64") == "f32" else 0)
         torch.cuda.synchronize(self.device)   # field initialisation ran on torch's stream
 
     # ---- plumbing: describe the problem to the library -----------------------------------------

@@ -202,6 +202,15 @@ int32_t csi_context_destroy(csi_context* ctx);
 /* Text of the most recent failure on ctx (or of context creation when ctx == NULL). */
 const char* csi_last_error(const csi_context* ctx);
 int32_t csi_sync(csi_context* ctx);
+/* csi_sync + the halo transport's status reduced over ALL ranks of the context's communicator (collective: every rank calls it
+ * between the same two steps; one rank: the same as csi_sync).  A peer-transport wait that gave up reaches only the direct
+ * neighbours' abort words; this is the call that lets every rank see it and take the same decision -- what the Julia side calls
+ * before output writers / checkpointers read a Distributed model's fields (julia/ClimaSeaIceHIP.jl validate_state!; the
+ * reference's own check of a distributed run is done after the fact, test/distributed_tests_utils.jl:40-88). */
+int32_t csi_validate_all(csi_context* ctx);
+/* Testing aid: leaves the host side in the state a timed-out wait of the peer transport's flag protocol leaves it in (the sticky
+ * CSI_ERR_COMM above), without the wait.  Not for production use. */
+int32_t csi_debug_peer_abort(csi_context* ctx);
 int32_t csi_set_mode(csi_context* ctx, int32_t mode);
 
 /* ---- problem description ----------------------------------------------------------------- */
@@ -265,6 +274,16 @@ int32_t csi_evp_finalize(csi_context* ctx);
 int32_t csi_time_step_momentum(csi_context* ctx, double dt, int32_t substeps, int32_t rk_reset);
 /* compute_tracer_tendencies!(model), tracer_tendency_kernel_functions.jl:9-45 */
 int32_t csi_compute_tracer_tendencies(csi_context* ctx, int32_t scheme);
+/* Precision of a WENO scheme's smoothness indicators and nonlinear weights inside csi_compute_tracer_tendencies / the time steppers.
+ * CSI_WEIGHTS_F64 (default): everything in double.  CSI_WEIGHTS_F32: the indicators, tau, the ratios, the unnormalised weights and
+ * their sum in float on float-converted stencil values; candidates and the final combination in double -- the library's reading
+ * of the second float type parameter FT2 (= Float32 by default) that newer Oceananigans versions give WENO{N, FT, FT2, ...}, whose
+ * instances the reference only calls (src/sea_ice_advection.jl:51-58).  RECALLED, not verified: the Julia side
+ * selects the mode from typeof(model.advection) (julia/ClimaSeaIceHIP.jl weight_dtype), bench/reference_driver.jl dumps that type
+ * with its fields so that a reference run shows which mode it was.  Both modes: STRICT equals the oracle bit for bit. */
+enum { CSI_WEIGHTS_F64 = 0, CSI_WEIGHTS_F32 = 1 };
+int32_t csi_set_weno_weight_dtype(csi_context* ctx, int32_t dtype);
+int32_t csi_weno_weight_dtype(csi_context* ctx, int32_t* dtype);
 /* dynamic_time_step!(model, dt): sea_ice_fe_step.jl:36-82 (from_cache = 0), sea_ice_rk_substep.jl:134-152 (1) */
 int32_t csi_dynamic_step_tracers(csi_context* ctx, double dt, int32_t from_cache);
 /* cache_current_fields!(model), sea_ice_rk_substep.jl:29-42 */
@@ -413,15 +432,23 @@ int32_t csi_set_exchange_interval(csi_context* ctx, int32_t k);
 enum { CSI_TRANSPORT_RCCL = 0, CSI_TRANSPORT_PEER = 1 };
 int32_t csi_set_halo_transport(csi_context* ctx, int32_t kind);
 int32_t csi_halo_transport(csi_context* ctx, int32_t* kind);
-/* Run-time tiers of the peer transport's memory-ordering protocol.  Every rank of a decomposition must set the SAME tier (the
- * host decides for all ranks: bench.py walks the ladder 0 -> 1 -> 2 -> RCCL and keeps the first tier whose tiled run reproduces
- * the one-GPU run bit for bit).
- *   0 (default): halo images are write-through stores at system scope, flags follow the drained store queue; a waiting tile
- *      loads nothing before it has seen the flags and issues no cache maintenance (measured fastest);
- *   1: + a system-scope acquire fence (buffer_inv sc0 sc1) in every waiting tile once the flags have been seen;
+/* Run-time tiers of the peer transport's memory-ordering protocol.  Every rank of a decomposition must set the SAME tier.
+ *  -1 (default): automatic -- tier 1 whenever a neighbour lives in another process or on another device (one process per GPU, the
+ *      host-channel group), tier 0 for a tile connected to itself and for the tiles of an in-process group on one device;
+ *   0: halo images are write-through stores at system scope, flags follow the drained store queue; a waiting tile loads nothing
+ *      before it has seen the flags and issues no cache maintenance (measured fastest).  It rests on an
+ *      argument about what CANNOT be cached on the receiving GPU; that argument has only ever run inside one L2 domain, and a
+ *      passing tiled == untiled check does not prove it (a violation would be a rare, timing-dependent stale line): across
+ *      devices tier 0 is an explicit opt-in (bench.py --peer-tier 0), never the default;
+ *   1: + a system-scope acquire fence (buffer_inv sc0 sc1) in every waiting tile once the flags have been seen (edge tiles only);
  *   2: + a system-scope release fence (buffer_wbl2 sc0 sc1) before a tile publishes its flags -- the textbook protocol.
+ * csi_peer_tier returns the tier the kernels run (automatic resolved).
  * A wait that gives up after 3 s makes its workgroup leave without storing or publishing, sets this rank's error word and the
- * abort word of every neighbour's flag array; every entry point that advances the model and csi_sync report CSI_ERR_COMM. */
+ * abort word of every neighbour's flag array; every entry point that advances the model and csi_sync report CSI_ERR_COMM -- and
+ * keep reporting it (the error is STICKY: the flags cannot recover by themselves) until the caller has re-armed the transport on
+ * EVERY rank with csi_set_halo_transport (CSI_TRANSPORT_PEER: the next sub-cycle runs the collective set-up again, which clears
+ * flags, abort words and launch numbers once all ranks have arrived; CSI_TRANSPORT_RCCL: the message exchange) or csi_comm_init*.
+ * csi_validate_all spreads the status to ranks that are not neighbours of the one that gave up. */
 int32_t csi_set_peer_tier(csi_context* ctx, int32_t tier);
 int32_t csi_peer_tier(csi_context* ctx, int32_t* tier);
 
@@ -448,6 +475,11 @@ int32_t csi_plan_exchange(int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_
 /* Device time (ms) of the last csi_evp_subcycle / csi_time_step_momentum call measured with HIP
  * events on the context's stream; valid after csi_sync. */
 int32_t csi_last_subcycle_ms(csi_context* ctx, double* ms);
+/* Device time of ALL sub-cycles between the two calls (HIP events on the context's stream around every sub-step loop; _end
+ * synchronises): their sum in ms, their number and the number of kernel launches inside them -- what bench.py divides to get the
+ * dominant kernel's average launch time over the TIMED region itself (at most 4096 sub-cycles are kept). */
+int32_t csi_subcycle_stats_begin(csi_context* ctx);
+int32_t csi_subcycle_stats_end(csi_context* ctx, double* total_ms, int32_t* cycles, int32_t* launches);
 /* How the launch loop would run one PAIR of sub-steps (csi_set_fusion level 2) at position m (even) of an exchange
  * batch of k sub-steps on a grid of this shape: out32[0] = 1 if the pair kernel applies (0: the rest is zero),
  * [1..3] wave-tile geometry (56-column strips, row chunks, rows per chunk), then six index ranges (i0, i1, j0, j1):

@@ -361,9 +361,21 @@ end
 function ClimaSeaIce.compute_tracer_tendencies!(model::HIPSeaIceModel)
     ctx = context(model)
     order = Oceananigans.Advection.required_halo_size_x(model.advection) == 4 ? 7 : 5     # WENO(order = 7 | 5)
+    # precision of the scheme's smoothness / weight arithmetic (round 5): newer upstream versions give WENO a SECOND float type
+    # parameter (WENO{N, FT, FT2, ...}, FT2 = Float32 by default) -- the library has both modes (include/csi.h:
+    # csi_set_weno_weight_dtype) and STRICT equals its oracle bit for bit in either
+    check(ctx, ccall((:csi_set_weno_weight_dtype, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, weight_dtype(model.advection)))
     GC.@preserve model check(ctx, ccall((:csi_compute_tracer_tendencies, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, order))
     return nothing
 end
+
+# CSI_WEIGHTS_F64 (0) / CSI_WEIGHTS_F32 (1) from the scheme's type parameters: the first parameter that is a float type is FT, a
+# second float type -- where the upstream version has one -- is FT2.  Versions with a single float type compute the weights in FT.
+function weight_dtype(scheme)
+    floats = [p for p in typeof(scheme).parameters if p isa Type && p <: AbstractFloat]
+    return (length(floats) >= 2 && floats[2] === Float32) ? Int32(1) : Int32(0)
+end
+weight_dtype(::Nothing) = Int32(0)
 
 # dynamic_time_step!, sea_ice_fe_step.jl:36-50 (Forward Euler: from the current fields) and sea_ice_rk_substep.jl:134-152 (RK: from Ψ⁻)
 function hip_dynamic_time_step!(model, Δt, from_cache)
@@ -383,10 +395,22 @@ ClimaSeaIce.dynamic_time_step!(model::HIPRKSeaIceModel, Δt) = hip_dynamic_time_
 function Oceananigans.TimeSteppers.update_state!(model::HIPSeaIceModel, callbacks = [])
     ctx = context(model)
     GC.@preserve model check(ctx, ccall((:csi_update_state, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
-    # a Distributed grid: the end of a stage is where the host learns that the stage is valid on EVERY rank (a peer-transport wait
-    # that gave up anywhere fails here, not a call later)
-    model.grid.architecture isa Distributed && synchronize!(ctx)
+    # No host synchronisation here (round 5; the round-4 stub drained the stream after every RK stage on Distributed grids, which
+    # cost the host / device overlap of a whole stage and still proved nothing about ranks that are not direct neighbours: a
+    # peer-transport abort reaches the neighbours' abort words only).  csi_update_state -- like every entry point that advances
+    # the model -- reports a transport error it already knows of; `validate_state!` below is the collective check for the places
+    # that need a state known good on EVERY rank (output, checkpoints).
     Oceananigans.Models.update_model_field_time_series!(model, model.clock)
+    return nothing
+end
+
+# Before output writers / checkpointers read the fields of a Distributed model: drain this rank's stream and reduce the transport's
+# error word over ALL ranks (csi_validate_all: an all-reduce on the context's communicator), so that every rank takes the same
+# decision.  A non-zero status anywhere throws on every rank; the peer transport then stays refused until every rank has called
+# csi_set_halo_transport again (include/csi.h), which is a collective decision of the caller.
+function validate_state!(model::HIPSeaIceModel)
+    ctx = context(model)
+    GC.@preserve model check(ctx, ccall((:csi_validate_all, libcsi), Int32, (Ptr{Cvoid},), ctx.handle))
     return nothing
 end
 

@@ -750,6 +750,84 @@ static double upwind3(const double* p) {
     /* UpwindBiased(order = 3), the buffer scheme of UpwindBiased(order = 5) */
     return (-p[0] + 5 * p[1] + 2 * p[2]) / 6;
 }
+/* ---- WENO weights in single precision (weight_dtype f32; SURVEY.md App. B: newer upstream versions carry a second float type
+ * parameter FT2, default Float32, for the smoothness / weight arithmetic of a WENO scheme -- recalled, unverified; the reference
+ * constructs its schemes with the upstream default, /root/reference/src/sea_ice_advection.jl:51-58 only calls them).  What this
+ * mode ASSUMES, stated so that a reference run can confirm or refute it: the stencil values are converted to float, the smoothness
+ * indicators, tau, the ratios and the unnormalised weights alpha_s = C_s (1 + (tau / (beta_s + eps))^2) are evaluated in float with
+ * float constants (the same expressions, the same order, eps = 1e-8f), their sum too; the candidate values stay double, and the
+ * result is (sum alpha_s q_s) / (sum alpha_s) in double with the alphas widened.  Default is f64 (weight_f32 = 0). */
+#define WENO_EPS_F 1e-8f
+static void weno5_parts_f32(const double* p, double* q, float* b, float* a, float* tau_out) {
+    float f[5];
+    for (int k = 0; k < 5; ++k) f[k] = (float)p[k];
+    q[0] = (2 * p[2] + 5 * p[3] - p[4]) / 6;
+    q[1] = (-p[1] + 5 * p[2] + 2 * p[3]) / 6;
+    q[2] = (2 * p[0] - 7 * p[1] + 11 * p[2]) / 6;
+    b[0] = (f[2] * (10 * f[2] - 31 * f[3] + 11 * f[4]) + f[3] * (25 * f[3] - 19 * f[4]) + f[4] * (4 * f[4])) / 3;
+    b[1] = (f[1] * (4 * f[1] - 13 * f[2] + 5 * f[3]) + f[2] * (13 * f[2] - 13 * f[3]) + f[3] * (4 * f[3])) / 3;
+    b[2] = (f[0] * (4 * f[0] - 19 * f[1] + 11 * f[2]) + f[1] * (25 * f[1] - 31 * f[2]) + f[2] * (10 * f[2])) / 3;
+    float tau = fabsf(b[0] - b[2]);
+    float r0 = tau / (b[0] + WENO_EPS_F), r1 = tau / (b[1] + WENO_EPS_F), r2 = tau / (b[2] + WENO_EPS_F);
+    a[0] = (float)(3.0 / 10) * (1 + r0 * r0);
+    a[1] = (float)(3.0 / 5) * (1 + r1 * r1);
+    a[2] = (float)(1.0 / 10) * (1 + r2 * r2);
+    *tau_out = tau;
+}
+static double weno5_f32(const double* p) {
+    double q[3]; float b[3], a[3], tau;
+    weno5_parts_f32(p, q, b, a, &tau);
+    float s = a[0] + a[1] + a[2];
+    return ((double)a[0] * q[0] + (double)a[1] * q[1] + (double)a[2] * q[2]) / (double)s;
+}
+static void weno7_parts_f32(const double* p, double* q, float* b, float* a, float* tau_out) {
+    float f[7];
+    for (int k = 0; k < 7; ++k) f[k] = (float)p[k];
+    q[0] = (3 * p[3] + 13 * p[4] - 5 * p[5] + p[6]) / 12;
+    q[1] = (-p[2] + 7 * p[3] + 7 * p[4] - p[5]) / 12;
+    q[2] = (p[1] - 5 * p[2] + 13 * p[3] + 3 * p[4]) / 12;
+    q[3] = (-3 * p[0] + 13 * p[1] - 23 * p[2] + 25 * p[3]) / 12;
+    b[0] = f[3] * (2.107f * f[3] - 9.402f * f[4] + 7.042f * f[5] - 1.854f * f[6]) +
+           f[4] * (11.003f * f[4] - 17.246f * f[5] + 4.642f * f[6]) + f[5] * (7.043f * f[5] - 3.882f * f[6]) + f[6] * (0.547f * f[6]);
+    b[1] = f[2] * (0.547f * f[2] - 2.522f * f[3] + 1.922f * f[4] - 0.494f * f[5]) +
+           f[3] * (3.443f * f[3] - 5.966f * f[4] + 1.602f * f[5]) + f[4] * (2.843f * f[4] - 1.642f * f[5]) + f[5] * (0.267f * f[5]);
+    b[2] = f[1] * (0.267f * f[1] - 1.642f * f[2] + 1.602f * f[3] - 0.494f * f[4]) +
+           f[2] * (2.843f * f[2] - 5.966f * f[3] + 1.922f * f[4]) + f[3] * (3.443f * f[3] - 2.522f * f[4]) + f[4] * (0.547f * f[4]);
+    b[3] = f[0] * (0.547f * f[0] - 3.882f * f[1] + 4.642f * f[2] - 1.854f * f[3]) +
+           f[1] * (7.043f * f[1] - 17.246f * f[2] + 7.042f * f[3]) + f[2] * (11.003f * f[2] - 9.402f * f[3]) + f[3] * (2.107f * f[3]);
+    float tau = fabsf(b[0] + 3 * b[1] - 3 * b[2] - b[3]);
+    float r0 = tau / (b[0] + WENO_EPS_F), r1 = tau / (b[1] + WENO_EPS_F), r2 = tau / (b[2] + WENO_EPS_F), r3 = tau / (b[3] + WENO_EPS_F);
+    a[0] = (float)(4.0 / 35) * (1 + r0 * r0);
+    a[1] = (float)(18.0 / 35) * (1 + r1 * r1);
+    a[2] = (float)(12.0 / 35) * (1 + r2 * r2);
+    a[3] = (float)(1.0 / 35) * (1 + r3 * r3);
+    *tau_out = tau;
+}
+static double weno7_f32(const double* p) {
+    double q[4]; float b[4], a[4], tau;
+    weno7_parts_f32(p, q, b, a, &tau);
+    float s = a[0] + a[1] + a[2] + a[3];
+    return ((double)a[0] * q[0] + (double)a[1] * q[1] + (double)a[2] * q[2] + (double)a[3] * q[3]) / (double)s;
+}
+static void weno3_parts_f32(const double* p, double* q, float* b, float* a, float* tau_out) {
+    float f[3];
+    for (int k = 0; k < 3; ++k) f[k] = (float)p[k];
+    q[0] = (p[1] + p[2]) / 2;
+    q[1] = (-p[0] + 3 * p[1]) / 2;
+    b[0] = f[1] * (f[1] - 2 * f[2]) + f[2] * f[2];
+    b[1] = f[0] * (f[0] - 2 * f[1]) + f[1] * f[1];
+    float tau = fabsf(b[0] - b[1]);
+    float r0 = tau / (b[0] + WENO_EPS_F), r1 = tau / (b[1] + WENO_EPS_F);
+    a[0] = (float)(2.0 / 3) * (1 + r0 * r0);
+    a[1] = (float)(1.0 / 3) * (1 + r1 * r1);
+    *tau_out = tau;
+}
+static double weno3_f32(const double* p) {
+    double q[2]; float b[2], a[2], tau;
+    weno3_parts_f32(p, q, b, a, &tau);
+    float s = a[0] + a[1];
+    return ((double)a[0] * q[0] + (double)a[1] * q[1]) / (double)s;
+}
 /* Boundary-order reduction next to walls (upstream topologically_conditional_interpolation, recalled -- SURVEY.md
  * App. B): a scheme with buffer B (order 2B-1) is used at face `idx` (1-based along the line, N cells) only if its
  * biased stencil stays inside the domain, otherwise its buffer scheme (order 2B-3) is tried, down to first-order
@@ -779,21 +857,21 @@ static int reduced_buffer_immersed(const ora_problem* g, int B, int i, int j, in
 }
 /* reconstruct c at a face from a 1-D line of values with the scheme of buffer B; `up` is the upwind cell value index
  * stepping `st` (= +1 for left bias reading towards increasing index). */
-static double reconstruct(int scheme, const double* line, int64_t up, int64_t st, int B) {
+static double reconstruct(int scheme, const double* line, int64_t up, int64_t st, int B, int w32) {
     double p[7];
     if (scheme == 1) return line[up];
     const int weno = scheme > 0;
     if (B == 1) return line[up];
     if (B == 2) {
         for (int k = 0; k < 3; ++k) p[k] = line[up + (k - 1) * st];
-        return weno ? weno3(p) : upwind3(p);
+        return weno ? (w32 ? weno3_f32(p) : weno3(p)) : upwind3(p);
     }
     if (B == 3) {
         for (int k = 0; k < 5; ++k) p[k] = line[up + (k - 2) * st];
-        return weno ? weno5(p) : upwind5(p);
+        return weno ? (w32 ? weno5_f32(p) : weno5(p)) : upwind5(p);
     }
     for (int k = 0; k < 7; ++k) p[k] = line[up + (k - 3) * st];
-    return weno7(p);
+    return w32 ? weno7_f32(p) : weno7(p);
 }
 /* Test hook (tests/test_weno_published.py): the parts of one reconstruction.  order 3 / 5 / 7: WENO; -3 / -5: UpwindBiased
  * (value only).  p: the 2B - 1 stencil values, upwind-most first (B = (|order| + 1) / 2); out: value, then for WENO
@@ -806,6 +884,14 @@ int ora_test_weno(int order, const double* p, double* out) {
     if (order == 3) { B = 2; out[0] = weno3(p); weno3_parts(p, q, b, a, &tau); }
     else if (order == 5) { B = 3; out[0] = weno5(p); weno5_parts(p, q, b, a, &tau); }
     else if (order == 7) { B = 4; out[0] = weno7(p); weno7_parts(p, q, b, a, &tau); }
+    else if (order == 103 || order == 105 || order == 107) {      /* 100 + order: the f32-weight variant, its parts widened to double */
+        float bf[4], af[4], tf = 0.f;
+        if (order == 103) { B = 2; out[0] = weno3_f32(p); weno3_parts_f32(p, q, bf, af, &tf); }
+        else if (order == 105) { B = 3; out[0] = weno5_f32(p); weno5_parts_f32(p, q, bf, af, &tf); }
+        else { B = 4; out[0] = weno7_f32(p); weno7_parts_f32(p, q, bf, af, &tf); }
+        for (int k = 0; k < B; ++k) { b[k] = bf[k]; a[k] = af[k]; }
+        tau = tf;
+    }
     else return 0;
     for (int k = 0; k < B; ++k) { out[1 + k] = q[k]; out[1 + B + k] = b[k]; out[1 + 2 * B + k] = a[k]; }
     out[1 + 3 * B] = tau;
@@ -823,8 +909,8 @@ double ora_weno_flux_x(const ora_problem* g, int scheme, ora_field c, int i, int
     double uu = AT(g, g->u, i, j);
     const double* base = &AT(g, c, i, j);   /* cell i; upwind of a left-biased face i is cell i-1 */
     if (g->has_mask && ora_peripheral_u(g, i, j)) return 0.0;
-    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1, buffer_at(g, scheme, i, j, 0, 1))
-                         : reconstruct(scheme, base, 0, -1, buffer_at(g, scheme, i, j, 0, 0));
+    double ct = (uu > 0) ? reconstruct(scheme, base, -1, 1, buffer_at(g, scheme, i, j, 0, 1), g->weno_weights_f32)
+                         : reconstruct(scheme, base, 0, -1, buffer_at(g, scheme, i, j, 0, 0), g->weno_weights_f32);
     return ora_dy(g, F_, C_, i, j) * uu * ct;    /* Ax = dy * dz, dz = 1 */
 }
 double ora_weno_flux_y(const ora_problem* g, int scheme, ora_field c, int i, int j) {
@@ -832,8 +918,8 @@ double ora_weno_flux_y(const ora_problem* g, int scheme, ora_field c, int i, int
     const double* base = &AT(g, c, i, j);
     int64_t ld = c.ld;
     if (g->has_mask && ora_peripheral_v(g, i, j)) return 0.0;
-    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld, buffer_at(g, scheme, i, j, 1, 1))
-                         : reconstruct(scheme, base, 0, -ld, buffer_at(g, scheme, i, j, 1, 0));
+    double ct = (vv > 0) ? reconstruct(scheme, base, -ld, ld, buffer_at(g, scheme, i, j, 1, 1), g->weno_weights_f32)
+                         : reconstruct(scheme, base, 0, -ld, buffer_at(g, scheme, i, j, 1, 0), g->weno_weights_f32);
     return ora_dx(g, C_, F_, i, j) * vv * ct;    /* Ay = dx^{cf} * dz */
 }
 /* horizontal_div_Uc, sea_ice_advection.jl:51-54 ; G = -div, tracer_tendency_kernel_functions.jl:39-42 */

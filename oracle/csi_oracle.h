@@ -107,7 +107,8 @@ typedef struct {
     ora_field Gh, Ga;            /* tracer tendencies (c,c) */
     ora_field hm, am, um, vm;    /* Psi^- cache for RK3: h, aice, u, v */
     ora_field hs, Ghs, hsm;      /* snow thickness, its tendency and Psi^- copy (used when has_snow) */
-    int32_t has_snow, pad_snow;
+    int32_t has_snow;
+    int32_t weno_weights_f32;    /* 1: WENO smoothness indicators / weights in single precision (upstream's FT2 = Float32, recalled: csi_oracle.c) */
     /* ValueBoundaryCondition on the tangential velocity at a wall (no-slip: examples/ice_advected_on_coastline.jl:96-99):
      * u on the south / north walls, v on the west / east walls; [0] low side, [1] high side.  Upstream fills ONE halo
      * cell, c[0] = 2 val - c[1]; deeper halo cells are left alone.  Default (on = 0): no-flux mirror. */

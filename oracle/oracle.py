@@ -69,7 +69,7 @@ class ProblemStruct(C.Structure):
                  ("fu_rows", C.POINTER(C.c_double)), ("fv_rows", C.POINTER(C.c_double)),
                  ("m2d", C.POINTER(C.c_double) * 12), ("m2d_ld", C.c_int64),
                  ("top", Stress), ("bottom", Stress)] +
-                [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("pad_snow", C.c_int32),
+                [(n, Field) for n in _FIELD_NAMES] + [("has_snow", C.c_int32), ("weno_weights_f32", C.c_int32),
                                                       ("u_value_on", C.c_int32 * 2), ("v_value_on", C.c_int32 * 2),
                                                       ("u_value", C.c_double * 2), ("v_value", C.c_double * 2),
                                                       ("has_forcing", C.c_int32), ("pad_forcing", C.c_int32),

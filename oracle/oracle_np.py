@@ -285,3 +285,80 @@ class NP:
             else:
                 self.v_step(dt); self.fill_halo("v", 0, 1)
                 self.u_step(dt); self.fill_halo("u", 1, 0)
+
+
+# ---- WENO reconstructions (round 5) ---------------------------------------------------------------------------------------------
+# Whole-array restatement of the upwind-biased WENO-Z face values the advection of h and aice uses (upstream Oceananigans, called at
+# /root/reference/src/sea_ice_advection.jl:51-58; candidates, optimal weights, smoothness indicators and tau as derived independently in
+# tests/test_weno_published.py), written without looking at csi_oracle.c's expressions beyond their documented ORDER -- the two must
+# agree bit for bit (tests/test_weno_published.py), in both weight precisions.
+#   P[..., k], k = 0 .. 2B-2: the stencil, upwind-most value first (B = (order + 1) / 2)
+#   weight_dtype "f64": everything in double.  "f32": the smoothness indicators, tau, the ratios, the unnormalised weights and their
+#   sum in float32 on float32-converted stencil values (upstream's second float type FT2 = Float32, recalled -- csi_oracle.c), the
+#   candidates and the final combination in double.
+_WENO = {
+    3: dict(q=[[0, 1, 1], [-1, 3, 0]], qd=2.0, C=[2.0 / 3, 1.0 / 3]),
+    5: dict(q=[[0, 0, 2, 5, -1], [0, -1, 5, 2, 0], [2, -7, 11, 0, 0]], qd=6.0, C=[3.0 / 10, 3.0 / 5, 1.0 / 10]),
+    7: dict(q=[[0, 0, 0, 3, 13, -5, 1], [0, 0, -1, 7, 7, -1, 0], [0, 1, -5, 13, 3, 0, 0], [-3, 13, -23, 25, 0, 0, 0]], qd=12.0,
+            C=[4.0 / 35, 18.0 / 35, 12.0 / 35, 1.0 / 35]),
+}
+
+
+def _weno_beta(p, order, T):
+    """smoothness indicators of the candidates (downwind-most stencil first), dtype T, csi_oracle.c's grouping"""
+    c = lambda x: T(x)      # noqa: E731
+    if order == 3:
+        return [p[1] * (p[1] - c(2) * p[2]) + p[2] * p[2], p[0] * (p[0] - c(2) * p[1]) + p[1] * p[1]]
+    if order == 5:
+        return [(p[2] * (c(10) * p[2] - c(31) * p[3] + c(11) * p[4]) + p[3] * (c(25) * p[3] - c(19) * p[4]) + p[4] * (c(4) * p[4])) / c(3),
+                (p[1] * (c(4) * p[1] - c(13) * p[2] + c(5) * p[3]) + p[2] * (c(13) * p[2] - c(13) * p[3]) + p[3] * (c(4) * p[3])) / c(3),
+                (p[0] * (c(4) * p[0] - c(19) * p[1] + c(11) * p[2]) + p[1] * (c(25) * p[1] - c(31) * p[2]) + p[2] * (c(10) * p[2])) / c(3)]
+    tab = [[2.107, -9.402, 7.042, -1.854, 11.003, -17.246, 4.642, 7.043, -3.882, 0.547],
+           [0.547, -2.522, 1.922, -0.494, 3.443, -5.966, 1.602, 2.843, -1.642, 0.267],
+           [0.267, -1.642, 1.602, -0.494, 2.843, -5.966, 1.922, 3.443, -2.522, 0.547],
+           [0.547, -3.882, 4.642, -1.854, 7.043, -17.246, 7.042, 11.003, -9.402, 2.107]]
+    out = []
+    for s, t in enumerate(tab):
+        a, b, cc, d = p[3 - s], p[4 - s], p[5 - s], p[6 - s]
+        out.append(a * (c(t[0]) * a + c(t[1]) * b + c(t[2]) * cc + c(t[3]) * d) + b * (c(t[4]) * b + c(t[5]) * cc + c(t[6]) * d) +
+                   cc * (c(t[7]) * cc + c(t[8]) * d) + d * (c(t[9]) * d))
+    return out
+
+
+def weno_value(P, order, weight_dtype="f64"):
+    """upwind-biased WENO-Z face value from stencils P[..., 2B-1] (upwind-most first)"""
+    P = np.asarray(P, dtype=np.float64)
+    W = _WENO[order]
+    B = (order + 1) // 2
+    p = [P[..., k] for k in range(2 * B - 1)]
+    q = []
+    for row in W["q"]:
+        acc = None
+        for k, w in enumerate(row):          # left to right over the non-zero entries, as written in the C oracle
+            if w == 0:
+                continue
+            term = p[k] if w == 1 else (-p[k] if w == -1 else w * p[k])
+            acc = term if acc is None else acc + term
+        q.append(acc / W["qd"])
+    # (the C oracle writes the subtractions as "- c p": a + (-c) p == a - c p bit for bit)
+    T = np.float32 if weight_dtype == "f32" else np.float64
+    pw = [x.astype(T) for x in p]
+    beta = _weno_beta(pw, order, T)
+    if order == 3:
+        tau = np.abs(beta[0] - beta[1])
+    elif order == 5:
+        tau = np.abs(beta[0] - beta[2])
+    else:
+        tau = np.abs(beta[0] + T(3) * beta[1] - T(3) * beta[2] - beta[3])
+    eps = T(1e-8)
+    alpha = []
+    for s in range(B):
+        r = tau / (beta[s] + eps)
+        alpha.append(T(W["C"][s]) * (T(1) + r * r))
+    ssum = alpha[0]
+    for s in range(1, B):
+        ssum = ssum + alpha[s]
+    num = alpha[0].astype(np.float64) * q[0]
+    for s in range(1, B):
+        num = num + alpha[s].astype(np.float64) * q[s]
+    return num / ssum.astype(np.float64)

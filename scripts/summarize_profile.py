@@ -120,6 +120,14 @@ if dom:
         ctr["traced_run"] = {"ms_per_step": traced["ms_per_step"], "hip_event_launch_us": traced["roofline"]["avg_launch_ms"] * 1e3, "value": traced["value"]}
     if "SQ_INSTS_VALU" in v:
         ctr["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
+    # round 5: the DYNAMIC mix by class (pmc_mix pass): FP64 fma / mul / add, transcendental (v_rcp_f64 / v_rsq_f64), integer; the rest
+    # -- DPP moves, compares, selects, 64-bit moves -- is what is left of SQ_INSTS_VALU
+    mixkeys = {"SQ_INSTS_VALU_FMA_F64": "fma_f64", "SQ_INSTS_VALU_MUL_F64": "mul_f64", "SQ_INSTS_VALU_ADD_F64": "add_f64",
+               "SQ_INSTS_VALU_TRANS_F64": "trans_f64", "SQ_INSTS_VALU_INT32": "int32", "SQ_INSTS_VALU_INT64": "int64"}
+    if all(k in v for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")):
+        mix = {name_: v[k] for k, name_ in mixkeys.items() if k in v}
+        mix["other"] = v["SQ_INSTS_VALU"] - sum(mix.values())
+        ctr["valu_mix_per_launch"] = mix
     if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v:
         # SQ_ACTIVE_INST_VALU: quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs
         ctr["valu_busy_frac"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0)

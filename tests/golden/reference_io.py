@@ -103,13 +103,25 @@ if __name__ == "__main__":
     (export if sys.argv[1] == "export" else import_)(sys.argv[2])
 
 
-def oracle_run(kw, tag):
-    """The oracle's counterpart of one reference_driver.jl run (same entry points, same order); returns interiors."""
+def weight_dtype_of(versions):
+    """"f64" / "f32" from the DONE file of a reference run (bench/reference_driver.jl writes `weight_dtype ...` from the type
+    parameters of WENO(order = 7): a second float type parameter is the precision of the smoothness / weight arithmetic)."""
+    for ln in str(versions).splitlines():
+        t = ln.split()
+        if len(t) == 2 and t[0] == "weight_dtype" and t[1] in ("f64", "f32"):
+            return t[1]
+    return "f64"
+
+
+def oracle_run(kw, tag, weight_dtype="f64"):
+    """The oracle's counterpart of one reference_driver.jl run (same entry points, same order); returns interiors.
+    weight_dtype: the WENO weight precision the reference run reported (weight_dtype_of)."""
     import cases
     import climaseaice_jl_amd as csi
     nsub = 1 if tag == "momentum1" else 10
     c = cases.make_case(substeps=nsub, **kw)
     p = cases.oracle_problem(c)
+    p.s.weno_weights_f32 = 1 if weight_dtype == "f32" else 0
     if tag.startswith("momentum"):
         p.time_step_momentum(c["dt"])
     else:

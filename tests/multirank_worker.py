@@ -16,6 +16,9 @@ def main():
     kw = json.loads(sys.argv[7])
     kw["topo"] = tuple(kw["topo"])
     k = int(sys.argv[8])
+    extra = sys.argv[9:]
+    tier = int(extra[extra.index("--tier") + 1]) if "--tier" in extra else None
+    cycles = int(extra[extra.index("--cycles") + 1]) if "--cycles" in extra else 1
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import numpy as np
     import torch
@@ -31,11 +34,20 @@ def main():
         m.set_exchange_interval(max(k, 0))        # k = -1: automatic interval on the RCCL exchange; k = 0: the peer transport
         if k < 0:
             m.set_halo_transport("rccl")
-        csi.time_step_momentum(m, c["dt"])
+        if tier is not None:
+            m.set_peer_tier(tier)                 # the protocol tier, forced (tests/test_gpu_multirank.py: the ladder across devices)
+        for _ in range(cycles):
+            csi.time_step_momentum(m, c["dt"])
         m.synchronize()
         from test_gpu_evp import EVP_FIELDS
         res = {f"mom_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
-        res["path"] = np.array(json.dumps(dict(m.ctx.last_path(), transport=m.ctx.halo_transport())))
+        res["path"] = np.array(json.dumps(dict(m.ctx.last_path(), transport=m.ctx.halo_transport(), tier=m.ctx.peer_tier())))
+        g = m.grid
+        res["offsets"] = np.array([g.i_off, g.j_off, g.Nx, g.Ny])
+        if tier is not None:                      # the ladder test compares the sub-cycles only
+            np.savez(f"{out}.rank{rank}.npz", **res)
+            dist.barrier()
+            return
         csi.time_step(m, c["dt"])
         m.synchronize()
         res.update({f"step_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v")})

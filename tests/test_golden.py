@@ -91,7 +91,8 @@ def compare_with_reference(path):
             kw[k] = tuple(kw[k])
     exact, total = 0, 0
     for tag in rio.TAGS:
-        c, got = rio.oracle_run(kw, tag)
+        # (the WENO weight precision the reference run reported for its scheme: bench/reference_driver.jl, DONE file)
+        c, got = rio.oracle_run(kw, tag, rio.weight_dtype_of(d["versions"]) if "versions" in d else "f64")
         for k in ("h", "a", "u", "v"):
             assert np.array_equal(c[k], d[f"in_{k}"]), "seeded inputs changed"
         vmax = max(np.abs(d[f"u_{tag}"]).max(), np.abs(d[f"v_{tag}"]).max())

@@ -549,6 +549,45 @@ def test_peer_protocol_tiers_bitwise(name, tier):
         til.set_peer_tier(3)
 
 
+def test_peer_abort_is_sticky_until_rearmed():
+    """A wait of the flag protocol that gave up (simulated: csi_debug_peer_abort leaves the pinned error word the way the kernel's
+    time-out does) makes EVERY later entry point fail with CSI_ERR_COMM -- not only the next one: the flags cannot recover by
+    themselves -- until the caller re-arms the transport (csi_set_halo_transport, on all ranks); the next sub-cycle
+    then runs the collective set-up again and the tile reproduces the untiled run bit for bit."""
+    kw, fc = PEER_CASES["periodic_xy"]
+    c = cases.make_case(substeps=12, patches=True, random_uv=0.05, **kw)
+    ref = cases.csi_model(c, mode="fast")
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, fc))
+    csi.time_step_momentum(ref, c["dt"]); csi.time_step_momentum(til, c["dt"])
+    til.synchronize()
+    assert til.ctx.halo_transport() == "peer"
+    til.ctx.call("csi_debug_peer_abort")
+    for _ in range(3):                                    # sticky: every call, not only the first
+        with pytest.raises(csi.CsiError) as e:
+            csi.time_step_momentum(til, c["dt"])
+        assert "peer halo transport" in str(e.value)
+    with pytest.raises(csi.CsiError):
+        til.synchronize()
+    with pytest.raises(csi.CsiError):
+        til.ctx.validate_all()
+    til.set_halo_transport("peer")                        # re-armed (on a real node: by every rank)
+    csi.time_step_momentum(ref, c["dt"]); csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    assert til.ctx.halo_transport() == "peer"
+    for f in ("u", "v", "s11", "s22", "s12"):
+        a, b = EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()
+        assert np.array_equal(a, b), (f, np.abs(a - b).max())
+    til.ctx.call("csi_debug_peer_abort")                  # ... and the message exchange is the other way out
+    with pytest.raises(csi.CsiError):
+        csi.time_step_momentum(til, c["dt"])
+    til.set_halo_transport("rccl")
+    csi.time_step_momentum(ref, c["dt"]); csi.time_step_momentum(til, c["dt"])
+    ref.synchronize(); til.synchronize()
+    assert til.ctx.halo_transport() == "rccl"
+    for f in ("u", "v", "s11", "s22", "s12"):
+        assert np.array_equal(EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()), f
+
+
 def test_peer_halo_transport_falls_back_and_can_be_switched_off():
     """Explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the peer transport off; odd
     sub-step counts stay on it; all bit-identical."""

@@ -24,21 +24,26 @@ def _get(m, f):
     return (getattr(m.velocities, f) if f in ("u", "v") else getattr(m.dynamics.auxiliaries.fields, f)).interior_numpy().copy()
 
 
-def _rank(conn, name, kw, Rx, Ry, rank, transport, cycles, tier):
+def _rank(conn, name, kw, Rx, Ry, rank, transport, cycles, tier, device="cuda:0"):
+    """tier: the protocol tier asked for (-1: the library's automatic choice, which must come out as 1 -- the neighbour lives in
+    another process).  device: tests/test_gpu_multirank.py runs the same ranks on one DEVICE each."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         import cases
         import climaseaice_jl_amd as csi
+        if device != "cuda:0":
+            import torch
+            torch.cuda.set_device(int(device.split(":")[1]))
         c = cases.make_case(**kw)
-        m = cases.csi_model(c, mode="fast", tile=(Rx, Ry, rank), host_group=name)
+        m = cases.csi_model(c, mode="fast", tile=(Rx, Ry, rank), host_group=name, device=device)
         m.set_halo_transport(transport)
-        if tier:
-            m.set_peer_tier(tier)
+        m.set_peer_tier(tier)
         for _ in range(cycles):
             csi.time_step_momentum(m, c["dt"])
         m.synchronize()
         out = {f: _get(m, f) for f in FIELDS}
         out["transport"] = m.ctx.halo_transport()
+        out["tier"] = m.ctx.peer_tier()
         out["path"] = m.ctx.last_path()
         out["ranks"] = m.ctx.comm_count()
         g = m.grid
@@ -57,7 +62,7 @@ HOST_CASES = {
 }
 
 
-@pytest.mark.parametrize("transport,nsub,tier", [("peer", 12, 0), ("peer", 7, 0), ("peer", 12, 1), ("rccl", 12, 0)])
+@pytest.mark.parametrize("transport,nsub,tier", [("peer", 12, 0), ("peer", 7, -1), ("peer", 12, 1), ("peer", 12, 2), ("rccl", 12, -1)])
 @pytest.mark.parametrize("name", sorted(HOST_CASES))
 def test_processes_on_one_gpu_tiled_equals_untiled_bitwise(name, transport, nsub, tier):
     import cases
@@ -91,6 +96,8 @@ def test_processes_on_one_gpu_tiled_equals_untiled_bitwise(name, transport, nsub
         assert got[r]["ranks"] == world
         # "peer": every rank mapped its neighbours' arrays over HIP IPC and ran the flag protocol; one host exchange per sub-cycle
         assert got[r]["transport"] == transport, (r, got[r]["transport"], got[r]["path"])
+        # the automatic tier: 1 as soon as a neighbour lives in another process (the fence-free tier 0 is an explicit opt-in there)
+        assert got[r]["tier"] == (1 if tier < 0 else tier), (r, got[r]["tier"])
         i0, j0, nx, ny = got[r]["offsets"]
         for f in FIELDS:
             mine, w = got[r][f][:ny, :nx], want[f][j0:j0 + ny, i0:i0 + nx]
@@ -103,7 +110,7 @@ def test_bench_rehearsal_of_the_multi_rank_path_on_one_gpu(n, partition):
     torch.distributed.run launch, one rank per process, peer set-up over HIP IPC, the tier ladder, the tiled == untiled check before
     anything is timed, the timed region with its barriers, the one-GPU rate of the same grid, the single JSON line -- with the
     ranks sharing GPU 0 over the host-channel group.  Its numbers are not scaling results (the line says so); what is asserted is
-    that every step of that path runs and that the bitwise check passed on the peer transport at tier 0."""
+    that every step of that path runs and that the bitwise check passed on the peer transport at the library's automatic tier."""
     import json
     import subprocess
     import sys
@@ -116,7 +123,14 @@ def test_bench_rehearsal_of_the_multi_rank_path_on_one_gpu(n, partition):
     d = json.loads(line)
     assert d["n_gpus"] == n and d["rehearsal_on_one_gpu"] is True and d["rccl_ranks"] == n
     assert d["tiled_equals_untiled_bitwise"] is True
-    assert d["path"]["halo_transport"] == "peer" and d["path"]["peer_tier"] == 0, d["path"]
-    assert d["path"]["peer_tier_ladder"] == [{"tier": 0, "passed": True, "problem": None}]
+    # the ladder starts at the library's automatic tier: 1 across processes; the fence-free tier 0 is timed beside it as an opt-in
+    assert d["path"]["halo_transport"] == "peer" and d["path"]["peer_tier"] == 1, d["path"]
+    assert d["path"]["peer_tier_ladder"] == [{"tier": 1, "passed": True, "problem": None}]
+    assert d["peer_tier0"]["bitwise"] is True and d["peer_tier0"]["value"] > 0, d.get("peer_tier0")
+    # both decompositions of the grid in one run: the slabs of the headline and the 2 x (N / 2) layout BASELINE config 4 names
+    other = [k for k in d if k.startswith("partition_") and k != "partition_note"]
+    assert len(other) == 1 and d[other[0]]["bitwise"] is True and d[other[0]]["value"] > 0, {k: d[k] for k in other}
+    # the dominant kernel's launch time comes from the timed region: launches x average <= ms_per_step
+    assert d["roofline"]["launches_x_avg_ms"] <= d["ms_per_step"] * 1.0001, (d["roofline"]["launches_x_avg_ms"], d["ms_per_step"])
     assert d["config"]["partition"] == ([int(t) for t in partition.split("x")] if partition else [1, n])
     assert d["single_gpu"]["value"] > 0 and d["parallel_efficiency"] > 0 and d["value"] > 0

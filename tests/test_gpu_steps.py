@@ -606,3 +606,92 @@ def test_checkpoint_round_trip_bitwise(name):
         if k != "clock":
             assert np.array_equal(want[k], got[k]), (k, np.abs(want[k] - got[k]).max())
     assert not np.array_equal(ckpt["h"], want["h"])
+
+
+# ---- round 5: WENO weights in single precision (csi_set_weno_weight_dtype; upstream's second float type FT2 = Float32, recalled) ----
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("scheme", [7, 5, 3])
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("bounded", "bounded")])
+def test_weno_f32_weights_match_the_oracle(topo, scheme, mode, oracle_lib):
+    """weight_dtype f32: STRICT equals the oracle's f32-weight mode bit for bit (same float expressions, two compilers); FAST runs
+    the SAME float weights and contracts only the double part: 1e-13 of max|G| like the double mode.  The walls exercise the
+    buffer schemes (WENO7 -> 5 -> 3) in the f32 mode too.  A whole RK3 step with the stage launches follows."""
+    c = cases.make_case(Nx=96, Ny=80, topo=topo, substeps=2, random_uv=0.3, patches=True)
+    p = cases.oracle_problem(c)
+    p.s.weno_weights_f32 = 1
+    m = cases.csi_model(c, mode=mode, timestepper="SplitRungeKutta3", advection=csi.WENO(order=scheme, weight_dtype="f32"))
+    v = C.c_int32()
+    m.ctx.call("csi_weno_weight_dtype", C.byref(v))
+    assert v.value == 1
+    p.compute_tracer_tendencies(scheme)
+    m.ctx.call("csi_compute_tracer_tendencies", scheme)
+    m.synchronize()
+    for k, f in (("Gh", m.timestepper.Gn.h), ("Ga", m.timestepper.Gn.aice)):
+        got, want = f.interior_numpy(), p.interior(k)
+        assert np.abs(want).max() > 0
+        same_tendency(mode, got, want, (k, "f32 weights"))
+    # the switch is live: the double mode gives other bits
+    m.ctx.call("csi_set_weno_weight_dtype", 0)
+    m.ctx.call("csi_compute_tracer_tendencies", scheme)
+    m.synchronize()
+    assert not np.array_equal(m.timestepper.Gn.h.interior_numpy(), p.interior("Gh"))
+    with pytest.raises(csi.CsiError):
+        m.ctx.call("csi_set_weno_weight_dtype", 2)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_weno_f32_weights_whole_rk3_step_advection_only(mode, oracle_lib):
+    """BASELINE config 2's path (advection-only RK3: one launch per stage, k_tendencies<..., STEP>) in the f32-weight mode."""
+    c = anticyclone_case(96)
+    p = cases.oracle_problem(c)
+    p.s.weno_weights_f32 = 1
+    m = csi.SeaIceModel(c["g"], dynamics=None, advection=csi.WENO(order=7, weight_dtype="f32"), timestepper="SplitRungeKutta3", mode=mode)
+    csi.set_(m, h=c["h"], aice=c["a"], u=c["u"], v=c["v"])
+    dt = 120.0
+    for n in range(3):
+        p.f["hm"][...] = p.f["h"]; p.f["am"][...] = p.f["aice"]
+        for beta in (3, 2, 1):
+            p.compute_tracer_tendencies(7)
+            p.dynamic_step_tracers(dt / beta, True)
+            p.update_state()
+        csi.time_step(m, dt)
+    m.synchronize()
+    if mode == "strict":
+        assert np.array_equal(m.ice_thickness.numpy(), p.f["h"])
+        assert np.array_equal(m.ice_concentration.numpy(), p.f["aice"])
+    else:
+        assert np.abs(m.ice_thickness.numpy() - p.f["h"]).max() <= 3 * ADV_TOL * np.abs(p.f["h"]).max()
+        assert np.abs(m.ice_concentration.numpy() - p.f["aice"]).max() <= 3 * ADV_TOL
+
+
+# ---- round 5: two tracers per thread in the tendency kernel (large grids) ----------------------------------------------------------
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("scheme", [7, 5, -5, 3, 1])
+@pytest.mark.parametrize("topo", [("periodic", "periodic"), ("bounded", "bounded"), ("periodic", "bounded")])
+def test_two_tracers_per_thread_bit_identical(topo, scheme, mode, oracle_lib, monkeypatch):
+    """k_tendencies<..., NT = 2> (h and aice in one thread: large grids) against NT = 1 (one thread per cell and tracer): the same
+    operations per value, so the tendencies and a whole advection-only RK3 step (the one-launch-per-stage variant too) are
+    bit-identical; the layout is forced with CSI_ADV_NT, which a context reads when it is created.  With land in the bounded case."""
+    kw = dict(Nx=130, Ny=75, topo=topo, substeps=2, random_uv=0.3, patches=True)
+    if topo == ("bounded", "bounded"):
+        kw["land"] = 0.2
+    c = cases.make_case(**kw)
+    out = {}
+    for nt in (1, 2):
+        monkeypatch.setenv("CSI_ADV_NT", str(nt))
+        adv = csi.WENO(order=scheme) if scheme > 1 else csi.UpwindBiased(order=abs(scheme))
+        m = cases.csi_model(c, mode=mode, timestepper="SplitRungeKutta3", advection=adv)
+        m.ctx.call("csi_compute_tracer_tendencies", adv.scheme)
+        m.synchronize()
+        G = (m.timestepper.Gn.h.numpy().copy(), m.timestepper.Gn.aice.numpy().copy())
+        m2 = csi.SeaIceModel(c["g"], dynamics=None, advection=adv, timestepper="SplitRungeKutta3", mode=mode)
+        if c.get("mask") is not None:
+            m2.set_mask(c["mask"])
+        csi.set_(m2, h=c["h"], aice=c["a"], u=c["u"], v=c["v"])
+        for _ in range(2):
+            csi.time_step(m2, 120.0)
+        m2.synchronize()
+        out[nt] = G + (m2.ice_thickness.numpy().copy(), m2.ice_concentration.numpy().copy())
+    for a, b, what in zip(out[1], out[2], ("Gh", "Ga", "h after 2 RK3 steps", "aice after 2 RK3 steps")):
+        assert np.array_equal(a, b), (what, np.abs(a - b).max())
+    assert np.abs(out[1][0]).max() > 0

@@ -38,7 +38,7 @@ def _hook(O, order, p):
     assert n > 0
     if order < 0:
         return out[0]
-    r = R_OF[order]
+    r = R_OF[order % 100]                # (100 + order: the single-precision-weights variant)
     return dict(value=out[0], q=out[1:1 + r].copy(), beta=out[1 + r:1 + 2 * r].copy(), alpha=out[1 + 2 * r:1 + 3 * r].copy(), tau=out[1 + 3 * r])
 
 
@@ -288,3 +288,79 @@ def test_rk3_stage_factors_reproduce_the_third_order_taylor_polynomial(scheme, o
     # ... and it is NOT the second-order or the fourth-order polynomial (the cubic term matters at this CFL number)
     assert np.abs(got - (h0 + dt * g1 + dt ** 2 / 2 * g2)).max() > 1e-6
     assert np.array_equal(p.interior("u"), c["u"])
+
+
+# ---- round 5: the weight-precision switch (weight_dtype f64 | f32; upstream's second float type FT2, recalled) --------------------
+@pytest.mark.parametrize("wd", ["f64", "f32"])
+@pytest.mark.parametrize("order", [3, 5, 7])
+def test_c_oracle_equals_the_numpy_restatement_bit_for_bit_in_both_weight_precisions(order, wd, oracle_lib):
+    """oracle/csi_oracle.c weno*(_f32) against oracle/oracle_np.weno_value on 4000 random stencils (smooth, rough, with plateaus
+    and zeros): two restatements, written separately, the same bits -- in the double mode and in the single-precision-weights mode."""
+    import oracle_np
+    rng = np.random.default_rng(50 + order)
+    r = R_OF[order]
+    n = 2 * r - 1
+    P = np.concatenate([0.3 + 0.005 * rng.standard_normal((1500, n)), rng.random((1500, n)), np.round(rng.random((600, n)) * 3) / 3,
+                        1e-6 * rng.standard_normal((400, n))])
+    P[3000:3100] = 0.7                                   # plateaus: beta = tau = 0
+    want = oracle_np.weno_value(P, order, wd)
+    got = np.array([_hook(oracle_lib, order + (100 if wd == "f32" else 0), p)["value"] for p in P])
+    assert np.array_equal(got, want), (order, wd, np.abs(got - want).max(), int((got != want).sum()))
+
+
+@pytest.mark.parametrize("order", [3, 5, 7])
+def test_single_precision_weights_keep_the_published_scheme_to_single_precision(order, oracle_lib):
+    """The f32 mode is the SAME scheme with its nonlinear weights rounded to float: indicators, tau and unnormalised weights agree
+    with the double mode to a few float ulps of their scale, the face value to ~1e-6 of the stencil's spread (the candidates are
+    convexly combined, so a weight error of 1e-7 moves the value by 1e-7 of the candidates' spread), and a polynomial of degree
+    <= r - 1 is still reproduced whatever the weights (every candidate is exact for it), to the precision of their normalisation."""
+    rng = np.random.default_rng(70 + order)
+    r = R_OF[order]
+    n = 2 * r - 1
+    for _ in range(300):
+        p = 0.3 + 0.05 * rng.standard_normal(n)
+        a, b = _hook(oracle_lib, order, p), _hook(oracle_lib, order + 100, p)
+        assert np.array_equal(a["q"], b["q"])                                            # candidates: double in both modes
+        scale = np.abs(a["beta"]).max() + 1e-8
+        assert np.abs(a["beta"] - b["beta"]).max() <= 2e-5 * scale + 5e-6 * np.abs(p).max() ** 2     # (float cancellation in the quadratic forms: coefficients up to 31 x p^2 x 6e-8)
+        spread = np.abs(a["q"] - a["q"].mean()).max()
+        assert abs(a["value"] - b["value"]) <= 2e-3 * spread + 1e-15, (a["value"], b["value"], spread)
+    # smooth data (the regime the advection runs in): the two modes agree to a few 1e-6 of the value.  (Not better: converted to
+    # float, values of 0.3 carry 2e-8 of rounding, the quadratic forms of the indicators 5e-9 of cancellation noise -- the size of
+    # eps and far above the true beta ~ 1e-10 of such data -- so the single-precision weights wander between the candidates, whose
+    # spread is ~1e-5 here.  A property of the mode, which is why the default stays double.)
+    x = np.arange(n) - (r - 1)
+    worst = 0.0
+    for k in range(200):
+        p = 0.3 + 0.005 * np.sin(0.05 * x + 0.1 * k)
+        a, b = _hook(oracle_lib, order, p), _hook(oracle_lib, order + 100, p)
+        worst = max(worst, abs(a["value"] - b["value"]) / np.abs(p).max())
+    assert worst <= 5e-6, (order, worst)
+    # polynomial exactness for degree <= r - 1 survives any weights -- to the precision of their NORMALISATION: the assumed form
+    # divides the double sum of alpha_s q_s by the FLOAT sum of the alphas, which differs from their double sum by up to a float
+    # ulp, so even a constant comes back with 6e-8 relative error (in the double mode: 1e-16).  Whether upstream's FT2 arithmetic
+    # has this property is exactly what a reference run has to show (DESIGN.md section 6).
+    for deg in range(r):
+        coef = rng.standard_normal(deg + 1)
+        cellavg = lambda lo: sum(c * ((lo + 1) ** (m + 1) - lo ** (m + 1)) / (m + 1) for m, c in enumerate(coef))      # noqa: E731
+        p = np.array([cellavg(float(m - r)) for m in range(n)])
+        exact = coef[0]                                                                     # the polynomial at the face x = 0
+        v = _hook(oracle_lib, order + 100, p)["value"]
+        assert abs(v - exact) <= 2e-7 * (1 + np.abs(p).max()), (order, deg, v, exact)
+        v64 = _hook(oracle_lib, order, p)["value"]
+        assert abs(v64 - exact) <= 1e-12 * (1 + np.abs(p).max()), (order, deg, v64, exact)
+
+
+def test_weight_precision_reaches_the_tendencies(oracle_lib):
+    """ora_problem.weno_weights_f32 switches the reconstruction inside horizontal_div_Uc: the tendencies of the two modes differ (the
+    switch is live) by no more than single precision allows, and the default is the double mode."""
+    c = cases.make_case(Nx=40, Ny=32, substeps=2, topo=("periodic", "periodic"), random_uv=0.3)
+    p = cases.oracle_problem(c)
+    assert p.s.weno_weights_f32 == 0
+    p.compute_tracer_tendencies(7)
+    g64 = p.f["Gh"].copy()
+    p.s.weno_weights_f32 = 1
+    p.compute_tracer_tendencies(7)
+    g32 = p.f["Gh"].copy()
+    assert not np.array_equal(g64, g32)
+    assert np.abs(g64 - g32).max() <= 1e-4 * np.abs(g64).max()
