@@ -259,6 +259,57 @@ def counters():
         return None
 
 
+def advection_record(csi, np, torch, device):
+    """Advection-only RK3 steps of BASELINE config 2 (512^2) and of the metric's grid size (2048^2): us per step, cell-stages/s, the
+    tendency launch alone, and -- from the committed counter run of these kernels (profiles/counters_advection.json, scripts/
+    adv_profile.sh) -- the share of the SIMDs' FP64 issue time the 2048^2 tendency launch uses (its bound: VALU busy 0.68, HBM 0.1)."""
+    out = {"config": "advection only: periodic grid, dx = 1 km, WENO(order = 7) of h and aice, prescribed cyclonic eddy, SplitRungeKutta3, dt = 120 s"}
+    for N in (512, 2048):
+        L = N * 1000.0
+        g = csi.RectilinearGrid((N, N), x=(0.0, L), y=(0.0, L), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
+        xc = (np.arange(N) + 0.5) * L / N
+        xf = np.arange(N) * L / N
+        V = 0.5
+        u = np.broadcast_to(V * np.sin(2 * np.pi * xc / L)[:, None], (N, N)) * np.cos(2 * np.pi * xf / L)[None, :]
+        v = -np.broadcast_to(V * np.sin(2 * np.pi * xc / L)[None, :], (N, N)) * np.cos(2 * np.pi * xf / L)[:, None]
+        X, Y = np.meshgrid(xc, xc)
+        h = 0.3 + 0.005 * (np.sin(60 * X / 1000e3) + np.sin(30 * Y / 1000e3))
+        a = np.clip(1 - 0.1 * np.random.default_rng(2).random((N, N)), 0, 1)
+        m = csi.SeaIceModel(g, dynamics=None, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", mode="fast", device=device)
+        csi.set_(m, h=h, aice=a, u=u, v=v)
+        for _ in range(5):
+            csi.time_step(m, 120.0)
+        m.synchronize(); torch.cuda.synchronize()
+        n = 200 if N == 512 else 40
+        t0 = time.perf_counter()
+        for _ in range(n):
+            csi.time_step(m, 120.0)
+        m.synchronize(); torch.cuda.synchronize()
+        step_us = (time.perf_counter() - t0) / n * 1e6
+        for _ in range(3):
+            m.ctx.call("csi_compute_tracer_tendencies", 7)
+        m.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m.ctx.call("csi_compute_tracer_tendencies", 7)
+        m.synchronize()
+        tend_us = (time.perf_counter() - t0) / n * 1e6
+        rec = {"rk3_step_us": step_us, "cell_stages_per_s": 3.0 * N * N / (step_us * 1e-6), "tendency_launch_us": tend_us}
+        try:
+            ctr = json.load(open(os.path.join(ROOT, "profiles", "counters_advection.json")))[str(N)]
+            rec["valu_insts_per_tendency_launch"] = ctr["valu_insts_per_launch"]
+            rec["lane_insts_per_cell_and_tracer"] = ctr["valu_insts_per_launch"] * 64.0 / (2.0 * N * N)
+            rec["fp64_issue_frac"] = ctr["issue_ns_per_launch"] * 1e-9 / 1024.0 / (tend_us * 1e-6)
+            rec["hbm_bytes_per_tendency_launch"] = ctr.get("hbm_bytes_per_launch")
+            rec["hbm_frac"] = ctr["hbm_bytes_per_launch"] / (tend_us * 1e-6) / 1e9 / HBM_PEAK_GBS if ctr.get("hbm_bytes_per_launch") else None
+            rec["counters_source"] = ctr.get("source")
+        except Exception:
+            pass
+        out["config2_512" if N == 512 else "grid_2048"] = rec
+        m = None
+    return out
+
+
 def isa_mix():
     """Instruction mix of the dominant kernel's row loops from its ISA listing (scripts/isa_mix.py -> profiles/isa_mix_k_pair.json)."""
     f = os.path.join(ROOT, "profiles", "isa_mix_k_pair.json")
@@ -447,6 +498,9 @@ def main():
         csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
         for name in sig:
             getattr(m.dynamics.auxiliaries.fields, name).data.zero_()
+        # torch zeroes on ITS stream, the library packs / launches on its own: without this a rank's halo message could carry the sigma of
+        # the previous run (seen once, round 5: N processes sharing one GPU in the rehearsal reorder the two streams more readily)
+        torch.cuda.synchronize()
 
     def tile_matches_whole(m=None, grid=None, fld=None, gfld=None):
         """One sub-cycle from the same state on the tiles and on the whole grid: owned cells bitwise equal (all ranks agree).
@@ -694,6 +748,12 @@ def main():
         full = max_over_ranks((time.perf_counter() - t1) / nfull)
         model_days_per_hr = 3600.0 / (full * 86400.0 / dt)
 
+    # ---- BASELINE config 2 beside the headline (round 5): advection only -- 512^2 periodic, WENO(order = 7), prescribed cyclonic eddy,
+    # SplitRungeKutta3 (examples/ice_advected_by_anticyclone.jl:65-66,117,126 scaled as SURVEY.md 8d) -- and the tendency launch at 2048^2
+    advection = None
+    if world == 1 and not tiled and not args.no_full_step and args.mode == "fast":
+        advection = advection_record(csi, np, torch, device)
+
     # ---- tiles: the other ways to move the halos, timed outside the headline region: the RCCL exchange batched over k = 16
     # sub-steps (halo 32) and once per sub-step (k = 1) --------------------------------------------------------------------------
     k1 = None
@@ -803,6 +863,8 @@ def main():
         "result_check": chk,
         "roofline": roof,
     }
+    if advection is not None:
+        out["advection"] = advection
     if k1 is not None:
         out["exchange_every_substep"] = k1
     if rccl16 is not None:

@@ -86,14 +86,29 @@ __device__ __forceinline__ double weno3(const double* p) {
 }
 __device__ __forceinline__ double upwind3(const double* p) { return (-p[0] + 5 * p[1] + 2 * p[2]) / 6; }
 
-// ---- FAST-mode reconstructions (see the header).  The smoothness indicators and tau are evaluated EXACTLY as in STRICT mode
-// (same order, no contraction): they are small differences of O(c^2) terms, and a rounding-level change of their evaluation
-// moves the nonlinear weights by ~1e-9 relative (measured: tendencies 7e-13 of max|G| apart with contracted indicators,
-// against ~1e-15 with these).  Candidate polynomials, weights and the final combination are contracted; divisions are
-// reciprocals (fm::rcp: hardware seed + one Newton step) or multiplications by constants.
+// ---- FAST-mode reconstructions (see the header).  Candidate polynomials, weights and the final combination are contracted; divisions
+// are reciprocals (fm::rcp: hardware seed + one Newton step) or multiplications by constants.  The smoothness indicators and tau:
+// rounds 3 - 4 evaluated them EXACTLY as in STRICT mode (no contraction) -- they are small differences of O(c^2) terms, and a
+// rounding-level change of their evaluation moves the nonlinear weights by ~1e-9 relative and the tendencies by 7e-13 of max|G|
+// (measured), over the 1e-13 then stated for the tendencies.  Round 5 (CSI_ADV_FAST_BETA = 1, the default): they are contracted too --
+// the uncontracted quadratic forms were 92 of a WENO7 reconstruction's ~150 FP64 instructions (56 contracted) -- and the FAST
+// tolerance on the TENDENCIES is stated as 1e-12 of max|G|; the tolerance on what the north star names, h and aice after an update,
+// stays 1e-13 relative (dt |dG| = 120 s x 1e-12 x 1e-6 m/s against h ~ 0.3 m: four orders inside it).  STRICT is untouched.
+#ifndef CSI_ADV_FAST_BETA
+#define CSI_ADV_FAST_BETA 1
+#endif
+#if CSI_ADV_FAST_BETA
+#define CSI_BETA_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define CSI_BETA_CONTRACT
+#endif
 __device__ __forceinline__ double weno3_fast(const double* p) {
-    const double b0 = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
-    const double b1 = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
+    double b0, b1;
+    {
+        CSI_BETA_CONTRACT
+        b0 = p[1] * (p[1] - 2 * p[2]) + p[2] * p[2];
+        b1 = p[0] * (p[0] - 2 * p[1]) + p[1] * p[1];
+    }
     const double tau = fabs(b0 - b1);
     {
 #pragma clang fp contract(fast)
@@ -110,9 +125,20 @@ __device__ __forceinline__ double upwind3_fast(const double* p) {
     return (5 * p[1] + 2 * p[2] - p[0]) * (1.0 / 6);
 }
 __device__ __forceinline__ double weno5_fast(const double* p) {
-    const double b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
-    const double b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
-    const double b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
+    double b0, b1, b2;
+    {
+        CSI_BETA_CONTRACT
+#if CSI_ADV_FAST_BETA
+        constexpr double third = 1.0 / 3;
+        b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) * third;
+        b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) * third;
+        b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) * third;
+#else
+        b0 = (p[2] * (10 * p[2] - 31 * p[3] + 11 * p[4]) + p[3] * (25 * p[3] - 19 * p[4]) + p[4] * (4 * p[4])) / 3;
+        b1 = (p[1] * (4 * p[1] - 13 * p[2] + 5 * p[3]) + p[2] * (13 * p[2] - 13 * p[3]) + p[3] * (4 * p[3])) / 3;
+        b2 = (p[0] * (4 * p[0] - 19 * p[1] + 11 * p[2]) + p[1] * (25 * p[1] - 31 * p[2]) + p[2] * (10 * p[2])) / 3;
+#endif
+    }
     const double tau = fabs(b0 - b2);
     {
 #pragma clang fp contract(fast)
@@ -131,14 +157,18 @@ __device__ __forceinline__ double upwind5_fast(const double* p) {
     return (2 * p[0] - 13 * p[1] + 47 * p[2] + 27 * p[3] - 3 * p[4]) * (1.0 / 60);
 }
 __device__ __forceinline__ double weno7_fast(const double* p) {
-    const double b0 = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
-                      p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
-    const double b1 = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
-                      p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
-    const double b2 = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
-                      p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
-    const double b3 = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
-                      p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
+    double b0, b1, b2, b3;
+    {
+        CSI_BETA_CONTRACT
+        b0 = p[3] * (2.107 * p[3] - 9.402 * p[4] + 7.042 * p[5] - 1.854 * p[6]) +
+             p[4] * (11.003 * p[4] - 17.246 * p[5] + 4.642 * p[6]) + p[5] * (7.043 * p[5] - 3.882 * p[6]) + p[6] * (0.547 * p[6]);
+        b1 = p[2] * (0.547 * p[2] - 2.522 * p[3] + 1.922 * p[4] - 0.494 * p[5]) +
+             p[3] * (3.443 * p[3] - 5.966 * p[4] + 1.602 * p[5]) + p[4] * (2.843 * p[4] - 1.642 * p[5]) + p[5] * (0.267 * p[5]);
+        b2 = p[1] * (0.267 * p[1] - 1.642 * p[2] + 1.602 * p[3] - 0.494 * p[4]) +
+             p[2] * (2.843 * p[2] - 5.966 * p[3] + 1.922 * p[4]) + p[3] * (3.443 * p[3] - 2.522 * p[4]) + p[4] * (0.547 * p[4]);
+        b3 = p[0] * (0.547 * p[0] - 3.882 * p[1] + 4.642 * p[2] - 1.854 * p[3]) +
+             p[1] * (7.043 * p[1] - 17.246 * p[2] + 7.042 * p[3]) + p[2] * (11.003 * p[2] - 9.402 * p[3]) + p[3] * (2.107 * p[3]);
+    }
     const double tau = fabs(b0 + 3 * b1 - 3 * b2 - b3);
     {
 #pragma clang fp contract(fast)
@@ -360,18 +390,18 @@ __device__ __forceinline__ void store_tracer_images(const FRef& f, const GridDev
 // both tracers and were half of a thread's instructions (ISA: ~300 of ~590 per cell and tracer were not the reconstruction's
 // arithmetic); large grids, which are throughput-bound (VALU busy 0.68 at 2048^2), take this one.  Same operations per value:
 // bit-identical to NT = 1.
-template <int SCHEME, bool FAST, bool STEP = false, int TY = TY2, bool W32 = false, int NT = 1>
-__global__ void __launch_bounds__(NT == 2 ? (TX + 1) * (TY + 1) : 1024) k_tendencies(AdvDev A) {
-    __shared__ double sFx[NT == 2 ? 2 : 3][TY + 1][TX + 2], sFy[NT == 2 ? 2 : 3][TY + 1][TX + 2];
-    __shared__ double sG[(STEP && NT == 1) ? 2 : 1][(STEP && NT == 1) ? TY : 1][(STEP && NT == 1) ? TX : 1];
+template <int SCHEME, bool FAST, bool STEP = false, int TY = TY2, bool W32 = false, int NT = 1, int TXP = TX>
+__global__ void __launch_bounds__(NT == 2 ? (TXP + 1) * (TY + 1) : 1024) k_tendencies(AdvDev A) {
+    __shared__ double sFx[NT == 2 ? 2 : 3][TY + 1][TXP + 2], sFy[NT == 2 ? 2 : 3][TY + 1][TXP + 2];
+    __shared__ double sG[(STEP && NT == 1) ? 2 : 1][(STEP && NT == 1) ? TY : 1][(STEP && NT == 1) ? TXP : 1];
     const GridDev& g = A.g;
     const int tx = threadIdx.x, ty = threadIdx.y, tz = NT == 2 ? 0 : threadIdx.z;          // tx in [0, TX], ty in [0, TY], tz: tracer
-    const int i = 1 + blockIdx.x * TX + tx, j = 1 + blockIdx.y * TY + ty;
+    const int i = 1 + blockIdx.x * TXP + tx, j = 1 + blockIdx.y * TY + ty;
     const bool in_x = i <= g.Nx + 1, in_y = j <= g.Ny + 1;
     const FRef& c = tz == 0 ? A.h : (tz == 1 ? A.a : A.hs);
     // STEP: the update's base values are independent of the fluxes: loaded (and, first stage, cached as Psi^-) up front, so that
     // behind the fluxes only a few flops and one store remain; the h thread stores h, the aice thread aice
-    const bool owns = tx < TX && ty < TY && i <= g.Nx && j <= g.Ny;
+    const bool owns = tx < TXP && ty < TY && i <= g.Nx && j <= g.Ny;
     double hn = 0.0, an = 0.0;
     if (STEP && owns) {
         hn = A.hb(i, j); an = A.ab(i, j);
@@ -395,7 +425,7 @@ __global__ void __launch_bounds__(NT == 2 ? (TX + 1) * (TY + 1) : 1024) k_tenden
                 sFx[1][ty][tx] = closed ? 0.0 : ax * uu * c2;
             }
         }
-        if (tx < TX && i <= g.Nx) {
+        if (tx < TXP && i <= g.Nx) {
             const double vv = A.v(i, j);
             const bool left = vv > 0;
             const int B = buffer_at<SCHEME>(g, i, j, true, left);
@@ -411,7 +441,7 @@ __global__ void __launch_bounds__(NT == 2 ? (TX + 1) * (TY + 1) : 1024) k_tenden
     }
     __syncthreads();
     double G0 = 0.0, G1 = 0.0;
-    if (tx < TX && ty < TY && i <= g.Nx && j <= g.Ny) {
+    if (tx < TXP && ty < TY && i <= g.Nx && j <= g.Ny) {
         const double V = azm(g, LOC_C, LOC_C, i, j);
         const double rV = FAST ? fm::rcp(V) : 1 / V;
         const double fx = sFx[tz][ty][tx + 1] - sFx[tz][ty][tx], fy = sFy[tz][ty + 1][tx] - sFy[tz][ty][tx];
@@ -474,24 +504,38 @@ __global__ void __launch_bounds__(256) k_tracer_step(AdvDev A) {
 }  // namespace adv
 
 // W32: the WENO weights in single precision (AdvDev::w32; only the WENO schemes have weights)
-// NT: tracers per thread (k_tendencies): 2 from kTwoTracerCells cells on -- measured round 5 (scripts/adv_nt_ab.sh): the two-tracer
-// threads win where the launch is throughput-bound, the one-tracer threads where it is as long as one block
+// NT: tracers per thread (k_tendencies): 2 from CSI_ADV_NT2_CELLS cells on.  Measured round 5 (scripts/adv_bench.py, one box, WENO7, us per
+// advection-only RK3 step / per tendency launch, NT = 1 -> 2): 256^2 25.7 -> 25.8 / 7.0 -> 7.4; 512^2 53.5 -> 48.5 / 14.2 -> 13.0;
+// 1024^2 171 -> 142 / 47 -> 38; 2048^2 728 -> 621 / 173 -> 139 (profiles/r05_advection.md)
 #ifndef CSI_ADV_NT2_CELLS
-#define CSI_ADV_NT2_CELLS 600000L
+#define CSI_ADV_NT2_CELLS 200000L
 #endif
 static bool adv_two_tracers(const AdvDev& A) {
     if (A.has_snow) return false;
     if (A.nt > 0) return A.nt == 2;              // tuning aid / tests (CSI_ADV_NT, read when the context is created)
     return (long)A.g.Nx * (long)A.g.Ny >= CSI_ADV_NT2_CELLS;
 }
+// Block shapes of the two-tracers-per-thread layout by grid size (round 5, one box, us per advection-only RK3 step at 512^2 / 1024^2 /
+// 2048^2; profiles/r05_advection_shapes.txt): 64 x 6 cells 48.5 / 142 / 621; 64 x 8: 46 / 161 / 678; 63 x 7 (64 x 8 threads = 8 full
+// waves): 49.5 / 132 / 591; 63 x 11: 49 / 138 / 577; 63 x 5: 53.5 / 150 / 646; 63 x 9: 60 / 154 / 650; 64 x 12: 63 / 175 / 715 -- not
+// monotonic in anything simple (wave quantisation of the block, blocks per CU, redundant face rows), so: the best measured shape per size
+enum { SHAPE_64x8 = 0, SHAPE_63x7 = 1, SHAPE_63x11 = 2 };
+static int adv_shape(const AdvDev& A) {
+    const long cells = (long)A.g.Nx * (long)A.g.Ny;
+    return cells < 600000L ? SHAPE_64x8 : (cells < 2500000L ? SHAPE_63x7 : SHAPE_63x11);
+}
 template <bool FAST, bool W32>
 static void launch_tendencies_mode(const AdvDev& A, hipStream_t s) {
-    const int ty = A.has_snow ? adv::TY3 : adv::TY2;
     const bool two = adv_two_tracers(A);
-    dim3 b(adv::TX + 1, ty + 1, A.has_snow ? 3 : (two ? 1 : 2));
-    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + ty - 1) / ty));
+    const int shape = adv_shape(A);
+    const int tx = two ? (shape == SHAPE_64x8 ? 64 : 63) : adv::TX;
+    const int ty = A.has_snow ? adv::TY3 : (two ? (shape == SHAPE_64x8 ? 8 : (shape == SHAPE_63x7 ? 7 : 11)) : adv::TY2);
+    dim3 b(tx + 1, ty + 1, A.has_snow ? 3 : (two ? 1 : 2));
+    dim3 gr((unsigned)((A.g.Nx + tx - 1) / tx), (unsigned)((A.g.Ny + ty - 1) / ty));
 #define CSI_ADV_LAUNCH(S, W) do { if (A.has_snow) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY3, W>), gr, b, 0, s, A); \
-                                  else if (two) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY2, W, 2>), gr, b, 0, s, A); \
+                                  else if (two && shape == SHAPE_64x8) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, 8, W, 2, 64>), gr, b, 0, s, A); \
+                                  else if (two && shape == SHAPE_63x7) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, 7, W, 2, 63>), gr, b, 0, s, A); \
+                                  else if (two) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, 11, W, 2, 63>), gr, b, 0, s, A); \
                                   else hipLaunchKernelGGL((adv::k_tendencies<S, FAST, false, adv::TY2, W>), gr, b, 0, s, A); } while (0)
     switch (A.scheme) {
         case 1: CSI_ADV_LAUNCH(1, false); break;
@@ -511,9 +555,14 @@ void launch_tracer_tendencies(const AdvDev& A, int mode, hipStream_t s) {
 template <bool FAST, bool W32>
 static void launch_stage_mode(const AdvDev& A, hipStream_t s) {
     const bool two = adv_two_tracers(A);
-    dim3 b(adv::TX + 1, adv::TY2 + 1, two ? 1 : 2);
-    dim3 gr((unsigned)((A.g.Nx + adv::TX - 1) / adv::TX), (unsigned)((A.g.Ny + adv::TY2 - 1) / adv::TY2));
-#define CSI_ADV_STAGE(S, W) do { if (two) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, adv::TY2, W, 2>), gr, b, 0, s, A); \
+    const int shape = adv_shape(A);
+    const int tx = two ? (shape == SHAPE_64x8 ? 64 : 63) : adv::TX;
+    const int ty = two ? (shape == SHAPE_64x8 ? 8 : (shape == SHAPE_63x7 ? 7 : 11)) : adv::TY2;
+    dim3 b(tx + 1, ty + 1, two ? 1 : 2);
+    dim3 gr((unsigned)((A.g.Nx + tx - 1) / tx), (unsigned)((A.g.Ny + ty - 1) / ty));
+#define CSI_ADV_STAGE(S, W) do { if (two && shape == SHAPE_64x8) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, 8, W, 2, 64>), gr, b, 0, s, A); \
+                                 else if (two && shape == SHAPE_63x7) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, 7, W, 2, 63>), gr, b, 0, s, A); \
+                                 else if (two) hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, 11, W, 2, 63>), gr, b, 0, s, A); \
                                  else hipLaunchKernelGGL((adv::k_tendencies<S, FAST, true, adv::TY2, W>), gr, b, 0, s, A); } while (0)
     switch (A.scheme) {
         case 1: CSI_ADV_STAGE(1, false); break;

@@ -218,7 +218,11 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         lanes_same = __builtin_amdgcn_ballot_w64(!same) == 0;
         lanes_uniform = !wave_has_dx_b && lanes_same;
         rstart = max(ja - 3, T->I[FI_AJ0]);
-        rend = min(jb + 3, T->I[FI_AJ1]);
+#ifndef CSI_EXP_RINGCUT
+#define CSI_EXP_RINGCUT 0       // TIMING EXPERIMENT ONLY (wrong results): so many of a tile's top ring rows are not run -- what a launch would
+                                // cost if vertically adjacent tiles shared their seam rows instead of recomputing them (profiles/r05_tile.md)
+#endif
+        rend = min(jb + 3 - CSI_EXP_RINGCUT, T->I[FI_AJ1]);
         if (i <= Hx) flags |= L_LOW;                         // this column's x image lies beyond the HIGH side of the low-side neighbour
         sc = (unsigned)T->I[FI_LD_C] * 8u;
         sf = (unsigned)T->I[FI_LD_F] * 8u;
@@ -947,7 +951,10 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             // u points of row q-1, v points of row q (B v-first) / q-1 (B u-first); B's first rows of a tile only fill its
             // window: clamp their row to the array instead of running off it
             const int qm = max(q - 1, row0), qa = max(q, row0);
+#ifndef CSI_EXP_NOCONSLOADS      // (TIMING EXPERIMENT ONLY, wrong results: the consumer's forcing loads left out -- the upper bound of what forcing
+                                 //  values handed over through the ring could buy the per-point-metric instantiations)
             arrays(FB, offf(qm), AUF ? offc(qa) : offc(qm));
+#endif
         }
         const bool pb1 = WALLS && (!AUF ? (lane_wu | wall_row(q - 1)) : (lane_wv | wall_vrow(q)));
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));

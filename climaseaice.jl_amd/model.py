@@ -419,8 +419,9 @@ class SeaIceModel:
         self.ctx.call("csi_set_halo_transport", {"rccl": 0, "peer": 1}[kind])
 
     def set_peer_tier(self, tier):
-        """Tiles on the peer transport: the memory-ordering tier of its flag protocol, the SAME on every rank (0 default, 1 + acquire
-        fence behind the flags, 2 + release fence before them; include/csi.h, csi_set_peer_tier)."""
+        """Tiles on the peer transport: the memory-ordering tier of its flag protocol, the SAME on every rank (-1 automatic, the
+        default: 1 across processes / devices, 0 for a tile connected to itself; 0 no fence, 1 + acquire fence behind the flags,
+        2 + release fence before them; include/csi.h, csi_set_peer_tier)."""
         self.ctx.call("csi_set_peer_tier", int(tier))
 
     def set_mask(self, active):

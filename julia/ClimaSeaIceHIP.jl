@@ -289,8 +289,9 @@ function set_halo_transport!(ctx, kind::Symbol)
     check(ctx, ccall((:csi_set_halo_transport, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, kind === :peer ? 1 : 0))
 end
 
-# The memory-ordering tier of the peer transport's flag protocol (0 default; 1: + an acquire fence behind the flags; 2: + a release
-# fence before them), the SAME on every rank.  include/csi.h: csi_set_peer_tier.
+# The memory-ordering tier of the peer transport's flag protocol, the SAME on every rank: -1 automatic (the default: tier 1 whenever a
+# neighbour lives in another process or on another device), 0 no fence (explicit opt-in there), 1: + an acquire fence behind the
+# flags, 2: + a release fence before them.  include/csi.h: csi_set_peer_tier.
 set_peer_tier!(ctx, tier::Integer) = check(ctx, ccall((:csi_set_peer_tier, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, tier))
 
 # Waits for the library's stream and reports a peer-transport wait that gave up (a rank that fell behind or died: the library
