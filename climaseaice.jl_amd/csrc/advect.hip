@@ -13,7 +13,7 @@
 // same smoothness indicators, same WENO-Z weights per tracer, same order reduction -- with the divisions by constants as
 // multiplications, the four or five true divisions of a reconstruction as hardware reciprocal + one Newton step (fm::rcp,
 // <= 11 ulp) and fused multiply-adds: a WENO7 reconstruction is ~150 instead of ~450 instructions (nine IEEE divisions of
-// ~35 instructions each were two thirds of it).  Stated tolerance: |dG| <= 1e-13 max|G| on the tendencies, 1e-13 relative on
+// ~35 instructions each were two thirds of it).  Stated tolerance: |dG| <= 1e-12 max|G| on the tendencies (round 5: contracted smoothness indicators, below; 1e-13 before), 1e-13 relative on
 // h, aice after a step (measured ~1e-16); masks, zero sets and the order-reduction decisions are the same code.  Each thread owns one
 // face pair (west, south) of its cell: fluxes are computed once, shared with the east / north
 // neighbours through LDS, so every face flux is evaluated exactly once per tile interior.

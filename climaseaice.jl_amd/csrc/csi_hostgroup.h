@@ -21,7 +21,11 @@ namespace csi {
 
 struct HostGroup;      // opaque (csi_hostgroup.hip)
 
-// Join (rank 0 .. world - 1 all call it with the same name): creates or opens the segment, waits for every rank, unlinks the name.
+// Join (rank 0 .. world - 1 all call it with the same name).  Rank 0 OWNS the name: it unlinks whatever an earlier run left under it and
+// creates the segment with O_EXCL, stamped with its pid; the other ranks never create -- they accept an existing segment only if it is
+// complete, initialised, for this world size and stamped by a LIVING process (kill(pid, 0): the ranks must share a PID namespace, which
+// processes sharing /dev/shm on one node normally do), else they drop it and look again until the time-out.  Everybody waits for every
+// rank; the name is unlinked once all have it mapped and on every failure path of rank 0.
 HostGroup* hostgroup_join(const char* shm_name, int world, int rank, std::string* err);
 void hostgroup_leave(HostGroup* g);
 int hostgroup_world(const HostGroup* g);
