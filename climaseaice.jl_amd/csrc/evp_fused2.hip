@@ -121,8 +121,15 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 #endif
 constexpr int RF_FORCING = 8;
 enum : int { RF_FU_TAU = 10, RF_FU_WE, RF_FU_WB, RF_FU_FD, RF_FV_TAU, RF_FV_WE, RF_FV_WB, RF_FV_FD };
-constexpr int RF_PLANES = 9;
-enum : int { RF_PL_DXV = 10, RF_PL_RDYV, RF_PL_RDXU, RF_PL_DXF2, RF_PL_DYF2, RF_PL_RAZF, RF_PL_DYU, RF_PL_DYC2, RF_PL_DXC2 };
+// Round 5: ALL TWELVE plane values of a stage-row travel from the producer to the consumer, through a ring of their own that is
+// THREE rows deep -- 12 x 3 x 512 B = 18 KB, exactly what nine fields in the four-row ring took, so still four workgroups per CU.
+// Three rows suffice because the consumer reads a row's planes one iteration EARLIER than it uses them (between the phases of its
+// previous step, into the registers its memory prefetch of 1 / Az used to fill): written at producer iteration r (slot r mod 3), read
+// during consumer iteration r + 1, which runs beside producer iteration r + 2 (slot r + 2 mod 3).  The three planes the consumer
+// still loaded itself -- 1 / Az at the cell and at the two velocity points -- were a SECOND fetch of 24 B per cell, every one a miss in
+// the XCD's L2 (counted traffic 1.23 x the compulsory bytes).  Timing experiment without those loads: curvilinear 40.6 -> 44.1 G.
+constexpr int RP_ROWS = 3, RP_FIELDS = 12;
+enum : int { RP_DXV = 0, RP_RDYV, RP_RDXU, RP_DXF2, RP_DYF2, RP_RAZF, RP_DYU, RP_DYC2, RP_DXC2, RP_RAZC, RP_RAZU, RP_RAZV };
 
 // FULL (orthogonal curvilinear grids, per-point metric planes, csi_fast_coef.h): 14 more loads per stage-row
 // in flight -- compiled for 2 waves per SIMD (256 VGPRs); the kernel is bound by the planes' traffic and load count there.
@@ -133,10 +140,10 @@ enum : int { RF_PL_DXV = 10, RF_PL_RDYV, RF_PL_RDXU, RF_PL_DXF2, RF_PL_DYF2, RF_
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
 __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
-                                       double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p) {
+                                       double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p, double* __restrict__ ringp) {
     constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
-    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
+    constexpr int RING_FIELDS = FRING ? 10 + RF_FORCING : (PRE ? 13 : 10);      // (FULL: ten fields; its plane values have a ring of their own, ringp)
 #define peer_abort (*peer_abort_p)
     const int b = (int)blockIdx.x;
     const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
@@ -609,7 +616,12 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         // the ring starts clean: the consumer's first iterations read rows the producer never wrote (their results only
         // fill B's window and are never used -- but they must not be NaN patterns left in LDS by an earlier workgroup)
 #pragma unroll
-        for (int q = 0; q < RING_ROWS * RING_FIELDS; ++q) ring[q * 64 + lane] = (FULL && (q % RING_FIELDS) >= 10) ? 1.0 : 0.0;     // (plane values: finite reciprocals)
+        for (int q = 0; q < RING_ROWS * RING_FIELDS; ++q) ring[q * 64 + lane] = 0.0;
+        if constexpr (FULL) {
+#pragma unroll
+            for (int q = 0; q < RP_ROWS * RP_FIELDS; ++q) ringp[q * 64 + lane] = 1.0;      // (plane values: finite reciprocals)
+            A.RAZU_m = 1.0; A.RAZV_x = 1.0; A.RAZC_0 = 1.0;      // (the first step runs no velocity phase and loads none of the first two)
+        }
         // MASK: two bits per row (bit 0 inactive, bit 1 beyond a wall), newest row in bits 1:0; row rstart-1 from memory,
         // older rows count as beyond the domain (their results are never used)
         unsigned mhist = 0xffffffffu;
@@ -744,9 +756,12 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 }
                 if constexpr (FULL) {
                     // the plane values this step consumed (v-point and corner planes of row r + 1, u-point and cell planes of row r)
-                    ring[s0 + RF_PL_DXV * 64] = A.DXV_p; ring[s0 + RF_PL_RDYV * 64] = A.RDYV_p; ring[s0 + RF_PL_RDXU * 64] = A.RDXU_p;
-                    ring[s0 + RF_PL_DXF2 * 64] = A.DXF2_p; ring[s0 + RF_PL_DYF2 * 64] = A.DYF2_p; ring[s0 + RF_PL_RAZF * 64] = A.RAZF_p;
-                    ring[s0 + RF_PL_DYU * 64] = A.DYU_0; ring[s0 + RF_PL_DYC2 * 64] = A.DYC2_0; ring[s0 + RF_PL_DXC2 * 64] = A.DXC2_0;
+                    // + 1 / Az at the cell (row r) and at the velocity points (u: row r - 1; v: row r - 1 for a u-first producer, r for a v-first one)
+                    const unsigned p0 = (unsigned)k * (RP_FIELDS * 64) + lane_it;      // (k = (r - rstart) mod 3: the body is unrolled three times)
+                    ringp[p0 + RP_DXV * 64] = A.DXV_p; ringp[p0 + RP_RDYV * 64] = A.RDYV_p; ringp[p0 + RP_RDXU * 64] = A.RDXU_p;
+                    ringp[p0 + RP_DXF2 * 64] = A.DXF2_p; ringp[p0 + RP_DYF2 * 64] = A.DYF2_p; ringp[p0 + RP_RAZF * 64] = A.RAZF_p;
+                    ringp[p0 + RP_DYU * 64] = A.DYU_0; ringp[p0 + RP_DYC2 * 64] = A.DYC2_0; ringp[p0 + RP_DXC2 * 64] = A.DXC2_0;
+                    ringp[p0 + RP_RAZC * 64] = A.RAZC_0; ringp[p0 + RP_RAZU * 64] = A.RAZU_m; ringp[p0 + RP_RAZV * 64] = A.RAZV_x;
                 }
                 if (MASK) ringm[(unsigned)((r - rstart) & (RING_ROWS - 1)) * 64 + lane_it] = mhist & 3u;
             }
@@ -865,6 +880,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     const int rlo = rstart - 1;
     unsigned mhistB = 0xffffffffu;
     double vn_delay = 0.0;                                // B u-first: v^n of row q - 1 (read one iteration earlier as row q)
+    double razv_delay = 1.0;                              // FULL, B u-first: 1 / Az at the v points of row q - 1 likewise (midB)
     double fvd_tau = 0.0, fvd_we = 0.0, fvd_wb = 0.0, fvd_fd = 0.0;      // FRING, B u-first: the v-point forcing values of row q - 1 likewise
     int r = rstart;
     auto bodyB = [&](auto KK) __attribute__((always_inline)) {
@@ -887,12 +903,6 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         const double s11 = ring[s2 + RF_S11 * 64], s22 = ring[s2 + RF_S22 * 64], s12 = ring[s2 + RF_S12 * 64];
         const double bP_0 = ring[s2 + RF_P * 64], bm_0 = ring[s2 + RF_M * 64], ba_0 = ring[s2 + RF_A * 64];
         if (PRE) { B.Pf_0 = ring[s2 + RF_PF * 64]; B.rmc_0 = ring[s2 + RF_RMC * 64]; B.rmf_0 = ring[s2 + RF_RMF * 64]; }
-        if constexpr (FULL) {
-            // rows the producer never ran (the consumer's first two iterations of a tile only fill its window): the ring's initial 1.0
-            B.N_DXV = ring[s2 + RF_PL_DXV * 64]; B.N_RDYV = ring[s2 + RF_PL_RDYV * 64]; B.N_RDXU = ring[s2 + RF_PL_RDXU * 64];
-            B.N_DXF2 = ring[s2 + RF_PL_DXF2 * 64]; B.N_DYF2 = ring[s2 + RF_PL_DYF2 * 64]; B.N_RAZF = ring[s2 + RF_PL_RAZF * 64];
-            B.N_DYU = ring[s2 + RF_PL_DYU * 64]; B.N_DYC2 = ring[s2 + RF_PL_DYC2 * 64]; B.N_DXC2 = ring[s2 + RF_PL_DXC2 * 64];
-        }
         const double bun = ring[s3 + RF_UN * 64], vn_new = ring[s2 + RF_VN * 64];
         const double bvn = AUF ? vn_new : vn_delay;       // B v-first: v^n(q); B u-first: v^n(q - 1)
         vn_delay = vn_new;
@@ -960,8 +970,23 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         const bool pb2 = WALLS && (!AUF ? (lane_wv | wall_vrow(q - 1)) : (lane_wu | wall_row(q - 1)));
         if constexpr (FULL) {
             // (rows below the planes only fill the window: clamped)
-            B.template step<PRE, typename decltype(B)::NoMid, true, true>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
-                   off2(max(q, row0)), c2s, off2(max(q + 1, row0)), off2(max(q - 1, row0)), typename decltype(B)::NoMid(), off2(max(q, row0)));
+            // The plane values of the NEXT step (row q + 1 = r - 1), read between the phases of this one: slot (r - 1 - rstart) mod 3 =
+            // (k + 2) mod 3 -- the producer, one iteration ahead, is writing slot (k + 1) mod 3.  Rows it never ran (the first iterations
+            // only fill the window): the ring's initial 1.0.  1 / Az at the v point: a v-first producer's slot X holds row X, the u-first
+            // consumer needs row q of its step q + 1 = the slot read ONE iteration ago (razv_delay); a u-first producer's slot X holds
+            // row X - 1, the v-first consumer needs row q + 1 = slot r, which the producer finished before this iteration's barrier.
+            constexpr int kk = decltype(KK)::value;
+            auto midB = [&]() __attribute__((always_inline)) {
+                const unsigned pn = (unsigned)((kk + 2) % 3) * (RP_FIELDS * 64) + lane_it;
+                B.N_DXV = ringp[pn + RP_DXV * 64]; B.N_RDYV = ringp[pn + RP_RDYV * 64]; B.N_RDXU = ringp[pn + RP_RDXU * 64];
+                B.N_DXF2 = ringp[pn + RP_DXF2 * 64]; B.N_DYF2 = ringp[pn + RP_DYF2 * 64]; B.N_RAZF = ringp[pn + RP_RAZF * 64];
+                B.N_DYU = ringp[pn + RP_DYU * 64]; B.N_DYC2 = ringp[pn + RP_DYC2 * 64]; B.N_DXC2 = ringp[pn + RP_DXC2 * 64];
+                B.N_RAZC = ringp[pn + RP_RAZC * 64]; B.N_RAZU = ringp[pn + RP_RAZU * 64];
+                if (AUF) B.N_RAZV = ringp[(unsigned)kk * (RP_FIELDS * 64) + lane_it + RP_RAZV * 64];
+                else { const double x = ringp[pn + RP_RAZV * 64]; B.N_RAZV = razv_delay; razv_delay = x; }
+            };
+            B.template step<PRE, decltype(midB), true, true>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB,
+                   off2(max(q, row0)), c2s, off2(max(q + 1, row0)), off2(max(q - 1, row0)), midB, off2(max(q, row0)));
             fq = q; f11 = B.S11_0; f22 = B.S22_0; f12 = B.S12_0; ffirst = B.first; fsecond = B.second; fhave = true;
         } else {
         B.template step<PRE>(T, ks, kv, q, bu_p, bv_p, bP_0, bm_0, ba_0, s11, s22, s12, bun, bvn, q >= ja - 1, q >= ja, pb1, pb2, mhistB, FB);
@@ -1012,8 +1037,9 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
-    constexpr int RING_FIELDS = FULL ? 10 + RF_PLANES : (FRING ? 10 + RF_FORCING : (PRE ? 13 : 10));
+    constexpr int RING_FIELDS = FRING ? 10 + RF_FORCING : (PRE ? 13 : 10);      // (FULL: ten fields; its plane values have a ring of their own, ringp)
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
+    __shared__ double ringp[FULL ? RP_ROWS * RP_FIELDS * 64 : 1];      // FULL: the plane values of three rows
     __shared__ unsigned ringm[MASK ? RING_ROWS * 64 : 1];
     __shared__ double outr[(CSI_PAIR_STORES & 7) != 7 ? 2 * 5 * 64 : 1];      // stage B's results on their way to the producer's stores
     __shared__ unsigned peer_abort_w;                      // PEER: the producer's wait has given up
@@ -1029,11 +1055,11 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
         const unsigned pd = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
                              ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)T->I[FI_PMASK];
         if (__builtin_amdgcn_readfirstlane((int)pd) == 0) {
-            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w);
+            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp);
             return;
         }
     }
-    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w);
+    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp);
 }
 
 }  // namespace fused

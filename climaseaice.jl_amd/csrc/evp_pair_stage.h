@@ -108,6 +108,10 @@ struct Stage {
         N_FU = 0.0; N_FV = 0.0;
         if (T->I[FI_FKIND] == 2) { N_FU = ldg(T->P[FP_F2U], om); N_FV = ldg(T->P[FP_F2V], UFIRST ? om : on); }
     }
+    __device__ __forceinline__ void full_prefetch_f(tptr_t T, unsigned on, unsigned om) {
+        N_FU = 0.0; N_FV = 0.0;
+        if (T->I[FI_FKIND] == 2) { N_FU = ldg(T->P[FP_F2U], om); N_FV = ldg(T->P[FP_F2V], UFIRST ? om : on); }
+    }
     __device__ __forceinline__ void full_prefetch(tptr_t T, unsigned on, unsigned s2) {
         N_DXV = c2m(T, C2_DXV, on + s2); N_RDYV = c2m(T, C2_RDYV, on + s2); N_RDXU = c2m(T, C2_RDXU, on + s2);
         N_DXF2 = c2m(T, C2_DXF2, on + s2); N_DYF2 = c2m(T, C2_DYF2, on + s2); N_RAZF = c2m(T, C2_RAZF, on + s2);
@@ -150,8 +154,9 @@ struct Stage {
     // not across the stress phase, where the register pressure peaks)
     // ALLPRE (FULL): 1 / Az at the velocity points and the per-point Coriolis planes were prefetched by the previous step as well
     // (full_prefetch_vel; o2nm: the row below the next step's row) -- the consumer wave, which has the registers for it
-    // PLR (FULL): the nine plane values of full_prefetch but 1 / Az at the cell come from the pair kernel's ring (the caller has set
-    // N_DXV .. N_DXC2 for THIS step); the step prefetches 1 / Az at the next row's cells only
+    // PLR (FULL): every plane value of a step comes from the pair kernel's plane ring: the caller's mid() functor, called between the
+    // phases of the PREVIOUS step, has set N_DXV .. N_RAZV for this one (round 4 handed nine of them over at the top of the step and
+    // loaded 1 / Az at the cell and at the velocity points from memory: a second fetch of three planes, every one a miss in the XCD's L2)
     template <bool PRE = false, class MID = NoMid, bool ALLPRE = false, bool PLR = false>
     __device__ __forceinline__ void step(tptr_t T, const fm::StressConst& ks_in, const fm::VelConst& kv_in, int r,
                                          double u_p, double v_p, double P_0, double m_0, double a_0,
@@ -275,9 +280,10 @@ struct Stage {
         if constexpr (FULL) {
             // the next step's plane values: issued here, behind the stress phase, consumed after the velocity phase and the row barrier
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PLR) N_RAZC = c2m(T, C2_RAZC, o2n);
-            else full_prefetch(T, o2n, s2);
-            if constexpr (ALLPRE) full_prefetch_vel(T, o2n, o2nm);
+            if constexpr (!PLR) full_prefetch(T, o2n, s2);
+            // PLR (round 5: the consumer wave): ALL twelve plane values of the next step come from the pair kernel's plane ring -- the
+            // caller's mid() reads them --, only the per-point Coriolis planes, where a grid has them, are still loaded here
+            if constexpr (ALLPRE) { if constexpr (PLR) full_prefetch_f(T, o2n, o2nm); else full_prefetch_vel(T, o2n, o2nm); }
             mid();
             __builtin_amdgcn_sched_barrier(0);
         }
