@@ -790,36 +790,55 @@ def main():
             alt = (1, world)
         if alt and args.size % alt[0] == 0 and args.size % alt[1] == 0 and alt != (Rx, Ry):
             part = (alt[0], alt[1], args.size // alt[0], args.size // alt[1])
+            # (every collective of this block -- the all_ranks() reductions, the barriers inside timed() -- is reached by EVERY rank whatever
+            #  a rank's own library calls did: a rank that caught an error must not leave the others waiting in an all-reduce)
+            err2, same2_local = None, False
             try:
                 g2, f2, model, _ = build(args.transport if not transport_note else "rccl", part)
                 for _ in range(max(args.warmup, 1)):
                     csi.time_step_momentum(model, dt)
-                same2 = all_ranks(tile_matches_whole(model, g2, f2, global_fields(np, part[2], part[3], part[0], part[1])))
-                restart(model, f2)
-                for _ in range(max(args.warmup, 1)):
-                    csi.time_step_momentum(model, dt)
-                e2 = timed(args.steps)
-                second = {"partition": list(alt), "tile": [part[2], part[3]], "value": owned * args.substeps * args.steps / e2,
-                          "ms_per_step": 1e3 * e2 / args.steps, "bitwise": bool(same2),
-                          "halo_transport": model.ctx.halo_transport(), "peer_tier": model.ctx.peer_tier() if model.ctx.halo_transport() == "peer" else None}
+                same2_local = tile_matches_whole(model, g2, f2, global_fields(np, part[2], part[3], part[0], part[1]))
             except csi.CsiError as e:
-                second = {"partition": list(alt), "error": str(e)}
+                err2 = str(e)
+            if all_ranks(err2 is None):
+                same2 = all_ranks(same2_local)
+                try:
+                    restart(model, f2)
+                    for _ in range(max(args.warmup, 1)):
+                        csi.time_step_momentum(model, dt)
+                except csi.CsiError as e:
+                    err2 = str(e)
+                if all_ranks(err2 is None):
+                    e2 = timed(args.steps)
+                    second = {"partition": list(alt), "tile": [part[2], part[3]], "value": owned * args.substeps * args.steps / e2,
+                              "ms_per_step": 1e3 * e2 / args.steps, "bitwise": bool(same2),
+                              "halo_transport": model.ctx.halo_transport(), "peer_tier": model.ctx.peer_tier() if model.ctx.halo_transport() == "peer" else None}
+            if second is None:
+                second = {"partition": list(alt), "error": err2 or "another rank reported a library error"}
             model = headline_model
     # ---- the fence-free tier 0 of the peer protocol as an explicit opt-in, timed next to the default (never the default across
     # devices: include/csi.h) ----
     tier0 = None
     if tiled and path["halo_transport"] == "peer" and args.peer_tier < 0 and path.get("peer_tier", 0) >= 1 and verify and not args.no_compare:
+        err0, same0_local = None, False
         try:
             model.set_peer_tier(0)
-            same0 = all_ranks(tile_matches_whole())
+            same0_local = tile_matches_whole()
             restart(model, f)
             csi.time_step_momentum(model, dt)
+        except csi.CsiError as e:
+            err0 = str(e)
+        if all_ranks(err0 is None):                      # (collectives outside the try: see the block above)
+            same0 = all_ranks(same0_local)
             e0 = timed(args.steps)
             tier0 = {"value": owned * args.substeps * args.steps / e0, "ms_per_step": 1e3 * e0 / args.steps, "bitwise": bool(same0),
                      "note": "opt-in (--peer-tier 0): no acquire fence behind the flags; a passing check does not prove the protocol"}
-        except csi.CsiError as e:
-            tier0 = {"error": str(e)}
-        model.set_peer_tier(path["peer_tier"])
+        else:
+            tier0 = {"error": err0 or "another rank reported a library error"}
+        try:
+            model.set_peer_tier(path["peer_tier"])
+        except csi.CsiError:
+            pass
 
     # ---- N > 1: the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported
     single = None

@@ -286,3 +286,50 @@ def test_peer_transport_follows_a_change_of_the_forcing_kinds():
         for got, want, what in ((d["a"], want0, "numbers"), (d["b"], want1, "arrays")):
             for f in want:
                 assert np.array_equal(got[f][:ny, :nx], want[f][j0:j0 + ny, i0:i0 + nx]), (what, rank, f)
+
+
+def test_validate_all_spreads_a_transport_abort_to_non_neighbours():
+    """csi_validate_all (round 5): a wait of the peer transport that gave up reaches only the direct neighbours' abort words; the
+    all-reduce of the status makes EVERY rank of the decomposition see it -- here four slabs in a row, the error raised on rank 0
+    (csi_debug_peer_abort leaves what the kernel's time-out leaves), rank 2 is not its neighbour -- and after every rank has re-armed
+    the transport the tiles reproduce the untiled run bit for bit again."""
+    c = cases.make_case(Nx=160, Ny=256, substeps=8, topo=("periodic", "bounded"), patches=True, random_uv=0.05)
+    ref = cases.csi_model(c, mode="fast")
+    for _ in range(3):
+        csi.time_step_momentum(ref, c["dt"])
+    ref.synchronize()
+    want = {f: EVP_FIELDS[f](ref).interior_numpy().copy() for f in ("u", "v", "s11")}
+    barrier = threading.Barrier(4)
+
+    def tile(rank, group):
+        m = cases.csi_model(c, mode="fast", tile=(1, 4, rank), local_group=group)
+        csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        assert m.ctx.halo_transport() == "peer"
+        m.ctx.validate_all()                                   # clean: nothing raised anywhere
+        barrier.wait()
+        if rank == 0:
+            m.ctx.call("csi_debug_peer_abort")
+        barrier.wait()
+        seen = False
+        try:
+            m.ctx.validate_all()
+        except csi.CsiError as e:
+            seen = "peer halo transport" in str(e)
+        with pytest.raises(csi.CsiError):                      # sticky on every rank, not only on rank 0
+            csi.time_step_momentum(m, c["dt"])
+        barrier.wait()
+        m.set_halo_transport("peer")                           # every rank re-arms: the next sub-cycle sets the transport up again
+        csi.time_step_momentum(m, c["dt"])
+        csi.time_step_momentum(m, c["dt"])
+        m.synchronize()
+        g = m.grid
+        return dict(seen=seen, transport=m.ctx.halo_transport(), off=(g.i_off, g.j_off, g.Nx, g.Ny),
+                    **{f: EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11")})
+
+    for r, res in enumerate(run_tile_threads(4, tile)):
+        assert res["seen"], f"rank {r} did not see the abort of rank 0"
+        assert res["transport"] == "peer"
+        i0, j0, nx, ny = res["off"]
+        for f, w in want.items():
+            assert np.array_equal(res[f][:ny, :nx], w[j0:j0 + ny, i0:i0 + nx]), (r, f)
