@@ -580,7 +580,12 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         // ===== PRODUCER: stage A = sub-step s, rows rstart .. rend ===================================================
         PROBE_DECL;
         Stage<UNI, AUF, MASK, FORCE, CF, FULL> A;    // (TIGHT scalar live ranges in the array-forcing variants)
-        unsigned oc = offc(rstart), of = offf(rstart), om = MASK ? offm(rstart) : 0u;
+#ifndef CSI_EXP_RINGALIAS
+#define CSI_EXP_RINGALIAS 0     // TIMING EXPERIMENT ONLY (wrong results): a tile's ring rows are read from the nearest rows it owns -- same instructions,
+                                // same arithmetic, but no ring row ever comes from HBM: what it would be worth if every ring-row re-read hit the L2
+#endif
+        auto alias_row = [&](int j) __attribute__((always_inline)) { return CSI_EXP_RINGALIAS ? min(max(j, ja + 1), max(jb - 1, ja + 1)) : j; };
+        unsigned oc = offc(alias_row(rstart)), of = offf(alias_row(rstart)), om = MASK ? offm(rstart) : 0u;
         {
             const double rho0 = T->K[FK_RHO];
             A.u_m = ldg(T->P[FP_U_IN], of - sf); A.v_m = ldg(T->P[FP_V_IN], oc - sc);
@@ -666,6 +671,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         int rnext = rstart;
         auto advance = [&]() __attribute__((always_inline)) {
             const bool more = rnext < rend;
+            if (CSI_EXP_RINGALIAS) { rnext += more ? 1 : 0; oc = offc(alias_row(rnext)); of = offf(alias_row(rnext)); return; }
             oc += more ? sc : 0u; of += more ? sf : 0u;
             if (MASK) om += more ? sm : 0u;
             rnext += more ? 1 : 0;
