@@ -201,6 +201,50 @@ def test_config4_latlon_few_substeps_tight(topo, nsub):
     _record(f"config4_latlon_{topo[0]}_{nsub}_substeps_tight", entry)
 
 
+def test_config4_latlon_two_substeps_from_states_along_the_strict_cycle():
+    """Config 4's grid at full size (2048^2 lat-lon, bounded): the FAST pair kernel restarted from STRICT's state at twelve points of
+    the 120-sub-step cycle (every tenth sub-step: u, v, sigma copied parent for parent; P, u^n, v^n too) and advanced by two sub-steps
+    beside it, each time on the TIGHT bound of the test above (1e-13 max|u|, 1e-10 max|sigma| on the owned cells).  With this the
+    "10 x STRICT's own sensitivity" branch the whole-cycle and RK3 comparisons of this grid may take is about the ITERATION, not the
+    kernel: its error is rounding-level at every state the cycle passes through (round 5; the small-grid twin against the oracle:
+    tests/test_gpu_evp.py::test_fast_two_substeps_from_every_state_of_the_oracle_cycle)."""
+    import torch
+    N = 2048
+    c = latlon_case(N, 4, ("bounded", "bounded"))
+    ms = cases.csi_model(c, mode="strict")
+    mf = cases.csi_model(c, mode="fast")
+    ms.ctx.call("csi_evp_initialize"); mf.ctx.call("csi_evp_initialize")
+    ms.synchronize(); mf.synchronize()
+    names = ("u", "v", "s11", "s22", "s12", "P", "un", "vn")
+    entry = {}
+    s = 1
+    while s + 1 <= 120:
+        for k in names:
+            EVP_FIELDS[k](mf).data.copy_(EVP_FIELDS[k](ms).data)
+        torch.cuda.synchronize()
+        ms.ctx.call("csi_evp_subcycle", float(c["dt"]), 2, s)
+        mf.ctx.call("csi_evp_subcycle", float(c["dt"]), 2, s)
+        ms.synchronize(); mf.synchronize()
+        assert mf.ctx.last_path()["level"] == 2 and ms.ctx.last_path()["level"] == 0
+        a = {k: EVP_FIELDS[k](ms).interior_numpy() for k in ("u", "v", "s11", "s22", "s12")}
+        b = {k: EVP_FIELDS[k](mf).interior_numpy() for k in ("u", "v", "s11", "s22", "s12")}
+        vmax = max(np.abs(a["u"]).max(), np.abs(a["v"]).max())
+        smax = max(np.abs(a[k]).max() for k in ("s11", "s22", "s12"))
+        for k in ("u", "v", "s11", "s22", "s12"):
+            d = float(np.abs(a[k] - b[k]).max())
+            tol = 1e-13 * vmax if k in ("u", "v") else 1e-10 * smax
+            assert np.all(np.isfinite(b[k])) and d <= tol, ("sub-steps", s, s + 1, k, d, tol)
+            entry[k] = max(entry.get(k, 0.0), d / (vmax if k in ("u", "v") else smax))
+        for k in ("u", "v"):
+            assert np.array_equal(a[k] == 0.0, b[k] == 0.0), (s, k)
+        # STRICT goes on alone to the next sample
+        if s + 10 <= 119:
+            ms.ctx.call("csi_evp_subcycle", float(c["dt"]), 8, s + 2)
+            ms.synchronize()           # the copies above run on torch's stream, the sub-cycle on the library's
+        s += 10
+    _record("config4_latlon_two_substeps_along_the_strict_cycle", {"worst_relative_difference": entry, "samples": 12})
+
+
 def test_config4_latlon_one_cycle_branch_recorded():
     """One 120-sub-step momentum cycle (not the three of an RK3 step) on the 2048^2 lat-lon grid: FAST against STRICT, with the
     bound each field needed -- the stated tolerance, or 10 x STRICT's own response to a 1e-15 relative input perturbation --
