@@ -385,6 +385,17 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     //  four workgroups per CU, two waves per SIMD, like the per-point-metric instantiations)
     const bool force_ring = c->metric_kind != CSI_METRIC_FULL && evp_ring_forcing(evp_dev(c, 0.0));
     int target = (c->metric_kind == CSI_METRIC_FULL || force_ring) ? 1024 : 1536;
+    // Uniform coefficients (plain / walls / mask families on uniform metrics with an FPlane): two waves per SIMD with taller tiles
+    // beat three at every size measured (round 5, profiles/r05_tile_count.txt: 1536^2 +4.5 %, 2048^2 +1.2 ... 3 %, 3072^2 +7.5 %,
+    // 4096^2 +11 %, config 5's masked 4096^2 64.8 -> 71.8 G): a launch at 2048^2 is 83 iterations of 1.42 us instead of 57 of 2.09.
+    // Per-row coefficients (lat-lon, BetaPlane: 65 vs 59 G at 2048^2) and the immersed flux conditions (55 vs 49) keep three:
+    // their scalar loads per row want the third wave.
+    {
+        bool any_ibc = false;
+        for (int k = 0; k < 4; ++k) any_ibc |= (c->ibc[0][k] != 0.0) | (c->ibc[1][k] != 0.0);
+        if (target == 1536 && c->coef.uniform != 0 && !(any_ibc && c->g.has_mask)) target = 1024;
+    }
+    if (c->tune.pair_target >= 0) target = c->tune.pair_target;      // tuning aid (CSI_PAIR_TARGET: the rules below still apply)
     // Beside a fold band (its own stream: eight small launches per pair of sub-steps) the pair launch leaves a third of the wave
     // slots free, so that the band runs DURING the launch instead of in its tail -- a launch that fills every slot lets only the
     // band's first kernel in (round 3: 123 + 31 us per pair of sub-steps at 2048^2).  Measured at 2048^2, round 4: fold on uniform
@@ -419,18 +430,25 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     if (c->geom_peer && !forced && c->tune.pair_rows < 0 && c->tune.peer_edge != 0) {
         // (the NEXT chunk must stay out of the side's tile set: it may neither read halo rows nor own rows whose images go to the
         //  neighbour -- rows 1 .. max(Hy, 4) / the last max(Hy, 4) rows; dec starts at row 0 / ends at row Ny + 1)
-        const int reach = std::max(c->Hy, 4), want = rows - (c->tune.peer_edge > 0 ? c->tune.peer_edge : 4);
-        const int e_lo = std::max(reach + 1 - dec.j0, want), e_hi = std::max(reach + (dec.j1 - c->Ny), want);
-        const bool lo = c->peer.sync_rank[2] >= 0 && e_lo < rows, hi = c->peer.sync_rank[3] >= 0 && e_hi < rows;
-        if (height >= 4 * rows && (lo || hi)) {
-            G.elo = lo ? e_lo : rows;
-            G.ehi = hi ? e_hi : 0;
-            const int mid = height - G.elo - G.ehi;
-            G.nchunks = 1 + (mid + rows - 1) / rows + (hi ? 1 : 0);
-            if (!hi) {
-                // (no short chunk at the high side: the formula's last chunk is simply what is left behind chunk 0)
-                G.nchunks = 1 + (height - G.elo + rows - 1) / rows;
+        // The short chunks must not push the tile count over the resident set (one tile too many puts a third wave on some SIMDs
+        // for the whole launch: 2048 x 1024 connected in y, 28 x 37 tiles: 52.6 G; 27 x 37: 68): taller rows until they fit.
+        for (;; ++rows) {
+            const int reach = std::max(c->Hy, 4), want = rows - (c->tune.peer_edge > 0 ? c->tune.peer_edge : 4);
+            const int e_lo = std::max(reach + 1 - dec.j0, want), e_hi = std::max(reach + (dec.j1 - c->Ny), want);
+            const bool lo = c->peer.sync_rank[2] >= 0 && e_lo < rows, hi = c->peer.sync_rank[3] >= 0 && e_hi < rows;
+            G.rows = rows; G.elo = G.ehi = 0;
+            G.nchunks = (height + rows - 1) / rows;
+            if (height >= 4 * rows && (lo || hi)) {
+                G.elo = lo ? e_lo : rows;
+                G.ehi = hi ? e_hi : 0;
+                const int mid = height - G.elo - G.ehi;
+                G.nchunks = 1 + (mid + rows - 1) / rows + (hi ? 1 : 0);
+                if (!hi) {
+                    // (no short chunk at the high side: the formula's last chunk is simply what is left behind chunk 0)
+                    G.nchunks = 1 + (height - G.elo + rows - 1) / rows;
+                }
             }
+            if (G.nchunks <= max_chunks || rows >= height) break;
         }
     }
     return G;
