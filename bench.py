@@ -52,6 +52,63 @@ HBM_ACHIEVABLE_GBS = 6300.0                                    # ... and the mea
 #   k_pair / k_substep: read u, v, P, h, aice, sigma x 3, u^n, v^n + write sigma x 3, u, v = 15 x 8 B (k_pair does two
 #   sub-steps on them); three-kernel path: the per-phase figures of SURVEY.md 8(d).
 KERNEL_BYTES = {"pair": 120.0, "substep": 120.0, "stress": 96.0, "ustep": 80.0, "vstep": 80.0}
+class ClockSampler:
+    """Shader clock and board power of THIS GPU while the timed region runs (round 5: at 2048^2 the sub-cycle runs at the board's
+    power cap -- ~2.08 GHz at ~1380 W where small tiles get 2.4 GHz -- so a launch time only means something beside the clock it
+    was measured at; profiles/r05_power_clock.md).  A thread reads the hwmon files of the card whose PCI address is the device's
+    (the boxes show every card of their host); nothing here touches the GPU.  Unreadable sysfs -> every field None."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.freq = self.power = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)).lower() == bdf:
+                    f = glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input"))
+                    w = glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average")) or glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_input"))
+                    self.freq = f[0] if f else None
+                    self.power = w[0] if w else None
+        except Exception:
+            pass
+
+    def _read(self, path):
+        try:
+            with open(path) as fh:
+                return int(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((self._read(self.freq) if self.freq else None, self._read(self.power) if self.power else None))
+            self._stop.wait(0.004)
+
+    def __enter__(self):
+        import threading
+        if self.freq or self.power:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thread:
+            self._thread.join()
+
+    def summary(self):
+        fr = sorted(x[0] for x in self.samples if x[0]); pw = sorted(x[1] for x in self.samples if x[1])
+        return {"sclk_mhz": fr[len(fr) // 2] / 1e6 if fr else None, "sclk_mhz_min": fr[0] / 1e6 if fr else None,
+                "sclk_mhz_max": fr[-1] / 1e6 if fr else None, "power_w": pw[len(pw) // 2] / 1e6 if pw else None,
+                "samples": len(self.samples), "source": "sysfs hwmon freq1_input / power1_average of this device, 4 ms period, timed region" if self.samples else None}
+
+
 # Default decomposition of the metric's grid on N GPUs: slabs in y (Rx = 1).  Measured per tile shape on one MI355X, the tile connected
 # to itself over the peer transport in the directions its partition connects (scripts/tile_shapes.py, profiles/r04_tile_1024x512.md; G
 # cell-updates/s): N = 8: 1x8 (2048 x 256) 39.9, 2x4 (1024 x 512) 36.8, 8x1 35.9, 4x2 35.5; N = 4: 1x4 54.4, 2x2 51.4; N = 2: 1x2 65.9,
@@ -584,7 +641,8 @@ def main():
     # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
     # below is the last thing this process writes
     ctypes.CDLL(None).fflush(None)
-    elapsed = timed(args.steps, stats=True)
+    with ClockSampler(local_rank) as clock:
+        elapsed = timed(args.steps, stats=True)
 
     owned = nx_l * ny_l * world
     value = owned * args.substeps * args.steps / elapsed
@@ -659,6 +717,9 @@ def main():
             "algorithmic_note": "SURVEY.md 8(d): 256 B per cell-update of the unfused stress / u / v split; above 1 = traffic removed by fusion",
             "substep_ms": sub_ms}
     roof["frac_of_achievable"] = achieved / HBM_ACHIEVABLE_GBS
+    # the clock and the power the timed launches ran at (rank 0's GPU): 2048^2 sits at the board's power cap, below the 2.4 GHz the
+    # issue intervals of FP64_ISSUE_NS were measured near; small tiles do not (profiles/r05_power_clock.md)
+    roof["clock"] = clock.summary()
     # ---- the SURVEY.md 8(d)-literal figure, measured in the SAME run (outside the headline region): the unfused three-kernel FAST
     # path (k_stress, k_ustep, k_vstep: every array crosses HBM once per phase) moves the contract's 256 B per cell-update, so
     # cell-updates/s x 256 B is a roofline fraction in the contract's own terms (< 1); the fused kernels above do the same work
