@@ -105,7 +105,7 @@ class ClockSampler:
     def summary(self):
         fr = sorted(x[0] for x in self.samples if x[0]); pw = sorted(x[1] for x in self.samples if x[1])
         return {"sclk_mhz": fr[len(fr) // 2] / 1e6 if fr else None, "sclk_mhz_min": fr[0] / 1e6 if fr else None,
-                "sclk_mhz_max": fr[-1] / 1e6 if fr else None, "power_w": pw[len(pw) // 2] / 1e6 if pw else None,
+                "sclk_mhz_max": fr[-1] / 1e6 if fr else None, "power_w": pw[-1] / 1e6 if pw else None,      # (the largest sample: hwmon's figure is a moving average that lags a 0.15 s region)
                 "samples": len(self.samples), "source": "sysfs hwmon freq1_input / power1_average of this device, 4 ms period, timed region" if self.samples else None}
 
 
