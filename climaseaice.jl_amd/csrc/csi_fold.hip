@@ -68,7 +68,7 @@ int32_t band_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, in
         rows_from(q, bd.M - 7, cur == 0 ? b.p : c->alt[q], c->band[q], in);
         rows_from(q, bd.M + 1, c->band[q], cur == 0 ? c->alt[q] : b.p, out);
     }
-    launch_copy_batch(in, st);
+    launch_copy_batch(in, st, 64);
     FRef b[5], d[4];
     for (int q = 0; q < 5; ++q) b[q] = band_ref(c, q);
     for (int q = 0; q < 4; ++q) d[q] = band_ref(c, 5 + q);
@@ -78,10 +78,10 @@ int32_t band_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, in
         if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 5, false, st))) return rc;
         if ((rc = band_substep(c, bd, fc, b, d, ((s + 1) % 2) == 0, bd.M - 2, last, st))) return rc;
     } else if ((rc = band_substep(c, bd, fc, b, d, (s % 2) == 0, bd.M - 3, last, st))) return rc;
-    launch_copy_batch(out, st);
+    launch_copy_batch(out, st, 64);
     if (last) {
         for (int q = 5; q < 9; ++q) rows_from(q, bd.M + 1, c->band[q], band_bound(c, q).p, diag);
-        launch_copy_batch(diag, st);
+        launch_copy_batch(diag, st, 64);
     }
     HIP_TRY(c, hipEventRecord(c->band_ev_band, st));
     return CSI_OK;

@@ -119,7 +119,7 @@ void launch_fill_halo_batch(const HaloBatch& B, const GridDev& g, hipStream_t s)
 void launch_fill_halo_xcolumns(const HaloBatch& B, const GridDev& g, hipStream_t s);
 void launch_mask_v(const FRef& f, const GridDev& g, hipStream_t s);
 struct CopyBatch { const double* src[6]; double* dst[6]; long n[6]; int count; int aligned16; };
-void launch_copy_batch(const CopyBatch& B, hipStream_t s);
+void launch_copy_batch(const CopyBatch& B, hipStream_t s, int block = 256);      // block 64: beside a pair launch (one-wave workgroups find a slot)
 
 // advection + tracer update (advect.hip)
 struct AdvDev {

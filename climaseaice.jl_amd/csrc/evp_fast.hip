@@ -41,6 +41,7 @@ __device__ __forceinline__ double coef(const FastCoef& c, int which, int j) {
 struct TileMap {
     int gx, ntiles, per_xcd;
     int ibase, jbase;
+    int ty;              // rows per block (blockDim.y): TILE_Y, or 1 on short ranges (the fold band: see tile_map)
 };
 constexpr int TILE_X = 64, TILE_Y = 4;
 
@@ -50,7 +51,7 @@ constexpr int TILE_X = 64, TILE_Y = 4;
     if ((b_ >> 3) >= (tm).per_xcd || t_ >= (tm).ntiles) return;                 \
     const int by_ = t_ / (tm).gx, bx_ = t_ - by_ * (tm).gx;                     \
     const int i = (tm).ibase + bx_ * TILE_X + (int)threadIdx.x;                 \
-    const int j = __builtin_amdgcn_readfirstlane((tm).jbase + by_ * TILE_Y + (int)threadIdx.y); \
+    const int j = __builtin_amdgcn_readfirstlane((tm).jbase + by_ * (tm).ty + (int)threadIdx.y); \
     if (i < (r).i0 || i > (r).i1 || j > (r).j1) return;
 
 __global__ void __launch_bounds__(256) k_init(EvpDev P, Range r) {
@@ -398,7 +399,12 @@ static fast::TileMap tile_map(const EvpDev& P, const Range& r, dim3& grid) {
     if (tm.ibase > r.i0) tm.ibase = r.i0;
     tm.jbase = r.j0;
     tm.gx = (r.i1 - tm.ibase + fast::TILE_X) / fast::TILE_X;
-    const int gy = (r.j1 - r.j0 + fast::TILE_Y) / fast::TILE_Y;
+    // Short ranges are the fold band's: its launches run BESIDE a pair launch whose waves hold 232-240 of a SIMD's 512 registers
+    // each, so a four-wave workgroup finds room only when a pair tile retires (round 4's trace of the tripolar-like case: k_stress2
+    // of a 16-row band "ran" 276 us).  One wave per workgroup fits wherever ONE slot is free.
+    static const int band_ty = [] { const char* e = getenv("CSI_BAND_TY"); return (e && *e) ? atoi(e) : 1; }();
+    tm.ty = (r.j1 - r.j0 + 1 <= 32) ? std::min(std::max(band_ty, 1), fast::TILE_Y) : fast::TILE_Y;
+    const int gy = (r.j1 - r.j0 + tm.ty) / tm.ty;
     tm.ntiles = tm.gx * gy;
     tm.per_xcd = (tm.ntiles + 7) / 8;
     grid = dim3((unsigned)(tm.per_xcd * 8), 1, 1);
@@ -408,6 +414,7 @@ static fast::TileMap tile_map(const EvpDev& P, const Range& r, dim3& grid) {
 void launch_fast_stress(const EvpDev& P, const Range& r, const FastCoef& c, hipStream_t s) {
     dim3 b(fast::TILE_X, fast::TILE_Y), g;
     const fast::TileMap tm = tile_map(P, r, g);
+    b.y = (unsigned)tm.ty;
     if (c.full) { hipLaunchKernelGGL(fast::k_stress2, g, b, 0, s, P, r, c, tm); return; }
     if (c.uniform) hipLaunchKernelGGL(fast::k_stress<true>, g, b, 0, s, P, r, c, tm);
     else hipLaunchKernelGGL(fast::k_stress<false>, g, b, 0, s, P, r, c, tm);
@@ -415,6 +422,7 @@ void launch_fast_stress(const EvpDev& P, const Range& r, const FastCoef& c, hipS
 void launch_fast_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s) {
     dim3 b(fast::TILE_X, fast::TILE_Y), g;
     const fast::TileMap tm = tile_map(P, r, g);
+    b.y = (unsigned)tm.ty;
     const bool m = P.g.has_mask != 0;
     if (c.full) {
         if (m) hipLaunchKernelGGL((fast::k_ustep2<true>), g, b, 0, s, P, r, im, c, tm);
@@ -432,6 +440,7 @@ void launch_fast_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, con
 void launch_fast_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s) {
     dim3 b(fast::TILE_X, fast::TILE_Y), g;
     const fast::TileMap tm = tile_map(P, r, g);
+    b.y = (unsigned)tm.ty;
     const bool m = P.g.has_mask != 0;
     if (c.full) {
         if (m) hipLaunchKernelGGL((fast::k_vstep2<true>), g, b, 0, s, P, r, im, c, tm);

@@ -130,14 +130,14 @@ __global__ void __launch_bounds__(256) k_copy_batch(CopyBatch B) {
         }
     }
 }
-void launch_copy_batch(const CopyBatch& B, hipStream_t s) {
+void launch_copy_batch(const CopyBatch& B, hipStream_t s, int block) {
     if (B.count <= 0) return;
     long nmax = 0;
     for (int k = 0; k < B.count; ++k) nmax = B.n[k] > nmax ? B.n[k] : nmax;
-    unsigned gx = (unsigned)((nmax / 2 + 255) / 256);
+    unsigned gx = (unsigned)((nmax / 2 + block - 1) / block);
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(k_copy_batch, dim3(gx, (unsigned)B.count), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_copy_batch, dim3(gx, (unsigned)B.count), dim3((unsigned)block), 0, s, B);
 }
 
 // mask_immersed_field_xy!(field, k = Nz), sea_ice_model.jl:381-389: zero at peripheral nodes of an
