@@ -32,6 +32,9 @@
 #ifndef CSI_PAIR_WAVES
 #define CSI_PAIR_WAVES 3        // waves per SIMD the register allocation aims at (512 / 3 -> 168 VGPRs)
 #endif
+#ifndef CSI_PAIR_UNI_WAVES
+#define CSI_PAIR_UNI_WAVES 2    // ... of the uniform-coefficient instantiations: pair_geom (csi_core.hip) gives them 1024 tiles = two waves per SIMD
+#endif                          //     (round 5), so the velocity coefficients they hold in vector registers (Stage::hoist_uniform) cost no occupancy
 #ifndef CSI_PAIR_FULL_WAVES
 #define CSI_PAIR_FULL_WAVES 2   // ... of the per-point-coefficient (CSI_METRIC_FULL) instantiations
 #endif
@@ -579,7 +582,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     if (!consumer) {
         // ===== PRODUCER: stage A = sub-step s, rows rstart .. rend ===================================================
         PROBE_DECL;
-        Stage<UNI, AUF, MASK, FORCE, CF, FULL> A;    // (TIGHT scalar live ranges in the array-forcing variants)
+        Stage<UNI, AUF, MASK, FORCE, CF, FULL, !(EXTRA == 1 && MASK)> A;    // (TIGHT scalar live ranges in the array-forcing variants)
 #ifndef CSI_EXP_RINGALIAS
 #define CSI_EXP_RINGALIAS 0     // TIMING EXPERIMENT ONLY (wrong results): a tile's ring rows are read from the nearest rows it owns -- same instructions,
                                 // same arithmetic, but no ring row ever comes from HBM: what it would be worth if every ring-row re-read hit the L2
@@ -600,6 +603,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             A.Xv_0 = fm::sum2(from_left(A.v_0), A.v_0);
             double e11_m, e22_m;
             const int jm = rstart - 1;
+            A.hoist_uniform(T);
             if constexpr (FULL) {
                 const unsigned om2 = off2(jm), o02 = off2(rstart);
                 full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m);
@@ -861,7 +865,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 
     // ===== CONSUMER: stage B = sub-step s + 1, rows q = r - 2, one iteration behind the producer ====================
     PROBE_DECL;
-    Stage<UNI, !AUF, MASK, FORCE, CF, FULL> B;
+    Stage<UNI, !AUF, MASK, FORCE, CF, FULL, !(EXTRA == 1 && MASK)> B;
     B.u_m = 0; B.u_0 = 0; B.v_m = 0; B.v_0 = 0; B.Xv_m = 0; B.Xv_0 = 0;
     B.a_mm = 0; B.a_m = 0; B.m_mm = 0; B.m_m = 0;
     B.XP_m = 0; B.Xm_m = 0; B.Xa_m = 0; B.Xe11_m = 0; B.Xe22_m = 0; B.Ye12_0 = 0; B.e12_0 = 0;
@@ -869,6 +873,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     B.S11_mm = 0; B.S22_mm = 0; B.S12_mm = 0; B.AL_mm = 0; B.S11_m = 0; B.S22_m = 0; B.S12_m = 0; B.AL_m = 0;
     B.S11_0 = 0; B.S22_0 = 0; B.S12_0 = 0; B.AL_0 = 0; B.first = 0; B.second = 0;
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0; B.Pf_0 = 0; B.rmc_0 = 0; B.rmf_0 = 0;
+    B.hoist_uniform(T);
     if constexpr (FULL) {
         B.hoist_planes(T);
         B.full_init(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)), c2s);
@@ -1039,7 +1044,8 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
 }
 
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
-__global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+__global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING)) ? CSI_PAIR_FULL_WAVES
+                                       : (UNI && !(EXTRA == 1 && MASK)) ? CSI_PAIR_UNI_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;

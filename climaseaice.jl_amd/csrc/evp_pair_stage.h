@@ -60,7 +60,7 @@ __device__ __forceinline__ double full_corner(tptr_t T, unsigned o, unsigned s2,
     return fm::full_strain_corner(Ux_n, Ux_s, Vy_e, from_left(Vy_e), c2at(T, C2_DXF2, o), c2at(T, C2_DYF2, o), c2at(T, C2_RAZF, o));
 }
 
-template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, int CF = 0, bool FULL = false>
+template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, int CF = 0, bool FULL = false, bool HOLDK = true>
 struct Stage {
     double u_m, u_0, v_m, v_0, Xv_m, Xv_0;
     double a_mm, a_m, m_mm, m_m;
@@ -91,6 +91,26 @@ struct Stage {
     __device__ __forceinline__ double c2m(tptr_t T, int which, unsigned off) const { return c2at(T, which, off); }
 #endif
     double RAZC_0, RAZU_m, RAZV_x, FU_m, FV_x;       // this step's 1 / Az at the cell (row r), the u point (row r - 1), the v point (row r - 1 / r); f likewise
+
+    // Uniform coefficients, round 5: the velocity phase's seven coefficients and the bottom drag constant live in VECTOR registers.
+    // The kernel has no scalar register left for them (106 in use, 36-55 spilled to lanes outside the loops), so the compiler
+    // re-read them from the table in every row -- three scalar loads per stage-row, each waited for on the spot (24-42 ns,
+    // profiles/r01_microbenchmarks.md) by a wave that shares its SIMD with ONE other since the tile-count rule.  The opaque
+    // asm pins the VGPR copy (a value the compiler cannot rematerialise from the table).
+#ifndef CSI_PAIR_VK
+#define CSI_PAIR_VK 1
+#endif
+    static constexpr bool VKC = UNI && !FULL && HOLDK && (CSI_PAIR_VK != 0);       // (k_pair's register budget of these instantiations: CSI_PAIR_UNI_WAVES)
+    double VK_E, VK_FN, VK_FS, VK_FU, VK_Q2N, VK_K, VK_FV, VK_BRHO;
+    __device__ __forceinline__ void hoist_uniform(tptr_t T) {
+        if constexpr (VKC) {
+            VK_E = T->K[FK_PCOEF0 + FC_E]; VK_FN = T->K[FK_PCOEF0 + FC_FN]; VK_FS = T->K[FK_PCOEF0 + FC_FS]; VK_FU = T->K[FK_PCOEF0 + FC_FU];
+            VK_Q2N = T->K[FK_PCOEF0 + FC_Q2N]; VK_K = T->K[FK_PCOEF0 + FC_K]; VK_FV = T->K[FK_PCOEF0 + FC_FV]; VK_BRHO = T->K[FK_BOT_RHOCD];
+            asm volatile("" : "+v"(VK_E), "+v"(VK_FN), "+v"(VK_FS), "+v"(VK_FU), "+v"(VK_Q2N), "+v"(VK_K), "+v"(VK_FV), "+v"(VK_BRHO));
+        }
+    }
+    __device__ __forceinline__ double vk(tptr_t T, int which, int j, double held) const { if constexpr (VKC) return held; else return pcoef<UNI>(T, which, j); }
+    __device__ __forceinline__ double brho(tptr_t T) const { if constexpr (VKC) return VK_BRHO; else return T->K[FK_BOT_RHOCD]; }
 
     // FULL, round 4: the plane values a step needs are loaded DURING THE PREVIOUS step, between its stress phase and its velocity
     // phase (N_*: a phase of arithmetic and the row barrier lie between a load and its use; loaded at use -- round 3 -- every
@@ -302,15 +322,15 @@ struct Stage {
                 const double vbar = fm::quarter(Xv_m, Xv_0);
                 double div;
                 if constexpr (FULL) div = div1_full();
-                else div = fm::div1(pcoef<UNI>(T, FC_E, j), pcoef<UNI>(T, FC_FN, j), pcoef<UNI>(T, FC_FS, j),
+                else div = fm::div1(vk(T, FC_E, j, VK_E), vk(T, FC_FN, j, VK_FN), vk(T, FC_FS, j, VK_FS),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], u_m, vbar, exb, imb);
-                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(brho(T), u_m, vbar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, brho(T), F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
-                else cor = pcoef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                else cor = vk(T, FC_FU, j, VK_FU) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 if (F.extra & 1) cor += F.xc_u;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_u, div);      // (div is twice the divergence)
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_first, F.fd_u)
@@ -321,16 +341,16 @@ struct Stage {
                 const double ubar = fm::quarter(XW, XW_0);
                 double div;
                 if constexpr (FULL) div = div2_full(true);
-                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, j), pcoef<UNI>(T, FC_Q2N, j), pcoef<UNI>(T, FC_Q1S, j),
-                                            pcoef<UNI>(T, FC_Q2S, j), pcoef<UNI>(T, FC_K, j),
+                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, j), vk(T, FC_Q2N, j, VK_Q2N), pcoef<UNI>(T, FC_Q1S, j),
+                                            pcoef<UNI>(T, FC_Q2S, j), vk(T, FC_K, j, VK_K),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
-                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], v_m, ubar, exb, imb);
-                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(brho(T), v_m, ubar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, brho(T), F.b_we_v, F.b_wb_v, v_m, ubar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2 - s2, j) * ubar;
-                else cor = -pcoef<UNI>(T, FC_FV, j) * ubar;
+                else cor = -vk(T, FC_FV, j, VK_FV) * ubar;
                 if (F.extra & 1) cor += F.xc_v;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_v, div);
                 second = F.fd ? fm::vel_update_sum_fd(kv, v_m, vn_x, m_mm + m_m, a_mm + a_m, AL_mm + AL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_v)
@@ -344,16 +364,16 @@ struct Stage {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
                 double div;
                 if constexpr (FULL) div = div2_full(false);
-                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, r), pcoef<UNI>(T, FC_Q2N, r), pcoef<UNI>(T, FC_Q1S, r),
-                                            pcoef<UNI>(T, FC_Q2S, r), pcoef<UNI>(T, FC_K, r),
+                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, r), vk(T, FC_Q2N, r, VK_Q2N), pcoef<UNI>(T, FC_Q1S, r),
+                                            pcoef<UNI>(T, FC_Q2S, r), vk(T, FC_K, r, VK_K),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
-                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], v_0, ubar, exb, imb);
-                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, T->K[FK_BOT_RHOCD], F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(brho(T), v_0, ubar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_v, brho(T), F.b_we_v, F.b_wb_v, v_0, ubar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = -f_full(FP_FROW_V, FP_F2V, o2, r) * ubar;
-                else cor = -pcoef<UNI>(T, FC_FV, r) * ubar;
+                else cor = -vk(T, FC_FV, r, VK_FV) * ubar;
                 if (F.extra & 1) cor += F.xc_v;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_v, div);
                 W_0 = F.fd ? fm::vel_update_sum_fd(kv, v_0, vn_x, m_m + m_0, a_m + a_0, AL_m + AL_0, div, cor, ext, imt, exb, imb, per_first, F.fd_v)
@@ -365,15 +385,15 @@ struct Stage {
                 const double vbar = fm::quarter(XW, XW_0);
                 double div;
                 if constexpr (FULL) div = div1_full();
-                else div = fm::div1(pcoef<UNI>(T, FC_E, j), pcoef<UNI>(T, FC_FN, j), pcoef<UNI>(T, FC_FS, j),
+                else div = fm::div1(vk(T, FC_E, j, VK_E), vk(T, FC_FN, j, VK_FN), vk(T, FC_FS, j, VK_FS),
                                             d11_m, d11_mL, d12_0, d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_u; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_u, T->K[FK_TOP_RHOCD], F.t_we_u, F.t_wb_u, u_m, vbar, ext, imt);
-                if (CF == 2) fm::ext_stress_rest(T->K[FK_BOT_RHOCD], u_m, vbar, exb, imb);
-                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, T->K[FK_BOT_RHOCD], F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
+                if (CF == 2) fm::ext_stress_rest(brho(T), u_m, vbar, exb, imb);
+                else fm::ext_stress(CF ? 3 : T->I[FI_BOT_KIND], F.b_tau_u, brho(T), F.b_we_u, F.b_wb_u, u_m, vbar, exb, imb);
                 double cor;
                 if constexpr (FULL) cor = f_full(FP_FROW_U, FP_F2U, o2 - s2, j) * vbar;
-                else cor = pcoef<UNI>(T, FC_FU, j) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
+                else cor = vk(T, FC_FU, j, VK_FU) * vbar;   // f = 0 without Coriolis (csi_abi.hip)
                 if (F.extra & 1) cor += F.xc_u;
                 if (F.extra & 2) div = fm::fma_(2.0, F.xd_u, div);      // (div is twice the divergence)
                 second = F.fd ? fm::vel_update_sum_fd(kv, u_m, un_m, Xm_m, Xa_m, XAL_m, div, cor, ext, imt, exb, imb, per_second, F.fd_u)
