@@ -374,9 +374,9 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     FusedGeom G;
     G.rs = dec;
     // (56-column strip) x (rows) tiles, one workgroup of two waves (producer: first sub-step, consumer: second) per tile.
-    // The kernel is compiled for 3 waves per SIMD (<= 168 VGPRs): 256 CUs x 6 workgroups = 1536 resident tiles.  Exactly
-    // one round of tiles, as tall as possible: every SIMD keeps its waves from start to end and each tile pays its 6 ring
-    // rows once.
+    // Exactly ONE round of tiles, as tall as possible: every SIMD keeps its waves from start to end and each tile pays its ring
+    // rows once.  How many tiles a round holds follows the family's register budget (evp_fused2.hip, k_pair's launch bounds):
+    // 3 waves per SIMD (<= 168 VGPRs) = 256 CUs x 6 workgroups = 1536; 2 waves per SIMD = 1024.
     const int width = dec.i1 - dec.i0 + 1, height = dec.j1 - dec.j0 + 1;
     G.nstrips = (width + 55) / 56;
     // (per-point coefficients: the kernel is compiled for 2 waves per SIMD -> 1024 resident tiles; measured at 2048^2:
