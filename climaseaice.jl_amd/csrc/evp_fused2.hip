@@ -154,7 +154,10 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     // Roles: wave 0 produces, wave 1 consumes.  (Measured placement of the 12 waves of a CU's six workgroups, in dispatch
     // order, on its SIMDs a..d: a b | b c | c d | d a | a b | c d -- every SIMD gets producers and consumers, the two waves
     // of a workgroup never share a SIMD; swapping the roles in some workgroups changed nothing measurable.)
-    const bool consumer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
+#ifndef CSI_EXP_ROLESWAP
+#define CSI_EXP_ROLESWAP 0     // experiment: workgroups of odd arrival rank on their CU swap the roles of their waves (SIMDs then hold two producers or two consumers)
+#endif
+    const bool consumer = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) != (CSI_EXP_ROLESWAP && ((((b >> 3) / CSI_EXP_ROLESWAP) & 1) != 0));
     const int chunk = w / nstrips, strip = w - chunk * nstrips;
     const int lane = (int)(threadIdx.x & 63);
     tptr_t T = (tptr_t)table;
