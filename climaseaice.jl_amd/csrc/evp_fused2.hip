@@ -780,6 +780,10 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             }
             A.shift(C.u_p, C.v_p, m_0, C.a_0);
             PROBE(pacc1);
+#ifndef CSI_EXP_HALFBARRIER
+#define CSI_EXP_HALFBARRIER 0      // timing experiment (RACY, wrong results): the two waves meet at every second row only
+#endif
+            if (!(CSI_EXP_HALFBARRIER && ((r - rstart) & 1)))
             __syncthreads();                              // row r is complete: the consumer may run its iteration r
             PROBE(pacc2);
         };
@@ -902,6 +906,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         set_prio(decltype(KK)::value);
         const int q = r - 2;
         PROBE_START;
+        if (!(CSI_EXP_HALFBARRIER && ((r - rstart) & 1)))
         __syncthreads();                                  // the producer has finished row r
         PROBE(pacc0);
         // The consumer's first iterations of a tile (q < ja - 3: q = rstart - 2, rstart - 1 unless the tile starts at the low end of
