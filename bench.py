@@ -106,7 +106,11 @@ class ClockSampler:
         fr = sorted(x[0] for x in self.samples if x[0]); pw = sorted(x[1] for x in self.samples if x[1])
         return {"sclk_mhz": fr[len(fr) // 2] / 1e6 if fr else None, "sclk_mhz_min": fr[0] / 1e6 if fr else None,
                 "sclk_mhz_max": fr[-1] / 1e6 if fr else None, "power_w": pw[-1] / 1e6 if pw else None,      # (the largest sample: hwmon's figure is a moving average that lags a 0.15 s region)
-                "samples": len(self.samples), "source": "sysfs hwmon freq1_input / power1_average of this device, 4 ms period, timed region" if self.samples else None}
+                "sclk_mhz_last": (lambda v: v[-1] / 1e6 if v else None)([x[0] for x in self.samples if x[0]]),
+                "samples": len(self.samples),
+                "note": "the firmware's figures are moving averages: over a region of a few tenths of a second they lag (idle time before it pulls them down); "
+                        "scripts/clock_watch.sh over a 10 s run is the reference (profiles/r05_power_clock.md)",
+                "source": "sysfs hwmon freq1_input / power1_average of this device, 4 ms period, timed region" if self.samples else None}
 
 
 # Default decomposition of the metric's grid on N GPUs: slabs in y (Rx = 1).  Measured per tile shape on one MI355X, the tile connected
