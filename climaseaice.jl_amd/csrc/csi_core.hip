@@ -393,7 +393,7 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     {
         bool any_ibc = false;
         for (int k = 0; k < 4; ++k) any_ibc |= (c->ibc[0][k] != 0.0) | (c->ibc[1][k] != 0.0);
-        if (target == 1536 && c->coef.uniform != 0 && !(any_ibc && c->g.has_mask)) target = 1024;
+        if (target == 1536 && (c->coef.uniform != 0 || c->tune.row_target_1024 != 0) && !(any_ibc && c->g.has_mask)) target = 1024;
     }
     if (c->tune.pair_target >= 0) target = c->tune.pair_target;      // tuning aid (CSI_PAIR_TARGET: the rules below still apply)
     // Beside a fold band (its own stream: eight small launches per pair of sub-steps) the pair launch leaves a third of the wave

@@ -193,7 +193,7 @@ struct csi_context {
     int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
     int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
-    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
+    struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, row_target_1024 = 0, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
                     adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
                     no_geom_sig = -1;      // debugging aid (CSI_DEBUG_NO_GEOM_SIG=1): skip the launch-geometry check of the peer set-up (tests/test_gpu_local_tiles.py)
     } tune;

@@ -98,6 +98,9 @@ enum : int { RF_S11 = 0, RF_S22, RF_S12, RF_U, RF_V, RF_P, RF_M, RF_A, RF_UN, RF
 // two reciprocals, a lane shift and four more operations per row (it is the longer wave of the pair); 26 KB of LDS per
 // workgroup instead of 20: six workgroups per CU still fit, except with the mask rows of the immersed-boundary
 // instantiations, which therefore keep the ten-field ring (CSI_PAIR_PRE).
+#ifndef CSI_PAIR_LDSC_NOPRE
+#define CSI_PAIR_LDSC_NOPRE 1   // per-row coefficients through the LDS window (Stage::pc): the ten-field ring, so that six workgroups per CU still fit
+#endif
 #ifndef CSI_PAIR_PRE
 #define CSI_PAIR_PRE 1
 #endif
@@ -143,9 +146,11 @@ enum : int { RP_DXV = 0, RP_RDYV, RP_RDXU, RP_DXF2, RP_DYF2, RP_RAZF, RP_DYU, RP
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
 __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
-                                       double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p, double* __restrict__ ringp) {
+                                       double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p, double* __restrict__ ringp,
+                                       double* __restrict__ ringc) {
+    constexpr bool LDSC = !UNI && !FULL && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0);
     constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;      // the forcing values of a stage-row travel through the ring too (below)
-    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING && !(CSI_PAIR_LDSC_NOPRE && !UNI && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0));
     constexpr int RING_FIELDS = FRING ? 10 + RF_FORCING : (PRE ? 13 : 10);      // (FULL: ten fields; its plane values have a ring of their own, ringp)
 #define peer_abort (*peer_abort_p)
     const int b = (int)blockIdx.x;
@@ -586,6 +591,13 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         // ===== PRODUCER: stage A = sub-step s, rows rstart .. rend ===================================================
         PROBE_DECL;
         Stage<UNI, AUF, MASK, FORCE, CF, FULL, !(EXTRA == 1 && MASK)> A;    // (TIGHT scalar live ranges in the array-forcing variants)
+        A.lc = ringc;
+        // LDSC: the address of lane k's entry (k < FC_COUNT; the other lanes re-read the last one) of coefficient row j of the table
+        const int cjmin = LDSC ? T->I[FI_COEF_JMIN] : 0, cjmax = LDSC ? T->I[FI_COEF_JMAX] : 0;
+        const unsigned ck_lane = (unsigned)min(lane, FC_COUNT - 1) * 8u;
+        auto coef_row_base = [&](int j) __attribute__((always_inline)) {
+            return T->P[FP_PCOEF_VEC] + (unsigned long)((long)min(max(j, cjmin), cjmax) * (long)(FC_COUNT * 8));
+        };
 #ifndef CSI_EXP_RINGALIAS
 #define CSI_EXP_RINGALIAS 0     // TIMING EXPERIMENT ONLY (wrong results): a tile's ring rows are read from the nearest rows it owns -- same instructions,
                                 // same arithmetic, but no ring row ever comes from HBM: what it would be worth if every ring-row re-read hit the L2
@@ -659,6 +671,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
         const unsigned long hU = HIN ? T->P[FP_U_IN] : 0ul, hV = HIN ? T->P[FP_V_IN] : 0ul, hP = HIN ? T->P[FP_P] : 0ul, hH = HIN ? T->P[FP_H] : 0ul,
                             hA = HIN ? T->P[FP_A] : 0ul, h11 = HIN ? T->P[FP_S11_IN] : 0ul, h22 = HIN ? T->P[FP_S22_IN] : 0ul, h12 = HIN ? T->P[FP_S12_IN] : 0ul,
                             hUN = HIN ? T->P[FP_UN] : 0ul, hVN = HIN ? T->P[FP_VN] : 0ul;
+        int rnext = rstart;                               // the row the NEXT load_row fetches (advance())
         auto load_row = [&](RowIn& Q) __attribute__((always_inline)) {
             if constexpr (HIN) {
                 Q.u_p = ldg(hU, of + sf); Q.v_p = ldg(hV, oc + sc);
@@ -672,10 +685,10 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             Q.un_m = ldg(T->P[FP_UN], of - sf); Q.vn_x = ldg(T->P[FP_VN], AUF ? oc - sc : oc);
             }
             Q.mk = MASK ? ldub(T->P[FP_MASK], om) : 1u;
+            if constexpr (LDSC) Q.ck = ldg(coef_row_base(rnext + 2), ck_lane);      // coefficient row (state row) + 2: in LDS one iteration before its first use
         };
         // oc / of / om: offsets of the row the NEXT load_row fetches; advance by one row, stopping at rend (the last
         // iterations re-read row rend: an unconditional prefetch keeps the number of loads in flight static)
-        int rnext = rstart;
         auto advance = [&]() __attribute__((always_inline)) {
             const bool more = rnext < rend;
             if (CSI_EXP_RINGALIAS) { rnext += more ? 1 : 0; oc = offc(alias_row(rnext)); of = offf(alias_row(rnext)); return; }
@@ -697,6 +710,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             else __builtin_amdgcn_s_waitcnt(0x0F70 | 10);
             PROBE(pacc0);
             const RowIn& C = R[k];
+            // LDSC: this row's loads brought lane k's entry of coefficient row r + 2: into the window, behind this iteration's barrier
+            // it is visible to both waves (first use: the corner coefficients of the producer's iteration r + 1)
+            if constexpr (LDSC) { if (lane < FC_COUNT) ringc[(unsigned)((r + 2) & 7) * FC_COUNT + (unsigned)lane] = C.ck; }
             // stage B's results of two iterations ago (rows r - 4 / r - 5): read them now, store them after the prefetch
             const unsigned so = (unsigned)((r - rstart) & 1) * (5 * 64) + (unsigned)lane;
             constexpr int PW = 7 & ~CSI_PAIR_STORES;          // what the producer stores
@@ -787,6 +803,15 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             __syncthreads();                              // row r is complete: the consumer may run its iteration r
             PROBE(pacc2);
         };
+        if constexpr (LDSC) {
+            // the window's first rows: rstart - 3 .. rstart + 1 (the consumer's first iteration reads down to rstart - 3, the producer's
+            // first up to rstart + 1); the same wave reads them back in order, the consumer behind the first row barrier
+#pragma unroll
+            for (int d = -3; d <= 1; ++d) {
+                const double v = ldg(coef_row_base(rstart + d), ck_lane);
+                if (lane < FC_COUNT) ringc[(unsigned)((rstart + d) & 7) * FC_COUNT + (unsigned)lane] = v;
+            }
+        }
         load_row(R[0]);                                   // row rstart
         if (CSI_PAIR_PD == 2) {
             advance();
@@ -873,6 +898,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     // ===== CONSUMER: stage B = sub-step s + 1, rows q = r - 2, one iteration behind the producer ====================
     PROBE_DECL;
     Stage<UNI, !AUF, MASK, FORCE, CF, FULL, !(EXTRA == 1 && MASK)> B;
+    B.lc = ringc;
     B.u_m = 0; B.u_0 = 0; B.v_m = 0; B.v_0 = 0; B.Xv_m = 0; B.Xv_0 = 0;
     B.a_mm = 0; B.a_m = 0; B.m_mm = 0; B.m_m = 0;
     B.XP_m = 0; B.Xm_m = 0; B.Xa_m = 0; B.Xe11_m = 0; B.Xe22_m = 0; B.Ye12_0 = 0; B.e12_0 = 0;
@@ -1056,13 +1082,15 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
                                        : (UNI && !(EXTRA == 1 && MASK)) ? CSI_PAIR_UNI_WAVES : CSI_PAIR_WAVES) k_pair(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
                                                               int blocks_per_xcd, int write_diag, unsigned long long seq) {
     constexpr bool FRING = FORCE && !FULL && (EXTRA != 1 || !MASK) && CSI_PAIR_FRING;
-    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING;
+    constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING && !(CSI_PAIR_LDSC_NOPRE && !UNI && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0));
     constexpr int RING_FIELDS = FRING ? 10 + RF_FORCING : (PRE ? 13 : 10);      // (FULL: ten fields; its plane values have a ring of their own, ringp)
     __shared__ double ring[RING_ROWS * RING_FIELDS * 64];
     __shared__ double ringp[FULL ? RP_ROWS * RP_FIELDS * 64 : 1];      // FULL: the plane values of three rows
     __shared__ unsigned ringm[MASK ? RING_ROWS * 64 : 1];
     __shared__ double outr[(CSI_PAIR_STORES & 7) != 7 ? 2 * 5 * 64 : 1];      // stage B's results on their way to the producer's stores
     __shared__ unsigned peer_abort_w;                      // PEER: the producer's wait has given up
+    constexpr bool LDSC = !UNI && !FULL && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0);
+    __shared__ double ringc[LDSC ? 8 * FC_COUNT : 1];      // per-row coefficients: an eight-row window (Stage::pc)
     if constexpr (PEER) {
         // an interior tile of a peer-connected launch (in no direction's set): the untiled instantiation's body
         const int b = (int)blockIdx.x;
@@ -1075,11 +1103,11 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
         const unsigned pd = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
                              ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)T->I[FI_PMASK];
         if (__builtin_amdgcn_readfirstlane((int)pd) == 0) {
-            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp);
+            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp, ringc);
             return;
         }
     }
-    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp);
+    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp, ringc);
 }
 
 }  // namespace fused

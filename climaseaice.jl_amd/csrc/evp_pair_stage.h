@@ -22,7 +22,7 @@ struct Forcing {
     int extra;           // bit 0: xc present, bit 1: xd present (0 in every other instantiation: the terms vanish at compile time)
 };
 
-struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; };
+struct RowIn { double u_p, v_p, P_0, h_0, a_0, s11, s22, s12, un_m, vn_x; unsigned mk; double ck; };      // ck: lane k's entry of a per-row coefficient row (Stage::LDSC)
 
 // One sub-step as a row pipeline.  step(r) consumes row r of P, m, a, sigma, rows r+1 of u, v and produces
 // sigma(r) and  UFIRST: u(r-1) ["first"], v(r-1) ["second"]   /   v first: v(r) ["first"], u(r-1) ["second"].
@@ -109,7 +109,21 @@ struct Stage {
             asm volatile("" : "+v"(VK_E), "+v"(VK_FN), "+v"(VK_FS), "+v"(VK_FU), "+v"(VK_Q2N), "+v"(VK_K), "+v"(VK_FV), "+v"(VK_BRHO));
         }
     }
-    __device__ __forceinline__ double vk(tptr_t T, int which, int j, double held) const { if constexpr (VKC) return held; else return pcoef<UNI>(T, which, j); }
+    // Per-row coefficients from an eight-row window in LDS (`lc`, filled by the producer wave one row ahead of its first use:
+    // evp_fused2.hip) instead of the table's scalar loads -- built in round 5 and LEFT OFF (CSI_PAIR_LDSC=1 enables it).  The scalar
+    // loads come in five or six bursts per stage-row, each waited for on the spot (no scalar register is left to hold a row's twenty
+    // values), and lat-lon tiles run 10-14 % behind uniform ones of the same shape where the arithmetic explains 4 %; but the
+    // broadcast `ds_read`s that replace them wait too (and share lgkmcnt with the ring traffic), and the window's 1.3 KB end the
+    // six-workgroups-per-CU fit of the 13-field ring: tiles +0-3 %, 2048^2 -3 %, 4096^2 -7 % (profiles/r05_row_coef_lds.txt).
+#ifndef CSI_PAIR_LDSC
+#define CSI_PAIR_LDSC 0
+#endif
+    static constexpr bool LDSC = !UNI && !FULL && HOLDK && (CSI_PAIR_LDSC != 0);
+    const double* lc = nullptr;
+    __device__ __forceinline__ double pc(tptr_t T, int which, int j) const {
+        if constexpr (LDSC) return lc[(unsigned)(j & 7) * FC_COUNT + which]; else return pcoef<UNI>(T, which, j);
+    }
+    __device__ __forceinline__ double vk(tptr_t T, int which, int j, double held) const { if constexpr (VKC) return held; else return pc(T, which, j); }
     __device__ __forceinline__ double brho(tptr_t T) const { if constexpr (VKC) return VK_BRHO; else return T->K[FK_BOT_RHOCD]; }
 
     // FULL, round 4: the plane values a step needs are loaded DURING THE PREVIOUS step, between its stress phase and its velocity
@@ -207,9 +221,9 @@ struct Stage {
             const double Vy_e = RDYV_p * v_p;
             e12_p = fm::full_strain_corner8(RDXU_p * u_p, RDXU_0 * u_0, Vy_e, from_left(Vy_e), DXF2_p, DYF2_p, RAZF_p);      // 8 e12 (see below)
         } else {
-        fm::strain_cell<UNI>(pcoef<UNI>(T, FC_A, r), pcoef<UNI>(T, FC_BN, r), pcoef<UNI>(T, FC_BS, r), pcoef<UNI>(T, FC_CN, r),
-                        pcoef<UNI>(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
-        e12_p = fm::strain_corner<UNI>(pcoef<UNI>(T, FC_SN, r + 1), pcoef<UNI>(T, FC_SS, r + 1), pcoef<UNI>(T, FC_SV, r + 1),
+        fm::strain_cell<UNI>(pc(T, FC_A, r), pc(T, FC_BN, r), pc(T, FC_BS, r), pc(T, FC_CN, r),
+                        pc(T, FC_CS, r), from_right(u_0), u_0, v_p, v_0, e11_0, e22_0);
+        e12_p = fm::strain_corner<UNI>(pc(T, FC_SN, r + 1), pc(T, FC_SS, r + 1), pc(T, FC_SV, r + 1),
                                   u_p, u_0, v_p, from_left(v_p));
         }
         // Scaled quantities (round 4): the corner strain rate is carried times 8 (e12_0, e12_p, Ye12_*: scaled coefficients, pcoef /
@@ -244,7 +258,7 @@ struct Stage {
                 }
                 double kc, kf;      // kf: FOUR times c_alpha dt / (2 Az) at the corner
                 if constexpr (FULL) { kc = T->K[FK_CA_DT] * RAZC_0; kf = T->K[FK_PK_CA_DT4] * RAZF_0; }
-                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * pcoef<UNI>(T, FC_RAZC, r); kf = UNI ? T->K[FK_PK_HKF4] : T->K[FK_PK_CA_DT4] * pcoef<UNI>(T, FC_RAZF, r); }
+                else { kc = UNI ? T->K[FK_HKC] : T->K[FK_CA_DT] * pc(T, FC_RAZC, r); kf = UNI ? T->K[FK_PK_HKF4] : T->K[FK_PK_CA_DT4] * pc(T, FC_RAZF, r); }
                 const fm::StressOut o = fm::stress_update_s(ks, e11_0, e22_0, e12_0, e11f, e22f, e12c, P_0, Pf, m_0, mf, rmc_0, rmf_0, kc, kf, s11, s22, s12);
                 S11_0 = o.s11; S22_0 = o.s22; S12_0 = o.s12; AL_0 = o.alpha; zc = o.zc2; zf = o.zf2; Dc = o.xc; rDc = o.rDc;      // zc, zf: 2 zeta; Dc: Delta^2
             }
@@ -341,8 +355,8 @@ struct Stage {
                 const double ubar = fm::quarter(XW, XW_0);
                 double div;
                 if constexpr (FULL) div = div2_full(true);
-                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, j), vk(T, FC_Q2N, j, VK_Q2N), pcoef<UNI>(T, FC_Q1S, j),
-                                            pcoef<UNI>(T, FC_Q2S, j), vk(T, FC_K, j, VK_K),
+                else div = fm::div2<UNI>(pc(T, FC_Q1N, j), vk(T, FC_Q2N, j, VK_Q2N), pc(T, FC_Q1S, j),
+                                            pc(T, FC_Q2S, j), vk(T, FC_K, j, VK_K),
                                             d11_m, d22_m, d11_mm, d22_mm, from_right(d12_m), d12_m);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_m, ubar, ext, imt);
@@ -364,8 +378,8 @@ struct Stage {
                 const double ubar = fm::avg4(u_m, from_right(u_m), u_0, from_right(u_0));
                 double div;
                 if constexpr (FULL) div = div2_full(false);
-                else div = fm::div2<UNI>(pcoef<UNI>(T, FC_Q1N, r), vk(T, FC_Q2N, r, VK_Q2N), pcoef<UNI>(T, FC_Q1S, r),
-                                            pcoef<UNI>(T, FC_Q2S, r), vk(T, FC_K, r, VK_K),
+                else div = fm::div2<UNI>(pc(T, FC_Q1N, r), vk(T, FC_Q2N, r, VK_Q2N), pc(T, FC_Q1S, r),
+                                            pc(T, FC_Q2S, r), vk(T, FC_K, r, VK_K),
                                             d11_0, d22_0, d11_m, d22_m, from_right(d12_0), d12_0);
                 double ext, imt, exb, imb;
                 if (CF) { ext = F.t_tau_v; imt = 0.0; } else fm::ext_stress(T->I[FI_TOP_KIND], F.t_tau_v, T->K[FK_TOP_RHOCD], F.t_we_v, F.t_wb_v, v_0, ubar, ext, imt);
