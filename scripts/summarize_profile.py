@@ -142,6 +142,7 @@ if dom:
                    f"<= its own ms_per_step {traced['ms_per_step'] if traced else float('nan'):.3f}; the unprofiled run of the same lease: ms_per_step {b['ms_per_step']:.3f}, "
                    f"HIP-event launch time {b['roofline']['avg_launch_ms']*1e3:.1f} us (a step also holds initialize_rheology!, the halo fills and finalize_rheology!).\n")
         open(f"profiles/{name}.md", "w").write("".join(out))
-    json.dump(ctr, open("profiles/counters_latest.json", "w"), indent=1)
+    # (a fourth argument "keep": a profile of something other than the headline -- a tile -- leaves bench.py's static evidence alone)
+    json.dump(ctr, open("profiles/counters_latest.json" if not (len(sys.argv) > 4 and sys.argv[4] == "keep") else f"profiles/{name}_counters.json", "w"), indent=1)
 shutil.copy(ks, f"profiles/{name}_kernel_stats.csv")
 print("".join(out))
