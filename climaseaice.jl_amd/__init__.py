@@ -12,7 +12,7 @@ from .dynamics import (Auxiliaries, BetaPlane, PointwiseCoriolis, ElastoViscoPla
 from .fields import CenterField, CornerField, Field, XFaceField, YFaceField
 from .grids import (Bounded, Center, Face, Flat, FullyConnected, LatitudeLongitudeGrid, LeftConnected,
                     OrthogonalCurvilinearGrid, Periodic, LeftConnectedRightFolded, RightFolded, fold_north,
-                    RectilinearGrid, RightConnected, TileGrid)
+                    RectilinearGrid, RightConnected, TileGrid, TripolarGrid)
 from .model import (FieldBoundaryConditions, FluxBoundaryCondition, ImmersedBoundaryCondition, MeltingConstrainedFluxBalance, ValueBoundaryCondition, PrescribedTemperature, SeaIceModel, SlabThermodynamics, SnowSlabThermodynamics,
                     snow_slab_thermodynamics, UpwindBiased, WENO, set_, time_step, time_step_momentum, update_state,
                     prognostic_state, restore_prognostic_state)

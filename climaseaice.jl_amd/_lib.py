@@ -32,7 +32,8 @@ SYMBOLS = ["csi_version", "csi_context_create", "csi_context_destroy", "csi_last
            "csi_update_state", "csi_fill_halo_local", "csi_time_step_fe", "csi_time_step_rk3",
            "csi_slab_thermo_step", "csi_slab_params_set", "csi_layered_thermo_step", "csi_snow_params_set", "csi_tile_set", "csi_comm_unique_id", "csi_comm_init", "csi_comm_count", "csi_local_group_create", "csi_local_group_destroy", "csi_comm_init_local", "csi_comm_init_host", "csi_halo_exchange",
            "csi_plan_exchange", "csi_set_fusion", "csi_set_exchange_interval", "csi_set_halo_transport", "csi_halo_transport", "csi_set_peer_tier", "csi_peer_tier", "csi_plan_ranges", "csi_profile_substeps", "csi_last_path", "csi_last_subcycle_ms", "csi_launches_per_substep", "csi_last_launches", "csi_plan_pair", "csi_plan_peer_chunks", "csi_free_drift_set", "csi_coriolis_rows_set", "csi_velocity_bc_set",
-           "csi_immersed_flux_bc_set", "csi_coriolis_points_set", "csi_validate_all", "csi_debug_peer_abort", "csi_set_weno_weight_dtype", "csi_weno_weight_dtype", "csi_subcycle_stats_begin", "csi_subcycle_stats_end"]
+           "csi_immersed_flux_bc_set", "csi_coriolis_points_set", "csi_validate_all", "csi_debug_peer_abort", "csi_set_weno_weight_dtype", "csi_weno_weight_dtype", "csi_subcycle_stats_begin", "csi_subcycle_stats_end",
+           "csi_set_tile_skipping", "csi_tile_activity", "csi_set_row_constant", "csi_row_constant_rows"]
 
 
 class Metrics(C.Structure):
@@ -126,6 +127,8 @@ def load():
         "csi_set_halo_transport": [vp, i32], "csi_halo_transport": [vp, C.POINTER(i32)],
         "csi_set_peer_tier": [vp, i32], "csi_peer_tier": [vp, C.POINTER(i32)],
         "csi_set_fusion": [vp, i32], "csi_free_drift_set": [vp, i32],
+        "csi_set_tile_skipping": [vp, i32], "csi_tile_activity": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+        "csi_set_row_constant": [vp, i32, dbl], "csi_row_constant_rows": [vp, C.POINTER(i32)],
         "csi_coriolis_rows_set": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32],
         "csi_velocity_bc_set": [vp, i32, i32, i32, dbl],
         "csi_coriolis_points_set": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i64],

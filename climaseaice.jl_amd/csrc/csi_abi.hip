@@ -108,6 +108,12 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->peer.err_host) hipHostFree(c->peer.err_host);
     if (c->peer.xbuf) hipFree(c->peer.xbuf);
     if (c->dev_coef2) hipFree(c->dev_coef2);
+    if (c->dev_c2row) hipFree(c->dev_c2row);
+    if (c->dev_rcsum) hipFree(c->dev_rcsum);
+    if (c->act.flags) hipFree(c->act.flags);
+    if (c->act.list) hipFree(c->act.list);
+    if (c->act.host) hipHostFree(c->act.host);
+    for (auto& e : c->act.ev) if (e) hipEventDestroy(e);
     if (c->host_ring) hipHostFree(c->host_ring);
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
     if (c->dev_coef) hipFree(c->dev_coef);
@@ -189,6 +195,44 @@ int32_t csi_set_mode(csi_context* c, int32_t mode) {
     return CSI_OK;
 }
 
+int32_t csi_set_tile_skipping(csi_context* c, int32_t on) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    c->act.enabled = on ? 1 : 0;
+    c->act.scale = 1.0; c->act.last_live = -1; c->act.last_tiles = 0;
+    return CSI_OK;
+}
+
+int32_t csi_tile_activity(csi_context* c, int32_t* tiles, int32_t* live, int32_t* used) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    // the newest sample that has arrived (no synchronisation: call csi_sync first for the last sub-cycle's)
+    for (int q = 0; q < csi_context::Activity::kSamples; ++q)
+        if (c->act.used[q] && c->act.sample_seq[q] > c->act.seen_seq && hipEventQuery(c->act.ev[q]) == hipSuccess) {
+            c->act.seen_seq = c->act.sample_seq[q];
+            c->act.last_live = c->act.host[2 * q]; c->act.last_tiles = c->act.host[2 * q + 1];
+        }
+    if (tiles) *tiles = c->act.last_tiles;
+    if (live) *live = c->act.last_live;
+    if (used) *used = c->act.last_used;
+    return CSI_OK;
+}
+
+int32_t csi_set_row_constant(csi_context* c, int32_t on, double rtol) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    if (!(rtol >= 0.0) || rtol > 1e-6) return fail(c, CSI_ERR_INVALID_ARGUMENT, "row-constant tolerance: 0 <= rtol <= 1e-6");
+    c->rc_enabled = on ? 1 : 0;
+    c->rc_rtol = rtol;
+    c->rc_dirty = true;
+    return CSI_OK;
+}
+
+int32_t csi_row_constant_rows(csi_context* c, int32_t* rows) {
+    if (!c) return CSI_ERR_INVALID_ARGUMENT;
+    int32_t rc = ensure_row_constant(c);
+    if (rc) return rc;
+    if (rows) *rows = c->rc_rows;
+    return CSI_OK;
+}
+
 int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t Hy, int32_t topo_x, int32_t topo_y,
                      int32_t metric_kind, const csi_metrics* m) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
@@ -248,7 +292,12 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
         if (c->dev_coef2) { hipFree(c->dev_coef2); c->dev_coef2 = nullptr; }
         HIP_TRY(c, hipMalloc((void**)&c->dev_coef2, sizeof(double) * coef2.size()));
         HIP_TRY(c, hipMemcpy(c->dev_coef2, coef2.data(), sizeof(double) * coef2.size(), hipMemcpyHostToDevice));
+        c->coef2_host.swap(coef2);      // (row-constant marks: ensure_row_constant)
+    } else {
+        c->coef2_host.clear();
     }
+    c->fcor2_host.clear();
+    c->rc_dirty = true;
     // FAST-mode stencil coefficients
     if (c->dev_coef) { hipFree(c->dev_coef); c->dev_coef = nullptr; }
     if (c->dev_fcor) { hipFree(c->dev_fcor); c->dev_fcor = nullptr; }
@@ -359,6 +408,8 @@ int32_t csi_coriolis_points_set(csi_context* c, const double* f_u, const double*
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->dev_fcor2) { hipFree(c->dev_fcor2); c->dev_fcor2 = nullptr; }
+    c->fcor2_host.clear();
+    c->rc_dirty = true;
     if (!f_u) return CSI_OK;
     if (c->metric_kind != CSI_METRIC_FULL)
         return fail(c, CSI_ERR_UNSUPPORTED, "per-point Coriolis parameter: CSI_METRIC_FULL grids only (use csi_coriolis_rows_set on per-row grids)");
@@ -370,6 +421,7 @@ int32_t csi_coriolis_points_set(csi_context* c, const double* f_u, const double*
     HIP_TRY(c, hipMalloc((void**)&c->dev_fcor2, sizeof(double) * host.size()));
     HIP_TRY(c, hipMemcpy(c->dev_fcor2, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
     c->fcor2_ld = ni; c->fcor2_plane = ni * nj;
+    c->fcor2_host.swap(host);
     return CSI_OK;
 }
 

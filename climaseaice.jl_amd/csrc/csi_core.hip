@@ -369,8 +369,58 @@ bool pair_supported(const csi_context* c) {
     if (c->metric_kind == CSI_METRIC_PER_J && (g.ylo == SIDE_PERIODIC || g.yhi == SIDE_PERIODIC)) return false;   // (BetaPlane rows wrap: csi.h)
     return ok(g.xlo) && ok(g.xhi) && ok(g.ylo) && ok(g.yhi) && c->Hx >= 4 && c->Hy >= 4 && c->Nx >= 2 * c->Hx && c->Ny >= 2 * c->Hy;
 }
+// CSI_METRIC_FULL: which rows of the coefficient planes hold ONE value per row (a tripolar grid south of its cap, any grid handed over
+// as twelve arrays that is a latitude-longitude or rectilinear grid in disguise).  All Nx + 2Hx + 1 columns of all twelve planes --
+// and of the per-point Coriolis planes, where set -- are compared bit for bit (rc_rtol > 0: within that relative distance of the first
+// interior column, whose value then stands for the row: the caller's choice, changes results at that level).  The pair kernel reads
+// the marked rows' values from per-row vectors (evp_fused2.hip `rcd`).
+int32_t ensure_row_constant(csi_context* c) {
+    if (!c->rc_dirty) return CSI_OK;
+    c->rc_dirty = false;
+    c->rc_rows = 0;
+    c->coef.c2row = nullptr; c->coef.rcsum = nullptr; c->coef.c2row_n = 0;
+    if (c->metric_kind != CSI_METRIC_FULL || !c->rc_enabled || c->coef2_host.empty()) return CSI_OK;
+    const long ni = c->Nx + 2 * c->Hx + 1, nj = c->Ny + 2 * c->Hy + 1;
+    const bool hasf = !c->fcor2_host.empty();
+    const int nv = C2_COUNT + 2;
+    std::vector<double> rowv((size_t)nv * nj, 0.0);
+    std::vector<int> sum((size_t)nj + 1, 0);
+    const long ref = c->Hx;                               // parent column of i = 1
+    for (long t = 0; t < nj; ++t) {
+        bool same = true;
+        for (int k = 0; k < nv && same; ++k) {
+            const double* row;
+            if (k < C2_COUNT) row = c->coef2_host.data() + ((size_t)k * nj + t) * ni;
+            else if (hasf) row = c->fcor2_host.data() + ((size_t)(k - C2_COUNT) * nj + t) * ni;
+            else continue;
+            const double v = row[ref];
+            rowv[(size_t)k * nj + t] = v;
+            if (c->rc_rtol > 0.0) {
+                const double tol = c->rc_rtol * std::fabs(v);
+                for (long a = 0; a < ni && same; ++a) same = std::fabs(row[a] - v) <= tol;
+            } else {
+                for (long a = 0; a < ni && same; ++a) same = std::memcmp(&row[a], &v, sizeof(double)) == 0;
+            }
+        }
+        sum[t + 1] = sum[t] + (same ? 1 : 0);
+    }
+    c->rc_rows = sum[nj];
+    if (c->rc_rows == 0) return CSI_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dev_c2row) { hipFree(c->dev_c2row); c->dev_c2row = nullptr; }
+    if (c->dev_rcsum) { hipFree(c->dev_rcsum); c->dev_rcsum = nullptr; }
+    HIP_TRY(c, hipMalloc((void**)&c->dev_c2row, sizeof(double) * rowv.size()));
+    HIP_TRY(c, hipMalloc((void**)&c->dev_rcsum, sizeof(int) * sum.size()));
+    HIP_TRY(c, hipMemcpy(c->dev_c2row, rowv.data(), sizeof(double) * rowv.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dev_rcsum, sum.data(), sizeof(int) * sum.size(), hipMemcpyHostToDevice));
+    c->coef.c2row = c->dev_c2row; c->coef.c2row_n = nj; c->coef.rcsum = c->dev_rcsum;
+    return CSI_OK;
+}
+
 constexpr long kWriteThroughCells = 1152L * 1024L;      // (scripts/wt_sweep.py, profiles/r04_wt_sweep.txt: 512^2 +4 %, 1024 x 512 +3.4 %, 2048 x 256 +3.7 %, 2048 x 512 +1.8 %, 1024^2 +0.6 %; 1536^2 -1 %, 2048^2 -9 %)
-FusedGeom pair_geom(const csi_context* c, const Range& dec) {
+// tile_scale > 1: so many times the tiles of the one-round geometry (run_fused: launches of the LIVE tiles only -- the fraction of
+// live tiles times the number of tiles is what has to fit one round)
+FusedGeom pair_geom(const csi_context* c, const Range& dec, double tile_scale) {
     FusedGeom G;
     G.rs = dec;
     // (56-column strip) x (rows) tiles, one workgroup of two waves (producer: first sub-step, consumer: second) per tile.
@@ -401,6 +451,7 @@ FusedGeom pair_geom(const csi_context* c, const Range& dec) {
     // band's first kernel in (round 3: 123 + 31 us per pair of sub-steps at 2048^2).  Measured at 2048^2, round 4: fold on uniform
     // metrics 1536 tiles 53.1, 1280 52.6, 1024 58.7, 896 56.1 G; tripolar-like (per-point metrics) 1024 tiles 20.4, 896 21.9, 768 20.5
     if (c->geom_band) target = c->metric_kind == CSI_METRIC_FULL ? 896 : 1024;
+    if (tile_scale > 1.0) target = (int)std::lround(target * tile_scale);
     bool forced = false;
     if (c->tune.pair_tiles >= 0) { target = c->tune.pair_tiles; forced = true; }   // tuning aid (CSI_PAIR_TILES)
     int max_chunks = target / G.nstrips;

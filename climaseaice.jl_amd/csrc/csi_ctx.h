@@ -190,6 +190,32 @@ struct csi_context {
     int last_fused = 0;
     double ibc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // csi_immersed_flux_bc_set: [u | v][west, east, south, north]
     int exch_k = 0;       // sub-steps per halo exchange (0 = auto: the largest k with 2k <= halo, at most 4)
+    // Tile activity (csi_activity.hip, run_fused): the live-tile list of the current sub-cycle and, read back asynchronously, how many
+    // tiles were live in earlier ones -- the launch geometry of the NEXT sub-cycles is refined so that the live tiles fill one round
+    // (correctness never depends on that estimate: the list is made afresh, on the device, before every sub-cycle's first launch)
+    struct Activity {
+        static constexpr int kSamples = 4;
+        int enabled = 1;                     // csi_set_tile_skipping
+        int* flags = nullptr;                // device: one int per tile
+        int* list = nullptr;                 // device: {live, tiles, the live tiles' numbers}
+        int* host = nullptr;                 // pinned: kSamples x {live, tiles}
+        hipEvent_t ev[kSamples] = {nullptr, nullptr, nullptr, nullptr};
+        bool used[kSamples] = {false, false, false, false};
+        double sample_scale[kSamples] = {1, 1, 1, 1};
+        unsigned long sample_seq[kSamples] = {0, 0, 0, 0};
+        unsigned long seq = 0, seen_seq = 0;
+        double scale = 1.0;                  // tiles of a live launch relative to the one-round geometry (pair_geom's tile_scale)
+        int last_live = -1, last_tiles = 0;  // the newest sample that has arrived
+        int last_used = 0;                   // the last sub-cycle ran live launches
+    } act;
+    // CSI_METRIC_FULL: rows whose twelve coefficient planes (and per-point Coriolis planes) hold one value per row (ensure_row_constant)
+    std::vector<double> coef2_host, fcor2_host;      // host copies of the planes the marks are made from
+    double* dev_c2row = nullptr;         // (C2_COUNT + 2) vectors of nj doubles
+    int* dev_rcsum = nullptr;            // nj + 1 prefix sums
+    bool rc_dirty = true;
+    int rc_enabled = 1;                  // csi_set_row_constant(ctx, on, rtol)
+    double rc_rtol = 0.0;                // 0: bitwise-equal columns only (results unchanged); > 0: columns within this relative distance of column 1 count as equal -- CHANGES results at that level
+    int rc_rows = 0;                     // rows marked
     int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
     int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
@@ -312,7 +338,8 @@ bool has_walls(const csi_context* c);
 bool offsets_fit_32bit(int Nx, int Ny, int Hx, int Hy, int64_t max_ld);
 int64_t max_bound_ld(const csi_context* c);
 bool pair_supported(const csi_context* c);
-FusedGeom pair_geom(const csi_context* c, const Range& dec);
+FusedGeom pair_geom(const csi_context* c, const Range& dec, double tile_scale = 1.0);
+int32_t ensure_row_constant(csi_context* c);
 PeerSets peer_wait_counts(const csi_context* c, const FusedGeom& G);
 void peer_local_arrays(const csi_context* c, const void* out[csi_context::Peer::NARR]);
 void peer_release(csi_context* c);

@@ -79,6 +79,11 @@ struct FastCoef {
     long c2_plane;
     int c2_ld;
     int full;
+    // ... rows whose plane values are the same in every column (csi_core.hip ensure_row_constant): C2_COUNT + 2 vectors of c2row_n
+    // doubles (the planes, then the per-point Coriolis planes at u / v points), entry [parent row]; rcsum: prefix sums of the marks
+    const double* c2row;
+    long c2row_n;
+    const int* rcsum;
     double rdt;             // 1 / dt
     double Dmin2, rDmin, amin2, amax2, ramin, ramax;   // Delta_min^2, 1/Delta_min, alpha-^2, alpha+^2, 1/alpha-, 1/alpha+
 };

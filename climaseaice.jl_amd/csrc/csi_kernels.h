@@ -53,6 +53,12 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
              FP_SLOT_IN = FP_IMG0 + 72,     // peer flags: per direction, this rank's slots the neighbour there writes ...
              FP_SLOT_OUT = FP_SLOT_IN + 8,  // ... and that neighbour's slots this rank writes (device addresses)
              FP_PERR = FP_SLOT_OUT + 8,     // error word (a wait timed out)
+             FP_ACT_LIVE,                   // tile activity (csi_activity.hip): device int array {live tiles, all tiles, list of the live tiles' numbers ...};
+                                            // 0: every tile runs.  Read by launches whose write_diag has bit 2 set (run_fused: not the first two, not the last)
+             FP_ROWPAD_ = FP_ACT_LIVE + (FP_C2_0 - FP_F2U),      // (room for FP_F2ROW_U / _V below FP_C2ROW_0)
+             FP_C2ROW_0,                    // CSI_METRIC_FULL: the C2_COUNT planes as per-ROW vectors (ptr[parent row]), valid for the rows FP_RCSUM marks constant
+             FP_F2ROW_U = FP_F2U + (FP_C2ROW_0 - FP_C2_0), FP_F2ROW_V,      // ... and the per-point Coriolis planes likewise (the SAME distance from FP_F2U / _V as the vectors from the planes: Stage::rcd_)
+             FP_RCSUM = FP_C2ROW_0 + C2_COUNT,      // int prefix sums over parent rows: rcsum[t] = rows among parent rows [0, t) whose plane values are the same in every column (0: none marked)
              FP_COUNT };   // (FP_FT_* .. FP_FD_*: forcing arrays; FP_MASK: the uint8 mask; FP_C2_0 ..: the C2_COUNT per-point coefficient planes -- parent addresses)
 enum : int { FI_NX = 0, FI_NY, FI_HX, FI_HY, FI_XLO, FI_XHI, FI_YLO, FI_YHI, FI_LD_C, FI_LD_F,
              FI_RS, FI_R1 = FI_RS + 4, FI_R1C = FI_R1 + 4, FI_R2 = FI_R1C + 4, FI_IMU = FI_R2 + 4, FI_IMV = FI_IMU + 4,
@@ -94,6 +100,20 @@ void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec
                            const ImageSpec& ims12, FusedTable* host_table, int elo = 0, int ehi = 0, int write_through = 0);
 // seq: launch number of the peer-flag protocol (0 on grids without peer-connected sides)
 // extra: model.forcing arrays / immersed flux boundary conditions (the EXTRA instantiations; implies force)
+// Tile activity (csi_activity.hip).  A tile of the two-sub-steps launch is QUIESCENT when the ice mass h rho aice is exactly zero in every cell
+// of its owned box and one cell around it and no owned stress holds a negative zero: there sigma += (m > 0 ? ... : 0) and the velocity
+// select's zero branch (elasto_visco_plastic_rheology.jl:343-347, split_explicit_momentum_equations.jl:217-228) make both sub-steps
+// an exact fixed point of u, v, sigma -- every later launch would store what the launch two before it stored.  `act` receives
+// {number of live tiles, number of tiles, the live tiles' numbers in ascending order}.
+struct ActivityArgs {
+    FRef h, a, s11, s22, s12;          // (0,0)-offset references; sigma: the CURRENT state
+    double rho;
+    Range dec;                         // the range the launch's tiles decompose (FI_DEC)
+    int nstrips, nchunks, rows, elo, ehi;
+    Range pc, pf;                      // index bounds of the Center-Center / Face-Face parents
+};
+constexpr int kMaxActTiles = 16384;
+void launch_tile_activity(const ActivityArgs& A, int* flags, int* act, hipStream_t s);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, int extra,
                        int common_forcing, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s);
 // stress divergence of the immersed FluxBoundaryConditions at every u / v point whose stencil stays inside the parents (evp_fast.hip)

@@ -119,6 +119,36 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     if (k > KMAX) return fail(c, CSI_ERR_UNSUPPORTED, "exchange interval too large for the fused path");
     if (!c->dev_tables) HIP_TRY(c, hipMalloc((void**)&c->dev_tables, (NSINGLE + NPAIR) * sizeof(FusedTable)));
     FusedGeom G[KMAX], GP[KMAX / 2];
+    // Tile activity (csi_activity.hip): untiled grids (a fold band beside them or not) advanced by pair launches.  The first two pair
+    // launches and the last launch of the sub-cycle run every tile on the one-round geometry; the launches in between run the LIVE
+    // tiles of a finer geometry GA -- so many more tiles as the newest sample of the live fraction says fit one round.
+    FusedGeom GA{};
+    bool act_on = c->act.enabled != 0 && pairs && !tiled && !peer && substeps >= 8 && c->tune.peer_kernel <= 0;
+    if (act_on) {
+        csi_context::Activity& a = c->act;
+        if (!a.list) {
+            HIP_TRY(c, hipMalloc((void**)&a.flags, sizeof(int) * kMaxActTiles));
+            HIP_TRY(c, hipMalloc((void**)&a.list, sizeof(int) * (kMaxActTiles + 2)));
+            HIP_TRY(c, hipHostMalloc((void**)&a.host, sizeof(int) * 2 * csi_context::Activity::kSamples, hipHostMallocDefault));
+            for (auto& e : a.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        // the newest sample that has arrived: live tiles / tiles on the geometry of its sub-cycle
+        double s_scale = 1.0;
+        bool fresh = false;
+        for (int q = 0; q < csi_context::Activity::kSamples; ++q)
+            if (a.used[q] && a.sample_seq[q] > a.seen_seq && hipEventQuery(a.ev[q]) == hipSuccess) {
+                a.seen_seq = a.sample_seq[q];
+                a.last_live = a.host[2 * q]; a.last_tiles = a.host[2 * q + 1];
+                s_scale = a.sample_scale[q];
+                fresh = true;
+            }
+        if (fresh && a.last_tiles > 0) {
+            const double f = (double)std::max(a.last_live, 1) / (double)a.last_tiles;
+            // keep the geometry while the live tiles fill 90 .. 100 % of a round; otherwise aim at 97 %
+            if (f >= 0.97) a.scale = 1.0;
+            else if (s_scale * f > 1.0 || s_scale * f < 0.90 || a.scale != s_scale) a.scale = std::min(4.0, 0.97 / f);
+        }
+    }
     // configurations only the two-sub-steps kernel takes (masks, array forcing, per-point metrics): a single sub-step (the odd
     // trailing one) runs through that kernel too, its consumer wave storing stage A's results (evp_fused2.hip, `single`)
     const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL || peer || band);      // (peer: the flag protocol lives in this kernel only; band: its cut tile)
@@ -166,6 +196,10 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                 const SideV va = pair_side_v(c, W - 4 * mp, 4), vb = pair_side_v(c, W - 4 * mp - 2, 2);
                 const Range dec = v_stress_range(c, vb), ra = v_stress_range(c, va);
                 GP[mp] = pair_geom(c, dec);
+                if (act_on && mp == 0) {
+                    GA = pair_geom(c, dec, c->act.scale);
+                    if (GA.nstrips * GA.nchunks > kMaxActTiles || GA.elo != GP[0].elo || GA.ehi != GP[0].ehi || GA.wt != GP[0].wt) act_on = false;
+                }
                 for (int cur = 0; cur < 2; ++cur)
                     for (int auf = 0; auf < 2; ++auf) {
                         const bool buf = auf == 0;                  // the second sub-step has the other order
@@ -180,6 +214,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         if (force) { fused_fill_forcing(P, ubar_v, vbar_u, t); if (wind) fused_fill_forcing_top(P, tbar_v, tbar_u, t); }
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, GP[mp], cur == 0, t))) return rc;
+                        if (act_on) t->P[FP_ACT_LIVE] = (unsigned long)c->act.list;
                     }
             }
         }
@@ -190,8 +225,33 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     unsigned long long peer_dld_bit = 0ull;      // neighbours with other row strides: the DLD instantiation (bit 63 of the launch number)
     if (peer)
         for (int d = 0; d < 8; ++d) if (c->peer.dld[d][0] | c->peer.dld[d][1]) peer_dld_bit = 1ull << 63;
+    c->act.last_used = 0;
+    if (act_on) {
+        // which tiles of GA are live: h, aice (constant over the sub-cycle) and the sign bits of the current stresses
+        ActivityArgs A{};
+        A.h = ref_of(c, CSI_F_H); A.a = ref_of(c, CSI_F_A);
+        A.s11 = orig[2]; A.s22 = orig[3]; A.s12 = orig[4];
+        A.rho = P.rho;
+        A.dec = GA.rs;
+        A.nstrips = GA.nstrips; A.nchunks = GA.nchunks; A.rows = GA.rows; A.elo = GA.elo; A.ehi = GA.ehi;
+        // (band: the arrays are those of the whole grid, c->Ny is the cut one -- the parents' own extents)
+        const Bound &bc = c->f[CSI_F_H], &bf = c->f[CSI_F_S12];
+        A.pc = Range{1 - c->Hx, bc.ni - c->Hx, 1 - c->Hy, bc.nj - c->Hy};
+        A.pf = Range{1 - c->Hx, bf.ni - c->Hx, 1 - c->Hy, bf.nj - c->Hy};
+        launch_tile_activity(A, c->act.flags, c->act.list, c->stream);
+        csi_context::Activity& a = c->act;
+        const int q = (int)(a.seq % csi_context::Activity::kSamples);
+        if (!a.used[q] || hipEventQuery(a.ev[q]) == hipSuccess) {      // (a slot still on its way keeps its sample: this one is not read back)
+            HIP_TRY(c, hipMemcpyAsync(a.host + 2 * q, a.list, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipEventRecord(a.ev[q], c->stream));
+            a.used[q] = true; a.sample_scale[q] = a.scale; a.sample_seq[q] = ++a.seq;
+        } else {
+            ++a.seq;
+        }
+        a.last_used = 1;
+    }
     int cur = 0;   // 0: the caller's arrays hold the current state
-    int m = 0, nex = 0, nlaunch = 0;
+    int m = 0, nex = 0, nlaunch = 0, npair = 0;
     const int end = first + substeps;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     if ((rc = stats_mark(c))) return rc;
@@ -208,10 +268,16 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                 if ((rc = band_substeps(c, *band, fc, cur, s, 2, s + 2 == end))) return rc;
                 nlaunch += 8;
             }
+            // (write_diag bit 2: the live tiles of GA only -- not in the first two pair launches, which bring BOTH buffers to the
+            //  quiescent tiles' fixed point, halo images included, nor in the last launch, which stores every tile's diagnostics)
+            const bool live_only = act_on && npair >= 2 && s + 2 != end;
+            const FusedGeom& GL = live_only ? GA : GP[mp];
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
-                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, GP[mp].nstrips, GP[mp].nchunks, GP[mp].rows, s + 2 == end,
+                              has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, GL.nstrips, GL.nchunks, GL.rows,
+                              (s + 2 == end ? 1 : 0) | (live_only ? 4 : 0),
                               peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
+            ++npair;
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 2; s += 2;
         } else if (single_by_pair) {
@@ -322,6 +388,7 @@ int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int subste
 int32_t do_subcycle(csi_context* c, double dt, int substeps, int first) {
     int32_t rc;
     if ((rc = peer_check_entry(c))) return rc;
+    if ((rc = ensure_row_constant(c))) return rc;
     {                                                // :170-171, both fields in one batch of two launches
         HaloBatch B{};
         B.f[0] = ref_of(c, CSI_F_U); B.im[0] = image_spec(c, CSI_F_U);

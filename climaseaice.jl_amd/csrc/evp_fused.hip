@@ -445,6 +445,13 @@ void fused_fill_table(const EvpDev& P, const FastCoef& c, const FRef* in, const 
             I[FI_FKIND] = 1;
             Q[FP_FROW_U] = (unsigned long)P.fcor_u; Q[FP_FROW_V] = (unsigned long)P.fcor_v;
         }
+        // rows with one value per row: their vectors (entry [parent row]) and the prefix sums of the marks (csi_core.hip ensure_row_constant)
+        if (c.c2row && c.rcsum) {
+            for (int k = 0; k < C2_COUNT; ++k) Q[FP_C2ROW_0 + k] = (unsigned long)(c.c2row + (long)k * c.c2row_n);
+            Q[FP_F2ROW_U] = (unsigned long)(c.c2row + (long)C2_COUNT * c.c2row_n);
+            Q[FP_F2ROW_V] = (unsigned long)(c.c2row + (long)(C2_COUNT + 1) * c.c2row_n);
+            Q[FP_RCSUM] = (unsigned long)c.rcsum;
+        }
     }
 }
 

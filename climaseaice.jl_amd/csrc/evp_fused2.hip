@@ -154,8 +154,18 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     constexpr int RING_FIELDS = FRING ? 10 + RF_FORCING : (PRE ? 13 : 10);      // (FULL: ten fields; its plane values have a ring of their own, ringp)
 #define peer_abort (*peer_abort_p)
     const int b = (int)blockIdx.x;
-    const int w = (b & 7) * blocks_per_xcd + (b >> 3);      // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
-    if (w >= nstrips * nchunks) return;                      // (uniform over the workgroup: both waves leave)
+    int w = (b & 7) * blocks_per_xcd + (b >> 3);            // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
+    if (!PEER && (write_diag & 4)) {
+        // Tile activity (csi_activity.hip; write_diag bit 2: not one of the first two launches of a sub-cycle, not its last): only the LIVE
+        // tiles run -- a quiescent tile (no ice mass in or around it) would store exactly what it stored two launches ago.  The live
+        // tiles' numbers come from a list, dealt over the XCDs like the tiles themselves (each XCD a band of consecutive tiles); the
+        // workgroups beyond the list leave at once.
+        typedef const __attribute__((address_space(4))) int* iptr_t;
+        iptr_t act = (iptr_t)((tptr_t)table)->P[FP_ACT_LIVE];
+        const int live = act[0], per = (live + 7) >> 3, k = b >> 3, p = (b & 7) * per + k;
+        if ((k >= per) | (p >= live)) return;
+        w = act[2 + p];
+    } else if (w >= nstrips * nchunks) return;               // (uniform over the workgroup: both waves leave)
     // Roles: wave 0 produces, wave 1 consumes.  (Measured placement of the 12 waves of a CU's six workgroups, in dispatch
     // order, on its SIMDs a..d: a b | b c | c d | d a | a b | c d -- every SIMD gets producers and consumers, the two waves
     // of a workgroup never share a SIMD; swapping the roles in some workgroups changed nothing measurable.)
@@ -318,9 +328,26 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     auto offc = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * sc; };
     auto offf = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * sf; };
     auto offm = [&](int j) __attribute__((always_inline)) { return lm + (unsigned)(j - row0) * sm; };
-    const unsigned c2s = FULL ? (unsigned)T->I[FI_C2_LD] * 8u : 0u;         // row stride of the per-point coefficient planes
-    auto off2 = [&](int j) __attribute__((always_inline)) { return loff + (unsigned)(j - row0) * c2s; };
     const int NyW = T->I[FI_NY], HyW = T->I[FI_HY];
+    // FULL, round 6: ROW-CONSTANT tiles.  A real tripolar grid is a latitude-longitude grid south of its bipolar cap: there the
+    // twelve planes (and a per-point Coriolis parameter) have the same value in every column of a row.  csi_abi.hip marks such
+    // rows (bitwise comparison of all columns, FP_RCSUM: prefix sums over parent rows) and keeps the planes' values of those rows as
+    // per-row vectors (FP_C2ROW_0 ...).  A tile whose rows -- window warm-up and look-ahead included -- are all marked reads every
+    // plane value from the vectors: same instructions, same operands, bit for bit the same results, but the twelve loads of a
+    // stage-row all hit one cached line instead of streaming 96 B per cell from HBM (the per-point-metric kernel runs at its byte
+    // roof: 216 B per cell and launch, of which these are 96).
+    int rcd = 0;
+    if constexpr (FULL) {
+        typedef const __attribute__((address_space(4))) int* iptr_t;
+        iptr_t rcs = (iptr_t)T->P[FP_RCSUM];
+        if (rcs) {
+            const int t0 = max(rstart - 4, row0) - row0, t1 = min(rend + 2, NyW + HyW + 1) - row0;
+            if (rcs[t1 + 1] - rcs[t0] == t1 - t0 + 1) rcd = FP_C2ROW_0 - FP_C2_0;
+        }
+    }
+    const unsigned c2s = FULL ? (rcd ? 8u : (unsigned)T->I[FI_C2_LD] * 8u) : 0u;         // row stride of the per-point coefficient planes / of their per-row vectors
+    const unsigned loff2 = (FULL && rcd) ? 0u : loff;
+    auto off2 = [&](int j) __attribute__((always_inline)) { return loff2 + (unsigned)(j - row0) * c2s; };
     const int NyLoW = PEER ? T->I[FI_NYLO] : NyW;       // rows from a low row to its image: the height of the tile BELOW (a fold tile's own is cut)
     // u, Center in y, is also mirrored across y walls: row j in [1, H] -> 1 - j, row in (N - H, N] -> 2N + 1 - j
     const bool wrap_lo_b = T->I[FI_YLO] == SIDE_PERIODIC, wrap_hi_b = T->I[FI_YHI] == SIDE_PERIODIC;      // (per side, as in x)
@@ -621,9 +648,9 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
             A.hoist_uniform(T);
             if constexpr (FULL) {
                 const unsigned om2 = off2(jm), o02 = off2(rstart);
-                full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m);
-                A.e12_0 = 8.0 * full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0);      // (the stage carries 8 e12: evp_pair_stage.h)
-                A.hoist_planes(T);
+                full_cell(T, om2, c2s, A.u_m, A.v_m, A.v_0, e11_m, e22_m, rcd);
+                A.e12_0 = 8.0 * full_corner(T, o02, c2s, A.u_0, A.u_m, A.v_0, rcd);      // (the stage carries 8 e12: evp_pair_stage.h)
+                A.hoist_planes(T, rcd);
                 A.full_init(T, o02, om2, c2s);
             } else {
             fm::strain_cell<UNI>(pcoef<UNI>(T, FC_A, jm), pcoef<UNI>(T, FC_BN, jm), pcoef<UNI>(T, FC_BS, jm), pcoef<UNI>(T, FC_CN, jm),
@@ -908,7 +935,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     B.zc = 0; B.zf = 0; B.Dc = 0; B.rDc = 0; B.Pf_0 = 0; B.rmc_0 = 0; B.rmf_0 = 0;
     B.hoist_uniform(T);
     if constexpr (FULL) {
-        B.hoist_planes(T);
+        B.hoist_planes(T, rcd);
         B.full_init(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)), c2s);
         B.full_prefetch_vel(T, off2(max(rstart - 2, row0)), off2(max(rstart - 3, row0)));
     }

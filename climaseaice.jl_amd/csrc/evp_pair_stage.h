@@ -46,18 +46,20 @@ __device__ __forceinline__ unsigned left_bits(unsigned x) { return (unsigned)__b
 // CSI_METRIC_FULL: strain rates of cell (i, row of `o`) from u(i, row), v(i, row), v(i, row + 1) / of corner (i, row of `o`) from
 // u(i, row), u(i, row - 1), v(i, row): the operations of evp_fast.hip's strain_cell2 / strain_corner2 (the neighbouring
 // column's products come over the lane shift); s2: row pitch of the planes in bytes
-__device__ __forceinline__ void full_cell(tptr_t T, unsigned o, unsigned s2, double u_0, double v_0, double v_p, double& e11, double& e22) {
-    const double dyu = c2at(T, C2_DYU, o), dxv_s = c2at(T, C2_DXV, o), dxv_n = c2at(T, C2_DXV, o + s2);
+// rcd: 0, or the distance from the planes' table entries to their per-row vectors' (FP_C2ROW_0 - FP_C2_0: a tile whose rows are all
+// marked row-constant reads the SAME values from vectors that stay in the caches; evp_fused2.hip `rowc`)
+__device__ __forceinline__ void full_cell(tptr_t T, unsigned o, unsigned s2, double u_0, double v_0, double v_p, double& e11, double& e22, int rcd = 0) {
+    const double dyu = c2at(T, C2_DYU + rcd, o), dxv_s = c2at(T, C2_DXV + rcd, o), dxv_n = c2at(T, C2_DXV + rcd, o + s2);
     const double Uy_w = dyu * u_0, Ur_w = fm::rcp(dyu) * u_0;
     const double Vx_s = dxv_s * v_0, Vr_s = fm::rcp(dxv_s) * v_0;
     const double Vx_n = dxv_n * v_p, Vr_n = fm::rcp(dxv_n) * v_p;
     fm::full_strain_cell(from_right(Uy_w), Uy_w, Vx_n, Vx_s, from_right(Ur_w), Ur_w, Vr_n, Vr_s,
-                         c2at(T, C2_DYC2, o), c2at(T, C2_DXC2, o), c2at(T, C2_RAZC, o), e11, e22);
+                         c2at(T, C2_DYC2 + rcd, o), c2at(T, C2_DXC2 + rcd, o), c2at(T, C2_RAZC + rcd, o), e11, e22);
 }
-__device__ __forceinline__ double full_corner(tptr_t T, unsigned o, unsigned s2, double u_n, double u_s, double v_e) {
-    const double Ux_n = c2at(T, C2_RDXU, o) * u_n, Ux_s = c2at(T, C2_RDXU, o - s2) * u_s;
-    const double Vy_e = c2at(T, C2_RDYV, o) * v_e;
-    return fm::full_strain_corner(Ux_n, Ux_s, Vy_e, from_left(Vy_e), c2at(T, C2_DXF2, o), c2at(T, C2_DYF2, o), c2at(T, C2_RAZF, o));
+__device__ __forceinline__ double full_corner(tptr_t T, unsigned o, unsigned s2, double u_n, double u_s, double v_e, int rcd = 0) {
+    const double Ux_n = c2at(T, C2_RDXU + rcd, o) * u_n, Ux_s = c2at(T, C2_RDXU + rcd, o - s2) * u_s;
+    const double Vy_e = c2at(T, C2_RDYV + rcd, o) * v_e;
+    return fm::full_strain_corner(Ux_n, Ux_s, Vy_e, from_left(Vy_e), c2at(T, C2_DXF2 + rcd, o), c2at(T, C2_DYF2 + rcd, o), c2at(T, C2_RAZF + rcd, o));
 }
 
 template <bool UNI, bool UFIRST, bool MASK, bool TIGHT = false, int CF = 0, bool FULL = false, bool HOLDK = true>
@@ -81,15 +83,22 @@ struct Stage {
     // FULL: the twelve plane base addresses, read from the table ONCE (the row loop's reload fence on the table pointer does not reach
     // them): two wide scalar loads and their waits per stage-row less
     unsigned long c2p[12];
-    __device__ __forceinline__ void hoist_planes(tptr_t T) {
+    // rcd: 0 (the planes), or FP_C2ROW_0 - FP_C2_0 for a tile whose rows are all row-constant (their per-row vectors; the per-point
+    // Coriolis planes' vectors sit the same distance from FP_F2U / FP_F2V: csi_kernels.h)
+    int rcd_ = 0;
+    __device__ __forceinline__ void hoist_planes(tptr_t T, int rcd = 0) {
+        rcd_ = rcd;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) c2p[k] = T->P[FP_C2_0 + k];
+        for (int k = 0; k < 12; ++k) c2p[k] = T->P[FP_C2_0 + k + rcd];
     }
     __device__ __forceinline__ double c2m(tptr_t, int which, unsigned off) const { return ldg_keep(c2p[which], off); }
 #else
-    __device__ __forceinline__ void hoist_planes(tptr_t) {}
-    __device__ __forceinline__ double c2m(tptr_t T, int which, unsigned off) const { return c2at(T, which, off); }
+    int rcd_ = 0;
+    __device__ __forceinline__ void hoist_planes(tptr_t, int rcd = 0) { rcd_ = rcd; }
+    __device__ __forceinline__ double c2m(tptr_t T, int which, unsigned off) const { return c2at(T, which + rcd_, off); }
 #endif
+    __device__ __forceinline__ unsigned long f2u(tptr_t T) const { return T->P[FP_F2U + rcd_]; }
+    __device__ __forceinline__ unsigned long f2v(tptr_t T) const { return T->P[FP_F2V + rcd_]; }
     double RAZC_0, RAZU_m, RAZV_x, FU_m, FV_x;       // this step's 1 / Az at the cell (row r), the u point (row r - 1), the v point (row r - 1 / r); f likewise
 
     // Uniform coefficients, round 5: the velocity phase's seven coefficients and the bottom drag constant live in VECTOR registers.
@@ -140,11 +149,11 @@ struct Stage {
     __device__ __forceinline__ void full_prefetch_vel(tptr_t T, unsigned on, unsigned om) {
         N_RAZU = c2m(T, C2_RAZU, om); N_RAZV = c2m(T, C2_RAZV, UFIRST ? om : on);
         N_FU = 0.0; N_FV = 0.0;
-        if (T->I[FI_FKIND] == 2) { N_FU = ldg(T->P[FP_F2U], om); N_FV = ldg(T->P[FP_F2V], UFIRST ? om : on); }
+        if (T->I[FI_FKIND] == 2) { N_FU = ldg(f2u(T), om); N_FV = ldg(f2v(T), UFIRST ? om : on); }
     }
     __device__ __forceinline__ void full_prefetch_f(tptr_t T, unsigned on, unsigned om) {
         N_FU = 0.0; N_FV = 0.0;
-        if (T->I[FI_FKIND] == 2) { N_FU = ldg(T->P[FP_F2U], om); N_FV = ldg(T->P[FP_F2V], UFIRST ? om : on); }
+        if (T->I[FI_FKIND] == 2) { N_FU = ldg(f2u(T), om); N_FV = ldg(f2v(T), UFIRST ? om : on); }
     }
     __device__ __forceinline__ void full_prefetch(tptr_t T, unsigned on, unsigned s2) {
         N_DXV = c2m(T, C2_DXV, on + s2); N_RDYV = c2m(T, C2_RDYV, on + s2); N_RDXU = c2m(T, C2_RDXU, on + s2);
@@ -213,7 +222,7 @@ struct Stage {
                 RAZU_m = N_RAZU; RAZV_x = N_RAZV; FU_m = N_FU; FV_x = N_FV;
             } else if (do_vel) {
                 RAZU_m = c2m(T, C2_RAZU, o2m); RAZV_x = c2m(T, C2_RAZV, UFIRST ? o2m : o2);
-                if (T->I[FI_FKIND] == 2) { FU_m = ldg(T->P[FP_F2U], o2m); FV_x = ldg(T->P[FP_F2V], UFIRST ? o2m : o2); }
+                if (T->I[FI_FKIND] == 2) { FU_m = ldg(f2u(T), o2m); FV_x = ldg(f2v(T), UFIRST ? o2m : o2); }
             }
             const double Uy_w = DYU_0 * u_0, Ur_w = RDYU_0 * u_0;
             fm::full_strain_cell(from_right(Uy_w), Uy_w, DXV_p * v_p, DXV_0 * v_0, from_right(Ur_w), Ur_w, RDXV_p * v_p, RDXV_0 * v_0,

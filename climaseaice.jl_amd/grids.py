@@ -278,6 +278,164 @@ class OrthogonalCurvilinearGrid(_Grid2D):
         return dict(kind="full", **self._m)
 
 
+def _haversine(lam1, phi1, lam2, phi2, radius):
+    """Great-circle distance (degrees in, metres out), the numerically stable half-angle form."""
+    p1, p2 = np.deg2rad(phi1), np.deg2rad(phi2)
+    dl, dp = np.deg2rad(lam2 - lam1), p2 - p1
+    a = np.sin(0.5 * dp) ** 2 + np.cos(p1) * np.cos(p2) * np.sin(0.5 * dl) ** 2
+    return 2.0 * radius * np.arcsin(np.sqrt(np.clip(a, 0.0, 1.0)))
+
+
+class TripolarGrid(OrthogonalCurvilinearGrid):
+    """TripolarGrid(size=(Nx, Ny), southernmost_latitude, north_poles_latitude, first_pole_longitude, halo): a global-like grid
+    with the STRUCTURE of the reference's flagship grid (test/distributed_tests_utils.jl:170-183, 226-259 build
+    `TripolarGrid(size = (60, 120, 1), southernmost_latitude = 60)` and immerse discs around its poles):
+
+      * rows south of `north_poles_latitude`: a regular latitude-longitude grid -- every metric is a function of the row;
+      * north of it: a bipolar cap.  In the stereographic plane of the north pole the cap is the disc |z| <= r0 =
+        tan((90 - phi0) / 2); s = log((1 + z / r0) / (1 - z / r0)) maps it conformally onto the strip |Im s| <= pi / 2, the two
+        poles z = +-r0 (on the cap's boundary circle, at first_pole_longitude and 180 degrees from it) to +-infinity.  Columns are
+        the lines Re s = log cot(theta / 2) -- they leave the boundary circle where the meridian of longitude theta arrives --,
+        rows the lines Im s = +-2 atan(r / r0), r = tan((90 - psi) / 2), psi uniform from phi0 to 90: along the meridian
+        perpendicular to the pole axis psi IS the latitude (Murray 1996's bipolar projection, the form MOM's tripolar grids use).
+        The row psi = 90 is the segment between the two poles: the north fold, through the centres of row Ny, column i onto
+        column Nx - i + 1 (`RightFolded`); rows beyond it are the analytic continuation = the fold images.
+
+    Both families of lines are level sets of a conformal map: the net is orthogonal.  Metrics are great-circle distances between
+    neighbouring nodes of the staggered net (Az = dx dy), as upstream computes a TripolarGrid's -- except that a row of the
+    latitude-longitude part takes the distance of its first interior column in every column, so that it is constant bit for bit
+    (per-point evaluation leaves rounding noise there).  NOT upstream's node-for-node construction -- that cannot be recalled or run
+    here --: the same topology, the same fold, the same split into a row-constant part and a curvilinear cap, singular poles.
+    The (Face, .) nodes of columns 1 and Nx / 2 + 1 lie ON the pole axis, where every row of the cap passes through the pole: they
+    are moved 1e-3 of a column off the axis so that no metric is exactly zero (the reference immerses the cells around the poles)."""
+
+    def __init__(self, size, southernmost_latitude=-80.0, north_poles_latitude=55.0, first_pole_longitude=70.0, halo=(4, 4),
+                 radius=6371e3):
+        Nx, Ny = int(size[0]), int(size[1])
+        Hx, Hy = int(halo[0]), int(halo[1])
+        if Nx % 2:
+            raise ValueError("a TripolarGrid needs an even number of columns (column i folds onto Nx - i + 1)")
+        self.southernmost_latitude = float(southernmost_latitude)
+        self.first_pole_longitude = float(first_pole_longitude)
+        self.radius = float(radius)
+        dth = 360.0 / Nx
+        dpsi = (90.0 - self.southernmost_latitude) / (Ny - 0.5)        # the fold runs through the centres of row Ny
+        Jc = int(round((north_poles_latitude - self.southernmost_latitude) / dpsi))
+        Jc = min(max(Jc, 0), Ny - 2)
+        phi0 = self.southernmost_latitude + Jc * dpsi
+        self.north_poles_latitude = phi0            # (moved onto the nearest row face)
+        self.cap_first_row = Jc + 1                 # rows 1 .. Jc: latitude-longitude; Jc + 1 .. Ny: the cap
+        self.dtheta, self.dpsi = dth, dpsi
+        r0 = np.tan(np.deg2rad(0.5 * (90.0 - phi0)))
+
+        def nodes(xi, eta):
+            """(longitude, latitude) of the net's points at column coordinate xi (face i at i - 1, centre at i - 1/2) and row
+            coordinate eta (likewise), broadcast."""
+            th = np.asarray(xi, dtype=np.float64) * dth
+            psi = self.southernmost_latitude + np.asarray(eta, dtype=np.float64) * dpsi
+            th, psi = np.broadcast_arrays(th, psi)
+            lam, phi = self.first_pole_longitude + th, psi.copy()
+            cap = psi > phi0
+            if cap.any():
+                t = np.deg2rad(th[cap])
+                # off the pole axis by 1e-3 of a column (see the class docstring)
+                eps = 1e-3 * np.deg2rad(dth)
+                near = np.abs(np.sin(t)) < np.sin(eps)
+                t = np.where(near, t + eps, t)
+                r = np.tan(np.deg2rad(0.5 * (90.0 - psi[cap])))          # negative beyond the fold: the mirror image
+                g = 2.0 * np.arctan(r / r0) * np.sign(np.sin(t))
+                a = np.log(np.abs(1.0 / np.tan(0.5 * t)))
+                z = r0 * np.tanh(0.5 * (a + 1j * g))
+                lam = lam.copy()
+                lam[cap] = self.first_pole_longitude + np.rad2deg(np.angle(z))
+                phi[cap] = 90.0 - 2.0 * np.rad2deg(np.arctan(np.abs(z)))
+            return lam, phi
+
+        self._node_fn = nodes
+        n, ni = Ny + 2 * Hy + 1, Nx + 2 * Hx + 1
+        ia = np.arange(ni) - (Hx - 1)                # index i of every entry
+        ja = np.arange(n) - (Hy - 1)
+        xc, xf = (ia - 0.5)[None, :], (ia - 1.0)[None, :]
+        yc, yf = (ja - 0.5)[:, None], (ja - 1.0)[:, None]
+        R = self.radius
+        d = lambda A, B: _haversine(A[0], A[1], B[0], B[1], R)      # noqa: E731
+        m = {}
+        m["dxcc"] = d(nodes(xf + 1.0, yc), nodes(xf, yc))
+        m["dxfc"] = d(nodes(xc, yc), nodes(xc - 1.0, yc))
+        m["dxcf"] = d(nodes(xf + 1.0, yf), nodes(xf, yf))
+        m["dxff"] = d(nodes(xc, yf), nodes(xc - 1.0, yf))
+        m["dycc"] = d(nodes(xc, yf + 1.0), nodes(xc, yf))
+        m["dyfc"] = d(nodes(xf, yf + 1.0), nodes(xf, yf))
+        m["dycf"] = d(nodes(xc, yc), nodes(xc, yc - 1.0))
+        m["dyff"] = d(nodes(xf, yc), nodes(xf, yc - 1.0))
+        # the two pole points are u points of row Ny (columns 1 and Nx / 2 + 1, where cells i - 1 and i are fold images of each other:
+        # dx = 0) -- upstream's "north singularities"; the reference immerses the cells around them.  No metric below one metre, so
+        # that every reciprocal stays finite.
+        for k in list(m):
+            m[k] = np.maximum(m[k], 1.0)
+        for l in ("cc", "fc", "cf", "ff"):
+            m["az" + l] = m["dx" + l] * m["dy" + l]
+        # latitude-longitude rows: one value per row, bit for bit (rows j <= Jc of every location; parent row j + Hy - 1)
+        tlat = Jc + Hy                               # parent rows [0, tlat) have j <= Jc
+        for name in METRIC_NAMES:
+            m[name][:tlat, :] = m[name][:tlat, Hx:Hx + 1]
+        # exact images: periodic in x, folded in y (analytically they are; this removes the rounding noise)
+        for name in METRIC_NAMES:
+            a = m[name]
+            for k in range(1, Hx + 1):
+                a[:, (1 - k) + Hx - 1] = a[:, (Nx + 1 - k) + Hx - 1]
+                a[:, (Nx + k) + Hx - 1] = a[:, k + Hx - 1]
+            a[:, Nx + Hx + 1 + Hx - 1] = a[:, Hx + 1 + Hx - 1]      # (the extra column Nx + Hx + 1 images column Hx + 1)
+            m[name] = fold_north(a, Nx, Ny, Hx, Hy, name[2] == "f", name[3] == "f", 1)
+        super().__init__((Nx, Ny), m, topology=(Periodic, RightFolded), halo=(Hx, Hy), nodes=None)
+
+    def nodes_2d(self, LX, LY, with_halo=False):
+        """(longitude, latitude) of the interior points at (LX, LY) as (Ny, Nx) arrays (with_halo: the metric planes' shape)."""
+        if with_halo:
+            ia = np.arange(self.Nx + 2 * self.Hx + 1) - (self.Hx - 1)
+            ja = np.arange(self.Ny + 2 * self.Hy + 1) - (self.Hy - 1)
+        else:
+            ia, ja = np.arange(1, self.Nx + 1), np.arange(1, self.Ny + 1)
+        xi = (ia - 1.0 if LX is Face else ia - 0.5)[None, :]
+        eta = (ja - 1.0 if LY is Face else ja - 0.5)[:, None]
+        lam, phi = self._node_fn(xi, eta)
+        return (lam + 180.0) % 360.0 - 180.0, phi
+
+    def coriolis_planes(self, rotation_rate=7.292115e-5):
+        """f = 2 Omega sin(latitude) at the u and the v points, in the metric planes' layout (PointwiseCoriolis): per row in the
+        latitude-longitude part (one value per row, bit for bit), per point in the cap, fold images beyond the fold."""
+        out = []
+        for LX, LY in ((Face, Center), (Center, Face)):
+            _, phi = self.nodes_2d(LX, LY, with_halo=True)
+            f = 2.0 * rotation_rate * np.sin(np.deg2rad(phi))
+            tlat = self.cap_first_row - 1 + self.Hy
+            f[:tlat, :] = f[:tlat, self.Hx:self.Hx + 1]
+            f = fold_north(f, self.Nx, self.Ny, self.Hx, self.Hy, LX is Face, LY is Face, 1)
+            out.append(np.ascontiguousarray(f))
+        return tuple(out)
+
+    def analytic_land(self, radius=5.0):
+        """The reference's `analytical_immersed_tripolar_grid` (test/distributed_tests_utils.jl:170-183): land within `radius`
+        degrees (in longitude AND latitude) of the two north poles and within `radius` degrees of the southern edge.  Returns
+        the (Ny, Nx) bool array of WET cells; row Ny is its own fold image by symmetry (enforced)."""
+        lam, phi = self.nodes_2d(Center, Center)
+        lp, pp, pm = self.first_pole_longitude, self.north_poles_latitude, self.southernmost_latitude
+        dl = lambda l0: np.abs((lam - l0 + 180.0) % 360.0 - 180.0)      # noqa: E731
+        land = ((dl(lp) < radius) & (np.abs(pp - phi) < radius)) | ((dl(lp + 180.0) < radius) & (np.abs(pp - phi) < radius)) | \
+               (phi < pm + radius)
+        wet = ~land
+        wet[-1, :] &= wet[-1, ::-1]
+        return wet
+
+    def _ynode(self, j, LY):
+        raise NotImplementedError("a TripolarGrid has no per-row y nodes (use nodes_2d / coriolis_planes)")
+
+    def xnodes(self, LX):
+        raise NotImplementedError("a TripolarGrid has 2-D nodes (nodes_2d)")
+
+    ynodes = xnodes
+
+
 class TileGrid(_Grid2D):
     """One tile of an Rx x Ry decomposition of a global grid (the analogue of an Oceananigans grid built on
     Distributed(arch; partition = Partition(Rx, Ry)), test/distributed_tests_utils.jl:60-62).

@@ -409,6 +409,29 @@ class SeaIceModel:
         level = 2 if level is True else int(level)
         self.ctx.call("csi_set_fusion", level)
 
+    def set_tile_skipping(self, on):
+        """Untiled grids on the two-sub-steps kernel: skip the tiles with no ice mass in or around them (exact: include/csi.h,
+        csi_set_tile_skipping; default on)."""
+        self.ctx.call("csi_set_tile_skipping", 1 if on else 0)
+
+    def tile_activity(self):
+        """(tiles, live, used): the newest counts that have arrived from the device (synchronize() first for the last sub-cycle's)."""
+        import ctypes as C
+        t, l, u = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.ctx.call("csi_tile_activity", C.byref(t), C.byref(l), C.byref(u))
+        return t.value, l.value, u.value
+
+    def set_row_constant(self, on=True, rtol=0.0):
+        """CSI_METRIC_FULL grids: rows whose twelve metric planes hold one value per row are read from per-row vectors (bitwise-equal
+        columns only unless rtol > 0: include/csi.h, csi_set_row_constant)."""
+        self.ctx.call("csi_set_row_constant", 1 if on else 0, float(rtol))
+
+    def row_constant_rows(self):
+        import ctypes as C
+        n = C.c_int32(0)
+        self.ctx.call("csi_row_constant_rows", C.byref(n))
+        return n.value
+
     def set_exchange_interval(self, k):
         """Tiles: exchange u, v halos of width 2k every k sub-steps (0 = automatic from the halo size)."""
         self.ctx.call("csi_set_exchange_interval", int(k))

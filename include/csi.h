@@ -407,6 +407,30 @@ int32_t csi_free_drift_set(csi_context* ctx, int32_t kind);
  * DESIGN.md section 3.)  Levels other than 0, 1, 2 are refused. */
 int32_t csi_set_fusion(csi_context* ctx, int32_t level);
 
+/* Tile activity (round 6; default on).  Where the ice mass h rho aice is exactly zero -- land after mask_immersed_field_xy!
+ * (src/sea_ice_model.jl:379-384), ice-free ocean -- the EVP sub-step is an exact no-op: sigma += ifelse(m > 0, ..., 0)
+ * (src/Rheologies/elasto_visco_plastic_rheology.jl:343-347) and the velocity select's zero branch
+ * (src/SeaIceDynamics/split_explicit_momentum_equations.jl:217-228, 251-263).  On untiled grids advanced by the two-sub-steps
+ * kernel the library tests, before the first launch of every sub-cycle, which 56-column tiles of the launch have no ice mass in
+ * or one cell around them (and no -0.0 among their stresses); the first two launches and the last one run every tile, the
+ * launches in between only the live ones, on a finer tiling chosen so that the live tiles fill the GPU once.  Results are
+ * bit-identical with skipping off (tests/test_gpu_activity.py) as long as the fields are finite.
+ * csi_tile_activity: the newest counts that have arrived from the device (tiles of the live launches, live ones among them;
+ * -1 live: none yet), and whether the last sub-cycle used live launches -- call csi_sync first for the last sub-cycle's counts. */
+int32_t csi_set_tile_skipping(csi_context* ctx, int32_t on);
+int32_t csi_tile_activity(csi_context* ctx, int32_t* tiles, int32_t* live, int32_t* used);
+
+/* CSI_METRIC_FULL grids, row-constant rows (round 6; default on, rtol 0).  A TripolarGrid is a latitude-longitude grid south of
+ * its bipolar cap: there every metric plane holds one value per row.  The library marks the rows in which all Nx + 2Hx + 1
+ * columns of all twelve coefficient planes (and of a per-point Coriolis parameter) are EQUAL BIT FOR BIT and lets the
+ * two-sub-steps kernel read those rows' values from per-row vectors -- the same operands, the same operations, 96 B per cell and
+ * launch less HBM traffic; results are unchanged.  rtol > 0 (at most 1e-6) also marks rows whose columns agree with the first
+ * interior column to that relative distance and uses that column's value for the row: for grids whose row-constant part
+ * carries rounding noise (metrics computed per point); this CHANGES results at the rtol level and is the caller's decision.
+ * csi_row_constant_rows: how many of the Ny + 2Hy + 1 plane rows are marked. */
+int32_t csi_set_row_constant(csi_context* ctx, int32_t on, double rtol);
+int32_t csi_row_constant_rows(csi_context* ctx, int32_t* rows);
+
 /* RCCL halo exchange of u, v every k sub-steps with width 2k (needs halo >= 2k).  k = 0 (default): automatic -- the peer
  * transport below where it applies, else the largest k <= 16 the halo allows; k >= 1 selects the RCCL exchange with that
  * interval (k = 1: every sub-step); the reference is the k = substeps extreme (halo 2*substeps+3,

@@ -15,7 +15,8 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
               substeps=10, dt=120.0, coriolis=1e-4, top=(0.01, 0.01), bottom="semi", ue=0.0, ve=0.0,
               patches=True, noise=0.05, seed=3, u0=0.1, v0=0.0, random_uv=0.0, pressure="replacement",
               field_forcing=False, land=0.0, free_drift=False, beta=None, curvilinear=None, noslip=False,
-              user_forcing=False, immersed_bc=None, coriolis_points=False, wind_drag=None):
+              user_forcing=False, immersed_bc=None, coriolis_points=False, wind_drag=None,
+              tripolar=None, ice_edge=None, ice_free_rows=None):
     rng = np.random.default_rng(seed)
     c = dict(Nx=Nx, Ny=Ny, H=H, topo=topo, grid=grid, spacing=spacing, substeps=substeps, dt=dt, coriolis=coriolis,
              top=top, bottom=bottom, ue=ue, ve=ve, pressure=pressure, field_forcing=field_forcing,
@@ -27,7 +28,16 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
              wind_drag=wind_drag)                  # top stress = SemiImplicitStress(air velocities; rho 1.3, Cd 1.2e-3): "numbers" / "arrays"
     T = {"periodic": csi.Periodic, "bounded": csi.Bounded, "folded": csi.RightFolded}     # "folded": y of a TripolarGrid
     tt = (T[topo[0]], T[topo[1]])
-    if grid == "rectilinear":
+    # grid = "tripolar": csi.TripolarGrid(size, **tripolar) -- latitude-longitude rows below a bipolar cap, north fold, the reference's
+    # analytic land around the poles and along the southern edge (+ `land` discs); f = 2 Omega sin(latitude) per point when
+    # coriolis_points.  ice_edge (degrees): ice only poleward of that latitude (a seasonal-ice state: most of the ocean ice-free);
+    # ice_free_rows = (y0, y1): on the other grids, no ice in that fraction of the rows.
+    c["ice_edge"], c["ice_free_rows"] = ice_edge, ice_free_rows
+    if grid == "tripolar":
+        topo = ("periodic", "folded")
+        c["topo"] = topo
+        g = csi.TripolarGrid((Nx, Ny), halo=(H, H), **(tripolar or {}))
+    elif grid == "rectilinear":
         g = csi.RectilinearGrid((Nx, Ny), x=(0.0, Nx * spacing), y=(0.0, Ny * spacing), topology=tt, halo=(H, H))
     else:
         g = csi.LatitudeLongitudeGrid((Nx, Ny), longitude=(0, 60), latitude=(20, 70), topology=tt, halo=(H, H))
@@ -62,12 +72,27 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
     if topo[1] == "folded":
         v[0, :] = 0.0                               # the south wall; the north side is the fold (no wall face row)
     c["mask"] = None
-    if land:
+    if grid == "tripolar":
+        wet_t = g.analytic_land()
+        lam_c, phi_c = g.nodes_2d(csi.Center, csi.Center)
+        if ice_edge is not None:
+            icy = np.abs(phi_c) > ice_edge
+            h = np.where(icy, h, 0.0)
+            a = np.where(icy, a, 0.0)
+        if coriolis_points:
+            c["f_points"] = g.coriolis_planes()
+    elif ice_free_rows is not None:
+        j0, j1 = int(ice_free_rows[0] * Ny), int(ice_free_rows[1] * Ny)
+        h[j0:j1, :] = 0.0
+        a[j0:j1, :] = 0.0
+    if land or grid == "tripolar":
         # immersed "land": union of seeded discs covering about `land` of the domain
         lr = np.random.default_rng(5)
         wet = np.ones((Ny, Nx), dtype=bool)
         II, JJ = np.meshgrid(np.arange(Nx), np.arange(Ny))
-        while 1.0 - wet.mean() < land:
+        if grid == "tripolar":
+            wet &= wet_t
+        while land and 1.0 - wet.mean() < land:
             cx, cy, rad = lr.integers(0, Nx), lr.integers(0, Ny), lr.integers(2, max(3, min(Nx, Ny) // 6))
             ddx = np.minimum(np.abs(II - cx), Nx - np.abs(II - cx)) if topo[0] == "periodic" else np.abs(II - cx)
             ddy = np.minimum(np.abs(JJ - cy), Ny - np.abs(JJ - cy)) if topo[1] == "periodic" else np.abs(JJ - cy)
@@ -79,7 +104,7 @@ def make_case(Nx=64, Ny=48, H=4, topo=("periodic", "periodic"), grid="rectilinea
         h = np.where(wet, h, 0.0)
         a = np.where(wet, a, 0.0)
     c.update(h=h, a=a, u=u, v=v)
-    if coriolis_points:
+    if coriolis_points and grid != "tripolar":
         # f(i, j) = f0 (1 + 0.3 sin cos) at the u / v nodes, metric-plane layout; halo entries image their points
         n, ni = Ny + 2 * H + 1, Nx + 2 * H + 1
         ia, ja = np.arange(ni) - (H - 1), np.arange(n) - (H - 1)

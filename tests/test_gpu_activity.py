@@ -1,0 +1,271 @@
+"""GPU tests of the two structure cuts of round 6 (both exact):
+
+  * tile activity (csi_set_tile_skipping, csrc/csi_activity.hip): tiles with no ice mass in or around them are left out of all
+    launches of a sub-cycle but the first two and the last -- every field, halo cells included, must be BIT-IDENTICAL with
+    skipping off;
+  * row-constant rows of a CSI_METRIC_FULL grid (csi_set_row_constant): tiles whose rows hold one value per row in all twelve
+    coefficient planes read them from per-row vectors -- bit-identical with the feature off;
+  * the real tripolar geometry (csi.TripolarGrid: latitude-longitude rows below a conformal bipolar cap, the reference's analytic
+    land, test/distributed_tests_utils.jl:170-183): against the oracle, with both cuts at work.
+
+Why skipping is exact: sigma += ifelse(m > 0, sigma*, 0) (src/Rheologies/elasto_visco_plastic_rheology.jl:343-347) and the
+velocity select's zero branch (src/SeaIceDynamics/split_explicit_momentum_equations.jl:217-228, 251-263).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import climaseaice_jl_amd as csi
+from test_gpu_evp import EVP_FIELDS
+
+pytestmark = pytest.mark.gpu
+
+OUT = ("u", "v", "s11", "s22", "s12", "alpha", "zeta_c", "zeta_f", "Delta")
+
+
+def parents(m):
+    m.synchronize()
+    return {k: EVP_FIELDS[k](m).numpy().copy() for k in OUT}
+
+
+def run(case, steps=3, skipping=True, row_constant=True, mode="fast", **kw):
+    m = cases.csi_model(case, mode=mode, **kw)
+    m.set_tile_skipping(skipping)
+    m.set_row_constant(row_constant)
+    acts = []
+    for _ in range(steps):
+        csi.time_step_momentum(m, case["dt"])
+        m.synchronize()
+        acts.append(m.tile_activity())
+    return parents(m), acts, m
+
+
+def assert_bitwise(a, b, what):
+    for k in OUT:
+        same = (a[k].view(np.int64) == b[k].view(np.int64)) | (np.isnan(a[k]) & np.isnan(b[k]))
+        assert same.all(), f"{what}: {k} differs in {np.count_nonzero(~same)} parent cells (first at {np.argwhere(~same)[0]})"
+
+
+# ice-free ocean and land large enough to hold whole 56-column tiles; odd and even numbers of sub-steps; every kernel family
+SKIP_CASES = {
+    "periodic_half_free": dict(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=False, random_uv=0.03, ice_free_rows=(0.3, 0.8), substeps=20),
+    "periodic_odd": dict(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=True, random_uv=0.03, ice_free_rows=(0.0, 0.6), substeps=21),
+    "bounded_free": dict(Nx=400, Ny=300, topo=("bounded", "bounded"), patches=False, random_uv=0.03, ice_free_rows=(0.5, 1.0), substeps=16),
+    "latlon_free": dict(Nx=336, Ny=280, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, ice_free_rows=(0.0, 0.5), substeps=12),
+    "masked_channel": dict(Nx=448, Ny=300, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.45, substeps=20),
+    "masked_free": dict(Nx=448, Ny=300, topo=("periodic", "bounded"), patches=False, random_uv=0.03, land=0.3, ice_free_rows=(0.2, 0.7), substeps=14),
+    "coupled_free": dict(Nx=392, Ny=260, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.3, field_forcing=True,
+                         ice_free_rows=(0.4, 0.9), substeps=12),
+    "omip_free": dict(Nx=392, Ny=260, topo=("periodic", "bounded"), patches=True, random_uv=0.03, land=0.3, field_forcing=True, free_drift=True,
+                      ice_free_rows=(0.1, 0.6), substeps=12),
+    "user_forcing_free": dict(Nx=336, Ny=240, topo=("periodic", "periodic"), patches=False, random_uv=0.03, user_forcing=True,
+                              ice_free_rows=(0.25, 0.75), substeps=10),
+    "immersed_bc_free": dict(Nx=336, Ny=240, topo=("periodic", "bounded"), patches=False, random_uv=0.03, land=0.35,
+                             immersed_bc=((0.02, -0.01, 0.015, 0.005), (-0.01, 0.02, 0.01, -0.015)), substeps=10),
+    "wind_drag_free": dict(Nx=336, Ny=240, topo=("periodic", "periodic"), patches=False, random_uv=0.03, wind_drag="arrays", field_forcing=True,
+                           ice_free_rows=(0.2, 0.8), substeps=10),
+    "curvilinear_free": dict(Nx=336, Ny=260, topo=("periodic", "bounded"), patches=False, random_uv=0.03, curvilinear=0.05, land=0.3,
+                             ice_free_rows=(0.3, 0.8), substeps=12),
+    "fold_free": dict(Nx=336, Ny=260, topo=("periodic", "folded"), patches=False, random_uv=0.03, ice_free_rows=(0.1, 0.7), substeps=12),
+    "tripolar_like_free": dict(Nx=336, Ny=260, topo=("periodic", "folded"), patches=False, random_uv=0.03, curvilinear=0.05, land=0.3, field_forcing=True,
+                               free_drift=True, ice_free_rows=(0.1, 0.6), substeps=12),
+    "beta_free": dict(Nx=336, Ny=240, topo=("periodic", "bounded"), patches=False, random_uv=0.03, beta=2e-10, ice_free_rows=(0.0, 0.5), substeps=10),
+    "noslip_free": dict(Nx=336, Ny=240, topo=("periodic", "bounded"), patches=False, random_uv=0.03, noslip=True, land=0.3,
+                        ice_free_rows=(0.5, 1.0), substeps=10),
+}
+
+
+@pytest.mark.parametrize("name", list(SKIP_CASES))
+def test_skipping_is_bit_identical(name):
+    """Three sub-cycles (the launch geometry follows the live fraction from the second on) with and without tile skipping."""
+    case = cases.make_case(**SKIP_CASES[name])
+    on, acts, m = run(case, skipping=True)
+    off, acts_off, _ = run(case, skipping=False)
+    assert_bitwise(on, off, name)
+    tiles, live, used = acts[-1]
+    assert used == 1 and 0 < live < tiles, (name, acts)          # something was skipped, something ran
+    assert acts_off[-1][2] == 0
+    assert m.ctx.last_path()["level"] == 2
+
+
+def test_negative_zero_stress_keeps_a_tile_alive():
+    """fma(x, 0, -0.0) takes the sign of x: a -0.0 among the stresses of an ice-free tile must keep it in the launches."""
+    case = cases.make_case(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=False, random_uv=0.03, ice_free_rows=(0.3, 0.9), substeps=12)
+    res = []
+    for skipping in (True, False):
+        m = cases.csi_model(case, mode="fast")
+        m.set_tile_skipping(skipping)
+        for key in ("s11", "s22", "s12"):
+            p = EVP_FIELDS[key](m).data
+            p[int(0.55 * p.shape[0]):int(0.65 * p.shape[0]), :] = -0.0           # a band of rows inside the ice-free part
+        torch.cuda.synchronize()
+        csi.time_step_momentum(m, case["dt"])
+        m.synchronize()
+        res.append((parents(m), m.tile_activity()))
+    assert_bitwise(res[0][0], res[1][0], "negative zeros")
+    # the -0.0 rows are gone after the sub-cycle either way (x * 0 + (-0.0) = +0.0 for x >= 0), and fewer tiles were skipped
+    m2 = cases.csi_model(case, mode="fast")
+    csi.time_step_momentum(m2, case["dt"])
+    m2.synchronize()
+    assert res[0][1][1] > m2.tile_activity()[1]
+
+
+def test_ice_free_velocities_are_zeroed_like_the_reference():
+    """u0 = 0.1 everywhere, also where there is no ice: the first sub-step zeroes it (split_explicit...:228) -- the skipped tiles' cells
+    included, because the first two launches run every tile."""
+    case = cases.make_case(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=False, u0=0.1, v0=-0.05, ice_free_rows=(0.2, 0.9), substeps=10)
+    on, acts, m = run(case, steps=1, skipping=True)
+    H = case["H"]
+    j0, j1 = int(0.3 * 320), int(0.8 * 320)
+    assert np.all(on["u"][H + j0:H + j1, :] == 0.0) and np.all(on["v"][H + j0:H + j1, :] == 0.0)
+    p = cases.oracle_problem(case)
+    p.time_step_momentum(case["dt"])
+    vmax = np.abs(p.f["u"]).max()
+    for k in ("u", "v"):
+        assert np.abs(m_field(m, k) - p.f[k]).max() <= 1e-12 * vmax
+        assert np.array_equal(m_field(m, k) == 0.0, p.f[k] == 0.0)
+
+
+def m_field(m, k):
+    return EVP_FIELDS[k](m).numpy()
+
+
+def test_short_subcycles_do_not_skip():
+    case = cases.make_case(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=False, ice_free_rows=(0.2, 0.9), substeps=6)
+    _, acts, _ = run(case, steps=2)
+    assert acts[-1][2] == 0
+
+
+def test_whole_steps_with_skipping_match():
+    """SplitRungeKutta3 steps with advection: the ice edge moves, the live set is made afresh before every sub-cycle."""
+    kw = dict(Nx=392, Ny=300, topo=("periodic", "bounded"), patches=False, random_uv=0.02, land=0.3, ice_free_rows=(0.3, 0.8), substeps=12)
+    case = cases.make_case(**kw)
+    out = []
+    for skipping in (True, False):
+        m = cases.csi_model(case, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=5))
+        m.set_tile_skipping(skipping)
+        for _ in range(3):
+            csi.time_step(m, 600.0)
+        m.synchronize()
+        st = parents(m)
+        st["h"] = m.ice_thickness.numpy().copy()
+        st["a"] = m.ice_concentration.numpy().copy()
+        out.append(st)
+    assert_bitwise(out[0], out[1], "RK3 steps")
+    assert np.array_equal(out[0]["h"], out[1]["h"]) and np.array_equal(out[0]["a"], out[1]["a"])
+
+
+# ---- row-constant rows ----------------------------------------------------------------------------------------------------------------
+
+ROWC_CASES = {
+    # a latitude-longitude / rectilinear grid handed over as twelve arrays: every row constant
+    "latlon_as_full": dict(Nx=200, Ny=140, topo=("bounded", "bounded"), grid="latlon", patches=True, random_uv=0.03, curvilinear=0.0, substeps=10),
+    "rect_as_full_masked": dict(Nx=200, Ny=140, topo=("periodic", "bounded"), patches=True, random_uv=0.03, curvilinear=0.0, land=0.25, substeps=11),
+    "rect_as_full_forced": dict(Nx=200, Ny=140, topo=("periodic", "bounded"), patches=True, random_uv=0.03, curvilinear=0.0, field_forcing=True,
+                                free_drift=True, land=0.2, substeps=10),
+    "fold_as_full": dict(Nx=200, Ny=160, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.0, substeps=10),
+}
+
+
+@pytest.mark.parametrize("name", list(ROWC_CASES))
+def test_row_constant_tiles_are_bit_identical(name):
+    case = cases.make_case(**ROWC_CASES[name])      # (curvilinear = 0.0: the twelve arrays, undistorted)
+    on, _, m = run(case, steps=2, row_constant=True, skipping=False)
+    off, _, m0 = run(case, steps=2, row_constant=False, skipping=False)
+    assert_bitwise(on, off, name)
+    n = case["Ny"] + 2 * case["H"] + 1
+    assert m.row_constant_rows() >= n - (2 * case["H"] + 2 if case["topo"][1] == "folded" else 0)
+    assert m0.row_constant_rows() == 0
+
+
+def test_row_constant_needs_bitwise_equal_columns():
+    """One column of one plane one ulp off in a band of rows: those rows are not marked, the others are; results unchanged."""
+    case = cases.make_case(Nx=200, Ny=160, topo=("periodic", "bounded"), patches=True, random_uv=0.03, curvilinear=0.0, substeps=10)
+    g = case["g"]
+    a = g.metrics()["dycf"]
+    a[60:70, 17] = np.nextafter(a[60:70, 17], np.inf)
+    on, _, m = run(case, steps=2, row_constant=True, skipping=False)
+    off, _, _ = run(case, steps=2, row_constant=False, skipping=False)
+    assert_bitwise(on, off, "ulp band")
+    n = case["Ny"] + 2 * case["H"] + 1
+    assert m.row_constant_rows() == n - 10
+    # a tolerance marks them again (the caller's decision; results then move at that level)
+    m.set_row_constant(True, rtol=1e-12)
+    assert m.row_constant_rows() == n
+
+
+# ---- the real tripolar geometry ---------------------------------------------------------------------------------------------------
+
+TRIPOLAR = dict(Nx=224, Ny=192, grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), patches=False, random_uv=0.02,
+                field_forcing=True, free_drift=True, coriolis_points=True, ice_edge=58.0, substeps=20)
+
+
+def test_tripolar_grid_structure():
+    g = csi.TripolarGrid((224, 192), southernmost_latitude=-78.0)
+    m = g.metrics()
+    H = 4
+    names = list(m)
+    names.remove("kind")
+    for k in names:
+        assert np.isfinite(m[k]).all() and (m[k] > 0).all()
+    # latitude-longitude rows: one value per row in every plane; the cap: not
+    lat_rows = g.cap_first_row - 1 + H
+    for k in names:
+        assert (m[k][:lat_rows, :] == m[k][:lat_rows, :1]).all()
+    assert not (m["dxcc"][lat_rows + 3, :] == m["dxcc"][lat_rows + 3, 0]).all()
+    # the net is orthogonal: the angle between the two families of lines at the cell centres of the cap
+    lam_e, phi_e = g.nodes_2d(csi.Face, csi.Center)
+    lam_n, phi_n = g.nodes_2d(csi.Center, csi.Face)
+
+    def xyz(lam, phi):
+        l, p = np.deg2rad(lam), np.deg2rad(phi)
+        return np.stack([np.cos(p) * np.cos(l), np.cos(p) * np.sin(l), np.sin(p)], -1)
+    E, N = xyz(lam_e, phi_e), xyz(lam_n, phi_n)
+    tx = E[:-1, 1:, :] - E[:-1, :-1, :]                   # across cell (i, j): east face - west face; i = 1 .. Nx - 1, j = 1 .. Ny - 1
+    ty = N[1:, :-1, :] - N[:-1, :-1, :]                   # north face - south face
+    cosang = np.abs((tx * ty).sum(-1)) / (np.linalg.norm(tx, axis=-1) * np.linalg.norm(ty, axis=-1))
+    cap = slice(g.cap_first_row, g.Ny - 2)
+    inner = np.ones(cosang.shape[1], bool)
+    for ip in (1, g.Nx // 2 + 1):                         # columns next to the pole axis: the cells there wrap around the pole
+        inner[max(ip - 4, 0):ip + 2] = False
+    assert cosang[cap][:, inner].max() < 2e-2             # second-order in the spacing
+    # the fold: row Ny is its own image
+    lam_c, phi_c = g.nodes_2d(csi.Center, csi.Center)
+    assert np.abs(phi_c[-1] - phi_c[-1, ::-1]).max() < 1e-10
+    wet = g.analytic_land()
+    assert not wet[:5].any() and 0.85 < wet.mean() < 0.99
+
+
+def test_tripolar_against_the_oracle_and_both_cuts():
+    case = cases.make_case(**TRIPOLAR)
+    full, acts, m = run(case, steps=1)
+    p = cases.oracle_problem(case)
+    p.time_step_momentum(case["dt"])
+    vmax = max(np.abs(p.f["u"]).max(), np.abs(p.f["v"]).max())
+    smax = max(np.abs(p.f[k]).max() for k in ("s11", "s22", "s12"))
+    for k in ("u", "v"):
+        d = np.abs(full[k] - p.f[k]).max()
+        assert d <= 1e-12 * vmax, (k, d, vmax)
+        assert np.array_equal(full[k] == 0.0, p.f[k] == 0.0)
+    for k in ("s11", "s22", "s12"):
+        d = np.abs(full[k] - p.f[k]).max()
+        assert d <= 1e-11 * smax, (k, d, smax)
+    # both cuts off: the same bits
+    plain, _, m0 = run(case, steps=1, skipping=False, row_constant=False)
+    assert_bitwise(full, plain, "tripolar")
+    assert m.row_constant_rows() >= m.grid.cap_first_row - 1 + case["H"] and m0.row_constant_rows() == 0
+    tiles, live, used = acts[-1]
+    assert used == 1 and live < tiles
+
+
+def test_tripolar_strict_matches_the_oracle_bitwise():
+    kw = dict(TRIPOLAR, Nx=96, Ny=80, substeps=8)
+    case = cases.make_case(**kw)
+    m = cases.csi_model(case, mode="strict")
+    csi.time_step_momentum(m, case["dt"])
+    got = parents(m)
+    p = cases.oracle_problem(case)
+    p.time_step_momentum(case["dt"])
+    for k in ("u", "v", "s11", "s22", "s12"):
+        assert np.array_equal(got[k], p.f[k]), k
