@@ -142,7 +142,11 @@ def load():
         "csi_subcycle_stats_end": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(i32)],
     }
     for name, args in sig.items():
-        fn = getattr(L, name)
+        fn = getattr(L, name, None)
+        if fn is None and "CSI_HIP_LIBRARY" in os.environ:
+            continue                      # an older build in an A/B run (scripts/ab_libs.sh): entry points added since are absent
+        if fn is None:
+            raise AttributeError(f"libcsi_hip.so does not export {name}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         fn.restype = i32
         fn.argtypes = args
     L.csi_local_group_destroy.restype = None

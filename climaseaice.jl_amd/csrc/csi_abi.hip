@@ -89,6 +89,8 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
         c->tune.write_through = env_int("CSI_WRITE_THROUGH");  // 0 / 1: never / always store the pair kernel's results write-through (default: by grid size)
         c->tune.adv_nt = env_int("CSI_ADV_NT"); c->tune.pair_target = env_int("CSI_PAIR_TARGET");
         { const int v = env_int("CSI_ROW_TARGET_1024"); if (v >= 0) c->tune.row_target_1024 = v; }      // 0: per-row coefficients keep 1536 tiles (rounds 3-5a)
+        { const int v = env_int("CSI_TILE_SKIPPING"); if (v >= 0) c->act.enabled = v != 0; }      // A/B: the defaults of csi_set_tile_skipping / csi_set_row_constant
+        { const int v = env_int("CSI_ROW_CONSTANT"); if (v >= 0) c->rc_enabled = v != 0; }
         c->tune.peer_kernel = env_int("CSI_PEER_KERNEL");      // 1: untiled grids run the PEER instantiation of the pair kernel (no neighbour, no waits): what the instantiation itself costs
     }
     *out = c;

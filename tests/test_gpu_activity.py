@@ -114,7 +114,7 @@ def test_negative_zero_stress_keeps_a_tile_alive():
 def test_ice_free_velocities_are_zeroed_like_the_reference():
     """u0 = 0.1 everywhere, also where there is no ice: the first sub-step zeroes it (split_explicit...:228) -- the skipped tiles' cells
     included, because the first two launches run every tile."""
-    case = cases.make_case(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=False, u0=0.1, v0=-0.05, ice_free_rows=(0.2, 0.9), substeps=10)
+    case = cases.make_case(Nx=448, Ny=320, topo=("periodic", "periodic"), patches=False, u0=0.1, v0=-0.05, random_uv=0.03, ice_free_rows=(0.2, 0.9), substeps=10)
     on, acts, m = run(case, steps=1, skipping=True)
     H = case["H"]
     j0, j1 = int(0.3 * 320), int(0.8 * 320)
