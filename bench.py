@@ -110,7 +110,7 @@ class ClockSampler:
                 "samples": len(self.samples),
                 "note": "the firmware's figures are moving averages: over a region of a few tenths of a second they lag (idle time before it pulls them down); "
                         "scripts/clock_watch.sh over a 10 s run is the reference (profiles/r05_power_clock.md)",
-                "source": "sysfs hwmon freq1_input / power1_average of this device, 4 ms period, timed region" if self.samples else None}
+                "source": "sysfs hwmon freq1_input / power1_average of this device, 4 ms period, over a repetition of the timed loop right behind the timed region" if self.samples else None}
 
 
 # Default decomposition of the metric's grid on N GPUs: slabs in y (Rx = 1).  Measured per tile shape on one MI355X, the tile connected
@@ -371,6 +371,54 @@ def advection_record(csi, np, torch, device):
     return out
 
 
+def structure_record(csi, np, torch, device, substeps, quick=False):
+    """The reference's flagship workload beside the headline (round 6): grids with land and ice-free ocean, where the two exact
+    structure cuts work -- tile activity (tiles with no ice mass are left out of the inner launches) and row-constant rows of a
+    tripolar grid's latitude-longitude part (read from per-row vectors).  Every rate is given for ALL cells of the grid (the metric's
+    counting), for the WET cells and for the cells that hold ICE, with the cuts on and off, so that nothing is oversold:
+      config5_masked : BASELINE config 5's grid -- 4096^2, 38.6 % land in seeded discs (tests/cases.py), ice on every wet cell;
+      tripolar       : csi.TripolarGrid 2048^2 (78 S .. 90 N, latitude-longitude rows below a conformal bipolar cap at 55 N, north fold),
+                       the reference's analytic land + 30 % land discs, wind-stress and ocean-velocity arrays, StressBalanceFreeDrift,
+                       f = 2 Omega sin(latitude) per point, ice poleward of 58 degrees -- test/distributed_tests_utils.jl:186-224 at scale;
+      tripolar_like  : round 5's stand-in (rectilinear grid distorted everywhere, 30 % land discs, ice everywhere): no row-constant rows."""
+    import cases
+    todo = {
+        "config5_masked": (4096 if not quick else 1024, dict(topo=("periodic", "bounded"), land=0.386)),
+        "tripolar": (2048 if not quick else 512, dict(grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), land=0.3, field_forcing=True, free_drift=True,
+                                                       coriolis_points=True, ice_edge=58.0)),
+        "tripolar_like": (2048 if not quick else 512, dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True)),
+    }
+    out = {"substeps": substeps, "note": "cell-updates/s = cells x sub-steps / wall time of time_step_momentum!; all = every cell of the grid (the metric's counting), "
+                                         "wet = cells that are not land, icy = cells with h > 0 and aice > 0; cuts = tile activity + row-constant rows "
+                                         "(bit-identical results: tests/test_gpu_activity.py)"}
+    for name, (N, kw) in todo.items():
+        c = cases.make_case(Nx=N, Ny=N, substeps=substeps, patches=False, noise=0.05, **kw)
+        wet = 1.0 if c["mask"] is None else float(c["mask"].mean())
+        icy = float(((c["h"] > 0) & (c["a"] > 0)).mean())
+        rec = {"grid": [N, N], "wet_fraction": wet, "icy_fraction": icy}
+        for key, on in (("cuts_on", True), ("cuts_off", False)):
+            m = cases.csi_model(c, mode="fast", device=device)
+            m.set_tile_skipping(on)
+            m.set_row_constant(on)
+            for _ in range(3):                            # (the launch geometry follows the live fraction from the second sub-cycle on)
+                csi.time_step_momentum(m, c["dt"])
+            m.synchronize(); torch.cuda.synchronize()
+            n = 3
+            t0 = time.perf_counter()
+            for _ in range(n):
+                csi.time_step_momentum(m, c["dt"])
+            m.synchronize(); torch.cuda.synchronize()
+            e = (time.perf_counter() - t0) / n
+            tiles, live, used = m.tile_activity()
+            rec[key] = {"ms_per_step": 1e3 * e, "all_cells_per_s": N * N * substeps / e, "wet_cells_per_s": wet * N * N * substeps / e,
+                        "icy_cells_per_s": icy * N * N * substeps / e, "tiles": tiles, "live_tiles": live, "live_launches_used": bool(used),
+                        "row_constant_rows": m.row_constant_rows() if c["g"].metric_kind == "full" else None, "level": m.ctx.last_path()["level"]}
+            m = None
+        rec["speedup"] = rec["cuts_off"]["ms_per_step"] / rec["cuts_on"]["ms_per_step"]
+        out[name] = rec
+    return out
+
+
 def isa_mix():
     """Instruction mix of the dominant kernel's row loops from its ISA listing (scripts/isa_mix.py -> profiles/isa_mix_k_pair.json)."""
     f = os.path.join(ROOT, "profiles", "isa_mix_k_pair.json")
@@ -416,6 +464,7 @@ def main():
     ap.add_argument("--no-second-partition", action="store_true", help="N > 1: do not time the other decomposition (2x4-style vs y slabs) after the headline")
     ap.add_argument("--partition", type=str, default="", help="RxxRy tiles instead of the default y slabs (e.g. 2x4: BASELINE config 4's decomposition); Rx * Ry = --gpus")
     ap.add_argument("--no-unfused", action="store_true", help="one GPU: do not time the unfused three-kernel path (roofline.unfused) after the headline")
+    ap.add_argument("--no-structure", action="store_true", help="one GPU: do not time the masked / tripolar configurations (`structure`) after the headline")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
     args = ap.parse_args()
     if args.gpus not in PARTITION:
@@ -645,8 +694,11 @@ def main():
     # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
     # below is the last thing this process writes
     ctypes.CDLL(None).fflush(None)
+    elapsed = timed(args.steps, stats=True)
+    # the clock / power sampler reads sysfs from a Python thread: it runs over a REPETITION of the timed loop right behind it, so that
+    # the headline region holds the launch loop alone, as in rounds 1-4
     with ClockSampler(local_rank) as clock:
-        elapsed = timed(args.steps, stats=True)
+        timed(args.steps)
 
     owned = nx_l * ny_l * world
     value = owned * args.substeps * args.steps / elapsed
@@ -819,6 +871,10 @@ def main():
     if world == 1 and not tiled and not args.no_full_step and args.mode == "fast":
         advection = advection_record(csi, np, torch, device)
 
+    structure = None
+    if world == 1 and not tiled and not args.no_structure and not args.tile and args.mode == "fast" and not args.no_fusion and args.fusion_level >= 2:
+        structure = structure_record(csi, np, torch, device, args.substeps, quick=args.size < 2048)
+
     # ---- tiles: the other ways to move the halos, timed outside the headline region: the RCCL exchange batched over k = 16
     # sub-steps (halo 32) and once per sub-step (k = 1) --------------------------------------------------------------------------
     k1 = None
@@ -949,6 +1005,8 @@ def main():
     }
     if advection is not None:
         out["advection"] = advection
+    if structure is not None:
+        out["structure"] = structure
     if k1 is not None:
         out["exchange_every_substep"] = k1
     if rccl16 is not None:

@@ -715,6 +715,8 @@ int32_t csi_comm_init_local(csi_context* c, csi_local_group* G, int32_t rank) {
     }
     std::unique_lock<std::mutex> lk(G->mu);
     ++G->joined;
+    if ((int)G->device.size() != G->world) G->device.assign((size_t)G->world, -1);
+    G->device[(size_t)rank] = c->device;
     return CSI_OK;
 }
 

@@ -77,6 +77,7 @@ struct csi_local_group {
     std::vector<std::vector<uint8_t>> payload;
     long arrived = 0, generation = 0;
     int joined = 0;
+    std::vector<int> device;                       // per rank: the HIP device of its context (-1: not joined); peer_effective_tier
 };
 
 struct csi_context {

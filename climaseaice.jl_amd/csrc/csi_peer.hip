@@ -80,7 +80,14 @@ PeerSets peer_my_sets(csi_context* c) {
 // bitwise check cannot prove a protocol whose failure would be a rare, timing-dependent stale line).
 int peer_effective_tier(const csi_context* c) {
     if (c->peer.tier >= 0) return c->peer.tier;
-    return (c->world > 1 && !c->local) ? 1 : 0;
+    if (c->world > 1 && c->local) {
+        // an in-process group: tier 0 only while all its contexts share ONE device (a group that spans GPUs got the
+        // fence-free tier silently)
+        std::unique_lock<std::mutex> lk(c->local->mu);
+        for (int d : c->local->device) if (d >= 0 && d != c->device) return 1;
+        return 0;
+    }
+    return c->world > 1 ? 1 : 0;
 }
 
 // Collective over the context's communicator: every rank publishes IPC handles of its arrays and flags, maps its neighbours'.
@@ -243,7 +250,10 @@ int32_t peer_setup(csi_context* c, bool local_ok) {
         int* flag = (int*)pr.xbuf;
         // (a failing upload votes with a zeroed word: hipMemset is tried, and whatever the word holds this rank itself ends with ok = 0)
         const bool up = soft(hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(vote)");
-        if (!up) (void)hipMemset(flag, 0, sizeof(int));
+        // (... and when the word can be neither written nor zeroed it still holds all-gather bytes: this rank would vote non-zero while ending
+        //  with ok = 0 itself -- a hard error instead of ranks that disagree about the transport)
+        if (!up && hipMemset(flag, 0, sizeof(int)) != hipSuccess)
+            return fail(c, CSI_ERR_HIP, "peer set-up: the vote word can be neither uploaded nor cleared (the ranks could disagree about the halo transport)");
         NCCL_TRY(c, ncclAllReduce(flag, flag, 1, ncclInt32, ncclMin, c->comm, c->stream));
         int voted = 0;
         if (soft(hipStreamSynchronize(c->stream), "hipStreamSynchronize(vote)") && soft(hipMemcpy(&voted, flag, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy(vote back)"))

@@ -547,7 +547,12 @@ def prognostic_state(model):
     """Oceananigans.prognostic_state(model) (sea_ice_model.jl:414-426): host copies of the whole parent arrays (halos included)
     plus the clock.  The library keeps no state of its own between calls -- pointers, scratch that every sub-cycle rebuilds --
     so this is all a checkpoint needs (tests/test_gpu_steps.py::test_checkpoint_round_trip_bitwise)."""
-    model.synchronize()
+    # (a tiled model: the collective check -- csi_sync on every rank + the halo transport's status reduced over ALL ranks -- so that a
+    #  checkpoint is never written from an aborted sub-cycle's fields; every rank of the decomposition saves at the same step)
+    if isinstance(model.grid, TileGrid):
+        model.ctx.validate_all()
+    else:
+        model.synchronize()
     state = {k: f.numpy().copy() for k, f in _state_fields(model).items()}
     state["clock"] = (model.clock.time, model.clock.iteration)
     return state
@@ -589,3 +594,7 @@ def time_step(model, dt):
         model.ctx.call("csi_time_step_rk3", float(dt), model.substeps, model.scheme)
     model.clock.time += float(dt)
     model.clock.iteration += 1
+    # tiles: once per step, the state is checked on EVERY rank before anything between two steps (output, checkpoints, callbacks) reads
+    # it -- what the Julia stub does in the update_state! that ends time_step! (julia/ClimaSeaIceHIP.jl)
+    if isinstance(model.grid, TileGrid):
+        model.ctx.validate_all()

@@ -53,7 +53,8 @@ const F = (U=0, V=1, H=2, A=3, S11=4, S22=5, S12=6, UN=7, VN=8, P=9, ALPHA=10, D
 mutable struct Context
     handle::Ptr{Cvoid}
     mask::Any            # UInt8 activity mask of an immersed grid (owned here so that it outlives the library's pointer)
-    Context(handle) = new(handle, nothing)
+    validated_iteration::Int      # Distributed grids: the clock iteration whose state csi_validate_all has last checked on every rank
+    Context(handle) = new(handle, nothing, -1)
 end
 
 function check(ctx, rc)
@@ -362,9 +363,8 @@ end
 function ClimaSeaIce.compute_tracer_tendencies!(model::HIPSeaIceModel)
     ctx = context(model)
     order = Oceananigans.Advection.required_halo_size_x(model.advection) == 4 ? 7 : 5     # WENO(order = 7 | 5)
-    # precision of the scheme's smoothness / weight arithmetic (round 5): newer upstream versions give WENO a SECOND float type
-    # parameter (WENO{N, FT, FT2, ...}, FT2 = Float32 by default) -- the library has both modes (include/csi.h:
-    # csi_set_weno_weight_dtype) and STRICT equals its oracle bit for bit in either
+    # precision of the scheme's smoothness / weight arithmetic: f64 unless the user opts in (WENO_WEIGHT_DTYPE below; the library has
+    # both modes, include/csi.h: csi_set_weno_weight_dtype, and STRICT equals its oracle bit for bit in either)
     check(ctx, ccall((:csi_set_weno_weight_dtype, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, weight_dtype(model.advection)))
     GC.@preserve model check(ctx, ccall((:csi_compute_tracer_tendencies, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, order))
     return nothing
@@ -372,8 +372,16 @@ end
 
 # CSI_WEIGHTS_F64 (0) / CSI_WEIGHTS_F32 (1) from the scheme's type parameters: the first parameter that is a float type is FT, a
 # second float type -- where the upstream version has one -- is FT2.  Versions with a single float type compute the weights in FT.
+# Round 6 (ADVICE round 5): NOT selected automatically.  The f32 arithmetic of the library is a reading of upstream's FT2 that no
+# reference run has confirmed (its weights are normalised by a float sum: a constant is reproduced to 6e-8 only), the reference
+# pins Oceananigans 0.110 / 0.111, and the Python front end defaults to f64 -- so this stub does too, whatever the scheme's type
+# parameters say.  Opt in with `ClimaSeaIceHIP.WENO_WEIGHT_DTYPE[] = :f32` (or :auto for the type-parameter rule below) once
+# bench/reference_driver.jl's DONE file and golden outputs have shown which arithmetic the installed upstream runs.
+const WENO_WEIGHT_DTYPE = Ref(:f64)
 function weight_dtype(scheme)
-    floats = [p for p in typeof(scheme).parameters if p isa Type && p <: AbstractFloat]
+    WENO_WEIGHT_DTYPE[] === :f64 && return Int32(0)
+    WENO_WEIGHT_DTYPE[] === :f32 && return Int32(1)
+    floats = [p for p in typeof(scheme).parameters if p isa Type && p <: AbstractFloat]      # :auto
     return (length(floats) >= 2 && floats[2] === Float32) ? Int32(1) : Int32(0)
 end
 weight_dtype(::Nothing) = Int32(0)
@@ -402,6 +410,15 @@ function Oceananigans.TimeSteppers.update_state!(model::HIPSeaIceModel, callback
     # the model -- reports a transport error it already knows of; `validate_state!` below is the collective check for the places
     # that need a state known good on EVERY rank (output, checkpoints).
     Oceananigans.Models.update_model_field_time_series!(model, model.clock)
+    # ONCE PER STEP on a Distributed grid (round 6, ADVICE round 5): the first update_state! after the clock has ticked -- the one that
+    # ends time_step! (sea_ice_fe_step.jl:30-31; upstream's SplitRungeKutta time_step! likewise) -- runs the collective check, so that
+    # whatever reads the fields between two steps (output writers, checkpointers, callbacks) reads a state every rank knows to be
+    # good: an aborted sub-cycle throws HERE, on every rank, not at the next step and only on the failed rank's neighbours.  One drain
+    # of the stream and one all-reduce per step, not per stage.
+    if architecture(model.grid) isa Distributed && model.clock.iteration != ctx.validated_iteration
+        ctx.validated_iteration = model.clock.iteration
+        validate_state!(model)
+    end
     return nothing
 end
 

@@ -628,6 +628,26 @@ def test_peer_abort_is_sticky_until_rearmed():
         assert np.array_equal(EVP_FIELDS[f](ref).interior_numpy(), EVP_FIELDS[f](til).interior_numpy()), f
 
 
+def test_peer_abort_throws_before_output_is_read():
+    """a step that ended on an aborted sub-cycle must not hand its fields to an output writer or a checkpointer.
+    time_step (its once-per-step collective check) and prognostic_state (the checkpoint path) both raise; nothing is returned."""
+    kw, fc = PEER_CASES["periodic_xy"]
+    c = cases.make_case(substeps=12, patches=True, random_uv=0.05, **kw)
+    til = cases.csi_model(c, mode="fast", tile=(1, 1, 0, fc), timestepper="ForwardEuler")
+    csi.time_step(til, c["dt"])
+    assert til.ctx.halo_transport() == "peer"
+    til.ctx.call("csi_debug_peer_abort")
+    with pytest.raises(csi.CsiError):
+        csi.prognostic_state(til)
+    it = til.clock.iteration
+    with pytest.raises(csi.CsiError):
+        csi.time_step(til, c["dt"])
+    assert til.clock.iteration == it                      # the failed step did not count
+    til.set_halo_transport("peer")
+    csi.time_step(til, c["dt"])
+    assert til.clock.iteration == it + 1 and "u" in csi.prognostic_state(til)
+
+
 def test_peer_halo_transport_falls_back_and_can_be_switched_off():
     """Explicit exchange intervals run the RCCL exchange; csi_set_halo_transport(RCCL) switches the peer transport off; odd
     sub-step counts stay on it; all bit-identical."""
