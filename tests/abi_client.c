@@ -132,6 +132,14 @@ static int run(const char* in, const char* out) {
             if (r->count != elems[k]) { fprintf(stderr, "abi_client: %s has %lld elements, expected %lld\n", names[k], (long long)r->count, (long long)elems[k]); return 2; }
             HIP(hipMemcpy(dev[k], r->data, (size_t)elems[k] * 8, hipMemcpyHostToDevice));
         }
+        if (ids[k] == CSI_F_ALPHA) {
+            /* rheology_auxiliary_fields pre-fills alpha with max_relaxation_parameter (elasto_visco_plastic_rheology.jl:147-161): the
+             * outermost halo layer keeps that value (no kernel writes it) */
+            double* host = (double*)malloc((size_t)elems[k] * 8);
+            for (int64_t t = 0; t < elems[k]; ++t) host[t] = getd("evp", 5);
+            HIP(hipMemcpy(dev[k], host, (size_t)elems[k] * 8, hipMemcpyHostToDevice));
+            free(host);
+        }
         CHECK(ctx, csi_field_bind(ctx, ids[k], dev[k], ni, ni, nj));
     }
 
