@@ -419,6 +419,25 @@ def structure_record(csi, np, torch, device, substeps, quick=False):
     return out
 
 
+def config3_record(csi, np, torch, make_model, substeps, dt):
+    """BASELINE config 3 as written -- 1024^2 f-plane, EVP, 120 sub-cycles, one GPU -- beside the headline (which is the same workload on the
+    2048^2 grid the metric is quoted on): shorter tiles carry the same seven ring rows, so its rate is lower."""
+    grid, fld = local_case(csi, np, 1024, 1024, 1, 1, 0, halo=4)
+    m = make_model(grid)
+    csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
+    for _ in range(3):
+        csi.time_step_momentum(m, dt)
+    m.synchronize(); torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        csi.time_step_momentum(m, dt)
+    m.synchronize(); torch.cuda.synchronize()
+    e = (time.perf_counter() - t0) / n
+    return {"workload": f"evp_subcycle_fplane_periodic_1024x1024_{substeps}substeps", "value": 1024 * 1024 * substeps / e, "unit": "cell-updates/s",
+            "ms_per_step": 1e3 * e, "steps": n, "level": m.ctx.last_path()["level"]}
+
+
 def isa_mix():
     """Instruction mix of the dominant kernel's row loops from its ISA listing (scripts/isa_mix.py -> profiles/isa_mix_k_pair.json)."""
     f = os.path.join(ROOT, "profiles", "isa_mix_k_pair.json")
@@ -871,6 +890,9 @@ def main():
     if world == 1 and not tiled and not args.no_full_step and args.mode == "fast":
         advection = advection_record(csi, np, torch, device)
 
+    config3 = None
+    if world == 1 and not tiled and not args.tile and args.mode == "fast" and (nx_l, ny_l) != (1024, 1024) and not args.no_structure:
+        config3 = config3_record(csi, np, torch, make_model, args.substeps, dt)
     structure = None
     if world == 1 and not tiled and not args.no_structure and not args.tile and args.mode == "fast" and not args.no_fusion and args.fusion_level >= 2:
         structure = structure_record(csi, np, torch, device, args.substeps, quick=args.size < 2048)
@@ -1005,6 +1027,8 @@ def main():
     }
     if advection is not None:
         out["advection"] = advection
+    if config3 is not None:
+        out["config3_1024"] = config3
     if structure is not None:
         out["structure"] = structure
     if k1 is not None:

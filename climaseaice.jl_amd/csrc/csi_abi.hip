@@ -88,6 +88,7 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
         c->tune.peer_edge = env_int("CSI_PEER_EDGE");          // rows the chunks next to a peer-connected y side are shorter by (default 4; 0: uniform chunks)
         c->tune.write_through = env_int("CSI_WRITE_THROUGH");  // 0 / 1: never / always store the pair kernel's results write-through (default: by grid size)
         c->tune.adv_nt = env_int("CSI_ADV_NT"); c->tune.pair_target = env_int("CSI_PAIR_TARGET");
+        { const char* e = getenv("CSI_ADV_STAGE_MAX_CELLS"); if (e && *e) c->tune.adv_stage_max_cells = atol(e); }      // A/B: largest grid that takes one launch per RK stage
         { const int v = env_int("CSI_ROW_TARGET_1024"); if (v >= 0) c->tune.row_target_1024 = v; }      // 0: per-row coefficients keep 1536 tiles (rounds 3-5a)
         { const int v = env_int("CSI_TILE_SKIPPING"); if (v >= 0) c->act.enabled = v != 0; }      // A/B: the defaults of csi_set_tile_skipping / csi_set_row_constant
         { const int v = env_int("CSI_ROW_CONSTANT"); if (v >= 0) c->rc_enabled = v != 0; }
@@ -555,10 +556,12 @@ bool advect_stage_supported(const csi_context* c, int scheme) {
     const ImageSpec im = image_spec(c, CSI_F_H);
     for (int side : {im.xlo, im.xhi, im.ylo, im.yhi}) if (side != IMG_WRAP && side != IMG_MIRROR) return false;      // (periodic / no-flux walls)
     if (c->Nx < 2 * c->Hx || c->Ny < 2 * c->Hy) return false;
-    // measured (scripts/r03_adv_sizes.sh, WENO7, us per RK3 step, separate launches -> one per stage): 256^2 38 -> 23,
-    // 512^2 71 -> 55, 1024^2 219 -> 187, 1536^2 427 -> 384, 2048^2 768 -> 794: the separate update is a pure streaming kernel,
-    // which wins once the grid is large enough for launch latencies not to matter
-    if ((long)c->Nx * c->Ny > 3000000L) return false;
+    // Round 3 cut this path off above 3 M cells (2048^2: 768 -> 794 us per RK3 step with it).  Re-measured in round 6 with two tracers
+    // per thread and the round-5 block shapes (scripts/ab_adv_stage.sh, profiles/r06_advection_stage_ab.txt; WENO7, us per RK3 step,
+    // separate launches -> one per stage): 1536^2 314 -> 264, 2048^2 538 -> 476, 3072^2 1205 -> 988, 4096^2 2110 -> 1711 -- the
+    // separate update streams another 7 arrays per stage, which the fused stage never touches: no cut any more (A/B knob:
+    // CSI_ADV_STAGE_MAX_CELLS)
+    if ((long)c->Nx * c->Ny > c->tune.adv_stage_max_cells) return false;
     return !c->evp_set && scheme != 0 && c->fusion && !c->slab_set && !c->g.has_mask && !is_tiled(c) &&
            c->f[CSI_F_HS].p == nullptr && c->f[CSI_F_H].ld == c->f[CSI_F_HM].ld && c->f[CSI_F_A].ld == c->f[CSI_F_AM].ld;
 }

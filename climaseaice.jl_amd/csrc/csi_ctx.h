@@ -223,6 +223,7 @@ struct csi_context {
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, row_target_1024 = 0, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
                     adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
                     no_geom_sig = -1;      // debugging aid (CSI_DEBUG_NO_GEOM_SIG=1): skip the launch-geometry check of the peer set-up (tests/test_gpu_local_tiles.py)
+      long adv_stage_max_cells = 1L << 40;      // advection-only models: one launch per RK stage up to this many cells (advect_stage_supported; no cut since round 6)
     } tune;
 };
 

@@ -45,6 +45,11 @@ struct TileMap {
 };
 constexpr int TILE_X = 64, TILE_Y = 4;
 
+// One-wave workgroups are the fold band's launches (tile_map): they run BESIDE a pair launch and are the sub-cycle's critical
+// path on tripolar grids (six dependent launches per pair of sub-steps) -- their waves take the top issue priority.
+#ifndef CSI_BAND_PRIO
+#define CSI_BAND_PRIO 3
+#endif
 #define CELL_IJ(r, tm)                                                          \
     const int b_ = (int)blockIdx.x;                                             \
     const int t_ = (b_ & 7) * (tm).per_xcd + (b_ >> 3);                         \
@@ -52,7 +57,8 @@ constexpr int TILE_X = 64, TILE_Y = 4;
     const int by_ = t_ / (tm).gx, bx_ = t_ - by_ * (tm).gx;                     \
     const int i = (tm).ibase + bx_ * TILE_X + (int)threadIdx.x;                 \
     const int j = __builtin_amdgcn_readfirstlane((tm).jbase + by_ * (tm).ty + (int)threadIdx.y); \
-    if (i < (r).i0 || i > (r).i1 || j > (r).j1) return;
+    if (i < (r).i0 || i > (r).i1 || j > (r).j1) return;                         \
+    if (CSI_BAND_PRIO && (tm).ty == 1) __builtin_amdgcn_s_setprio(CSI_BAND_PRIO);
 
 __global__ void __launch_bounds__(256) k_init(EvpDev P, Range r) {
     const int i = r.i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);

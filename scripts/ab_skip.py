@@ -3,25 +3,12 @@ rows on and off, alternating.  python scripts/ab_skip.py <case> [N] [reps]   (ca
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "scripts")):
     sys.path.insert(0, p)
 import climaseaice_jl_amd as csi
 import cases
 
-CASES = {
-    "headline": dict(topo=("periodic", "periodic")),
-    "masked": dict(topo=("periodic", "bounded"), land=0.386),                     # config 5's mask (38.6 % land in discs)
-    "masked_seasonal": dict(topo=("periodic", "bounded"), land=0.386, ice_free_rows=(0.25, 0.75)),
-    "tripolar_like": dict(topo=("periodic", "folded"), curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True),
-    "tripolar": dict(grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), field_forcing=True, free_drift=True, coriolis_points=True),
-    "tripolar_seasonal": dict(grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), field_forcing=True, free_drift=True, coriolis_points=True,
-                              ice_edge=58.0),
-    "tripolar_land": dict(grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), land=0.3, field_forcing=True, free_drift=True, coriolis_points=True,
-                          ice_edge=58.0),
-    "arctic_cap": dict(grid="tripolar", tripolar=dict(southernmost_latitude=60.0, north_poles_latitude=65.0), field_forcing=True, free_drift=True),
-    "curvilinear": dict(topo=("periodic", "bounded"), curvilinear=0.05),
-    "latlon_as_full": dict(topo=("periodic", "bounded"), grid="latlon", curvilinear=0.0),
-}
+from structure_cases import CASES      # noqa: E402
 name = sys.argv[1]
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
