@@ -64,6 +64,22 @@ def test_baseline_instantiations_spill_no_vector_register(rows):
     assert not bad, bad
 
 
+def test_even_first_substep_instantiations_of_the_baseline_families(rows):
+    """`AUF = 1` (the pair's first sub-step is u-first) is what csi_evp_subcycle runs when a caller that keeps the Julia sub-step loop
+    starts a pair on an EVEN sub-step; csi_time_step_momentum starts at sub-step 1 and never selects it.  In the families the
+    BASELINE configurations use, those instantiations are held to the same budget as their AUF = 0 twins: no spilled vector register, the
+    occupancy of the family.  (Array forcing and per-point metrics: tests/golden/spill_table.json.)"""
+    seen = 0
+    for k, r in rows.items():
+        base = r["variant"] == 0 or (r["variant"] == 1 and not r["peer"] and not r["full"]) or \
+            (r["variant"] == 2 and not r["peer"] and not r["full"] and r["uni"] and r["cf"] >= 1)
+        if base and r["auf"]:
+            seen += 1
+            assert r["vgpr_spill"] == 0, (k, r["vgpr_spill"])
+            assert r["occupancy"] >= (2 if r["uni"] else 3), (k, r["occupancy"])
+    assert seen >= 12 + 6 + 2
+
+
 def test_spills_do_not_grow(rows):
     table = json.load(open(TABLE))
     worse = [(k, r["vgpr_spill"], table.get(k, {}).get("vgpr_spill")) for k, r in rows.items()
