@@ -448,7 +448,7 @@ def isa_mix():
         return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -484,90 +484,98 @@ def main():
     ap.add_argument("--no-second-partition", action="store_true", help="N > 1: do not time the other decomposition (2x4-style vs y slabs) after the headline")
     ap.add_argument("--partition", type=str, default="", help="RxxRy tiles instead of the default y slabs (e.g. 2x4: BASELINE config 4's decomposition); Rx * Ry = --gpus")
     ap.add_argument("--no-unfused", action="store_true", help="one GPU: do not time the unfused three-kernel path (roofline.unfused) after the headline")
-    ap.add_argument("--no-structure", action="store_true", help="one GPU: do not time the masked / tripolar configurations (`structure`) after the headline")
+    ap.add_argument("--no-structure", action="store_true", help="one GPU: do not time the masked / tripolar configurations (`structure`) and config 3's 1024^2 after the headline")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the tiled == untiled bitwise check and the one-GPU rate of the same grid")
-    args = ap.parse_args()
-    if args.gpus not in PARTITION:
-        raise SystemExit(f"--gpus must be one of {sorted(PARTITION)}")
-    if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1 or args.print_launch:
-            # the parent: nothing below this line has touched HIP (no torch.cuda call, no library load)
-            sys.exit(run_parent(args, sys.argv[1:]))
-    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {os.environ['WORLD_SIZE']}: start N ranks with --gpus N "
-                         f"(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), or run `python bench.py --gpus N` alone")
+    return ap.parse_args(argv)
 
-    if args.self_test_launch:
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
-        t = torch.ones(1)
-        dist.all_reduce(t)
-        if dist.get_rank() == 0:
-            print(json.dumps({"metric": "self-test of the bench.py launcher", "self_test": True, "n_gpus": int(t.item()),
-                              "launched_by_parent": os.environ.get("CSI_BENCH_LAUNCHED_BY_PARENT") == "1"}), flush=True)
-        dist.destroy_process_group()
-        return
 
-    import numpy as np
+def self_test_launch():
+    """Host test of the launcher (no GPU): the ranks rendezvous over gloo, rank 0 prints a stub line."""
     import torch
-    import climaseaice_jl_amd as csi
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"metric": "self-test of the bench.py launcher", "self_test": True, "n_gpus": int(t.item()),
+                          "launched_by_parent": os.environ.get("CSI_BENCH_LAUNCHED_BY_PARENT") == "1"}), flush=True)
+    dist.destroy_process_group()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    rehearsal = bool(args.rehearse_on_one_gpu and world > 1)
-    if rehearsal:
-        local_rank = 0                                     # every rank on GPU 0
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but {torch.cuda.device_count()} are visible")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo")
+
+class Rank:
+    """One rank of the benchmark: its process-group plumbing, its tile of the metric's grid, the model being timed (`model`: the
+    helpers below act on whichever model is current) and the one-GPU copy of the whole grid it is checked against (`whole`)."""
+    SIG = ("s11", "s22", "s12")
+
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import climaseaice_jl_amd as csi
+        self.args, self.np, self.torch, self.csi = args, np, torch, csi
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.rehearsal = bool(args.rehearse_on_one_gpu and self.world > 1)
+        if self.rehearsal:
+            local_rank = 0                                     # every rank on GPU 0
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {self.rank} needs GPU {local_rank} but {torch.cuda.device_count()} are visible")
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            self.dist = dist
+        self.coll_device = "cpu" if self.rehearsal else None             # gloo reduces host tensors
+        self.Rx, self.Ry = PARTITION[self.world]
+        if args.partition:
+            self.Rx, self.Ry = (int(t) for t in args.partition.lower().split("x"))
+            if self.Rx * self.Ry != self.world:
+                raise SystemExit(f"--partition {args.partition}: {self.Rx} x {self.Ry} tiles but {self.world} rank(s)")
+        if args.tile:
+            self.nx_l, self.ny_l = (int(s) for s in args.tile.lower().split("x"))
+        elif args.scaling == "weak":
+            self.nx_l = self.ny_l = args.size
         else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    coll_device = "cpu" if rehearsal else None             # gloo reduces host tensors
-    Rx, Ry = PARTITION[world]
-    if args.partition:
-        Rx, Ry = (int(t) for t in args.partition.lower().split("x"))
-        if Rx * Ry != world:
-            raise SystemExit(f"--partition {args.partition}: {Rx} x {Ry} tiles but {world} rank(s)")
-    if args.tile:
-        nx_l, ny_l = (int(s) for s in args.tile.lower().split("x"))
-    elif args.scaling == "weak":
-        nx_l = ny_l = args.size
-    else:
-        if args.size % Rx or args.size % Ry:
-            raise SystemExit("--size must be divisible by the partition")
-        nx_l, ny_l = args.size // Rx, args.size // Ry
-    tiled = world > 1 or args.force_connected
-    user_halo = args.halo
-    device = f"cuda:{local_rank}"
+            if args.size % self.Rx or args.size % self.Ry:
+                raise SystemExit("--size must be divisible by the partition")
+            self.nx_l, self.ny_l = args.size // self.Rx, args.size // self.Ry
+        self.tiled = self.world > 1 or args.force_connected
+        self.user_halo = args.halo
+        self.device = f"cuda:{local_rank}"
+        self.dt = 120.0
+        self.builds = 0
+        self.region = {}
+        self.model = self.whole = self.gf = None
+        self.gN = (self.nx_l * self.Rx, self.ny_l * self.Ry)
+        self.owned = self.nx_l * self.ny_l * self.world
 
-    def make_model(grid):
+    # ---- models ------------------------------------------------------------------------------------------------------------------
+    def make_model(self, grid):
+        csi, args = self.csi, self.args
         dyn = csi.SeaIceMomentumEquation(grid, coriolis=csi.FPlane(f=1e-4), rheology=csi.ElastoViscoPlasticRheology(),
                                          top_momentum_stress=(0.01, 0.01), bottom_momentum_stress=csi.SemiImplicitStress(),
-                                         solver=csi.SplitExplicitSolver(substeps=args.substeps), device=device)
-        return csi.SeaIceModel(grid, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=device, mode=args.mode)
+                                         solver=csi.SplitExplicitSolver(substeps=args.substeps), device=self.device)
+        return csi.SeaIceModel(grid, dynamics=dyn, advection=csi.WENO(order=7), timestepper="SplitRungeKutta3", device=self.device, mode=args.mode)
 
-    nonlocal_builds = [0]
-
-    def build(transport, part=None):
+    def build(self, transport, part=None):
         """This rank's tile model.  Tiles: the peer transport needs the halo 4 of an untiled run; the RCCL exchange amortises its
         pack / send / unpack over k = 16 sub-steps with halo 32.  part = (Rx, Ry, nx, ny): another decomposition of the same grid."""
-        halo = user_halo or (4 if (not tiled or transport == "peer") else 32)
-        pRx, pRy, pnx, pny = part or (Rx, Ry, nx_l, ny_l)
-        grid, fld = local_case(csi, np, pnx, pny, pRx, pRy, rank, force_connected=args.force_connected, halo=halo)
-        if rehearsal:
-            nonlocal_builds[0] += 1
+        args, csi = self.args, self.csi
+        halo = self.user_halo or (4 if (not self.tiled or transport == "peer") else 32)
+        pRx, pRy, pnx, pny = part or (self.Rx, self.Ry, self.nx_l, self.ny_l)
+        grid, fld = local_case(csi, self.np, pnx, pny, pRx, pRy, self.rank, force_connected=args.force_connected, halo=halo)
+        if self.rehearsal:
+            self.builds += 1
             # (a fresh segment per model -- every rank builds its models in the same order; without the parent the name comes from
             #  the rendezvous port, which is the same on every rank of a job)
             base = os.environ.get("CSI_BENCH_HOST_GROUP") or f"/csi-bench-{os.environ.get('MASTER_PORT', '0')}-{os.getppid()}"      # (the ranks of one launcher share their parent: no name of an earlier job)
-            grid.host_group = f"{base}-{nonlocal_builds[0]}"
-        m = make_model(grid)
+            grid.host_group = f"{base}-{self.builds}"
+        m = self.make_model(grid)
         m.set_exchange_interval(args.exchange_interval)
         m.set_halo_transport(transport)
         if args.peer_tier >= 0:
@@ -576,163 +584,146 @@ def main():
         csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
         return grid, fld, m, halo
 
-    tg, f, model, args.halo = build(args.transport)
-    dt = 120.0
+    # ---- collectives and timing (they act on self.model) ------------------------------------------------------------------------
+    def barrier(self):
+        self.model.synchronize()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
 
-    def barrier():
-        model.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    def max_over_ranks(x):
-        if dist is None:
+    def max_over_ranks(self, x):
+        if self.dist is None:
             return x
-        t = torch.tensor([x], device=coll_device or device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = self.torch.tensor([x], device=self.coll_device or self.device, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    region = {}
+    def all_ranks(self, flag):
+        """logical AND over the ranks"""
+        if self.dist is None:
+            return bool(flag)
+        t = self.torch.tensor([1.0 if flag else 0.0], device=self.coll_device or self.device, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
 
-    def timed(nsteps, stats=False):
+    def timed(self, nsteps, stats=False):
         """K steps between two barriers, max over the ranks.  stats: HIP events around every sub-step loop INSIDE this region
         (csi_subcycle_stats_*): the dominant kernel's average launch time then comes from the timed launches themselves."""
-        barrier()
+        self.barrier()
         if stats:
-            model.ctx.subcycle_stats_begin()
+            self.model.ctx.subcycle_stats_begin()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            csi.time_step_momentum(model, dt)
-        barrier()
-        e = max_over_ranks(time.perf_counter() - t0)
+            self.csi.time_step_momentum(self.model, self.dt)
+        self.barrier()
+        e = self.max_over_ranks(time.perf_counter() - t0)
         if stats:
-            tot, ncyc, nl = model.ctx.subcycle_stats_end()
-            region.update(total_ms=tot, cycles=ncyc, launches=nl)
+            tot, ncyc, nl = self.model.ctx.subcycle_stats_end()
+            self.region.update(total_ms=tot, cycles=ncyc, launches=nl)
         return e
 
-    def all_ranks(flag):
-        """logical AND over the ranks"""
-        if dist is None:
-            return bool(flag)
-        t = torch.tensor([1.0 if flag else 0.0], device=coll_device or device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item() > 0.5)
+    def rate(self, e):
+        return self.owned * self.args.substeps * self.args.steps / e
 
     # ---- N > 1: the same job on ONE GPU, in the same run: its answer (every rank advances the whole grid alone from the same
     # state; its own tile must come out bit for bit) and, after the timed region, its rate (parallel_efficiency) -----------------
-    whole = None
-    gN = (nx_l * Rx, ny_l * Ry)
-    sig = ("s11", "s22", "s12")
-
-    def restart(m, fld):
-        csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
-        for name in sig:
+    def restart(self, m, fld):
+        self.csi.set_(m, h=fld["h"], aice=fld["a"], u=fld["u"], v=fld["v"])
+        for name in self.SIG:
             getattr(m.dynamics.auxiliaries.fields, name).data.zero_()
         # torch zeroes on ITS stream, the library packs / launches on its own: without this a rank's halo message could carry the sigma of
         # the previous run (seen once, round 5: N processes sharing one GPU in the rehearsal reorder the two streams more readily)
-        torch.cuda.synchronize()
+        self.torch.cuda.synchronize()
 
-    def tile_matches_whole(m=None, grid=None, fld=None, gfld=None):
+    def tile_matches_whole(self, m=None, grid=None, fld=None, gfld=None):
         """One sub-cycle from the same state on the tiles and on the whole grid: owned cells bitwise equal (all ranks agree).
         (gfld: the global state assembled from THAT decomposition's tiles -- the noise of the inputs is seeded per tile.)"""
-        m = model if m is None else m
-        grid = tg if grid is None else grid
-        fld = f if fld is None else fld
-        restart(whole, gf if gfld is None else gfld)
-        restart(m, fld)
-        csi.time_step_momentum(whole, dt)
-        csi.time_step_momentum(m, dt)
+        csi, np, whole = self.csi, self.np, self.whole
+        m = self.model if m is None else m
+        grid = self.tg if grid is None else grid
+        fld = self.f if fld is None else fld
+        self.restart(whole, self.gf if gfld is None else gfld)
+        self.restart(m, fld)
+        csi.time_step_momentum(whole, self.dt)
+        csi.time_step_momentum(m, self.dt)
         m.synchronize(); whole.synchronize()
         same = True
         for name, tf, wf in [("u", m.velocities.u, whole.velocities.u), ("v", m.velocities.v, whole.velocities.v)] + \
-                            [(n, getattr(m.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in sig]:
+                            [(n, getattr(m.dynamics.auxiliaries.fields, n), getattr(whole.dynamics.auxiliaries.fields, n)) for n in self.SIG]:
             mine = tf.interior_numpy()[:grid.Ny, :grid.Nx]
             ref = wf.interior_numpy()[grid.j_off:grid.j_off + grid.Ny, grid.i_off:grid.i_off + grid.Nx]
             same = same and bool(np.array_equal(mine, ref))
         return same
 
-    verify = world > 1 and not args.no_verify
+
+def warm_up_and_verify(R):
+    """Warm-up, then (N > 1) the bitwise check -- before anything is timed -- with the run-time ladder of the peer protocol
+    (include/csi.h, csi_set_peer_tier): it starts at the tier the library chooses by itself (1 as soon as a neighbour lives in another
+    process or on another device; --peer-tier overrides) and goes up to 2, then to the RCCL exchange.  A BITWISE mismatch raises the
+    tier; a library error (a wait that timed out: sticky, the flags cannot recover) goes straight to the RCCL exchange on freshly
+    built models.  Returns (verify, bitwise, ladder, transport_note)."""
+    args, csi = R.args, R.csi
+    verify = R.world > 1 and not args.no_verify
     if verify:
-        gg = csi.RectilinearGrid(gN, x=(0.0, gN[0] * 2000.0), y=(0.0, gN[1] * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
-        whole = make_model(gg)
-        whole.set_fusion(0 if args.no_fusion else args.fusion_level)
-        gf = global_fields(np, nx_l, ny_l, Rx, Ry)
+        gg = csi.RectilinearGrid(R.gN, x=(0.0, R.gN[0] * 2000.0), y=(0.0, R.gN[1] * 2000.0), topology=(csi.Periodic, csi.Periodic), halo=(4, 4))
+        R.whole = R.make_model(gg)
+        R.whole.set_fusion(0 if args.no_fusion else args.fusion_level)
+        R.gf = global_fields(R.np, R.nx_l, R.ny_l, R.Rx, R.Ry)
     transport_note = None
     bitwise = None
-    # run-time ladder of the peer protocol (include/csi.h, csi_set_peer_tier): it starts at the tier the library chooses by itself (1
-    # as soon as a neighbour lives in another process or on another device; --peer-tier overrides) and goes up to 2, then to the RCCL
-    # exchange.  A BITWISE mismatch raises the tier; a library error (a wait that timed out: sticky, the flags cannot recover) goes
-    # straight to the RCCL exchange on freshly built models (ADVICE round 4).
     peer_tier = None
     ladder = []
-    peer_expected = tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
-        and not args.no_fusion and args.fusion_level >= 2 and nx_l >= 128
+    peer_expected = R.tiled and args.transport == "peer" and args.exchange_interval == 0 and args.substeps % 2 == 0 and args.mode == "fast" \
+        and not args.no_fusion and args.fusion_level >= 2 and R.nx_l >= 128
     while True:
-        # warm-up, then (N > 1) the bitwise check -- before anything is timed.  A peer transport that cannot be set up (the library
-        # then runs RCCL by itself), times out or gives another answer than one GPU is replaced by the RCCL exchange on ALL ranks.
+        # A peer transport that cannot be set up (the library then runs RCCL by itself), times out or gives another answer than one
+        # GPU is replaced by the RCCL exchange on ALL ranks.
         problem = None
         lib_error = False
-        if peer_tier is None and tiled:
-            peer_tier = model.ctx.peer_tier()
+        if peer_tier is None and R.tiled:
+            peer_tier = R.model.ctx.peer_tier()
         try:
             for _ in range(args.warmup):
-                csi.time_step_momentum(model, dt)
-            model.synchronize()
-            if peer_expected and model.ctx.halo_transport() != "peer":
+                csi.time_step_momentum(R.model, R.dt)
+            R.model.synchronize()
+            if peer_expected and R.model.ctx.halo_transport() != "peer":
                 problem = "the peer transport could not be set up on this node"
             elif verify:
-                bitwise = tile_matches_whole()
+                bitwise = R.tile_matches_whole()
                 if not bitwise:
                     problem = "the tiled run did not reproduce the one-GPU run bit for bit"
         except csi.CsiError as e:
             problem = f"library error: {e}"
             lib_error = True
-        on_peer = tiled and model.ctx.halo_transport() == "peer"
+        on_peer = R.tiled and R.model.ctx.halo_transport() == "peer"
         if on_peer:
             ladder.append({"tier": peer_tier, "passed": problem is None, "problem": problem})
-        if all_ranks(problem is None):
+        if R.all_ranks(problem is None):
             break
-        if all_ranks(on_peer) and all_ranks(not lib_error) and peer_tier < 2:
+        if R.all_ranks(on_peer) and R.all_ranks(not lib_error) and peer_tier < 2:
             # every rank is on the peer transport and some rank's check failed: the next tier of its memory-ordering protocol, on ALL ranks
             peer_tier += 1
-            sys.stderr.write(f"bench.py[rank {rank}]: peer transport, tier {peer_tier - 1}: {problem or 'another rank reported a problem'}; trying tier {peer_tier}\n")
-            model.set_peer_tier(peer_tier)
+            sys.stderr.write(f"bench.py[rank {R.rank}]: peer transport, tier {peer_tier - 1}: {problem or 'another rank reported a problem'}; trying tier {peer_tier}\n")
+            R.model.set_peer_tier(peer_tier)
             continue
-        if model.ctx.halo_transport() == "peer" or (peer_expected and transport_note is None):
+        if R.model.ctx.halo_transport() == "peer" or (peer_expected and transport_note is None):
             transport_note = f"peer transport given up ({problem or 'another rank reported a problem'}): RCCL exchange (halo 32, k = 16) timed instead"
-            sys.stderr.write(f"bench.py[rank {rank}]: {transport_note}\n")
+            sys.stderr.write(f"bench.py[rank {R.rank}]: {transport_note}\n")
             peer_expected = False
-            model = None
-            tg, f, model, args.halo = build("rccl")
+            R.model = None
+            R.tg, R.f, R.model, args.halo = R.build("rccl")
             continue
-        raise SystemExit(f"bench.py[rank {rank}]: invalid run: {problem or 'another rank reported a problem'}")
+        raise SystemExit(f"bench.py[rank {R.rank}]: invalid run: {problem or 'another rank reported a problem'}")
     if verify:
-        restart(model, f)                                  # the timed steps start from the seeded state again
+        R.restart(R.model, R.f)                                  # the timed steps start from the seeded state again
         for _ in range(max(args.warmup, 1)):
-            csi.time_step_momentum(model, dt)
-    barrier()
-    # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
-    # below is the last thing this process writes
-    ctypes.CDLL(None).fflush(None)
-    elapsed = timed(args.steps, stats=True)
-    # the clock / power sampler reads sysfs from a Python thread: it runs over a REPETITION of the timed loop right behind it, so that
-    # the headline region holds the launch loop alone, as in rounds 1-4 (ADVICE round 5)
-    with ClockSampler(local_rank) as clock:
-        timed(args.steps)
+            csi.time_step_momentum(R.model, R.dt)
+    return verify, bitwise, ladder, transport_note
 
-    owned = nx_l * ny_l * world
-    value = owned * args.substeps * args.steps / elapsed
-    subcycle_ms = model.ctx.last_subcycle_ms()            # HIP events on the launch stream, last step
-    path = model.ctx.last_path()
-    path["halo_transport"] = model.ctx.halo_transport() if tiled else "none"
-    if transport_note:
-        path["halo_transport_note"] = transport_note
-    if tiled and path["halo_transport"] == "peer":
-        path["peer_tier"] = model.ctx.peer_tier()
-    if ladder:
-        path["peer_tier_ladder"] = ladder          # which tiers were tried before the timed region, and what each check said
 
-    # ---- result check (outside the timed region): the state the timed steps produced is finite and non-trivial -------
+def result_check(R):
+    """Outside the timed region: the state the timed steps produced is finite and non-trivial (on every rank)."""
+    torch, model = R.torch, R.model
     model.synchronize()
     chk = {}
     for name, fld in (("u", model.velocities.u), ("v", model.velocities.v), ("s11", model.dynamics.auxiliaries.fields.s11)):
@@ -741,16 +732,110 @@ def main():
                      "nonzero_frac": float((t != 0).double().mean().item())}
     ok = all(c["finite"] for c in chk.values()) and 0 < chk["u"]["max_abs"] < 10.0 and chk["u"]["nonzero_frac"] > 0.5 \
         and chk["s11"]["max_abs"] > 0
-    if dist is not None:
-        t = torch.tensor([1.0 if ok else 0.0], device=coll_device or device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(t.item() > 0.5)
-    if not ok:
+    if not R.all_ranks(ok):
         raise SystemExit(f"bench.py: the timed steps left a non-finite or trivial state: {chk}")
+    return chk
 
-    # ---- outside the timed region: per-kernel HIP-event times (roofline) and whole model steps ------------------------
-    phases = model.ctx.profile_substeps(dt, 32)
-    cells_launch = nx_l * ny_l
+
+def unfused_record(R):
+    """The SURVEY.md 8(d)-literal figure, measured in the SAME run (outside the headline region): the unfused three-kernel FAST path
+    (k_stress, k_ustep, k_vstep: every array crosses HBM once per phase) moves the contract's 256 B per cell-update, so
+    cell-updates/s x 256 B is a roofline fraction in the contract's own terms (< 1); the fused kernels do the same work on fewer bytes
+    (their `frac` is priced on their own compulsory bytes)."""
+    args, csi, torch = R.args, R.csi, R.torch
+    nx_l, ny_l = R.nx_l, R.ny_l
+    grid_u, fld_u = local_case(csi, R.np, nx_l, ny_l, R.Rx, R.Ry, R.rank, halo=args.halo)
+    mu = R.make_model(grid_u)
+    mu.set_fusion(0)
+    csi.set_(mu, h=fld_u["h"], aice=fld_u["a"], u=fld_u["u"], v=fld_u["v"])
+    csi.time_step_momentum(mu, R.dt)
+    mu.synchronize(); torch.cuda.synchronize()
+    nun = max(2, min(args.steps, 3))
+    t0u = time.perf_counter()
+    for _ in range(nun):
+        csi.time_step_momentum(mu, R.dt)
+    mu.synchronize(); torch.cuda.synchronize()
+    eu = time.perf_counter() - t0u
+    vu = nx_l * ny_l * args.substeps * nun / eu
+    phu = mu.ctx.profile_substeps(R.dt, 16)
+    return {"value": vu, "unit": "cell-updates/s", "ms_per_step": 1e3 * eu / nun, "steps": nun,
+            "kernels": "csi::fast::k_stress + k_ustep + k_vstep (three launches per sub-step)",
+            "algorithmic_bytes_per_cell_update": 256.0, "achieved": vu * 256.0 / 1e9, "unit_achieved": "GB/s",
+            "frac": vu * 256.0 / 1e9 / HBM_PEAK_GBS, "frac_of_achievable": vu * 256.0 / 1e9 / HBM_ACHIEVABLE_GBS,
+            "phases_ms": {k: phu[k] for k in ("stress", "ustep", "vstep")},
+            "phase_fracs": {k: nx_l * ny_l * ALGO_BYTES[k] / (phu[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in ("stress", "ustep", "vstep") if phu[k] > 0},
+            "note": "SURVEY.md 8(d) formula on the path that moves those bytes; same grid, same run, outside the timed region"}
+
+
+def counters_into_roofline(R, roof, dom, launch_s, kernel_bytes):
+    """PMC evidence of a committed rocprofv3 run of this kernel (scripts/same_lease_profile.sh): bytes and instruction counts per launch
+    are properties of the kernel; FRACTIONS of a roof need a time, and only this run's own clock is used for that -- and only when
+    this box runs the kernel as fast as the box the counters were taken on (within 5 %), otherwise the fractions are withheld rather
+    than mixed across machines."""
+    ctr = counters()
+    if not (ctr and R.world == 1 and not R.tiled and (R.nx_l, R.ny_l) == (2048, 2048) and R.args.mode == "fast" and ctr.get("kernel") == dom):
+        return
+    roof["traffic"] = ctr.get("hbm_bytes_per_launch")
+    roof["traffic_source"] = ctr.get("source", "profiles/counters_latest.json") + " (rocprofv3 --pmc passes; bytes per launch of this kernel, not re-measured by bench.py)"
+    ref_us = (ctr.get("same_lease_bench") or {}).get("avg_launch_us") or ctr.get("avg_launch_us")
+    same_speed = ref_us is not None and abs(launch_s * 1e6 - ref_us) <= 0.05 * ref_us
+    if ctr.get("valu_insts_per_launch"):
+        # third view: the kernel's vector instructions per launch (a property of the kernel, from the counters) at the FP64 issue
+        # interval this chip sustains, over THIS run's launch time.  A lower bound of the true share: the ~5 % of them that
+        # are v_rcp_f64 / v_rsq_f64 take 3 x as long (profiles/r04b_full_metric_kernel.md section 4)
+        roof["fp64_issue_frac"] = ctr["valu_insts_per_launch"] * FP64_ISSUE_NS * 1e-9 / 1024.0 / launch_s
+        roof["fp64_issue_note"] = (f"{ctr['valu_insts_per_launch'] / 1e6:.1f} M vector instructions per launch x {FP64_ISSUE_NS} ns (measured FP64 issue interval per SIMD, "
+                                   "profiles/r01_microbenchmarks.md) / 1024 SIMDs / this run's launch time")
+        dyn = ctr.get("valu_mix_per_launch")
+        if dyn:
+            # the same from the DYNAMIC mix (PMC pass SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64, same committed counter run): every
+            # class at its measured issue interval (profiles/r01_microbenchmarks.md): fma / mul 2.29 ns, add 2.00, transcendental
+            # (v_rcp_f64 / v_rsq_f64) 7.03, integer 1.31, the rest (DPP shifts, compares, selects, 64-bit moves) 2.0
+            w = {"fma_f64": 2.29, "mul_f64": 2.29, "add_f64": 2.00, "trans_f64": 7.03, "int32": 1.31, "int64": 1.79, "other": 2.0}
+            busy_ns = sum(dyn.get(k, 0.0) * w[k] for k in w)
+            roof["fp64_issue_frac_dynamic"] = busy_ns * 1e-9 / 1024.0 / launch_s
+            roof["fp64_issue_dynamic_mix"] = {"per_launch": dyn, "issue_ns": w}
+        mix = isa_mix()
+        if mix and mix.get("kernel") == dom:
+            # the same with every class of vector instruction at ITS measured issue interval (profiles/r01_microbenchmarks.md
+            # `valu_rate` at >= 2 waves per SIMD): v_rcp_f64 / v_rsq_f64 take 7.03 ns, FP64 fma / mul 2.29, add 2.00, max / min /
+            # compares 1.9-2.2, DPP shifts 2.18, 64-bit moves 1.79, 32-bit 1.31.  Shares from the ISA listing of this
+            # instantiation (scripts/isa_mix.py, static counts of the two row loops).
+            ns = sum(mix["share"][k] * mix["issue_ns"][k] for k in mix["share"])
+            roof["fp64_issue_frac_weighted"] = ctr["valu_insts_per_launch"] * ns * 1e-9 / 1024.0 / launch_s
+            roof["fp64_issue_mix"] = {"share": mix["share"], "issue_ns": mix["issue_ns"], "mean_issue_ns": ns,
+                                      "valu_per_stage_row": mix.get("valu_per_stage_row"), "source": mix.get("source")}
+    # the same fraction at the launch time the kernel has in the committed rocprofv3 kernel trace of the counters' lease: a reader who
+    # divides the compulsory bytes by the trace's average duration gets this number (round 5's trace was a cold 3-step run, 12 % slow:
+    # profiles/r06_profiler_vs_bench.md; a warm trace agrees with `frac`)
+    if ctr.get("avg_launch_us"):
+        roof["frac_under_profiler"] = kernel_bytes / (ctr["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        roof["frac_under_profiler_note"] = (f"{KERNEL_BYTES[dom]:.0f} B x cells / {ctr['avg_launch_us']:.1f} us (rocprofv3 --kernel-trace average of the timed launches, "
+                                            f"{ctr.get('source', 'profiles/counters_latest.json')}) / 8 TB/s")
+    roof["counters_run_launch_us"] = ref_us
+    roof["counters_run_matches_this_box"] = bool(same_speed)
+    if same_speed:
+        if ctr.get("hbm_bytes_per_launch"):
+            roof["traffic_frac"] = ctr["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBS
+        # second roof: FP64 vector issue.  valu_frac = share of the SIMDs' VALU issue time the launch used, from the
+        # same counter passes: SQ_ACTIVE_INST_VALU (quad-cycles, summed over SIMDs) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+        if ctr.get("valu_busy_frac") is not None:
+            roof["valu_frac"] = ctr["valu_busy_frac"]
+            roof["valu_insts_per_launch"] = ctr.get("valu_insts_per_launch")
+            roof["valu_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), PMC pass of the counters' run"
+    else:
+        roof["traffic_note"] = (f"this box runs the kernel in {launch_s * 1e6:.1f} us per launch, the counters' run took {ref_us:.1f} us: "
+                                "traffic_frac / valu_frac withheld (not the same speed)")
+
+
+def roofline_record(R, path, clock):
+    """`roofline` of the dominant kernel: per-kernel HIP-event times outside the timed region (csi_profile_substeps) for the three-kernel
+    paths; for the fused kernels the average launch time of the TIMED region itself (round 5): HIP events around every sub-step loop of the
+    K timed steps, divided by the launches inside them -- so that launches x average <= ms_per_step holds by construction.  The figure of the
+    separate profiling pass (a short run behind the timed region, 10-15 % colder) stays in the line as `profile_pass_launch_ms`."""
+    args, model, region = R.args, R.model, R.region
+    phases = model.ctx.profile_substeps(R.dt, 32)
+    cells_launch = R.nx_l * R.ny_l
     spl = 1.0                                             # sub-steps per launch of the dominant kernel
     if path["fused"]:
         launches, nsub = model.ctx.last_launches()
@@ -761,10 +846,6 @@ def main():
     else:
         dom = max(("stress", "ustep", "vstep"), key=lambda k: phases[k])
         sub_ms = phases["stress"] + phases["ustep"] + phases["vstep"]
-    # The dominant kernel's average launch time comes from the TIMED region (round 5): HIP events around every sub-step loop of the
-    # K timed steps, divided by the launches inside them -- so that launches x average <= ms_per_step holds by construction.  The
-    # figure of the separate profiling pass above (a short run behind the timed region, 10-15 % colder) stays in the line as
-    # `profile_pass_launch_ms`; the three-kernel paths, whose loops mix three kernels, keep their per-kernel events.
     profile_pass_ms = phases[dom]
     launch_src = "csi_profile_substeps: a separate pass of 32 sub-steps behind the timed region"
     if path["fused"] and region.get("launches"):
@@ -793,224 +874,210 @@ def main():
             "algorithmic_note": "SURVEY.md 8(d): 256 B per cell-update of the unfused stress / u / v split; above 1 = traffic removed by fusion",
             "substep_ms": sub_ms}
     roof["frac_of_achievable"] = achieved / HBM_ACHIEVABLE_GBS
-    # the clock and the power the timed launches ran at (rank 0's GPU): 2048^2 sits at the board's power cap, below the 2.4 GHz the
-    # issue intervals of FP64_ISSUE_NS were measured near; small tiles do not (profiles/r05_power_clock.md)
+    # the clock and the power the launches ran at (rank 0's GPU, sampled over a repetition of the timed loop): 2048^2 sits at the board's
+    # power cap, below the 2.4 GHz the issue intervals of FP64_ISSUE_NS were measured near; small tiles do not (profiles/r05_power_clock.md)
     roof["clock"] = clock.summary()
-    # ---- the SURVEY.md 8(d)-literal figure, measured in the SAME run (outside the headline region): the unfused three-kernel FAST
-    # path (k_stress, k_ustep, k_vstep: every array crosses HBM once per phase) moves the contract's 256 B per cell-update, so
-    # cell-updates/s x 256 B is a roofline fraction in the contract's own terms (< 1); the fused kernels above do the same work
-    # on fewer bytes (their `frac` is priced on their own compulsory bytes)
-    if world == 1 and not tiled and args.mode == "fast" and path["fused"] and not args.no_unfused:
-        grid_u, fld_u = local_case(csi, np, nx_l, ny_l, Rx, Ry, rank, halo=args.halo)
-        mu = make_model(grid_u)
-        mu.set_fusion(0)
-        csi.set_(mu, h=fld_u["h"], aice=fld_u["a"], u=fld_u["u"], v=fld_u["v"])
-        csi.time_step_momentum(mu, dt)
-        mu.synchronize(); torch.cuda.synchronize()
-        nun = max(2, min(args.steps, 3))
-        t0u = time.perf_counter()
-        for _ in range(nun):
-            csi.time_step_momentum(mu, dt)
-        mu.synchronize(); torch.cuda.synchronize()
-        eu = time.perf_counter() - t0u
-        vu = nx_l * ny_l * args.substeps * nun / eu
-        phu = mu.ctx.profile_substeps(dt, 16)
-        roof["unfused"] = {"value": vu, "unit": "cell-updates/s", "ms_per_step": 1e3 * eu / nun, "steps": nun,
-                           "kernels": "csi::fast::k_stress + k_ustep + k_vstep (three launches per sub-step)",
-                           "algorithmic_bytes_per_cell_update": 256.0, "achieved": vu * 256.0 / 1e9, "unit_achieved": "GB/s",
-                           "frac": vu * 256.0 / 1e9 / HBM_PEAK_GBS, "frac_of_achievable": vu * 256.0 / 1e9 / HBM_ACHIEVABLE_GBS,
-                           "phases_ms": {k: phu[k] for k in ("stress", "ustep", "vstep")},
-                           "phase_fracs": {k: nx_l * ny_l * ALGO_BYTES[k] / (phu[k] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in ("stress", "ustep", "vstep") if phu[k] > 0},
-                           "note": "SURVEY.md 8(d) formula on the path that moves those bytes; same grid, same run, outside the timed region"}
-        mu = None
-    ctr = counters()
-    if ctr and world == 1 and not tiled and (nx_l, ny_l) == (2048, 2048) and args.mode == "fast" and ctr.get("kernel") == dom:
-        # PMC evidence of a committed rocprofv3 run of this kernel (scripts/same_lease_profile.sh): bytes and instruction counts per
-        # launch are properties of the kernel; FRACTIONS of a roof need a time, and only this run's own clock is used for that --
-        # and only when this box runs the kernel as fast as the box the counters were taken on (within 5 %), otherwise the
-        # fractions are withheld rather than mixed across machines
-        roof["traffic"] = ctr.get("hbm_bytes_per_launch")
-        roof["traffic_source"] = ctr.get("source", "profiles/counters_latest.json") + " (rocprofv3 --pmc passes; bytes per launch of this kernel, not re-measured by bench.py)"
-        ref_us = (ctr.get("same_lease_bench") or {}).get("avg_launch_us") or ctr.get("avg_launch_us")
-        same_speed = ref_us is not None and abs(launch_s * 1e6 - ref_us) <= 0.05 * ref_us
-        if ctr.get("valu_insts_per_launch"):
-            # third view: the kernel's vector instructions per launch (a property of the kernel, from the counters) at the FP64 issue
-            # interval this chip sustains, over THIS run's launch time.  A lower bound of the true share: the ~5 % of them that
-            # are v_rcp_f64 / v_rsq_f64 take 3 x as long (profiles/r04b_full_metric_kernel.md section 4)
-            roof["fp64_issue_frac"] = ctr["valu_insts_per_launch"] * FP64_ISSUE_NS * 1e-9 / 1024.0 / launch_s
-            roof["fp64_issue_note"] = (f"{ctr['valu_insts_per_launch'] / 1e6:.1f} M vector instructions per launch x {FP64_ISSUE_NS} ns (measured FP64 issue interval per SIMD, "
-                                       "profiles/r01_microbenchmarks.md) / 1024 SIMDs / this run's launch time")
-            dyn = ctr.get("valu_mix_per_launch")
-            if dyn:
-                # the same from the DYNAMIC mix (PMC pass SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64, same committed counter run): every
-                # class at its measured issue interval (profiles/r01_microbenchmarks.md): fma / mul 2.29 ns, add 2.00, transcendental
-                # (v_rcp_f64 / v_rsq_f64) 7.03, integer 1.31, the rest (DPP shifts, compares, selects, 64-bit moves) 2.0
-                w = {"fma_f64": 2.29, "mul_f64": 2.29, "add_f64": 2.00, "trans_f64": 7.03, "int32": 1.31, "int64": 1.79, "other": 2.0}
-                busy_ns = sum(dyn.get(k, 0.0) * w[k] for k in w)
-                roof["fp64_issue_frac_dynamic"] = busy_ns * 1e-9 / 1024.0 / launch_s
-                roof["fp64_issue_dynamic_mix"] = {"per_launch": dyn, "issue_ns": w}
-            mix = isa_mix()
-            if mix and mix.get("kernel") == dom:
-                # the same with every class of vector instruction at ITS measured issue interval (profiles/r01_microbenchmarks.md
-                # `valu_rate` at >= 2 waves per SIMD): v_rcp_f64 / v_rsq_f64 take 7.03 ns, FP64 fma / mul 2.29, add 2.00, max / min /
-                # compares 1.9-2.2, DPP shifts 2.18, 64-bit moves 1.79, 32-bit 1.31.  Shares from the ISA listing of this
-                # instantiation (scripts/isa_mix.py, static counts of the two row loops).
-                ns = sum(mix["share"][k] * mix["issue_ns"][k] for k in mix["share"])
-                roof["fp64_issue_frac_weighted"] = ctr["valu_insts_per_launch"] * ns * 1e-9 / 1024.0 / launch_s
-                roof["fp64_issue_mix"] = {"share": mix["share"], "issue_ns": mix["issue_ns"], "mean_issue_ns": ns,
-                                          "valu_per_stage_row": mix.get("valu_per_stage_row"), "source": mix.get("source")}
-        # the same fraction at the launch time the kernel has UNDER rocprofv3 (the committed kernel trace of the counters' lease): the
-        # profiler stretches every launch by about an eighth (profiles/r06_profiler_vs_bench.md says where that goes), so a reader who
-        # divides the compulsory bytes by the trace's average duration gets this number, not `frac`
-        if ctr.get("avg_launch_us"):
-            roof["frac_under_profiler"] = kernel_bytes / (ctr["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            roof["frac_under_profiler_note"] = (f"{KERNEL_BYTES[dom]:.0f} B x cells / {ctr['avg_launch_us']:.1f} us (rocprofv3 --kernel-trace average of the timed launches, "
-                                                f"{ctr.get('source', 'profiles/counters_latest.json')}) / 8 TB/s")
-        roof["counters_run_launch_us"] = ref_us
-        roof["counters_run_matches_this_box"] = bool(same_speed)
-        if same_speed:
-            if ctr.get("hbm_bytes_per_launch"):
-                roof["traffic_frac"] = ctr["hbm_bytes_per_launch"] / launch_s / 1e9 / HBM_PEAK_GBS
-            # second roof: FP64 vector issue.  valu_frac = share of the SIMDs' VALU issue time the launch used, from the
-            # same counter passes: SQ_ACTIVE_INST_VALU (quad-cycles, summed over SIMDs) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
-            if ctr.get("valu_busy_frac") is not None:
-                roof["valu_frac"] = ctr["valu_busy_frac"]
-                roof["valu_insts_per_launch"] = ctr.get("valu_insts_per_launch")
-                roof["valu_note"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), PMC pass of the counters' run"
-        else:
-            roof["traffic_note"] = (f"this box runs the kernel in {launch_s * 1e6:.1f} us per launch, the counters' run took {ref_us:.1f} us: "
-                                    "traffic_frac / valu_frac withheld (not the same speed)")
+    if R.world == 1 and not R.tiled and args.mode == "fast" and path["fused"] and not args.no_unfused:
+        roof["unfused"] = unfused_record(R)
+    counters_into_roofline(R, roof, dom, launch_s, kernel_bytes)
+    return roof
+
+
+def other_transports(R, path):
+    """Tiles: the other ways to move the halos, timed outside the headline region: the RCCL exchange batched over k = 16 sub-steps
+    (halo 32) and once per sub-step (k = 1).  Returns (rccl16, k1)."""
+    args, csi = R.args, R.csi
+    k1 = rccl16 = None
+    headline_model = R.model
+    if R.tiled and args.exchange_interval == 0 and not args.no_compare:
+        if path["halo_transport"] == "peer" and not R.user_halo:
+            _, _, R.model, _ = R.build("rccl")                       # (timed() and barrier() act on R.model)
+            for _ in range(max(args.warmup, 1)):
+                csi.time_step_momentum(R.model, R.dt)
+            e16 = R.timed(args.steps)
+            p16 = R.model.ctx.last_path()
+            rccl16 = {"value": R.rate(e16), "ms_per_step": 1e3 * e16 / args.steps, "halo": 32,
+                      "exchange_interval": p16["exchange_interval"], "exchanges_per_step": p16["exchanges"], "level": p16["level"]}
+        if R.model.ctx.halo_transport() == "rccl" and R.model.ctx.last_path()["exchange_interval"] != 1:
+            R.model.set_exchange_interval(1)
+            csi.time_step_momentum(R.model, R.dt)
+            e1 = R.timed(args.steps)
+            p1 = R.model.ctx.last_path()
+            k1 = {"value": R.rate(e1), "ms_per_step": 1e3 * e1 / args.steps,
+                  "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
+            R.model.set_exchange_interval(args.exchange_interval)
+        R.model = headline_model
+    return rccl16, k1
+
+
+def second_partition(R, verify, transport_note):
+    """N > 1: the OTHER decomposition of the same grid, same run (round 5): BASELINE config 4 names 2 x 4 tiles, the headline runs y slabs
+    (the faster shape on every one-GPU stand-in) -- both are checked bit for bit and timed, so that the first run on
+    a real node answers the contract's layout as written and tells whether the slab choice holds over xGMI."""
+    args, csi = R.args, R.csi
+    if not (R.world > 1 and not args.no_second_partition and not args.tile and args.scaling == "strong" and verify):
+        return None
+    alt = None
+    if R.Rx == 1 and R.world >= 2:
+        alt = (2, R.world // 2)
+    elif R.Ry != R.world or R.Rx != 1:
+        alt = (1, R.world)
+    if not (alt and args.size % alt[0] == 0 and args.size % alt[1] == 0 and alt != (R.Rx, R.Ry)):
+        return None
+    headline_model = R.model
+    second = None
+    part = (alt[0], alt[1], args.size // alt[0], args.size // alt[1])
+    # (every collective of this block -- the all_ranks() reductions, the barriers inside timed() -- is reached by EVERY rank whatever
+    #  a rank's own library calls did: a rank that caught an error must not leave the others waiting in an all-reduce)
+    err2, same2_local = None, False
+    try:
+        g2, f2, R.model, _ = R.build(args.transport if not transport_note else "rccl", part)
+        for _ in range(max(args.warmup, 1)):
+            csi.time_step_momentum(R.model, R.dt)
+        same2_local = R.tile_matches_whole(R.model, g2, f2, global_fields(R.np, part[2], part[3], part[0], part[1]))
+    except csi.CsiError as e:
+        err2 = str(e)
+    if R.all_ranks(err2 is None):
+        same2 = R.all_ranks(same2_local)
+        try:
+            R.restart(R.model, f2)
+            for _ in range(max(args.warmup, 1)):
+                csi.time_step_momentum(R.model, R.dt)
+        except csi.CsiError as e:
+            err2 = str(e)
+        if R.all_ranks(err2 is None):
+            e2 = R.timed(args.steps)
+            second = {"partition": list(alt), "tile": [part[2], part[3]], "value": R.rate(e2),
+                      "ms_per_step": 1e3 * e2 / args.steps, "bitwise": bool(same2),
+                      "halo_transport": R.model.ctx.halo_transport(), "peer_tier": R.model.ctx.peer_tier() if R.model.ctx.halo_transport() == "peer" else None}
+    if second is None:
+        second = {"partition": list(alt), "error": err2 or "another rank reported a library error"}
+    R.model = headline_model
+    return second
+
+
+def tier0_record(R, path, verify):
+    """The fence-free tier 0 of the peer protocol as an explicit opt-in, timed next to the default (never the default across devices:
+    include/csi.h)."""
+    args, csi, model = R.args, R.csi, R.model
+    if not (R.tiled and path["halo_transport"] == "peer" and args.peer_tier < 0 and path.get("peer_tier", 0) >= 1 and verify and not args.no_compare):
+        return None
+    err0, same0_local = None, False
+    try:
+        model.set_peer_tier(0)
+        same0_local = R.tile_matches_whole()
+        R.restart(model, R.f)
+        csi.time_step_momentum(model, R.dt)
+    except csi.CsiError as e:
+        err0 = str(e)
+    if R.all_ranks(err0 is None):                      # (collectives outside the try: see second_partition)
+        same0 = R.all_ranks(same0_local)
+        e0 = R.timed(args.steps)
+        tier0 = {"value": R.rate(e0), "ms_per_step": 1e3 * e0 / args.steps, "bitwise": bool(same0),
+                 "note": "opt-in (--peer-tier 0): no acquire fence behind the flags; a passing check does not prove the protocol"}
+    else:
+        tier0 = {"error": err0 or "another rank reported a library error"}
+    try:
+        model.set_peer_tier(path["peer_tier"])
+    except csi.CsiError:
+        pass
+    return tier0
+
+
+def single_gpu_record(R, verify):
+    """N > 1: the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported."""
+    if not verify:
+        return None
+    args, csi, whole, torch = R.args, R.csi, R.whole, R.torch
+    R.restart(whole, R.gf)
+    for _ in range(max(args.warmup, 1)):
+        csi.time_step_momentum(whole, R.dt)
+    whole.synchronize(); torch.cuda.synchronize()
+    R.dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        csi.time_step_momentum(whole, R.dt)
+    whole.synchronize(); torch.cuda.synchronize()
+    e_single = time.perf_counter() - t0
+    R.whole = None
+    return {"value": R.gN[0] * R.gN[1] * args.substeps * args.steps / e_single, "ms_per_step": 1e3 * e_single / args.steps,
+            "grid": list(R.gN), "note": "the same global grid advanced by ONE GPU (rank 0) in this run, same kernels, halo 4 "
+                                        "(every rank runs its own copy at the same time, each on its own GPU)"}
+
+
+def main():
+    args = parse_args()
+    if args.gpus not in PARTITION:
+        raise SystemExit(f"--gpus must be one of {sorted(PARTITION)}")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1 or args.print_launch:
+            # the parent: nothing below this line has touched HIP (no torch.cuda call, no library load)
+            sys.exit(run_parent(args, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {os.environ['WORLD_SIZE']}: start N ranks with --gpus N "
+                         f"(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N), or run `python bench.py --gpus N` alone")
+    if args.self_test_launch:
+        return self_test_launch()
+
+    R = Rank(args)
+    csi, np, torch = R.csi, R.np, R.torch
+    world, rank, tiled, dt = R.world, R.rank, R.tiled, R.dt
+    Rx, Ry, nx_l, ny_l = R.Rx, R.Ry, R.nx_l, R.ny_l
+    R.tg, R.f, R.model, args.halo = R.build(args.transport)
+
+    # ---- warm-up, the N > 1 bitwise check and the peer tier ladder; then the headline region --------------------------------------------
+    verify, bitwise, ladder, transport_note = warm_up_and_verify(R)
+    R.barrier()
+    # RCCL prints its version banner through C stdio at communicator creation; flush it now so that the JSON line
+    # below is the last thing this process writes
+    ctypes.CDLL(None).fflush(None)
+    elapsed = R.timed(args.steps, stats=True)
+    # the clock / power sampler reads sysfs from a Python thread: it runs over a REPETITION of the timed loop right behind it, so that
+    # the headline region holds the launch loop alone, as in rounds 1-4 (ADVICE round 5)
+    with ClockSampler(R.local_rank) as clock:
+        R.timed(args.steps)
+
+    model = R.model
+    value = R.rate(elapsed)
+    subcycle_ms = model.ctx.last_subcycle_ms()            # HIP events on the launch stream, last step
+    path = model.ctx.last_path()
+    path["halo_transport"] = model.ctx.halo_transport() if tiled else "none"
+    if transport_note:
+        path["halo_transport_note"] = transport_note
+    if tiled and path["halo_transport"] == "peer":
+        path["peer_tier"] = model.ctx.peer_tier()
+    if ladder:
+        path["peer_tier_ladder"] = ladder          # which tiers were tried before the timed region, and what each check said
+    chk = result_check(R)
+
+    # ---- outside the timed region: the roofline of the dominant kernel, whole model steps, the other configurations ----------------------
+    roof = roofline_record(R, path, clock)
     model_days_per_hr = None
     if not args.no_full_step:
         nfull = 2
         csi.time_step(model, dt)                           # warm-up (WENO kernels, RK3 copies)
-        barrier()
+        R.barrier()
         t1 = time.perf_counter()
         for _ in range(nfull):
             csi.time_step(model, dt)                       # RK3: 3 x [WENO7 tendencies + sub-cycle + tracer update + halos]
-        barrier()
-        full = max_over_ranks((time.perf_counter() - t1) / nfull)
+        R.barrier()
+        full = R.max_over_ranks((time.perf_counter() - t1) / nfull)
         model_days_per_hr = 3600.0 / (full * 86400.0 / dt)
-
-    # ---- BASELINE config 2 beside the headline (round 5): advection only -- 512^2 periodic, WENO(order = 7), prescribed cyclonic eddy,
+    one_gpu_extras = world == 1 and not tiled and args.mode == "fast"
+    # BASELINE config 2 beside the headline (round 5): advection only -- 512^2 periodic, WENO(order = 7), prescribed cyclonic eddy,
     # SplitRungeKutta3 (examples/ice_advected_by_anticyclone.jl:65-66,117,126 scaled as SURVEY.md 8d) -- and the tendency launch at 2048^2
-    advection = None
-    if world == 1 and not tiled and not args.no_full_step and args.mode == "fast":
-        advection = advection_record(csi, np, torch, device)
-
-    config3 = None
-    if world == 1 and not tiled and not args.tile and args.mode == "fast" and (nx_l, ny_l) != (1024, 1024) and not args.no_structure:
-        config3 = config3_record(csi, np, torch, make_model, args.substeps, dt)
-    structure = None
-    if world == 1 and not tiled and not args.no_structure and not args.tile and args.mode == "fast" and not args.no_fusion and args.fusion_level >= 2:
-        structure = structure_record(csi, np, torch, device, args.substeps, quick=args.size < 2048)
-
-    # ---- tiles: the other ways to move the halos, timed outside the headline region: the RCCL exchange batched over k = 16
-    # sub-steps (halo 32) and once per sub-step (k = 1) --------------------------------------------------------------------------
-    k1 = None
-    rccl16 = None
-    headline_model = model
-    if tiled and args.exchange_interval == 0 and not args.no_compare:
-        if path["halo_transport"] == "peer" and not user_halo:
-            _, _, model, _ = build("rccl")                       # (timed() and barrier() act on `model`)
-            for _ in range(max(args.warmup, 1)):
-                csi.time_step_momentum(model, dt)
-            e16 = timed(args.steps)
-            p16 = model.ctx.last_path()
-            rccl16 = {"value": owned * args.substeps * args.steps / e16, "ms_per_step": 1e3 * e16 / args.steps, "halo": 32,
-                      "exchange_interval": p16["exchange_interval"], "exchanges_per_step": p16["exchanges"], "level": p16["level"]}
-        if model.ctx.halo_transport() == "rccl" and model.ctx.last_path()["exchange_interval"] != 1:
-            model.set_exchange_interval(1)
-            csi.time_step_momentum(model, dt)
-            e1 = timed(args.steps)
-            p1 = model.ctx.last_path()
-            k1 = {"value": owned * args.substeps * args.steps / e1, "ms_per_step": 1e3 * e1 / args.steps,
-                  "exchanges_per_step": p1["exchanges"], "level": p1["level"]}
-            model.set_exchange_interval(args.exchange_interval)
-        model = headline_model
-
-    # ---- N > 1: the OTHER decomposition of the same grid, same run (round 5): BASELINE config 4 names 2 x 4 tiles, the headline runs y
-    # slabs (the faster shape on every one-GPU stand-in) -- both are checked bit for bit and timed, so that
-    # the first run on a real node answers the contract's layout as written and tells whether the slab choice holds over xGMI ----
-    second = None
-    if world > 1 and not args.no_second_partition and not args.tile and args.scaling == "strong" and verify:
-        alt = None
-        if Rx == 1 and world >= 2:
-            alt = (2, world // 2)
-        elif Ry != world or Rx != 1:
-            alt = (1, world)
-        if alt and args.size % alt[0] == 0 and args.size % alt[1] == 0 and alt != (Rx, Ry):
-            part = (alt[0], alt[1], args.size // alt[0], args.size // alt[1])
-            # (every collective of this block -- the all_ranks() reductions, the barriers inside timed() -- is reached by EVERY rank whatever
-            #  a rank's own library calls did: a rank that caught an error must not leave the others waiting in an all-reduce)
-            err2, same2_local = None, False
-            try:
-                g2, f2, model, _ = build(args.transport if not transport_note else "rccl", part)
-                for _ in range(max(args.warmup, 1)):
-                    csi.time_step_momentum(model, dt)
-                same2_local = tile_matches_whole(model, g2, f2, global_fields(np, part[2], part[3], part[0], part[1]))
-            except csi.CsiError as e:
-                err2 = str(e)
-            if all_ranks(err2 is None):
-                same2 = all_ranks(same2_local)
-                try:
-                    restart(model, f2)
-                    for _ in range(max(args.warmup, 1)):
-                        csi.time_step_momentum(model, dt)
-                except csi.CsiError as e:
-                    err2 = str(e)
-                if all_ranks(err2 is None):
-                    e2 = timed(args.steps)
-                    second = {"partition": list(alt), "tile": [part[2], part[3]], "value": owned * args.substeps * args.steps / e2,
-                              "ms_per_step": 1e3 * e2 / args.steps, "bitwise": bool(same2),
-                              "halo_transport": model.ctx.halo_transport(), "peer_tier": model.ctx.peer_tier() if model.ctx.halo_transport() == "peer" else None}
-            if second is None:
-                second = {"partition": list(alt), "error": err2 or "another rank reported a library error"}
-            model = headline_model
-    # ---- the fence-free tier 0 of the peer protocol as an explicit opt-in, timed next to the default (never the default across
-    # devices: include/csi.h) ----
-    tier0 = None
-    if tiled and path["halo_transport"] == "peer" and args.peer_tier < 0 and path.get("peer_tier", 0) >= 1 and verify and not args.no_compare:
-        err0, same0_local = None, False
-        try:
-            model.set_peer_tier(0)
-            same0_local = tile_matches_whole()
-            restart(model, f)
-            csi.time_step_momentum(model, dt)
-        except csi.CsiError as e:
-            err0 = str(e)
-        if all_ranks(err0 is None):                      # (collectives outside the try: see the block above)
-            same0 = all_ranks(same0_local)
-            e0 = timed(args.steps)
-            tier0 = {"value": owned * args.substeps * args.steps / e0, "ms_per_step": 1e3 * e0 / args.steps, "bitwise": bool(same0),
-                     "note": "opt-in (--peer-tier 0): no acquire fence behind the flags; a passing check does not prove the protocol"}
-        else:
-            tier0 = {"error": err0 or "another rank reported a library error"}
-        try:
-            model.set_peer_tier(path["peer_tier"])
-        except csi.CsiError:
-            pass
-
-    # ---- N > 1: the one-GPU rate of the same global grid: every rank times its own copy (no shared resource), rank 0's is reported
-    single = None
-    rccl_ranks = model.ctx.comm_count()
+    advection = advection_record(csi, np, torch, R.device) if (one_gpu_extras and not args.no_full_step) else None
+    config3 = config3_record(csi, np, torch, R.make_model, args.substeps, dt) \
+        if (one_gpu_extras and not args.tile and (nx_l, ny_l) != (1024, 1024) and not args.no_structure) else None
+    structure = structure_record(csi, np, torch, R.device, args.substeps, quick=args.size < 2048) \
+        if (one_gpu_extras and not args.no_structure and not args.tile and not args.no_fusion and args.fusion_level >= 2) else None
+    rccl16, k1 = other_transports(R, path)
+    second = second_partition(R, verify, transport_note)
+    tier0 = tier0_record(R, path, verify)
+    rccl_ranks = R.model.ctx.comm_count()
     if world > 1 and rccl_ranks != world:
         raise SystemExit(f"bench.py: {world} ranks but the library's RCCL communicator has {rccl_ranks}")
-    if verify:
-        restart(whole, gf)
-        for _ in range(max(args.warmup, 1)):
-            csi.time_step_momentum(whole, dt)
-        whole.synchronize(); torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            csi.time_step_momentum(whole, dt)
-        whole.synchronize(); torch.cuda.synchronize()
-        e_single = time.perf_counter() - t0
-        single = {"value": gN[0] * gN[1] * args.substeps * args.steps / e_single, "ms_per_step": 1e3 * e_single / args.steps,
-                  "grid": list(gN), "note": "the same global grid advanced by ONE GPU (rank 0) in this run, same kernels, halo 4 "
-                                            "(every rank runs its own copy at the same time, each on its own GPU)"}
-        whole = None
+    single = single_gpu_record(R, verify)
 
     out = {
         "metric": "EVP sub-cycle cell-updates/s", "value": value, "unit": "cell-updates/s",
@@ -1043,7 +1110,7 @@ def main():
         out["exchange_every_substep"] = k1
     if rccl16 is not None:
         out["rccl_exchange"] = rccl16
-    if rehearsal:
+    if R.rehearsal:
         out["rehearsal_on_one_gpu"] = True
         out["rehearsal_note"] = (f"{world} ranks are PROCESSES sharing GPU 0 (host-channel group: shared memory + HIP IPC, gloo): a rehearsal of the "
                                  "N > 1 path, NOT a scaling measurement -- value, ms_per_step and parallel_efficiency are those of a shared device")
@@ -1075,11 +1142,12 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     model = None                                   # contexts (and their RCCL communicators) go before the line is printed
+    R.model = R.whole = None
     import gc
     gc.collect()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if R.dist is not None:
+        R.dist.barrier()
+        R.dist.destroy_process_group()
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)
