@@ -269,3 +269,52 @@ def test_tripolar_strict_matches_the_oracle_bitwise():
     p.time_step_momentum(case["dt"])
     for k in ("u", "v", "s11", "s22", "s12"):
         assert np.array_equal(got[k], p.f[k]), k
+
+
+# ---- fuzz (24 seeds here; scripts/fuzz_activity.py runs campaigns) ------------------------------------------------------------------
+
+def fuzz_case(seed):
+    """A random configuration with land and / or ice-free ocean large enough for whole tiles to go quiet."""
+    rng = np.random.default_rng(9000 + seed)
+    topo = [("periodic", "periodic"), ("periodic", "bounded"), ("bounded", "bounded"), ("periodic", "folded")][rng.integers(0, 4)]
+    kw = dict(Nx=int(rng.integers(2, 9)) * 56 + int(rng.integers(-20, 21)), Ny=int(rng.integers(120, 360)), topo=topo,
+              patches=bool(rng.integers(0, 2)), random_uv=0.03, substeps=int(rng.integers(8, 27)), seed=int(seed))
+    fam = rng.integers(0, 8)
+    if topo[1] == "folded":
+        kw["Nx"] += kw["Nx"] % 2                      # (the fold pairs column i with Nx - i + 1)
+        if fam % 2:
+            kw["curvilinear"] = [0.0, 0.05][rng.integers(0, 2)]
+    elif fam == 1 and topo[0] == "bounded":
+        kw["grid"] = "latlon"
+    elif fam == 2:
+        kw["curvilinear"] = [0.0, 0.04][rng.integers(0, 2)]
+    elif fam == 3:
+        kw["beta"] = 2e-10
+    if rng.random() < 0.6 and topo[0] != "bounded":
+        kw["land"] = float(rng.uniform(0.2, 0.5))
+    if rng.random() < 0.4:
+        kw["field_forcing"] = True
+        kw["free_drift"] = bool(rng.integers(0, 2))
+    elif rng.random() < 0.2:
+        kw["user_forcing"] = True
+    if "land" not in kw or rng.random() < 0.6:
+        a = float(rng.uniform(0.0, 0.5))
+        kw["ice_free_rows"] = (a, min(1.0, a + float(rng.uniform(0.3, 0.6))))
+    if rng.random() < 0.2:
+        kw["noslip"] = topo[1] == "bounded"
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_cuts_fuzz_bitwise(seed):
+    kw = fuzz_case(seed)
+    case = cases.make_case(**kw)
+    steps = 2 + seed % 2
+    on, acts, m = run(case, steps=steps, skipping=True, row_constant=True)
+    off, _, _ = run(case, steps=steps, skipping=False, row_constant=False)
+    assert_bitwise(on, off, f"seed {seed}: {kw}")
+    assert m.ctx.last_path()["level"] == 2, kw
+    LAST_FUZZ.update(activity=acts[-1], row_constant_rows=m.row_constant_rows() if case["g"].metric_kind == "full" else None)
+
+
+LAST_FUZZ = {}
