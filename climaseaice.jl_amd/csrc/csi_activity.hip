@@ -36,6 +36,13 @@ __global__ void __launch_bounds__(256) k_tile_activity(ActivityArgs A, int* __re
     act_chunk_rows(A, chunk, ja, jb);
     const int i0 = A.dec.i0 + strip * 56, i1 = min(i0 + 55, A.dec.i1);
     const int lane = (int)(threadIdx.x & 63), ty = (int)(threadIdx.x >> 6);
+    if (A.pmask) {
+        // a tile of a direction set of the peer transport (evp_fused2.hip, k_pair): it takes part in the flag protocol whatever it holds
+        const bool pw = strip < A.pset[0], pe = strip >= A.nstrips - A.pset[1], ps = chunk < A.pset[2], pn = chunk >= A.nchunks - A.pset[3];
+        const unsigned pd = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
+                             ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)A.pmask;
+        if (pd) { if (threadIdx.x == 0) flags[w] = 1; return; }
+    }
     // the ice mass of the owned box and one cell around it (clipped to the parent: the launch reads nothing beyond it either)
     const int i = i0 - 1 + lane;
     const bool col = (i <= i1 + 1) & (i >= A.pc.i0) & (i <= A.pc.i1);

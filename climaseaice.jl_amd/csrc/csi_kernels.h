@@ -111,6 +111,8 @@ struct ActivityArgs {
     Range dec;                         // the range the launch's tiles decompose (FI_DEC)
     int nstrips, nchunks, rows, elo, ehi;
     Range pc, pf;                      // index bounds of the Center-Center / Face-Face parents
+    int pset[4], pmask;                // peer-connected launches (FI_PSET, FI_PMASK): the tiles of the direction sets wait for / publish flags
+                                       // and store halo images into the neighbours' arrays -- always live
 };
 constexpr int kMaxActTiles = 16384;
 void launch_tile_activity(const ActivityArgs& A, int* flags, int* act, hipStream_t s);

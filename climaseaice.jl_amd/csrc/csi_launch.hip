@@ -123,7 +123,9 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     // launches and the last launch of the sub-cycle run every tile on the one-round geometry; the launches in between run the LIVE
     // tiles of a finer geometry GA -- so many more tiles as the newest sample of the live fraction says fit one round.
     FusedGeom GA{};
-    bool act_on = c->act.enabled != 0 && pairs && !tiled && !peer && substeps >= 8 && c->tune.peer_kernel <= 0;
+    // (peer-connected tiles: the tiles of the direction sets always run -- they publish their flags whatever they hold --, the interior
+    //  ones may go quiet; the launch geometry stays the one the transport was set up for)
+    bool act_on = c->act.enabled != 0 && pairs && !tiled && substeps >= 8;
     if (act_on) {
         csi_context::Activity& a = c->act;
         if (!a.list) {
@@ -197,7 +199,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                 const Range dec = v_stress_range(c, vb), ra = v_stress_range(c, va);
                 GP[mp] = pair_geom(c, dec);
                 if (act_on && mp == 0) {
-                    GA = pair_geom(c, dec, c->act.scale);
+                    GA = pair_geom(c, dec, peer ? 1.0 : c->act.scale);
                     if (GA.nstrips * GA.nchunks > kMaxActTiles || GA.elo != GP[0].elo || GA.ehi != GP[0].ehi || GA.wt != GP[0].wt) act_on = false;
                 }
                 for (int cur = 0; cur < 2; ++cur)
@@ -238,6 +240,11 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         const Bound &bc = c->f[CSI_F_H], &bf = c->f[CSI_F_S12];
         A.pc = Range{1 - c->Hx, bc.ni - c->Hx, 1 - c->Hy, bc.nj - c->Hy};
         A.pf = Range{1 - c->Hx, bf.ni - c->Hx, 1 - c->Hy, bf.nj - c->Hy};
+        if (peer) {
+            const FusedTable* t0 = &(c->host_ring + (size_t)((c->ring_pos - 1) % csi_context::kRing) * (NSINGLE + NPAIR))[NSINGLE];      // (the pair tables just filled)
+            for (int q = 0; q < 4; ++q) A.pset[q] = t0->I[FI_PSET + q];
+            A.pmask = t0->I[FI_PMASK];
+        }
         launch_tile_activity(A, c->act.flags, c->act.list, c->stream);
         csi_context::Activity& a = c->act;
         const int q = (int)(a.seq % csi_context::Activity::kSamples);

@@ -144,7 +144,7 @@ enum : int { RP_DXV = 0, RP_RDYV, RP_RDXU, RP_DXF2, RP_DYF2, RP_RAZF, RP_DYU, RP
 // instantiation: compiled into one function with the flag protocol and the redirected image stores, the row loops of every tile
 // were 6 % slower (1.7 us per launch on a 1024 x 512 tile with no neighbour at all; round 4, profiles/r04_tile_1024x512.md).
 template <bool UNI, bool AUF, bool WALLS, bool MASK, bool FORCE, bool FD, int CF, bool FULL = false, bool PEER = false, int EXTRA = 0, bool DLD = false>
-__device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, int nstrips, int nchunks, int rows,
+__device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, const int w, int nstrips, int nchunks, int rows,
                                        int blocks_per_xcd, int write_diag, unsigned long long seq,
                                        double* __restrict__ ring, unsigned* __restrict__ ringm, double* __restrict__ outr, unsigned* __restrict__ peer_abort_p, double* __restrict__ ringp,
                                        double* __restrict__ ringc) {
@@ -153,19 +153,7 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
     constexpr bool PRE = CSI_PAIR_PRE && !MASK && !FULL && !FRING && !(CSI_PAIR_LDSC_NOPRE && !UNI && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0));
     constexpr int RING_FIELDS = FRING ? 10 + RF_FORCING : (PRE ? 13 : 10);      // (FULL: ten fields; its plane values have a ring of their own, ringp)
 #define peer_abort (*peer_abort_p)
-    const int b = (int)blockIdx.x;
-    int w = (b & 7) * blocks_per_xcd + (b >> 3);            // XCD-aware: blocks are dealt round-robin, each XCD walks one band of tiles
-    if (!PEER && (write_diag & 4)) {
-        // Tile activity (csi_activity.hip; write_diag bit 2: not one of the first two launches of a sub-cycle, not its last): only the LIVE
-        // tiles run -- a quiescent tile (no ice mass in or around it) would store exactly what it stored two launches ago.  The live
-        // tiles' numbers come from a list, dealt over the XCDs like the tiles themselves (each XCD a band of consecutive tiles); the
-        // workgroups beyond the list leave at once.
-        typedef const __attribute__((address_space(4))) int* iptr_t;
-        iptr_t act = (iptr_t)((tptr_t)table)->P[FP_ACT_LIVE];
-        const int live = act[0], per = (live + 7) >> 3, k = b >> 3, p = (b & 7) * per + k;
-        if ((k >= per) | (p >= live)) return;
-        w = act[2 + p];
-    } else if (w >= nstrips * nchunks) return;               // (uniform over the workgroup: both waves leave)
+    const int b = (int)blockIdx.x;      // (w: this workgroup's tile, from k_pair -- dealt over the XCDs there)
     // Roles: wave 0 produces, wave 1 consumes.  (Measured placement of the 12 waves of a CU's six workgroups, in dispatch
     // order, on its SIMDs a..d: a b | b c | c d | d a | a b | c d -- every SIMD gets producers and consumers, the two waves
     // of a workgroup never share a SIMD; swapping the roles in some workgroups changed nothing measurable.)
@@ -1118,11 +1106,22 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
     __shared__ unsigned peer_abort_w;                      // PEER: the producer's wait has given up
     constexpr bool LDSC = !UNI && !FULL && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0);
     __shared__ double ringc[LDSC ? 8 * FC_COUNT : 1];      // per-row coefficients: an eight-row window (Stage::pc)
+    // This workgroup's tile.  XCD-aware: blocks are dealt round-robin over the XCDs, each XCD walks one band of consecutive tiles.
+    const int b = (int)blockIdx.x;
+    int w = (b & 7) * blocks_per_xcd + (b >> 3);
+    if (write_diag & 4) {
+        // Tile activity (csi_activity.hip; write_diag bit 2: not one of the first two launches of a sub-cycle, not its last): only the LIVE
+        // tiles run -- a quiescent tile (no ice mass in or around it) would store exactly what it stored two launches ago.  The live
+        // tiles' numbers come from a list, dealt over the XCDs like the tiles themselves; the workgroups beyond the list leave at once.
+        // (Peer-connected launches: the tiles of the direction sets are always on the list -- they publish their flags whatever they hold.)
+        typedef const __attribute__((address_space(4))) int* iptr_t;
+        iptr_t act = (iptr_t)((tptr_t)table)->P[FP_ACT_LIVE];
+        const int live = act[0], per = (live + 7) >> 3, k = b >> 3, p = (b & 7) * per + k;
+        if ((k >= per) | (p >= live)) return;
+        w = act[2 + p];
+    } else if (w >= nstrips * nchunks) return;               // (uniform over the workgroup: both waves leave)
     if constexpr (PEER) {
         // an interior tile of a peer-connected launch (in no direction's set): the untiled instantiation's body
-        const int b = (int)blockIdx.x;
-        const int w = (b & 7) * blocks_per_xcd + (b >> 3);
-        if (w >= nstrips * nchunks) return;
         const int chunk = w / nstrips, strip = w - chunk * nstrips;
         tptr_t T = (tptr_t)table;
         const bool pw = strip < T->I[FI_PSET], pe = strip >= nstrips - T->I[FI_PSET + 1], ps = chunk < T->I[FI_PSET + 2],
@@ -1130,11 +1129,11 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
         const unsigned pd = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
                              ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)T->I[FI_PMASK];
         if (__builtin_amdgcn_readfirstlane((int)pd) == 0) {
-            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp, ringc);
+            pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, false, EXTRA, false>(table, w, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp, ringc);
             return;
         }
     }
-    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp, ringc);
+    pair_body<UNI, AUF, WALLS, MASK, FORCE, FD, CF, FULL, PEER, EXTRA, DLD>(table, w, nstrips, nchunks, rows, blocks_per_xcd, write_diag, seq, ring, ringm, outr, &peer_abort_w, ringp, ringc);
 }
 
 }  // namespace fused

@@ -156,6 +156,39 @@ def test_whole_steps_with_skipping_match():
     assert np.array_equal(out[0]["h"], out[1]["h"]) and np.array_equal(out[0]["a"], out[1]["a"])
 
 
+# ---- tiles on the peer halo transport: the interior tiles may go quiet, the direction sets always run ---------------------------------
+
+PEER_SKIP_CASES = {
+    # (make_case keywords, which periodic directions are connected to the tile itself)
+    "periodic_xy": (dict(Nx=560, Ny=420, topo=("periodic", "periodic"), patches=False, random_uv=0.03, ice_free_rows=(0.2, 0.8), substeps=16), (True, True)),
+    "slab_y": (dict(Nx=448, Ny=400, topo=("periodic", "periodic"), patches=True, random_uv=0.03, ice_free_rows=(0.0, 0.55), substeps=12), (False, True)),
+    "channel_land": (dict(Nx=504, Ny=360, topo=("periodic", "bounded"), patches=False, random_uv=0.03, land=0.45, substeps=14), (True, False)),
+    "omip": (dict(Nx=448, Ny=320, topo=("periodic", "bounded"), patches=False, random_uv=0.03, land=0.3, field_forcing=True, free_drift=True,
+                  ice_free_rows=(0.3, 0.8), substeps=12), (True, False)),
+    "curvilinear": (dict(Nx=448, Ny=300, topo=("periodic", "bounded"), patches=False, random_uv=0.03, curvilinear=0.04, ice_free_rows=(0.25, 0.75),
+                         substeps=12), (True, False)),
+}
+
+
+@pytest.mark.parametrize("name", list(PEER_SKIP_CASES))
+def test_skipping_on_a_peer_connected_tile(name):
+    """One tile connected to itself over the peer transport (flags, halo images through the image table): with skipping, without, and the
+    untiled grid -- owned cells bit for bit; interior tiles were skipped, the transport stayed `peer`."""
+    kw, fc = PEER_SKIP_CASES[name]
+    case = cases.make_case(**kw)
+    on, acts, m = run(case, steps=3, skipping=True, tile=(1, 1, 0, fc))
+    off, _, m0 = run(case, steps=3, skipping=False, tile=(1, 1, 0, fc))
+    ref, _, _ = run(case, steps=3, skipping=False)
+    assert m.ctx.halo_transport() == "peer" and m0.ctx.halo_transport() == "peer"
+    assert_bitwise(on, off, name)
+    H = case["H"]
+    for k in ("u", "v", "s11", "s22", "s12"):
+        a, b = on[k][H:H + case["Ny"], H:H + case["Nx"]], ref[k][H:H + case["Ny"], H:H + case["Nx"]]
+        assert np.array_equal(a.view(np.int64), b.view(np.int64)), (name, k)
+    tiles, live, used = acts[-1]
+    assert used == 1 and 0 < live < tiles, (name, acts)
+
+
 # ---- row-constant rows ----------------------------------------------------------------------------------------------------------------
 
 ROWC_CASES = {

@@ -50,7 +50,7 @@ def run_tiles(c, Rx, Ry, k, full_step=True, mode="fast"):
         csi.time_step_momentum(m, c["dt"])
         m.synchronize()
         res = {f"mom_{f}": EVP_FIELDS[f](m).interior_numpy().copy() for f in ("u", "v", "s11", "s22", "s12")}
-        res["path"] = dict(m.ctx.last_path(), transport=m.ctx.halo_transport(), ranks=m.ctx.comm_count())
+        res["path"] = dict(m.ctx.last_path(), transport=m.ctx.halo_transport(), ranks=m.ctx.comm_count(), activity=m.tile_activity())
         if full_step:
             csi.time_step(m, c["dt"])
             m.synchronize()
@@ -109,6 +109,10 @@ DECOMPOSITIONS = {
     # three-kernel band, on either transport
     "1x2_fold": (1, 2, dict(Nx=192, Ny=192, topo=("periodic", "folded")), True),
     "1x4_fold_tripolar": (1, 4, dict(Nx=128, Ny=256, topo=("periodic", "folded"), curvilinear=0.04, land=0.2, field_forcing=True), True),
+    # round 6: ice-free ocean / land wide enough for whole interior tiles of the peer-connected launches to go quiet (tile activity)
+    "2x2_seasonal": (2, 2, dict(Nx=896, Ny=640, topo=("periodic", "periodic"), ice_free_rows=(0.15, 0.85)), True),
+    "1x2_seasonal_land_arrays": (1, 2, dict(Nx=672, Ny=560, topo=("periodic", "bounded"), land=0.4, field_forcing=True, free_drift=True,
+                                          ice_free_rows=(0.3, 0.7)), True),
 }
 
 
@@ -125,6 +129,9 @@ def test_local_tiles_bitwise(name, k):
         # the fold tile too runs the two-sub-steps kernel (below its three-kernel band) whenever the exchange interval is even
         assert (d["path"]["level"] in (0, 1)) if k == 1 else (d["path"]["level"] == 2), d["path"]
     check(tiles, mom, step, (name, k))
+    if "seasonal" in name and k == 0:
+        acts = [d["path"]["activity"] for d in tiles]
+        assert all(a[2] == 1 for a in acts) and any(0 < a[1] < a[0] for a in acts), acts      # interior tiles went quiet on the peer transport
 
 
 @pytest.mark.parametrize("name", ["2x2_periodic", "1x2_fold", "2x1_bounded_x", "2x2_channel_land_arrays"])
