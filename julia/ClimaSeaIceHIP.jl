@@ -295,6 +295,26 @@ end
 # flags, 2: + a release fence before them.  include/csi.h: csi_set_peer_tier.
 set_peer_tier!(ctx, tier::Integer) = check(ctx, ccall((:csi_set_peer_tier, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, tier))
 
+# Round 6: the two exact structure cuts (include/csi.h).  Both are on by default; nothing has to be called.
+#   set_tile_skipping!(ctx, on): tiles with no ice mass in or around them are left out of the inner launches of a sub-cycle
+#   tile_activity(ctx) -> (tiles, live, used): the newest counts that have arrived from the device
+#   set_row_constant!(ctx, on, rtol = 0.0): rows of a TripolarGrid's latitude-longitude part whose metric planes hold one value per row are
+#       read from per-row vectors; rtol > 0 also marks rows whose columns agree to that relative distance (Oceananigans computes a
+#       tripolar grid's metrics per point: its lat-lon rows may carry rounding noise) -- that changes results at the rtol level
+set_tile_skipping!(ctx, on::Bool) = check(ctx, ccall((:csi_set_tile_skipping, libcsi), Int32, (Ptr{Cvoid}, Int32), ctx.handle, on ? 1 : 0))
+function tile_activity(ctx)
+    t, l, u = Ref{Int32}(0), Ref{Int32}(0), Ref{Int32}(0)
+    check(ctx, ccall((:csi_tile_activity, libcsi), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), ctx.handle, t, l, u))
+    return (tiles = t[], live = l[], used = u[] != 0)
+end
+set_row_constant!(ctx, on::Bool, rtol::Real = 0.0) =
+    check(ctx, ccall((:csi_set_row_constant, libcsi), Int32, (Ptr{Cvoid}, Int32, Cdouble), ctx.handle, on ? 1 : 0, rtol))
+function row_constant_rows(ctx)
+    n = Ref{Int32}(0)
+    check(ctx, ccall((:csi_row_constant_rows, libcsi), Int32, (Ptr{Cvoid}, Ref{Int32}), ctx.handle, n))
+    return Int(n[])
+end
+
 # Waits for the library's stream and reports a peer-transport wait that gave up (a rank that fell behind or died: the library
 # never hangs, it fails).  Every entry point that advances the model reports such an error too, at its start and at its end, so an
 # explicit call is needed only where the host must KNOW that a step is complete and valid (before output, before a checkpoint).
