@@ -109,6 +109,13 @@ DECOMPOSITIONS = {
     # three-kernel band, on either transport
     "1x2_fold": (1, 2, dict(Nx=192, Ny=192, topo=("periodic", "folded")), True),
     "1x4_fold_tripolar": (1, 4, dict(Nx=128, Ny=256, topo=("periodic", "folded"), curvilinear=0.04, land=0.2, field_forcing=True), True),
+    # round 6: the REAL tripolar geometry (csi.TripolarGrid: latitude-longitude rows + conformal bipolar cap, the reference's analytic
+    # land, per-point f, arrays, free drift) in the reference's own distributed layout, Partition(1, 4)
+    # (test/distributed_tests_utils.jl:226-259: serial == distributed), with ice everywhere and with seasonal ice
+    "1x4_tripolar_grid": (1, 4, dict(Nx=224, Ny=256, grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), field_forcing=True,
+                                   free_drift=True, coriolis_points=True), True),
+    "1x2_tripolar_grid_seasonal": (1, 2, dict(Nx=448, Ny=512, grid="tripolar", tripolar=dict(southernmost_latitude=-78.0), field_forcing=True,
+                                            free_drift=True, coriolis_points=True, ice_edge=60.0, land=0.2), True),
     # round 6: ice-free ocean / land wide enough for whole interior tiles of the peer-connected launches to go quiet (tile activity)
     "2x2_seasonal": (2, 2, dict(Nx=896, Ny=640, topo=("periodic", "periodic"), ice_free_rows=(0.15, 0.85)), True),
     "1x2_seasonal_land_arrays": (1, 2, dict(Nx=672, Ny=560, topo=("periodic", "bounded"), land=0.4, field_forcing=True, free_drift=True,
