@@ -89,6 +89,8 @@ PARTITIONS = [
     ("y2_user_forcing", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "periodic"), user_forcing=True)),
     ("y2_folded", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "folded"))),
     ("y2_folded_curvilinear", 1, 2, dict(Nx=40, Ny=48, topo=("periodic", "folded"), curvilinear=0.04)),
+    # round 6: the real tripolar geometry (csi.TripolarGrid: lat-lon rows + conformal bipolar cap), its analytic land and per-point f
+    ("y2_tripolar_grid", 1, 2, dict(Nx=48, Ny=56, grid="tripolar", tripolar=dict(southernmost_latitude=-70.0), coriolis_points=True)),
 ]
 
 

@@ -34,6 +34,24 @@ def tile_problem(case, Rx, Ry, rank, force_connected=False):
         p.set_stress("top", O.STRESS_CONST, tau=case["top"])
     if case["bottom"] == "semi":
         p.set_stress("bottom", O.STRESS_SEMI_IMPLICIT, ue=case["ue"] or None, ve=case["ve"] or None)
+    if case.get("coriolis_points"):
+        # per-point f (a TripolarGrid's 2 Omega sin(latitude)): the tile's slice of the global planes, halo entries included
+        n, ni = tg.Ny + 2 * tg.Hy + 1, tg.Nx + 2 * tg.Hx + 1
+        p.set_coriolis_points(*(np.ascontiguousarray(a[tg.j_off:tg.j_off + n, tg.i_off:tg.i_off + ni]) for a in case["f_points"]))
+    if case.get("mask") is not None:
+        # the tile's slice (halo included) of the global activity mask as cases.oracle_problem builds it
+        G = g
+        full = np.zeros((G.Ny + 2 * G.Hy, G.Nx + 2 * G.Hx), dtype=np.uint8)
+        full[G.Hy:G.Hy + G.Ny, G.Hx:G.Hx + G.Nx] = case["mask"]
+        if G.topology[0] is csi.Periodic:
+            full[:, :G.Hx] = full[:, G.Nx:G.Nx + G.Hx]
+            full[:, G.Nx + G.Hx:] = full[:, G.Hx:2 * G.Hx]
+        if G.topology[1] is csi.Periodic:
+            full[:G.Hy, :] = full[G.Ny:G.Ny + G.Hy, :]
+            full[G.Ny + G.Hy:, :] = full[G.Hy:2 * G.Hy, :]
+        if G.topology[1] is csi.RightFolded:
+            full = csi.fold_north(full, G.Nx, G.Ny, G.Hx, G.Hy, False, False, 1).astype(np.uint8)
+        p.set_mask(np.ascontiguousarray(full[tg.j_off:tg.j_off + tg.Ny + 2 * tg.Hy, tg.i_off:tg.i_off + tg.Nx + 2 * tg.Hx]))
     for name, key in (("h", "h"), ("aice", "a"), ("u", "u"), ("v", "v")):
         p.interior(name)[...] = tg.local_interior(case[key], *_LOC[name])
     if case.get("user_forcing"):
