@@ -115,8 +115,8 @@ int32_t csi_context_destroy(csi_context* c) {
     if (c->dev_rcsum) hipFree(c->dev_rcsum);
     if (c->act.flags) hipFree(c->act.flags);
     if (c->act.list) hipFree(c->act.list);
+    if (c->act.list0) hipFree(c->act.list0);
     if (c->act.host) hipHostFree(c->act.host);
-    for (auto& e : c->act.ev) if (e) hipEventDestroy(e);
     if (c->host_ring) hipHostFree(c->host_ring);
     for (auto& e : c->ring_ev) if (e) hipEventDestroy(e);
     if (c->dev_coef) hipFree(c->dev_coef);
@@ -201,18 +201,14 @@ int32_t csi_set_mode(csi_context* c, int32_t mode) {
 int32_t csi_set_tile_skipping(csi_context* c, int32_t on) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
     c->act.enabled = on ? 1 : 0;
-    c->act.scale = 1.0; c->act.last_live = -1; c->act.last_tiles = 0;
+    c->act.scale = 1.0; c->act.last_live = -1; c->act.last_tiles = 0; c->act.last_used = 0; c->act.since_probe = 0;
     return CSI_OK;
 }
 
 int32_t csi_tile_activity(csi_context* c, int32_t* tiles, int32_t* live, int32_t* used) {
     if (!c) return CSI_ERR_INVALID_ARGUMENT;
-    // the newest sample that has arrived (no synchronisation: call csi_sync first for the last sub-cycle's)
-    for (int q = 0; q < csi_context::Activity::kSamples; ++q)
-        if (c->act.used[q] && c->act.sample_seq[q] > c->act.seen_seq && hipEventQuery(c->act.ev[q]) == hipSuccess) {
-            c->act.seen_seq = c->act.sample_seq[q];
-            c->act.last_live = c->act.host[2 * q]; c->act.last_tiles = c->act.host[2 * q + 1];
-        }
+    // the newest sample the device has written (no synchronisation: call csi_sync first for the last sub-cycle's)
+    activity_sample(c);
     if (tiles) *tiles = c->act.last_tiles;
     if (live) *live = c->act.last_live;
     if (used) *used = c->act.last_used;

@@ -28,7 +28,9 @@ __device__ __forceinline__ void act_chunk_rows(const ActivityArgs& A, int q, int
     jb = q == 0 ? min(ja + elo - 1, A.dec.j1) : (q == A.nchunks - 1 ? A.dec.j1 : min(ja + A.rows - 1, A.dec.j1 - A.ehi));
 }
 
-// one workgroup (four waves) per tile: flags[w] = 1 when the tile must run
+// one workgroup (four waves) per tile: flags[w] = 2 live, 1 quiescent once both buffers hold its fixed point (after two launches),
+// 0 quiescent from the start: its velocities are +0.0 already and it stores no halo image, so that with the two buffers equal at the
+// start of the sub-cycle (run_fused copies them) even the first two launches may leave it out
 __global__ void __launch_bounds__(256) k_tile_activity(ActivityArgs A, int* __restrict__ flags) {
     const int w = (int)blockIdx.x;
     const int chunk = w / A.nstrips, strip = w - chunk * A.nstrips;
@@ -41,7 +43,7 @@ __global__ void __launch_bounds__(256) k_tile_activity(ActivityArgs A, int* __re
         const bool pw = strip < A.pset[0], pe = strip >= A.nstrips - A.pset[1], ps = chunk < A.pset[2], pn = chunk >= A.nchunks - A.pset[3];
         const unsigned pd = ((pw ? 1u : 0u) | (pe ? 2u : 0u) | (ps ? 4u : 0u) | (pn ? 8u : 0u) | ((ps & pw) ? 16u : 0u) | ((ps & pe) ? 32u : 0u) |
                              ((pn & pw) ? 64u : 0u) | ((pn & pe) ? 128u : 0u)) & (unsigned)A.pmask;
-        if (pd) { if (threadIdx.x == 0) flags[w] = 1; return; }
+        if (pd) { if (threadIdx.x == 0) flags[w] = 2; return; }
     }
     // the ice mass of the owned box and one cell around it (clipped to the parent: the launch reads nothing beyond it either)
     const int i = i0 - 1 + lane;
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(256) k_tile_activity(ActivityArgs A, int* __re
             live |= !(m == 0.0);                                         // (NaN counts as ice)
         }
     if (__syncthreads_or(live ? 1 : 0)) {
-        if (threadIdx.x == 0) flags[w] = 1;
+        if (threadIdx.x == 0) flags[w] = 2;
         return;
     }
     // no ice anywhere near: the owned stresses must hold no -0.0 (fma(x, 0, -0.0) is +0.0 or -0.0 with the sign of x)
@@ -70,12 +72,28 @@ __global__ void __launch_bounds__(256) k_tile_activity(ActivityArgs A, int* __re
             if (in_f & (j >= A.pf.j0) & (j <= A.pf.j1)) live |= (unsigned long long)__double_as_longlong(A.s12.ld_(i, j)) == neg0;
         }
     }
-    const int any = __syncthreads_or(live ? 1 : 0);
+    if (__syncthreads_or(live ? 1 : 0)) {
+        if (threadIdx.x == 0) flags[w] = 2;
+        return;
+    }
+    // quiescent.  From the start?  Not a tile within H of a side of the grid (its stores carry halo images: the first two launches write
+    // them), and every owned velocity must be +0.0 bit for bit already (the first sub-step would zero it; its neighbours read the old value)
+    bool later = (i0 <= A.Hx) | (i1 > A.Nx - A.Hx) | (ja <= A.Hy) | (jb > A.Ny - A.Hy);
+    if (!later && own) {
+        const bool in_u = (i >= A.pu.i0) & (i <= A.pu.i1), in_v = (i >= A.pv.i0) & (i <= A.pv.i1);
+        for (int j = ja + ty; j <= jb; j += 4) {
+            if (in_u & (j >= A.pu.j0) & (j <= A.pu.j1)) later |= __double_as_longlong(A.u.ld_(i, j)) != 0ll;
+            if (in_v & (j >= A.pv.j0) & (j <= A.pv.j1)) later |= __double_as_longlong(A.v.ld_(i, j)) != 0ll;
+        }
+    }
+    const int any = __syncthreads_or(later ? 1 : 0);
     if (threadIdx.x == 0) flags[w] = any ? 1 : 0;
 }
 
 // act = {live, tiles, the live tiles' numbers in ascending order}: one workgroup, a ballot scan per 1024 tiles
-__global__ void __launch_bounds__(1024) k_activity_compact(const int* __restrict__ flags, int tiles, int* __restrict__ act) {
+// sample (may be null): device-visible pinned host words {seqlock, live, tiles, id}: the host reads them without any API call
+__global__ void __launch_bounds__(1024) k_activity_compact(const int* __restrict__ flags, int tiles, int level, int* __restrict__ act,
+                                                           int* sample, int sample_id) {
     __shared__ int wave_count[16];
     __shared__ int base;
     const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -83,7 +101,7 @@ __global__ void __launch_bounds__(1024) k_activity_compact(const int* __restrict
     __syncthreads();
     for (int t0 = 0; t0 < tiles; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
-        const bool on = t < tiles && flags[t] != 0;
+        const bool on = t < tiles && flags[t] >= level;
         const unsigned long long bal = __ballot(on);
         if (lane == 0) wave_count[wv] = __popcll(bal);
         __syncthreads();
@@ -94,15 +112,29 @@ __global__ void __launch_bounds__(1024) k_activity_compact(const int* __restrict
         if (threadIdx.x == 0) { int s = 0; for (int q = 0; q < 16; ++q) s += wave_count[q]; base += s; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { act[0] = base; act[1] = tiles; }
+    if (threadIdx.x == 0) {
+        act[0] = base; act[1] = tiles;
+        if (sample) {
+            // seqlock: odd while the words change; system scope (the words live in host memory)
+            const int s0 = __hip_atomic_load(sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sample, s0 | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(sample + 1, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sample + 2, tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sample + 3, sample_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(sample, (s0 | 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace
 
-void launch_tile_activity(const ActivityArgs& A, int* flags, int* act, hipStream_t s) {
+void launch_tile_activity(const ActivityArgs& A, int* flags, int* act, int* act0, int* sample, int sample_id, hipStream_t s) {
     const int tiles = A.nstrips * A.nchunks;
     hipLaunchKernelGGL(k_tile_activity, dim3((unsigned)tiles), dim3(256), 0, s, A, flags);
-    hipLaunchKernelGGL(k_activity_compact, dim3(1), dim3(1024), 0, s, (const int*)flags, tiles, act);
+    hipLaunchKernelGGL(k_activity_compact, dim3(1), dim3(1024), 0, s, (const int*)flags, tiles, 2, act, sample, sample_id);
+    if (act0) hipLaunchKernelGGL(k_activity_compact, dim3(1), dim3(1024), 0, s, (const int*)flags, tiles, 1, act0, (int*)nullptr, 0);
 }
 
 }  // namespace csi

@@ -199,15 +199,16 @@ struct csi_context {
         int enabled = 1;                     // csi_set_tile_skipping
         int* flags = nullptr;                // device: one int per tile
         int* list = nullptr;                 // device: {live, tiles, the live tiles' numbers}
-        int* host = nullptr;                 // pinned: kSamples x {live, tiles}
-        hipEvent_t ev[kSamples] = {nullptr, nullptr, nullptr, nullptr};
-        bool used[kSamples] = {false, false, false, false};
-        double sample_scale[kSamples] = {1, 1, 1, 1};
-        unsigned long sample_seq[kSamples] = {0, 0, 0, 0};
-        unsigned long seq = 0, seen_seq = 0;
+        int* list0 = nullptr;                // device: the same for the first two launches (all but the tiles quiescent from the start)
+        int* host = nullptr;                 // pinned, device-visible: {seqlock, live, tiles, sample id} written by k_activity_compact
+        int* host_dev = nullptr;             // ... as the device addresses it
+        double sample_scale[kSamples] = {1, 1, 1, 1};      // the geometry scale of sample id % kSamples
+        unsigned seq = 0;                    // sample ids handed out
+        int seen_id = -1;                    // the newest sample the host has taken
         double scale = 1.0;                  // tiles of a live launch relative to the one-round geometry (pair_geom's tile_scale)
         int last_live = -1, last_tiles = 0;  // the newest sample that has arrived
         int last_used = 0;                   // the last sub-cycle ran live launches
+        int since_probe = 0;                 // sub-cycles since the last test while nothing is quiescent (run_fused: probed every 32nd)
     } act;
     // CSI_METRIC_FULL: rows whose twelve coefficient planes (and per-point Coriolis planes) hold one value per row (ensure_row_constant)
     std::vector<double> coef2_host, fcor2_host;      // host copies of the planes the marks are made from
@@ -342,6 +343,7 @@ int64_t max_bound_ld(const csi_context* c);
 bool pair_supported(const csi_context* c);
 FusedGeom pair_geom(const csi_context* c, const Range& dec, double tile_scale = 1.0);
 int32_t ensure_row_constant(csi_context* c);
+bool activity_sample(csi_context* c);
 PeerSets peer_wait_counts(const csi_context* c, const FusedGeom& G);
 void peer_local_arrays(const csi_context* c, const void* out[csi_context::Peer::NARR]);
 void peer_release(csi_context* c);

@@ -55,7 +55,9 @@ enum : int { FP_U_IN = 0, FP_V_IN, FP_S11_IN, FP_S22_IN, FP_S12_IN, FP_P, FP_H, 
              FP_PERR = FP_SLOT_OUT + 8,     // error word (a wait timed out)
              FP_ACT_LIVE,                   // tile activity (csi_activity.hip): device int array {live tiles, all tiles, list of the live tiles' numbers ...};
                                             // 0: every tile runs.  Read by launches whose write_diag has bit 2 set (run_fused: not the first two, not the last)
-             FP_ROWPAD_ = FP_ACT_LIVE + (FP_C2_0 - FP_F2U),      // (room for FP_F2ROW_U / _V below FP_C2ROW_0)
+             FP_ACT_LIVE0,                  // ... the same for the FIRST TWO launches (write_diag bit 3): every tile but those that are quiescent from the
+                                            // start -- u = v = +0.0 as well, no halo image to store --, 0: every tile runs
+             FP_ROWPAD_ = FP_ACT_LIVE0 + (FP_C2_0 - FP_F2U),      // (room for FP_F2ROW_U / _V below FP_C2ROW_0)
              FP_C2ROW_0,                    // CSI_METRIC_FULL: the C2_COUNT planes as per-ROW vectors (ptr[parent row]), valid for the rows FP_RCSUM marks constant
              FP_F2ROW_U = FP_F2U + (FP_C2ROW_0 - FP_C2_0), FP_F2ROW_V,      // ... and the per-point Coriolis planes likewise (the SAME distance from FP_F2U / _V as the vectors from the planes: Stage::rcd_)
              FP_RCSUM = FP_C2ROW_0 + C2_COUNT,      // int prefix sums over parent rows: rcsum[t] = rows among parent rows [0, t) whose plane values are the same in every column (0: none marked)
@@ -106,16 +108,21 @@ void fused_fill_pair_extra(const Range& dec, int a_j0, int a_j1, const ImageSpec
 // an exact fixed point of u, v, sigma -- every later launch would store what the launch two before it stored.  `act` receives
 // {number of live tiles, number of tiles, the live tiles' numbers in ascending order}.
 struct ActivityArgs {
-    FRef h, a, s11, s22, s12;          // (0,0)-offset references; sigma: the CURRENT state
+    FRef h, a, s11, s22, s12, u, v;    // (0,0)-offset references; sigma, u, v: the CURRENT state
     double rho;
     Range dec;                         // the range the launch's tiles decompose (FI_DEC)
     int nstrips, nchunks, rows, elo, ehi;
     Range pc, pf;                      // index bounds of the Center-Center / Face-Face parents
+    Range pu, pv;                      // ... of the u / v parents
+    int Nx, Ny, Hx, Hy;                // the launch's grid: tiles within H of a side store halo images (never quiescent from the start)
     int pset[4], pmask;                // peer-connected launches (FI_PSET, FI_PMASK): the tiles of the direction sets wait for / publish flags
                                        // and store halo images into the neighbours' arrays -- always live
 };
 constexpr int kMaxActTiles = 16384;
-void launch_tile_activity(const ActivityArgs& A, int* flags, int* act, hipStream_t s);
+// flags: 0 quiescent from the start (the first two launches may leave it out as well), 1 quiescent after two launches, 2 live.
+// act / act0: {count, tiles, numbers ...} of the tiles with flag 2 / with flag >= 1.
+// sample: device-visible pinned host words {seqlock, live, tiles, sample_id} the compaction writes for the host to read without an API call
+void launch_tile_activity(const ActivityArgs& A, int* flags, int* act, int* act0, int* sample, int sample_id, hipStream_t s);
 void launch_fused_pair(const FusedTable* dev_table, int metric, bool a_ufirst, bool walls, bool mask, bool force, bool free_drift, int extra,
                        int common_forcing, int nstrips, int nchunks, int rows, int write_diag, unsigned long long seq, hipStream_t s);
 // stress divergence of the immersed FluxBoundaryConditions at every u / v point whose stencil stays inside the parents (evp_fast.hip)

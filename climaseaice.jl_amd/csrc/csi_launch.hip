@@ -14,6 +14,21 @@ static int32_t stats_mark(csi_context* c) {
 }
 static void stats_launches(csi_context* c, int n) { if (c->stats.on && c->stats.launches.size() * 2 < c->stats.ev.size()) c->stats.launches.push_back(n); }
 
+// The newest activity sample the device has written into the pinned words (k_activity_compact's seqlock): true when a new one was taken.
+bool activity_sample(csi_context* c) {
+    csi_context::Activity& a = c->act;
+    if (!a.host) return false;
+    volatile int* w = a.host;
+    const int s1 = w[0];
+    if (s1 & 1) return false;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const int live = w[1], tiles = w[2], id = w[3];
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (w[0] != s1 || s1 == 0 || id == a.seen_id) return false;
+    a.seen_id = id; a.last_live = live; a.last_tiles = tiles;
+    return true;
+}
+
 // peer: the caller (run_fused_peer) has turned the connected sides of c->g / P.g into periodic ones: the launch loop is that of an
 // untiled periodic grid, the halo images of those sides go to the neighbouring tiles' arrays and every pair launch carries a
 // number of the flag protocol.  band: the caller (run_fused_fold) has cut the rows next to a north fold off c->g / P.g.
@@ -107,11 +122,6 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
     // under the one-sub-step kernel) agree in both.  A fully periodic, untiled grid advanced by pair launches only
     // rewrites every cell of the five parents -- interior and all halo images -- at every launch: no copy needed.
     const bool every_cell_written = pairs && !tiled && !has_walls(c) && substeps % 2 == 0;
-    if (!every_cell_written && !peer)                      // (peer: run_fused_peer has made the copy, BEFORE its exchange)
-        for (int q = 0; q < 5; ++q) {
-            const Bound& b = c->f[kPing[q]];
-            HIP_TRY(c, hipMemcpyAsync(c->alt[q], b.p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        }
     const ImageSpec imu = image_spec(c, CSI_F_U), imv = image_spec(c, CSI_F_V);
     // tables: singles (position in the exchange batch) x (which buffer is current) x (u first / v first), then
     // pairs (pair position) x (buffer) x (first sub-step u first / v first)
@@ -131,19 +141,15 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         if (!a.list) {
             HIP_TRY(c, hipMalloc((void**)&a.flags, sizeof(int) * kMaxActTiles));
             HIP_TRY(c, hipMalloc((void**)&a.list, sizeof(int) * (kMaxActTiles + 2)));
-            HIP_TRY(c, hipHostMalloc((void**)&a.host, sizeof(int) * 2 * csi_context::Activity::kSamples, hipHostMallocDefault));
-            for (auto& e : a.ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(c, hipMalloc((void**)&a.list0, sizeof(int) * (kMaxActTiles + 2)));
+            HIP_TRY(c, hipHostMalloc((void**)&a.host, sizeof(int) * 4, hipHostMallocMapped));
+            memset(a.host, 0, sizeof(int) * 4);
+            HIP_TRY(c, hipHostGetDevicePointer((void**)&a.host_dev, a.host, 0));
         }
-        // the newest sample that has arrived: live tiles / tiles on the geometry of its sub-cycle
+        // the newest sample the device has written (seqlock; no API call, no synchronisation): live tiles / tiles on the geometry of its sub-cycle
         double s_scale = 1.0;
         bool fresh = false;
-        for (int q = 0; q < csi_context::Activity::kSamples; ++q)
-            if (a.used[q] && a.sample_seq[q] > a.seen_seq && hipEventQuery(a.ev[q]) == hipSuccess) {
-                a.seen_seq = a.sample_seq[q];
-                a.last_live = a.host[2 * q]; a.last_tiles = a.host[2 * q + 1];
-                s_scale = a.sample_scale[q];
-                fresh = true;
-            }
+        if (csi_host::activity_sample(c)) { s_scale = a.sample_scale[(unsigned)a.seen_id % csi_context::Activity::kSamples]; fresh = true; }
         if (fresh && a.last_tiles > 0) {
             const double f = (double)std::max(a.last_live, 1) / (double)a.last_tiles;
             // keep the geometry while the live tiles fill 90 .. 100 % of a round; otherwise aim at 97 %
@@ -151,6 +157,28 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             else if (s_scale * f > 1.0 || s_scale * f < 0.90 || a.scale != s_scale) a.scale = std::min(4.0, 0.97 / f);
         }
     }
+    // (Almost) nothing quiescent in the newest sample -- the headline's grid: no land, ice everywhere but one patch of open water, 987
+    // of 999 tiles live --: the test, the scan, the copy below and the list-mapped launches cost 3 % of such a sub-cycle (measured: 7.12
+    // against 6.89 ms at 2048^2, scripts/ab_headline_skip.sh) and leaving a dozen tiles out of a one-round launch buys nothing.  So
+    // unless fewer than nine tiles in ten are live the grid is only PROBED, every kProbeEvery-th sub-cycle, and the sub-cycles in
+    // between run the plain launches.  Ice-free ocean that spreads is found within that many sub-cycles; while the cut is in use the
+    // test runs before every sub-cycle (it must: the list decides what is skipped).
+    if (act_on && c->act.last_live >= 0 && 10L * c->act.last_live >= 9L * c->act.last_tiles) {
+        constexpr int kProbeEvery = 32;
+        if (++c->act.since_probe < kProbeEvery) act_on = false;
+        else c->act.since_probe = 0;
+    } else {
+        c->act.since_probe = 0;
+    }
+    // Tiles quiescent FROM THE START (no ice mass, velocities +0.0 already, no halo image to store): with the two buffers equal before
+    // the first launch even the first two launches may leave them out.  Worth the copy below only when the newest sample says that
+    // something is quiescent at all; not on peer-connected tiles (their copy is made before the sub-cycle's exchange, run_fused_peer).
+    const bool q0_on = act_on && !peer && c->act.last_live >= 0 && 10L * c->act.last_live < 9L * c->act.last_tiles;
+    if ((!every_cell_written || q0_on) && !peer)           // (peer: run_fused_peer has made the copy, BEFORE its exchange)
+        for (int q = 0; q < 5; ++q) {
+            const Bound& b = c->f[kPing[q]];
+            HIP_TRY(c, hipMemcpyAsync(c->alt[q], b.p, c->alt_elems[q] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
     // configurations only the two-sub-steps kernel takes (masks, array forcing, per-point metrics): a single sub-step (the odd
     // trailing one) runs through that kernel too, its consumer wave storing stage A's results (evp_fused2.hip, `single`)
     const bool single_by_pair = pairs && (masked || force || c->metric_kind == CSI_METRIC_FULL || peer || band);      // (peer: the flag protocol lives in this kernel only; band: its cut tile)
@@ -216,7 +244,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                         if (force) { fused_fill_forcing(P, ubar_v, vbar_u, t); if (wind) fused_fill_forcing_top(P, tbar_v, tbar_u, t); }
                         if (extra) fused_fill_extra(P, xd_u, xd_v, t);
                         if (peer && (rc = peer_fill_table(c, GP[mp], cur == 0, t))) return rc;
-                        if (act_on) t->P[FP_ACT_LIVE] = (unsigned long)c->act.list;
+                        if (act_on) { t->P[FP_ACT_LIVE] = (unsigned long)c->act.list; t->P[FP_ACT_LIVE0] = (unsigned long)c->act.list0; }
                     }
             }
         }
@@ -232,7 +260,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         // which tiles of GA are live: h, aice (constant over the sub-cycle) and the sign bits of the current stresses
         ActivityArgs A{};
         A.h = ref_of(c, CSI_F_H); A.a = ref_of(c, CSI_F_A);
-        A.s11 = orig[2]; A.s22 = orig[3]; A.s12 = orig[4];
+        A.s11 = orig[2]; A.s22 = orig[3]; A.s12 = orig[4]; A.u = orig[0]; A.v = orig[1];
         A.rho = P.rho;
         A.dec = GA.rs;
         A.nstrips = GA.nstrips; A.nchunks = GA.nchunks; A.rows = GA.rows; A.elo = GA.elo; A.ehi = GA.ehi;
@@ -240,22 +268,20 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         const Bound &bc = c->f[CSI_F_H], &bf = c->f[CSI_F_S12];
         A.pc = Range{1 - c->Hx, bc.ni - c->Hx, 1 - c->Hy, bc.nj - c->Hy};
         A.pf = Range{1 - c->Hx, bf.ni - c->Hx, 1 - c->Hy, bf.nj - c->Hy};
+        const Bound &bu = c->f[CSI_F_U], &bv = c->f[CSI_F_V];
+        A.pu = Range{1 - c->Hx, bu.ni - c->Hx, 1 - c->Hy, bu.nj - c->Hy};
+        A.pv = Range{1 - c->Hx, bv.ni - c->Hx, 1 - c->Hy, bv.nj - c->Hy};
+        A.Nx = c->Nx; A.Ny = c->Ny; A.Hx = c->Hx; A.Hy = c->Hy;      // (band: the cut grid -- the tiles next to the band count as edge tiles)
         if (peer) {
             const FusedTable* t0 = &(c->host_ring + (size_t)((c->ring_pos - 1) % csi_context::kRing) * (NSINGLE + NPAIR))[NSINGLE];      // (the pair tables just filled)
             for (int q = 0; q < 4; ++q) A.pset[q] = t0->I[FI_PSET + q];
             A.pmask = t0->I[FI_PMASK];
         }
-        launch_tile_activity(A, c->act.flags, c->act.list, c->stream);
         csi_context::Activity& a = c->act;
-        const int q = (int)(a.seq % csi_context::Activity::kSamples);
-        if (!a.used[q] || hipEventQuery(a.ev[q]) == hipSuccess) {      // (a slot still on its way keeps its sample: this one is not read back)
-            HIP_TRY(c, hipMemcpyAsync(a.host + 2 * q, a.list, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipEventRecord(a.ev[q], c->stream));
-            a.used[q] = true; a.sample_scale[q] = a.scale; a.sample_seq[q] = ++a.seq;
-        } else {
-            ++a.seq;
-        }
-        a.last_used = 1;
+        const int id = (int)(a.seq++ & 0x3fffffffu);
+        a.sample_scale[(unsigned)id % csi_context::Activity::kSamples] = a.scale;
+        launch_tile_activity(A, a.flags, a.list, q0_on ? a.list0 : nullptr, a.host_dev, id, c->stream);
+        a.last_used = q0_on ? 2 : 1;
     }
     int cur = 0;   // 0: the caller's arrays hold the current state
     int m = 0, nex = 0, nlaunch = 0, npair = 0;
@@ -278,11 +304,12 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             // (write_diag bit 2: the live tiles of GA only -- not in the first two pair launches, which bring BOTH buffers to the
             //  quiescent tiles' fixed point, halo images included, nor in the last launch, which stores every tile's diagnostics)
             const bool live_only = act_on && npair >= 2 && s + 2 != end;
-            const FusedGeom& GL = live_only ? GA : GP[mp];
+            const bool start_only = q0_on && npair < 2 && s + 2 != end;      // (the first two launches: all but the tiles quiescent from the start)
+            const FusedGeom& GL = (live_only || start_only) ? GA : GP[mp];
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, GL.nstrips, GL.nchunks, GL.rows,
-                              (s + 2 == end ? 1 : 0) | (live_only ? 4 : 0),
+                              (s + 2 == end ? 1 : 0) | (live_only ? 4 : 0) | (start_only ? 8 : 0),
                               peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
             ++npair;
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));

@@ -1109,13 +1109,14 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
     // This workgroup's tile.  XCD-aware: blocks are dealt round-robin over the XCDs, each XCD walks one band of consecutive tiles.
     const int b = (int)blockIdx.x;
     int w = (b & 7) * blocks_per_xcd + (b >> 3);
-    if (write_diag & 4) {
+    if (write_diag & 12) {
         // Tile activity (csi_activity.hip; write_diag bit 2: not one of the first two launches of a sub-cycle, not its last): only the LIVE
         // tiles run -- a quiescent tile (no ice mass in or around it) would store exactly what it stored two launches ago.  The live
         // tiles' numbers come from a list, dealt over the XCDs like the tiles themselves; the workgroups beyond the list leave at once.
         // (Peer-connected launches: the tiles of the direction sets are always on the list -- they publish their flags whatever they hold.)
         typedef const __attribute__((address_space(4))) int* iptr_t;
-        iptr_t act = (iptr_t)((tptr_t)table)->P[FP_ACT_LIVE];
+        // (bit 3: one of the first two launches -- the list that leaves out only the tiles quiescent from the start)
+        iptr_t act = (iptr_t)((tptr_t)table)->P[(write_diag & 8) ? FP_ACT_LIVE0 : FP_ACT_LIVE];
         const int live = act[0], per = (live + 7) >> 3, k = b >> 3, p = (b & 7) * per + k;
         if ((k >= per) | (p >= live)) return;
         w = act[2 + p];

@@ -416,7 +416,9 @@ int32_t csi_set_fusion(csi_context* ctx, int32_t level);
  * launches in between only the live ones, on a finer tiling chosen so that the live tiles fill the GPU once.  Results are
  * bit-identical with skipping off (tests/test_gpu_activity.py) as long as the fields are finite.
  * csi_tile_activity: the newest counts that have arrived from the device (tiles of the live launches, live ones among them;
- * -1 live: none yet), and whether the last sub-cycle used live launches -- call csi_sync first for the last sub-cycle's counts. */
+ * -1 live: none yet), and whether the last sub-cycle used live launches (1; 2: its first two launches also left out the tiles that
+ * were quiescent from the start -- no ice mass, velocities +0.0 already, no halo image to store --, which takes one copy of u, v,
+ * sigma per sub-cycle and is done once a sample has shown quiescent tiles) -- call csi_sync first for the last sub-cycle's counts. */
 int32_t csi_set_tile_skipping(csi_context* ctx, int32_t on);
 int32_t csi_tile_activity(csi_context* ctx, int32_t* tiles, int32_t* live, int32_t* used);
 
