@@ -321,6 +321,7 @@ int32_t csi_grid_set(csi_context* c, int32_t Nx, int32_t Ny, int32_t Hx, int32_t
         c->coef_host = host;          // uploaded, with the Coriolis columns, by sync_coriolis
     }
     for (auto& b : c->f) b = Bound{};   // bindings refer to the previous grid
+    c->act.scale = 1.0; c->act.last_live = -1; c->act.last_tiles = 0; c->act.since_probe = 0;      // (tile activity: what was learnt belongs to the previous grid)
     c->grid_set = true;
     return CSI_OK;
 }
