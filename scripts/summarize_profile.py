@@ -23,8 +23,9 @@ def classify(kname):
 
 
 out = [f"# rocprofv3 summary: {name}\n\n{note}\n\n",
-       "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-full-step`\n"
-       "(2048x2048 periodic f-plane, 120 sub-steps, FAST mode; counters in separate `--pmc` passes)\n\n## kernel stats\n\n",
+       "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-full-step --no-unfused --no-structure`\n"
+       "(a WARM run since round 6: the first ~150 launches from an idle chip are 5-25 % slower, profiles/r06_profiler_vs_bench.md; 2048x2048 periodic f-plane, 120 sub-steps, FAST mode;\n"
+       "counters in separate `--pmc` passes of `--steps 2 --warmup 1`: counts per launch do not depend on the clock)\n\n## kernel stats\n\n",
        "| kernel | calls | avg us | total ms | % |\n|---|---|---|---|---|\n"]
 ks = glob.glob(base + "/trace/*/*_kernel_stats.csv")[0]
 avg = collections.defaultdict(list)
