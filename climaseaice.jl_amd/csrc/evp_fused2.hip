@@ -1104,6 +1104,11 @@ __global__ void __launch_bounds__(128, (FULL || (FORCE && (EXTRA != 1 || !MASK) 
     __shared__ unsigned ringm[MASK ? RING_ROWS * 64 : 1];
     __shared__ double outr[(CSI_PAIR_STORES & 7) != 7 ? 2 * 5 * 64 : 1];      // stage B's results on their way to the producer's stores
     __shared__ unsigned peer_abort_w;                      // PEER: the producer's wait has given up
+#ifdef CSI_EXP_LDSPAD      // TIMING EXPERIMENT ONLY: so many more bytes of LDS per workgroup of the per-point-metric + array-forcing instantiations -- what a
+                           // forcing ring there would cost in occupancy (12 KB more: three workgroups per CU instead of four; profiles/r06_full_force_ring_experiment.txt)
+    __shared__ double lds_pad[(FULL && FORCE) ? CSI_EXP_LDSPAD / 8 : 1];
+    if (FULL && FORCE) { lds_pad[threadIdx.x] = 0.0; asm volatile("" :: "v"(lds_pad[threadIdx.x])); }
+#endif
     constexpr bool LDSC = !UNI && !FULL && !(EXTRA == 1 && MASK) && (CSI_PAIR_LDSC != 0);
     __shared__ double ringc[LDSC ? 8 * FC_COUNT : 1];      // per-row coefficients: an eight-row window (Stage::pc)
     // This workgroup's tile.  XCD-aware: blocks are dealt round-robin over the XCDs, each XCD walks one band of consecutive tiles.
