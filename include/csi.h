@@ -78,10 +78,11 @@ typedef enum {
 typedef enum {
     CSI_METRIC_UNIFORM = 0,   /* RectilinearGrid, regular spacing */
     CSI_METRIC_PER_J = 1,     /* LatitudeLongitudeGrid, regular: metrics vary with j only */
-    CSI_METRIC_FULL = 2       /* orthogonal curvilinear grid (OrthogonalSphericalShellGrid and the like): 2-D metric arrays.
-                               * Every operator takes them (same calls as the reference's Oceananigans.Operators).  FAST
-                               * mode folds them into per-POINT stencil coefficients and runs the three-kernel path (the
-                               * fused kernels rely on coefficients that depend on the row alone). */
+    CSI_METRIC_FULL = 2       /* orthogonal curvilinear grid (OrthogonalSphericalShellGrid, TripolarGrid and the like): 2-D metric
+                               * arrays.  Every operator takes them (same calls as the reference's Oceananigans.Operators).  FAST
+                               * mode folds them into twelve per-POINT coefficient planes; the two-sub-steps kernel has
+                               * instantiations for them (fusion level 2), level 1 runs the three kernels.  Rows whose planes hold
+                               * one value per row are read from per-row vectors (csi_set_row_constant). */
 } csi_metric_kind;
 
 /* Host-side description of the grid metrics (copied by csi_grid_set).  PER_J vectors have
@@ -239,8 +240,8 @@ int32_t csi_velocity_bc_set(csi_context* ctx, int32_t field_id, int32_t side, in
 /* Immersed boundary conditions of u / v: ImmersedBoundaryCondition(west = FluxBoundaryCondition(number), ...) entering
  * immersed_dj_sigma_1j / immersed_dj_sigma_2j (ice_stress_divergence.jl:65-123; the stress is minus the flux on west / south
  * faces and plus the flux on east / north faces, :115-123).  field_id CSI_F_U or CSI_F_V; all zeros (the default) is the
- * reference's default `nothing`.  Non-zero values need a mask (csi_mask_set) to have any effect and run the three-kernel
- * paths (the fused kernels take the default only). */
+ * reference's default `nothing`.  Non-zero values need a mask (csi_mask_set) to have any effect; the two-sub-steps kernel takes
+ * them (their divergence is evaluated once per sub-cycle into two library arrays), the one-sub-step kernel does not (three kernels). */
 int32_t csi_immersed_flux_bc_set(csi_context* ctx, int32_t field_id, double west, double east, double south, double north);
 /* Row-dependent Coriolis parameter: BetaPlane, f = f0 + beta * ynode (upstream x_f_cross_U / y_f_cross_U called at
  * momentum_tendencies_kernel_functions.jl:31,64; in the reference's test matrix, test/test_time_stepping.jl:35).
