@@ -248,42 +248,6 @@ TRIPOLAR = dict(Nx=224, Ny=192, grid="tripolar", tripolar=dict(southernmost_lati
                 field_forcing=True, free_drift=True, coriolis_points=True, ice_edge=58.0, substeps=20)
 
 
-def test_tripolar_grid_structure():
-    g = csi.TripolarGrid((224, 192), southernmost_latitude=-78.0)
-    m = g.metrics()
-    H = 4
-    names = list(m)
-    names.remove("kind")
-    for k in names:
-        assert np.isfinite(m[k]).all() and (m[k] > 0).all()
-    # latitude-longitude rows: one value per row in every plane; the cap: not
-    lat_rows = g.cap_first_row - 1 + H
-    for k in names:
-        assert (m[k][:lat_rows, :] == m[k][:lat_rows, :1]).all()
-    assert not (m["dxcc"][lat_rows + 3, :] == m["dxcc"][lat_rows + 3, 0]).all()
-    # the net is orthogonal: the angle between the two families of lines at the cell centres of the cap
-    lam_e, phi_e = g.nodes_2d(csi.Face, csi.Center)
-    lam_n, phi_n = g.nodes_2d(csi.Center, csi.Face)
-
-    def xyz(lam, phi):
-        l, p = np.deg2rad(lam), np.deg2rad(phi)
-        return np.stack([np.cos(p) * np.cos(l), np.cos(p) * np.sin(l), np.sin(p)], -1)
-    E, N = xyz(lam_e, phi_e), xyz(lam_n, phi_n)
-    tx = E[:-1, 1:, :] - E[:-1, :-1, :]                   # across cell (i, j): east face - west face; i = 1 .. Nx - 1, j = 1 .. Ny - 1
-    ty = N[1:, :-1, :] - N[:-1, :-1, :]                   # north face - south face
-    cosang = np.abs((tx * ty).sum(-1)) / (np.linalg.norm(tx, axis=-1) * np.linalg.norm(ty, axis=-1))
-    cap = slice(g.cap_first_row, g.Ny - 2)
-    inner = np.ones(cosang.shape[1], bool)
-    for ip in (1, g.Nx // 2 + 1):                         # columns next to the pole axis: the cells there wrap around the pole
-        inner[max(ip - 4, 0):ip + 2] = False
-    assert cosang[cap][:, inner].max() < 2e-2             # second-order in the spacing
-    # the fold: row Ny is its own image
-    lam_c, phi_c = g.nodes_2d(csi.Center, csi.Center)
-    assert np.abs(phi_c[-1] - phi_c[-1, ::-1]).max() < 1e-10
-    wet = g.analytic_land()
-    assert not wet[:5].any() and 0.85 < wet.mean() < 0.99
-
-
 def test_tripolar_against_the_oracle_and_both_cuts():
     case = cases.make_case(**TRIPOLAR)
     full, acts, m = run(case, steps=1)
