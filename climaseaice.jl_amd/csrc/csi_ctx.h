@@ -167,6 +167,7 @@ struct csi_context {
     double* band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t band_elems[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipStream_t band_stream = nullptr;
+    hipEvent_t exp_ev[2] = {nullptr, nullptr};      // (CSI_EXP_OVERLAP: the second stream is band_stream)
     hipEvent_t band_ev_pair = nullptr, band_ev_band = nullptr;
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
     double* fbar_top[2] = {nullptr, nullptr};   // the same of the air velocities (array-valued wind drag)
@@ -219,10 +220,11 @@ struct csi_context {
     double rc_rtol = 0.0;                // 0: bitwise-equal columns only (results unchanged); > 0: columns within this relative distance of column 1 count as equal -- CHANGES results at that level
     int rc_rows = 0;                     // rows marked
     int geom_band = 0;    // the pair launches being laid out run beside a fold band (FoldCut / PeerView of a fold tile): see pair_geom
-    int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides
+    int geom_peer = 0;    // ... are launches of the peer transport (PeerView): shorter chunks next to the connected y sides (bit 0; bits 1 / 2: both x / y sides connected)
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, row_target_1024 = 0, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
                     adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
+                    exp_overlap = -1,     // EXPERIMENT (CSI_EXP_OVERLAP, profiles/r06_tile_overlap.txt): bit 0 every tile of a peer-connected launch in the sets of both sides of a connected axis, bit 1 consecutive launches on two streams
                     no_geom_sig = -1;      // debugging aid (CSI_DEBUG_NO_GEOM_SIG=1): skip the launch-geometry check of the peer set-up (tests/test_gpu_local_tiles.py)
       long adv_stage_max_cells = 1L << 40;      // advection-only models: one launch per RK stage up to this many cells (advect_stage_supported; no cut since round 6)
     } tune;
@@ -278,7 +280,7 @@ constexpr int kPeerRecs = csi_context::Peer::NARR + 1;      // + the flag array
 struct PeerView {
     csi_context* c; GridDev g; int Ny;
     explicit PeerView(csi_context* cc) : c(cc), g(cc->g), Ny(cc->Ny), peer_was(cc->geom_peer) {
-        c->geom_peer = 1;
+        c->geom_peer = 1 | (c->g.xlo == SIDE_CONNECTED && c->g.xhi == SIDE_CONNECTED ? 2 : 0) | (c->g.ylo == SIDE_CONNECTED && c->g.yhi == SIDE_CONNECTED ? 4 : 0);
         for (int* side : {&c->g.xlo, &c->g.xhi, &c->g.ylo, &c->g.yhi}) if (*side == SIDE_CONNECTED) *side = SIDE_PERIODIC;
         if (c->g.yhi == SIDE_FOLD) { const int M = c->Ny - c->Hy - 4; c->Ny = M; c->g.Ny = M; c->g.yhi = SIDE_CONNECTED; band = c->geom_band; c->geom_band = 1; }
     }

@@ -292,6 +292,17 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));      // the first band starts behind everything queued so far
         HIP_TRY(c, hipEventRecord(c->band_ev_band, c->stream));      // (nothing for the first pair launch to wait for)
     }
+    // EXPERIMENT (CSI_EXP_OVERLAP bit 1, tiles connected to themselves: profiles/r06_tile_overlap.txt): consecutive launches of the peer
+    // transport on two streams -- with every tile on the flag protocol (bit 0) nothing but the flags orders launch n + 1 behind launch n
+    const bool two_streams = peer && !band && c->tune.exp_overlap > 0 && (c->tune.exp_overlap & 2);
+    if (two_streams) {
+        if (!c->band_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->exp_ev) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->exp_ev[0], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->band_stream, c->exp_ev[0], 0));
+    }
+    int nflip = 0;
+    auto launch_stream = [&]() { return (two_streams && (nflip++ & 1)) ? c->band_stream : c->stream; };
     for (int s = first; s < end;) {
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
         if (pairs && end - s >= 2 && m + 1 < kb) {
@@ -310,7 +321,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, GL.nstrips, GL.nchunks, GL.rows,
                               (s + 2 == end ? 1 : 0) | (live_only ? 4 : 0) | (start_only ? 8 : 0),
-                              peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), c->stream);
+                              peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), launch_stream());
             ++npair;
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 2; s += 2;
@@ -324,7 +335,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
-                              2 | (s + 1 == end ? 1 : 0), peer ? (++c->peer.seq | peer_dld_bit) : 0ull, c->stream);
+                              2 | (s + 1 == end ? 1 : 0), peer ? (++c->peer.seq | peer_dld_bit) : 0ull, launch_stream());
             if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
             m += 1; s += 1;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
@@ -356,6 +367,10 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         }
     }
     if (band) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
+    if (two_streams) {
+        HIP_TRY(c, hipEventRecord(c->exp_ev[1], c->band_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->exp_ev[1], 0));
+    }
     if (peer) {
         // the neighbours' last launch wrote into this rank's halos: wait for all of it before anything later on this stream
         // (the copy back, finalize_rheology!, the next exchange) reads them

@@ -28,6 +28,12 @@ PeerSets peer_wait_counts(const csi_context* c, const FusedGeom& G) {
         if (ja <= reach) ++ps.nS;
         if (jb + reach > c->Ny) ++ps.nN;
     }
+    if (c->tune.exp_overlap > 0 && (c->tune.exp_overlap & 1)) {
+        // EXPERIMENT (profiles/r06_tile_overlap.txt): every tile in the sets of both sides of a connected axis -- each publishes its
+        // flag at every launch and waits before it loads anything, so that consecutive launches need no stream order between them
+        if (c->geom_peer & 4) ps.nS = ps.nN = G.nchunks;
+        if (c->geom_peer & 2) ps.nW = ps.nE = G.nstrips;
+    }
     const int sz[8] = {ps.nW * G.nchunks, ps.nE * G.nchunks, ps.nS * G.nstrips, ps.nN * G.nstrips,
                        ps.nW * ps.nS, ps.nE * ps.nS, ps.nW * ps.nN, ps.nE * ps.nN};
     for (int d = 0; d < 8; ++d) ps.size[d] = sz[d];

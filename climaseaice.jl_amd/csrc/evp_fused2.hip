@@ -58,7 +58,8 @@
                                 // stores at system scope (sc0 sc1) and the flags follow a drained store queue (vmcnt(0)); 0: plain stores and a
                                 // system-scope release fence before the flags -- the fence writes the XCD's whole L2 back (buffer_wbl2), once per
                                 // edge tile: +6 us per launch on a 1024 x 512 tile, +20 us at 2048^2 (profiles/r03_peer_protocol.md); bit 0 alone:
-                                // no fence, bit 2: no wait at the start of an edge tile (timing experiments, not valid protocols)
+                                // no fence, bit 2: no wait at the start of an edge tile (timing experiments, not valid protocols); bit 3: wait for the fifteen tiles
+                                // around this one only (experiment on a tile connected to itself, CSI_EXP_OVERLAP=3: profiles/r06_tile_overlap.txt)
 #endif
 #ifndef CSI_PAIR_SKIPB
 #define CSI_PAIR_SKIPB 0       // 1: the consumer wave skips its first iterations of a tile (pure pipeline lag; see bodyB).  Measured round 5, same-box A/B: 2048 x 256 43.0 G with, 43.4 without; 1024 x 512 43.1 / 43.5 -- the test in every iteration costs more than two idle iterations save: off
@@ -276,6 +277,16 @@ __device__ __forceinline__ void pair_body(const FusedTable* __restrict__ table, 
                 bool dead = false;
                 for (;;) {
                     bool behind = false, poison = false;
+                    if constexpr ((CSI_PEER_EXP & 8) != 0) {
+                        // TIMING EXPERIMENT (a tile connected to ITSELF in y with every tile in its S and N sets, CSI_EXP_OVERLAP=3:
+                        // profiles/r06_tile_overlap.txt): wait for the tiles of the previous launch around this one only (3 strips x 5 chunks) -- the
+                        // tiles whose stores this one reads and whose loads its stores would overtake -- instead of for all of them
+                        const unsigned long long* slots = (const unsigned long long*)T->P[FP_SLOT_IN + 2];      // (direction S)
+                        if (lane < 15) {      // (two chunks up and down: the chunks next to a connected side may be shorter than a footprint's reach)
+                            const int cq = (chunk + lane / 3 - 2 + 2 * nchunks) % nchunks, cs = (strip + lane % 3 - 1 + nstrips) % nstrips;
+                            behind |= __hip_atomic_load(slots + (cq * nstrips + cs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1ull < seq;
+                        }
+                    } else
 #pragma unroll
                     for (int d = 0; d < 8; ++d) {
                         if (!((pdirs >> d) & 1u)) continue;
