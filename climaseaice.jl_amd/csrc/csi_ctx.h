@@ -167,7 +167,8 @@ struct csi_context {
     double* band[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t band_elems[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipStream_t band_stream = nullptr;
-    hipEvent_t exp_ev[2] = {nullptr, nullptr};      // (CSI_EXP_OVERLAP: the second stream is band_stream)
+    hipEvent_t exp_ev[2] = {nullptr, nullptr};      // (CSI_EXP_OVERLAP: the second stream is band_stream; band_cus: order between stream and pair_stream)
+    hipStream_t pair_stream = nullptr;              // fold band with reserved CUs (tune.band_cus): the pair launches' stream, masked to the other CUs
     hipEvent_t band_ev_pair = nullptr, band_ev_band = nullptr;
     double* fbar[2] = {nullptr, nullptr};   // ocean ubar at v points, vbar at u points (array-valued bottom drag)
     double* fbar_top[2] = {nullptr, nullptr};   // the same of the air velocities (array-valued wind drag)
@@ -224,6 +225,9 @@ struct csi_context {
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, row_target_1024 = 0, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
                     adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
+                    band_cus = -1,        // CSI_BAND_CUS: CUs per XCD reserved for the fold band's launches (the pair launches beside them run on the others)
+                    band_cus_share = -1,  // CSI_BAND_CUS_SHARE=1: the band may use every CU (only the pair launches are masked)
+                    exp_band_only = -1,   // TIMING EXPERIMENT (CSI_EXP_BAND_ONLY=1, wrong results): fold grids run the band's launches without the pair launches beside them
                     exp_overlap = -1,     // EXPERIMENT (CSI_EXP_OVERLAP, profiles/r06_tile_overlap.txt): bit 0 every tile of a peer-connected launch in the sets of both sides of a connected axis, bit 1 consecutive launches on two streams
                     no_geom_sig = -1;      // debugging aid (CSI_DEBUG_NO_GEOM_SIG=1): skip the launch-geometry check of the peer set-up (tests/test_gpu_local_tiles.py)
       long adv_stage_max_cells = 1L << 40;      // advection-only models: one launch per RK stage up to this many cells (advect_stage_supported; no cut since round 6)

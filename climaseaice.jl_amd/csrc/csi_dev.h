@@ -85,27 +85,31 @@ struct EvpDev {
 struct Range { int i0, i1, j0, j1; };
 
 // Coriolis parameter at the u / v point (i, j): per point, per row or a number
+// (one conditional load from a selected address: nested loads under nested tests were two memory round trips)
 __device__ __forceinline__ double fcor_at_u(const EvpDev& P, int i, int j) {
-    return P.fcor2_u ? P.fcor2_u[i + (long)j * P.fcor2_ld] : (P.fcor_u ? P.fcor_u[j] : P.fcor);
+    const double* p = P.fcor2_u ? P.fcor2_u + (i + (long)j * P.fcor2_ld) : (P.fcor_u ? P.fcor_u + j : nullptr);
+    return p ? *p : P.fcor;
 }
 __device__ __forceinline__ double fcor_at_v(const EvpDev& P, int i, int j) {
-    return P.fcor2_v ? P.fcor2_v[i + (long)j * P.fcor2_ld] : (P.fcor_v ? P.fcor_v[j] : P.fcor);
+    const double* p = P.fcor2_v ? P.fcor2_v + (i + (long)j * P.fcor2_ld) : (P.fcor_v ? P.fcor_v + j : nullptr);
+    return p ? *p : P.fcor;
 }
 
 // ---- activity / peripheral nodes (upstream Grids.inactive_cell / peripheral_node) ------------
-__device__ __forceinline__ bool inactive_cell(const GridDev& g, int i, int j) {
-    if ((g.xlo == SIDE_WALL && i < 1) || (g.xhi == SIDE_WALL && i > g.Nx)) return true;
-    if ((g.ylo == SIDE_WALL && j < 1) || (g.yhi == SIDE_WALL && j > g.Ny)) return true;
-    if (g.has_mask) {
-        if (i < 1 - g.Hx || i > g.Nx + g.Hx || j < 1 - g.Hy || j > g.Ny + g.Hy) return true;
-        return g.mask[i + (long)j * g.mask_ld] == 0;
-    }
-    return false;
-}
+// (No branch between the tests, and the mask byte is loaded from a clamped index whatever they say: a velocity kernel looks at a dozen
+//  cells, and with a branch around every load each of them was a memory round trip of its own -- forty in k_ustep2 with a mask, the
+//  whole duration of the fold band's latency-bound launches; round 6, profiles/r06_band.md.)
 __device__ __forceinline__ bool inactive_cell_underlying(const GridDev& g, int i, int j) {
-    if ((g.xlo == SIDE_WALL && i < 1) || (g.xhi == SIDE_WALL && i > g.Nx)) return true;
-    if ((g.ylo == SIDE_WALL && j < 1) || (g.yhi == SIDE_WALL && j > g.Ny)) return true;
-    return false;
+    return ((g.xlo == SIDE_WALL) & (i < 1)) | ((g.xhi == SIDE_WALL) & (i > g.Nx)) | ((g.ylo == SIDE_WALL) & (j < 1)) | ((g.yhi == SIDE_WALL) & (j > g.Ny));
+}
+__device__ __forceinline__ bool inactive_cell(const GridDev& g, int i, int j) {
+    bool out = inactive_cell_underlying(g, i, j);
+    if (g.has_mask) {
+        const bool beyond = (i < 1 - g.Hx) | (i > g.Nx + g.Hx) | (j < 1 - g.Hy) | (j > g.Ny + g.Hy);
+        const int ic = min(max(i, 1 - g.Hx), g.Nx + g.Hx), jc = min(max(j, 1 - g.Hy), g.Ny + g.Hy);
+        out |= beyond | (g.mask[ic + (long)jc * g.mask_ld] == 0);
+    }
+    return out;
 }
 __device__ __forceinline__ bool peripheral_u(const GridDev& g, int i, int j) {
     return inactive_cell(g, i, j) | inactive_cell(g, i - 1, j);

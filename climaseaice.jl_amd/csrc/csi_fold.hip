@@ -33,6 +33,19 @@ int32_t ensure_band(csi_context* c) {
         }
     }
     if (!c->band_stream) {
+        // Reserved CUs (tune.band_cus = r per XCD): the band's launches are six dependent, latency-bound kernels per pair of sub-steps
+        // that otherwise queue for wave slots behind the pair kernel's workgroups.  Mask bit k is a CU of XCD k % 8
+        // (scripts/microbench/cu_mask_probe.hip): bits 0 .. 8 r - 1 are r CUs of every XCD.
+        const int r = c->tune.band_cus;
+        if (r > 0 && r < 16) {
+            uint32_t band_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pair_mask[8];
+            for (int k = 0; k < 8 * r; ++k) band_mask[k >> 5] |= 1u << (k & 31);
+            for (int w = 0; w < 8; ++w) pair_mask[w] = ~band_mask[w];
+            if (c->tune.band_cus_share > 0) for (int w = 0; w < 8; ++w) band_mask[w] = 0xffffffffu;
+            HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->band_stream, 8, band_mask));
+            HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->pair_stream, 8, pair_mask));
+            for (hipEvent_t& e : c->exp_ev) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        } else
         HIP_TRY(c, hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_pair, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_band, hipEventDisableTiming));

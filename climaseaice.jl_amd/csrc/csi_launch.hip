@@ -301,14 +301,21 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         HIP_TRY(c, hipEventRecord(c->exp_ev[0], c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->band_stream, c->exp_ev[0], 0));
     }
+    // fold band on reserved CUs (csi_fold.hip, ensure_band): the pair launches beside it on their own stream, masked to the other CUs
+    hipStream_t ps = (band && c->pair_stream) ? c->pair_stream : c->stream;
+    if (ps != c->stream) {
+        HIP_TRY(c, hipEventRecord(c->exp_ev[0], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(ps, c->exp_ev[0], 0));
+    }
+    const bool skip_pair = band && c->tune.exp_band_only > 0;      // TIMING EXPERIMENT (wrong results): the band's launches alone
     int nflip = 0;
-    auto launch_stream = [&]() { return (two_streams && (nflip++ & 1)) ? c->band_stream : c->stream; };
+    auto launch_stream = [&]() { return ps != c->stream ? ps : ((two_streams && (nflip++ & 1)) ? c->band_stream : c->stream); };
     for (int s = first; s < end;) {
         const bool ufirst = (s % 2) == 0;                  // split_explicit_momentum_equations.jl:178
         if (pairs && end - s >= 2 && m + 1 < kb) {
             const int mp = m / 2;
             if (band) {
-                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));       // the previous band: this launch's rows M + 1 .. M + 4
+                HIP_TRY(c, hipStreamWaitEvent(ps, c->band_ev_band, 0));       // the previous band: this launch's rows M + 1 .. M + 4
                 if ((rc = band_substeps(c, *band, fc, cur, s, 2, s + 2 == end))) return rc;
                 nlaunch += 8;
             }
@@ -317,26 +324,28 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             const bool live_only = act_on && npair >= 2 && s + 2 != end;
             const bool start_only = q0_on && npair < 2 && s + 2 != end;      // (the first two launches: all but the tiles quiescent from the start)
             const FusedGeom& GL = (live_only || start_only) ? GA : GP[mp];
+            if (!skip_pair)
             launch_fused_pair(c->dev_tables + NSINGLE + ((mp * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, GL.nstrips, GL.nchunks, GL.rows,
                               (s + 2 == end ? 1 : 0) | (live_only ? 4 : 0) | (start_only ? 8 : 0),
                               peer ? (++c->peer.seq | peer_dld_bit) : (c->tune.peer_kernel > 0 ? 1ull : 0ull), launch_stream());
             ++npair;
-            if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
+            if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, ps));
             m += 2; s += 2;
         } else if (single_by_pair) {
             // one sub-step through the two-sub-steps kernel (write_diag bit 1): masks, array forcing, per-point metrics
             if (band) {
-                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
+                HIP_TRY(c, hipStreamWaitEvent(ps, c->band_ev_band, 0));
                 if ((rc = band_substeps(c, *band, fc, cur, s, 1, s + 1 == end))) return rc;
                 nlaunch += 5;
             }
+            if (!skip_pair)
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),
                               c->metric_kind == CSI_METRIC_FULL ? 2 : (c->coef.uniform != 0 ? 0 : 1), ufirst,
                               has_walls(c) || masked || force || peer_dld_bit != 0, masked, force, P.free_drift != 0, extra_kind, common_forcing, G[m].nstrips, G[m].nchunks, G[m].rows,
                               2 | (s + 1 == end ? 1 : 0), peer ? (++c->peer.seq | peer_dld_bit) : 0ull, launch_stream());
-            if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, c->stream));
+            if (band) HIP_TRY(c, hipEventRecord(c->band_ev_pair, ps));
             m += 1; s += 1;
         } else if (masked || force || c->metric_kind == CSI_METRIC_FULL) {
             // (no pair kernel for this grid -- halo < 4, tiny tiles: the three kernels in place on whichever buffer is current)
@@ -367,8 +376,8 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
         }
     }
     if (band) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->band_ev_band, 0));
-    if (two_streams) {
-        HIP_TRY(c, hipEventRecord(c->exp_ev[1], c->band_stream));
+    if (two_streams || ps != c->stream) {
+        HIP_TRY(c, hipEventRecord(c->exp_ev[1], ps != c->stream ? ps : c->band_stream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->exp_ev[1], 0));
     }
     if (peer) {

@@ -86,9 +86,10 @@ __device__ __forceinline__ fm::VelConst vel_const(const EvpDev& P, const FastCoe
     return k;
 }
 
+// (the value functions below are the kernels' bodies: the three kernels store what they return, the fold band's fused launches
+//  -- k_band_stress, k_band_uv further down -- evaluate the same functions, so that both give the same bits)
 template <bool UNI>
-__global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, TileMap tm) {
-    CELL_IJ(r, tm)
+__device__ __forceinline__ fm::StressOut stress_value(const EvpDev& P, const FastCoef& c, int i, int j) {
     // u, v neighbourhood: u[i-1..i+1][j-1..j+1] (no (i-1, j+1)), v likewise (no (i+1, j-1))
     const double u_mm = P.u(i - 1, j - 1), u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1);
     const double u_m0 = P.u(i - 1, j),     u_00 = P.u(i, j),     u_p0 = P.u(i + 1, j);
@@ -129,8 +130,10 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
     const double mf = fm::avg4(m_mm, m_0m, m_m0, m_00);
     const double kc = UNI ? c.hkc : c.ca_dt * coef<UNI>(c, FC_RAZC, j), kf = UNI ? c.hkf : c.ca_dt * coef<UNI>(c, FC_RAZF, j);
 
-    const fm::StressOut o = fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
-                                              m_00, mf, kc, kf, s11, s22, s12);
+    return fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
+                             m_00, mf, kc, kf, s11, s22, s12);
+}
+__device__ __forceinline__ void store_stress(const EvpDev& P, int i, int j, const fm::StressOut& o) {
     P.s11(i, j) = o.s11;
     P.s22(i, j) = o.s22;
     P.s12(i, j) = o.s12;
@@ -141,92 +144,203 @@ __global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, T
         P.Dl(i, j) = o.xc * o.rDc;
     }
 }
+template <bool UNI>
+__global__ void __launch_bounds__(256) k_stress(EvpDev P, Range r, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
+    store_stress(P, i, j, stress_value<UNI>(P, c, i, j));
+}
 
 // ------------------------------------------------------------------------------------------------
-// external stresses: gather the scalars fm::ext_stress needs
+// external stresses: gather the scalars fm::ext_stress needs.  Two phases -- the loads (ext_gather_*), then the arithmetic
+// (stress_*_from) -- so that a velocity function can issue every load of its point before it uses any (see ustep_value).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stress_x(const StressDev& s, int i, int j, double u, double vbar, double& ex, double& im) {
+struct ExtIn { double own, c0, c1, c2, c3; };      // array values: the own component's (kind 2: tau) and the cross component's four
+__device__ __forceinline__ ExtIn ext_gather_x(const StressDev& s, int i, int j) {
+    ExtIn e{0.0, 0.0, 0.0, 0.0, 0.0};
+    if ((s.kind == 2) | ((s.kind == 3) & (s.ue_kind == 2))) e.own = s.fu(i, j);
+    if ((s.kind == 3) & (s.ve_kind == 2)) { e.c0 = s.fv(i - 1, j); e.c1 = s.fv(i, j); e.c2 = s.fv(i - 1, j + 1); e.c3 = s.fv(i, j + 1); }
+    return e;
+}
+__device__ __forceinline__ ExtIn ext_gather_y(const StressDev& s, int i, int j) {
+    ExtIn e{0.0, 0.0, 0.0, 0.0, 0.0};
+    if ((s.kind == 2) | ((s.kind == 3) & (s.ve_kind == 2))) e.own = s.fv(i, j);
+    if ((s.kind == 3) & (s.ue_kind == 2)) { e.c0 = s.fu(i, j - 1); e.c1 = s.fu(i + 1, j - 1); e.c2 = s.fu(i, j); e.c3 = s.fu(i + 1, j); }
+    return e;
+}
+__device__ __forceinline__ void stress_x_from(const StressDev& s, const ExtIn& e, double u, double vbar, double& ex, double& im) {
     double tau = 0.0, ue = 0.0, vebar = 0.0;
     if (s.kind == 1) tau = s.tau_u;
-    else if (s.kind == 2) tau = s.fu(i, j);
+    else if (s.kind == 2) tau = e.own;
     else if (s.kind == 3) {
-        ue = s.ue_kind == 2 ? s.fu(i, j) : (s.ue_kind == 1 ? s.ue : 0.0);
-        if (s.ve_kind == 2) vebar = fm::avg4(s.fv(i - 1, j), s.fv(i, j), s.fv(i - 1, j + 1), s.fv(i, j + 1));
+        ue = s.ue_kind == 2 ? e.own : (s.ue_kind == 1 ? s.ue : 0.0);
+        if (s.ve_kind == 2) vebar = fm::avg4(e.c0, e.c1, e.c2, e.c3);
         else vebar = (s.ve_kind == 1) ? s.ve : 0.0;
     }
     fm::ext_stress(s.kind, tau, s.rho_e * s.Cd, ue, vebar, u, vbar, ex, im);
 }
-__device__ __forceinline__ void stress_y(const StressDev& s, int i, int j, double v, double ubar, double& ex, double& im) {
+__device__ __forceinline__ void stress_y_from(const StressDev& s, const ExtIn& e, double v, double ubar, double& ex, double& im) {
     double tau = 0.0, ve = 0.0, uebar = 0.0;
     if (s.kind == 1) tau = s.tau_v;
-    else if (s.kind == 2) tau = s.fv(i, j);
+    else if (s.kind == 2) tau = e.own;
     else if (s.kind == 3) {
-        ve = s.ve_kind == 2 ? s.fv(i, j) : (s.ve_kind == 1 ? s.ve : 0.0);
-        if (s.ue_kind == 2) uebar = fm::avg4(s.fu(i, j - 1), s.fu(i + 1, j - 1), s.fu(i, j), s.fu(i + 1, j));
+        ve = s.ve_kind == 2 ? e.own : (s.ve_kind == 1 ? s.ve : 0.0);
+        if (s.ue_kind == 2) uebar = fm::avg4(e.c0, e.c1, e.c2, e.c3);
         else uebar = (s.ue_kind == 1) ? s.ue : 0.0;
     }
     fm::ext_stress(s.kind, tau, s.rho_e * s.Cd, ve, uebar, v, ubar, ex, im);
 }
 
+// the mask bytes of the six cells a velocity point's tests look at, loaded before any is used (csi_dev.h: inactive_cell and the
+// tests made of it -- the same truth tables, from the gathered bytes)
+struct MaskIn { unsigned b0, b1, b2, b3, b4, b5; };      // (a register each: packing bytes would be a use of the loaded values)
+__device__ __forceinline__ unsigned mask_byte(const GridDev& g, int i, int j) {      // (only where the grid has a mask: the kernels' MASK = has_mask)
+    const int ic = min(max(i, 1 - g.Hx), g.Nx + g.Hx), jc = min(max(j, 1 - g.Hy), g.Ny + g.Hy);
+    return g.mask[ic + (long)jc * g.mask_ld];
+}
+__device__ __forceinline__ bool inactive_from(const GridDev& g, int i, int j, unsigned byte) {
+    bool out = inactive_cell_underlying(g, i, j);
+    if (g.has_mask) out |= (i < 1 - g.Hx) | (i > g.Nx + g.Hx) | (j < 1 - g.Hy) | (j > g.Ny + g.Hy) | (byte == 0);
+    return out;
+}
+// everything fm::vel_update_* needs that is not arithmetic on gathered values: the loads of one velocity point
+struct VelIn {
+    double h0, hm, a0, am, al0, alm, w, wn, fd, forcing;
+    ExtIn top, bot;
+    MaskIn m;
+};
+// the stresses a u point reads with the immersed cells' zeroed (MASK), its peripheral flag; cells: 0 (i, j), 1 (i-1, j), 2 (i, j-1), 3 (i-1, j-1), 4 (i, j+1), 5 (i-1, j+1)
+template <bool MASK>
+__device__ __forceinline__ VelIn gather_u(const EvpDev& P, int i, int j) {
+    VelIn q;
+    q.h0 = P.h(i, j); q.hm = P.h(i - 1, j); q.a0 = P.a(i, j); q.am = P.a(i - 1, j);
+    q.al0 = P.al(i, j); q.alm = P.al(i - 1, j);
+    q.w = P.u(i, j); q.wn = P.un(i, j);
+    q.fd = P.free_drift ? P.ufd(i, j) : 0.0;
+    q.forcing = (P.extra && P.has_forcing) ? P.forcing_u(i, j) : 0.0;
+    q.top = ext_gather_x(P.top, i, j);
+    q.bot = ext_gather_x(P.bot, i, j);
+    q.m.b0 = q.m.b1 = q.m.b2 = q.m.b3 = q.m.b4 = q.m.b5 = 1u;
+    if (MASK) { q.m.b0 = mask_byte(P.g, i, j); q.m.b1 = mask_byte(P.g, i - 1, j); q.m.b2 = mask_byte(P.g, i, j - 1); q.m.b3 = mask_byte(P.g, i - 1, j - 1); q.m.b4 = mask_byte(P.g, i, j + 1); q.m.b5 = mask_byte(P.g, i - 1, j + 1); }
+    return q;
+}
+// v point; cells: 0 (i, j), 1 (i, j-1), 2 (i-1, j), 3 (i-1, j-1), 4 (i+1, j), 5 (i+1, j-1)
+template <bool MASK>
+__device__ __forceinline__ VelIn gather_v(const EvpDev& P, int i, int j) {
+    VelIn q;
+    q.h0 = P.h(i, j); q.hm = P.h(i, j - 1); q.a0 = P.a(i, j); q.am = P.a(i, j - 1);
+    q.al0 = P.al(i, j); q.alm = P.al(i, j - 1);
+    q.w = P.v(i, j); q.wn = P.vn(i, j);
+    q.fd = P.free_drift ? P.vfd(i, j) : 0.0;
+    q.forcing = (P.extra && P.has_forcing) ? P.forcing_v(i, j) : 0.0;
+    q.top = ext_gather_y(P.top, i, j);
+    q.bot = ext_gather_y(P.bot, i, j);
+    q.m.b0 = q.m.b1 = q.m.b2 = q.m.b3 = q.m.b4 = q.m.b5 = 1u;
+    if (MASK) { q.m.b0 = mask_byte(P.g, i, j); q.m.b1 = mask_byte(P.g, i, j - 1); q.m.b2 = mask_byte(P.g, i - 1, j); q.m.b3 = mask_byte(P.g, i - 1, j - 1); q.m.b4 = mask_byte(P.g, i + 1, j); q.m.b5 = mask_byte(P.g, i + 1, j - 1); }
+    return q;
+}
+// immersed_peripheral_cc / _ff (csi_dev.h) from gathered bytes: n = inactive, w = inactive without the mask
+struct UMask { bool cc0, ccm, ff0, ffp, peripheral; };
+template <bool MASK>
+__device__ __forceinline__ UMask umask_from(const GridDev& g, int i, int j, const MaskIn& m) {
+    UMask r{false, false, false, false, false};
+    const bool n0 = inactive_from(g, i, j, m.b0), n1 = inactive_from(g, i - 1, j, m.b1);
+    r.peripheral = n0 | n1;
+    if (MASK) {
+        const bool n2 = inactive_from(g, i, j - 1, m.b2), n3 = inactive_from(g, i - 1, j - 1, m.b3), n4 = inactive_from(g, i, j + 1, m.b4), n5 = inactive_from(g, i - 1, j + 1, m.b5);
+        const bool w0 = inactive_cell_underlying(g, i, j), w1 = inactive_cell_underlying(g, i - 1, j), w2 = inactive_cell_underlying(g, i, j - 1),
+                   w3 = inactive_cell_underlying(g, i - 1, j - 1), w4 = inactive_cell_underlying(g, i, j + 1), w5 = inactive_cell_underlying(g, i - 1, j + 1);
+        r.cc0 = n0 & !w0; r.ccm = n1 & !w1;                                  // cells (i, j), (i - 1, j)
+        r.ff0 = (n0 | n1 | n2 | n3) & !(w0 | w1 | w2 | w3);                  // corner (i, j): cells (i, j), (i-1, j), (i, j-1), (i-1, j-1)
+        r.ffp = (n4 | n5 | n0 | n1) & !(w4 | w5 | w0 | w1);                  // corner (i, j + 1)
+    }
+    return r;
+}
+template <bool MASK>
+__device__ __forceinline__ UMask vmask_from(const GridDev& g, int i, int j, const MaskIn& m) {
+    UMask r{false, false, false, false, false};
+    const bool n0 = inactive_from(g, i, j, m.b0), n1 = inactive_from(g, i, j - 1, m.b1);
+    r.peripheral = n0 | n1;
+    if (MASK) {
+        const bool n2 = inactive_from(g, i - 1, j, m.b2), n3 = inactive_from(g, i - 1, j - 1, m.b3), n4 = inactive_from(g, i + 1, j, m.b4), n5 = inactive_from(g, i + 1, j - 1, m.b5);
+        const bool w0 = inactive_cell_underlying(g, i, j), w1 = inactive_cell_underlying(g, i, j - 1), w2 = inactive_cell_underlying(g, i - 1, j),
+                   w3 = inactive_cell_underlying(g, i - 1, j - 1), w4 = inactive_cell_underlying(g, i + 1, j), w5 = inactive_cell_underlying(g, i + 1, j - 1);
+        r.cc0 = n0 & !w0; r.ccm = n1 & !w1;                                  // cells (i, j), (i, j - 1)
+        r.ff0 = (n0 | n2 | n1 | n3) & !(w0 | w2 | w1 | w3);                  // corner (i, j)
+        r.ffp = (n4 | n0 | n5 | n1) & !(w4 | w0 | w5 | w1);                  // corner (i + 1, j): cells (i+1, j), (i, j), (i+1, j-1), (i, j-1)
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // velocity phases
 // ------------------------------------------------------------------------------------------------
+// u after the sub-step at (i, j), given v at the four points around it: (i - 1, j), (i, j), (i - 1, j + 1), (i, j + 1)
+template <bool UNI, bool MASK>
+__device__ __forceinline__ double ustep_value(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
+    // every load of this point first (nothing between them waits for a loaded value: one memory round trip instead of a dozen)
+    const VelIn q = gather_u<MASK>(P, i, j);
+    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
+    const double cE = coef<UNI>(c, FC_E, j), cFN = coef<UNI>(c, FC_FN, j), cFS = coef<UNI>(c, FC_FS, j), cFU = coef<UNI>(c, FC_FU, j);
+    __builtin_amdgcn_sched_barrier(0);
+    const UMask k = umask_from<MASK>(P.g, i, j, q.m);
+    if (MASK) {
+        if (k.cc0) s11_0 = 0.0;
+        if (k.ccm) s11_m = 0.0;
+        if (k.ff0) s12_0 = 0.0;
+        if (k.ffp) s12_p = 0.0;
+    }
+    const double u = q.w, un = q.wn;
+    const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
+    double div = fm::div1(cE, cFN, cFS, s11_0, s11_m, s12_p, s12_0);
+    double ext, imt, exb, imb;
+    stress_x_from(P.top, q.top, u, vbar, ext, imt);
+    stress_x_from(P.bot, q.bot, u, vbar, exb, imb);
+    double cor = cFU * vbar;               // -x_f_cross_U = +f vbar (f = 0 without Coriolis)
+    if (P.extra) { if (P.has_forcing) cor += q.forcing; div += immersed_div_sigma_1(P, i, j); }   // model.forcing.u; immersed flux BCs
+    const double mi = fm::avg2(q.hm * P.rho * q.am, q.h0 * P.rho * q.a0), ai = fm::avg2(q.am, q.a0), abar = fm::avg2(q.alm, q.al0);
+    return P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral, q.fd)
+        : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
+}
 template <bool UNI, bool MASK>
 __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
-    const double h0 = P.h(i, j), hm = P.h(i - 1, j), a0 = P.a(i, j), am = P.a(i - 1, j);
-    const double al0 = P.al(i, j), alm = P.al(i - 1, j);
-    const double u = P.u(i, j), un = P.un(i, j);
-    const double v_m0 = P.v(i - 1, j), v_00 = P.v(i, j), v_mp = P.v(i - 1, j + 1), v_0p = P.v(i, j + 1);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
-    if (MASK) {
-        if (immersed_peripheral_cc(P.g, i, j)) s11_0 = 0.0;
-        if (immersed_peripheral_cc(P.g, i - 1, j)) s11_m = 0.0;
-        if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
-        if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
-    }
-    const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
-    double div = fm::div1(coef<UNI>(c, FC_E, j), coef<UNI>(c, FC_FN, j), coef<UNI>(c, FC_FS, j), s11_0, s11_m, s12_p, s12_0);
-    double ext, imt, exb, imb;
-    stress_x(P.top, i, j, u, vbar, ext, imt);
-    stress_x(P.bot, i, j, u, vbar, exb, imb);
-    double cor = coef<UNI>(c, FC_FU, j) * vbar;               // -x_f_cross_U = +f vbar (f = 0 without Coriolis)
-    if (P.extra) { if (P.has_forcing) cor += P.forcing_u(i, j); div += immersed_div_sigma_1(P, i, j); }   // model.forcing.u; immersed flux BCs
-    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
-    const double res = P.free_drift
-        ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
-        : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j));
-    store_with_images(P.u, P.g, img, i, j, res);
+    store_with_images(P.u, P.g, img, i, j, ustep_value<UNI, MASK>(P, c, i, j, P.v(i - 1, j), P.v(i, j), P.v(i - 1, j + 1), P.v(i, j + 1)));
 }
 
+// v after the sub-step at (i, j), given u at (i, j - 1), (i + 1, j - 1), (i, j), (i + 1, j)
+template <bool UNI, bool MASK>
+__device__ __forceinline__ double vstep_value(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
+    const VelIn q = gather_v<MASK>(P, i, j);
+    double s11_0 = P.s11(i, j), s11_m = P.s11(i, j - 1), s22_0 = P.s22(i, j), s22_m = P.s22(i, j - 1);
+    double s12_0 = P.s12(i, j), s12_p = P.s12(i + 1, j);
+    const double cQ1N = coef<UNI>(c, FC_Q1N, j), cQ2N = coef<UNI>(c, FC_Q2N, j), cQ1S = coef<UNI>(c, FC_Q1S, j), cQ2S = coef<UNI>(c, FC_Q2S, j),
+                 cK = coef<UNI>(c, FC_K, j), cFV = coef<UNI>(c, FC_FV, j);
+    __builtin_amdgcn_sched_barrier(0);
+    const UMask k = vmask_from<MASK>(P.g, i, j, q.m);
+    if (MASK) {
+        if (k.cc0) { s11_0 = 0.0; s22_0 = 0.0; }
+        if (k.ccm) { s11_m = 0.0; s22_m = 0.0; }
+        if (k.ff0) s12_0 = 0.0;
+        if (k.ffp) s12_p = 0.0;
+    }
+    const double v = q.w, vn = q.wn;
+    const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
+    double div = fm::div2<UNI>(cQ1N, cQ2N, cQ1S, cQ2S, cK, s11_0, s22_0, s11_m, s22_m, s12_p, s12_0);
+    double ext, imt, exb, imb;
+    stress_y_from(P.top, q.top, v, ubar, ext, imt);
+    stress_y_from(P.bot, q.bot, v, ubar, exb, imb);
+    double cor = -cFV * ubar;             // -y_f_cross_U = -f ubar
+    if (P.extra) { if (P.has_forcing) cor += q.forcing; div += immersed_div_sigma_2(P, i, j); }
+    const double mi = fm::avg2(q.hm * P.rho * q.am, q.h0 * P.rho * q.a0), ai = fm::avg2(q.am, q.a0), abar = fm::avg2(q.alm, q.al0);
+    return P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral, q.fd)
+        : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
+}
 template <bool UNI, bool MASK>
 __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
-    const double h0 = P.h(i, j), hm = P.h(i, j - 1), a0 = P.a(i, j), am = P.a(i, j - 1);
-    const double al0 = P.al(i, j), alm = P.al(i, j - 1);
-    const double v = P.v(i, j), vn = P.vn(i, j);
-    const double u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1), u_00 = P.u(i, j), u_p0 = P.u(i + 1, j);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i, j - 1), s22_0 = P.s22(i, j), s22_m = P.s22(i, j - 1);
-    double s12_0 = P.s12(i, j), s12_p = P.s12(i + 1, j);
-    if (MASK) {
-        if (immersed_peripheral_cc(P.g, i, j)) { s11_0 = 0.0; s22_0 = 0.0; }
-        if (immersed_peripheral_cc(P.g, i, j - 1)) { s11_m = 0.0; s22_m = 0.0; }
-        if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
-        if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
-    }
-    const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
-    double div = fm::div2<UNI>(coef<UNI>(c, FC_Q1N, j), coef<UNI>(c, FC_Q2N, j), coef<UNI>(c, FC_Q1S, j), coef<UNI>(c, FC_Q2S, j),
-                                coef<UNI>(c, FC_K, j), s11_0, s22_0, s11_m, s22_m, s12_p, s12_0);
-    double ext, imt, exb, imb;
-    stress_y(P.top, i, j, v, ubar, ext, imt);
-    stress_y(P.bot, i, j, v, ubar, exb, imb);
-    double cor = -coef<UNI>(c, FC_FV, j) * ubar;             // -y_f_cross_U = -f ubar
-    if (P.extra) { if (P.has_forcing) cor += P.forcing_v(i, j); div += immersed_div_sigma_2(P, i, j); }
-    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
-    const double res = P.free_drift
-        ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))
-        : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j));
-    store_with_images(P.v, P.g, img, i, j, res);
+    store_with_images(P.v, P.g, img, i, j, vstep_value<UNI, MASK>(P, c, i, j, P.u(i, j - 1), P.u(i + 1, j - 1), P.u(i, j), P.u(i + 1, j)));
 }
 
 
@@ -247,8 +361,7 @@ __device__ __forceinline__ double strain_corner2(const FastCoef& c, int i, int j
                                   c2(c, C2_DXF2, i, j), c2(c, C2_DYF2, i, j), c2(c, C2_RAZF, i, j));
 }
 
-__global__ void __launch_bounds__(256) k_stress2(EvpDev P, Range r, FastCoef c, TileMap tm) {
-    CELL_IJ(r, tm)
+__device__ __forceinline__ fm::StressOut stress_value2(const EvpDev& P, const FastCoef& c, int i, int j) {
     const double u_mm = P.u(i - 1, j - 1), u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1);
     const double u_m0 = P.u(i - 1, j),     u_00 = P.u(i, j),     u_p0 = P.u(i + 1, j);
     const double                           u_0p = P.u(i, j + 1), u_pp = P.u(i + 1, j + 1);
@@ -275,78 +388,167 @@ __global__ void __launch_bounds__(256) k_stress2(EvpDev P, Range r, FastCoef c, 
     const double m_00 = h_00 * P.rho * a_00, m_m0 = h_m0 * P.rho * a_m0, m_0m = h_0m * P.rho * a_0m, m_mm = h_mm * P.rho * a_mm;
     const double mf = fm::avg4(m_mm, m_0m, m_m0, m_00);
     const double kc = c.ca_dt * c2(c, C2_RAZC, i, j), kf = c.ca_dt * c2(c, C2_RAZF, i, j);
-    const fm::StressOut o = fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
-                                              m_00, mf, kc, kf, s11, s22, s12);
-    P.s11(i, j) = o.s11;
-    P.s22(i, j) = o.s22;
-    P.s12(i, j) = o.s12;
-    P.al(i, j) = o.alpha;
-    if (P.write_diag) {
-        P.zf(i, j) = 0.5 * o.zf2;
-        P.zc(i, j) = 0.5 * o.zc2;
-        P.Dl(i, j) = o.xc * o.rDc;
-    }
+    return fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
+                             m_00, mf, kc, kf, s11, s22, s12);
+}
+__global__ void __launch_bounds__(256) k_stress2(EvpDev P, Range r, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
+    store_stress(P, i, j, stress_value2(P, c, i, j));
 }
 
+template <bool MASK>
+__device__ __forceinline__ double ustep_value2(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
+    const VelIn q = gather_u<MASK>(P, i, j);
+    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s22_0 = P.s22(i, j), s22_m = P.s22(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
+    const double dyu = c2(c, C2_DYU, i, j), rdxu = c2(c, C2_RDXU, i, j), razu = c2(c, C2_RAZU, i, j), dyc2_0 = c2(c, C2_DYC2, i, j), dyc2_m = c2(c, C2_DYC2, i - 1, j),
+                 dxf2_p = c2(c, C2_DXF2, i, j + 1), dxf2_0 = c2(c, C2_DXF2, i, j), f = fcor_at_u(P, i, j);
+    __builtin_amdgcn_sched_barrier(0);
+    const UMask k = umask_from<MASK>(P.g, i, j, q.m);
+    if (MASK) {
+        if (k.cc0) { s11_0 = 0.0; s22_0 = 0.0; }
+        if (k.ccm) { s11_m = 0.0; s22_m = 0.0; }
+        if (k.ff0) s12_0 = 0.0;
+        if (k.ffp) s12_p = 0.0;
+    }
+    const double u = q.w, un = q.wn;
+    const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
+    double div = fm::full_div1(dyu, fm::rcp(dyu), rdxu, razu,
+                               s11_0 + s22_0, s11_m + s22_m, dyc2_0 * (s11_0 - s22_0), dyc2_m * (s11_m - s22_m),
+                               dxf2_p * s12_p, dxf2_0 * s12_0);
+    double ext, imt, exb, imb;
+    stress_x_from(P.top, q.top, u, vbar, ext, imt);
+    stress_x_from(P.bot, q.bot, u, vbar, exb, imb);
+    double cor = f * vbar;
+    if (P.extra) { if (P.has_forcing) cor += q.forcing; div += immersed_div_sigma_1(P, i, j); }
+    const double mi = fm::avg2(q.hm * P.rho * q.am, q.h0 * P.rho * q.a0), ai = fm::avg2(q.am, q.a0), abar = fm::avg2(q.alm, q.al0);
+    return P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral, q.fd)
+        : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
+}
 template <bool MASK>
 __global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
-    const double h0 = P.h(i, j), hm = P.h(i - 1, j), a0 = P.a(i, j), am = P.a(i - 1, j);
-    const double al0 = P.al(i, j), alm = P.al(i - 1, j);
-    const double u = P.u(i, j), un = P.un(i, j);
-    const double v_m0 = P.v(i - 1, j), v_00 = P.v(i, j), v_mp = P.v(i - 1, j + 1), v_0p = P.v(i, j + 1);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s22_0 = P.s22(i, j), s22_m = P.s22(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
-    if (MASK) {
-        if (immersed_peripheral_cc(P.g, i, j)) { s11_0 = 0.0; s22_0 = 0.0; }
-        if (immersed_peripheral_cc(P.g, i - 1, j)) { s11_m = 0.0; s22_m = 0.0; }
-        if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
-        if (immersed_peripheral_ff(P.g, i, j + 1)) s12_p = 0.0;
-    }
-    const double vbar = fm::avg4(v_m0, v_00, v_mp, v_0p);
-    double div = fm::full_div1(c2(c, C2_DYU, i, j), fm::rcp(c2(c, C2_DYU, i, j)), c2(c, C2_RDXU, i, j), c2(c, C2_RAZU, i, j),
-                               s11_0 + s22_0, s11_m + s22_m, c2(c, C2_DYC2, i, j) * (s11_0 - s22_0), c2(c, C2_DYC2, i - 1, j) * (s11_m - s22_m),
-                               c2(c, C2_DXF2, i, j + 1) * s12_p, c2(c, C2_DXF2, i, j) * s12_0);
-    double ext, imt, exb, imb;
-    stress_x(P.top, i, j, u, vbar, ext, imt);
-    stress_x(P.bot, i, j, u, vbar, exb, imb);
-    double cor = fcor_at_u(P, i, j) * vbar;
-    if (P.extra) { if (P.has_forcing) cor += P.forcing_u(i, j); div += immersed_div_sigma_1(P, i, j); }
-    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
-    const double res = P.free_drift
-        ? fm::vel_update_avg_fd(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j), P.ufd(i, j))
-        : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_u(P.g, i, j));
-    store_with_images(P.u, P.g, img, i, j, res);
+    store_with_images(P.u, P.g, img, i, j, ustep_value2<MASK>(P, c, i, j, P.v(i - 1, j), P.v(i, j), P.v(i - 1, j + 1), P.v(i, j + 1)));
 }
 
 template <bool MASK>
-__global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
-    CELL_IJ(r, tm)
-    const double h0 = P.h(i, j), hm = P.h(i, j - 1), a0 = P.a(i, j), am = P.a(i, j - 1);
-    const double al0 = P.al(i, j), alm = P.al(i, j - 1);
-    const double v = P.v(i, j), vn = P.vn(i, j);
-    const double u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1), u_00 = P.u(i, j), u_p0 = P.u(i + 1, j);
+__device__ __forceinline__ double vstep_value2(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
+    const VelIn q = gather_v<MASK>(P, i, j);
     double s11_0 = P.s11(i, j), s11_m = P.s11(i, j - 1), s22_0 = P.s22(i, j), s22_m = P.s22(i, j - 1);
     double s12_0 = P.s12(i, j), s12_p = P.s12(i + 1, j);
+    const double dxv = c2(c, C2_DXV, i, j), rdyv = c2(c, C2_RDYV, i, j), razv = c2(c, C2_RAZV, i, j), dxc2_0 = c2(c, C2_DXC2, i, j), dxc2_m = c2(c, C2_DXC2, i, j - 1),
+                 dyf2_p = c2(c, C2_DYF2, i + 1, j), dyf2_0 = c2(c, C2_DYF2, i, j), f = fcor_at_v(P, i, j);
+    __builtin_amdgcn_sched_barrier(0);
+    const UMask k = vmask_from<MASK>(P.g, i, j, q.m);
     if (MASK) {
-        if (immersed_peripheral_cc(P.g, i, j)) { s11_0 = 0.0; s22_0 = 0.0; }
-        if (immersed_peripheral_cc(P.g, i, j - 1)) { s11_m = 0.0; s22_m = 0.0; }
-        if (immersed_peripheral_ff(P.g, i, j)) s12_0 = 0.0;
-        if (immersed_peripheral_ff(P.g, i + 1, j)) s12_p = 0.0;
+        if (k.cc0) { s11_0 = 0.0; s22_0 = 0.0; }
+        if (k.ccm) { s11_m = 0.0; s22_m = 0.0; }
+        if (k.ff0) s12_0 = 0.0;
+        if (k.ffp) s12_p = 0.0;
     }
+    const double v = q.w, vn = q.wn;
     const double ubar = fm::avg4(u_0m, u_pm, u_00, u_p0);
-    double div = fm::full_div2(c2(c, C2_DXV, i, j), fm::rcp(c2(c, C2_DXV, i, j)), c2(c, C2_RDYV, i, j), c2(c, C2_RAZV, i, j),
-                               s11_0 + s22_0, s11_m + s22_m, c2(c, C2_DXC2, i, j) * (s11_0 - s22_0), c2(c, C2_DXC2, i, j - 1) * (s11_m - s22_m),
-                               c2(c, C2_DYF2, i + 1, j) * s12_p, c2(c, C2_DYF2, i, j) * s12_0);
+    double div = fm::full_div2(dxv, fm::rcp(dxv), rdyv, razv,
+                               s11_0 + s22_0, s11_m + s22_m, dxc2_0 * (s11_0 - s22_0), dxc2_m * (s11_m - s22_m),
+                               dyf2_p * s12_p, dyf2_0 * s12_0);
     double ext, imt, exb, imb;
-    stress_y(P.top, i, j, v, ubar, ext, imt);
-    stress_y(P.bot, i, j, v, ubar, exb, imb);
-    double cor = -fcor_at_v(P, i, j) * ubar;
-    if (P.extra) { if (P.has_forcing) cor += P.forcing_v(i, j); div += immersed_div_sigma_2(P, i, j); }
-    const double mi = fm::avg2(hm * P.rho * am, h0 * P.rho * a0), ai = fm::avg2(am, a0), abar = fm::avg2(alm, al0);
-    const double res = P.free_drift
-        ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j), P.vfd(i, j))
-        : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, peripheral_v(P.g, i, j));
-    store_with_images(P.v, P.g, img, i, j, res);
+    stress_y_from(P.top, q.top, v, ubar, ext, imt);
+    stress_y_from(P.bot, q.bot, v, ubar, exb, imb);
+    double cor = -f * ubar;
+    if (P.extra) { if (P.has_forcing) cor += q.forcing; div += immersed_div_sigma_2(P, i, j); }
+    const double mi = fm::avg2(q.hm * P.rho * q.am, q.h0 * P.rho * q.a0), ai = fm::avg2(q.am, q.a0), abar = fm::avg2(q.alm, q.al0);
+    return P.free_drift
+        ? fm::vel_update_avg_fd(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral, q.fd)
+        : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
+}
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
+    CELL_IJ(r, tm)
+    store_with_images(P.v, P.g, img, i, j, vstep_value2<MASK>(P, c, i, j, P.u(i, j - 1), P.u(i + 1, j - 1), P.u(i, j), P.u(i + 1, j)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fold band's launches (csi_fold.hip, round 6b).  Beside a pair launch the band of rows next to a north fold is the critical path
+// of a tripolar sub-cycle: a chain of dependent, latency-bound launches (alone on the chip 96 us per pair of sub-steps -- eight
+// launches of 5-10 us with 4 us between them -- against the pair launch's 97; profiles/r06_band.md).  Two changes halve the chain:
+//   * the two velocity kernels of a sub-step are ONE launch: the thread of point (i, j) evaluates the first component at the (up to)
+//     four points its second component reads -- the same value functions, hence the same bits as the stored values, halo points
+//     through the inverse of store_with_images (periodic x: the source column; the fold: v(i, Ny + 1) = sign * v(Nx - i + 1, Ny)) --,
+//     and stores the first component at its own point.  Inputs and outputs are different arrays (no thread may read a value another
+//     has already replaced);
+//   * no copy kernels: the first sub-step reads the current buffer and writes the band's copies, the second reads those and stores
+//     rows >= M + 1 (BandOut::j0) straight into the other buffer; the second stress launch works in place (it reads sigma at its own
+//     point only) and stores rows >= M + 1 twice.
+// KIND: 0 uniform coefficients, 1 per row, 2 per point (CSI_METRIC_FULL).
+template <int KIND>
+__device__ __forceinline__ fm::StressOut band_stress_value(const EvpDev& P, const FastCoef& c, int i, int j) {
+    if constexpr (KIND == 2) return stress_value2(P, c, i, j);
+    else return stress_value<KIND == 0>(P, c, i, j);
+}
+template <int KIND, bool MASK>
+__device__ __forceinline__ double band_u_value(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
+    if constexpr (KIND == 2) return ustep_value2<MASK>(P, c, i, j, v_m0, v_00, v_mp, v_0p);
+    else return ustep_value<KIND == 0, MASK>(P, c, i, j, v_m0, v_00, v_mp, v_0p);
+}
+template <int KIND, bool MASK>
+__device__ __forceinline__ double band_v_value(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
+    if constexpr (KIND == 2) return vstep_value2<MASK>(P, c, i, j, u_0m, u_pm, u_00, u_p0);
+    else return vstep_value<KIND == 0, MASK>(P, c, i, j, u_0m, u_pm, u_00, u_p0);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(64) k_band_stress(EvpDev P, Range r, FastCoef c, TileMap tm, BandOut o) {
+    CELL_IJ(r, tm)
+    const fm::StressOut s = band_stress_value<KIND>(P, c, i, j);
+    o.a(i, j) = s.s11; o.b(i, j) = s.s22; o.c(i, j) = s.s12;
+    P.al(i, j) = s.alpha;
+    if (o.da.p && j >= o.j0) { o.da(i, j) = s.s11; o.db(i, j) = s.s22; o.dc(i, j) = s.s12; }
+    if (P.write_diag) {
+        P.zf(i, j) = 0.5 * s.zf2;
+        P.zc(i, j) = 0.5 * s.zc2;
+        P.Dl(i, j) = s.xc * s.rDc;
+    }
+}
+
+// r: all columns 1 .. Nx, the rows of r1 and r2 together; r1 / r2: the first / second component's rows (columns 1 .. Nx: x is periodic)
+template <int KIND, bool MASK, bool UFIRST>
+__global__ void __launch_bounds__(64) k_band_uv(EvpDev P, Range r, Range r1, Range r2, ImageSpec imu, ImageSpec imv, FastCoef c, TileMap tm, BandOut o) {
+    CELL_IJ(r, tm)
+    const GridDev& g = P.g;
+    const bool do1 = (j >= r1.j0) & (j <= r1.j1), do2 = (j >= r2.j0) & (j <= r2.j1);
+    if (!(do1 | do2)) return;
+    auto wrap = [&](int ii) __attribute__((always_inline)) { return ii < 1 ? ii + g.Nx : (ii > g.Nx ? ii - g.Nx : ii); };
+    if (UFIRST) {
+        // u where the three-kernel path's v step would read it: a stored new value (rows of r1; halo columns = images of the source
+        // column), else the old one
+        auto u_at = [&](int ii, int jj) __attribute__((always_inline)) -> double {
+            if ((jj < r1.j0) | (jj > r1.j1)) return P.u(ii, jj);
+            const int is = wrap(ii);
+            return band_u_value<KIND, MASK>(P, c, is, jj, P.v(is - 1, jj), P.v(is, jj), P.v(is - 1, jj + 1), P.v(is, jj + 1));
+        };
+        const double u_00 = u_at(i, j);
+        if (do1 & (j >= o.j0)) store_with_images(o.a, g, imu, i, j, u_00);
+        if (do2) {
+            const double res = band_v_value<KIND, MASK>(P, c, i, j, u_at(i, j - 1), u_at(i + 1, j - 1), u_00, u_at(i + 1, j));
+            if (j >= o.j0) store_with_images(o.b, g, imv, i, j, res);
+        }
+    } else {
+        auto v_at = [&](int ii, int jj) __attribute__((always_inline)) -> double {
+            int is = wrap(ii), js = jj;
+            // the fold row Ny + 1 of a (Center, Face) field: the image of row Ny, mirrored in x (store_with_images, csi_dev.h)
+            const bool fold = (imv.yhi == IMG_FOLD) & (jj == g.Ny + 1) & (g.Ny >= r1.j0) & (g.Ny <= r1.j1);
+            if (fold) { is = g.Nx - is + 1; js = g.Ny; }
+            else if ((jj < r1.j0) | (jj > r1.j1)) return P.v(ii, jj);
+            const double val = band_v_value<KIND, MASK>(P, c, is, js, P.u(is, js - 1), P.u(is + 1, js - 1), P.u(is, js), P.u(is + 1, js));
+            return fold ? (double)imv.fold_sign * val : val;
+        };
+        const double v_00 = v_at(i, j);
+        if (do1 & (j >= o.j0)) store_with_images(o.b, g, imv, i, j, v_00);
+        if (do2) {
+            const double res = band_u_value<KIND, MASK>(P, c, i, j, v_at(i - 1, j), v_00, v_at(i - 1, j + 1), v_at(i, j + 1));
+            if (j >= o.j0) store_with_images(o.a, g, imu, i, j, res);
+        }
+    }
 }
 
 }  // namespace fast
@@ -460,6 +662,50 @@ void launch_fast_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, con
         if (m) hipLaunchKernelGGL((fast::k_vstep<false, true>), g, b, 0, s, P, r, im, c, tm);
         else hipLaunchKernelGGL((fast::k_vstep<false, false>), g, b, 0, s, P, r, im, c, tm);
     }
+}
+
+// the fold band's fused launches (fast::k_band_stress, fast::k_band_uv)
+static fast::TileMap tile_map_band(const EvpDev& P, const Range& r, dim3& grid) {      // one-wave workgroups whatever the number of rows
+    fast::TileMap tm;
+    tm.ibase = 1 - P.g.Hx;
+    if (tm.ibase > r.i0) tm.ibase = r.i0;
+    tm.jbase = r.j0;
+    tm.gx = (r.i1 - tm.ibase + fast::TILE_X) / fast::TILE_X;
+    tm.ty = 1;
+    tm.ntiles = tm.gx * (r.j1 - r.j0 + 1);
+    tm.per_xcd = (tm.ntiles + 7) / 8;
+    grid = dim3((unsigned)(tm.per_xcd * 8), 1, 1);
+    return tm;
+}
+void launch_band_stress(const EvpDev& P, const Range& r, const FastCoef& c, const BandOut& o, hipStream_t s) {
+    dim3 b(fast::TILE_X, 1), g;
+    const fast::TileMap tm = tile_map_band(P, r, g);
+    if (c.full) hipLaunchKernelGGL((fast::k_band_stress<2>), g, b, 0, s, P, r, c, tm, o);
+    else if (c.uniform) hipLaunchKernelGGL((fast::k_band_stress<0>), g, b, 0, s, P, r, c, tm, o);
+    else hipLaunchKernelGGL((fast::k_band_stress<1>), g, b, 0, s, P, r, c, tm, o);
+}
+template <int KIND>
+static void launch_band_uv_kind(const EvpDev& P, const Range& r, const Range& r1, const Range& r2, const ImageSpec& imu, const ImageSpec& imv, const FastCoef& c, bool ufirst,
+                                const BandOut& o, hipStream_t s) {
+    dim3 b(fast::TILE_X, 1), g;
+    const fast::TileMap tm = tile_map_band(P, r, g);
+    const bool m = P.g.has_mask != 0;
+    if (m) {
+        if (ufirst) hipLaunchKernelGGL((fast::k_band_uv<KIND, true, true>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
+        else hipLaunchKernelGGL((fast::k_band_uv<KIND, true, false>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
+    } else {
+        if (ufirst) hipLaunchKernelGGL((fast::k_band_uv<KIND, false, true>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
+        else hipLaunchKernelGGL((fast::k_band_uv<KIND, false, false>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
+    }
+}
+void launch_band_uv(const EvpDev& P, const Range& r1, const Range& r2, const ImageSpec& imu, const ImageSpec& imv, const FastCoef& c, bool ufirst, const BandOut& o,
+                    hipStream_t s) {
+    Range r = r1;
+    if (r2.j0 < r.j0) r.j0 = r2.j0;
+    if (r2.j1 > r.j1) r.j1 = r2.j1;
+    if (c.full) launch_band_uv_kind<2>(P, r, r1, r2, imu, imv, c, ufirst, o, s);
+    else if (c.uniform) launch_band_uv_kind<0>(P, r, r1, r2, imu, imv, c, ufirst, o, s);
+    else launch_band_uv_kind<1>(P, r, r1, r2, imu, imv, c, ufirst, o, s);
 }
 
 }  // namespace csi
