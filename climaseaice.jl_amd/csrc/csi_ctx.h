@@ -225,6 +225,7 @@ struct csi_context {
     // tuning aids (A/B runs), read from the environment ONCE, when the context is created; -1 = not set
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, row_target_1024 = 0, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
                     adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
+                    band_fused = -1,      // CSI_BAND_FUSED=0: the fold band on the three kernels + two copies per step (rounds 4-6a); default: six launches per step without copies, loads hoisted (csi_fold.hip band_substeps_fused)
                     band_cus = -1,        // CSI_BAND_CUS: CUs per XCD reserved for the fold band's launches (the pair launches beside them run on the others)
                     band_cus_share = -1,  // CSI_BAND_CUS_SHARE=1: the band may use every CU (only the pair launches are masked)
                     exp_band_only = -1,   // TIMING EXPERIMENT (CSI_EXP_BAND_ONLY=1, wrong results): fold grids run the band's launches without the pair launches beside them
@@ -363,6 +364,7 @@ FRef band_ref(const csi_context* c, int q);
 int32_t ensure_band(csi_context* c);
 int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, const FRef* b, const FRef* d, bool ufirst, int jlo, bool last, hipStream_t st);
 int32_t band_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, int n, bool last);
+int band_launches(const csi_context* c, int n);
 int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int substeps, int first, bool peer = false, const FoldBand* band = nullptr);
 int32_t run_fused_peer(csi_context* c, double dt, const FastCoef& fc, int substeps, int first);
 bool fold_band_supported(csi_context* c, const EvpDev& Pfull, int substeps);

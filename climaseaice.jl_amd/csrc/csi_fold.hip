@@ -65,8 +65,67 @@ int32_t band_substep(csi_context* c, const FoldBand& bd, const FastCoef& fc, con
     else { launch_fast_vstep(Q, from(bd.rv1, jlo + 1), bd.imv, fc, st); launch_fast_ustep(Q, from(bd.r2, jlo + 1), bd.imu, fc, st); }
     return CSI_OK;
 }
+// The same without the copy kernels (round 6b; evp_fast.hip, k_band_stress / k_band_vel): the band's launches are a chain of dependent,
+// latency-bound kernels beside the pair launch -- eight per pair of sub-steps with 3-4 us between two of them; this is six, each with
+// every load of a point in flight at once.  The first sub-step reads the current buffer and writes the band's copies; the second
+// works on those in place and stores rows >= M + 1 into the other buffer as well.  Same bits as band_substep's three kernels (the same
+// value functions; tests/test_gpu_activity.py compares the two paths).
+int32_t band_substeps_fused(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, int n, bool last) {
+    hipStream_t st = c->band_stream;
+    HIP_TRY(c, hipStreamWaitEvent(st, c->band_ev_pair, 0));
+    FRef src[5], dst[5], b[5], d[4];
+    for (int q = 0; q < 5; ++q) {
+        const FRef o = ref_of(c, kPing[q]), a = alt_ref(c, q);
+        src[q] = cur == 0 ? o : a; dst[q] = cur == 0 ? a : o;
+        b[q] = band_ref(c, q);
+    }
+    for (int q = 0; q < 4; ++q) d[q] = band_ref(c, 5 + q);
+    auto from = [&](Range r, int j0) { if (j0 > r.j0) r.j0 = j0; return r; };
+    const FRef none{nullptr, 0};
+    // one sub-step: u, v, sigma from `in` (each launch reads the component it replaces at the point itself only), results into the
+    // band's copies and -- `out` -- rows >= M + 1 into dst
+    auto substep = [&](const FRef* in, bool ufirst, int jlo, bool diag, bool out) {
+        EvpDev Q = bd.P;
+        Q.u = in[0]; Q.v = in[1]; Q.s11 = in[2]; Q.s22 = in[3]; Q.s12 = in[4];
+        Q.al = d[0]; Q.zc = d[1]; Q.zf = d[2]; Q.Dl = d[3];
+        Q.write_diag = diag;
+        const int j0 = bd.M + 1;
+        launch_band_stress(Q, from(bd.rs, jlo), fc, BandOut{b[2], b[3], b[4], out ? dst[2] : none, out ? dst[3] : none, out ? dst[4] : none, j0}, st);
+        Q.s11 = b[2]; Q.s22 = b[3]; Q.s12 = b[4];
+        const BandOut ou{b[0], none, none, out ? dst[0] : none, none, none, j0}, ov{b[1], none, none, out ? dst[1] : none, none, none, j0};
+        if (ufirst) {
+            launch_band_vel(Q, from(bd.ru1, jlo + 1), bd.imu, fc, true, ou, st);
+            Q.u = b[0];                                                              // (v reads the new u)
+            launch_band_vel(Q, from(bd.r2, jlo + 1), bd.imv, fc, false, ov, st);
+        } else {
+            launch_band_vel(Q, from(bd.rv1, jlo + 1), bd.imv, fc, false, ov, st);
+            Q.v = b[1];
+            launch_band_vel(Q, from(bd.r2, jlo + 1), bd.imu, fc, true, ou, st);
+        }
+    };
+    if (n == 2) {
+        substep(src, (s % 2) == 0, bd.M - 5, false, false);
+        substep(b, ((s + 1) % 2) == 0, bd.M - 2, last, true);
+    } else substep(src, (s % 2) == 0, bd.M - 3, last, true);
+    if (last) {
+        CopyBatch diag{};
+        for (int q = 5; q < 9; ++q) {
+            const Bound& bb = band_bound(c, q);
+            const size_t row = (size_t)(bd.M + 1 - 1 + c->Hy), off = row * (size_t)bb.ld;
+            diag.src[diag.count] = c->band[q] + off; diag.dst[diag.count] = bb.p + off; diag.n[diag.count] = (long)(((size_t)bb.nj - row) * (size_t)bb.ld);
+            ++diag.count;
+        }
+        launch_copy_batch(diag, st, 64);
+    }
+    HIP_TRY(c, hipEventRecord(c->band_ev_band, st));
+    return CSI_OK;
+}
+// launches of one band step (the sub-cycle's launch statistics)
+int band_launches(const csi_context* c, int n) { return c->tune.band_fused != 0 ? 3 * n : (n == 2 ? 8 : 5); }
+
 // two sub-steps (or the trailing single one) of the band: buffer `cur` (0: the caller's arrays) -> the other one, on the band's stream
 int32_t band_substeps(csi_context* c, const FoldBand& bd, const FastCoef& fc, int cur, int s, int n, bool last) {
+    if (c->tune.band_fused != 0) return band_substeps_fused(c, bd, fc, cur, s, n, last);
     hipStream_t st = c->band_stream;
     HIP_TRY(c, hipStreamWaitEvent(st, c->band_ev_pair, 0));
     auto rows_from = [&](int q, int j0, const double* src, double* dst, CopyBatch& B) {

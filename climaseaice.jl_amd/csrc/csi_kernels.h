@@ -20,11 +20,11 @@ void launch_fast_init(const EvpDev& P, const Range& r, hipStream_t s);
 void launch_fast_stress(const EvpDev& P, const Range& r, const FastCoef& c, hipStream_t s);
 void launch_fast_ustep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s);
 void launch_fast_vstep(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, hipStream_t s);
-// the fold band's fused launches (evp_fast.hip, k_band_stress / k_band_uv).  a, b, c: where sigma11, sigma22, sigma12 (stress) or u, v
-// (a, b; velocities) are stored; stress: da, db, dc (may be null) take rows >= j0 a second time; velocities: only rows >= j0 are stored.
+// the fold band's launches (evp_fast.hip, k_band_stress / k_band_vel): inputs from P, outputs into other arrays.  stress: a, b, c take
+// sigma11, sigma22, sigma12 and da, db, dc (may be null) rows >= j0 a second time; a velocity component: a (and da, rows >= j0).
 struct BandOut { FRef a, b, c, da, db, dc; int j0; };
 void launch_band_stress(const EvpDev& P, const Range& r, const FastCoef& c, const BandOut& o, hipStream_t s);
-void launch_band_uv(const EvpDev& P, const Range& r1, const Range& r2, const ImageSpec& imu, const ImageSpec& imv, const FastCoef& c, bool ufirst, const BandOut& o, hipStream_t s);
+void launch_band_vel(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, bool u, const BandOut& o, hipStream_t s);
 bool fast_supported(const EvpDev& P);
 
 // fused sub-step (evp_fused.hip): stress + both velocities in one launch, double-buffered u, v, sigma.

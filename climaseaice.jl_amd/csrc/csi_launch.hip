@@ -317,7 +317,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             if (band) {
                 HIP_TRY(c, hipStreamWaitEvent(ps, c->band_ev_band, 0));       // the previous band: this launch's rows M + 1 .. M + 4
                 if ((rc = band_substeps(c, *band, fc, cur, s, 2, s + 2 == end))) return rc;
-                nlaunch += 8;
+                nlaunch += band_launches(c, 2);
             }
             // (write_diag bit 2: the live tiles of GA only -- not in the first two pair launches, which bring BOTH buffers to the
             //  quiescent tiles' fixed point, halo images included, nor in the last launch, which stores every tile's diagnostics)
@@ -338,7 +338,7 @@ int32_t run_fused(csi_context* c, const EvpDev& P, const FastCoef& fc, int subst
             if (band) {
                 HIP_TRY(c, hipStreamWaitEvent(ps, c->band_ev_band, 0));
                 if ((rc = band_substeps(c, *band, fc, cur, s, 1, s + 1 == end))) return rc;
-                nlaunch += 5;
+                nlaunch += band_launches(c, 1);
             }
             if (!skip_pair)
             launch_fused_pair(c->dev_tables + ((m * 2 + cur) * 2 + (ufirst ? 1 : 0)),

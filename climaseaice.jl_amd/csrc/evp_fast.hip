@@ -275,13 +275,21 @@ __device__ __forceinline__ UMask vmask_from(const GridDev& g, int i, int j, cons
 // velocity phases
 // ------------------------------------------------------------------------------------------------
 // u after the sub-step at (i, j), given v at the four points around it: (i - 1, j), (i, j), (i - 1, j + 1), (i, j + 1)
+struct UInRow { VelIn q; double s11_0, s11_m, s12_0, s12_p, cE, cFN, cFS, cFU; };
 template <bool UNI, bool MASK>
-__device__ __forceinline__ double ustep_value(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
-    // every load of this point first (nothing between them waits for a loaded value: one memory round trip instead of a dozen)
-    const VelIn q = gather_u<MASK>(P, i, j);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
-    const double cE = coef<UNI>(c, FC_E, j), cFN = coef<UNI>(c, FC_FN, j), cFS = coef<UNI>(c, FC_FS, j), cFU = coef<UNI>(c, FC_FU, j);
-    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ UInRow ustep_gather(const EvpDev& P, const FastCoef& c, int i, int j) {
+    // every load of this point (nothing between them waits for a loaded value: one memory round trip instead of a dozen)
+    UInRow g;
+    g.q = gather_u<MASK>(P, i, j);
+    g.s11_0 = P.s11(i, j); g.s11_m = P.s11(i - 1, j); g.s12_0 = P.s12(i, j); g.s12_p = P.s12(i, j + 1);
+    g.cE = coef<UNI>(c, FC_E, j); g.cFN = coef<UNI>(c, FC_FN, j); g.cFS = coef<UNI>(c, FC_FS, j); g.cFU = coef<UNI>(c, FC_FU, j);
+    return g;
+}
+template <bool UNI, bool MASK>
+__device__ __forceinline__ double ustep_compute(const EvpDev& P, const FastCoef& c, int i, int j, const UInRow& g, double v_m0, double v_00, double v_mp, double v_0p) {
+    const VelIn& q = g.q;
+    double s11_0 = g.s11_0, s11_m = g.s11_m, s12_0 = g.s12_0, s12_p = g.s12_p;
+    const double cE = g.cE, cFN = g.cFN, cFS = g.cFS, cFU = g.cFU;
     const UMask k = umask_from<MASK>(P.g, i, j, q.m);
     if (MASK) {
         if (k.cc0) s11_0 = 0.0;
@@ -303,20 +311,34 @@ __device__ __forceinline__ double ustep_value(const EvpDev& P, const FastCoef& c
         : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
 }
 template <bool UNI, bool MASK>
+__device__ __forceinline__ double ustep_value(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
+    const UInRow g = ustep_gather<UNI, MASK>(P, c, i, j);
+    __builtin_amdgcn_sched_barrier(0);
+    return ustep_compute<UNI, MASK>(P, c, i, j, g, v_m0, v_00, v_mp, v_0p);
+}
+template <bool UNI, bool MASK>
 __global__ void __launch_bounds__(256) k_ustep(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
     store_with_images(P.u, P.g, img, i, j, ustep_value<UNI, MASK>(P, c, i, j, P.v(i - 1, j), P.v(i, j), P.v(i - 1, j + 1), P.v(i, j + 1)));
 }
 
 // v after the sub-step at (i, j), given u at (i, j - 1), (i + 1, j - 1), (i, j), (i + 1, j)
+struct VInRow { VelIn q; double s11_0, s11_m, s22_0, s22_m, s12_0, s12_p, cQ1N, cQ2N, cQ1S, cQ2S, cK, cFV; };
 template <bool UNI, bool MASK>
-__device__ __forceinline__ double vstep_value(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
-    const VelIn q = gather_v<MASK>(P, i, j);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i, j - 1), s22_0 = P.s22(i, j), s22_m = P.s22(i, j - 1);
-    double s12_0 = P.s12(i, j), s12_p = P.s12(i + 1, j);
-    const double cQ1N = coef<UNI>(c, FC_Q1N, j), cQ2N = coef<UNI>(c, FC_Q2N, j), cQ1S = coef<UNI>(c, FC_Q1S, j), cQ2S = coef<UNI>(c, FC_Q2S, j),
-                 cK = coef<UNI>(c, FC_K, j), cFV = coef<UNI>(c, FC_FV, j);
-    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ VInRow vstep_gather(const EvpDev& P, const FastCoef& c, int i, int j) {
+    VInRow g;
+    g.q = gather_v<MASK>(P, i, j);
+    g.s11_0 = P.s11(i, j); g.s11_m = P.s11(i, j - 1); g.s22_0 = P.s22(i, j); g.s22_m = P.s22(i, j - 1);
+    g.s12_0 = P.s12(i, j); g.s12_p = P.s12(i + 1, j);
+    g.cQ1N = coef<UNI>(c, FC_Q1N, j); g.cQ2N = coef<UNI>(c, FC_Q2N, j); g.cQ1S = coef<UNI>(c, FC_Q1S, j); g.cQ2S = coef<UNI>(c, FC_Q2S, j);
+    g.cK = coef<UNI>(c, FC_K, j); g.cFV = coef<UNI>(c, FC_FV, j);
+    return g;
+}
+template <bool UNI, bool MASK>
+__device__ __forceinline__ double vstep_compute(const EvpDev& P, const FastCoef& c, int i, int j, const VInRow& g, double u_0m, double u_pm, double u_00, double u_p0) {
+    const VelIn& q = g.q;
+    double s11_0 = g.s11_0, s11_m = g.s11_m, s22_0 = g.s22_0, s22_m = g.s22_m, s12_0 = g.s12_0, s12_p = g.s12_p;
+    const double cQ1N = g.cQ1N, cQ2N = g.cQ2N, cQ1S = g.cQ1S, cQ2S = g.cQ2S, cK = g.cK, cFV = g.cFV;
     const UMask k = vmask_from<MASK>(P.g, i, j, q.m);
     if (MASK) {
         if (k.cc0) { s11_0 = 0.0; s22_0 = 0.0; }
@@ -338,6 +360,12 @@ __device__ __forceinline__ double vstep_value(const EvpDev& P, const FastCoef& c
         : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
 }
 template <bool UNI, bool MASK>
+__device__ __forceinline__ double vstep_value(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
+    const VInRow g = vstep_gather<UNI, MASK>(P, c, i, j);
+    __builtin_amdgcn_sched_barrier(0);
+    return vstep_compute<UNI, MASK>(P, c, i, j, g, u_0m, u_pm, u_00, u_p0);
+}
+template <bool UNI, bool MASK>
 __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
     store_with_images(P.v, P.g, img, i, j, vstep_value<UNI, MASK>(P, c, i, j, P.u(i, j - 1), P.u(i + 1, j - 1), P.u(i, j), P.u(i + 1, j)));
@@ -351,17 +379,33 @@ __global__ void __launch_bounds__(256) k_vstep(EvpDev P, Range r, ImageSpec img,
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double c2(const FastCoef& c, int w, int i, int j) { return c.c2[(long)w * c.c2_plane + i + (long)j * c.c2_ld]; }
 
-__device__ __forceinline__ void strain_cell2(const FastCoef& c, int i, int j, double u_e, double u_w, double v_n, double v_s, double& e11, double& e22) {
-    fm::full_strain_cell(c2(c, C2_DYU, i + 1, j) * u_e, c2(c, C2_DYU, i, j) * u_w, c2(c, C2_DXV, i, j + 1) * v_n, c2(c, C2_DXV, i, j) * v_s,
-                         fm::rcp(c2(c, C2_DYU, i + 1, j)) * u_e, fm::rcp(c2(c, C2_DYU, i, j)) * u_w, fm::rcp(c2(c, C2_DXV, i, j + 1)) * v_n, fm::rcp(c2(c, C2_DXV, i, j)) * v_s,
-                         c2(c, C2_DYC2, i, j), c2(c, C2_DXC2, i, j), c2(c, C2_RAZC, i, j), e11, e22);
+// the plane values either straight from memory (where they are used) or from a window around (i, j) loaded beforehand (the fold band's
+// one-wave launches: every load of the point in flight at once, stress_value2_hoisted)
+struct C2Direct {
+    const FastCoef& c;
+    static constexpr bool hoisted = false;
+    __device__ __forceinline__ double operator()(int w, int i, int j) const { return c2(c, w, i, j); }
+};
+struct C2Window {
+    double v[C2_COUNT][3][3];
+    int i0, j0;                       // v[w][a][b] = plane w at (i0 + a, j0 + b)
+    static constexpr bool hoisted = true;
+    __device__ __forceinline__ double operator()(int w, int i, int j) const { return v[w][i - i0][j - j0]; }
+};
+template <class A>
+__device__ __forceinline__ void strain_cell2(const A& m, int i, int j, double u_e, double u_w, double v_n, double v_s, double& e11, double& e22) {
+    fm::full_strain_cell(m(C2_DYU, i + 1, j) * u_e, m(C2_DYU, i, j) * u_w, m(C2_DXV, i, j + 1) * v_n, m(C2_DXV, i, j) * v_s,
+                         fm::rcp(m(C2_DYU, i + 1, j)) * u_e, fm::rcp(m(C2_DYU, i, j)) * u_w, fm::rcp(m(C2_DXV, i, j + 1)) * v_n, fm::rcp(m(C2_DXV, i, j)) * v_s,
+                         m(C2_DYC2, i, j), m(C2_DXC2, i, j), m(C2_RAZC, i, j), e11, e22);
 }
-__device__ __forceinline__ double strain_corner2(const FastCoef& c, int i, int j, double u_n, double u_s, double v_e, double v_w) {
-    return fm::full_strain_corner(c2(c, C2_RDXU, i, j) * u_n, c2(c, C2_RDXU, i, j - 1) * u_s, c2(c, C2_RDYV, i, j) * v_e, c2(c, C2_RDYV, i - 1, j) * v_w,
-                                  c2(c, C2_DXF2, i, j), c2(c, C2_DYF2, i, j), c2(c, C2_RAZF, i, j));
+template <class A>
+__device__ __forceinline__ double strain_corner2(const A& m, int i, int j, double u_n, double u_s, double v_e, double v_w) {
+    return fm::full_strain_corner(m(C2_RDXU, i, j) * u_n, m(C2_RDXU, i, j - 1) * u_s, m(C2_RDYV, i, j) * v_e, m(C2_RDYV, i - 1, j) * v_w,
+                                  m(C2_DXF2, i, j), m(C2_DYF2, i, j), m(C2_RAZF, i, j));
 }
 
-__device__ __forceinline__ fm::StressOut stress_value2(const EvpDev& P, const FastCoef& c, int i, int j) {
+template <class A>
+__device__ __forceinline__ fm::StressOut stress_core2(const EvpDev& P, const FastCoef& c, const A& m, int i, int j) {
     const double u_mm = P.u(i - 1, j - 1), u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1);
     const double u_m0 = P.u(i - 1, j),     u_00 = P.u(i, j),     u_p0 = P.u(i + 1, j);
     const double                           u_0p = P.u(i, j + 1), u_pp = P.u(i + 1, j + 1);
@@ -372,37 +416,81 @@ __device__ __forceinline__ fm::StressOut stress_value2(const EvpDev& P, const Fa
     const double h_mm = P.h(i - 1, j - 1), h_0m = P.h(i, j - 1), h_m0 = P.h(i - 1, j), h_00 = P.h(i, j);
     const double a_mm = P.a(i - 1, j - 1), a_0m = P.a(i, j - 1), a_m0 = P.a(i - 1, j), a_00 = P.a(i, j);
     const double s11 = P.s11(i, j), s22 = P.s22(i, j), s12 = P.s12(i, j);
+    if (A::hoisted) __builtin_amdgcn_sched_barrier(0);
     double e11_00, e22_00, e11_m0, e22_m0, e11_0m, e22_0m, e11_mm, e22_mm;
-    strain_cell2(c, i, j, u_p0, u_00, v_0p, v_00, e11_00, e22_00);
-    strain_cell2(c, i - 1, j, u_00, u_m0, v_mp, v_m0, e11_m0, e22_m0);
-    strain_cell2(c, i, j - 1, u_pm, u_0m, v_00, v_0m, e11_0m, e22_0m);
-    strain_cell2(c, i - 1, j - 1, u_0m, u_mm, v_m0, v_mm, e11_mm, e22_mm);
-    const double e12_00 = strain_corner2(c, i, j, u_00, u_0m, v_00, v_m0);
-    const double e12_p0 = strain_corner2(c, i + 1, j, u_p0, u_pm, v_p0, v_00);
-    const double e12_0p = strain_corner2(c, i, j + 1, u_0p, u_00, v_0p, v_mp);
-    const double e12_pp = strain_corner2(c, i + 1, j + 1, u_pp, u_p0, v_pp, v_0p);
+    strain_cell2(m, i, j, u_p0, u_00, v_0p, v_00, e11_00, e22_00);
+    strain_cell2(m, i - 1, j, u_00, u_m0, v_mp, v_m0, e11_m0, e22_m0);
+    strain_cell2(m, i, j - 1, u_pm, u_0m, v_00, v_0m, e11_0m, e22_0m);
+    strain_cell2(m, i - 1, j - 1, u_0m, u_mm, v_m0, v_mm, e11_mm, e22_mm);
+    const double e12_00 = strain_corner2(m, i, j, u_00, u_0m, v_00, v_m0);
+    const double e12_p0 = strain_corner2(m, i + 1, j, u_p0, u_pm, v_p0, v_00);
+    const double e12_0p = strain_corner2(m, i, j + 1, u_0p, u_00, v_0p, v_mp);
+    const double e12_pp = strain_corner2(m, i + 1, j + 1, u_pp, u_p0, v_pp, v_0p);
     const double e11f = fm::avg4(e11_mm, e11_0m, e11_m0, e11_00);
     const double e22f = fm::avg4(e22_mm, e22_0m, e22_m0, e22_00);
     const double e12c = fm::avg4(e12_00, e12_p0, e12_0p, e12_pp);
     const double Pf = fm::avg4(P_mm, P_0m, P_m0, P_00);
     const double m_00 = h_00 * P.rho * a_00, m_m0 = h_m0 * P.rho * a_m0, m_0m = h_0m * P.rho * a_0m, m_mm = h_mm * P.rho * a_mm;
     const double mf = fm::avg4(m_mm, m_0m, m_m0, m_00);
-    const double kc = c.ca_dt * c2(c, C2_RAZC, i, j), kf = c.ca_dt * c2(c, C2_RAZF, i, j);
+    const double kc = c.ca_dt * m(C2_RAZC, i, j), kf = c.ca_dt * m(C2_RAZF, i, j);
     return fm::stress_update(stress_const(P, c), e11_00, e22_00, e12_00, e11f, e22f, e12c, P_00, Pf,
                              m_00, mf, kc, kf, s11, s22, s12);
+}
+__device__ __forceinline__ fm::StressOut stress_value2(const EvpDev& P, const FastCoef& c, int i, int j) {
+    return stress_core2(P, c, C2Direct{c}, i, j);
+}
+// the same with the 48 plane values of the point loaded first (160 vector registers more: one-wave workgroups only)
+__device__ __forceinline__ fm::StressOut stress_value2_hoisted(const EvpDev& P, const FastCoef& c, int i, int j) {
+    C2Window w;
+    w.i0 = i - 1; w.j0 = j - 1;
+#define CSI_W(pl, a, b) w.v[pl][(a) + 1][(b) + 1] = c2(c, pl, i + (a), j + (b))
+#pragma unroll
+    for (int a = -1; a <= 1; ++a)
+#pragma unroll
+        for (int b = -1; b <= 0; ++b) CSI_W(C2_DYU, a, b);           // cells (i-1 .. i, j-1 .. j): their east and west faces
+#pragma unroll
+    for (int a = -1; a <= 0; ++a)
+#pragma unroll
+        for (int b = -1; b <= 1; ++b) CSI_W(C2_DXV, a, b);           // ... north and south faces
+#pragma unroll
+    for (int a = -1; a <= 0; ++a)
+#pragma unroll
+        for (int b = -1; b <= 0; ++b) { CSI_W(C2_DYC2, a, b); CSI_W(C2_DXC2, a, b); CSI_W(C2_RAZC, a, b); }
+#pragma unroll
+    for (int a = 0; a <= 1; ++a)
+#pragma unroll
+        for (int b = -1; b <= 1; ++b) CSI_W(C2_RDXU, a, b);          // corners (i .. i+1, j .. j+1): the u points north and south of them
+#pragma unroll
+    for (int a = -1; a <= 1; ++a)
+#pragma unroll
+        for (int b = 0; b <= 1; ++b) CSI_W(C2_RDYV, a, b);           // ... the v points east and west
+#pragma unroll
+    for (int a = 0; a <= 1; ++a)
+#pragma unroll
+        for (int b = 0; b <= 1; ++b) { CSI_W(C2_DXF2, a, b); CSI_W(C2_DYF2, a, b); CSI_W(C2_RAZF, a, b); }
+#undef CSI_W
+    return stress_core2(P, c, w, i, j);
 }
 __global__ void __launch_bounds__(256) k_stress2(EvpDev P, Range r, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
     store_stress(P, i, j, stress_value2(P, c, i, j));
 }
 
+struct UInFull { VelIn q; double s11_0, s11_m, s22_0, s22_m, s12_0, s12_p, dyu, rdxu, razu, dyc2_0, dyc2_m, dxf2_p, dxf2_0, f; };
 template <bool MASK>
-__device__ __forceinline__ double ustep_value2(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
-    const VelIn q = gather_u<MASK>(P, i, j);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i - 1, j), s22_0 = P.s22(i, j), s22_m = P.s22(i - 1, j), s12_0 = P.s12(i, j), s12_p = P.s12(i, j + 1);
-    const double dyu = c2(c, C2_DYU, i, j), rdxu = c2(c, C2_RDXU, i, j), razu = c2(c, C2_RAZU, i, j), dyc2_0 = c2(c, C2_DYC2, i, j), dyc2_m = c2(c, C2_DYC2, i - 1, j),
-                 dxf2_p = c2(c, C2_DXF2, i, j + 1), dxf2_0 = c2(c, C2_DXF2, i, j), f = fcor_at_u(P, i, j);
-    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ UInFull ustep_gather2(const EvpDev& P, const FastCoef& c, int i, int j) {
+    UInFull g;
+    g.q = gather_u<MASK>(P, i, j);
+    g.s11_0 = P.s11(i, j); g.s11_m = P.s11(i - 1, j); g.s22_0 = P.s22(i, j); g.s22_m = P.s22(i - 1, j); g.s12_0 = P.s12(i, j); g.s12_p = P.s12(i, j + 1);
+    g.dyu = c2(c, C2_DYU, i, j); g.rdxu = c2(c, C2_RDXU, i, j); g.razu = c2(c, C2_RAZU, i, j); g.dyc2_0 = c2(c, C2_DYC2, i, j); g.dyc2_m = c2(c, C2_DYC2, i - 1, j);
+    g.dxf2_p = c2(c, C2_DXF2, i, j + 1); g.dxf2_0 = c2(c, C2_DXF2, i, j); g.f = fcor_at_u(P, i, j);
+    return g;
+}
+template <bool MASK>
+__device__ __forceinline__ double ustep_compute2(const EvpDev& P, const FastCoef& c, int i, int j, const UInFull& g, double v_m0, double v_00, double v_mp, double v_0p) {
+    const VelIn& q = g.q;
+    double s11_0 = g.s11_0, s11_m = g.s11_m, s22_0 = g.s22_0, s22_m = g.s22_m, s12_0 = g.s12_0, s12_p = g.s12_p;
+    const double dyu = g.dyu, rdxu = g.rdxu, razu = g.razu, dyc2_0 = g.dyc2_0, dyc2_m = g.dyc2_m, dxf2_p = g.dxf2_p, dxf2_0 = g.dxf2_0, f = g.f;
     const UMask k = umask_from<MASK>(P.g, i, j, q.m);
     if (MASK) {
         if (k.cc0) { s11_0 = 0.0; s22_0 = 0.0; }
@@ -426,19 +514,33 @@ __device__ __forceinline__ double ustep_value2(const EvpDev& P, const FastCoef& 
         : fm::vel_update_avg(vel_const(P, c), u, un, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
 }
 template <bool MASK>
+__device__ __forceinline__ double ustep_value2(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
+    const UInFull g = ustep_gather2<MASK>(P, c, i, j);
+    __builtin_amdgcn_sched_barrier(0);
+    return ustep_compute2<MASK>(P, c, i, j, g, v_m0, v_00, v_mp, v_0p);
+}
+template <bool MASK>
 __global__ void __launch_bounds__(256) k_ustep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
     store_with_images(P.u, P.g, img, i, j, ustep_value2<MASK>(P, c, i, j, P.v(i - 1, j), P.v(i, j), P.v(i - 1, j + 1), P.v(i, j + 1)));
 }
 
+struct VInFull { VelIn q; double s11_0, s11_m, s22_0, s22_m, s12_0, s12_p, dxv, rdyv, razv, dxc2_0, dxc2_m, dyf2_p, dyf2_0, f; };
 template <bool MASK>
-__device__ __forceinline__ double vstep_value2(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
-    const VelIn q = gather_v<MASK>(P, i, j);
-    double s11_0 = P.s11(i, j), s11_m = P.s11(i, j - 1), s22_0 = P.s22(i, j), s22_m = P.s22(i, j - 1);
-    double s12_0 = P.s12(i, j), s12_p = P.s12(i + 1, j);
-    const double dxv = c2(c, C2_DXV, i, j), rdyv = c2(c, C2_RDYV, i, j), razv = c2(c, C2_RAZV, i, j), dxc2_0 = c2(c, C2_DXC2, i, j), dxc2_m = c2(c, C2_DXC2, i, j - 1),
-                 dyf2_p = c2(c, C2_DYF2, i + 1, j), dyf2_0 = c2(c, C2_DYF2, i, j), f = fcor_at_v(P, i, j);
-    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ VInFull vstep_gather2(const EvpDev& P, const FastCoef& c, int i, int j) {
+    VInFull g;
+    g.q = gather_v<MASK>(P, i, j);
+    g.s11_0 = P.s11(i, j); g.s11_m = P.s11(i, j - 1); g.s22_0 = P.s22(i, j); g.s22_m = P.s22(i, j - 1);
+    g.s12_0 = P.s12(i, j); g.s12_p = P.s12(i + 1, j);
+    g.dxv = c2(c, C2_DXV, i, j); g.rdyv = c2(c, C2_RDYV, i, j); g.razv = c2(c, C2_RAZV, i, j); g.dxc2_0 = c2(c, C2_DXC2, i, j); g.dxc2_m = c2(c, C2_DXC2, i, j - 1);
+    g.dyf2_p = c2(c, C2_DYF2, i + 1, j); g.dyf2_0 = c2(c, C2_DYF2, i, j); g.f = fcor_at_v(P, i, j);
+    return g;
+}
+template <bool MASK>
+__device__ __forceinline__ double vstep_compute2(const EvpDev& P, const FastCoef& c, int i, int j, const VInFull& g, double u_0m, double u_pm, double u_00, double u_p0) {
+    const VelIn& q = g.q;
+    double s11_0 = g.s11_0, s11_m = g.s11_m, s22_0 = g.s22_0, s22_m = g.s22_m, s12_0 = g.s12_0, s12_p = g.s12_p;
+    const double dxv = g.dxv, rdyv = g.rdyv, razv = g.razv, dxc2_0 = g.dxc2_0, dxc2_m = g.dxc2_m, dyf2_p = g.dyf2_p, dyf2_0 = g.dyf2_0, f = g.f;
     const UMask k = vmask_from<MASK>(P.g, i, j, q.m);
     if (MASK) {
         if (k.cc0) { s11_0 = 0.0; s22_0 = 0.0; }
@@ -462,6 +564,12 @@ __device__ __forceinline__ double vstep_value2(const EvpDev& P, const FastCoef& 
         : fm::vel_update_avg(vel_const(P, c), v, vn, mi, ai, abar, div, cor, ext, imt, exb, imb, k.peripheral);
 }
 template <bool MASK>
+__device__ __forceinline__ double vstep_value2(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
+    const VInFull g = vstep_gather2<MASK>(P, c, i, j);
+    __builtin_amdgcn_sched_barrier(0);
+    return vstep_compute2<MASK>(P, c, i, j, g, u_0m, u_pm, u_00, u_p0);
+}
+template <bool MASK>
 __global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm) {
     CELL_IJ(r, tm)
     store_with_images(P.v, P.g, img, i, j, vstep_value2<MASK>(P, c, i, j, P.u(i, j - 1), P.u(i + 1, j - 1), P.u(i, j), P.u(i + 1, j)));
@@ -470,32 +578,19 @@ __global__ void __launch_bounds__(256) k_vstep2(EvpDev P, Range r, ImageSpec img
 // ------------------------------------------------------------------------------------------------
 // The fold band's launches (csi_fold.hip, round 6b).  Beside a pair launch the band of rows next to a north fold is the critical path
 // of a tripolar sub-cycle: a chain of dependent, latency-bound launches (alone on the chip 96 us per pair of sub-steps -- eight
-// launches of 5-10 us with 4 us between them -- against the pair launch's 97; profiles/r06_band.md).  Two changes halve the chain:
-//   * the two velocity kernels of a sub-step are ONE launch: the thread of point (i, j) evaluates the first component at the (up to)
-//     four points its second component reads -- the same value functions, hence the same bits as the stored values, halo points
-//     through the inverse of store_with_images (periodic x: the source column; the fold: v(i, Ny + 1) = sign * v(Nx - i + 1, Ny)) --,
-//     and stores the first component at its own point.  Inputs and outputs are different arrays (no thread may read a value another
-//     has already replaced);
-//   * no copy kernels: the first sub-step reads the current buffer and writes the band's copies, the second reads those and stores
-//     rows >= M + 1 (BandOut::j0) straight into the other buffer; the second stress launch works in place (it reads sigma at its own
-//     point only) and stores rows >= M + 1 twice.
+// launches of 5-10 us with 3-4 us between them -- against the pair launch's 97; profiles/r06_band.md).  What shortens the chain:
+//   * every load of a point in flight before any is used (the value functions above; the stress launch with its 48 plane values
+//     loaded first, stress_value2_hoisted: a one-wave workgroup has the registers);
+//   * no copy kernels: inputs and outputs are separate arrays -- the first sub-step reads the current buffer and writes the band's
+//     copies, the second works on those in place and stores rows >= M + 1 (BandOut::j0) into the other buffer as well.
+// (Measured and NOT kept: both velocity components in one launch, the first evaluated again at the four points the second reads --
+//  five evaluations in one thread take longer than two launches of one, and a 256-register wave finds no slot beside a pair launch.)
 // KIND: 0 uniform coefficients, 1 per row, 2 per point (CSI_METRIC_FULL).
 template <int KIND>
 __device__ __forceinline__ fm::StressOut band_stress_value(const EvpDev& P, const FastCoef& c, int i, int j) {
-    if constexpr (KIND == 2) return stress_value2(P, c, i, j);
+    if constexpr (KIND == 2) return stress_value2_hoisted(P, c, i, j);
     else return stress_value<KIND == 0>(P, c, i, j);
 }
-template <int KIND, bool MASK>
-__device__ __forceinline__ double band_u_value(const EvpDev& P, const FastCoef& c, int i, int j, double v_m0, double v_00, double v_mp, double v_0p) {
-    if constexpr (KIND == 2) return ustep_value2<MASK>(P, c, i, j, v_m0, v_00, v_mp, v_0p);
-    else return ustep_value<KIND == 0, MASK>(P, c, i, j, v_m0, v_00, v_mp, v_0p);
-}
-template <int KIND, bool MASK>
-__device__ __forceinline__ double band_v_value(const EvpDev& P, const FastCoef& c, int i, int j, double u_0m, double u_pm, double u_00, double u_p0) {
-    if constexpr (KIND == 2) return vstep_value2<MASK>(P, c, i, j, u_0m, u_pm, u_00, u_p0);
-    else return vstep_value<KIND == 0, MASK>(P, c, i, j, u_0m, u_pm, u_00, u_p0);
-}
-
 template <int KIND>
 __global__ void __launch_bounds__(64) k_band_stress(EvpDev P, Range r, FastCoef c, TileMap tm, BandOut o) {
     CELL_IJ(r, tm)
@@ -510,45 +605,22 @@ __global__ void __launch_bounds__(64) k_band_stress(EvpDev P, Range r, FastCoef 
     }
 }
 
-// r: all columns 1 .. Nx, the rows of r1 and r2 together; r1 / r2: the first / second component's rows (columns 1 .. Nx: x is periodic)
-template <int KIND, bool MASK, bool UFIRST>
-__global__ void __launch_bounds__(64) k_band_uv(EvpDev P, Range r, Range r1, Range r2, ImageSpec imu, ImageSpec imv, FastCoef c, TileMap tm, BandOut o) {
+// one velocity component (U: u, else v) of the band: inputs from P, the result (+ its halo images) into o.a and, rows >= o.j0, into o.da
+template <int KIND, bool MASK, bool U>
+__global__ void __launch_bounds__(64) k_band_vel(EvpDev P, Range r, ImageSpec img, FastCoef c, TileMap tm, BandOut o) {
     CELL_IJ(r, tm)
-    const GridDev& g = P.g;
-    const bool do1 = (j >= r1.j0) & (j <= r1.j1), do2 = (j >= r2.j0) & (j <= r2.j1);
-    if (!(do1 | do2)) return;
-    auto wrap = [&](int ii) __attribute__((always_inline)) { return ii < 1 ? ii + g.Nx : (ii > g.Nx ? ii - g.Nx : ii); };
-    if (UFIRST) {
-        // u where the three-kernel path's v step would read it: a stored new value (rows of r1; halo columns = images of the source
-        // column), else the old one
-        auto u_at = [&](int ii, int jj) __attribute__((always_inline)) -> double {
-            if ((jj < r1.j0) | (jj > r1.j1)) return P.u(ii, jj);
-            const int is = wrap(ii);
-            return band_u_value<KIND, MASK>(P, c, is, jj, P.v(is - 1, jj), P.v(is, jj), P.v(is - 1, jj + 1), P.v(is, jj + 1));
-        };
-        const double u_00 = u_at(i, j);
-        if (do1 & (j >= o.j0)) store_with_images(o.a, g, imu, i, j, u_00);
-        if (do2) {
-            const double res = band_v_value<KIND, MASK>(P, c, i, j, u_at(i, j - 1), u_at(i + 1, j - 1), u_00, u_at(i + 1, j));
-            if (j >= o.j0) store_with_images(o.b, g, imv, i, j, res);
-        }
+    double res;
+    if constexpr (U) {
+        const double v_m0 = P.v(i - 1, j), v_00 = P.v(i, j), v_mp = P.v(i - 1, j + 1), v_0p = P.v(i, j + 1);
+        if constexpr (KIND == 2) res = ustep_value2<MASK>(P, c, i, j, v_m0, v_00, v_mp, v_0p);
+        else res = ustep_value<KIND == 0, MASK>(P, c, i, j, v_m0, v_00, v_mp, v_0p);
     } else {
-        auto v_at = [&](int ii, int jj) __attribute__((always_inline)) -> double {
-            int is = wrap(ii), js = jj;
-            // the fold row Ny + 1 of a (Center, Face) field: the image of row Ny, mirrored in x (store_with_images, csi_dev.h)
-            const bool fold = (imv.yhi == IMG_FOLD) & (jj == g.Ny + 1) & (g.Ny >= r1.j0) & (g.Ny <= r1.j1);
-            if (fold) { is = g.Nx - is + 1; js = g.Ny; }
-            else if ((jj < r1.j0) | (jj > r1.j1)) return P.v(ii, jj);
-            const double val = band_v_value<KIND, MASK>(P, c, is, js, P.u(is, js - 1), P.u(is + 1, js - 1), P.u(is, js), P.u(is + 1, js));
-            return fold ? (double)imv.fold_sign * val : val;
-        };
-        const double v_00 = v_at(i, j);
-        if (do1 & (j >= o.j0)) store_with_images(o.b, g, imv, i, j, v_00);
-        if (do2) {
-            const double res = band_u_value<KIND, MASK>(P, c, i, j, v_at(i - 1, j), v_00, v_at(i - 1, j + 1), v_at(i, j + 1));
-            if (j >= o.j0) store_with_images(o.a, g, imu, i, j, res);
-        }
+        const double u_0m = P.u(i, j - 1), u_pm = P.u(i + 1, j - 1), u_00 = P.u(i, j), u_p0 = P.u(i + 1, j);
+        if constexpr (KIND == 2) res = vstep_value2<MASK>(P, c, i, j, u_0m, u_pm, u_00, u_p0);
+        else res = vstep_value<KIND == 0, MASK>(P, c, i, j, u_0m, u_pm, u_00, u_p0);
     }
+    store_with_images(o.a, P.g, img, i, j, res);
+    if (o.da.p && j >= o.j0) store_with_images(o.da, P.g, img, i, j, res);
 }
 
 }  // namespace fast
@@ -685,27 +757,22 @@ void launch_band_stress(const EvpDev& P, const Range& r, const FastCoef& c, cons
     else hipLaunchKernelGGL((fast::k_band_stress<1>), g, b, 0, s, P, r, c, tm, o);
 }
 template <int KIND>
-static void launch_band_uv_kind(const EvpDev& P, const Range& r, const Range& r1, const Range& r2, const ImageSpec& imu, const ImageSpec& imv, const FastCoef& c, bool ufirst,
-                                const BandOut& o, hipStream_t s) {
+static void launch_band_vel_kind(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, bool u, const BandOut& o, hipStream_t s) {
     dim3 b(fast::TILE_X, 1), g;
     const fast::TileMap tm = tile_map_band(P, r, g);
     const bool m = P.g.has_mask != 0;
     if (m) {
-        if (ufirst) hipLaunchKernelGGL((fast::k_band_uv<KIND, true, true>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
-        else hipLaunchKernelGGL((fast::k_band_uv<KIND, true, false>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
+        if (u) hipLaunchKernelGGL((fast::k_band_vel<KIND, true, true>), g, b, 0, s, P, r, im, c, tm, o);
+        else hipLaunchKernelGGL((fast::k_band_vel<KIND, true, false>), g, b, 0, s, P, r, im, c, tm, o);
     } else {
-        if (ufirst) hipLaunchKernelGGL((fast::k_band_uv<KIND, false, true>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
-        else hipLaunchKernelGGL((fast::k_band_uv<KIND, false, false>), g, b, 0, s, P, r, r1, r2, imu, imv, c, tm, o);
+        if (u) hipLaunchKernelGGL((fast::k_band_vel<KIND, false, true>), g, b, 0, s, P, r, im, c, tm, o);
+        else hipLaunchKernelGGL((fast::k_band_vel<KIND, false, false>), g, b, 0, s, P, r, im, c, tm, o);
     }
 }
-void launch_band_uv(const EvpDev& P, const Range& r1, const Range& r2, const ImageSpec& imu, const ImageSpec& imv, const FastCoef& c, bool ufirst, const BandOut& o,
-                    hipStream_t s) {
-    Range r = r1;
-    if (r2.j0 < r.j0) r.j0 = r2.j0;
-    if (r2.j1 > r.j1) r.j1 = r2.j1;
-    if (c.full) launch_band_uv_kind<2>(P, r, r1, r2, imu, imv, c, ufirst, o, s);
-    else if (c.uniform) launch_band_uv_kind<0>(P, r, r1, r2, imu, imv, c, ufirst, o, s);
-    else launch_band_uv_kind<1>(P, r, r1, r2, imu, imv, c, ufirst, o, s);
+void launch_band_vel(const EvpDev& P, const Range& r, const ImageSpec& im, const FastCoef& c, bool u, const BandOut& o, hipStream_t s) {
+    if (c.full) launch_band_vel_kind<2>(P, r, im, c, u, o, s);
+    else if (c.uniform) launch_band_vel_kind<0>(P, r, im, c, u, o, s);
+    else launch_band_vel_kind<1>(P, r, im, c, u, o, s);
 }
 
 }  // namespace csi

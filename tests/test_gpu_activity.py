@@ -329,3 +329,69 @@ def test_cuts_fuzz_bitwise(seed):
 
 
 LAST_FUZZ = {}
+
+
+# ---- the fold band's fused launches (round 6b; csrc/csi_fold.hip band_substeps_fused, evp_fast.hip k_band_stress / k_band_uv) -----------
+# Four launches per pair of sub-steps (stress; both velocity components in one launch, the first evaluated again at the points the
+# second reads; no copy kernels) against the three kernels + two copies of rounds 4-6a (CSI_BAND_FUSED=0): every field, halo cells
+# included, bit for bit -- uniform / per-row / per-point coefficients, masks, array forcing, free drift, user forcing, odd and even
+# numbers of sub-steps (the trailing single sub-step; both orders of the components in either position).
+BAND_CASES = {
+    "rectilinear": dict(Nx=200, Ny=160, topo=("periodic", "folded"), patches=True, random_uv=0.03, substeps=10),
+    "rectilinear_odd": dict(Nx=200, Ny=160, topo=("periodic", "folded"), patches=True, random_uv=0.03, substeps=11),
+    "latlon": dict(Nx=200, Ny=160, topo=("periodic", "folded"), grid="latlon", patches=True, random_uv=0.03, substeps=10),
+    "latlon_masked_forced": dict(Nx=200, Ny=160, topo=("periodic", "folded"), grid="latlon", patches=True, random_uv=0.03, land=0.3, field_forcing=True, substeps=9),
+    "curvilinear": dict(Nx=200, Ny=160, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.05, substeps=10),
+    "curvilinear_masked": dict(Nx=224, Ny=170, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.3, substeps=13),
+    "tripolar_like": dict(Nx=336, Ny=260, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.3, field_forcing=True, free_drift=True,
+                          substeps=12),
+    "tripolar_like_user_forcing": dict(Nx=224, Ny=170, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.3, field_forcing=True,
+                                       free_drift=True, user_forcing=True, substeps=7),
+    "tripolar_like_immersed_bc": dict(Nx=224, Ny=170, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.3,
+                                      immersed_bc=((1e-3, -2e-3, 3e-3, 1e-3), (2e-3, 1e-3, -1e-3, 2e-3)), substeps=7),
+    "rectilinear_user_forcing": dict(Nx=200, Ny=160, topo=("periodic", "folded"), patches=True, random_uv=0.03, user_forcing=True, land=0.2, substeps=8),
+    "tripolar_grid": dict(Nx=240, Ny=180, grid="tripolar", tripolar=dict(southernmost_latitude=-70.0), patches=True, random_uv=0.03, field_forcing=True, free_drift=True,
+                          coriolis_points=True, land=0.2, substeps=10),
+    "tripolar_grid_wind": dict(Nx=240, Ny=180, grid="tripolar", tripolar=dict(southernmost_latitude=-70.0), patches=True, random_uv=0.03, wind_drag="arrays",
+                               coriolis_points=True, ice_edge=40.0, substeps=15),
+    "wide_halo": dict(Nx=200, Ny=160, H=6, topo=("periodic", "folded"), patches=True, random_uv=0.03, curvilinear=0.05, land=0.2, substeps=8),
+}
+
+
+def band_run(case, fused, monkeypatch, steps=2, **kw):
+    if fused: monkeypatch.delenv("CSI_BAND_FUSED", raising=False)
+    else: monkeypatch.setenv("CSI_BAND_FUSED", "0")
+    out, _, m = run(case, steps=steps, **kw)          # (the knob is read when the context is created)
+    return out, m
+
+
+@pytest.mark.parametrize("name", list(BAND_CASES))
+def test_fused_band_launches_are_bit_identical(name, monkeypatch):
+    case = cases.make_case(**BAND_CASES[name])
+    a, ma = band_run(case, True, monkeypatch)
+    b, mb = band_run(case, False, monkeypatch)
+    if not ma.ctx.last_path()["fused"]:
+        pytest.skip("this configuration does not take the fold band at all (three kernels on the whole grid)")
+    assert mb.ctx.last_path()["fused"]
+    la, lb = ma.ctx.last_launches()[0], mb.ctx.last_launches()[0]
+    assert la < lb, (la, lb)                              # four launches per band step instead of eight
+    assert_bitwise(a, b, f"{name}: fused band launches vs three kernels + copies")
+
+
+def test_fused_band_with_rk3_whole_steps_and_cuts(monkeypatch):
+    # whole time steps (dynamics + advection, an odd and an even first sub-step index through the RK3 stages) on the tripolar grid
+    case = cases.make_case(Nx=240, Ny=180, grid="tripolar", tripolar=dict(southernmost_latitude=-70.0), patches=True, random_uv=0.03, field_forcing=True,
+                           free_drift=True, coriolis_points=True, land=0.2, ice_edge=45.0, substeps=9)
+    outs = []
+    for fused in (True, False):
+        if fused: monkeypatch.delenv("CSI_BAND_FUSED", raising=False)
+        else: monkeypatch.setenv("CSI_BAND_FUSED", "0")
+        m = cases.csi_model(case, mode="fast", timestepper="SplitRungeKutta3", advection=csi.WENO(order=5))
+        for _ in range(2): csi.time_step(m, 600.0)
+        m.synchronize()
+        st = parents(m)
+        st["h"] = m.ice_thickness.numpy().copy(); st["a"] = m.ice_concentration.numpy().copy()
+        outs.append(st)
+    assert_bitwise(outs[0], outs[1], "RK3 whole steps")
+    for k in ("h", "a"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
