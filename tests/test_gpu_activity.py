@@ -395,3 +395,38 @@ def test_fused_band_with_rk3_whole_steps_and_cuts(monkeypatch):
     assert_bitwise(outs[0], outs[1], "RK3 whole steps")
     for k in ("h", "a"):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+
+
+def band_fuzz_case(seed):
+    """A random north-fold configuration (every coefficient kind, masks, forcing kinds, halo widths, sub-step counts)."""
+    rng = np.random.default_rng(7000 + seed)
+    kw = dict(Nx=2 * int(rng.integers(70, 200)), Ny=int(rng.integers(110, 260)), H=int([4, 4, 5, 6][rng.integers(0, 4)]), topo=("periodic", "folded"),
+              patches=bool(rng.integers(0, 2)), random_uv=0.03, substeps=int(rng.integers(2, 19)), seed=int(seed))
+    kind = rng.integers(0, 4)
+    if kind == 1: kw["grid"] = "latlon"
+    elif kind == 2: kw["curvilinear"] = float([0.0, 0.03, 0.06][rng.integers(0, 3)])
+    elif kind == 3:
+        kw.update(grid="tripolar", tripolar=dict(southernmost_latitude=float(rng.uniform(-75.0, -40.0))), coriolis_points=bool(rng.integers(0, 2)))
+        kw["Ny"] = max(kw["Ny"], 140)
+    if rng.random() < 0.6: kw["land"] = float(rng.uniform(0.1, 0.4))
+    r = rng.random()
+    if r < 0.45:
+        kw["field_forcing"] = True
+        kw["free_drift"] = bool(rng.integers(0, 2))
+    elif r < 0.6: kw["wind_drag"] = ["numbers", "arrays"][rng.integers(0, 2)]
+    elif r < 0.7: kw["user_forcing"] = True
+    if rng.random() < 0.3:
+        a = float(rng.uniform(0.0, 0.5))
+        kw["ice_free_rows"] = (a, min(1.0, a + float(rng.uniform(0.3, 0.5))))
+    if kind != 3 and rng.random() < 0.25: kw["beta"] = 2e-10 if kind != 2 else None
+    return {k: v for k, v in kw.items() if v is not None}
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_band_fuzz_bitwise(seed, monkeypatch):
+    kw = band_fuzz_case(seed)
+    case = cases.make_case(**kw)
+    a, ma = band_run(case, True, monkeypatch, steps=2 + seed % 2)
+    b, mb = band_run(case, False, monkeypatch, steps=2 + seed % 2)
+    assert_bitwise(a, b, f"seed {seed}: {kw}")
+    LAST_FUZZ.update(band=bool(ma.ctx.last_path()["fused"]) and ma.ctx.last_launches()[0] < mb.ctx.last_launches()[0])
