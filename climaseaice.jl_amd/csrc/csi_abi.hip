@@ -92,7 +92,7 @@ int32_t csi_context_create(int32_t device_id, void* hip_stream, csi_context** ou
         { const int v = env_int("CSI_ROW_TARGET_1024"); if (v >= 0) c->tune.row_target_1024 = v; }      // 0: per-row coefficients keep 1536 tiles (rounds 3-5a)
         { const int v = env_int("CSI_TILE_SKIPPING"); if (v >= 0) c->act.enabled = v != 0; }      // A/B: the defaults of csi_set_tile_skipping / csi_set_row_constant
         { const int v = env_int("CSI_ROW_CONSTANT"); if (v >= 0) c->rc_enabled = v != 0; }
-        c->tune.band_fused = env_int("CSI_BAND_FUSED");
+        c->tune.band_fused = env_int("CSI_BAND_FUSED"); c->tune.band_event_flags = env_int("CSI_BAND_EVENT_FLAGS");
         c->tune.band_cus = env_int("CSI_BAND_CUS"); c->tune.band_cus_share = env_int("CSI_BAND_CUS_SHARE");
         c->tune.exp_band_only = env_int("CSI_EXP_BAND_ONLY");
         c->tune.exp_overlap = env_int("CSI_EXP_OVERLAP");    // timing experiment, tiles connected to themselves only (scripts/tile_overlap_dependent.py)

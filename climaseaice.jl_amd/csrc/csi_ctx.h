@@ -226,6 +226,7 @@ struct csi_context {
     struct Tuning { int fused_rows = -1, pair_tiles = -1, pair_target = -1, row_target_1024 = 0, pair_minrows = -1, pair_rows = -1, pair_common = -1, peer_kernel = -1, peer_edge = -1, write_through = -1,
                     adv_nt = -1,           // CSI_ADV_NT: tracers per thread of the advection tendency kernel (1 / 2; default by grid size)
                     band_fused = -1,      // CSI_BAND_FUSED=0: the fold band on the three kernels + two copies per step (rounds 4-6a); default: six launches per step without copies, loads hoisted (csi_fold.hip band_substeps_fused)
+                    band_event_flags = -1,   // CSI_BAND_EVENT_FLAGS (csi_fold.hip ensure_band)
                     band_cus = -1,        // CSI_BAND_CUS: CUs per XCD reserved for the fold band's launches (the pair launches beside them run on the others)
                     band_cus_share = -1,  // CSI_BAND_CUS_SHARE=1: the band may use every CU (only the pair launches are masked)
                     exp_band_only = -1,   // TIMING EXPERIMENT (CSI_EXP_BAND_ONLY=1, wrong results): fold grids run the band's launches without the pair launches beside them

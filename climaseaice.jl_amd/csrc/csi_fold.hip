@@ -47,8 +47,14 @@ int32_t ensure_band(csi_context* c) {
             for (hipEvent_t& e : c->exp_ev) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         } else
         HIP_TRY(c, hipStreamCreateWithFlags(&c->band_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_pair, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_band, hipEventDisableTiming));
+        // the two events order kernels of ONE device against each other (pair launch <-> band step), sixty times per sub-cycle each: no
+        // system-scope fence (what they guard reaches the host and other devices behind the kernels that follow on the context's stream).
+        // CSI_BAND_EVENT_FLAGS: 0 default events (7.18-7.26 ms per tripolar step), 1 hipEventDisableSystemFence (7.04-7.06: the default),
+        // 2 hipEventReleaseToDevice (7.30); profiles/r06_band.md section 6
+        const int ef = c->tune.band_event_flags < 0 ? 1 : c->tune.band_event_flags;
+        const unsigned evf = hipEventDisableTiming | (ef == 1 ? hipEventDisableSystemFence : (ef == 2 ? hipEventReleaseToDevice : 0u));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_pair, evf));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->band_ev_band, evf));
     }
     return CSI_OK;
 }
